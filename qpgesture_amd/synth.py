@@ -1,0 +1,92 @@
+"""Synthetic inputs with the reference's on-disk schema.
+
+No real BEAT database or checkpoint ships with the reference, so every test,
+golden vector and bench line is driven by these generators.  Everything is
+drawn from numpy.random.Generator(PCG64(seed)) so that the GPU box can
+regenerate byte-identical inputs from a seed instead of shipping them.
+"""
+import os
+import numpy as np
+
+from .constant import codebook_size, num_frames, num_frames_code
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def make_codes(n_seq, seed, force_all_present=True):
+    """(n_seq, 30) int64 code ids; every code forced present on grid rows 0..25 when it fits.
+
+    Presence has to hold on the 26 grid positions the scans visit
+    (GestureKNN.py:673-675, 713-714), not merely somewhere in the row.
+    """
+    rng = _rng(seed)
+    code = rng.integers(0, codebook_size, size=(n_seq, num_frames_code), dtype=np.int64)
+    if force_all_present and n_seq * 26 >= codebook_size:
+        slots = rng.permutation(n_seq * 26)[:codebook_size]
+        code[slots // 26, slots % 26] = np.arange(codebook_size)
+    return code
+
+
+def make_db(n_seq, seed, wavlm_dim=1024, with_body=False):
+    """Dict of arrays for one split (train or test) of a speaker database."""
+    rng = _rng(seed)
+    d = {}
+    d["mfcc"] = rng.standard_normal((n_seq, num_frames, 14)).astype(np.float32)
+    d["energy"] = rng.random((n_seq, num_frames)).astype(np.float32)
+    d["pitch"] = rng.random((n_seq, num_frames)).astype(np.float32)
+    d["volume"] = rng.random((n_seq, num_frames)).astype(np.float32)
+    d["context"] = rng.standard_normal((n_seq, num_frames_code, 1, 384)).astype(np.float32)
+    # dense phase: (n, 240, 4, 8); index 0 = phase shift p, 2 = amplitude a (PAE.py:505-508)
+    d["phase_dense"] = rng.standard_normal((n_seq, num_frames, 4, 8)).astype(np.float32)
+    d["wavlm"] = rng.standard_normal((n_seq, 199, wavlm_dim)).astype(np.float32)
+    d["wavvq"] = rng.integers(0, 320, size=(n_seq, 398, 2), dtype=np.int64)
+    if with_body:
+        d["body"] = rng.standard_normal((n_seq, num_frames, 135)).astype(np.float32)
+    return d
+
+
+def make_signature(seed):
+    return _rng(seed).standard_normal((codebook_size, 135)).astype(np.float32)
+
+
+def phase_dense_to_object(phase_dense):
+    """(n,240,4,8) f32 -> object array (n,240,4) of torch tensors shaped (1,8,1).
+
+    That is the layout PAE.py:505-508 / fix_device_bug.py:14-22 leave in the
+    reference's *_txt_2.npz files.
+    """
+    import torch
+    n, t, c, _ = phase_dense.shape
+    out = np.empty((n, t, c), dtype=object)
+    for i in range(n):
+        for j in range(t):
+            for k in range(c):
+                out[i, j, k] = torch.from_numpy(phase_dense[i, j, k].copy()).reshape(1, 8, 1)
+    return out
+
+
+def write_npz_set(outdir, n_train, n_test, seed_train=0, seed_test=1, seed_code=2, seed_sig=3,
+                  wavlm_dim=1024):
+    """Write the 8 npz files GestureKNN.py's CLI takes; returns the path dict (flag -> path)."""
+    os.makedirs(outdir, exist_ok=True)
+    tr = make_db(n_train, seed_train, wavlm_dim)
+    te = make_db(n_test, seed_test, wavlm_dim)
+    code = make_codes(n_train, seed_code)
+    sig = make_signature(seed_sig)
+    p = {k: os.path.join(outdir, v) for k, v in dict(
+        train_database="train_240_txt_2.npz", test_data="test_240_txt_2.npz",
+        train_codebook="train_240_code.npz", codebook_signature="code.npz",
+        train_wavlm="train_240_WavLM.npz", test_wavlm="test_240_WavLM.npz",
+        train_wavvq="train_240_WavVQ.npz", test_wavvq="test_wavvq_240.npz").items()}
+    for d, path in ((tr, p["train_database"]), (te, p["test_data"])):
+        np.savez(path, mfcc=d["mfcc"], energy=d["energy"], pitch=d["pitch"], volume=d["volume"],
+                 context=d["context"], phase=phase_dense_to_object(d["phase_dense"]))
+    np.savez(p["train_codebook"], code=code)
+    np.savez(p["codebook_signature"], signature=sig)
+    np.savez(p["train_wavlm"], wavlm=tr["wavlm"])
+    np.savez(p["test_wavlm"], wavlm=te["wavlm"])
+    np.savez(p["train_wavvq"], wavvq=tr["wavvq"])
+    np.savez(p["test_wavvq"], wavvq=te["wavvq"])
+    return p
