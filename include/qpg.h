@@ -1,0 +1,148 @@
+/*
+ * qpg.h — C ABI of libqpg_hip.so: the MI355X (gfx950) implementation of QPGesture's
+ * code-level motion-matching hot path (CodeKNN) and gesture VQ-VAE encode/quantise/decode.
+ *
+ * The reference (YoungSeng/QPGesture) is pure Python and has no FFI layer; each entry point
+ * below names the reference interface it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer marked [dev] is a device pointer owned by the caller (the Python host keeps
+ *     torch tensors alive); the library never allocates or frees caller-visible memory;
+ *   - all work is enqueued on the hipStream_t passed as `void* stream` (0 = null stream) and
+ *     is stream-ordered; no call synchronises the device;
+ *   - every function returns QPG_OK (0) or a negative QPG_E* code and never throws;
+ *     qpg_last_error() returns the text of the last failure on the calling thread;
+ *   - no global mutable state except the per-device qpg_ctx.
+ *   - tie rule everywhere: lowest index wins (== the reference's strict `<` first-wins scan,
+ *     GestureKNN.py:686,717) and ranks are stable (documented deviation from NumPy's unstable
+ *     default argsort, DESIGN.md "Tie contract").
+ */
+#ifndef QPG_H
+#define QPG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPG_OK 0
+#define QPG_EINVAL (-1)   /* bad argument (null pointer, size out of range)          */
+#define QPG_EHIP (-2)     /* a HIP runtime call or kernel launch failed               */
+#define QPG_EUNSUP (-3)   /* shape not supported by the compiled kernels              */
+
+typedef struct qpg_ctx qpg_ctx;
+
+int qpg_version(void);
+int qpg_ctx_create(int device, qpg_ctx** out);
+int qpg_ctx_destroy(qpg_ctx* ctx);
+int qpg_last_error(char* buf, size_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * Database preparation (one-off per speaker DB; replaces the host-side feature windowing of
+ * codebook/Speech2GestureMatching/data_processing.py:255-274, which materialises an
+ * (N,180,6144) float64 stack — here nothing is materialised, only per-candidate norms).
+ * ---------------------------------------------------------------------------------------- */
+
+/* out[r] = sum_e x[r][e]^2 in float64, r < rows.  x: [dev] f32 [rows][F]. */
+int qpg_frame_norm2_f64(qpg_ctx*, void* stream, const float* x, int64_t rows, int F, double* out);
+
+/* cn2[j][g] = sum_{i<n_taps} fn2[j][cand_t[g] + i*tap_stride]  (0 past T).
+ * fn2: [dev] f64 [N][T]; cand_t: [dev] i32 [G]; cn2: [dev] f64 [N][G]. */
+int qpg_audio_cand_norm2(qpg_ctx*, void* stream, const double* fn2, int N, int T, const int32_t* cand_t,
+                         int G, int n_taps, int tap_stride, double* cn2);
+
+/* Row-wise L2 normalisation with scikit-learn's float32 arithmetic, bit-exact
+ * (sklearn.preprocessing.normalize as used by paired_cosine_distances; zero rows stay zero).
+ * x, out: [dev] f32 [rows][D]. */
+int qpg_l2_normalize_rows_f32(qpg_ctx*, void* stream, const float* x, int64_t rows, int D, float* out);
+
+/* ------------------------------------------------------------------------------------------
+ * Candidate sweeps.  Replace CodeKNN.search_audio_cands(mode='wavlm_feat') and
+ * CodeKNN.search_text_cands (GestureKNN.py:666-691, 708-721) for ALL Q query steps of a clip
+ * at once: the scans depend only on the query position, never on the matching state.
+ * Candidate index c = j*G + g (j = DB window, g = grid position) = the reference's scan order.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Gather + widen the audio queries of a clip.
+ * qbase: [dev] f32 [M][T][F] (interpolated WavLM of the test windows);
+ * q_win/q_t: [dev] i32 [Q] window and start frame of each query (GestureKNN.py:565: clip_test[i]);
+ * q64: [dev] f64 [Q][n_taps*F] out; qn2: [dev] f64 [Q] out (squared norms). */
+int qpg_audio_pack_queries(qpg_ctx*, void* stream, const float* qbase, int M, int T, int F,
+                           const int32_t* q_win, const int32_t* q_t, int Q, int n_taps, int tap_stride,
+                           double* q64, double* qn2);
+
+/* Cosine distance of every query against every audio candidate, float64 arithmetic
+ * (the reference computes this distance in float64: data_processing.py:264, sklearn keeps f64):
+ *   D[q][c] = 1 - <q, cand_c> / (|q| |cand_c|),  cand_c = concat_i base[j][cand_t[g] + i*tap_stride][:]
+ * (== 0.5*|q/|q| - c/|c||^2 of sklearn.metrics.pairwise.paired_cosine_distances up to f64 rounding;
+ * zero-norm rows follow sklearn: they stay zero vectors).
+ * base: [dev] f32 [N][T][F]; cn2: [dev] f64 [N][G]; D: [dev] f64 [Q][N*G], row stride ldD elements. */
+int qpg_audio_cosine_f64(qpg_ctx*, void* stream, const float* base, int N, int T, int F,
+                         const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
+                         const double* q64, const double* qn2, int Q, double* D, int64_t ldD);
+
+/* Cosine distance with scikit-learn's float32 arithmetic, bit-exact (GestureKNN.py:716 keeps f32):
+ *   D[q][c] = 0.5 * einsum_sq(qn[q] - xn[j][cand_r[g]])     (NumPy einsum summation order)
+ * xn: [dev] f32 [N][R][Dm] rows already normalised by qpg_l2_normalize_rows_f32;
+ * qn: [dev] f32 [Q][Dm] normalised queries; cand_r: [dev] i32 [G]; D: [dev] f32 [Q][N*G]. */
+int qpg_text_cosine_f32(qpg_ctx*, void* stream, const float* xn, int N, int R, int Dm,
+                        const int32_t* cand_r, int G, const float* qn, int Q, float* D, int64_t ldD);
+
+/* Segmented min + argmin by code id, first index wins on ties (GestureKNN.py:686-689).
+ * code: [dev] i32 [N][code_ld]; cand_cidx: [dev] i32 [G] column of `code` for grid position g;
+ * out_dist: [dev] [Q][K] (initialised to `absent`, the reference's 1e+3); out_idx: [dev] i32 [Q][K]
+ * global candidate index + idx_base, -1 where the code never occurs. */
+int qpg_percode_argmin_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int32_t* code,
+                           int code_ld, int N, const int32_t* cand_cidx, int G, int K, double absent,
+                           int32_t idx_base, double* out_dist, int32_t* out_idx);
+int qpg_percode_argmin_f32(qpg_ctx*, void* stream, const float* D, int64_t ldD, int Q, const int32_t* code,
+                           int code_ld, int N, const int32_t* cand_cidx, int G, int K, float absent,
+                           int32_t idx_base, float* out_dist, int32_t* out_idx);
+
+/* Stable ranks of each row: rank[q][c] = #{c' : d[c'] < d[c] or (d[c'] == d[c] and c' < c)}
+ * (== np.argsort(kind='stable').argsort(); the reference calls the unstable default,
+ * GestureKNN.py:553,574).  out: [dev] i16 [Q][K]. */
+int qpg_rank_rows_f64(qpg_ctx*, void* stream, const double* d, int Q, int K, int16_t* out);
+int qpg_rank_rows_f32(qpg_ctx*, void* stream, const float* d, int Q, int K, int16_t* out);
+
+/* ------------------------------------------------------------------------------------------
+ * State-dependent tail of CodeKNN.search_code_knn + the window loop of predict_code_from_audio
+ * (GestureKNN.py:501-664, 785-813).
+ * ---------------------------------------------------------------------------------------- */
+
+/* out[p][c] = |sig[p] - sig[c]|_2 in f32 (f64 accumulation, one rounding), +inf on the diagonal
+ * (GestureKNN.py:531-536: `1e10000` for the current code).  sig: [dev] f32 [K][Dm]; out: [dev] f32 [K][K]. */
+int qpg_l2_table_f32(qpg_ctx*, void* stream, const float* sig, int K, int Dm, float* out);
+
+#define QPG_MODE_AUD_TXT 0 /* shipped flags: audio top-1 vs text top-1, phase gate (GestureKNN.py:627-657) */
+#define QPG_MODE_AUD 1     /* audio only: top-2 audio candidates through the phase gate (:593-608)          */
+#define QPG_MODE_TXT 2     /* text only: top-2 text candidates through the phase gate (:610-625)            */
+
+/* Walk all M windows x `steps` matching steps of a clip on the device.
+ *   aud_rank/txt_rank: [dev] i16 [Q][K] stable ranks of the per-code minima (Q = M*steps);
+ *   aud_idx/txt_idx:   [dev] i32 [Q][K] winning candidate index j*G+g (-1 = code absent);
+ *   pos_rank:          [dev] i16 [K][K] stable ranks of qpg_l2_table_f32 rows;
+ *   freq_rank:         [dev] i16 [K] rank of 1-count/total (GestureKNN.py:481-499, 544);
+ *   code:              [dev] i32 [N][code_ld]; *_cidx [G]: code column of a grid position;
+ *   *_pslot [G]:       phase start frame int(k/398*240) of a grid position (GestureKNN.py:632);
+ *   phase:             [dev] f32 [N][Tp][2][8] (phase shift, amplitude);
+ *   seed_code/seed_phase [dev f32 8x16]: init_code_phase() draw (GestureKNN.py:462-473);
+ *   out_codes [dev] i32 [M][30]; out_phase [dev] f32 [M][steps][8][16]; out_vote [dev] i32 [M][steps];
+ *   out_status [dev] i32 [1]: 1 if a code absent from the DB won a rank fusion (the reference raises
+ *   IndexError there, GestureKNN.py:631-632).
+ * combined = (pos_rank + freq_rank*0.05) + rank in float64 in that order; argmin = lowest index. */
+int qpg_match_steps(qpg_ctx*, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
+                    const int16_t* txt_rank, const int32_t* txt_idx, const int16_t* pos_rank,
+                    const int16_t* freq_rank, const int32_t* code, int code_ld, const int32_t* aud_cidx,
+                    const int32_t* aud_pslot, int Ga, const int32_t* txt_cidx, const int32_t* txt_pslot, int Gt,
+                    const float* phase, int Tp, int mode, int M, int steps, int K, int seed_code,
+                    const float* seed_phase, int32_t* out_codes, float* out_phase, int32_t* out_vote,
+                    int32_t* out_status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPG_H */

@@ -63,9 +63,10 @@ def einsum_sq(x):
 
 
 def l2_normalize(x):
-    """sklearn.preprocessing.normalize(x, 'l2') row-wise; zero rows stay zero."""
+    """sklearn.preprocessing.normalize(x, 'l2') row-wise; rows with norm < 10*eps are left
+    unscaled (sklearn _handle_zeros_in_scale)."""
     n = np.sqrt(einsum_sq(x))
-    n = np.where(n == 0, np.ones_like(n), n)
+    n = np.where(n < 10 * np.finfo(n.dtype).eps, np.ones_like(n), n)
     return x / n[..., None]
 
 

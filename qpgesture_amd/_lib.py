@@ -1,0 +1,104 @@
+"""ctypes binding of libqpg_hip.so (the C ABI declared in include/qpg.h).
+
+The library is the product: if it is missing or a call fails this module raises —
+there is no CPU or PyTorch fallback anywhere in the package.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqpg_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "qpg.h")
+
+_lib = None
+_ctx = {}
+
+c_void_p, c_int, c_int64, c_double, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                               ctypes.c_double, ctypes.c_float)
+P, I, L = c_void_p, c_int, c_int64
+
+# name -> argtypes (after ctx, stream)
+_SIGS = {
+    "qpg_frame_norm2_f64": [P, L, I, P],
+    "qpg_audio_cand_norm2": [P, I, I, P, I, I, I, P],
+    "qpg_l2_normalize_rows_f32": [P, L, I, P],
+    "qpg_audio_pack_queries": [P, I, I, I, P, P, I, I, I, P, P],
+    "qpg_audio_cosine_f64": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
+    "qpg_text_cosine_f32": [P, I, I, I, P, I, P, I, P, L],
+    "qpg_percode_argmin_f64": [P, L, I, P, I, I, P, I, I, c_double, ctypes.c_int32, P, P],
+    "qpg_percode_argmin_f32": [P, L, I, P, I, I, P, I, I, c_float, ctypes.c_int32, P, P],
+    "qpg_rank_rows_f64": [P, I, I, P],
+    "qpg_rank_rows_f32": [P, I, I, P],
+    "qpg_l2_table_f32": [P, I, I, P],
+    "qpg_match_steps": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P],
+}
+
+
+def declared_symbols():
+    """Every function name include/qpg.h declares (used by the CPU symbol-export test)."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(qpg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load():
+    """dlopen the library (works without a GPU: symbols only)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libqpg_hip.so is missing (%s). Build it with `python -m qpgesture_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.qpg_version.restype = c_int
+    lib.qpg_ctx_create.argtypes = [c_int, ctypes.POINTER(c_void_p)]
+    lib.qpg_ctx_create.restype = c_int
+    lib.qpg_ctx_destroy.argtypes = [c_void_p]
+    lib.qpg_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [c_void_p, c_void_p] + sig
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    load().qpg_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def ctx(device):
+    """Per-device opaque context (created on first use)."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _ctx:
+        h = c_void_p()
+        rc = load().qpg_ctx_create(idx, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError("qpg_ctx_create(%d) failed: %s" % (idx, last_error()))
+        _ctx[idx] = h
+    return _ctx[idx]
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return c_void_p(t.data_ptr())
+
+
+def call(name, device, *args):
+    """Invoke a C-ABI entry point on torch's current stream of `device`; raise on error."""
+    lib = load()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    conv = [ptr(a) if isinstance(a, torch.Tensor) else a for a in args]
+    rc = getattr(lib, name)(ctx(device), c_void_p(stream), *conv)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, last_error()))

@@ -1,0 +1,313 @@
+"""Host side of the code-level motion matcher: mirrors the reference's `CodeKNN` /
+`predict_code_from_audio` interface (codebook/Speech2GestureMatching/GestureKNN.py:422-813)
+on top of the C ABI of libqpg_hip.so.  Python here is plumbing: it owns the device tensors,
+the index tables and the call order; every distance, minimum, rank and matching step runs in
+the hand-written HIP kernels.  No CPU fallback exists.
+
+Design difference from the reference (same results): the audio and text scans depend only on
+the query position, never on the running (code, phase) state, so all Q = 8*M scans of a clip are
+issued as two batched sweeps, and the sequential part walks (Q,512) tables on the device.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .constant import (ABSENT_DIST, NUM_AUDIO_FEAT_FRAMES, STEP_SZ, codebook_size, num_frames,
+                       num_frames_code)
+
+MODE_AUD_TXT, MODE_AUD, MODE_TXT = 0, 1, 2
+
+
+# ----------------------------------------------------------------------------------------------
+# index grids — literal restatement of the reference's float loops; tiny, host-side, done once
+# ----------------------------------------------------------------------------------------------
+def audio_grid(n_db_frm, step_sz):
+    """Grid of search_audio_cands (GestureKNN.py:672-690): k = 0, step, 2*step, ... while
+    k < n_db_frm - 4*step, with step_sz possibly a float (398/30 in wavvq mode) accumulated
+    sequentially.  Returns int(k) and int(k/step_sz) per grid position."""
+    kint, cidx = [], []
+    k = 0
+    while k < n_db_frm - STEP_SZ * step_sz:
+        kint.append(int(k))
+        cidx.append(int(k / step_sz))
+        k += step_sz
+    return kint, cidx
+
+
+def text_grid():
+    """Grid of search_text_cands (GestureKNN.py:713-720): k = 0,8,..,200; row/code column k//8."""
+    ks = list(range(0, num_frames - STEP_SZ * 8, 8))
+    return ks, [k // 8 for k in ks]
+
+
+def phase_slot(k):
+    """Phase start frame of a candidate: int(k/398*240) whatever unit k is in (GestureKNN.py:632)."""
+    return int(k / 398 * 240)
+
+
+def _i32(x, dev):
+    return torch.as_tensor(np.asarray(x, np.int32), device=dev)
+
+
+class GestureDB:
+    """A speaker database resident in HBM (what load_db_codebook + CodeKNN.__init__ build).
+
+    Layout:
+      base   f32 [n_local][180][F]   interpolated WavLM frames of this rank's row shard
+      cn2    f64 [n_local][26]       squared norm of each audio candidate (6 frames)
+      ctxn   f32 [n_local][30][384]  text context rows, sklearn-normalised
+      code   i32 [N][30]             replicated (payloads of winners are looked up from it)
+      phase  f32 [N][240][2][8]      replicated (phase shift, amplitude)
+      pos_rank i16 [512][512], freq_rank i16 [512]
+    Rows [lo, hi) of the N DB windows live on this rank; candidate indices are global.
+    """
+
+    def __init__(self, code, wavlm_interp, context, phase_dense, signature, device="cuda:0",
+                 freq_rank=None, pos_rank=None, rank=0, world=1):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("GestureDB needs a HIP device (got %s); there is no CPU path" % dev)
+        _lib.load()
+        self.device = dev
+        self.rank, self.world = rank, world
+        code = np.asarray(code)
+        self.N = N = code.shape[0]
+        per = (N + world - 1) // world
+        self.lo, self.hi = min(rank * per, N), min((rank + 1) * per, N)
+        self.n_local = self.hi - self.lo
+        self.K = codebook_size
+        self.code_host = code.astype(np.int64)
+        self.code = _i32(code, dev).contiguous()
+        self.code_local = self.code[self.lo:self.hi].contiguous()
+
+        wl = np.ascontiguousarray(wavlm_interp[self.lo:self.hi], np.float32)
+        self.T, self.F = wavlm_interp.shape[1], wavlm_interp.shape[2]
+        self.base = torch.from_numpy(wl).to(dev)
+        self.step_sz = self.T // num_frames_code                      # GestureKNN.py:432
+        kint, cidx = audio_grid(self.T, self.step_sz)
+        self.aud_k, self.aud_cidx_host = kint, cidx
+        self.Ga = len(kint)
+        self.aud_t = _i32(kint, dev)
+        self.aud_cidx = _i32(cidx, dev)
+        self.aud_pslot = _i32([phase_slot(k) for k in kint], dev)
+        self.tap_stride = 2                                           # FRAME_INTERVAL-2, data_processing.py:266
+
+        ks, rows = text_grid()
+        self.txt_k, self.txt_rows_host = ks, rows
+        self.Gt = len(ks)
+        self.txt_r = _i32(rows, dev)
+        self.txt_cidx = self.txt_r
+        self.txt_pslot = _i32([phase_slot(k) for k in ks], dev)
+
+        # per-candidate squared norms (f64) without materialising the 6144-d windows
+        fn2 = torch.empty((self.n_local, self.T), dtype=torch.float64, device=dev)
+        self.cn2 = torch.empty((self.n_local, self.Ga), dtype=torch.float64, device=dev)
+        if self.n_local:
+            _lib.call("qpg_frame_norm2_f64", dev, self.base, self.n_local * self.T, self.F, fn2)
+            _lib.call("qpg_audio_cand_norm2", dev, fn2, self.n_local, self.T, self.aud_t, self.Ga,
+                      NUM_AUDIO_FEAT_FRAMES, self.tap_stride, self.cn2)
+
+        ctx = np.ascontiguousarray(context[self.lo:self.hi], np.float32)
+        self.R, self.Dt = context.shape[1], context.shape[2]
+        ctx_d = torch.from_numpy(ctx).to(dev)
+        self.ctxn = torch.empty_like(ctx_d)
+        if self.n_local:
+            _lib.call("qpg_l2_normalize_rows_f32", dev, ctx_d, self.n_local * self.R, self.Dt, self.ctxn)
+
+        ph = np.ascontiguousarray(np.asarray(phase_dense, np.float32)[:, :, [0, 2], :])
+        self.Tp = ph.shape[1]
+        self.phase = torch.from_numpy(ph).to(dev)
+        self.phase_host = ph
+
+        sig = torch.from_numpy(np.ascontiguousarray(signature, np.float32)).to(dev)
+        self.signature = sig
+        if pos_rank is None:
+            pd = torch.empty((self.K, self.K), dtype=torch.float32, device=dev)
+            _lib.call("qpg_l2_table_f32", dev, sig, self.K, sig.shape[1], pd)
+            self.pos_dist = pd
+            self.pos_rank = torch.empty((self.K, self.K), dtype=torch.int16, device=dev)
+            _lib.call("qpg_rank_rows_f32", dev, pd, self.K, self.K, self.pos_rank)
+        else:
+            self.pos_rank = torch.as_tensor(np.asarray(pos_rank, np.int16), device=dev).contiguous()
+
+        # code_to_freq (GestureKNN.py:481-499): 1 - count/total, 1 for unseen codes; rank of it (:544)
+        cnt = np.bincount(code.reshape(-1), minlength=self.K)[:self.K]
+        self.freq_dist = np.where(cnt > 0, 1 - cnt / cnt.sum(), 1.0)
+        if freq_rank is None:
+            fd = torch.from_numpy(self.freq_dist[None].copy()).to(dev)
+            self.freq_rank = torch.empty((1, self.K), dtype=torch.int16, device=dev)
+            _lib.call("qpg_rank_rows_f64", dev, fd, 1, self.K, self.freq_rank)
+            self.freq_rank = self.freq_rank[0].contiguous()
+        else:
+            self.freq_rank = torch.as_tensor(np.asarray(freq_rank, np.int16), device=dev).contiguous()
+
+    @property
+    def idx_base(self):
+        return self.lo
+
+
+class CodeKNN:
+    """Mirror of the reference's CodeKNN (GestureKNN.py:422-721) over a GestureDB."""
+
+    def __init__(self, db, use_wavlm=True, use_wavvq=False, use_phase=True, use_txt=True, rng=None):
+        if use_wavvq or not use_wavlm:
+            raise NotImplementedError("only the shipped wavlm_feat mode is built so far (SURVEY.md §0.3)")
+        self.db = db
+        self.step_sz = db.step_sz
+        self.n_db_seq, self.n_db_frm = db.N, db.T
+        self.use_phase, self.use_txt = use_phase, use_txt
+        self.rng = rng if rng is not None else np.random
+
+    # -- init (GestureKNN.py:462-473): same two draws from the (seeded) NumPy global stream ------
+    def init_code_phase(self):
+        db = self.db
+        i = self.rng.randint(0, self.n_db_seq)
+        j = self.rng.randint(0, self.n_db_frm - int(num_frames / num_frames_code))
+        code = int(db.code_host[i, j // num_frames_code])
+        P = db.phase_host[i, j:j + 8]                              # (8,2,8)
+        return code, np.concatenate((P[:, 0], P[:, 1]), axis=1).astype(np.float32)
+
+    # -- batched sweeps ------------------------------------------------------------------------
+    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None):
+        """Per-code best audio candidate for every query: returns (dist f64 [Q,512], idx i32 [Q,512])
+        with global candidate indices j*26+g (-1 = code absent); min-reduced across ranks."""
+        db, dev = self.db, self.db.device
+        Q = len(q_win)
+        qbase = qbase.contiguous()
+        M, T, F = qbase.shape
+        ts = db.tap_stride if tap_stride is None else tap_stride
+        q64 = torch.empty((Q, NUM_AUDIO_FEAT_FRAMES * F), dtype=torch.float64, device=dev)
+        qn2 = torch.empty((Q,), dtype=torch.float64, device=dev)
+        _lib.call("qpg_audio_pack_queries", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
+                  NUM_AUDIO_FEAT_FRAMES, ts, q64, qn2)
+        C = db.n_local * db.Ga
+        D = torch.empty((Q, max(C, 1)), dtype=torch.float64, device=dev)
+        _lib.call("qpg_audio_cosine_f64", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
+                  NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q64, qn2, Q, D, D.stride(0))
+        dist = torch.empty((Q, db.K), dtype=torch.float64, device=dev)
+        idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+        _lib.call("qpg_percode_argmin_f64", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
+                  db.aud_cidx, db.Ga, db.K, float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx)
+        self._last_D_aud = D
+        return self._reduce_min(dist, idx)
+
+    def sweep_text(self, queries):
+        """queries: f32 [Q,384] on the device.  Returns (dist f32 [Q,512], idx i32 [Q,512])."""
+        db, dev = self.db, self.db.device
+        Q = queries.shape[0]
+        qn = torch.empty_like(queries)
+        _lib.call("qpg_l2_normalize_rows_f32", dev, queries, Q, db.Dt, qn)
+        C = db.n_local * db.Gt
+        D = torch.empty((Q, max(C, 1)), dtype=torch.float32, device=dev)
+        _lib.call("qpg_text_cosine_f32", dev, db.ctxn, db.n_local, db.R, db.Dt, db.txt_r, db.Gt, qn, Q, D,
+                  D.stride(0))
+        dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
+        idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+        _lib.call("qpg_percode_argmin_f32", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
+                  db.txt_cidx, db.Gt, db.K, float(ABSENT_DIST), db.idx_base * db.Gt, dist, idx)
+        self._last_D_txt = D
+        return self._reduce_min(dist, idx)
+
+    def _reduce_min(self, dist, idx):
+        """Cross-shard min + index: all-reduce(MIN) on the distances, then
+        all-reduce(MIN) on the indices of the ranks that hold that minimum.  Shards are contiguous
+        row blocks, so the lowest index == the reference's first-wins scan order."""
+        if self.db.world == 1:
+            return dist, idx
+        import torch.distributed as dist_
+        best = dist.clone()
+        dist_.all_reduce(best, op=dist_.ReduceOp.MIN)
+        cand = torch.where((dist == best) & (idx >= 0), idx, torch.full_like(idx, 2**31 - 1))
+        dist_.all_reduce(cand, op=dist_.ReduceOp.MIN)
+        cand = torch.where(cand == 2**31 - 1, torch.full_like(cand, -1), cand)
+        return best, cand
+
+    def rank_rows(self, dist):
+        out = torch.empty(dist.shape, dtype=torch.int16, device=dist.device)
+        name = "qpg_rank_rows_f64" if dist.dtype == torch.float64 else "qpg_rank_rows_f32"
+        _lib.call(name, self.db.device, dist.contiguous(), dist.shape[0], dist.shape[1], out)
+        return out
+
+    # -- reference-shaped single-query API (GestureKNN.py:666-691, 708-721) --------------------------
+    def _unpack(self, dist, idx, G, ks, cidx):
+        d = dist[0].cpu().numpy()
+        ix = idx[0].cpu().numpy()
+        code = self.db.code_host
+        dists, pays, aux = [], [], []
+        for c in range(self.db.K):
+            if ix[c] < 0:
+                dists.append(ABSENT_DIST)
+                pays.append([])
+                aux.append([])
+            else:
+                j, g = divmod(int(ix[c]), G)
+                dists.append(d[c])
+                pays.append(code[j, cidx[g]:cidx[g] + STEP_SZ])
+                aux.append([j, ks[g]])
+        return dists, pays, aux
+
+    def search_audio_cands(self, clip_input, mode="wavlm_feat"):
+        """clip_input: one 6144-d WavLM feature row (6 taps x 1024).  Same return triple as the
+        reference: per-code distance list, per-code 4-code payload (or []), per-code [j, k] (or [])."""
+        if mode != "wavlm_feat":
+            raise NotImplementedError(mode)
+        db = self.db
+        q = torch.as_tensor(np.asarray(clip_input, np.float32).reshape(1, NUM_AUDIO_FEAT_FRAMES, db.F),
+                            device=db.device).contiguous()
+        dist, idx = self.sweep_audio(q, [0], [0], tap_stride=1)
+        return self._unpack(dist, idx, db.Ga, db.aud_k, db.aud_cidx_host)
+
+    def search_text_cands(self, clip_input, mode="wavvq_feat"):
+        db = self.db
+        q = torch.as_tensor(np.asarray(clip_input, np.float32).reshape(1, db.Dt), device=db.device).contiguous()
+        dist, idx = self.sweep_text(q)
+        return self._unpack(dist, idx, db.Gt, db.txt_k, db.txt_rows_host)
+
+    # -- whole clip ---------------------------------------------------------------------------------
+    def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
+                   seed_phase=None, return_tables=False):
+        """All windows of a clip: two batched sweeps + rank kernels + one device-side tail walk.
+        test_interp: f32 [M,180,F] device tensor; test_context: f32 [M,30,384] device tensor.
+        Returns (codes int64 [M,30], phases f32 [M,8,8,16], votes [M,8]) as NumPy arrays."""
+        db, dev = self.db, self.db.device
+        M = n_windows
+        test_interp = test_interp.contiguous()
+        steps = len(range(0, db.T, STEP_SZ * self.step_sz))                   # GestureKNN.py:528,659
+        Q = M * steps
+        q_win = np.repeat(np.arange(M), steps)
+        q_t = np.tile(np.arange(steps) * STEP_SZ * self.step_sz, M)
+        aud_rank = aud_idx = txt_rank = txt_idx = None
+        if mode in (MODE_AUD_TXT, MODE_AUD):
+            aud_d, aud_idx = self.sweep_audio(test_interp, q_win, q_t)
+            aud_rank = self.rank_rows(aud_d)
+        if mode in (MODE_AUD_TXT, MODE_TXT):
+            rows = [int(i / db.T * 30) for i in q_t]                           # GestureKNN.py:549
+            qtxt = test_context[torch.as_tensor(q_win, device=dev), torch.as_tensor(rows, device=dev)].contiguous()
+            txt_d, txt_idx = self.sweep_text(qtxt)
+            txt_rank = self.rank_rows(txt_d)
+        if seed_code is None:
+            seed_code, seed_phase = self.init_code_phase()
+        sp = torch.as_tensor(np.asarray(seed_phase, np.float32), device=dev).contiguous()
+        out_codes = torch.empty((M, num_frames_code), dtype=torch.int32, device=dev)
+        out_phase = torch.empty((M, steps, 8, 16), dtype=torch.float32, device=dev)
+        out_vote = torch.empty((M, steps), dtype=torch.int32, device=dev)
+        status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        _lib.call("qpg_match_steps", dev, aud_rank, aud_idx, txt_rank, txt_idx, db.pos_rank, db.freq_rank,
+                  db.code, db.code.shape[1], db.aud_cidx, db.aud_pslot, db.Ga, db.txt_cidx, db.txt_pslot, db.Gt,
+                  db.phase, db.Tp, mode, M, steps, db.K, int(seed_code), sp, out_codes, out_phase, out_vote,
+                  status)
+        if return_tables:
+            self.tables = dict(aud_d=aud_d if aud_rank is not None else None, aud_idx=aud_idx, aud_rank=aud_rank,
+                               txt_d=txt_d if txt_rank is not None else None, txt_idx=txt_idx, txt_rank=txt_rank)
+        codes = out_codes.cpu().numpy().astype(np.int64)
+        if int(status.item()) != 0:
+            raise IndexError("a code that never occurs in the database won a rank fusion "
+                             "(the reference raises IndexError at GestureKNN.py:631-632)")
+        return codes, out_phase.cpu().numpy(), out_vote.cpu().numpy()
+
+
+def predict_code_from_audio(db, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, rng=None):
+    """predict_code_from_audio (GestureKNN.py:724-813) for the shipped flags; returns (M,30) int64."""
+    knn = CodeKNN(db, rng=rng)
+    codes, _, _ = knn.match_clip(test_interp, test_context, n_windows, mode=mode)
+    return codes

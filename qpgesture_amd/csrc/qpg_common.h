@@ -1,0 +1,51 @@
+// Shared host-side plumbing for libqpg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/qpg.h"
+
+struct qpg_ctx {
+  int device;
+  int n_cu;
+};
+
+void qpg_set_error(const char* fmt, ...);
+
+#define QPG_REQUIRE(cond, ...)      \
+  do {                              \
+    if (!(cond)) {                  \
+      qpg_set_error(__VA_ARGS__);   \
+      return QPG_EINVAL;            \
+    }                               \
+  } while (0)
+
+#define QPG_LAUNCH_CHECK(name)                                                \
+  do {                                                                        \
+    hipError_t e_ = hipGetLastError();                                        \
+    if (e_ != hipSuccess) {                                                   \
+      qpg_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));    \
+      return QPG_EHIP;                                                        \
+    }                                                                         \
+  } while (0)
+
+static inline hipStream_t qpg_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// IEEE single-rounding float ops: the text and phase-gate distances must reproduce
+// NumPy/scikit-learn float32 arithmetic bit for bit (separate multiply and add, correctly
+// rounded sqrt and divide).  hipcc's __fmul_rn/__fsqrt_rn are plain `*` / native sqrt unless
+// OCML_BASIC_ROUNDED_OPERATIONS is set, so exactness comes from the build flags instead:
+// every file is compiled with -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt, and
+// the pragma below repeats it where it matters.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float f_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float f_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float f_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float f_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float f_sqrt(float a) { return __builtin_sqrtf(a); }

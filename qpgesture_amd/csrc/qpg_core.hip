@@ -1,0 +1,152 @@
+// Context, error reporting and the one-off database preparation kernels.
+#include <stdarg.h>
+
+#include "qpg_common.h"
+
+static thread_local char g_err[512] = "";
+
+void qpg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int qpg_version(void) { return 100; }
+
+extern "C" int qpg_last_error(char* buf, size_t n) {
+  if (!buf || n == 0) return QPG_EINVAL;
+  strncpy(buf, g_err, n - 1);
+  buf[n - 1] = 0;
+  return QPG_OK;
+}
+
+extern "C" int qpg_ctx_create(int device, qpg_ctx** out) {
+  QPG_REQUIRE(out != nullptr, "qpg_ctx_create: out is null");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+    qpg_set_error("qpg_ctx_create: no HIP device %d (count %d)", device, n);
+    return QPG_EHIP;
+  }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) {
+    qpg_set_error("qpg_ctx_create: hipGetDeviceProperties failed");
+    return QPG_EHIP;
+  }
+  qpg_ctx* c = new qpg_ctx;
+  c->device = device;
+  c->n_cu = p.multiProcessorCount;
+  *out = c;
+  return QPG_OK;
+}
+
+extern "C" int qpg_ctx_destroy(qpg_ctx* ctx) {
+  delete ctx;
+  return QPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-frame squared norm in f64: one wave per row, 16 B loads, wave64 shuffle reduce.
+// HBM-bound: reads rows*F*4 bytes once.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_norm2_kernel(const float* __restrict__ x, int64_t rows, int F,
+                                                          double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = x + row * F;
+  double s = 0.0;
+  if ((F & 3) == 0) {
+    for (int e = lane * 4; e < F; e += 256) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(p + e);
+      s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (int e = lane; e < F; e += 64) s += (double)p[e] * p[e];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) out[row] = s;
+}
+
+extern "C" int qpg_frame_norm2_f64(qpg_ctx* ctx, void* stream, const float* x, int64_t rows, int F, double* out) {
+  QPG_REQUIRE(ctx && x && out && rows >= 0 && F > 0, "qpg_frame_norm2_f64: bad argument");
+  if (rows == 0) return QPG_OK;
+  hipLaunchKernelGGL(frame_norm2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, qpg_stream(stream), x, rows,
+                     F, out);
+  QPG_LAUNCH_CHECK("frame_norm2_kernel");
+  return QPG_OK;
+}
+
+__global__ void audio_cand_norm2_kernel(const double* __restrict__ fn2, int N, int T, const int32_t* __restrict__ cand_t,
+                                        int G, int n_taps, int tap_stride, double* __restrict__ cn2) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)N * G) return;
+  int j = (int)(i / G), g = (int)(i % G);
+  int t0 = cand_t[g];
+  double s = 0.0;
+  for (int k = 0; k < n_taps; ++k) {
+    int t = t0 + k * tap_stride;
+    if (t < T) s += fn2[(int64_t)j * T + t];
+  }
+  cn2[i] = s;
+}
+
+extern "C" int qpg_audio_cand_norm2(qpg_ctx* ctx, void* stream, const double* fn2, int N, int T,
+                                    const int32_t* cand_t, int G, int n_taps, int tap_stride, double* cn2) {
+  QPG_REQUIRE(ctx && fn2 && cand_t && cn2 && N >= 0 && T > 0 && G > 0 && n_taps > 0 && tap_stride > 0,
+              "qpg_audio_cand_norm2: bad argument");
+  int64_t n = (int64_t)N * G;
+  if (n == 0) return QPG_OK;
+  hipLaunchKernelGGL(audio_cand_norm2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, qpg_stream(stream),
+                     fn2, N, T, cand_t, G, n_taps, tap_stride, cn2);
+  QPG_LAUNCH_CHECK("audio_cand_norm2_kernel");
+  return QPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scikit-learn-exact float32 row normalisation.  One thread per row, four sequential lane
+// accumulators in NumPy-einsum order (16-element groups visited as u = 3,2,1,0; lane = e & 3),
+// tail in 4-wide zero-filled steps, horizontal (l0+l1)+(l2+l3).  See oracle/knn_oracle.py.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float einsum_sq_row(const float* __restrict__ p, int D) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int nfull = D >> 4;
+  for (int g = 0; g < nfull; ++g) {
+#pragma unroll
+    for (int u = 3; u >= 0; --u) {
+      const float* q = p + g * 16 + u * 4;
+      a0 = f_add(f_mul(q[0], q[0]), a0);
+      a1 = f_add(f_mul(q[1], q[1]), a1);
+      a2 = f_add(f_mul(q[2], q[2]), a2);
+      a3 = f_add(f_mul(q[3], q[3]), a3);
+    }
+  }
+  for (int i = nfull * 16; i < D; i += 4) {
+    float x0 = p[i], x1 = (i + 1 < D) ? p[i + 1] : 0.f, x2 = (i + 2 < D) ? p[i + 2] : 0.f,
+          x3 = (i + 3 < D) ? p[i + 3] : 0.f;
+    a0 = f_add(f_mul(x0, x0), a0);
+    a1 = f_add(f_mul(x1, x1), a1);
+    a2 = f_add(f_mul(x2, x2), a2);
+    a3 = f_add(f_mul(x3, x3), a3);
+  }
+  return f_add(f_add(a0, a1), f_add(a2, a3));
+}
+
+__global__ void l2_normalize_rows_kernel(const float* __restrict__ x, int64_t rows, int D, float* __restrict__ out) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* p = x + r * D;
+  float n = f_sqrt(einsum_sq_row(p, D));
+  if (n < 10.f * 1.1920928955078125e-07f) n = 1.f;  // sklearn _handle_zeros_in_scale
+  float* o = out + r * D;
+  for (int e = 0; e < D; ++e) o[e] = f_div(p[e], n);
+}
+
+extern "C" int qpg_l2_normalize_rows_f32(qpg_ctx* ctx, void* stream, const float* x, int64_t rows, int D, float* out) {
+  QPG_REQUIRE(ctx && x && out && rows >= 0 && D > 0, "qpg_l2_normalize_rows_f32: bad argument");
+  if (rows == 0) return QPG_OK;
+  hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, qpg_stream(stream), x,
+                     rows, D, out);
+  QPG_LAUNCH_CHECK("l2_normalize_rows_kernel");
+  return QPG_OK;
+}
