@@ -182,8 +182,15 @@ class CodeKNN:
                   NUM_AUDIO_FEAT_FRAMES, ts, q64, qn2)
         C = db.n_local * db.Ga
         D = torch.empty((Q, max(C, 1)), dtype=torch.float64, device=dev)
+        ev = getattr(self, "kernel_events", None)       # bench.py: HIP events around the dominant kernel
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
         _lib.call("qpg_audio_cosine_f64", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
                   NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q64, qn2, Q, D, D.stride(0))
+        if ev is not None:
+            e1.record(torch.cuda.current_stream(dev))
+            ev.append((e0, e1))
         dist = torch.empty((Q, db.K), dtype=torch.float64, device=dev)
         idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
         _lib.call("qpg_percode_argmin_f64", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
@@ -264,46 +271,70 @@ class CodeKNN:
         return self._unpack(dist, idx, db.Gt, db.txt_k, db.txt_rows_host)
 
     # -- whole clip ---------------------------------------------------------------------------------
-    def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
-                   seed_phase=None, return_tables=False):
-        """All windows of a clip: two batched sweeps + rank kernels + one device-side tail walk.
-        test_interp: f32 [M,180,F] device tensor; test_context: f32 [M,30,384] device tensor.
-        Returns (codes int64 [M,30], phases f32 [M,8,8,16], votes [M,8]) as NumPy arrays."""
+    def n_steps(self):
+        return len(range(0, self.db.T, STEP_SZ * self.step_sz))               # GestureKNN.py:528,659
+
+    def sweep_tables(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT):
+        """Both batched sweeps + ranks for all Q = n_windows*steps query positions (the windows may
+        belong to several clips).  test_interp: f32 [M,180,F]; test_context: f32 [M,30,384] (device).
+        Returns a dict of device tensors: aud_d/aud_idx/aud_rank, txt_d/txt_idx/txt_rank."""
         db, dev = self.db, self.db.device
-        M = n_windows
-        test_interp = test_interp.contiguous()
-        steps = len(range(0, db.T, STEP_SZ * self.step_sz))                   # GestureKNN.py:528,659
-        Q = M * steps
+        M, steps = n_windows, self.n_steps()
         q_win = np.repeat(np.arange(M), steps)
         q_t = np.tile(np.arange(steps) * STEP_SZ * self.step_sz, M)
-        aud_rank = aud_idx = txt_rank = txt_idx = None
+        T = dict(aud_d=None, aud_idx=None, aud_rank=None, txt_d=None, txt_idx=None, txt_rank=None)
         if mode in (MODE_AUD_TXT, MODE_AUD):
-            aud_d, aud_idx = self.sweep_audio(test_interp, q_win, q_t)
-            aud_rank = self.rank_rows(aud_d)
+            T["aud_d"], T["aud_idx"] = self.sweep_audio(test_interp, q_win, q_t)
+            T["aud_rank"] = self.rank_rows(T["aud_d"])
         if mode in (MODE_AUD_TXT, MODE_TXT):
             rows = [int(i / db.T * 30) for i in q_t]                           # GestureKNN.py:549
-            qtxt = test_context[torch.as_tensor(q_win, device=dev), torch.as_tensor(rows, device=dev)].contiguous()
-            txt_d, txt_idx = self.sweep_text(qtxt)
-            txt_rank = self.rank_rows(txt_d)
+            key = (M, steps)
+            if getattr(self, "_txt_gather_key", None) != key:
+                self._txt_gather = (torch.as_tensor(q_win, device=dev), torch.as_tensor(rows, device=dev))
+                self._txt_gather_key = key
+            qtxt = test_context[self._txt_gather[0], self._txt_gather[1]].contiguous()
+            T["txt_d"], T["txt_idx"] = self.sweep_text(qtxt)
+            T["txt_rank"] = self.rank_rows(T["txt_d"])
+        return T
+
+    def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True):
+        """Device-side walk of windows [window_offset, window_offset+n_windows) of the tables."""
+        db, dev = self.db, self.db.device
+        M, steps = n_windows, self.n_steps()
         if seed_code is None:
             seed_code, seed_phase = self.init_code_phase()
-        sp = torch.as_tensor(np.asarray(seed_phase, np.float32), device=dev).contiguous()
+        if isinstance(seed_phase, torch.Tensor):
+            sp = seed_phase.to(dev, torch.float32).contiguous()
+        else:
+            sp = torch.as_tensor(np.asarray(seed_phase, np.float32), device=dev).contiguous()
         out_codes = torch.empty((M, num_frames_code), dtype=torch.int32, device=dev)
         out_phase = torch.empty((M, steps, 8, 16), dtype=torch.float32, device=dev)
         out_vote = torch.empty((M, steps), dtype=torch.int32, device=dev)
         status = torch.zeros((1,), dtype=torch.int32, device=dev)
-        _lib.call("qpg_match_steps", dev, aud_rank, aud_idx, txt_rank, txt_idx, db.pos_rank, db.freq_rank,
-                  db.code, db.code.shape[1], db.aud_cidx, db.aud_pslot, db.Ga, db.txt_cidx, db.txt_pslot, db.Gt,
-                  db.phase, db.Tp, mode, M, steps, db.K, int(seed_code), sp, out_codes, out_phase, out_vote,
-                  status)
-        if return_tables:
-            self.tables = dict(aud_d=aud_d if aud_rank is not None else None, aud_idx=aud_idx, aud_rank=aud_rank,
-                               txt_d=txt_d if txt_rank is not None else None, txt_idx=txt_idx, txt_rank=txt_rank)
+        q0 = window_offset * steps
+
+        def sl(t):
+            return None if t is None else t[q0:q0 + M * steps]
+        _lib.call("qpg_match_steps", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]), sl(T["txt_idx"]),
+                  db.pos_rank, db.freq_rank, db.code, db.code.shape[1], db.aud_cidx, db.aud_pslot, db.Ga,
+                  db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode, M, steps, db.K, int(seed_code), sp,
+                  out_codes, out_phase, out_vote, status)
+        if not sync:
+            return out_codes, out_phase, out_vote, status
         codes = out_codes.cpu().numpy().astype(np.int64)
         if int(status.item()) != 0:
             raise IndexError("a code that never occurs in the database won a rank fusion "
                              "(the reference raises IndexError at GestureKNN.py:631-632)")
         return codes, out_phase.cpu().numpy(), out_vote.cpu().numpy()
+
+    def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
+                   seed_phase=None, return_tables=False):
+        """All windows of one clip: two batched sweeps + rank kernels + one device-side tail walk.
+        Returns (codes int64 [M,30], phases f32 [M,8,8,16], votes [M,8]) as NumPy arrays."""
+        T = self.sweep_tables(test_interp.contiguous(), test_context, n_windows, mode)
+        if return_tables:
+            self.tables = T
+        return self.walk(T, n_windows, 0, mode, seed_code, seed_phase)
 
 
 def predict_code_from_audio(db, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, rng=None):
