@@ -180,8 +180,9 @@ class CodeKNNOracle:
 
     def __init__(self, code_train, signature, phase_dense, context_train,
                  wavlm_interp=None, wavvq_train_feat=None, mode="wavlm",
-                 rng=None, rank_kind="numpy"):
+                 rng=None, rank_kind="numpy", scan="numpy"):
         self.mode = mode
+        self.scan = scan                              # "numpy" (this file) or "c" (oracle/sweep_ref.c, same bits)
         self.code = np.asarray(code_train)
         self.sig = np.asarray(signature, np.float32)
         self.phase = phase_dense                      # (n,240,4,8) f32
@@ -229,6 +230,10 @@ class CodeKNNOracle:
         """Per-code best audio candidate (GestureKNN.py:666-691).  q: (6144,) f64 [wavlm]
         or (22,) [wavvq].  Returns dist[512], payload[512,4] (-1 = empty), aux[512,2]."""
         ks, kint, cidx = audio_grid(self.n_db_frm, self.step_sz)
+        if self.scan == "c" and self.mode == "wavlm":
+            from . import cref
+            d, ix = cref.audio_scan(self.interp, kint, self.code, cidx, np.asarray(q, np.float64)[None])
+            return self._expand(d[0], ix[0], len(ks), kint, cidx)
         dist = np.full(K_CODES, ABSENT, np.float64)
         pay = np.full((K_CODES, 4), -1, np.int64)
         aux = np.full((K_CODES, 2), -1, np.int64)
@@ -254,6 +259,11 @@ class CodeKNNOracle:
         aux = np.full((K_CODES, 2), -1, np.int64)
         grid = list(range(0, N_FRAMES - STEP_SZ * 8, 8))
         rows = [k // 8 for k in grid]
+        if self.scan == "c":
+            from . import cref
+            d, ix = cref.text_scan(self.ctx, rows, self.code, rows, np.asarray(q, np.float32)[None])
+            dd, pay, aux = self._expand(d[0].astype(np.float64), ix[0], len(grid), grid, rows)
+            return dd, pay, aux
         for j in range(self.n_db_seq):
             d = cosine_rows(q, self.ctx[j, rows])       # f32
             for g, k in enumerate(grid):
@@ -263,6 +273,18 @@ class CodeKNNOracle:
                     pay[c] = self.code[j, k // 8:k // 8 + STEP_SZ]
                     aux[c] = (j, k)
         return dist, pay, aux
+
+    def _expand(self, d, ix, G, ks, cidx):
+        """(dist, flat index) -> the reference's (dist, 4-code payload, [j,k]) triple."""
+        pay = np.full((K_CODES, 4), -1, np.int64)
+        aux = np.full((K_CODES, 2), -1, np.int64)
+        for c in range(K_CODES):
+            if ix[c] >= 0:
+                j, g = divmod(int(ix[c]), G)
+                p = self.code[j, cidx[g]:cidx[g] + STEP_SZ]
+                pay[c, :len(p)] = p
+                aux[c] = (j, ks[g])
+        return np.asarray(d, np.float64), pay, aux
 
     # -- phase gate -------------------------------------------------------------
     def _cand_phase(self, aux_jk):
@@ -370,7 +392,7 @@ def predict_code_from_audio(knn, test_interp=None, test_vq_feat=None, test_ctx=N
     return np.array(motion), np.array(phases), np.array(votes)
 
 
-def load_and_match(paths, max_frames=0, seed=123456, rank_kind="numpy", trace=None):
+def load_and_match(paths, max_frames=0, seed=123456, rank_kind="numpy", trace=None, scan="numpy"):
     """main_codebook (GestureKNN.py:816-845), shipped flags (:842-843)."""
     tr = np.load(paths["train_database"], allow_pickle=True)
     te = np.load(paths["test_data"], allow_pickle=True)
@@ -381,7 +403,7 @@ def load_and_match(paths, max_frames=0, seed=123456, rank_kind="numpy", trace=No
     n_win = max_frames if max_frames != 0 else np.load(paths["test_wavvq"])["wavvq"].shape[0]   # :740
     rs = np.random.RandomState(seed)                                                          # :22
     knn = CodeKNNOracle(code, sig, densify_phase(tr["phase"]), tr["context"].squeeze(2),
-                        wavlm_interp=tr_interp, mode="wavlm", rng=rs, rank_kind=rank_kind)
+                        wavlm_interp=tr_interp, mode="wavlm", rng=rs, rank_kind=rank_kind, scan=scan)
     out = predict_code_from_audio(knn, test_interp=te_interp, test_ctx=te["context"].squeeze(2),
                                   n_windows=n_win, trace=trace)
     return out, knn

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .parallel import allreduce_min_index, shard_rows
 from .constant import (ABSENT_DIST, NUM_AUDIO_FEAT_FRAMES, STEP_SZ, codebook_size, num_frames,
                        num_frames_code)
 
@@ -72,8 +73,7 @@ class GestureDB:
         self.rank, self.world = rank, world
         code = np.asarray(code)
         self.N = N = code.shape[0]
-        per = (N + world - 1) // world
-        self.lo, self.hi = min(rank * per, N), min((rank + 1) * per, N)
+        self.lo, self.hi = shard_rows(N, rank, world)
         self.n_local = self.hi - self.lo
         self.K = codebook_size
         self.code_host = code.astype(np.int64)
@@ -221,13 +221,7 @@ class CodeKNN:
         row blocks, so the lowest index == the reference's first-wins scan order."""
         if self.db.world == 1:
             return dist, idx
-        import torch.distributed as dist_
-        best = dist.clone()
-        dist_.all_reduce(best, op=dist_.ReduceOp.MIN)
-        cand = torch.where((dist == best) & (idx >= 0), idx, torch.full_like(idx, 2**31 - 1))
-        dist_.all_reduce(cand, op=dist_.ReduceOp.MIN)
-        cand = torch.where(cand == 2**31 - 1, torch.full_like(cand, -1), cand)
-        return best, cand
+        return allreduce_min_index(dist, idx)
 
     def rank_rows(self, dist):
         out = torch.empty(dist.shape, dtype=torch.int16, device=dist.device)

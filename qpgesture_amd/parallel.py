@@ -1,0 +1,29 @@
+"""Multi-GPU decomposition of the matcher: the database's windows are split into
+contiguous row blocks, one per rank (one process per GPU, torch.distributed over RCCL/xGMI); each
+rank sweeps its block and the per-(query, code) minima are combined with a min + index exchange.
+
+The message is tiny (Q*512*(8+4) B = 295 KB for a 24 s clip), so the exchange is latency- not
+link-bound: two all-reduces on the packed tables, no per-candidate traffic."""
+import torch
+
+INT_MAX = 2 ** 31 - 1
+
+
+def shard_rows(n, rank, world):
+    """Contiguous row block [lo, hi) of rank `rank` (ceil split; trailing ranks may be empty)."""
+    per = (n + world - 1) // world
+    return min(rank * per, n), min((rank + 1) * per, n)
+
+
+def allreduce_min_index(dist, idx, group=None):
+    """all-reduce(min + index): `dist` [Q,K] per-shard minima, `idx` [Q,K] GLOBAL candidate indices
+    (-1 = absent).  Returns the global minima and, among ranks that hold the minimum, the lowest
+    index — i.e. the reference's first-wins scan order (GestureKNN.py:686), because shards are
+    contiguous ascending row blocks.  Works on any backend (nccl == RCCL on ROCm, gloo on CPU)."""
+    import torch.distributed as dist_
+    best = dist.clone()
+    dist_.all_reduce(best, op=dist_.ReduceOp.MIN, group=group)
+    cand = torch.where((dist == best) & (idx >= 0), idx, torch.full_like(idx, INT_MAX))
+    dist_.all_reduce(cand, op=dist_.ReduceOp.MIN, group=group)
+    cand = torch.where(cand == INT_MAX, torch.full_like(cand, -1), cand)
+    return best, cand

@@ -1,0 +1,78 @@
+"""world_size-2 CPU test (gloo) of the row-sharded scan + min/index exchange: two ranks scan
+disjoint row blocks with the oracle's C port, combine with qpgesture_amd.parallel.allreduce_min_index,
+and must reproduce the single-process scan bit for bit (distances AND first-wins indices),
+including duplicated rows that straddle the shard boundary (exact ties across ranks)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data():
+    from qpgesture_amd import synth
+    rng = np.random.default_rng(3)
+    N, F = 12, 64
+    base = rng.standard_normal((N, 180, F)).astype(np.float32)
+    ctx = rng.standard_normal((N, 30, 384)).astype(np.float32)
+    base[7] = base[2]          # window 7 (rank 1) duplicates window 2 (rank 0): exact ties across ranks
+    ctx[9] = ctx[1]
+    code = synth.make_codes(N, 4, force_all_present=False)
+    code[7], code[9] = code[2], code[1]
+    q = rng.standard_normal((5, 6 * F))
+    q[0] = np.concatenate([base[2, 6 * 3 + 2 * i] for i in range(6)])     # query == a DB candidate
+    qt = rng.standard_normal((5, 384)).astype(np.float32)
+    return base, ctx, code, q, qt
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cref
+    from qpgesture_amd.parallel import allreduce_min_index, shard_rows
+    base, ctx, code, q, qt = _data()
+    lo, hi = shard_rows(base.shape[0], rank, world)
+    g = np.arange(26)
+    d, ix = cref.audio_scan(base[lo:hi], g * 6, code[lo:hi], g, q)
+    ix = np.where(ix >= 0, ix + lo * 26, -1).astype(np.int32)
+    D, I = allreduce_min_index(torch.from_numpy(d), torch.from_numpy(ix))
+    dt, it = cref.text_scan(ctx[lo:hi], g, code[lo:hi], g, qt)
+    it = np.where(it >= 0, it + lo * 26, -1).astype(np.int32)
+    Dt, It = allreduce_min_index(torch.from_numpy(dt), torch.from_numpy(it))
+    if rank == 0:
+        np.savez(out, d=D.numpy(), i=I.numpy(), dt=Dt.numpy(), it=It.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_scan_world2(tmp_path):
+    from oracle import cref
+    out = str(tmp_path / "r.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = np.load(out)
+    base, ctx, code, q, qt = _data()
+    g = np.arange(26)
+    d, ix = cref.audio_scan(base, g * 6, code, g, q)
+    dt, it = cref.text_scan(ctx, g, code, g, qt)
+    assert np.array_equal(r["d"], d) and np.array_equal(r["i"], ix)
+    assert np.array_equal(r["dt"], dt) and np.array_equal(r["it"], it)
+    assert (ix == -1).any() and (r["i"][ix == -1] == -1).all()        # absent codes stay absent
+
+
+def test_shard_rows_cover_and_order():
+    from qpgesture_amd.parallel import shard_rows
+    for n in (0, 1, 7, 8, 2048, 2049):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_rows(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))

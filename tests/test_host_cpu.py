@@ -1,0 +1,74 @@
+"""CPU tests of the host logic and of the C-ABI library surface (no compute calls without a GPU)."""
+import ctypes
+import tempfile
+
+import numpy as np
+import pytest
+
+from qpgesture_amd import _lib, synth
+from qpgesture_amd import code_knn as ck
+from qpgesture_amd import data_processing as dp
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _lib.declared_symbols()
+    assert len(names) >= 16 and "qpg_audio_cosine_f64" in names and "qpg_match_steps" in names
+    for n in names:
+        assert hasattr(lib, n), "include/qpg.h declares %s but libqpg_hip.so does not export it" % n
+    assert lib.qpg_version() >= 100
+
+
+def test_bindings_cover_the_header():
+    declared = set(_lib.declared_symbols())
+    bound = set(_lib._SIGS) | {"qpg_version", "qpg_ctx_create", "qpg_ctx_destroy", "qpg_last_error"}
+    assert declared == bound
+
+
+def test_error_reporting_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    rc = lib.qpg_ctx_create(0, ctypes.byref(h))
+    assert rc < 0 and "qpg_ctx_create" in _lib.last_error()
+    assert lib.qpg_ctx_create(0, None) == -1
+
+
+def test_product_refuses_cpu_device():
+    A = synth.make_db(2, 0, 64)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ck.GestureDB(synth.make_codes(2, 1), dp.interp_wavlm(A["wavlm"]), A["context"].squeeze(2),
+                     A["phase_dense"], synth.make_signature(2), device="cpu")
+
+
+def test_grids_match_oracle():
+    from oracle import knn_oracle as O
+    for n, st in ((180, 6), (398, 398 / 30), (240, 8)):
+        ks, kint, cidx = O.audio_grid(n, st)
+        a, b = ck.audio_grid(n, st)
+        assert a == kint and b == cidx and len(a) == 26
+    ks, rows = ck.text_grid()
+    assert ks == list(range(0, 208, 8)) and rows == list(range(26))
+    assert [ck.phase_slot(k) for k in (0, 6, 150, 200, 331)] == [O.phase_slot(k) for k in (0, 6, 150, 200, 331)]
+
+
+def test_loader_matches_oracle_windowing():
+    from oracle import knn_oracle as O
+    with tempfile.TemporaryDirectory() as td:
+        p = synth.write_npz_set(td, 3, 2, 7, 8, 9, 10, wavlm_dim=64)
+        L = dp.load_db_codebook(p["train_database"], p["train_codebook"], p["test_data"], p["train_wavlm"],
+                                p["test_wavlm"], p["train_wavvq"], p["test_wavvq"])
+        tr = np.load(p["train_database"], allow_pickle=True)
+        assert np.array_equal(L.train_wavlm, O.interp_wavlm(np.load(p["train_wavlm"])["wavlm"]))
+        assert L.train_wavlm.shape == (3, 180, 64) and L.train_wavlm.flags.c_contiguous
+        assert np.array_equal(L.train_phase, O.densify_phase(tr["phase"]))
+        assert np.array_equal(L.train_phase, synth.make_db(3, 7, 64)["phase_dense"])
+        assert L.train_context.shape == (3, 30, 384) and L.code.shape == (3, 30)
+        assert L.test_wavvq.shape == (2, 398, 2)
+
+
+def test_densify_phase_accepts_dense():
+    x = np.random.default_rng(0).standard_normal((2, 240, 4, 8)).astype(np.float32)
+    assert np.array_equal(dp.densify_phase(x), x)

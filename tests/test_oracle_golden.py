@@ -1,0 +1,76 @@
+"""CPU tests: pin the oracle (NumPy restatement + its C port) to what the REFERENCE produced.
+
+tests/golden/*.npz were captured by tests/golden/make_golden.py, which imports /root/reference in
+the build container.  Inputs are regenerated from seeds; nothing here reads /root/reference."""
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import cref, knn_oracle as O
+from qpgesture_amd import synth
+from tests.helpers import fixture_arrays, load_golden
+
+GOLDENS = ["shipped_n48_m2_s0", "shipped_n64_m3_s10"]
+
+
+def test_cosine_emulation_bitexact():
+    """einsum-order restatement == sklearn.paired_distances, bit for bit, f32 and f64."""
+    from sklearn.metrics.pairwise import paired_distances
+    rng = np.random.default_rng(0)
+    for D, dt in ((384, np.float32), (128, np.float32), (6144, np.float64), (135, np.float32), (22, np.float64)):
+        for _ in range(40):
+            a, b = rng.standard_normal(D).astype(dt), rng.standard_normal(D).astype(dt)
+            ref = paired_distances([a], [b], metric="cosine")[0]
+            got = O.cosine_pair(a, b)
+            assert got.dtype == ref.dtype and got == ref
+    z = np.zeros(384, np.float32)                      # zero row: sklearn leaves it unscaled -> 0.5
+    a = rng.standard_normal(384).astype(np.float32)
+    assert O.cosine_pair(z, a) == paired_distances([z], [a], metric="cosine")[0]
+    assert O.cosine_pair(z, z) == 0
+
+
+def test_grids_literal():
+    ks, kint, cidx = O.audio_grid(180, 6)
+    assert kint == list(range(0, 156, 6)) and cidx == list(range(26))
+    ks, kint, cidx = O.audio_grid(398, 398 / 30)      # float grid: 26 positions, the 27th is excluded
+    assert len(ks) == 26 and kint[-1] == 331 and cidx[-1] == 25
+    assert O.phase_slot(150) == 90 and O.phase_slot(200) == 120
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_c_scans_vs_reference(name):
+    """oracle/sweep_ref.c: distances bit-identical and winners identical to the reference's
+    search_audio_cands / search_text_cands returns."""
+    g = load_golden(name)
+    ntr, nte, s0, s1, s2, s3, mf = [int(v) for v in g["meta"]]
+    A = fixture_arrays(ntr, nte, s0, s1, s2, s3)
+    q = np.stack([O.wavlm_feat_rows(A["te_interp"], w, [24 * s])[0] for w in range(nte) for s in range(8)])
+    d, ix = cref.audio_scan(A["tr_interp"], np.arange(26) * 6, A["code"], np.arange(26), q, n_threads=4)
+    assert np.array_equal(d, g["aud_dist"])
+    assert np.array_equal(ix, g["aud_aux"][..., 0] * 26 + g["aud_aux"][..., 1] // 6)
+    qt = np.stack([A["te_ctx"][w][int(24 * s / 180 * 30)] for w in range(nte) for s in range(8)])
+    d, ix = cref.text_scan(A["tr_ctx"], np.arange(26), A["code"], np.arange(26), qt, n_threads=4)
+    assert np.array_equal(d, g["txt_dist"])
+    assert np.array_equal(ix, g["txt_aux"][..., 0] * 26 + g["txt_aux"][..., 1] // 8)
+
+
+@pytest.mark.parametrize("name,scan", [("shipped_n48_m2_s0", "numpy"), ("shipped_n48_m2_s0", "c"),
+                                       ("shipped_n64_m3_s10", "c")])
+def test_oracle_pipeline_vs_reference(name, scan):
+    """Whole restated pipeline (npz load -> windowing -> scans -> rank fusion -> phase gate -> chaining)
+    == the reference CLI's knn_pred and every captured intermediate."""
+    g = load_golden(name)
+    ntr, nte, s0, s1, s2, s3, mf = [int(v) for v in g["meta"]]
+    with tempfile.TemporaryDirectory() as td:
+        paths = synth.write_npz_set(td, ntr, nte, s0, s1, s2, s3)
+        trace = []
+        (motion, phases, votes), knn = O.load_and_match(paths, max_frames=mf, trace=trace, scan=scan)
+    assert np.array_equal(motion, g["knn_pred"])
+    assert np.array_equal(votes, g["vote"])
+    assert np.array_equal(phases, g["phase_out"])
+    assert np.array_equal(np.array([t["aud_d"] for t in trace]), g["aud_dist"])
+    assert np.array_equal(np.array([t["txt_d"] for t in trace]).astype(np.float32), g["txt_dist"])
+    assert np.array_equal(np.array([t["pos_score"] for t in trace]), g["step_pos_score"])
+    assert np.array_equal(knn.freq_rank(), g["step_freq_score"])
+    assert knn.tied_decisions == 0          # fixtures are chosen tie-free at every decision point
