@@ -66,13 +66,14 @@ int qpg_l2_normalize_rows_f32(qpg_ctx*, void* stream, const float* x, int64_t ro
  * Candidate index c = j*G + g (j = DB window, g = grid position) = the reference's scan order.
  * ---------------------------------------------------------------------------------------- */
 
-/* Gather + widen the audio queries of a clip.
+/* Gather the audio queries of a clip into contiguous rows (values stay f32: WavLM features are f32
+ * in the reference too, only the arithmetic is f64) and compute their squared norms in f64.
  * qbase: [dev] f32 [M][T][F] (interpolated WavLM of the test windows);
  * q_win/q_t: [dev] i32 [Q] window and start frame of each query (GestureKNN.py:565: clip_test[i]);
- * q64: [dev] f64 [Q][n_taps*F] out; qn2: [dev] f64 [Q] out (squared norms). */
+ * q32: [dev] f32 [Q][n_taps*F] out; qn2: [dev] f64 [Q] out (squared norms). */
 int qpg_audio_pack_queries(qpg_ctx*, void* stream, const float* qbase, int M, int T, int F,
                            const int32_t* q_win, const int32_t* q_t, int Q, int n_taps, int tap_stride,
-                           double* q64, double* qn2);
+                           float* q32, double* qn2);
 
 /* Cosine distance of every query against every audio candidate, float64 arithmetic
  * (the reference computes this distance in float64: data_processing.py:264, sklearn keeps f64):
@@ -82,7 +83,7 @@ int qpg_audio_pack_queries(qpg_ctx*, void* stream, const float* qbase, int M, in
  * base: [dev] f32 [N][T][F]; cn2: [dev] f64 [N][G]; D: [dev] f64 [Q][N*G], row stride ldD elements. */
 int qpg_audio_cosine_f64(qpg_ctx*, void* stream, const float* base, int N, int T, int F,
                          const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
-                         const double* q64, const double* qn2, int Q, double* D, int64_t ldD);
+                         const float* q32, const double* qn2, int Q, double* D, int64_t ldD);
 
 /* Cosine distance with scikit-learn's float32 arithmetic, bit-exact (GestureKNN.py:716 keeps f32):
  *   D[q][c] = 0.5 * einsum_sq(qn[q] - xn[j][cand_r[g]])     (NumPy einsum summation order)
@@ -130,6 +131,8 @@ int qpg_l2_table_f32(qpg_ctx*, void* stream, const float* sig, int K, int Dm, fl
  *   *_pslot [G]:       phase start frame int(k/398*240) of a grid position (GestureKNN.py:632);
  *   phase:             [dev] f32 [N][Tp][2][8] (phase shift, amplitude);
  *   seed_code/seed_phase [dev f32 8x16]: init_code_phase() draw (GestureKNN.py:462-473);
+ *   gate_tables:       [dev] i32 [2][Q][K] scratch: the two phase-gate candidates for every (step, previous
+ *                      code), tabulated in parallel before the sequential walk;
  *   out_codes [dev] i32 [M][30]; out_phase [dev] f32 [M][steps][8][16]; out_vote [dev] i32 [M][steps];
  *   out_status [dev] i32 [1]: 1 if a code absent from the DB won a rank fusion (the reference raises
  *   IndexError there, GestureKNN.py:631-632).
@@ -139,8 +142,8 @@ int qpg_match_steps(qpg_ctx*, void* stream, const int16_t* aud_rank, const int32
                     const int16_t* freq_rank, const int32_t* code, int code_ld, const int32_t* aud_cidx,
                     const int32_t* aud_pslot, int Ga, const int32_t* txt_cidx, const int32_t* txt_pslot, int Gt,
                     const float* phase, int Tp, int mode, int M, int steps, int K, int seed_code,
-                    const float* seed_phase, int32_t* out_codes, float* out_phase, int32_t* out_vote,
-                    int32_t* out_status);
+                    const float* seed_phase, int32_t* gate_tables, int32_t* out_codes, float* out_phase,
+                    int32_t* out_vote, int32_t* out_status);
 
 #ifdef __cplusplus
 }

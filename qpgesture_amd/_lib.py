@@ -33,7 +33,7 @@ _SIGS = {
     "qpg_rank_rows_f64": [P, I, I, P],
     "qpg_rank_rows_f32": [P, I, I, P],
     "qpg_l2_table_f32": [P, I, I, P],
-    "qpg_match_steps": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P],
+    "qpg_match_steps": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P],
 }
 
 

@@ -176,10 +176,10 @@ class CodeKNN:
         qbase = qbase.contiguous()
         M, T, F = qbase.shape
         ts = db.tap_stride if tap_stride is None else tap_stride
-        q64 = torch.empty((Q, NUM_AUDIO_FEAT_FRAMES * F), dtype=torch.float64, device=dev)
+        q32 = torch.empty((Q, NUM_AUDIO_FEAT_FRAMES * F), dtype=torch.float32, device=dev)
         qn2 = torch.empty((Q,), dtype=torch.float64, device=dev)
         _lib.call("qpg_audio_pack_queries", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
-                  NUM_AUDIO_FEAT_FRAMES, ts, q64, qn2)
+                  NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2)
         C = db.n_local * db.Ga
         D = torch.empty((Q, max(C, 1)), dtype=torch.float64, device=dev)
         ev = getattr(self, "kernel_events", None)       # bench.py: HIP events around the dominant kernel
@@ -187,7 +187,7 @@ class CodeKNN:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
         _lib.call("qpg_audio_cosine_f64", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
-                  NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q64, qn2, Q, D, D.stride(0))
+                  NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, D.stride(0))
         if ev is not None:
             e1.record(torch.cuda.current_stream(dev))
             ev.append((e0, e1))
@@ -305,6 +305,7 @@ class CodeKNN:
         out_phase = torch.empty((M, steps, 8, 16), dtype=torch.float32, device=dev)
         out_vote = torch.empty((M, steps), dtype=torch.int32, device=dev)
         status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        gate = torch.empty((2, M * steps, db.K), dtype=torch.int32, device=dev)
         q0 = window_offset * steps
 
         def sl(t):
@@ -312,7 +313,7 @@ class CodeKNN:
         _lib.call("qpg_match_steps", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]), sl(T["txt_idx"]),
                   db.pos_rank, db.freq_rank, db.code, db.code.shape[1], db.aud_cidx, db.aud_pslot, db.Ga,
                   db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode, M, steps, db.K, int(seed_code), sp,
-                  out_codes, out_phase, out_vote, status)
+                  gate, out_codes, out_phase, out_vote, status)
         if not sync:
             return out_codes, out_phase, out_vote, status
         codes = out_codes.cpu().numpy().astype(np.int64)

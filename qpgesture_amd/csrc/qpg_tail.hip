@@ -58,16 +58,6 @@ __device__ __forceinline__ float einsum_sq_128(const float* v, int l) {
   return lane4_sum(a, l);
 }
 
-__device__ float gate_cosine_128(float* a, float* b, int l) {
-  const float eps10 = 10.f * 1.1920928955078125e-07f;
-  float na = f_sqrt(einsum_sq_128(a, l)), nb = f_sqrt(einsum_sq_128(b, l));
-  if (na < eps10) na = 1.f;
-  if (nb < eps10) nb = 1.f;
-  // diff into `a` (each lane touches only its own elements e with (e & 3) == l)
-  for (int e = l; e < 128; e += 4) a[e] = f_sub(f_div(a[e], na), f_div(b[e], nb));
-  return f_mul(0.5f, einsum_sq_128(a, l));
-}
-
 struct ArgMin {
   double v;
   int i;
@@ -75,42 +65,84 @@ struct ArgMin {
 __device__ __forceinline__ ArgMin amin(ArgMin a, ArgMin b) {
   return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
-
-// block-wide stable argmin of val over threads (tid = code index); excluded index gets +inf.
-__device__ ArgMin block_argmin(double val, int idx, ArgMin* scratch) {
-  ArgMin m{val, idx};
+__device__ __forceinline__ ArgMin wave_argmin(ArgMin m) {
+#pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    ArgMin t{__shfl_down(m.v, o, 64), __shfl_down(m.i, o, 64)};
+    ArgMin t{__shfl_xor(m.v, o, 64), __shfl_xor(m.i, o, 64)};
     m = amin(m, t);
   }
-  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) scratch[w] = m;
-  __syncthreads();
-  ArgMin r = scratch[0];
-  for (int k = 1; k < nw; ++k) r = amin(r, scratch[k]);
-  return r;
+  return m;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Rank fusion for EVERY possible previous code, in parallel (GestureKNN.py:540-545, 553-555, 574-576).
+// The fused score of step q depends on the running state only through the previous code p, and p
+// takes K values, so the argmin over codes is tabulated for all (q, p) up front: one wave per (q, p),
+// 8 codes per lane, float64 in the reference's operation order
+//     combined[c] = (pos_rank[p][c] + freq_rank[c]*0.05) + rank[q][c],   argmin = lowest index.
+// What is stored is the winning CANDIDATE index (idx[q][argmin]), so the sequential walk needs a
+// single LDS lookup per step instead of an O(K) reduction and a dependent global load.
+// ---------------------------------------------------------------------------------------------
+#define QPG_KMAX_PER_LANE 16  // K <= 1024
+
+__global__ __launch_bounds__(256) void fuse_best_kernel(const int16_t* __restrict__ rank0,
+                                                        const int32_t* __restrict__ idx0,
+                                                        const int16_t* __restrict__ rank1,
+                                                        const int32_t* __restrict__ idx1,
+                                                        const int16_t* __restrict__ pos_rank,
+                                                        const int16_t* __restrict__ freq_rank, int Q, int K, int mode,
+                                                        int32_t* __restrict__ T0, int32_t* __restrict__ T1) {
+  const int lane = threadIdx.x & 63;
+  const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (q, p)
+  if (task >= (int64_t)Q * K) return;
+  const int q = (int)(task / K), p = (int)(task - (int64_t)q * K);
+  const int which = blockIdx.y;                                       // mode 0: 0 = audio table, 1 = text table
+  const int16_t* rk = (mode == 0 ? (which ? rank1 : rank0) : (mode == 1 ? rank0 : rank1)) + (int64_t)q * K;
+  const int32_t* ix = (mode == 0 ? (which ? idx1 : idx0) : (mode == 1 ? idx0 : idx1)) + (int64_t)q * K;
+  ArgMin m{__builtin_inf(), 0x7fffffff};
+  double vals[QPG_KMAX_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < QPG_KMAX_PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    vals[i] = __builtin_inf();
+    if (c < K) {
+      const double pos_score = (double)pos_rank[(int64_t)p * K + c] + (double)freq_rank[c] * 0.05;
+      vals[i] = pos_score + (double)rk[c];
+      m = amin(m, ArgMin{vals[i], c});
+    }
+  }
+  m = wave_argmin(m);
+  if (mode == 0) {
+    if (lane == 0) (which ? T1 : T0)[task] = ix[m.i];
+    return;
+  }
+  // single-modality modes: the two best codes go through the phase gate (GestureKNN.py:596, 613)
+  ArgMin m2{__builtin_inf(), 0x7fffffff};
+#pragma unroll
+  for (int i = 0; i < QPG_KMAX_PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    if (c < K && c != m.i) m2 = amin(m2, ArgMin{vals[i], c});
+  }
+  m2 = wave_argmin(m2);
+  if (lane == 0) {
+    T0[task] = ix[m.i];
+    T1[task] = ix[m2.i];
+  }
+}
 
 struct TailArgs {
-  const int16_t* aud_rank;   // [Q][K]
-  const int32_t* aud_idx;    // [Q][K] local candidate index j*Ga+g (idx_base already removed), -1 = absent
-  const int16_t* txt_rank;
-  const int32_t* txt_idx;
-  const int16_t* pos_rank;   // [K][K]
-  const int16_t* freq_rank;  // [K]
+  const int32_t* T0;         // [Q][K] candidate index of the first gate candidate given previous code p
+  const int32_t* T1;         // [Q][K] second gate candidate
   const int32_t* code;       // [N][code_ld]
   int code_ld;
-  const int32_t* aud_cidx;   // [Ga] code column of grid position
-  const int32_t* aud_pslot;  // [Ga] phase start frame int(k/398*240)
-  int Ga;
-  const int32_t* txt_cidx;
-  const int32_t* txt_pslot;
-  int Gt;
-  const float* phase;        // [N][Tp][2][8]  (p, a)
+  const int32_t* cidx0;      // [G0] code column of grid position (source of T0)
+  const int32_t* pslot0;     // [G0] phase start frame int(k/398*240)
+  int G0;
+  const int32_t* cidx1;
+  const int32_t* pslot1;
+  int G1;
+  const float* phase;        // [N][Tp][2][8]  (p, a): one frame = 16 contiguous floats [phase | amp]
   int Tp;
-  int mode;
   int M, steps, step_codes, codes_per_window;
   int K;
   int seed_code;
@@ -121,112 +153,115 @@ struct TailArgs {
   int32_t* out_status;       // [1] 0 ok, 1 = an absent code won a rank fusion (reference would raise IndexError)
 };
 
-__global__ __launch_bounds__(1024) void match_steps_kernel(TailArgs A) {
-  __shared__ ArgMin scratch[16];
-  __shared__ float prev[8 * 16];        // running phase block (8 frames x [8 phase | 8 amp])
-  __shared__ float head[2][8 * 16];     // candidate first-8-frame blocks
-  __shared__ float tail[2][8 * 16];     // candidate last-8-frame blocks
+// sklearn-exact einsum_sq over 128 floats in LDS by 4 cooperating lanes (see lane4_sum).
+// ---------------------------------------------------------------------------------------------
+// The sequential walk: ONE wave.  Per step: two LDS lookups (the gate candidates for the current
+// previous code), one round of global loads (their phase blocks and codes), the 128-d phase-gate
+// cosine in scikit-learn's f32 arithmetic, and the state update.  A workgroup of one wave makes
+// __syncthreads() a plain LDS fence, so the chain has no multi-wave barrier latency.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
+  extern __shared__ __attribute__((aligned(16))) int32_t tab[];   // [2][steps][K] gate candidates of this window
+  __shared__ float prev[128];          // running phase block (8 frames x [8 phase | 8 amp])
+  __shared__ float blk[2][2][128];     // [candidate][head|tail][8 x 16]
   __shared__ float va[2][128], vb[2][128];
+  __shared__ float nrm[4];
   __shared__ float score[2];
-  __shared__ int cand_code[2], cand_j[2], cand_g[2], cand_src[2];
-  __shared__ int s_prev_code, s_final, s_bad;
   __shared__ int wincodes[64];
 
-  const int tid = threadIdx.x, K = A.K;
-  if (tid < 128) prev[tid] = A.seed_phase[tid];
-  if (tid == 0) {
-    s_prev_code = A.seed_code;
-    s_bad = 0;
-  }
-  __syncthreads();
+  const int lane = threadIdx.x, K = A.K;
+  prev[lane] = A.seed_phase[lane];
+  prev[lane + 64] = A.seed_phase[lane + 64];
+  int prev_code = A.seed_code;
+  int bad = 0;
+  const float eps10 = 10.f * 1.1920928955078125e-07f;
 
   for (int w = 0; w < A.M; ++w) {
+    // this window's gate tables -> LDS (steps*K*2 i32, 16-B loads)
+    const int n4 = A.steps * K / 4;
+    for (int t = 0; t < 2; ++t) {
+      const int4* src = reinterpret_cast<const int4*>((t ? A.T1 : A.T0) + (int64_t)w * A.steps * K);
+      int4* dst = reinterpret_cast<int4*>(tab + t * A.steps * K);
+      for (int v = lane; v < n4; v += 64) dst[v] = src[v];
+    }
+    __syncthreads();
     for (int s = 0; s < A.steps; ++s) {
-      const int q = w * A.steps + s;
-      const int pc = s_prev_code;
-      // ---- rank fusion (GestureKNN.py:540-545, 553-555, 574-576), f64 in the reference's op order
-      double ca = __builtin_inf(), ct = __builtin_inf();
-      if (tid < K) {
-        const double pos_score = (double)A.pos_rank[(int64_t)pc * K + tid] + (double)A.freq_rank[tid] * 0.05;
-        if (A.mode != QPG_MODE_TXT) ca = pos_score + (double)A.aud_rank[(int64_t)q * K + tid];
-        if (A.mode != QPG_MODE_AUD) ct = pos_score + (double)A.txt_rank[(int64_t)q * K + tid];
+      const int ci0 = tab[s * K + prev_code], ci1 = tab[A.steps * K + s * K + prev_code];
+      bad |= (ci0 < 0) | (ci1 < 0);
+      const int j0 = ci0 < 0 ? 0 : ci0 / A.G0, g0 = ci0 < 0 ? 0 : ci0 - j0 * A.G0;
+      const int j1 = ci1 < 0 ? 0 : ci1 / A.G1, g1 = ci1 < 0 ? 0 : ci1 - j1 * A.G1;
+      const int ps0 = A.pslot0[g0], ps1 = A.pslot1[g1];
+      // phase blocks: rows [ps, ps+8) and [ps+24, ps+32) are 128 contiguous floats each (GestureKNN.py:632-637)
+      {
+        const float* b0 = A.phase + ((int64_t)j0 * A.Tp + ps0) * 16;
+        const float* b1 = A.phase + ((int64_t)j1 * A.Tp + ps1) * 16;
+        const float2 h0 = reinterpret_cast<const float2*>(b0)[lane], t0 = reinterpret_cast<const float2*>(b0 + 384)[lane];
+        const float2 h1 = reinterpret_cast<const float2*>(b1)[lane], t1 = reinterpret_cast<const float2*>(b1 + 384)[lane];
+        reinterpret_cast<float2*>(blk[0][0])[lane] = h0;
+        reinterpret_cast<float2*>(blk[0][1])[lane] = t0;
+        reinterpret_cast<float2*>(blk[1][0])[lane] = h1;
+        reinterpret_cast<float2*>(blk[1][1])[lane] = t1;
       }
-      int c0, c1, src0, src1;
-      if (A.mode == QPG_MODE_AUD_TXT) {
-        c0 = block_argmin(ca, tid, scratch).i;
-        c1 = block_argmin(ct, tid, scratch).i;
-        src0 = 0;
-        src1 = 1;
-      } else {
-        const double v = (A.mode == QPG_MODE_AUD) ? ca : ct;
-        c0 = block_argmin(v, tid, scratch).i;
-        c1 = block_argmin(tid == c0 ? __builtin_inf() : v, tid, scratch).i;
-        src0 = src1 = (A.mode == QPG_MODE_AUD) ? 0 : 1;
+      // the winner's 4 codes, fetched for both candidates now so the loads overlap the gate arithmetic
+      int pay = 0;
+      if (lane < 8) {
+        const int k = lane >> 2, o = lane & 3;
+        const int col = (k ? A.cidx1[g1] : A.cidx0[g0]) + o;
+        pay = A.code[(int64_t)(k ? j1 : j0) * A.code_ld + col];
       }
-      if (tid < 2) {
-        const int c = tid ? c1 : c0, src = tid ? src1 : src0;
-        const int32_t ci = src ? A.txt_idx[(int64_t)q * K + c] : A.aud_idx[(int64_t)q * K + c];
-        const int G = src ? A.Gt : A.Ga;
-        cand_code[tid] = c;
-        cand_src[tid] = src;
-        if (ci < 0) {
-          s_bad = 1;
-          cand_j[tid] = 0;
-          cand_g[tid] = 0;
-        } else {
-          cand_j[tid] = ci / G;
-          cand_g[tid] = ci - (ci / G) * G;
+      __syncthreads();
+      // gate vectors: a = [prev[-5:], head[:3]], b = [prev[-3:], head[:5]]  (GestureKNN.py:636)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = lane + 64 * h;
+          va[k][e] = (e < 80) ? prev[48 + e] : blk[k][0][e - 80];
+          vb[k][e] = (e < 48) ? prev[80 + e] : blk[k][0][e - 48];
         }
+      __syncthreads();
+      // norms: lanes 0-3 |a0|, 4-7 |b0|, 8-11 |a1|, 12-15 |b1|
+      if (lane < 16) {
+        const int l = lane & 3, grp = lane >> 2;
+        const float* v = (grp & 1) ? vb[grp >> 1] : va[grp >> 1];
+        float n = f_sqrt(einsum_sq_128(v, l));
+        if (n < eps10) n = 1.f;
+        if (l == 0) nrm[grp] = n;
       }
       __syncthreads();
-      // ---- fetch both candidates' phase blocks: rows [ps, ps+8) and [ps+24, ps+32) (GestureKNN.py:632-637)
-      if (tid < 512) {
-        const int k = tid >> 8, part = (tid >> 7) & 1, e = tid & 127;   // part 0 = head, 1 = tail
-        const int r = e >> 4, col = e & 15;                              // row, [phase 0..7 | amp 0..7]
-        const int ps = (cand_src[k] ? A.txt_pslot : A.aud_pslot)[cand_g[k]];
-        const int t = ps + (part ? 24 : 0) + r;
-        const float v = A.phase[(((int64_t)cand_j[k] * A.Tp + t) * 2 + (col >> 3)) * 8 + (col & 7)];
-        (part ? tail : head)[k][e] = v;
-      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = lane + 64 * h;
+          va[k][e] = f_sub(f_div(va[k][e], nrm[2 * k]), f_div(vb[k][e], nrm[2 * k + 1]));
+        }
       __syncthreads();
-      // ---- gate vectors: a = [prev[-5:], head[:3]], b = [prev[-3:], head[:5]]  (128 floats each)
-      if (tid < 256) {
-        const int k = tid >> 7, e = tid & 127;
-        va[k][e] = (e < 80) ? prev[48 + e] : head[k][e - 80];
-        vb[k][e] = (e < 48) ? prev[80 + e] : head[k][e - 48];
-      }
-      __syncthreads();
-      if (tid < 8) {
-        const int k = tid >> 2, l = tid & 3;
-        const float sc = gate_cosine_128(va[k], vb[k], l);
+      if (lane < 8) {
+        const int l = lane & 3, k = lane >> 2;
+        const float sc = f_mul(0.5f, einsum_sq_128(va[k], l));
         if (l == 0) score[k] = sc;
       }
       __syncthreads();
-      if (tid == 0) s_final = (score[1] < score[0]) ? 1 : 0;   // list.index(min): first on ties
+      const int fi = (score[1] < score[0]) ? 1 : 0;            // list.index(min): first on ties
+      // append the winner's 4 codes, carry its last-8-frame block (GestureKNN.py:648-657)
+      prev[lane] = blk[fi][1][lane];
+      prev[lane + 64] = blk[fi][1][lane + 64];
+      float* op = A.out_phase + ((int64_t)w * A.steps + s) * 128;
+      op[lane] = blk[fi][1][lane];
+      op[lane + 64] = blk[fi][1][lane + 64];
+      if (lane < 8 && (lane >> 2) == fi) wincodes[s * A.step_codes + (lane & 3)] = pay;
+      if (lane == 0) A.out_vote[w * A.steps + s] = fi;
       __syncthreads();
-      const int fi = s_final;
-      // ---- append the winner's 4 codes, carry its last-8-frame block (GestureKNN.py:648-657)
-      if (tid < 128) {
-        prev[tid] = tail[fi][tid];
-        A.out_phase[(((int64_t)w * A.steps + s) * 128) + tid] = tail[fi][tid];
-      }
-      if (tid < A.step_codes) {
-        const int col = (cand_src[fi] ? A.txt_cidx : A.aud_cidx)[cand_g[fi]] + tid;
-        const int cv = A.code[(int64_t)cand_j[fi] * A.code_ld + col];
-        wincodes[s * A.step_codes + tid] = cv;
-      }
-      if (tid == 0) A.out_vote[w * A.steps + s] = fi;
-      __syncthreads();
-      if (tid == 0) s_prev_code = wincodes[s * A.step_codes + A.step_codes - 1];
-      __syncthreads();
+      prev_code = wincodes[s * A.step_codes + A.step_codes - 1];
     }
     // window result = first codes_per_window codes; the next window is seeded by the LAST KEPT code
     // (motion_output[-1][-1], GestureKNN.py:800) and the last phase block.
-    if (tid < A.codes_per_window) A.out_codes[(int64_t)w * A.codes_per_window + tid] = wincodes[tid];
-    if (tid == 0) s_prev_code = wincodes[A.codes_per_window - 1];
+    if (lane < A.codes_per_window) A.out_codes[(int64_t)w * A.codes_per_window + lane] = wincodes[lane];
+    prev_code = wincodes[A.codes_per_window - 1];
     __syncthreads();
   }
-  if (tid == 0) A.out_status[0] = s_bad;
+  if (lane == 0) A.out_status[0] = bad;
 }
 
 extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
@@ -234,29 +269,39 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
                                const int16_t* freq_rank, const int32_t* code, int code_ld, const int32_t* aud_cidx,
                                const int32_t* aud_pslot, int Ga, const int32_t* txt_cidx, const int32_t* txt_pslot,
                                int Gt, const float* phase, int Tp, int mode, int M, int steps, int K, int seed_code,
-                               const float* seed_phase, int32_t* out_codes, float* out_phase, int32_t* out_vote,
-                               int32_t* out_status) {
-  QPG_REQUIRE(ctx && pos_rank && freq_rank && code && phase && seed_phase && out_codes && out_phase && out_vote &&
-                  out_status,
+                               const float* seed_phase, int32_t* gate_tables, int32_t* out_codes, float* out_phase,
+                               int32_t* out_vote, int32_t* out_status) {
+  QPG_REQUIRE(ctx && pos_rank && freq_rank && code && phase && seed_phase && gate_tables && out_codes && out_phase &&
+                  out_vote && out_status,
               "qpg_match_steps: null pointer");
   QPG_REQUIRE(mode >= 0 && mode <= 2, "qpg_match_steps: bad mode %d", mode);
   QPG_REQUIRE(mode == QPG_MODE_TXT || (aud_rank && aud_idx && aud_cidx && aud_pslot && Ga > 0),
               "qpg_match_steps: audio tables missing");
   QPG_REQUIRE(mode == QPG_MODE_AUD || (txt_rank && txt_idx && txt_cidx && txt_pslot && Gt > 0),
               "qpg_match_steps: text tables missing");
-  QPG_REQUIRE(M >= 0 && steps > 0 && steps * 4 <= 64 && K > 0 && K <= 1024 && seed_code >= 0 && seed_code < K,
+  QPG_REQUIRE(M >= 0 && steps > 0 && steps * 4 <= 64 && K > 0 && K <= 64 * QPG_KMAX_PER_LANE && (K % 4) == 0 &&
+                  seed_code >= 0 && seed_code < K,
               "qpg_match_steps: bad size");
+  const size_t lds = (size_t)2 * steps * K * sizeof(int32_t);
+  QPG_REQUIRE(lds <= 96 * 1024, "qpg_match_steps: steps*K too large for the LDS gate tables");
   if (M == 0) return QPG_OK;
+  const int Q = M * steps;
+  int32_t* T0 = gate_tables;
+  int32_t* T1 = gate_tables + (int64_t)Q * K;
+  dim3 grid((unsigned)(((int64_t)Q * K + 3) / 4), mode == QPG_MODE_AUD_TXT ? 2 : 1);
+  hipLaunchKernelGGL(fuse_best_kernel, grid, dim3(256), 0, qpg_stream(stream), aud_rank, aud_idx, txt_rank, txt_idx,
+                     pos_rank, freq_rank, Q, K, mode, T0, T1);
+  QPG_LAUNCH_CHECK("fuse_best_kernel");
   TailArgs A;
-  A.aud_rank = aud_rank; A.aud_idx = aud_idx; A.txt_rank = txt_rank; A.txt_idx = txt_idx;
-  A.pos_rank = pos_rank; A.freq_rank = freq_rank; A.code = code; A.code_ld = code_ld;
-  A.aud_cidx = aud_cidx; A.aud_pslot = aud_pslot; A.Ga = Ga; A.txt_cidx = txt_cidx; A.txt_pslot = txt_pslot; A.Gt = Gt;
-  A.phase = phase; A.Tp = Tp; A.mode = mode; A.M = M; A.steps = steps; A.step_codes = 4;
+  A.T0 = T0; A.T1 = T1; A.code = code; A.code_ld = code_ld;
+  const bool txt0 = (mode == QPG_MODE_TXT), txt1 = (mode != QPG_MODE_AUD);
+  A.cidx0 = txt0 ? txt_cidx : aud_cidx; A.pslot0 = txt0 ? txt_pslot : aud_pslot; A.G0 = txt0 ? Gt : Ga;
+  A.cidx1 = txt1 ? txt_cidx : aud_cidx; A.pslot1 = txt1 ? txt_pslot : aud_pslot; A.G1 = txt1 ? Gt : Ga;
+  A.phase = phase; A.Tp = Tp; A.M = M; A.steps = steps; A.step_codes = 4;
   A.codes_per_window = (steps * 4 < 30) ? steps * 4 : 30;
   A.K = K; A.seed_code = seed_code; A.seed_phase = seed_phase;
   A.out_codes = out_codes; A.out_phase = out_phase; A.out_vote = out_vote; A.out_status = out_status;
-  int threads = K < 512 ? 512 : ((K + 63) / 64) * 64;
-  hipLaunchKernelGGL(match_steps_kernel, dim3(1), dim3(threads), 0, qpg_stream(stream), A);
-  QPG_LAUNCH_CHECK("match_steps_kernel");
+  hipLaunchKernelGGL(match_walk_kernel, dim3(1), dim3(64), lds, qpg_stream(stream), A);
+  QPG_LAUNCH_CHECK("match_walk_kernel");
   return QPG_OK;
 }
