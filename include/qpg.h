@@ -85,12 +85,19 @@ int qpg_audio_cosine_f64(qpg_ctx*, void* stream, const float* base, int N, int T
                          const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
                          const float* q32, const double* qn2, int Q, double* D, int64_t ldD);
 
+/* One-off DB preparation for the text sweep: sklearn-normalise the grid rows x[j][cand_r[g]] (bit-exact,
+ * as qpg_l2_normalize_rows_f32) and store them tiled for lane-per-candidate access:
+ *   xt[c/64][e/4][c%64][e%4],  c = j*G + g   (a wave's 64 lanes read 64 consecutive 16-B pieces).
+ * x: [dev] f32 [N][R][Dm]; xt: [dev] f32 [ceil(N*G/64)*64 * Dm]. */
+int qpg_text_pack_candidates_f32(qpg_ctx*, void* stream, const float* x, int N, int R, int Dm,
+                                 const int32_t* cand_r, int G, float* xt);
+
 /* Cosine distance with scikit-learn's float32 arithmetic, bit-exact (GestureKNN.py:716 keeps f32):
- *   D[q][c] = 0.5 * einsum_sq(qn[q] - xn[j][cand_r[g]])     (NumPy einsum summation order)
- * xn: [dev] f32 [N][R][Dm] rows already normalised by qpg_l2_normalize_rows_f32;
- * qn: [dev] f32 [Q][Dm] normalised queries; cand_r: [dev] i32 [G]; D: [dev] f32 [Q][N*G]. */
-int qpg_text_cosine_f32(qpg_ctx*, void* stream, const float* xn, int N, int R, int Dm,
-                        const int32_t* cand_r, int G, const float* qn, int Q, float* D, int64_t ldD);
+ *   D[q][c] = 0.5 * einsum_sq(qn[q] - xn_c)     (NumPy einsum summation order)
+ * xt: tiled normalised candidates from qpg_text_pack_candidates_f32 (C = N*G of them);
+ * qn: [dev] f32 [Q][Dm] queries normalised by qpg_l2_normalize_rows_f32; D: [dev] f32 [Q][C]. */
+int qpg_text_cosine_f32(qpg_ctx*, void* stream, const float* xt, int64_t C, int Dm, const float* qn, int Q,
+                        float* D, int64_t ldD);
 
 /* Segmented min + argmin by code id, first index wins on ties (GestureKNN.py:686-689).
  * code: [dev] i32 [N][code_ld]; cand_cidx: [dev] i32 [G] column of `code` for grid position g;
@@ -102,6 +109,22 @@ int qpg_percode_argmin_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD,
 int qpg_percode_argmin_f32(qpg_ctx*, void* stream, const float* D, int64_t ldD, int Q, const int32_t* code,
                            int code_ld, int N, const int32_t* cand_cidx, int G, int K, float absent,
                            int32_t idx_base, float* out_dist, int32_t* out_idx);
+
+/* Fast path of the per-code argmin.  resolve (f64): two full-chip passes over D — per-code minimum of the
+ * order-preserving 64-bit distance key -> best_key [dev] u64 [Q][K] (out), then the lowest candidate index
+ * (+idx_base) among the entries equal to it -> best_idx [dev] u32 [Q][K] (0xffffffff = code absent).
+ * resolve (f32): distance key and index share one u64, one pass -> packed [dev] u64 [Q][K].  finalize: keys -> out_dist
+ * (`absent` where the code never occurs), out_idx (-1 absent) and, if out_rank != NULL, the stable ranks. */
+int qpg_percode_resolve_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int32_t* code,
+                            int code_ld, int N, const int32_t* cand_cidx, int G, int K, int32_t idx_base,
+                            uint64_t* best_key, uint32_t* best_idx);
+int qpg_percode_resolve_f32(qpg_ctx*, void* stream, const float* D, int64_t ldD, int Q, const int32_t* code,
+                            int code_ld, int N, const int32_t* cand_cidx, int G, int K, int32_t idx_base,
+                            uint64_t* packed);
+int qpg_percode_finalize_f64(qpg_ctx*, void* stream, const uint64_t* best_key, const uint32_t* best_idx, int Q,
+                             int K, double absent, double* out_dist, int32_t* out_idx, int16_t* out_rank);
+int qpg_percode_finalize_f32(qpg_ctx*, void* stream, const uint64_t* packed, int Q, int K, float absent,
+                             float* out_dist, int32_t* out_idx, int16_t* out_rank);
 
 /* Stable ranks of each row: rank[q][c] = #{c' : d[c'] < d[c] or (d[c'] == d[c] and c' < c)}
  * (== np.argsort(kind='stable').argsort(); the reference calls the unstable default,

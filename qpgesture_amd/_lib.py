@@ -27,7 +27,12 @@ _SIGS = {
     "qpg_l2_normalize_rows_f32": [P, L, I, P],
     "qpg_audio_pack_queries": [P, I, I, I, P, P, I, I, I, P, P],
     "qpg_audio_cosine_f64": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
-    "qpg_text_cosine_f32": [P, I, I, I, P, I, P, I, P, L],
+    "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
+    "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
+    "qpg_percode_resolve_f32": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P],
+    "qpg_percode_resolve_f64": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P, P],
+    "qpg_percode_finalize_f64": [P, P, I, I, c_double, P, P, P],
+    "qpg_percode_finalize_f32": [P, I, I, c_float, P, P, P],
     "qpg_percode_argmin_f64": [P, L, I, P, I, I, P, I, I, c_double, ctypes.c_int32, P, P],
     "qpg_percode_argmin_f32": [P, L, I, P, I, I, P, I, I, c_float, ctypes.c_int32, P, P],
     "qpg_rank_rows_f64": [P, I, I, P],

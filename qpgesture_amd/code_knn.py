@@ -56,7 +56,7 @@ class GestureDB:
     Layout:
       base   f32 [n_local][180][F]   interpolated WavLM frames of this rank's row shard
       cn2    f64 [n_local][26]       squared norm of each audio candidate (6 frames)
-      ctxn   f32 [n_local][30][384]  text context rows, sklearn-normalised
+      ctxt   f32 [C/64][96][64][4]   text candidates (26 grid rows per window), sklearn-normalised, tiled
       code   i32 [N][30]             replicated (payloads of winners are looked up from it)
       phase  f32 [N][240][2][8]      replicated (phase shift, amplitude)
       pos_rank i16 [512][512], freq_rank i16 [512]
@@ -110,9 +110,13 @@ class GestureDB:
         ctx = np.ascontiguousarray(context[self.lo:self.hi], np.float32)
         self.R, self.Dt = context.shape[1], context.shape[2]
         ctx_d = torch.from_numpy(ctx).to(dev)
-        self.ctxn = torch.empty_like(ctx_d)
+        self.Ct = self.n_local * self.Gt
+        # normalised grid rows, tiled [C/64][Dt/4][64][4] for lane-per-candidate access
+        self.ctxt = torch.zeros((((self.Ct + 63) // 64) * 64 * self.Dt,), dtype=torch.float32, device=dev)
         if self.n_local:
-            _lib.call("qpg_l2_normalize_rows_f32", dev, ctx_d, self.n_local * self.R, self.Dt, self.ctxn)
+            _lib.call("qpg_text_pack_candidates_f32", dev, ctx_d, self.n_local, self.R, self.Dt, self.txt_r,
+                      self.Gt, self.ctxt)
+        del ctx_d
 
         ph = np.ascontiguousarray(np.asarray(phase_dense, np.float32)[:, :, [0, 2], :])
         self.Tp = ph.shape[1]
@@ -168,9 +172,10 @@ class CodeKNN:
         return code, np.concatenate((P[:, 0], P[:, 1]), axis=1).astype(np.float32)
 
     # -- batched sweeps ------------------------------------------------------------------------
-    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None):
+    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None, want_rank=False):
         """Per-code best audio candidate for every query: returns (dist f64 [Q,512], idx i32 [Q,512])
-        with global candidate indices j*26+g (-1 = code absent); min-reduced across ranks."""
+        with global candidate indices j*26+g (-1 = code absent), min-reduced across ranks; with
+        want_rank also the stable ranks i16 [Q,512]."""
         db, dev = self.db, self.db.device
         Q = len(q_win)
         qbase = qbase.contiguous()
@@ -182,6 +187,8 @@ class CodeKNN:
                   NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2)
         C = db.n_local * db.Ga
         D = torch.empty((Q, max(C, 1)), dtype=torch.float64, device=dev)
+        key = torch.empty((Q, db.K), dtype=torch.int64, device=dev)      # u64 ordered-distance keys
+        bidx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)     # u32 candidate indices
         ev = getattr(self, "kernel_events", None)       # bench.py: HIP events around the dominant kernel
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -191,29 +198,73 @@ class CodeKNN:
         if ev is not None:
             e1.record(torch.cuda.current_stream(dev))
             ev.append((e0, e1))
+        _lib.call("qpg_percode_resolve_f64", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
+                  db.aud_cidx, db.Ga, db.K, db.idx_base * db.Ga, key, bidx)
         dist = torch.empty((Q, db.K), dtype=torch.float64, device=dev)
         idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
-        _lib.call("qpg_percode_argmin_f64", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
-                  db.aud_cidx, db.Ga, db.K, float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx)
+        fused_rank = want_rank and db.world == 1
+        rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
+        _lib.call("qpg_percode_finalize_f64", dev, key, bidx, Q, db.K, float(ABSENT_DIST), dist, idx, rank)
         self._last_D_aud = D
-        return self._reduce_min(dist, idx)
+        dist, idx = self._reduce_min(dist, idx)
+        if want_rank:
+            return dist, idx, (rank if fused_rank else self.rank_rows(dist))
+        return dist, idx
 
-    def sweep_text(self, queries):
-        """queries: f32 [Q,384] on the device.  Returns (dist f32 [Q,512], idx i32 [Q,512])."""
+    def sweep_text(self, queries, want_rank=False):
+        """queries: f32 [Q,384] on the device.  Returns (dist f32 [Q,512], idx i32 [Q,512][, rank])."""
         db, dev = self.db, self.db.device
         Q = queries.shape[0]
         qn = torch.empty_like(queries)
         _lib.call("qpg_l2_normalize_rows_f32", dev, queries, Q, db.Dt, qn)
-        C = db.n_local * db.Gt
-        D = torch.empty((Q, max(C, 1)), dtype=torch.float32, device=dev)
-        _lib.call("qpg_text_cosine_f32", dev, db.ctxn, db.n_local, db.R, db.Dt, db.txt_r, db.Gt, qn, Q, D,
-                  D.stride(0))
+        D = torch.empty((Q, max(db.Ct, 1)), dtype=torch.float32, device=dev)
+        _lib.call("qpg_text_cosine_f32", dev, db.ctxt, db.Ct, db.Dt, qn, Q, D, D.stride(0))
+        packed = torch.empty((Q, db.K), dtype=torch.int64, device=dev)   # u64 (ordered dist << 32 | index)
+        _lib.call("qpg_percode_resolve_f32", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
+                  db.txt_cidx, db.Gt, db.K, db.idx_base * db.Gt, packed)
+        self._last_D_txt = D
+        dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
+        idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+        fused_rank = want_rank and db.world == 1
+        rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
+        _lib.call("qpg_percode_finalize_f32", dev, packed, Q, db.K, float(ABSENT_DIST), dist, idx, rank)
+        dist, idx = self._reduce_min(dist, idx)
+        if want_rank:
+            return dist, idx, (rank if fused_rank else self.rank_rows(dist))
+        return dist, idx
+
+    def sweep_audio_unfused(self, qbase, q_win, q_t):
+        """Same result through the stand-alone entry points (distance matrix, then qpg_percode_argmin_f64);
+        kept for the parity tests of those entry points."""
+        db, dev = self.db, self.db.device
+        Q = len(q_win)
+        qbase = qbase.contiguous()
+        M, T, F = qbase.shape
+        q32 = torch.empty((Q, NUM_AUDIO_FEAT_FRAMES * F), dtype=torch.float32, device=dev)
+        qn2 = torch.empty((Q,), dtype=torch.float64, device=dev)
+        _lib.call("qpg_audio_pack_queries", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
+                  NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2)
+        D = torch.empty((Q, max(db.n_local * db.Ga, 1)), dtype=torch.float64, device=dev)
+        _lib.call("qpg_audio_cosine_f64", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
+                  NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, D.stride(0))
+        dist = torch.empty((Q, db.K), dtype=torch.float64, device=dev)
+        idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+        _lib.call("qpg_percode_argmin_f64", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
+                  db.aud_cidx, db.Ga, db.K, float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx)
+        return dist, idx, D
+
+    def sweep_text_unfused(self, queries):
+        db, dev = self.db, self.db.device
+        Q = queries.shape[0]
+        qn = torch.empty_like(queries)
+        _lib.call("qpg_l2_normalize_rows_f32", dev, queries, Q, db.Dt, qn)
+        D = torch.empty((Q, max(db.Ct, 1)), dtype=torch.float32, device=dev)
+        _lib.call("qpg_text_cosine_f32", dev, db.ctxt, db.Ct, db.Dt, qn, Q, D, D.stride(0))
         dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
         idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
         _lib.call("qpg_percode_argmin_f32", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
                   db.txt_cidx, db.Gt, db.K, float(ABSENT_DIST), db.idx_base * db.Gt, dist, idx)
-        self._last_D_txt = D
-        return self._reduce_min(dist, idx)
+        return dist, idx, D
 
     def _reduce_min(self, dist, idx):
         """Cross-shard min + index: all-reduce(MIN) on the distances, then
@@ -278,8 +329,7 @@ class CodeKNN:
         q_t = np.tile(np.arange(steps) * STEP_SZ * self.step_sz, M)
         T = dict(aud_d=None, aud_idx=None, aud_rank=None, txt_d=None, txt_idx=None, txt_rank=None)
         if mode in (MODE_AUD_TXT, MODE_AUD):
-            T["aud_d"], T["aud_idx"] = self.sweep_audio(test_interp, q_win, q_t)
-            T["aud_rank"] = self.rank_rows(T["aud_d"])
+            T["aud_d"], T["aud_idx"], T["aud_rank"] = self.sweep_audio(test_interp, q_win, q_t, want_rank=True)
         if mode in (MODE_AUD_TXT, MODE_TXT):
             rows = [int(i / db.T * 30) for i in q_t]                           # GestureKNN.py:549
             key = (M, steps)
@@ -287,8 +337,7 @@ class CodeKNN:
                 self._txt_gather = (torch.as_tensor(q_win, device=dev), torch.as_tensor(rows, device=dev))
                 self._txt_gather_key = key
             qtxt = test_context[self._txt_gather[0], self._txt_gather[1]].contiguous()
-            T["txt_d"], T["txt_idx"] = self.sweep_text(qtxt)
-            T["txt_rank"] = self.rank_rows(T["txt_d"])
+            T["txt_d"], T["txt_idx"], T["txt_rank"] = self.sweep_text(qtxt, want_rank=True)
         return T
 
     def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True):

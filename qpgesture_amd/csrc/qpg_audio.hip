@@ -209,7 +209,10 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
     for (int k = 1; k < KS; ++k) dot += red[k][t][r][l];
     const int q = q0 + ql;
     const int64_t cc = c0 + cr;
-    if (q < Q && cc < C) D[(int64_t)q * ldD + cc] = cosine_from_dot(dot, qn2[q], cn2[cc]);
+    if (q < Q && cc < C) {
+      const double d = cosine_from_dot(dot, qn2[q], cn2[cc]);
+      D[(int64_t)q * ldD + cc] = d;
+    }
   }
 }
 
@@ -241,9 +244,11 @@ extern "C" int qpg_audio_cosine_f64(qpg_ctx* ctx, void* stream, const float* bas
   const int qt = (Q + 15) / 16;  // 16-query tiles
   // widest query tile that divides the work without an empty tail: prefer 3 (a 24 s clip is 48 queries)
 #define QPG_AUDIO_ARGS ctx, stream, base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q
-  if (qt % 3 == 0) return launch_audio<2, 3>(QPG_AUDIO_ARGS, qt / 3, D, ldD);
-  if (qt % 4 == 0) return launch_audio<2, 4>(QPG_AUDIO_ARGS, qt / 4, D, ldD);
-  if (qt % 2 == 0) return launch_audio<2, 2>(QPG_AUDIO_ARGS, qt / 2, D, ldD);
-  return launch_audio<2, 1>(QPG_AUDIO_ARGS, qt, D, ldD);
+#define QPG_AUDIO_TAIL D, ldD
+  if (qt % 3 == 0) return launch_audio<2, 3>(QPG_AUDIO_ARGS, qt / 3, QPG_AUDIO_TAIL);
+  if (qt % 4 == 0) return launch_audio<2, 4>(QPG_AUDIO_ARGS, qt / 4, QPG_AUDIO_TAIL);
+  if (qt % 2 == 0) return launch_audio<2, 2>(QPG_AUDIO_ARGS, qt / 2, QPG_AUDIO_TAIL);
+  return launch_audio<2, 1>(QPG_AUDIO_ARGS, qt, QPG_AUDIO_TAIL);
+#undef QPG_AUDIO_TAIL
 #undef QPG_AUDIO_ARGS
 }

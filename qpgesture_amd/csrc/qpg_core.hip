@@ -104,49 +104,49 @@ extern "C" int qpg_audio_cand_norm2(qpg_ctx* ctx, void* stream, const double* fn
 }
 
 // ---------------------------------------------------------------------------------------------
-// scikit-learn-exact float32 row normalisation.  One thread per row, four sequential lane
-// accumulators in NumPy-einsum order (16-element groups visited as u = 3,2,1,0; lane = e & 3),
-// tail in 4-wide zero-filled steps, horizontal (l0+l1)+(l2+l3).  See oracle/knn_oracle.py.
+// scikit-learn-exact float32 row normalisation.  NumPy's einsum keeps 4 lane accumulators
+// (lane = e & 3), visits 16-element groups as u = 3,2,1,0, finishes the tail in 4-wide zero-filled
+// steps and combines (l0+l1)+(l2+l3) — see oracle/knn_oracle.py.  The four lane chains are
+// independent, so a row is handled by 4 adjacent threads (one per einsum lane) and the horizontal
+// sum is two shuffles; every thread then divides its quarter of the row.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float einsum_sq_row(const float* __restrict__ p, int D) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int nfull = D >> 4;
+__global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __restrict__ x, int64_t rows, int D,
+                                                                float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t r = t >> 2;
+  const int l = (int)(t & 3);
+  const bool live = r < rows;
+  if (!live) r = rows - 1;          // keep the whole aligned group of 4 in the shuffles
+  const float* p = x + r * D;
+  float a = 0.f;
+  const int nfull = D >> 4;
   for (int g = 0; g < nfull; ++g) {
 #pragma unroll
     for (int u = 3; u >= 0; --u) {
-      const float* q = p + g * 16 + u * 4;
-      a0 = f_add(f_mul(q[0], q[0]), a0);
-      a1 = f_add(f_mul(q[1], q[1]), a1);
-      a2 = f_add(f_mul(q[2], q[2]), a2);
-      a3 = f_add(f_mul(q[3], q[3]), a3);
+      const float v = p[g * 16 + u * 4 + l];
+      a = f_add(f_mul(v, v), a);
     }
   }
   for (int i = nfull * 16; i < D; i += 4) {
-    float x0 = p[i], x1 = (i + 1 < D) ? p[i + 1] : 0.f, x2 = (i + 2 < D) ? p[i + 2] : 0.f,
-          x3 = (i + 3 < D) ? p[i + 3] : 0.f;
-    a0 = f_add(f_mul(x0, x0), a0);
-    a1 = f_add(f_mul(x1, x1), a1);
-    a2 = f_add(f_mul(x2, x2), a2);
-    a3 = f_add(f_mul(x3, x3), a3);
+    const float v = (i + l < D) ? p[i + l] : 0.f;
+    a = f_add(f_mul(v, v), a);
   }
-  return f_add(f_add(a0, a1), f_add(a2, a3));
-}
-
-__global__ void l2_normalize_rows_kernel(const float* __restrict__ x, int64_t rows, int D, float* __restrict__ out) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  const float* p = x + r * D;
-  float n = f_sqrt(einsum_sq_row(p, D));
-  if (n < 10.f * 1.1920928955078125e-07f) n = 1.f;  // sklearn _handle_zeros_in_scale
-  float* o = out + r * D;
-  for (int e = 0; e < D; ++e) o[e] = f_div(p[e], n);
+  const float o1 = __shfl_xor(a, 1, 64);
+  const float pair = f_add(a, o1);                    // (l0+l1) on lanes 0,1 ; (l2+l3) on lanes 2,3
+  const float o2 = __shfl_xor(pair, 2, 64);
+  float n = f_sqrt(f_add(pair, o2));                  // IEEE add is commutative: (l0+l1)+(l2+l3) on all 4
+  if (n < 10.f * 1.1920928955078125e-07f) n = 1.f;    // sklearn _handle_zeros_in_scale
+  if (live) {
+    float* o = out + r * D;
+    for (int e = l; e < D; e += 4) o[e] = f_div(p[e], n);
+  }
 }
 
 extern "C" int qpg_l2_normalize_rows_f32(qpg_ctx* ctx, void* stream, const float* x, int64_t rows, int D, float* out) {
   QPG_REQUIRE(ctx && x && out && rows >= 0 && D > 0, "qpg_l2_normalize_rows_f32: bad argument");
   if (rows == 0) return QPG_OK;
-  hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, qpg_stream(stream), x,
-                     rows, D, out);
+  hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0,
+                     qpg_stream(stream), x, rows, D, out);
   QPG_LAUNCH_CHECK("l2_normalize_rows_kernel");
   return QPG_OK;
 }

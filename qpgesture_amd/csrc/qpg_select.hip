@@ -97,6 +97,204 @@ extern "C" int qpg_percode_argmin_f32(qpg_ctx* ctx, void* stream, const float* D
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused-table protocol (the fast path; qpg_percode_argmin_* above is the stand-alone form).
+//   text  (f32): ordered distance (32 bit) and candidate index (32 bit) share one u64, so one pass of
+//                qpg_percode_resolve_f32 over D with atomicMin gives min distance + lowest index.
+//   audio (f64): distance + index do not fit one atomic word, so qpg_percode_resolve_f64 streams the
+//                distance matrix D (L2/MALL-resident, Q*C*8 B) twice with the whole chip: pass 1 takes the
+//                per-code minimum of the ordered 64-bit keys (LDS ds_min_u64 per block, then one global
+//                atomic per touched code), pass 2 the lowest candidate index among the entries equal to
+//                that minimum (== the reference's first-wins scan).  Folding pass 1 into the sweep's
+//                epilogue was measured slower (+70 us: 2.5 M uncached table probes at the end of every block).
+//   finalize:    keys -> distances (`absent` where the code never occurs), indices, and — when the
+//                table is final, i.e. single rank — the stable ranks of the row.
+// ---------------------------------------------------------------------------------------------
+#define RS_CHUNK 4096   // candidates per block in the two resolve passes
+
+__global__ __launch_bounds__(256) void percode_min_f64_kernel(const double* __restrict__ D, int64_t ldD,
+                                                              const int32_t* __restrict__ code, int code_ld, int N,
+                                                              const int32_t* __restrict__ cand_cidx, int G, int K,
+                                                              unsigned long long* __restrict__ best_key) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
+  const int q = blockIdx.y;
+  const int64_t C = (int64_t)N * G;
+  const double* row = D + (int64_t)q * ldD;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) best[k] = ~0ull;
+  __syncthreads();
+  const int64_t cb = (int64_t)blockIdx.x * RS_CHUNK;
+  const int64_t ce = cb + RS_CHUNK < C ? cb + RS_CHUNK : C;
+  for (int64_t c = cb + threadIdx.x; c < ce; c += blockDim.x) {
+    const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
+    const int cd = code[(int64_t)j * code_ld + cand_cidx[g]];
+    if ((unsigned)cd < (unsigned)K) atomicMin(&best[cd], order_key(row[c]));
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x)
+    if (best[k] != ~0ull) atomicMin(&best_key[(int64_t)q * K + k], best[k]);
+}
+
+__global__ __launch_bounds__(256) void percode_resolve_f64_kernel(const double* __restrict__ D, int64_t ldD,
+                                                                  const int32_t* __restrict__ code, int code_ld, int N,
+                                                                  const int32_t* __restrict__ cand_cidx, int G, int K,
+                                                                  int32_t idx_base,
+                                                                  const unsigned long long* __restrict__ best_key,
+                                                                  unsigned int* __restrict__ best_idx) {
+  const int q = blockIdx.y;
+  const int64_t C = (int64_t)N * G;
+  const double* row = D + (int64_t)q * ldD;
+  const int64_t cb = (int64_t)blockIdx.x * RS_CHUNK;
+  const int64_t ce = cb + RS_CHUNK < C ? cb + RS_CHUNK : C;
+  for (int64_t c = cb + threadIdx.x; c < ce; c += blockDim.x) {
+    const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
+    const int cd = code[(int64_t)j * code_ld + cand_cidx[g]];
+    if ((unsigned)cd < (unsigned)K && order_key(row[c]) == best_key[(int64_t)q * K + cd])
+      atomicMin(&best_idx[(int64_t)q * K + cd], (unsigned int)(c + idx_base));
+  }
+}
+
+extern "C" int qpg_percode_resolve_f64(qpg_ctx* ctx, void* stream, const double* D, int64_t ldD, int Q,
+                                       const int32_t* code, int code_ld, int N, const int32_t* cand_cidx, int G,
+                                       int K, int32_t idx_base, uint64_t* best_key, uint32_t* best_idx) {
+  QPG_REQUIRE(ctx && D && code && cand_cidx && best_key && best_idx, "qpg_percode_resolve_f64: null pointer");
+  QPG_REQUIRE(Q >= 0 && N >= 0 && G > 0 && K > 0 && K <= 4096 && code_ld > 0 && ldD >= (int64_t)N * G,
+              "qpg_percode_resolve_f64: bad size");
+  if (Q == 0) return QPG_OK;
+  hipStream_t st = qpg_stream(stream);
+  if (hipMemsetAsync(best_key, 0xFF, sizeof(uint64_t) * (size_t)Q * K, st) != hipSuccess ||
+      hipMemsetAsync(best_idx, 0xFF, sizeof(uint32_t) * (size_t)Q * K, st) != hipSuccess) {
+    qpg_set_error("qpg_percode_resolve_f64: hipMemsetAsync failed");
+    return QPG_EHIP;
+  }
+  if (N == 0) return QPG_OK;
+  const int64_t C = (int64_t)N * G;
+  const unsigned bx = (unsigned)((C + RS_CHUNK - 1) / RS_CHUNK);
+  unsigned long long* bk = reinterpret_cast<unsigned long long*>(best_key);
+  hipLaunchKernelGGL(percode_min_f64_kernel, dim3(bx, Q), dim3(256), sizeof(unsigned long long) * (size_t)K, st, D, ldD,
+                     code, code_ld, N, cand_cidx, G, K, bk);
+  QPG_LAUNCH_CHECK("percode_min_f64_kernel");
+  hipLaunchKernelGGL(percode_resolve_f64_kernel, dim3(bx, Q), dim3(256), 0, st, D, ldD, code, code_ld, N, cand_cidx, G,
+                     K, idx_base, bk, best_idx);
+  QPG_LAUNCH_CHECK("percode_resolve_f64_kernel");
+  return QPG_OK;
+}
+
+// f32: distance key (32 bit) and candidate index (32 bit) share one u64, so a single pass suffices.
+__global__ __launch_bounds__(256) void percode_min_packed_f32_kernel(const float* __restrict__ D, int64_t ldD,
+                                                                     const int32_t* __restrict__ code, int code_ld,
+                                                                     int N, const int32_t* __restrict__ cand_cidx,
+                                                                     int G, int K, int32_t idx_base,
+                                                                     unsigned long long* __restrict__ packed) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
+  const int q = blockIdx.y;
+  const int64_t C = (int64_t)N * G;
+  const float* row = D + (int64_t)q * ldD;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) best[k] = ~0ull;
+  __syncthreads();
+  const int64_t cb = (int64_t)blockIdx.x * RS_CHUNK;
+  const int64_t ce = cb + RS_CHUNK < C ? cb + RS_CHUNK : C;
+  for (int64_t c = cb + threadIdx.x; c < ce; c += blockDim.x) {
+    const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
+    const int cd = code[(int64_t)j * code_ld + cand_cidx[g]];
+    if ((unsigned)cd < (unsigned)K)
+      atomicMin(&best[cd], ((unsigned long long)order_key(row[c]) << 32) | (unsigned int)(c + idx_base));
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x)
+    if (best[k] != ~0ull) atomicMin(&packed[(int64_t)q * K + k], best[k]);
+}
+
+extern "C" int qpg_percode_resolve_f32(qpg_ctx* ctx, void* stream, const float* D, int64_t ldD, int Q,
+                                       const int32_t* code, int code_ld, int N, const int32_t* cand_cidx, int G,
+                                       int K, int32_t idx_base, uint64_t* packed) {
+  QPG_REQUIRE(ctx && D && code && cand_cidx && packed, "qpg_percode_resolve_f32: null pointer");
+  QPG_REQUIRE(Q >= 0 && N >= 0 && G > 0 && K > 0 && K <= 4096 && code_ld > 0 && ldD >= (int64_t)N * G,
+              "qpg_percode_resolve_f32: bad size");
+  if (Q == 0) return QPG_OK;
+  hipStream_t st = qpg_stream(stream);
+  if (hipMemsetAsync(packed, 0xFF, sizeof(uint64_t) * (size_t)Q * K, st) != hipSuccess) {
+    qpg_set_error("qpg_percode_resolve_f32: hipMemsetAsync failed");
+    return QPG_EHIP;
+  }
+  if (N == 0) return QPG_OK;
+  const int64_t C = (int64_t)N * G;
+  const unsigned bx = (unsigned)((C + RS_CHUNK - 1) / RS_CHUNK);
+  hipLaunchKernelGGL(percode_min_packed_f32_kernel, dim3(bx, Q), dim3(256), sizeof(unsigned long long) * (size_t)K, st,
+                     D, ldD, code, code_ld, N, cand_cidx, G, K, idx_base, reinterpret_cast<unsigned long long*>(packed));
+  QPG_LAUNCH_CHECK("percode_min_packed_f32_kernel");
+  return QPG_OK;
+}
+
+template <typename T, typename KeyT, bool PACKED>
+__global__ __launch_bounds__(1024) void percode_finalize_kernel(const unsigned long long* __restrict__ keys,
+                                                                const unsigned int* __restrict__ idxs, int K, T absent,
+                                                                T* __restrict__ out_dist, int32_t* __restrict__ out_idx,
+                                                                int16_t* __restrict__ out_rank) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* v = reinterpret_cast<T*>(smem);
+  const int q = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const unsigned long long kv = keys[(int64_t)q * K + k];
+    T d;
+    int32_t ix;
+    if (PACKED) {
+      const bool have = kv != ~0ull;
+      d = have ? key_value((KeyT)(kv >> 32), T(0)) : absent;
+      ix = have ? (int32_t)(kv & 0xffffffffu) : -1;
+    } else {
+      const unsigned int iv = idxs[(int64_t)q * K + k];
+      const bool have = iv != 0xffffffffu;
+      d = have ? key_value((KeyT)kv, T(0)) : absent;
+      ix = have ? (int32_t)iv : -1;
+    }
+    v[k] = d;
+    out_dist[(int64_t)q * K + k] = d;
+    out_idx[(int64_t)q * K + k] = ix;
+  }
+  if (!out_rank) return;
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const T x = v[k];
+    int r = 0;
+    for (int o = 0; o < K; ++o) {
+      const T y = v[o];
+      r += (y < x) || (y == x && o < k);
+    }
+    out_rank[(int64_t)q * K + k] = (int16_t)r;
+  }
+}
+
+extern "C" int qpg_percode_finalize_f64(qpg_ctx* ctx, void* stream, const uint64_t* best_key, const uint32_t* best_idx,
+                                        int Q, int K, double absent, double* out_dist, int32_t* out_idx,
+                                        int16_t* out_rank) {
+  QPG_REQUIRE(ctx && best_key && best_idx && out_dist && out_idx && Q >= 0 && K > 0 && K <= 8192,
+              "qpg_percode_finalize_f64: bad argument");
+  if (Q == 0) return QPG_OK;
+  int threads = K >= 1024 ? 1024 : ((K + 63) / 64) * 64;
+  hipLaunchKernelGGL((percode_finalize_kernel<double, unsigned long long, false>), dim3(Q), dim3(threads),
+                     sizeof(double) * (size_t)K, qpg_stream(stream),
+                     reinterpret_cast<const unsigned long long*>(best_key), best_idx, K, absent, out_dist, out_idx,
+                     out_rank);
+  QPG_LAUNCH_CHECK("percode_finalize_kernel<f64>");
+  return QPG_OK;
+}
+
+extern "C" int qpg_percode_finalize_f32(qpg_ctx* ctx, void* stream, const uint64_t* packed, int Q, int K, float absent,
+                                        float* out_dist, int32_t* out_idx, int16_t* out_rank) {
+  QPG_REQUIRE(ctx && packed && out_dist && out_idx && Q >= 0 && K > 0 && K <= 8192,
+              "qpg_percode_finalize_f32: bad argument");
+  if (Q == 0) return QPG_OK;
+  int threads = K >= 1024 ? 1024 : ((K + 63) / 64) * 64;
+  hipLaunchKernelGGL((percode_finalize_kernel<float, unsigned int, true>), dim3(Q), dim3(threads),
+                     sizeof(float) * (size_t)K, qpg_stream(stream),
+                     reinterpret_cast<const unsigned long long*>(packed), nullptr, K, absent, out_dist, out_idx,
+                     out_rank);
+  QPG_LAUNCH_CHECK("percode_finalize_kernel<f32>");
+  return QPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void rank_rows_kernel(const T* __restrict__ d, int K, int16_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -7,104 +7,157 @@
 // reference's indices — not merely close distances — this kernel reproduces that arithmetic:
 //     d = 0.5 * sum_e (qn[e] - xn[e])^2        with NumPy-einsum summation order
 // (4 lane accumulators, separate multiply and add, 16-element groups visited u = 3,2,1,0,
-// horizontal (l0+l1)+(l2+l3)); xn / qn are rows normalised by qpg_l2_normalize_rows_f32.
-// The order is fixed per (query, candidate) pair, so the parallelism is across pairs:
-//   block = 256 threads = 64 candidates x 4 query groups; each thread owns one candidate row and
-//   QB queries, 4 lane-accumulators each; the candidate tile and the query tile are staged in
-//   LDS in 64-element chunks (b128 reads, row stride 68 floats = conflict-free for ds_read_b128).
-// VALU-bound by construction (3 dependent-rounding ops per element pair, no FMA allowed).
+// horizontal (l0+l1)+(l2+l3)); xn / qn are sklearn-normalised rows.
+//
+// The summation order is fixed per (query, candidate) pair, so the parallelism is across pairs:
+// lane = candidate, QB queries per lane, 4 accumulators each.  Data layout is chosen for that:
+//   * candidates are stored pre-normalised and TILED by qpg_text_pack_candidates_f32 as
+//     xt[tile][Dm/4][64][4]: the 64 lanes of a wave read 64 consecutive 16-B pieces (1 KiB, fully
+//     coalesced), straight into registers — no LDS, no barriers, loads pipelined by the unrolled loop;
+//   * the QB query rows of a wave are the same for all lanes and arrive through scalar loads (SGPRs).
+// VALU-bound by construction: 3 separately rounded ops per element pair, FMA contraction forbidden.
+// (r01 history: LDS-staged tiles with per-chunk barriers ran 196-224 us at N_db=2048, latency-bound.)
 #include "qpg_common.h"
 
-#define TX_CH 64       // elements per LDS chunk (4 einsum groups of 16)
-#define TX_LD 68       // padded row stride in floats (16 B aligned, conflict-free b128)
-
-template <int QB>
-__global__ __launch_bounds__(256) void text_cosine_f32_kernel(const float* __restrict__ xn, int N, int R, int Dm,
-                                                              const int32_t* __restrict__ cand_r, int G,
-                                                              const float* __restrict__ qn, int Q,
-                                                              float* __restrict__ D, int64_t ldD) {
-  __shared__ __attribute__((aligned(16))) float xs[64 * TX_LD];
-  __shared__ __attribute__((aligned(16))) float qs[4 * QB * TX_CH];
-
+// ---------------------------------------------------------------------------------------------
+// DB preparation: normalise the grid rows of the context array (sklearn-exact, 4 threads per row as
+// in l2_normalize_rows_kernel) and write them in the tiled layout.  Candidate c = j*G + g.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_pack_candidates_kernel(const float* __restrict__ x, int N, int R, int Dm,
+                                                                   const int32_t* __restrict__ cand_r, int G,
+                                                                   float* __restrict__ xt) {
   const int64_t C = (int64_t)N * G;
-  const int lc = threadIdx.x & 63, qg = threadIdx.x >> 6;
-  const int64_t c0 = (int64_t)blockIdx.x * 64;
-  const int q0 = blockIdx.y * (4 * QB);
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t c = t >> 2;
+  const int l = (int)(t & 3);
+  const bool live = c < C;
+  if (!live) c = C - 1;
+  const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
+  const float* p = x + ((int64_t)j * R + cand_r[g]) * Dm;
+  float a = 0.f;
+  for (int k = 0; k < (Dm >> 4); ++k) {
+#pragma unroll
+    for (int u = 3; u >= 0; --u) {
+      const float v = p[k * 16 + u * 4 + l];
+      a = f_add(f_mul(v, v), a);
+    }
+  }
+  const float o1 = __shfl_xor(a, 1, 64);
+  const float pair = f_add(a, o1);
+  const float o2 = __shfl_xor(pair, 2, 64);
+  float n = f_sqrt(f_add(pair, o2));
+  if (n < 10.f * 1.1920928955078125e-07f) n = 1.f;
+  if (live) {
+    const int64_t tile = c >> 6;
+    const int lane = (int)(c & 63);
+    float* o = xt + tile * (int64_t)Dm * 64;
+    for (int e = l; e < Dm; e += 4) o[((int64_t)(e >> 2) * 64 + lane) * 4 + (e & 3)] = f_div(p[e], n);
+  }
+}
+
+extern "C" int qpg_text_pack_candidates_f32(qpg_ctx* ctx, void* stream, const float* x, int N, int R, int Dm,
+                                            const int32_t* cand_r, int G, float* xt) {
+  QPG_REQUIRE(ctx && x && cand_r && xt && N >= 0 && R > 0 && G > 0, "qpg_text_pack_candidates_f32: bad argument");
+  if (Dm <= 0 || (Dm % 16) != 0) {
+    qpg_set_error("qpg_text_pack_candidates_f32: compiled for Dm %% 16 == 0 (got %d)", Dm);
+    return QPG_EUNSUP;
+  }
+  const int64_t C = (int64_t)N * G;
+  if (C == 0) return QPG_OK;
+  hipLaunchKernelGGL(text_pack_candidates_kernel, dim3((unsigned)((C * 4 + 255) / 256)), dim3(256), 0,
+                     qpg_stream(stream), x, N, R, Dm, cand_r, G, xt);
+  QPG_LAUNCH_CHECK("text_pack_candidates_kernel");
+  return QPG_OK;
+}
+
+// QB queries per lane, NG waves per block (all on the same 64-candidate tile, different query groups).
+template <int QB, int NG>
+__global__ __launch_bounds__(64 * NG) void text_cosine_f32_kernel(const float* __restrict__ xt, int64_t C, int Dm,
+                                                                  const float* __restrict__ qn, int Q,
+                                                                  float* __restrict__ D, int64_t ldD) {
+  const int lane = threadIdx.x & 63;
+  const int qg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+  const int64_t tile = blockIdx.x;
+  const int q0 = blockIdx.y * (NG * QB) + qg * QB;
+  if (q0 >= Q) return;
+  const float* qrow[QB];
+#pragma unroll
+  for (int i = 0; i < QB; ++i) {
+    int q = q0 + i;
+    if (q >= Q) q = Q - 1;
+    qrow[i] = qn + (int64_t)q * Dm;
+  }
+  const f32x4* xp = reinterpret_cast<const f32x4*>(xt + tile * (int64_t)Dm * 64) + lane;
 
   float acc[QB][4];
 #pragma unroll
   for (int i = 0; i < QB; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
 
-  for (int ch = 0; ch < Dm; ch += TX_CH) {
-    // stage 64 candidate rows x 64 floats: 1024 float4, 4 per thread, coalesced along the row
-    for (int v = threadIdx.x; v < 64 * (TX_CH / 4); v += 256) {
-      const int r = v >> 4, e4 = (v & 15) << 2;
-      int64_t c = c0 + r;
-      if (c >= C) c = C - 1;
-      const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
-      const float* src = xn + ((int64_t)j * R + cand_r[g]) * Dm + ch + e4;
-      *reinterpret_cast<f32x4*>(&xs[r * TX_LD + e4]) = *reinterpret_cast<const f32x4*>(src);
-    }
-    for (int v = threadIdx.x; v < 4 * QB * (TX_CH / 4); v += 256) {
-      const int r = v >> 4, e4 = (v & 15) << 2;
-      int q = q0 + r;
-      if (q >= Q) q = Q - 1;
-      *reinterpret_cast<f32x4*>(&qs[r * TX_CH + e4]) = *reinterpret_cast<const f32x4*>(qn + (int64_t)q * Dm + ch + e4);
-    }
-    __syncthreads();
+  // Software pipeline: the 64-B scalar load of the NEXT query row segment is issued before the 48 VALU ops
+  // of the current one (two 16-SGPR buffers); element order per accumulator stays u = 3,2,1,0.
+  const int nk = Dm >> 4;
+  f32x16 qv = *reinterpret_cast<const f32x16*>(qrow[0]);
+  f32x4 xnext[4];
 #pragma unroll
-    for (int g16 = 0; g16 < TX_CH / 16; ++g16) {
+  for (int u = 0; u < 4; ++u) xnext[u] = xp[u * 64];
+  for (int k = 0; k < nk; ++k) {
+    f32x4 x[4];
+    const int kx = (k + 1 < nk) ? k + 1 : 0;      // candidate tile: prefetch the next 16-element group too
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = xnext[u];
+      xnext[u] = xp[(kx * 4 + u) * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < QB; ++i) {
+      const int kn = (i + 1 < QB) ? k : (k + 1 < nk ? k + 1 : 0);
+      const f32x16 qnext = *reinterpret_cast<const f32x16*>(qrow[(i + 1) % QB] + kn * 16);
 #pragma unroll
       for (int u = 3; u >= 0; --u) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[lc * TX_LD + g16 * 16 + u * 4]);
-#pragma unroll
-        for (int i = 0; i < QB; ++i) {
-          const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[(qg * QB + i) * TX_CH + g16 * 16 + u * 4]);
-          float d0 = f_sub(qv.x, x.x), d1 = f_sub(qv.y, x.y), d2 = f_sub(qv.z, x.z), d3 = f_sub(qv.w, x.w);
-          acc[i][0] = f_add(f_mul(d0, d0), acc[i][0]);
-          acc[i][1] = f_add(f_mul(d1, d1), acc[i][1]);
-          acc[i][2] = f_add(f_mul(d2, d2), acc[i][2]);
-          acc[i][3] = f_add(f_mul(d3, d3), acc[i][3]);
-        }
+        const float d0 = f_sub(qv[u * 4 + 0], x[u].x), d1 = f_sub(qv[u * 4 + 1], x[u].y),
+                    d2 = f_sub(qv[u * 4 + 2], x[u].z), d3 = f_sub(qv[u * 4 + 3], x[u].w);
+        acc[i][0] = f_add(f_mul(d0, d0), acc[i][0]);
+        acc[i][1] = f_add(f_mul(d1, d1), acc[i][1]);
+        acc[i][2] = f_add(f_mul(d2, d2), acc[i][2]);
+        acc[i][3] = f_add(f_mul(d3, d3), acc[i][3]);
       }
+      qv = qnext;
     }
-    __syncthreads();
   }
 
-  const int64_t c = c0 + lc;
+  const int64_t c = tile * 64 + lane;
   if (c < C) {
 #pragma unroll
     for (int i = 0; i < QB; ++i) {
-      const int q = q0 + qg * QB + i;
-      if (q < Q) {
+      if (q0 + i < Q) {
         const float s = f_add(f_add(acc[i][0], acc[i][1]), f_add(acc[i][2], acc[i][3]));
-        D[(int64_t)q * ldD + c] = f_mul(0.5f, s);
+        D[(int64_t)(q0 + i) * ldD + c] = f_mul(0.5f, s);
       }
     }
   }
 }
 
-template <int QB>
-static int launch_text(void* stream, const float* xn, int N, int R, int Dm, const int32_t* cand_r, int G,
-                       const float* qn, int Q, float* D, int64_t ldD) {
-  const int64_t C = (int64_t)N * G;
-  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((Q + 4 * QB - 1) / (4 * QB)));
-  hipLaunchKernelGGL((text_cosine_f32_kernel<QB>), grid, dim3(256), 0, qpg_stream(stream), xn, N, R, Dm, cand_r, G,
-                     qn, Q, D, ldD);
+template <int QB, int NG>
+static int launch_text(void* stream, const float* xt, int64_t C, int Dm, const float* qn, int Q, float* D,
+                       int64_t ldD) {
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((Q + NG * QB - 1) / (NG * QB)));
+  hipLaunchKernelGGL((text_cosine_f32_kernel<QB, NG>), grid, dim3(64 * NG), 0, qpg_stream(stream), xt, C, Dm, qn, Q,
+                     D, ldD);
   QPG_LAUNCH_CHECK("text_cosine_f32_kernel");
   return QPG_OK;
 }
 
-extern "C" int qpg_text_cosine_f32(qpg_ctx* ctx, void* stream, const float* xn, int N, int R, int Dm,
-                                   const int32_t* cand_r, int G, const float* qn, int Q, float* D, int64_t ldD) {
-  QPG_REQUIRE(ctx && xn && cand_r && qn && D, "qpg_text_cosine_f32: null pointer");
-  QPG_REQUIRE(N >= 0 && R > 0 && G > 0 && Q >= 0 && ldD >= (int64_t)N * G, "qpg_text_cosine_f32: bad size");
-  if (Dm <= 0 || (Dm % TX_CH) != 0) {
-    qpg_set_error("qpg_text_cosine_f32: compiled for Dm %% 64 == 0 (got %d)", Dm);
+extern "C" int qpg_text_cosine_f32(qpg_ctx* ctx, void* stream, const float* xt, int64_t C, int Dm, const float* qn,
+                                   int Q, float* D, int64_t ldD) {
+  QPG_REQUIRE(ctx && xt && qn && D, "qpg_text_cosine_f32: null pointer");
+  QPG_REQUIRE(C >= 0 && Q >= 0 && ldD >= C, "qpg_text_cosine_f32: bad size");
+  if (Dm <= 0 || (Dm % 16) != 0) {
+    qpg_set_error("qpg_text_cosine_f32: compiled for Dm %% 16 == 0 (got %d)", Dm);
     return QPG_EUNSUP;
   }
-  if (N == 0 || Q == 0) return QPG_OK;
-  if (Q > 16) return launch_text<12>(stream, xn, N, R, Dm, cand_r, G, qn, Q, D, ldD);
-  if (Q > 4) return launch_text<4>(stream, xn, N, R, Dm, cand_r, G, qn, Q, D, ldD);
-  return launch_text<1>(stream, xn, N, R, Dm, cand_r, G, qn, Q, D, ldD);
+  if (C == 0 || Q == 0) return QPG_OK;
+  if (Q > 24) return launch_text<12, 4>(stream, xt, C, Dm, qn, Q, D, ldD);
+  if (Q > 8) return launch_text<6, 4>(stream, xt, C, Dm, qn, Q, D, ldD);
+  if (Q > 2) return launch_text<2, 4>(stream, xt, C, Dm, qn, Q, D, ldD);
+  return launch_text<1, 2>(stream, xt, C, Dm, qn, Q, D, ldD);
 }

@@ -57,3 +57,43 @@ def test_knn_pred_vs_reference_golden(name):
     assert codes.dtype == np.int64 and np.array_equal(codes, g["knn_pred"])
     assert np.array_equal(votes, g["vote"])
     assert np.array_equal(phases, g["phase_out"])
+
+
+def test_unfused_entry_points_agree_with_fused():
+    """The stand-alone C-ABI entry points (distance matrix + qpg_percode_argmin_*, qpg_rank_rows_*) give
+    the same tables as the fused fast path, and the full distance matrices match the oracle's C port."""
+    import torch
+    from oracle import cref, knn_oracle as O
+    g = load_golden(GOLDENS[0])
+    A, db, knn, te_i, te_c, M = _build(g["meta"])
+    steps = knn.n_steps()
+    q_win, q_t = np.repeat(np.arange(M), steps), np.tile(np.arange(steps) * 24, M)
+    d0, i0, r0 = knn.sweep_audio(te_i, q_win, q_t, want_rank=True)
+    d1, i1, D = knn.sweep_audio_unfused(te_i, q_win, q_t)
+    assert torch.equal(d0, d1) and torch.equal(i0, i1)
+    assert torch.equal(r0, knn.rank_rows(d1))
+    rows = [int(i / 180 * 30) for i in q_t]
+    qt = te_c[torch.as_tensor(q_win, device=te_c.device), torch.as_tensor(rows, device=te_c.device)].contiguous()
+    t0, j0, s0 = knn.sweep_text(qt, want_rank=True)
+    t1, j1, Dt = knn.sweep_text_unfused(qt)
+    assert torch.equal(t0, t1) and torch.equal(j0, j1) and torch.equal(s0, knn.rank_rows(t1))
+    # ranks == stable argsort-argsort
+    want = np.argsort(np.argsort(d1.cpu().numpy(), axis=1, kind="stable"), axis=1, kind="stable")
+    assert np.array_equal(r0.cpu().numpy(), want)
+
+
+def test_reference_shaped_single_query_api():
+    """CodeKNN.search_audio_cands / search_text_cands: same argument and return shapes as the reference
+    (GestureKNN.py:666-691, 708-721), values equal to what the reference returned for the first step."""
+    from oracle import knn_oracle as O
+    g = load_golden(GOLDENS[0])
+    A, db, knn, te_i, te_c, M = _build(g["meta"])
+    clip = O.wavlm_feat_rows(A["te_interp"], 0, [0])[0]
+    dist, pay, aux = knn.search_audio_cands(clip, mode="wavlm_feat")
+    assert len(dist) == len(pay) == len(aux) == 512
+    assert np.abs(np.array(dist) - g["aud_dist"][0]).max() < 1e-13
+    assert all(list(aux[c]) == list(g["aud_aux"][0][c]) for c in range(512))
+    assert all(np.array_equal(pay[c], g["aud_pay"][0][c]) for c in range(512))
+    dist, pay, aux = knn.search_text_cands(A["te_ctx"][0][0])
+    assert np.array_equal(np.array(dist, np.float32), g["txt_dist"][0])
+    assert all(list(aux[c]) == list(g["txt_aux"][0][c]) for c in range(512))
