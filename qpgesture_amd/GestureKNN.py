@@ -1,0 +1,89 @@
+"""Drop-in for the reference's codebook/Speech2GestureMatching/GestureKNN.py command line.
+
+Same flags (GestureKNN.py:25-39), same .npz inputs, same output file
+(`np.savez_compressed(out, knn_pred=int64 (M,30))`, :845), same seeding (:19-22) — the matching
+itself runs on the MI355X through libqpg_hip.so.  Run as
+    python -m qpgesture_amd.GestureKNN --train_database ... --out_knn_filename result.npz
+
+Additive flags: --device (default cuda:0), --mode (default `shipped` = the flags hard-coded at
+GestureKNN.py:842-843: wavlm_feat + text + phase; `audio` / `text` = the single-modality phase
+branches :593-625), --tie_rule (how equal code frequencies are ranked: `numpy` = the reference's
+own `argsort().argsort()` call on the host, `stable` = lowest code first, deterministic).
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+seed_value = 123456
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('-d', '--train_database', type=str, default="/path/to/training_db_data.npz")
+    p.add_argument('-c', '--train_codebook', type=str, default="/path/to/training_db_data.npz")
+    p.add_argument('-w', '--train_wavlm', type=str, default="/path/to/training_db_data.npz")
+    p.add_argument('-wvq', '--train_wavvq', type=str, default="/path/to/training_db_data.npz")
+    p.add_argument('-s', '--codebook_signature', type=str, default="/path/to/training_db_data.npz")
+    p.add_argument('-e', '--test_data', type=str, default="/path/to/test_data.npz")
+    p.add_argument('-tw', '--test_wavlm', type=str, default="/path/to/training_db_data.npz")
+    p.add_argument('-twvq', '--test_wavvq', type=str, default="/path/to/training_db_data.npz")
+    p.add_argument('-om', '--out_knn_filename', type=str, default="/path/to/knn_pred.npz")
+    p.add_argument('-ov', '--out_video_path', type=str, default="/path/to/video/")
+    p.add_argument('-k', '--desired_k', type=int, default=0)
+    p.add_argument('-f', '--fake', type=bool, default=False)
+    p.add_argument('-of', '--out_fake_knn_filename', type=str, default="/path/to/knn_pred.npz")
+    p.add_argument('--max_frames', type=int, default=0)
+    # additive
+    p.add_argument('--device', type=str, default="cuda:0")
+    p.add_argument('--mode', choices=["shipped", "audio", "text"], default="shipped")
+    p.add_argument('--tie_rule', choices=["numpy", "stable"], default="numpy")
+    return p
+
+
+def main_codebook(args, maxFrames=0):
+    """main_codebook (GestureKNN.py:816-845)."""
+    import torch
+    from .code_knn import MODE_AUD, MODE_AUD_TXT, MODE_TXT, CodeKNN, GestureDB
+    from .data_processing import load_db_codebook
+
+    t0 = time.time()
+    L = load_db_codebook(args.train_database, args.train_codebook, args.test_data, args.train_wavlm,
+                         args.test_wavlm, args.train_wavvq, args.test_wavvq)
+    signature = np.load(args.codebook_signature)['signature']                     # :476
+    freq_rank = None
+    if args.tie_rule == "numpy":
+        cnt = np.bincount(np.asarray(L.code).reshape(-1), minlength=512)[:512]
+        freq = np.where(cnt > 0, 1 - cnt / cnt.sum(), 1.0)                       # :481-499
+        freq_rank = np.array(list(freq)).argsort().argsort()                     # :544, the reference's own call
+    db = GestureDB(L.code, L.train_wavlm, L.train_context, L.train_phase, signature, device=args.device,
+                   freq_rank=freq_rank)
+    knn = CodeKNN(db)                                                            # draws from np.random like :463-464
+    n_test_seq = maxFrames if maxFrames != 0 else L.test_wavvq.shape[0]          # :740
+    dev = db.device
+    te_i = torch.from_numpy(L.test_wavlm[:n_test_seq]).to(dev)
+    te_c = torch.from_numpy(L.test_context[:n_test_seq]).to(dev)
+    t1 = time.time()
+    print('begin search...')
+    mode = {"shipped": MODE_AUD_TXT, "audio": MODE_AUD, "text": MODE_TXT}[args.mode]
+    pred_seqs, _, _ = knn.match_clip(te_i, te_c, n_test_seq, mode=mode)
+    t2 = time.time()
+    print(pred_seqs.shape)
+    np.savez_compressed(args.out_knn_filename, knn_pred=pred_seqs)               # :845
+    print('load+prepare %.2fs, match %.4fs (%.0f frames/s)' % (t1 - t0, t2 - t1, 240 * n_test_seq / (t2 - t1)))
+    return pred_seqs
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    os.environ['PYTHONHASHSEED'] = str(seed_value)                               # :19-22
+    random.seed(seed_value)
+    np.random.seed(seed_value)
+    return main_codebook(args, maxFrames=args.max_frames)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -97,3 +97,22 @@ def test_reference_shaped_single_query_api():
     dist, pay, aux = knn.search_text_cands(A["te_ctx"][0][0])
     assert np.array_equal(np.array(dist, np.float32), g["txt_dist"][0])
     assert all(list(aux[c]) == list(g["txt_aux"][0][c]) for c in range(512))
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_cli_drop_in(name, tmp_path):
+    """python -m qpgesture_amd.GestureKNN with the reference's flags on the same .npz files writes the
+    same knn_pred bytes the reference CLI wrote."""
+    from qpgesture_amd import GestureKNN as cli
+    from qpgesture_amd import synth
+    g = load_golden(name)
+    ntr, nte, s0, s1, s2, s3, mf = [int(v) for v in g["meta"]]
+    paths = synth.write_npz_set(str(tmp_path), ntr, nte, s0, s1, s2, s3)
+    out = str(tmp_path / "result.npz")
+    argv = []
+    for k, v in paths.items():
+        argv += ["--" + k, v]
+    cli.main(argv + ["--out_knn_filename", out, "--max_frames", str(mf)])
+    got = np.load(out)["knn_pred"]
+    assert got.dtype == np.int64 and got.shape == g["knn_pred"].shape
+    assert np.array_equal(got, g["knn_pred"])
