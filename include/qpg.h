@@ -168,6 +168,37 @@ int qpg_match_steps(qpg_ctx*, void* stream, const int16_t* aud_rank, const int32
                     const float* seed_phase, int32_t* gate_tables, int32_t* out_codes, float* out_phase,
                     int32_t* out_vote, int32_t* out_status);
 
+/* ------------------------------------------------------------------------------------------
+ * Gesture VQ-VAE (codebook/models/{vqvae,encdec,resnet,bottleneck}.py).  Activations are channels-last
+ * [B][T][C] f32 — the layout of the pose tensors at VQVAE.encode/decode's API (vqvae.py:132-136 permutes
+ * to NCT and back; here nothing is permuted).
+ * ---------------------------------------------------------------------------------------- */
+
+/* One 1-D convolution as an implicit GEMM on the f32 matrix cores (exact f32 FMA chains):
+ *   y[b][t*out_stride+out_offset][co] = act_out( bias[co] + sum_{tap,ci} w[tap][ci][co] *
+ *                                         act_in(x[b][t*in_stride + in_offset + tap*dil][ci]) ) (+ residual)
+ * for t < T_out; input rows outside [0,T_in) are zero padding.  Serves nn.Conv1d(k4,s2,p1) (encdec.py:20),
+ * the dilated k3 and 1x1 convolutions of ResConv1DBlock with its ReLUs and residual (resnet.py:31-46),
+ * nn.Conv1d(k3) (encdec.py:24,39,113), the x.k^T GEMM of BottleneckBlock.quantise (bottleneck.py:123) and
+ * nn.ConvTranspose1d(k4,s2,p1) (encdec.py:45) as two 2-tap launches, one per output parity.
+ * w: [dev] f32 [taps][Cin_pad][Cout_pad] repacked weights (Cin_pad % 16 == 0, Cout_pad % 128 == 0, zero padded);
+ * bias: [dev] f32 [Cout_pad] or NULL; residual: indexed like y, or NULL; y: [dev] f32 [B][T_y][Cout]. */
+int qpg_conv1d_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, int Cin, const float* w,
+                   const float* bias, int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride, int in_offset,
+                   int dil, int T_out, int out_stride, int out_offset, int T_y, const float* residual, int relu_in,
+                   int relu_out, float* y);
+
+/* BottleneckBlock.quantise (bottleneck.py:120-126) after the GEMM: ids[r] = argmin_c (|z_r|^2 - 2 dot[r][c]) + kk[c]
+ * (f32, that operation order, lowest index on ties).  z: [dev] f32 [R][E]; dot: [dev] f32 [R][K]; kk: [dev] f32 [K];
+ * ids: [dev] i64 [R]; dmin / dsecond: optional [dev] f32 [R] best and runner-up distance (parity margin). */
+int qpg_vq_argmin_f32(qpg_ctx*, void* stream, const float* z, const float* dot, const float* kk, int64_t R, int E,
+                      int K, int64_t* ids, float* dmin, float* dsecond);
+
+/* BottleneckBlock.dequantise (bottleneck.py:128-130): out[r][:] = k[ids[r]][:].  status: optional [dev] i32, set to 1
+ * if an id is outside [0,K) (torch's F.embedding raises IndexError). */
+int qpg_vq_gather_f32(qpg_ctx*, void* stream, const float* k, const int64_t* ids, int64_t R, int E, int K, float* out,
+                      int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

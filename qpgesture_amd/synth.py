@@ -90,3 +90,46 @@ def write_npz_set(outdir, n_train, n_test, seed_train=0, seed_test=1, seed_code=
     np.savez(p["train_wavvq"], wavvq=tr["wavvq"])
     np.savez(p["test_wavvq"], wavvq=te["wavvq"])
     return p
+
+
+# ----------------------------------------------------------------------------------------------
+# gesture VQ-VAE: seeded weights with the reference's checkpoint key names
+# ----------------------------------------------------------------------------------------------
+VQVAE_HPS = dict(input_dim=135, width=512, emb_width=512, l_bins=512, down_t=3, stride_t=2, depth=3,
+                 dilation_growth_rate=3, reverse_decoder_dilation=True)
+
+
+def make_vqvae_state_dict(seed, hps=None, prefix="module."):
+    """No pretrained checkpoint ships with the reference (pretrained_model/ is an empty placeholder),
+    so parity runs use seeded weights with the checkpoint's exact key names and shapes
+    (train.py:114-116 saves a DataParallel state_dict: keys carry `module.`)."""
+    h = dict(VQVAE_HPS, **(hps or {}))
+    rng = _rng(seed)
+    W, E, Cin, K = h["width"], h["emb_width"], h["input_dim"], h["l_bins"]
+    sd = {}
+
+    def conv(name, cout, cin, k, gain=1.0):
+        sd[prefix + name + ".weight"] = (rng.standard_normal((cout, cin, k)) * gain / np.sqrt(cin * k)).astype(np.float32)
+        sd[prefix + name + ".bias"] = (rng.standard_normal((cout,)) * 0.05).astype(np.float32)
+
+    def resnet(name):
+        for d in range(h["depth"]):
+            conv("%s.model.%d.model.1" % (name, d), W, W, 3, 1.4)
+            conv("%s.model.%d.model.3" % (name, d), W, W, 1, 0.5)
+
+    enc = "encoders.0.level_blocks.0.model"
+    for i in range(h["down_t"]):
+        conv("%s.%d.0" % (enc, i), W, Cin if i == 0 else W, 2 * h["stride_t"])
+        resnet("%s.%d.1" % (enc, i))
+    conv("%s.%d" % (enc, h["down_t"]), E, W, 3)
+    dec = "decoders.0.level_blocks.0.model"
+    conv(dec + ".0", W, E, 3)
+    for i in range(h["down_t"]):
+        resnet("%s.%d.0" % (dec, i + 1))
+        # ConvTranspose1d weight is (C_in, C_out, k)
+        sd[prefix + "%s.%d.1.weight" % (dec, i + 1)] = (rng.standard_normal((W, W, 2 * h["stride_t"]))
+                                                        / np.sqrt(W * 2)).astype(np.float32)
+        sd[prefix + "%s.%d.1.bias" % (dec, i + 1)] = (rng.standard_normal((W,)) * 0.05).astype(np.float32)
+    conv("decoders.0.out", Cin, E, 3)
+    sd[prefix + "bottleneck.level_blocks.0.k"] = rng.standard_normal((K, E)).astype(np.float32)
+    return sd

@@ -74,3 +74,20 @@ def test_oracle_pipeline_vs_reference(name, scan):
     assert np.array_equal(np.array([t["pos_score"] for t in trace]), g["step_pos_score"])
     assert np.array_equal(knn.freq_rank(), g["step_freq_score"])
     assert knn.tied_decisions == 0          # fixtures are chosen tie-free at every decision point
+
+
+def test_vqvae_oracle_vs_reference():
+    """torch-fp32 functional restatement == the reference VQVAE class on the same seeded checkpoint."""
+    import torch
+    from oracle import vqvae_oracle as VO
+    g = load_golden("vqvae_w512_s7")
+    sd = synth.make_vqvae_state_dict(int(g["meta"][0]))
+    x = np.random.Generator(np.random.PCG64(int(g["meta"][1]))).standard_normal((4, 240, 135)).astype(np.float32)
+    with torch.no_grad():
+        lat = VO.encode_latent(sd, x)
+        ids, d1, d2 = VO.quantise(sd, lat)
+        assert np.abs(lat.numpy() - g["latent"]).max() < 1e-5
+        assert np.array_equal(ids.numpy(), g["ids"])
+        assert np.abs((d2 - d1).numpy() - g["margin"]).max() < 1e-3
+        assert np.abs(VO.decode(sd, g["ids_dec"]).numpy() - g["poses"]).max() < 1e-5
+        assert np.abs(VO.decode(sd, g["ids"]).numpy() - g["roundtrip"]).max() < 1e-5
