@@ -153,6 +153,8 @@ def main():
            "roofline": roofline,
            "realtime_factor": round(value / 60.0 / world, 1)}
 
+    out.update(vqvae_bench(dev, a, world, rank))
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, code, clips[0], M, N)
         out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
@@ -160,6 +162,46 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def vqvae_bench(dev, a, world, rank):
+    """Second half of BASELINE.json's metric: gesture VQ-VAE encode (and decode) frames/s.  Each rank encodes
+    its own batch of 64 pose windows (240 frames x 135) — pure data parallel, no collective — with the
+    full-size codebook.yml architecture and seeded weights; the decode leg decodes one 24 s clip's worth of
+    codes per rank in one pass (1440 frames)."""
+    import torch
+    import torch.distributed as dist
+    from qpgesture_amd import synth
+    from qpgesture_amd.vqvae import VQVAE
+    model = VQVAE(None, 135, device=dev).load_state_dict(synth.make_vqvae_state_dict(7))
+    Bw = 64
+    x = torch.randn((Bw, 240, 135), device=dev)
+    ids = torch.randint(0, 512, (1, 180), device=dev)
+
+    def timed(fn, iters):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / iters
+    te = timed(lambda: model.encode(x), 10)
+    td = timed(lambda: model.decode([ids]), 10)
+    enc_flop = 1.639e9 * Bw                                        # SURVEY §8d: 1.639 GFLOP per 240-frame window
+    return {"vqvae_encode_frames_per_s": round(240 * Bw * world / te, 1),
+            "vqvae_encode_ms_per_batch64": round(te * 1e3, 3),
+            "vqvae_encode_tflops_f32": round(enc_flop / te / 1e12, 2),
+            "vqvae_decode_frames_per_s": round(1440 * world / td, 1),
+            "vqvae_decode_ms_per_24s_clip": round(td * 1e3, 3)}
 
 
 class _ShardView:

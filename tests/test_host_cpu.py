@@ -72,3 +72,36 @@ def test_loader_matches_oracle_windowing():
 def test_densify_phase_accepts_dense():
     x = np.random.default_rng(0).standard_normal((2, 240, 4, 8)).astype(np.float32)
     assert np.array_equal(dp.densify_phase(x), x)
+
+
+def test_checkpoint_with_pickled_easydict(tmp_path):
+    """train.py:114-116 pickles an easydict.EasyDict into the checkpoint; it must load without easydict."""
+    import sys
+    import types
+    import torch
+    from qpgesture_amd.checkpoint import AttrDict, load_checkpoint
+    mod = types.ModuleType("easydict")
+    EasyDict = type("EasyDict", (dict,), {"__module__": "easydict", "__qualname__": "EasyDict"})
+    mod.EasyDict = EasyDict
+    sys.modules["easydict"] = mod
+    try:
+        sd = {"module.bottleneck.level_blocks.0.k": torch.arange(6.).reshape(2, 3)}
+        path = str(tmp_path / "ck.bin")
+        torch.save({"args": EasyDict({"VQVAE": {"width": 512}, "lr": 3e-5}), "epoch": 7, "model_dict": sd}, path)
+    finally:
+        del sys.modules["easydict"]
+    ck = load_checkpoint(path)
+    assert ck["epoch"] == 7 and isinstance(ck["args"], AttrDict) and ck["args"].lr == 3e-5
+    assert ck["args"].VQVAE.width == 512 and not hasattr(ck["args"], "dilation_cycle")
+    assert torch.equal(ck["model_dict"]["module.bottleneck.level_blocks.0.k"], sd["module.bottleneck.level_blocks.0.k"])
+    torch.save(sd, path)                                    # bare state_dict
+    assert "model_dict" in load_checkpoint(path)
+
+
+def test_reference_config_loads():
+    import os
+    from qpgesture_amd.checkpoint import load_config
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qpgesture_amd", "configs",
+                     "codebook.yml")
+    cfg = load_config(p)
+    assert cfg.VQVAE.width == 512 and cfg.VQVAE.downs_t == [3] and len(cfg.data_mean) == 135
