@@ -99,6 +99,17 @@ int qpg_text_pack_candidates_f32(qpg_ctx*, void* stream, const float* x, int N, 
 int qpg_text_cosine_f32(qpg_ctx*, void* stream, const float* xt, int64_t C, int Dm, const float* qn, int Q,
                         float* D, int64_t ldD);
 
+/* vq-wav2vec audio sweep (the mode the paper describes; flags use_wavvq/use_feature of GestureKNN.py:557-560):
+ * D[q][c] = Levenshtein distance (unit costs, python-Levenshtein distance()) between the 11-symbol strings of
+ * query q and candidate c, symbol = g1*320+g2 (wavvq_distances(mode='combine'), GestureKNN.py:57-67).  Strings
+ * are gathered in place from symbol tracks: string[i] = track[t + tap_off[i]] (0 outside the window), which is
+ * the 6-back/5-forward stack of data_processing.py:297-335 without materialising it.
+ * sym_db: [dev] i32 [N][T]; cand_t: [dev] i32 [G] (int(k) of the float grid); tap_off: HOST i32 [11];
+ * sym_q: [dev] i32 [Mq][Tq]; q_win/q_t: [dev] i32 [Q]; D: [dev] f32 [Q][N*G] (exact small integers). */
+int qpg_wavvq_lev_f32(qpg_ctx*, void* stream, const int32_t* sym_db, int N, int T, const int32_t* cand_t, int G,
+                      const int32_t* tap_off, int n_taps, const int32_t* sym_q, int Mq, int Tq,
+                      const int32_t* q_win, const int32_t* q_t, int Q, float* D, int64_t ldD);
+
 /* Segmented min + argmin by code id, first index wins on ties (GestureKNN.py:686-689).
  * code: [dev] i32 [N][code_ld]; cand_cidx: [dev] i32 [G] column of `code` for grid position g;
  * out_dist: [dev] [Q][K] (initialised to `absent`, the reference's 1e+3); out_idx: [dev] i32 [Q][K]

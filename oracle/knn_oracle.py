@@ -407,3 +407,22 @@ def load_and_match(paths, max_frames=0, seed=123456, rank_kind="numpy", trace=No
     out = predict_code_from_audio(knn, test_interp=te_interp, test_ctx=te["context"].squeeze(2),
                                   n_windows=n_win, trace=trace)
     return out, knn
+
+
+def load_and_match_wavvq(paths, use_txt=True, max_frames=0, seed=2, rank_kind="numpy", trace=None):
+    """predict_code_from_audio with the vq-wav2vec flags (use_wavvq, use_feature, use_phase, use_aud,
+    use_txt optional): Levenshtein audio distance on 11-symbol strings (GestureKNN.py:57-67, 558-560)."""
+    tr = np.load(paths["train_database"], allow_pickle=True)
+    te = np.load(paths["test_data"], allow_pickle=True)
+    code = np.load(paths["train_codebook"])["code"]
+    sig = np.load(paths["codebook_signature"])["signature"]
+    tr_vq = wavvq_feat(np.load(paths["train_wavvq"])["wavvq"])
+    te_wavvq = np.load(paths["test_wavvq"])["wavvq"]
+    te_vq = wavvq_feat(te_wavvq)
+    n_win = max_frames if max_frames != 0 else te_wavvq.shape[0]
+    rs = np.random.RandomState(seed)
+    knn = CodeKNNOracle(code, sig, densify_phase(tr["phase"]), tr["context"].squeeze(2),
+                        wavvq_train_feat=tr_vq, mode="wavvq", rng=rs, rank_kind=rank_kind)
+    out = predict_code_from_audio(knn, test_vq_feat=te_vq, test_ctx=te["context"].squeeze(2), n_windows=n_win,
+                                  use_txt=use_txt, use_aud=True, trace=trace)
+    return out, knn

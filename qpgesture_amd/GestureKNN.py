@@ -7,7 +7,9 @@ itself runs on the MI355X through libqpg_hip.so.  Run as
 
 Additive flags: --device (default cuda:0), --mode (default `shipped` = the flags hard-coded at
 GestureKNN.py:842-843: wavlm_feat + text + phase; `audio` / `text` = the single-modality phase
-branches :593-625), --tie_rule (how equal code frequencies are ranked: `numpy` = the reference's
+branches :593-625; `wavvq` / `wavvq_audio` = vq-wav2vec Levenshtein audio, the flags the paper describes,
+with / without text), --seed (default 123456 as :19; in wavvq modes that seed draws an invalid initial
+phase slice in the reference as well), --tie_rule (how equal code frequencies are ranked: `numpy` = the reference's
 own `argsort().argsort()` call on the host, `stable` = lowest code first, deterministic).
 """
 import argparse
@@ -39,7 +41,8 @@ def build_parser():
     p.add_argument('--max_frames', type=int, default=0)
     # additive
     p.add_argument('--device', type=str, default="cuda:0")
-    p.add_argument('--mode', choices=["shipped", "audio", "text"], default="shipped")
+    p.add_argument('--mode', choices=["shipped", "audio", "text", "wavvq", "wavvq_audio"], default="shipped")
+    p.add_argument('--seed', type=int, default=seed_value)
     p.add_argument('--tie_rule', choices=["numpy", "stable"], default="numpy")
     return p
 
@@ -59,16 +62,18 @@ def main_codebook(args, maxFrames=0):
         cnt = np.bincount(np.asarray(L.code).reshape(-1), minlength=512)[:512]
         freq = np.where(cnt > 0, 1 - cnt / cnt.sum(), 1.0)                       # :481-499
         freq_rank = np.array(list(freq)).argsort().argsort()                     # :544, the reference's own call
+    vq = args.mode.startswith("wavvq")
     db = GestureDB(L.code, L.train_wavlm, L.train_context, L.train_phase, signature, device=args.device,
-                   freq_rank=freq_rank)
-    knn = CodeKNN(db)                                                            # draws from np.random like :463-464
+                   freq_rank=freq_rank, wavvq=L.train_wavvq if vq else None)
+    knn = CodeKNN(db, use_wavlm=not vq, use_wavvq=vq)                            # draws from np.random like :463-464
     n_test_seq = maxFrames if maxFrames != 0 else L.test_wavvq.shape[0]          # :740
     dev = db.device
-    te_i = torch.from_numpy(L.test_wavlm[:n_test_seq]).to(dev)
+    te_i = torch.from_numpy(np.ascontiguousarray((L.test_wavvq if vq else L.test_wavlm)[:n_test_seq])).to(dev)
     te_c = torch.from_numpy(L.test_context[:n_test_seq]).to(dev)
     t1 = time.time()
     print('begin search...')
-    mode = {"shipped": MODE_AUD_TXT, "audio": MODE_AUD, "text": MODE_TXT}[args.mode]
+    mode = {"shipped": MODE_AUD_TXT, "audio": MODE_AUD, "text": MODE_TXT, "wavvq": MODE_AUD_TXT,
+            "wavvq_audio": MODE_AUD}[args.mode]
     pred_seqs, _, _ = knn.match_clip(te_i, te_c, n_test_seq, mode=mode)
     t2 = time.time()
     print(pred_seqs.shape)
@@ -80,8 +85,8 @@ def main_codebook(args, maxFrames=0):
 def main(argv=None):
     args = build_parser().parse_args(argv)
     os.environ['PYTHONHASHSEED'] = str(seed_value)                               # :19-22
-    random.seed(seed_value)
-    np.random.seed(seed_value)
+    random.seed(args.seed)
+    np.random.seed(args.seed)
     return main_codebook(args, maxFrames=args.max_frames)
 
 

@@ -13,7 +13,9 @@ import torch
 
 from . import _lib
 from .parallel import allreduce_min_index, shard_rows
-from .constant import (ABSENT_DIST, NUM_AUDIO_FEAT_FRAMES, STEP_SZ, codebook_size, num_frames,
+import ctypes
+
+from .constant import (ABSENT_DIST, NUM_AUDIO_FEAT_FRAMES, STEP_SZ, WAVVQ_GROUP_SIZE, codebook_size, num_frames,
                        num_frames_code)
 
 MODE_AUD_TXT, MODE_AUD, MODE_TXT = 0, 1, 2
@@ -46,6 +48,14 @@ def phase_slot(k):
     return int(k / 398 * 240)
 
 
+def wavvq_tap_offsets(T):
+    """Frame offsets of the 11 taps of a wavvq feature row (data_processing.py:281, 297-317):
+    6 backward taps shifted by int((5-i)*s), then 5 forward taps shifted by int(i*s), s = T/30."""
+    s = T / num_frames_code
+    return [-int((NUM_AUDIO_FEAT_FRAMES - i - 1) * s) for i in range(NUM_AUDIO_FEAT_FRAMES)] + \
+           [int(i * s) for i in range(1, NUM_AUDIO_FEAT_FRAMES)]
+
+
 def _i32(x, dev):
     return torch.as_tensor(np.asarray(x, np.int32), device=dev)
 
@@ -64,7 +74,7 @@ class GestureDB:
     """
 
     def __init__(self, code, wavlm_interp, context, phase_dense, signature, device="cuda:0",
-                 freq_rank=None, pos_rank=None, rank=0, world=1):
+                 freq_rank=None, pos_rank=None, rank=0, world=1, wavvq=None):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("GestureDB needs a HIP device (got %s); there is no CPU path" % dev)
@@ -91,6 +101,21 @@ class GestureDB:
         self.aud_cidx = _i32(cidx, dev)
         self.aud_pslot = _i32([phase_slot(k) for k in kint], dev)
         self.tap_stride = 2                                           # FRAME_INTERVAL-2, data_processing.py:266
+
+        # vq-wav2vec track (optional; the mode the paper describes): symbols g1*320+g2, float grid of 398/30
+        self.has_wavvq = wavvq is not None
+        if self.has_wavvq:
+            vq = np.asarray(wavvq[self.lo:self.hi])
+            self.Tv = wavvq.shape[1]
+            self.vq_sym = _i32(vq[..., 0].astype(np.int64) * WAVVQ_GROUP_SIZE + vq[..., 1], dev).contiguous()
+            self.vq_step = self.Tv / num_frames_code                              # GestureKNN.py:436
+            vk, vc = audio_grid(self.Tv, self.vq_step)
+            self.vq_k, self.vq_cidx_host = vk, vc
+            self.Gv = len(vk)
+            self.vq_t = _i32(vk, dev)
+            self.vq_cidx = _i32(vc, dev)
+            self.vq_pslot = _i32([phase_slot(k) for k in vk], dev)
+            self.vq_taps = wavvq_tap_offsets(self.Tv)
 
         ks, rows = text_grid()
         self.txt_k, self.txt_rows_host = ks, rows
@@ -154,13 +179,34 @@ class CodeKNN:
     """Mirror of the reference's CodeKNN (GestureKNN.py:422-721) over a GestureDB."""
 
     def __init__(self, db, use_wavlm=True, use_wavvq=False, use_phase=True, use_txt=True, rng=None):
-        if use_wavvq or not use_wavlm:
-            raise NotImplementedError("only the shipped wavlm_feat mode is built so far (SURVEY.md §0.3)")
+        if use_wavlm == use_wavvq:
+            raise ValueError("exactly one of use_wavlm / use_wavvq (GestureKNN.py:431-438)")
+        if use_wavvq and not db.has_wavvq:
+            raise ValueError("GestureDB was built without a wavvq track")
         self.db = db
-        self.step_sz = db.step_sz
-        self.n_db_seq, self.n_db_frm = db.N, db.T
+        self.use_wavvq = use_wavvq
+        if use_wavvq:                                                       # GestureKNN.py:435-438
+            self.step_sz, self.n_db_frm = db.vq_step, db.Tv
+        else:                                                               # :431-434
+            self.step_sz, self.n_db_frm = db.step_sz, db.T
+        self.n_db_seq = db.N
         self.use_phase, self.use_txt = use_phase, use_txt
         self.rng = rng if rng is not None else np.random
+
+    def _audio_grid(self):
+        db = self.db
+        if self.use_wavvq:
+            return db.vq_cidx, db.vq_pslot, db.Gv
+        return db.aud_cidx, db.aud_pslot, db.Ga
+
+    def query_positions(self):
+        """Matching-step positions of a window: i = 0, 4*step, ... while i < n (GestureKNN.py:528,659);
+        with the float wavvq step the literal accumulation is kept."""
+        pos, i = [], 0
+        while i < self.n_db_frm:
+            pos.append(i)
+            i += STEP_SZ * self.step_sz
+        return pos
 
     # -- init (GestureKNN.py:462-473): same two draws from the (seeded) NumPy global stream ------
     def init_code_phase(self):
@@ -169,6 +215,11 @@ class CodeKNN:
         j = self.rng.randint(0, self.n_db_frm - int(num_frames / num_frames_code))
         code = int(db.code_host[i, j // num_frames_code])
         P = db.phase_host[i, j:j + 8]                              # (8,2,8)
+        if P.shape[0] != 8:
+            # wavvq mode draws j up to 389 on a 240-frame phase track (GestureKNN.py:464-469): the reference's
+            # np.array(result_phase) then raises "inhomogeneous shape" on NumPy >= 1.24
+            raise ValueError("init_code_phase drew frame %d: phase slice has %d rows, not 8 "
+                             "(the reference fails on this draw too); use another seed" % (j, P.shape[0]))
         return code, np.concatenate((P[:, 0], P[:, 1]), axis=1).astype(np.float32)
 
     # -- batched sweeps ------------------------------------------------------------------------
@@ -228,6 +279,32 @@ class CodeKNN:
         fused_rank = want_rank and db.world == 1
         rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
         _lib.call("qpg_percode_finalize_f32", dev, packed, Q, db.K, float(ABSENT_DIST), dist, idx, rank)
+        dist, idx = self._reduce_min(dist, idx)
+        if want_rank:
+            return dist, idx, (rank if fused_rank else self.rank_rows(dist))
+        return dist, idx
+
+    def sweep_audio_wavvq(self, test_wavvq, q_win, q_t, want_rank=False):
+        """vq-wav2vec audio sweep: test_wavvq (M,398,2) ints (device tensor or array).  Distances are exact
+        small integers (Levenshtein), returned as f32 [Q,512] with the winners' global candidate indices."""
+        db, dev = self.db, self.db.device
+        tw = torch.as_tensor(test_wavvq).to(dev)
+        sym_q = (tw[..., 0].to(torch.int64) * WAVVQ_GROUP_SIZE + tw[..., 1].to(torch.int64)).to(torch.int32).contiguous()
+        Q = len(q_win)
+        C = db.n_local * db.Gv
+        D = torch.empty((Q, max(C, 1)), dtype=torch.float32, device=dev)
+        taps = (ctypes.c_int32 * len(db.vq_taps))(*db.vq_taps)
+        _lib.call("qpg_wavvq_lev_f32", dev, db.vq_sym, db.n_local, db.Tv, db.vq_t, db.Gv, taps, len(db.vq_taps),
+                  sym_q, sym_q.shape[0], sym_q.shape[1], _i32(q_win, dev), _i32(q_t, dev), Q, D, D.stride(0))
+        packed = torch.empty((Q, db.K), dtype=torch.int64, device=dev)
+        _lib.call("qpg_percode_resolve_f32", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
+                  db.vq_cidx, db.Gv, db.K, db.idx_base * db.Gv, packed)
+        dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
+        idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+        fused_rank = want_rank and db.world == 1
+        rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
+        _lib.call("qpg_percode_finalize_f32", dev, packed, Q, db.K, float(ABSENT_DIST), dist, idx, rank)
+        self._last_D_aud = D
         dist, idx = self._reduce_min(dist, idx)
         if want_rank:
             return dist, idx, (rank if fused_rank else self.rank_rows(dist))
@@ -301,9 +378,19 @@ class CodeKNN:
     def search_audio_cands(self, clip_input, mode="wavlm_feat"):
         """clip_input: one 6144-d WavLM feature row (6 taps x 1024).  Same return triple as the
         reference: per-code distance list, per-code 4-code payload (or []), per-code [j, k] (or [])."""
+        db = self.db
+        if mode == "wavvq_feat":
+            # clip_input: 22 numbers = 11 taps x (g1,g2) (data_processing.py:317); hand them to the kernel as a
+            # 1-window track whose tap gather reproduces exactly those 11 symbols
+            v = np.asarray(clip_input).reshape(11, 2).astype(np.int64)
+            track = np.zeros((1, db.Tv, 2), np.int64)
+            t0 = -min(db.vq_taps)
+            for i, off in enumerate(db.vq_taps):
+                track[0, t0 + off] = v[i]
+            dist, idx = self.sweep_audio_wavvq(track, [0], [t0])
+            return self._unpack(dist, idx, db.Gv, db.vq_k, db.vq_cidx_host)
         if mode != "wavlm_feat":
             raise NotImplementedError(mode)
-        db = self.db
         q = torch.as_tensor(np.asarray(clip_input, np.float32).reshape(1, NUM_AUDIO_FEAT_FRAMES, db.F),
                             device=db.device).contiguous()
         dist, idx = self.sweep_audio(q, [0], [0], tap_stride=1)
@@ -317,7 +404,7 @@ class CodeKNN:
 
     # -- whole clip ---------------------------------------------------------------------------------
     def n_steps(self):
-        return len(range(0, self.db.T, STEP_SZ * self.step_sz))               # GestureKNN.py:528,659
+        return len(self.query_positions())
 
     def sweep_tables(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT):
         """Both batched sweeps + ranks for all Q = n_windows*steps query positions (the windows may
@@ -325,13 +412,18 @@ class CodeKNN:
         Returns a dict of device tensors: aud_d/aud_idx/aud_rank, txt_d/txt_idx/txt_rank."""
         db, dev = self.db, self.db.device
         M, steps = n_windows, self.n_steps()
+        pos = self.query_positions()
         q_win = np.repeat(np.arange(M), steps)
-        q_t = np.tile(np.arange(steps) * STEP_SZ * self.step_sz, M)
+        q_t = np.tile(np.array([int(i) for i in pos]), M)                    # clip_test[int(i)]  (:559, :565)
         T = dict(aud_d=None, aud_idx=None, aud_rank=None, txt_d=None, txt_idx=None, txt_rank=None)
         if mode in (MODE_AUD_TXT, MODE_AUD):
-            T["aud_d"], T["aud_idx"], T["aud_rank"] = self.sweep_audio(test_interp, q_win, q_t, want_rank=True)
+            if self.use_wavvq:
+                T["aud_d"], T["aud_idx"], T["aud_rank"] = self.sweep_audio_wavvq(test_interp, q_win, q_t,
+                                                                                 want_rank=True)
+            else:
+                T["aud_d"], T["aud_idx"], T["aud_rank"] = self.sweep_audio(test_interp, q_win, q_t, want_rank=True)
         if mode in (MODE_AUD_TXT, MODE_TXT):
-            rows = [int(i / db.T * 30) for i in q_t]                           # GestureKNN.py:549
+            rows = [int(i / self.n_db_frm * 30) for i in pos] * M              # GestureKNN.py:549, 551
             key = (M, steps)
             if getattr(self, "_txt_gather_key", None) != key:
                 self._txt_gather = (torch.as_tensor(q_win, device=dev), torch.as_tensor(rows, device=dev))
@@ -359,8 +451,9 @@ class CodeKNN:
 
         def sl(t):
             return None if t is None else t[q0:q0 + M * steps]
+        a_cidx, a_pslot, a_G = self._audio_grid()
         _lib.call("qpg_match_steps", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]), sl(T["txt_idx"]),
-                  db.pos_rank, db.freq_rank, db.code, db.code.shape[1], db.aud_cidx, db.aud_pslot, db.Ga,
+                  db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
                   db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode, M, steps, db.K, int(seed_code), sp,
                   gate, out_codes, out_phase, out_vote, status)
         if not sync:

@@ -115,6 +115,37 @@ def run_reference(paths, mode, max_frames=0):
         if mode == "shipped":
             g["main_codebook"](maxFrames=max_frames)
             knn_pred = np.load(out)["knn_pred"]
+        elif mode in ("wavvq_aud_txt", "wavvq_aud"):
+            # main_codebook's body (GestureKNN.py:816-845) with the vq-wav2vec flags the paper describes
+            # instead of the hard-coded ones at :842-843
+            a = g["args"]
+            sys.path.insert(0, REF_DIR)
+            from data_processing import load_db_codebook, calc_data_stats
+            L = load_db_codebook(a.train_database, a.train_codebook, a.test_data, a.train_wavlm, a.test_wavlm,
+                                 a.train_wavvq, a.test_wavvq)
+            (train_mfcc, train_code, test_mfcc, train_feat, test_feat, train_wavlm, test_wavlm, train_wavlm_feat,
+             test_wavlm_feat, speech_features, test_speech_features, train_speech_features_feat,
+             test_speech_features_feat, train_wavvq_feat, test_wavvq_feat, train_phase, test_phase, train_context,
+             test_context) = L
+            T = lambda x: x.transpose((0, 2, 1))
+            st = {}
+            for nm, (x, y) in dict(mfcc=(train_mfcc, test_mfcc), feat=(train_feat, test_feat),
+                                   speech_features=(speech_features, test_speech_features),
+                                   speech_features_feat=(train_speech_features_feat,
+                                                         test_speech_features_feat)).items():
+                m_, s_, _, _ = calc_data_stats(T(x), T(y))
+                st[nm + "_train_mean"], st[nm + "_train_std"] = m_, s_
+            # With the seed the reference sets at import (123456) the first draw is init_j = 234 > 232, the
+            # 8-frame phase slice comes back short and np.array(result_phase) raises on NumPy >= 1.24
+            # (SURVEY.md §7.6).  Re-seed so the draw is valid; the tests seed the same way.
+            np.random.seed(2)
+            knn_pred = g["predict_code_from_audio"](
+                train_mfcc, train_code, test_mfcc, st, train_feat, test_feat, train_wavlm, test_wavlm,
+                train_wavlm_feat, test_wavlm_feat, speech_features, test_speech_features,
+                train_speech_features_feat, test_speech_features_feat, train_wavvq_feat, test_wavvq_feat,
+                train_phase, test_phase, train_context, test_context, use_feature=True, use_wavlm=False,
+                use_freq=False, use_speechfeat=False, use_wavvq=True, use_phase=True,
+                use_txt=(mode == "wavvq_aud_txt"), use_aud=True, frames=max_frames)
         else:
             raise ValueError(mode)
         wall = time.time() - t0
@@ -138,7 +169,7 @@ def run_reference(paths, mode, max_frames=0):
 
     if cap["aud"]:
         d, p, a = pack(cap["aud"])
-        assert d.dtype == np.float64
+        d = d.astype(np.float64)
         res.update(aud_dist=d, aud_pay=p.astype(np.int16), aud_aux=a.astype(np.int32))
     if cap["txt"]:
         d, p, a = pack(cap["txt"])
@@ -158,9 +189,12 @@ def run_reference(paths, mode, max_frames=0):
 
 
 FIXTURES = {
-    # name: (n_train, n_test, seeds(train,test,code,sig), max_frames)
-    "shipped_n48_m2_s0": (48, 2, (0, 1, 2, 3), 0),
-    "shipped_n64_m3_s10": (64, 3, (10, 11, 12, 13), 0),
+    # name: (n_train, n_test, seeds(train,test,code,sig), max_frames, mode)
+    "shipped_n48_m2_s0": (48, 2, (0, 1, 2, 3), 0, "shipped"),
+    "shipped_n64_m3_s10": (64, 3, (10, 11, 12, 13), 0, "shipped"),
+    # vq-wav2vec + Levenshtein audio (the mode the paper describes); wavlm_dim=8 keeps the unused WavLM small
+    "wavvq_aud_txt_n40_m2_s20": (40, 2, (20, 21, 22, 23), 0, "wavvq_aud_txt"),
+    "wavvq_aud_n40_m2_s20": (40, 2, (20, 21, 22, 23), 0, "wavvq_aud"),
 }
 
 
@@ -168,12 +202,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    for name, (ntr, nte, seeds, mf) in FIXTURES.items():
+    for name, (ntr, nte, seeds, mf, mode) in FIXTURES.items():
         if a.only and a.only != name:
             continue
         with tempfile.TemporaryDirectory() as td:
-            paths = synth.write_npz_set(td, ntr, nte, *seeds)
-            res = run_reference(paths, "shipped", mf)
+            paths = synth.write_npz_set(td, ntr, nte, *seeds, wavlm_dim=1024 if mode == "shipped" else 8)
+            res = run_reference(paths, mode, mf)
         res["meta"] = np.array([ntr, nte, *seeds, mf], np.int64)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
         print(name, "knn_pred", res["knn_pred"].shape, "ref wall %.1fs" % res["ref_wall_s"],

