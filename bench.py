@@ -56,7 +56,8 @@ def main():
     ap.add_argument("--n-db", type=int, default=2048)
     ap.add_argument("--windows", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="DB windows in the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="DB windows in the CPU baseline sample")
+    ap.add_argument("--check", action="store_true", help="verify the matched codes against a 1-rank run")
     a = ap.parse_args()
 
     import torch
@@ -69,11 +70,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
-    dev = torch.device("cuda", local)
+    # QPG_BENCH_ONE_GPU=1 (testing only): all ranks share cuda:0 and exchange through gloo, so that the
+    # N>1 code path can be exercised on a 1-GPU box; the driver's runs use one GPU per rank over RCCL.
+    one_gpu = os.environ.get("QPG_BENCH_ONE_GPU") == "1"
+    dev = torch.device("cuda", 0 if one_gpu else local)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     N, M = a.n_db, a.windows
     per = (N + world - 1) // world
@@ -158,6 +165,17 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, code, clips[0], M, N)
         out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+    if a.check:
+        # every rank re-matches ITS clip against the WHOLE database on its own (world=1 semantics) and must
+        # get the same codes as the sharded + all-reduced run above
+        full_i, full_c = chunked_db(N, 0, N, seed=0)
+        db1 = GestureDB(code, full_i, full_c, phase, sig, device=dev)
+        k1 = CodeKNN(db1, rng=np.random.RandomState(123456))
+        T1 = k1.sweep_tables(te_interp[rank * M:(rank + 1) * M], te_ctx[rank * M:(rank + 1) * M], M)
+        want, _, _ = k1.walk(T1, M, 0, seed_code=seed_code, seed_phase=seed_phase_d)
+        ok = bool(np.array_equal(want, codes.numpy().astype(np.int64)))
+        out["check"] = ok
+        assert ok, "rank %d: sharded result differs from the single-rank result" % rank
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
