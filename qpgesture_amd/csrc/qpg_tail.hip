@@ -153,13 +153,38 @@ struct TailArgs {
   int32_t* out_status;       // [1] 0 ok, 1 = an absent code won a rank fusion (reference would raise IndexError)
 };
 
-// sklearn-exact einsum_sq over 128 floats in LDS by 4 cooperating lanes (see lane4_sum).
 // ---------------------------------------------------------------------------------------------
-// The sequential walk: ONE wave.  Per step: two LDS lookups (the gate candidates for the current
-// previous code), one round of global loads (their phase blocks and codes), the 128-d phase-gate
-// cosine in scikit-learn's f32 arithmetic, and the state update.  A workgroup of one wave makes
-// __syncthreads() a plain LDS fence, so the chain has no multi-wave barrier latency.
+// The sequential walk: ONE wave.  A workgroup of one wave makes __syncthreads() a plain LDS fence, so the
+// chain has no multi-wave barrier latency.  Per step: two LDS lookups (the gate candidates for the current
+// previous code), the 128-d phase-gate cosine in scikit-learn's f32 arithmetic, the state update.
+//
+// The global loads are taken OFF the dependent chain by speculation: the next step's previous code can
+// only be the last payload code of one of the two current gate candidates, so as soon as their payloads
+// are known the phase blocks / payloads of all four possible next candidates are requested, and they
+// arrive while the current step's gate arithmetic runs (r01: 3.2 us/step with dependent loads).
 // ---------------------------------------------------------------------------------------------
+struct CandRegs {
+  float2 head, tail;   // this lane's 2 floats of the first / last 8-frame block (8 x 16 floats each)
+  int pay;             // lanes 0..3: the candidate's 4 codes
+  int absent;          // the table entry was -1 (code absent from the DB): only an error if this candidate is USED
+};
+
+__device__ __forceinline__ CandRegs load_cand(const TailArgs& A, int which, int ci, const int* s_cidx,
+                                              const int* s_pslot, int lane) {
+  // which: 0 -> table T0's grid, 1 -> table T1's grid.  s_cidx/s_pslot: LDS copies [2][64].
+  const int G = which ? A.G1 : A.G0;
+  const int cc = ci < 0 ? 0 : ci;
+  const int j = cc / G, g = cc - j * G;
+  const int ps = s_pslot[which * 64 + g];
+  const float* b = A.phase + ((int64_t)j * A.Tp + ps) * 16;   // rows [ps, ps+8) and [ps+24, ps+32): 128 floats each
+  CandRegs r;
+  r.absent = ci < 0;
+  r.head = reinterpret_cast<const float2*>(b)[lane];
+  r.tail = reinterpret_cast<const float2*>(b + 384)[lane];
+  r.pay = A.code[(int64_t)j * A.code_ld + s_cidx[which * 64 + g] + (lane & 3)];
+  return r;
+}
+
 __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
   extern __shared__ __attribute__((aligned(16))) int32_t tab[];   // [2][steps][K] gate candidates of this window
   __shared__ float prev[128];          // running phase block (8 frames x [8 phase | 8 amp])
@@ -168,46 +193,54 @@ __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
   __shared__ float nrm[4];
   __shared__ float score[2];
   __shared__ int wincodes[64];
+  __shared__ int s_cidx[128], s_pslot[128];
 
   const int lane = threadIdx.x, K = A.K;
   prev[lane] = A.seed_phase[lane];
   prev[lane + 64] = A.seed_phase[lane + 64];
+  if (lane < A.G0) {
+    s_cidx[lane] = A.cidx0[lane];
+    s_pslot[lane] = A.pslot0[lane];
+  }
+  if (lane < A.G1) {
+    s_cidx[64 + lane] = A.cidx1[lane];
+    s_pslot[64 + lane] = A.pslot1[lane];
+  }
   int prev_code = A.seed_code;
   int bad = 0;
   const float eps10 = 10.f * 1.1920928955078125e-07f;
+  const int last_idx = A.codes_per_window - 1;                 // the next window is seeded by this kept code
 
   for (int w = 0; w < A.M; ++w) {
     // this window's gate tables -> LDS (steps*K*2 i32, 16-B loads)
     const int n4 = A.steps * K / 4;
+    __syncthreads();
     for (int t = 0; t < 2; ++t) {
       const int4* src = reinterpret_cast<const int4*>((t ? A.T1 : A.T0) + (int64_t)w * A.steps * K);
       int4* dst = reinterpret_cast<int4*>(tab + t * A.steps * K);
       for (int v = lane; v < n4; v += 64) dst[v] = src[v];
     }
     __syncthreads();
+    CandRegs cur[2];
+    cur[0] = load_cand(A, 0, tab[prev_code], s_cidx, s_pslot, lane);
+    cur[1] = load_cand(A, 1, tab[A.steps * K + prev_code], s_cidx, s_pslot, lane);
+
     for (int s = 0; s < A.steps; ++s) {
-      const int ci0 = tab[s * K + prev_code], ci1 = tab[A.steps * K + s * K + prev_code];
-      bad |= (ci0 < 0) | (ci1 < 0);
-      const int j0 = ci0 < 0 ? 0 : ci0 / A.G0, g0 = ci0 < 0 ? 0 : ci0 - j0 * A.G0;
-      const int j1 = ci1 < 0 ? 0 : ci1 / A.G1, g1 = ci1 < 0 ? 0 : ci1 - j1 * A.G1;
-      const int ps0 = A.pslot0[g0], ps1 = A.pslot1[g1];
-      // phase blocks: rows [ps, ps+8) and [ps+24, ps+32) are 128 contiguous floats each (GestureKNN.py:632-637)
-      {
-        const float* b0 = A.phase + ((int64_t)j0 * A.Tp + ps0) * 16;
-        const float* b1 = A.phase + ((int64_t)j1 * A.Tp + ps1) * 16;
-        const float2 h0 = reinterpret_cast<const float2*>(b0)[lane], t0 = reinterpret_cast<const float2*>(b0 + 384)[lane];
-        const float2 h1 = reinterpret_cast<const float2*>(b1)[lane], t1 = reinterpret_cast<const float2*>(b1 + 384)[lane];
-        reinterpret_cast<float2*>(blk[0][0])[lane] = h0;
-        reinterpret_cast<float2*>(blk[0][1])[lane] = t0;
-        reinterpret_cast<float2*>(blk[1][0])[lane] = h1;
-        reinterpret_cast<float2*>(blk[1][1])[lane] = t1;
-      }
-      // the winner's 4 codes, fetched for both candidates now so the loads overlap the gate arithmetic
-      int pay = 0;
-      if (lane < 8) {
-        const int k = lane >> 2, o = lane & 3;
-        const int col = (k ? A.cidx1[g1] : A.cidx0[g0]) + o;
-        pay = A.code[(int64_t)(k ? j1 : j0) * A.code_ld + col];
+      bad |= cur[0].absent | cur[1].absent;
+      reinterpret_cast<float2*>(blk[0][0])[lane] = cur[0].head;
+      reinterpret_cast<float2*>(blk[0][1])[lane] = cur[0].tail;
+      reinterpret_cast<float2*>(blk[1][0])[lane] = cur[1].head;
+      reinterpret_cast<float2*>(blk[1][1])[lane] = cur[1].tail;
+      // speculation: the last payload code of either candidate is the next step's previous code
+      CandRegs nxt[2][2];
+      const bool spec = s + 1 < A.steps;
+      if (spec) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int pn = __shfl(cur[k].pay, 3, 64);
+          nxt[k][0] = load_cand(A, 0, tab[(s + 1) * K + pn], s_cidx, s_pslot, lane);
+          nxt[k][1] = load_cand(A, 1, tab[A.steps * K + (s + 1) * K + pn], s_cidx, s_pslot, lane);
+        }
       }
       __syncthreads();
       // gate vectors: a = [prev[-5:], head[:3]], b = [prev[-3:], head[:5]]  (GestureKNN.py:636)
@@ -245,21 +278,26 @@ __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
       __syncthreads();
       const int fi = (score[1] < score[0]) ? 1 : 0;            // list.index(min): first on ties
       // append the winner's 4 codes, carry its last-8-frame block (GestureKNN.py:648-657)
-      prev[lane] = blk[fi][1][lane];
-      prev[lane + 64] = blk[fi][1][lane + 64];
+      const float t0 = blk[fi][1][lane], t1 = blk[fi][1][lane + 64];
+      prev[lane] = t0;
+      prev[lane + 64] = t1;
       float* op = A.out_phase + ((int64_t)w * A.steps + s) * 128;
-      op[lane] = blk[fi][1][lane];
-      op[lane + 64] = blk[fi][1][lane + 64];
-      if (lane < 8 && (lane >> 2) == fi) wincodes[s * A.step_codes + (lane & 3)] = pay;
+      op[lane] = t0;
+      op[lane + 64] = t1;
+      const int wpay = fi ? cur[1].pay : cur[0].pay;
+      if (lane < A.step_codes) wincodes[s * A.step_codes + lane] = wpay;
       if (lane == 0) A.out_vote[w * A.steps + s] = fi;
+      prev_code = __shfl(wpay, A.step_codes - 1, 64);
+      if (spec) {
+        cur[0] = fi ? nxt[1][0] : nxt[0][0];
+        cur[1] = fi ? nxt[1][1] : nxt[0][1];
+      }
       __syncthreads();
-      prev_code = wincodes[s * A.step_codes + A.step_codes - 1];
     }
     // window result = first codes_per_window codes; the next window is seeded by the LAST KEPT code
     // (motion_output[-1][-1], GestureKNN.py:800) and the last phase block.
     if (lane < A.codes_per_window) A.out_codes[(int64_t)w * A.codes_per_window + lane] = wincodes[lane];
-    prev_code = wincodes[A.codes_per_window - 1];
-    __syncthreads();
+    prev_code = wincodes[last_idx];
   }
   if (lane == 0) A.out_status[0] = bad;
 }
@@ -280,7 +318,7 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   QPG_REQUIRE(mode == QPG_MODE_AUD || (txt_rank && txt_idx && txt_cidx && txt_pslot && Gt > 0),
               "qpg_match_steps: text tables missing");
   QPG_REQUIRE(M >= 0 && steps > 0 && steps * 4 <= 64 && K > 0 && K <= 64 * QPG_KMAX_PER_LANE && (K % 4) == 0 &&
-                  seed_code >= 0 && seed_code < K,
+                  seed_code >= 0 && seed_code < K && Ga <= 64 && Gt <= 64,
               "qpg_match_steps: bad size");
   const size_t lds = (size_t)2 * steps * K * sizeof(int32_t);
   QPG_REQUIRE(lds <= 96 * 1024, "qpg_match_steps: steps*K too large for the LDS gate tables");

@@ -1,0 +1,140 @@
+"""Full-size (BASELINE.json configs[1]/[2] scale) checks of the sweeps on the MI355X.
+
+At N_db = 2048 the oracle's C port still finishes in seconds on the GPU box's host cores, so the
+(Q,512) tables are compared directly; on top of that come size-independent properties of the path:
+planted exact matches (distance 0 wins its code), exact duplicates (lowest index wins), row-shard
+invariance, and empty / ragged shapes."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _db(N, seed, F=1024, dup=None, plant=None):
+    from qpgesture_amd import synth
+    from qpgesture_amd.data_processing import interp_wavlm
+    tr = synth.make_db(N, seed, F)
+    interp = interp_wavlm(tr["wavlm"])
+    ctx = np.ascontiguousarray(tr["context"].squeeze(2))
+    code = synth.make_codes(N, seed + 1)
+    return dict(interp=interp, ctx=ctx, code=code, phase=tr["phase_dense"], sig=synth.make_signature(seed + 2))
+
+
+def test_fullsize_tables_vs_c_oracle():
+    """N_db = 2048, Q = 48 (the bench workload): every per-code winner equals the C port's (which is
+    bit-identical to the reference), text distances bit-exact, audio distances to 1e-13."""
+    import torch
+    from oracle import cref, knn_oracle as O
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    from qpgesture_amd.data_processing import interp_wavlm
+    N, M = 2048, 6
+    A = _db(N, 100)
+    te = synth.make_db(M, 200)
+    te_i = interp_wavlm(te["wavlm"])
+    te_c = np.ascontiguousarray(te["context"].squeeze(2))
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    T = knn.sweep_tables(torch.from_numpy(te_i).cuda(), torch.from_numpy(te_c).cuda(), M)
+    cores = os.cpu_count() or 1
+    q = np.stack([O.wavlm_feat_rows(te_i, w, [24 * s])[0] for w in range(M) for s in range(8)])
+    d_ref, i_ref = cref.audio_scan(A["interp"], np.arange(26) * 6, A["code"], np.arange(26), q, n_threads=cores)
+    assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref)
+    assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+    qt = np.stack([te_c[w][int(24 * s / 180 * 30)] for w in range(M) for s in range(8)])
+    dt_ref, it_ref = cref.text_scan(A["ctx"], np.arange(26), A["code"], np.arange(26), qt, n_threads=cores)
+    assert np.array_equal(T["txt_d"].cpu().numpy(), dt_ref)
+    assert np.array_equal(T["txt_idx"].cpu().numpy(), it_ref)
+    want = np.argsort(np.argsort(d_ref, axis=1, kind="stable"), axis=1, kind="stable")
+    assert np.array_equal(T["aud_rank"].cpu().numpy(), want)
+
+
+def test_planted_match_and_duplicates():
+    """A query that IS a database candidate gets distance ~0 for that candidate's code and wins it; an exact
+    duplicate of that window later in the DB ties and must lose (first wins == lowest index)."""
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    N = 300
+    A = _db(N, 300)
+    A["interp"][250] = A["interp"][17]            # window 250 duplicates window 17
+    A["ctx"][250] = A["ctx"][17]
+    A["code"][250] = A["code"][17]
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    # query window = DB window 17: query step s (t=24s) is candidate g=4s of window 17
+    te_i = torch.from_numpy(A["interp"][17:18].copy()).cuda()
+    te_c = torch.from_numpy(A["ctx"][17:18].copy()).cuda()
+    T = knn.sweep_tables(te_i, te_c, 1)
+    aud_d, aud_i = T["aud_d"].cpu().numpy(), T["aud_idx"].cpu().numpy()
+    for s in range(7):                            # t = 24 s <= 150 is on the candidate grid
+        g = 4 * s
+        c = int(A["code"][17, g])
+        assert aud_i[s, c] == 17 * 26 + g, (s, aud_i[s, c])
+        assert abs(aud_d[s, c]) < 1e-15
+    txt_d, txt_i = T["txt_d"].cpu().numpy(), T["txt_idx"].cpu().numpy()
+    for s in range(7):
+        r = int(24 * s / 180 * 30)                # query row r == candidate row r of window 17
+        c = int(A["code"][17, r])
+        assert txt_i[s, c] == 17 * 26 + r and txt_d[s, c] == 0.0
+
+
+def test_ragged_and_small_shapes():
+    """N not a multiple of any tile, a single DB window, one query window, and codes absent from the DB."""
+    import torch
+    from oracle import cref, knn_oracle as O
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    from qpgesture_amd.data_processing import interp_wavlm
+    for N in (1, 3, 37):
+        A = _db(N, 400 + N, F=128)
+        te = synth.make_db(1, 500 + N, 128)
+        te_i = interp_wavlm(te["wavlm"])
+        te_c = np.ascontiguousarray(te["context"].squeeze(2))
+        db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+        knn = CodeKNN(db, rng=np.random.RandomState(1))
+        T = knn.sweep_tables(torch.from_numpy(te_i).cuda(), torch.from_numpy(te_c).cuda(), 1)
+        q = np.stack([O.wavlm_feat_rows(te_i, 0, [24 * s])[0] for s in range(8)])
+        d_ref, i_ref = cref.audio_scan(A["interp"], np.arange(26) * 6, A["code"], np.arange(26), q)
+        assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref)
+        absent = i_ref < 0
+        assert absent.any() == (N * 26 < 512)                            # few windows: most codes never occur
+        assert np.all(T["aud_d"].cpu().numpy()[absent] == 1e3)           # the reference's placeholder (:668)
+        assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+        qt = np.stack([te_c[0][int(24 * s / 180 * 30)] for s in range(8)])
+        dt_ref, it_ref = cref.text_scan(A["ctx"], np.arange(26), A["code"], np.arange(26), qt)
+        assert np.array_equal(T["txt_d"].cpu().numpy(), dt_ref) and np.array_equal(T["txt_idx"].cpu().numpy(), it_ref)
+
+
+def test_absent_code_winning_raises_like_reference():
+    """With one DB window almost every code is absent; the rank fusion then picks an absent code at some
+    step and the reference fails with IndexError (aux[index] == [], GestureKNN.py:631-632) — so do we."""
+    import torch
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    from qpgesture_amd.data_processing import interp_wavlm
+    A = _db(1, 600, F=128)
+    A["code"][:] = 7                                                       # a single code in the whole DB
+    te = synth.make_db(1, 601, 128)
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(3))
+    with pytest.raises(IndexError):
+        # previous code is 7 itself -> pos_dist[7] = inf -> its fused rank is worst -> an absent code wins
+        knn.match_clip(torch.from_numpy(interp_wavlm(te["wavlm"])).cuda(),
+                       torch.from_numpy(np.ascontiguousarray(te["context"].squeeze(2))).cuda(), 1)
+
+
+def test_empty_inputs():
+    import torch
+    from qpgesture_amd import _lib
+    dev = torch.device("cuda:0")
+    z = torch.zeros((1,), device=dev)
+    zi = torch.zeros((1,), dtype=torch.int32, device=dev)
+    # Q = 0 / N = 0 are no-ops that succeed (they must not launch with a zero-sized grid)
+    _lib.call("qpg_audio_cosine_f64", dev, z, 0, 180, 1024, zi, 26, 6, 2, z.double(), z, z.double(), 0, z.double(), 0)
+    _lib.call("qpg_text_cosine_f32", dev, z, 0, 384, z, 0, z, 0)
+    _lib.call("qpg_rank_rows_f32", dev, z, 0, 512, zi.to(torch.int16))
+    with pytest.raises(RuntimeError, match="F % 128"):
+        _lib.call("qpg_audio_cosine_f64", dev, z, 1, 180, 100, zi, 26, 6, 2, z.double(), z, z.double(), 1,
+                  z.double(), 26)
