@@ -141,7 +141,10 @@ def main():
     achieved = flops / (k_ms * 1e-3) / 1e12
     alg_bytes = db.n_local * 81 * db.F * 4 + C * 8 + Q * 6 * db.F * 8 + Q * C * 8
     roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4),
+                # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
+                # measured for exactly this launch shape only: profiles/r01_pmc_audio.md
+                "traffic": 942_000_000 if (world == 1 and N == 2048 and M == 6) else None,
                 "kernel": "audio_cosine_f64_kernel", "kernel_ms": round(k_ms, 4),
                 "algorithmic_gflop": round(flops / 1e9, 3),
                 "algorithmic_bytes": int(alg_bytes),
