@@ -187,7 +187,8 @@ def main():
 
 def vqvae_bench(dev, a, world, rank):
     """Second half of BASELINE.json's metric: gesture VQ-VAE encode (and decode) frames/s.  Each rank encodes
-    its own batch of 64 pose windows (240 frames x 135) — pure data parallel, no collective — with the
+    its own batch of 256 pose windows (240 frames x 135: dataset_to_code over a speaker DB runs in such
+    batches) — pure data parallel, no collective — with the
     full-size codebook.yml architecture and seeded weights; the decode leg decodes one 24 s clip's worth of
     codes per rank in one pass (1440 frames)."""
     import torch
@@ -195,7 +196,7 @@ def vqvae_bench(dev, a, world, rank):
     from qpgesture_amd import synth
     from qpgesture_amd.vqvae import VQVAE
     model = VQVAE(None, 135, device=dev).load_state_dict(synth.make_vqvae_state_dict(7))
-    Bw = 64
+    Bw = 256
     x = torch.randn((Bw, 240, 135), device=dev)
     ids = torch.randint(0, 512, (1, 180), device=dev)
 
@@ -219,7 +220,7 @@ def vqvae_bench(dev, a, world, rank):
     td = timed(lambda: model.decode([ids]), 10)
     enc_flop = 1.639e9 * Bw                                        # 1.639 GFLOP per 240-frame window
     return {"vqvae_encode_frames_per_s": round(240 * Bw * world / te, 1),
-            "vqvae_encode_ms_per_batch64": round(te * 1e3, 3),
+            "vqvae_encode_ms_per_batch256": round(te * 1e3, 3),
             "vqvae_encode_tflops_f32": round(enc_flop / te / 1e12, 2),
             "vqvae_decode_frames_per_s": round(1440 * world / td, 1),
             "vqvae_decode_ms_per_24s_clip": round(td * 1e3, 3)}

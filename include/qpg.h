@@ -210,6 +210,42 @@ int qpg_vq_argmin_f32(qpg_ctx*, void* stream, const float* z, const float* dot, 
 int qpg_vq_gather_f32(qpg_ctx*, void* stream, const float* k, const int64_t* ids, int64_t R, int E, int K, float* out,
                       int32_t* status);
 
+/* Whole-network entry points: VQVAE.encode / VQVAE.decode (vqvae.py:152-181) as ONE call each, the layer
+ * sequence of encdec.py:53-136 issued from C on the caller's stream (no host round trips between layers).
+ * The model is a plain descriptor of repacked device tensors filled by the caller (qpgesture_amd/vqvae.py
+ * builds it from the reference checkpoint's state_dict). */
+#define QPG_VQ_MAX_DOWN 4
+#define QPG_VQ_MAX_DEPTH 4
+typedef struct {
+  const float* w;    /* [dev] [taps][cin_pad][cout_pad] */
+  const float* b;    /* [dev] [cout_pad] or NULL */
+  int32_t taps, cin, cin_pad, cout, cout_pad;
+} qpg_conv_desc;
+typedef struct {
+  int32_t in_dim, width, emb, bins, down_t, depth, growth, reverse_dec;
+  qpg_conv_desc enc_down[QPG_VQ_MAX_DOWN];                       /* Conv1d k4 s2 p1              (encdec.py:20) */
+  qpg_conv_desc enc_res[QPG_VQ_MAX_DOWN][QPG_VQ_MAX_DEPTH][2];   /* [..][d][0] k3 dilated, [1] 1x1 (resnet.py:31-46) */
+  qpg_conv_desc enc_out;                                         /* Conv1d k3                    (encdec.py:24) */
+  qpg_conv_desc dec_in;                                          /* Conv1d k3                    (encdec.py:39) */
+  qpg_conv_desc dec_res[QPG_VQ_MAX_DOWN][QPG_VQ_MAX_DEPTH][2];
+  qpg_conv_desc dec_up_even[QPG_VQ_MAX_DOWN];                    /* ConvTranspose1d k4 s2 p1, output parity 0/1 (encdec.py:45) */
+  qpg_conv_desc dec_up_odd[QPG_VQ_MAX_DOWN];
+  qpg_conv_desc dec_out;                                         /* Conv1d k3 -> in_dim          (encdec.py:113) */
+  qpg_conv_desc kT;                                              /* codebook^T as a 1-tap conv   (bottleneck.py:123) */
+  const float* k;                                                /* [dev] [bins][emb] */
+  const float* kk;                                               /* [dev] [bins] sum_e k^2 */
+} qpg_vq_model;
+
+/* floats of scratch the two calls below need for a batch of B sequences of T pose frames */
+int64_t qpg_vq_workspace_floats(const qpg_vq_model* m, int B, int T);
+/* x: [dev] f32 [B][T][in_dim] (T %% 2^down_t == 0) -> ids [dev] i64 [B][T/2^down_t]; latent: optional [dev] f32
+ * [B][T/2^down_t][emb] (pre-quantisation encoder output); margin: optional [dev] f32 [B][T/2^down_t] runner-up minus best. */
+int qpg_vq_encode_f32(qpg_ctx*, void* stream, const qpg_vq_model* m, const float* x, int B, int T, float* ws,
+                      int64_t ws_floats, int64_t* ids, float* latent, float* margin);
+/* ids: [dev] i64 [B][L] -> out [dev] f32 [B][L*2^down_t][in_dim]; status [dev] i32: 1 if an id was out of range. */
+int qpg_vq_decode_f32(qpg_ctx*, void* stream, const qpg_vq_model* m, const int64_t* ids, int B, int L, float* ws,
+                      int64_t ws_floats, float* out, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

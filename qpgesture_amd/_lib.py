@@ -42,8 +42,31 @@ _SIGS = {
     "qpg_conv1d_f32": [P, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, P],
     "qpg_vq_argmin_f32": [P, P, P, L, I, I, P, P, P],
     "qpg_vq_gather_f32": [P, P, L, I, I, P, P],
+    "qpg_vq_encode_f32": [P, P, I, I, P, L, P, P, P],
+    "qpg_vq_decode_f32": [P, P, I, I, P, L, P, P],
     "qpg_match_steps": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P],
 }
+
+
+QPG_VQ_MAX_DOWN, QPG_VQ_MAX_DEPTH = 4, 4
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("taps", ctypes.c_int32), ("cin", ctypes.c_int32),
+                ("cin_pad", ctypes.c_int32), ("cout", ctypes.c_int32), ("cout_pad", ctypes.c_int32)]
+
+
+class VqModel(ctypes.Structure):
+    """qpg_vq_model of include/qpg.h."""
+    _fields_ = [("in_dim", ctypes.c_int32), ("width", ctypes.c_int32), ("emb", ctypes.c_int32),
+                ("bins", ctypes.c_int32), ("down_t", ctypes.c_int32), ("depth", ctypes.c_int32),
+                ("growth", ctypes.c_int32), ("reverse_dec", ctypes.c_int32),
+                ("enc_down", ConvDesc * QPG_VQ_MAX_DOWN),
+                ("enc_res", ((ConvDesc * 2) * QPG_VQ_MAX_DEPTH) * QPG_VQ_MAX_DOWN),
+                ("enc_out", ConvDesc), ("dec_in", ConvDesc),
+                ("dec_res", ((ConvDesc * 2) * QPG_VQ_MAX_DEPTH) * QPG_VQ_MAX_DOWN),
+                ("dec_up_even", ConvDesc * QPG_VQ_MAX_DOWN), ("dec_up_odd", ConvDesc * QPG_VQ_MAX_DOWN),
+                ("dec_out", ConvDesc), ("kT", ConvDesc), ("k", c_void_p), ("kk", c_void_p)]
 
 
 def declared_symbols():
@@ -68,6 +91,8 @@ def load():
     lib.qpg_ctx_create.restype = c_int
     lib.qpg_ctx_destroy.argtypes = [c_void_p]
     lib.qpg_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    lib.qpg_vq_workspace_floats.argtypes = [c_void_p, c_int, c_int]
+    lib.qpg_vq_workspace_floats.restype = c_int64
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = [c_void_p, c_void_p] + sig
@@ -107,7 +132,8 @@ def call(name, device, *args):
     """Invoke a C-ABI entry point on torch's current stream of `device`; raise on error."""
     lib = load()
     stream = torch.cuda.current_stream(device).cuda_stream
-    conv = [ptr(a) if isinstance(a, torch.Tensor) else a for a in args]
+    conv = [ptr(a) if isinstance(a, torch.Tensor) else (ctypes.byref(a) if isinstance(a, ctypes.Structure) else a)
+            for a in args]
     rc = getattr(lib, name)(ctx(device), c_void_p(stream), *conv)
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, last_error()))

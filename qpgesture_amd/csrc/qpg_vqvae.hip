@@ -12,14 +12,13 @@
 // Weights are repacked once at load to [tap][Cin_pad][Cout_pad] (K-major rows, output channel
 // contiguous, zero padded to the tile) so the B operand needs no guards.
 //
-// Tile: 64 positions x 128 channels per 256-thread block, 4 waves = 2(M) x 2(N), each wave two
-// 32x32 MFMA tiles; K advances in 16-wide slices staged through LDS (A rows padded to 17 floats:
+// Tile: 64 or 128 positions x 128 channels per 256-thread block, 4 waves = 2(M) x 2(N), each wave 1x2 or
+// 2x2 32x32 MFMA tiles; K advances in 16-wide slices staged through LDS (A rows padded to 17 floats:
 // conflict-free column reads; B rows read along the channel axis: conflict-free).  Fused in the
 // epilogue: bias, optional ReLU, optional residual add; fused in the A load: optional input ReLU
 // (ResConv1DBlock = x + conv1x1(relu(conv3_dil(relu(x)))), resnet.py:31-46).
 #include "qpg_common.h"
 
-#define CV_BM 64
 #define CV_BN 128
 #define CV_BK 16
 
@@ -36,18 +35,25 @@ struct ConvArgs {
   int relu_in, relu_out;
 };
 
+// MT = 32-row MFMA tiles per wave along M (block tile = 64*MT positions x 128 channels); VEC = 16-B loads of
+// the activation rows (needs Cin % 4 == 0; the 135-channel input layer takes the scalar path).
+// The next K slice's global loads are issued into registers before the current slice's MFMAs (register
+// double-buffer), so HBM/L2 latency overlaps the matrix pipe with a single LDS buffer.
+template <int MT, bool VEC>
 __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
-  __shared__ float As[CV_BM][CV_BK + 1];
+  constexpr int BM = 64 * MT;
+  constexpr int AR = BM * CV_BK / 256;                 // A floats per thread per slice: 4 (MT=1) or 8 (MT=2)
+  __shared__ float As[BM][CV_BK + 1];
   __shared__ __attribute__((aligned(16))) float Bs[CV_BK][CV_BN];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w & 1, wn = w >> 1;
   const int64_t M = (int64_t)a.B * a.T_out;
-  const int64_t m0 = (int64_t)blockIdx.x * CV_BM;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * CV_BN;
 
-  // A staging: thread -> (row, 4 consecutive k)
-  const int ar = tid >> 2, ak = (tid & 3) * 4;
+  // A staging: thread -> (row, AR consecutive k)
+  const int ar = tid / (CV_BK / AR), ak = (tid % (CV_BK / AR)) * AR;
   const int64_t am = m0 + ar;
   const bool a_live = am < M;
   const int ab = a_live ? (int)(am / a.T_out) : 0;
@@ -55,39 +61,67 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
   // B staging: thread -> (k row, 8 consecutive n)
   const int bk = tid >> 4, bn = (tid & 15) * 8;
 
-  f32x16 acc0, acc1;
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][h][i] = 0.f;
 
-  for (int tap = 0; tap < a.taps; ++tap) {
+  const int nslice = a.Cin_pad / CV_BK;
+  const int total = a.taps * nslice;
+  float av[AR];
+  f32x4 b0, b1;
+  auto fetch = [&](int it) {
+    const int tap = it / nslice, c0 = (it - tap * nslice) * CV_BK;
     const int t_in = at * a.in_stride + a.in_offset + tap * a.dil;
     const bool t_ok = a_live && t_in >= 0 && t_in < a.T_in;
-    const float* xrow = a.x + ((int64_t)ab * a.T_in + (t_ok ? t_in : 0)) * a.Cin;
-    const float* wtap = a.w + (int64_t)tap * a.Cin_pad * a.Cout_pad;
-    for (int c0 = 0; c0 < a.Cin_pad; c0 += CV_BK) {
-      float av[4];
+    const float* xrow = a.x + ((int64_t)ab * a.T_in + (t_ok ? t_in : 0)) * a.Cin + c0 + ak;
+    if (VEC) {
+      // Cin % 4 == 0 and Cin_pad == round_up(Cin,16): a 4-group is either fully inside or fully outside
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ci = c0 + ak + i;
-        float v = (t_ok && ci < a.Cin) ? xrow[ci] : 0.f;
-        if (a.relu_in) v = fmaxf(v, 0.f);
-        av[i] = v;
+      for (int v = 0; v < AR / 4; ++v) {
+        const bool ok = t_ok && (c0 + ak + 4 * v) < a.Cin;
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(ok ? xrow + 4 * v : a.x);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[4 * v + i] = ok ? x4[i] : 0.f;
       }
-      const float* wp = wtap + (int64_t)(c0 + bk) * a.Cout_pad + n0 + bn;
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(wp), b1 = *reinterpret_cast<const f32x4*>(wp + 4);
-      __syncthreads();   // previous slice fully consumed
+    } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) As[ar][ak + i] = av[i];
-      *reinterpret_cast<f32x4*>(&Bs[bk][bn]) = b0;
-      *reinterpret_cast<f32x4*>(&Bs[bk][bn + 4]) = b1;
-      __syncthreads();
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = t_ok && (c0 + ak + i) < a.Cin;
+        const float x1 = *(ok ? xrow + i : a.x);
+        av[i] = ok ? x1 : 0.f;
+      }
+    }
+    if (a.relu_in) {
 #pragma unroll
-      for (int ks = 0; ks < CV_BK / 2; ++ks) {
-        const int k = ks * 2 + (lane >> 5);
-        const float av_ = As[wm * 32 + (lane & 31)][k];
-        const float bv0 = Bs[k][wn * 64 + (lane & 31)], bv1 = Bs[k][wn * 64 + 32 + (lane & 31)];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bv0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bv1, acc1, 0, 0, 0);
+      for (int i = 0; i < AR; ++i) av[i] = fmaxf(av[i], 0.f);
+    }
+    const float* wp = a.w + ((int64_t)tap * a.Cin_pad + c0 + bk) * a.Cout_pad + n0 + bn;
+    b0 = *reinterpret_cast<const f32x4*>(wp);
+    b1 = *reinterpret_cast<const f32x4*>(wp + 4);
+  };
+
+  fetch(0);
+  for (int it = 0; it < total; ++it) {
+    __syncthreads();   // previous slice fully consumed
+#pragma unroll
+    for (int i = 0; i < AR; ++i) As[ar][ak + i] = av[i];
+    *reinterpret_cast<f32x4*>(&Bs[bk][bn]) = b0;
+    *reinterpret_cast<f32x4*>(&Bs[bk][bn + 4]) = b1;
+    __syncthreads();
+    if (it + 1 < total) fetch(it + 1);   // in flight during the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < CV_BK / 2; ++ks) {
+      const int k = ks * 2 + (lane >> 5);
+      const float bv0 = Bs[k][wn * 64 + (lane & 31)], bv1 = Bs[k][wn * 64 + 32 + (lane & 31)];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float av_ = As[(wm * MT + mt) * 32 + (lane & 31)][k];
+        acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bv0, acc[mt][0], 0, 0, 0);
+        acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bv1, acc[mt][1], 0, 0, 0);
       }
     }
   }
@@ -99,17 +133,20 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
     if (n >= a.Cout) continue;
     const float bias = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int64_t m = m0 + wm * 32 + row;
-      if (m >= M) continue;
-      const int b = (int)(m / a.T_out);
-      const int t = (int)(m - (int64_t)b * a.T_out);
-      const int64_t o = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout + n;
-      float v = (half ? acc1[r] : acc0[r]) + bias;
-      if (a.relu_out) v = fmaxf(v, 0.f);
-      if (a.res) v = a.res[o] + v;
-      a.y[o] = v;
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int64_t m = m0 + (wm * MT + mt) * 32 + row;
+        if (m >= M) continue;
+        const int b = (int)(m / a.T_out);
+        const int t = (int)(m - (int64_t)b * a.T_out);
+        const int64_t o = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout + n;
+        float v = acc[mt][half][r] + bias;
+        if (a.relu_out) v = fmaxf(v, 0.f);
+        if (a.res) v = a.res[o] + v;
+        a.y[o] = v;
+      }
     }
   }
 }
@@ -131,8 +168,16 @@ extern "C" int qpg_conv1d_f32(qpg_ctx* ctx, void* stream, const float* x, int B,
   a.in_stride = in_stride; a.in_offset = in_offset; a.dil = dil; a.T_out = T_out;
   a.out_stride = out_stride; a.out_offset = out_offset; a.T_y = T_y; a.relu_in = relu_in; a.relu_out = relu_out;
   const int64_t M = (int64_t)B * T_out;
-  dim3 grid((unsigned)((M + CV_BM - 1) / CV_BM), (unsigned)(Cout_pad / CV_BN));
-  hipLaunchKernelGGL(conv1d_mfma_f32_kernel, grid, dim3(256), 0, qpg_stream(stream), a);
+  const bool vec = (Cin % 4) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0;
+  // 128-row tiles once there are enough rows to fill the chip with them, 64-row tiles for short sequences
+  const bool big = M * (Cout_pad / CV_BN) >= (int64_t)128 * 2 * ctx->n_cu;
+  const int BM = big ? 128 : 64;
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(Cout_pad / CV_BN));
+  hipStream_t st = qpg_stream(stream);
+  if (big && vec) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<2, true>), grid, dim3(256), 0, st, a);
+  else if (big) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<2, false>), grid, dim3(256), 0, st, a);
+  else if (vec) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<1, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv1d_mfma_f32_kernel<1, false>), grid, dim3(256), 0, st, a);
   QPG_LAUNCH_CHECK("conv1d_mfma_f32_kernel");
   return QPG_OK;
 }
@@ -221,4 +266,129 @@ extern "C" int qpg_vq_gather_f32(qpg_ctx* ctx, void* stream, const float* k, con
                      E, K, out, status);
   QPG_LAUNCH_CHECK("vq_gather_kernel");
   return QPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole-network orchestration (host C++): the layer sequences of Encoder / Decoder (encdec.py:53-136)
+// issued back to back on the caller's stream.  Scratch = three [B][T_max][width] buffers.
+// ---------------------------------------------------------------------------------------------
+static int conv_call(qpg_ctx* ctx, void* stream, const qpg_conv_desc& c, const float* x, int B, int T_in, int in_stride,
+                     int in_offset, int dil, int T_out, int out_stride, int out_offset, int T_y, const float* res,
+                     int relu_in, int relu_out, float* y) {
+  return qpg_conv1d_f32(ctx, stream, x, B, T_in, c.cin, c.w, c.b, c.taps, c.cin_pad, c.cout, c.cout_pad, in_stride,
+                        in_offset, dil, T_out, out_stride, out_offset, T_y, res, relu_in, relu_out, y);
+}
+
+static int ipow(int b, int e) {
+  int r = 1;
+  while (e-- > 0) r *= b;
+  return r;
+}
+
+static bool model_ok(const qpg_vq_model* m) {
+  return m && m->down_t > 0 && m->down_t <= QPG_VQ_MAX_DOWN && m->depth > 0 && m->depth <= QPG_VQ_MAX_DEPTH &&
+         m->width > 0 && m->emb > 0 && m->bins > 0 && m->in_dim > 0 && m->growth > 0 && m->k && m->kk;
+}
+
+extern "C" int64_t qpg_vq_workspace_floats(const qpg_vq_model* m, int B, int T) {
+  if (!model_ok(m) || B < 0 || T < 0) return -1;
+  int64_t cmax = m->width > m->emb ? m->width : m->emb;
+  if (m->bins > cmax) cmax = m->bins;
+  return 3 * (int64_t)B * T * cmax + 64;
+}
+
+// x + conv1x1(relu(conv3_dil(relu(x)))) for each block; ping-pongs between cur and alt, h is the hidden buffer
+static int resnet_run(qpg_ctx* ctx, void* stream, const qpg_conv_desc (*blocks)[2], int depth, int growth, bool reverse,
+                      int B, int T, float*& cur, float*& alt, float* h) {
+  for (int d = 0; d < depth; ++d) {
+    const int dil = ipow(growth, reverse ? depth - 1 - d : d);                       // resnet.py:57-62
+    int rc = conv_call(ctx, stream, blocks[d][0], cur, B, T, 1, -dil, dil, T, 1, 0, T, nullptr, 1, 1, h);
+    if (rc) return rc;
+    rc = conv_call(ctx, stream, blocks[d][1], h, B, T, 1, 0, 1, T, 1, 0, T, cur, 0, 0, alt);
+    if (rc) return rc;
+    float* t = cur; cur = alt; alt = t;
+  }
+  return QPG_OK;
+}
+
+extern "C" int qpg_vq_encode_f32(qpg_ctx* ctx, void* stream, const qpg_vq_model* m, const float* x, int B, int T,
+                                 float* ws, int64_t ws_floats, int64_t* ids, float* latent, float* margin) {
+  QPG_REQUIRE(ctx && model_ok(m) && x && ws && ids, "qpg_vq_encode_f32: bad argument");
+  const int hop = ipow(2, m->down_t);
+  QPG_REQUIRE(B >= 0 && T > 0 && T % hop == 0, "qpg_vq_encode_f32: T must be a multiple of %d", hop);
+  QPG_REQUIRE(ws_floats >= qpg_vq_workspace_floats(m, B, T), "qpg_vq_encode_f32: workspace too small");
+  if (B == 0) return QPG_OK;
+  int64_t cmax = m->width > m->emb ? m->width : m->emb;
+  if (m->bins > cmax) cmax = m->bins;
+  const int64_t slab = (((int64_t)B * T * cmax + 3) / 4) * 4;                          // T/2 rows suffice; keep simple
+  float *cur = ws, *alt = ws + slab, *h = ws + 2 * slab;
+  const float* in = x;
+  int Tc = T;
+  for (int i = 0; i < m->down_t; ++i) {
+    const int To = Tc / 2;
+    int rc = conv_call(ctx, stream, m->enc_down[i], in, B, Tc, 2, -1, 1, To, 1, 0, To, nullptr, 0, 0, alt);
+    if (rc) return rc;
+    { float* t = cur; cur = alt; alt = t; }
+    Tc = To;
+    rc = resnet_run(ctx, stream, m->enc_res[i], m->depth, m->growth, false, B, Tc, cur, alt, h);
+    if (rc) return rc;
+    in = cur;
+  }
+  float* z = latent ? latent : alt;
+  int rc = conv_call(ctx, stream, m->enc_out, cur, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, z);
+  if (rc) return rc;
+  // quantise: dot = z . k^T (1-tap conv over the flattened rows), then the argmin kernel
+  const int64_t R = (int64_t)B * Tc;
+  QPG_REQUIRE(R < 0x7fffffffll, "qpg_vq_encode_f32: too many latent rows");
+  float* dot = h;
+  rc = conv_call(ctx, stream, m->kT, z, 1, (int)R, 1, 0, 1, (int)R, 1, 0, (int)R, nullptr, 0, 0, dot);
+  if (rc) return rc;
+  float* dmin = margin ? cur : nullptr;                                               // cur is free now
+  rc = qpg_vq_argmin_f32(ctx, stream, z, dot, m->kk, R, m->emb, m->bins, ids, dmin, margin);
+  if (rc) return rc;
+  if (margin) {   // margin currently holds the runner-up distance: subtract the minimum in place
+    extern void qpg_launch_sub_inplace(void* stream, float* a, const float* b, int64_t n);
+    qpg_launch_sub_inplace(stream, margin, dmin, R);
+    QPG_LAUNCH_CHECK("sub_inplace_kernel");
+  }
+  return QPG_OK;
+}
+
+__global__ void sub_inplace_kernel(float* a, const float* b, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = a[i] - b[i];
+}
+void qpg_launch_sub_inplace(void* stream, float* a, const float* b, int64_t n) {
+  hipLaunchKernelGGL(sub_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, qpg_stream(stream), a, b, n);
+}
+
+extern "C" int qpg_vq_decode_f32(qpg_ctx* ctx, void* stream, const qpg_vq_model* m, const int64_t* ids, int B, int L,
+                                 float* ws, int64_t ws_floats, float* out, int32_t* status) {
+  QPG_REQUIRE(ctx && model_ok(m) && ids && ws && out, "qpg_vq_decode_f32: bad argument");
+  QPG_REQUIRE(B >= 0 && L > 0 && (m->emb % 4) == 0, "qpg_vq_decode_f32: bad size");
+  const int hop = ipow(2, m->down_t);
+  const int T = L * hop;
+  QPG_REQUIRE(ws_floats >= qpg_vq_workspace_floats(m, B, T), "qpg_vq_decode_f32: workspace too small");
+  if (B == 0) return QPG_OK;
+  int64_t cmax = m->width > m->emb ? m->width : m->emb;
+  if (m->bins > cmax) cmax = m->bins;
+  const int64_t slab = (((int64_t)B * T * cmax + 3) / 4) * 4;
+  float *cur = ws, *alt = ws + slab, *h = ws + 2 * slab;
+  int rc = qpg_vq_gather_f32(ctx, stream, m->k, ids, (int64_t)B * L, m->emb, m->bins, alt, status);   // dequantise
+  if (rc) return rc;
+  int Tc = L;
+  rc = conv_call(ctx, stream, m->dec_in, alt, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, cur);
+  if (rc) return rc;
+  for (int i = 0; i < m->down_t; ++i) {
+    rc = resnet_run(ctx, stream, m->dec_res[i], m->depth, m->growth, m->reverse_dec != 0, B, Tc, cur, alt, h);
+    if (rc) return rc;
+    // ConvTranspose1d(k4,s2,p1): y[2m] = x[m-1].W3 + x[m].W1 ; y[2m+1] = x[m].W2 + x[m+1].W0
+    rc = conv_call(ctx, stream, m->dec_up_even[i], cur, B, Tc, 1, -1, 1, Tc, 2, 0, 2 * Tc, nullptr, 0, 0, alt);
+    if (rc) return rc;
+    rc = conv_call(ctx, stream, m->dec_up_odd[i], cur, B, Tc, 1, 0, 1, Tc, 2, 1, 2 * Tc, nullptr, 0, 0, alt);
+    if (rc) return rc;
+    { float* t = cur; cur = alt; alt = t; }
+    Tc *= 2;
+  }
+  return conv_call(ctx, stream, m->dec_out, cur, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, out);
 }

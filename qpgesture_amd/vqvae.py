@@ -103,8 +103,66 @@ class VQVAE:
         self.k = k.to(dev).contiguous()
         self.kT = _Conv(k.t().contiguous()[None], torch.zeros(self.bins), dev)      # x.k^T as a 1-tap "conv"
         self.kk = torch.sum(k.t() ** 2, dim=0).to(dev).contiguous()                # bottleneck.py:123
+        self._desc = self._build_descriptor()
         self._loaded = True
         return self
+
+    def _build_descriptor(self):
+        """qpg_vq_model (include/qpg.h): pointers into the packed tensors kept alive by this object."""
+        m = _lib.VqModel()
+        m.in_dim, m.width, m.emb, m.bins = self.input_dim, self.width, self.emb, self.bins
+        m.down_t, m.depth, m.growth, m.reverse_dec = self.down_t, self.depth, self.growth, int(self.reverse)
+        if self.down_t > _lib.QPG_VQ_MAX_DOWN or self.depth > _lib.QPG_VQ_MAX_DEPTH:
+            raise NotImplementedError("down_t/depth beyond the descriptor's capacity")
+
+        def fill(d, c):
+            d.w, d.b = c.w.data_ptr(), c.b.data_ptr()
+            d.taps, d.cin, d.cin_pad, d.cout, d.cout_pad = c.taps, c.cin, c.cin_pad, c.cout, c.cout_pad
+        for i, (c, res) in enumerate(self.enc_down):
+            fill(m.enc_down[i], c)
+            for d, (c3, c1) in enumerate(res):
+                fill(m.enc_res[i][d][0], c3)
+                fill(m.enc_res[i][d][1], c1)
+        fill(m.enc_out, self.enc_out)
+        fill(m.dec_in, self.dec_in)
+        for i, (res, even, odd) in enumerate(self.dec_up):
+            for d, (c3, c1) in enumerate(res):
+                fill(m.dec_res[i][d][0], c3)
+                fill(m.dec_res[i][d][1], c1)
+            fill(m.dec_up_even[i], even)
+            fill(m.dec_up_odd[i], odd)
+        fill(m.dec_out, self.dec_out)
+        fill(m.kT, self.kT)
+        m.k, m.kk = self.k.data_ptr(), self.kk.data_ptr()
+        return m
+
+    def _workspace(self, B, T):
+        import ctypes
+        n = _lib.load().qpg_vq_workspace_floats(ctypes.byref(self._desc), B, T)
+        if n < 0:
+            raise RuntimeError("qpg_vq_workspace_floats failed")
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < n:
+            self._ws = ws = torch.empty((n,), dtype=torch.float32, device=self.device)
+        return ws
+
+    def encode_fused(self, x, return_latent=False, return_margin=False):
+        """One C call for the whole encoder + quantiser (qpg_vq_encode_f32)."""
+        assert self._loaded, "load_state_dict first"
+        x = x.to(self.device, torch.float32).contiguous()
+        B, T, _ = x.shape
+        L = T // self.hop
+        ws = self._workspace(B, T)
+        ids = torch.empty((B, L), dtype=torch.int64, device=self.device)
+        lat = torch.empty((B, L, self.emb), dtype=torch.float32, device=self.device) if return_latent else None
+        mar = torch.empty((B, L), dtype=torch.float32, device=self.device) if return_margin else None
+        _lib.call("qpg_vq_encode_f32", self.device, self._desc, x, B, T, ws, ws.numel(), ids, lat, mar)
+        out = (ids,)
+        if return_latent:
+            out += (lat,)
+        if return_margin:
+            out += (mar,)
+        return out if len(out) > 1 else ids
 
     # ------------------------------------------------------------------------------------------
     def _conv(self, c, x, B, T_in, T_out, in_stride=1, in_offset=0, dil=1, out=None, out_stride=1, out_offset=0,
@@ -153,8 +211,26 @@ class VQVAE:
     def encode(self, x, start_level=0, end_level=None, bs_chunks=1):
         """VQVAE.encode (vqvae.py:174-181): returns [LongTensor (B, T/8)]."""
         x = torch.as_tensor(x)
-        outs = [self.quantise(self.encode_latent(xc)) for xc in torch.chunk(x, bs_chunks, dim=0)]
+        outs = [self.encode_fused(xc) for xc in torch.chunk(x, bs_chunks, dim=0)]
         return [torch.cat(outs, dim=0)]
+
+    def decode_layers(self, ids):
+        """Layer-by-layer decode through the per-layer entry points (qpg_vq_gather_f32 + qpg_conv1d_f32);
+        same result as decode(), kept to test those entry points."""
+        ids = torch.as_tensor(ids).to(self.device, torch.int64).contiguous()
+        B, L = ids.shape
+        status = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        x = torch.empty((B, L, self.emb), dtype=torch.float32, device=self.device)
+        _lib.call("qpg_vq_gather_f32", self.device, self.k, ids, B * L, self.emb, self.bins, x, status)
+        T = L
+        x = self._conv(self.dec_in, x, B, T, T, in_offset=-1)
+        for res, even, odd in self.dec_up:
+            x = self._resnet(res, x, B, T, self.reverse)
+            y = torch.empty((B, 2 * T, even.cout), dtype=torch.float32, device=self.device)
+            self._conv(even, x, B, T, T, in_offset=-1, out=y, out_stride=2, out_offset=0, T_y=2 * T)
+            self._conv(odd, x, B, T, T, in_offset=0, out=y, out_stride=2, out_offset=1, T_y=2 * T)
+            x, T = y, 2 * T
+        return self._conv(self.dec_out, x, B, T, T, in_offset=-1)
 
     def decode(self, zs, start_level=0, end_level=None, bs_chunks=1):
         """VQVAE.decode (vqvae.py:152-159): zs = [LongTensor (B,L)] -> FloatTensor (B, 8L, C).
@@ -166,17 +242,11 @@ class VQVAE:
             ids = ids.to(self.device, torch.int64).contiguous()
             B, L = ids.shape
             status = torch.zeros((1,), dtype=torch.int32, device=self.device)
-            x = torch.empty((B, L, self.emb), dtype=torch.float32, device=self.device)
-            _lib.call("qpg_vq_gather_f32", self.device, self.k, ids, B * L, self.emb, self.bins, x, status)
-            T = L
-            x = self._conv(self.dec_in, x, B, T, T, in_offset=-1)
-            for res, even, odd in self.dec_up:
-                x = self._resnet(res, x, B, T, self.reverse)
-                y = torch.empty((B, 2 * T, even.cout), dtype=torch.float32, device=self.device)
-                self._conv(even, x, B, T, T, in_offset=-1, out=y, out_stride=2, out_offset=0, T_y=2 * T)
-                self._conv(odd, x, B, T, T, in_offset=0, out=y, out_stride=2, out_offset=1, T_y=2 * T)
-                x, T = y, 2 * T
-            outs.append(self._conv(self.dec_out, x, B, T, T, in_offset=-1))
+            T = L * self.hop
+            ws = self._workspace(B, T)
+            out = torch.empty((B, T, self.input_dim), dtype=torch.float32, device=self.device)
+            _lib.call("qpg_vq_decode_f32", self.device, self._desc, ids, B, L, ws, ws.numel(), out, status)
+            outs.append(out)
             if int(status.item()):
                 raise IndexError("code id out of range [0,%d)" % self.bins)
         return torch.cat(outs, dim=0)
