@@ -46,6 +46,10 @@ int qpg_last_error(char* buf, size_t n);
  * (N,180,6144) float64 stack — here nothing is materialised, only per-candidate norms).
  * ---------------------------------------------------------------------------------------- */
 
+/* WavLM track resampling Tin -> Tout frames: F.interpolate(mode='linear', align_corners=True) in f32, bit-exact
+ * with torch's CPU kernel (data_processing.py:258-261: 199 -> 180).  x: [dev] f32 [N][Tin][F]; out: [dev] f32 [N][Tout][F]. */
+int qpg_wavlm_resample_f32(qpg_ctx*, void* stream, const float* x, int64_t N, int Tin, int F, int Tout, float* out);
+
 /* out[r] = sum_e x[r][e]^2 in float64, r < rows.  x: [dev] f32 [rows][F]. */
 int qpg_frame_norm2_f64(qpg_ctx*, void* stream, const float* x, int64_t rows, int F, double* out);
 

@@ -55,7 +55,7 @@ def main_codebook(args, maxFrames=0):
 
     t0 = time.time()
     L = load_db_codebook(args.train_database, args.train_codebook, args.test_data, args.train_wavlm,
-                         args.test_wavlm, args.train_wavvq, args.test_wavvq)
+                         args.test_wavlm, args.train_wavvq, args.test_wavvq, device=args.device)
     signature = np.load(args.codebook_signature)['signature']                     # :476
     freq_rank = None
     if args.tie_rule == "numpy":
@@ -68,7 +68,8 @@ def main_codebook(args, maxFrames=0):
     knn = CodeKNN(db, use_wavlm=not vq, use_wavvq=vq)                            # draws from np.random like :463-464
     n_test_seq = maxFrames if maxFrames != 0 else L.test_wavvq.shape[0]          # :740
     dev = db.device
-    te_i = torch.from_numpy(np.ascontiguousarray((L.test_wavvq if vq else L.test_wavlm)[:n_test_seq])).to(dev)
+    te_i = (torch.from_numpy(np.ascontiguousarray(L.test_wavvq[:n_test_seq])).to(dev) if vq
+            else L.test_wavlm[:n_test_seq].contiguous())
     te_c = torch.from_numpy(L.test_context[:n_test_seq]).to(dev)
     t1 = time.time()
     print('begin search...')

@@ -90,9 +90,11 @@ class GestureDB:
         self.code = _i32(code, dev).contiguous()
         self.code_local = self.code[self.lo:self.hi].contiguous()
 
-        wl = np.ascontiguousarray(wavlm_interp[self.lo:self.hi], np.float32)
         self.T, self.F = wavlm_interp.shape[1], wavlm_interp.shape[2]
-        self.base = torch.from_numpy(wl).to(dev)
+        if isinstance(wavlm_interp, torch.Tensor):        # already on the device (interp_wavlm_device)
+            self.base = wavlm_interp[self.lo:self.hi].to(dev, torch.float32).contiguous()
+        else:
+            self.base = torch.from_numpy(np.ascontiguousarray(wavlm_interp[self.lo:self.hi], np.float32)).to(dev)
         self.step_sz = self.T // num_frames_code                      # GestureKNN.py:432
         kint, cidx = audio_grid(self.T, self.step_sz)
         self.aud_k, self.aud_cidx_host = kint, cidx

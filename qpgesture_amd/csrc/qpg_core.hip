@@ -150,3 +150,39 @@ extern "C" int qpg_l2_normalize_rows_f32(qpg_ctx* ctx, void* stream, const float
   QPG_LAUNCH_CHECK("l2_normalize_rows_kernel");
   return QPG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// WavLM track resampling, 199 -> 180 frames: torch.nn.functional.interpolate(mode='linear',
+// align_corners=True) in f32 (data_processing.py:258-261), bit-exact with torch's CPU kernel:
+//   src = scale * t (f32), i0 = floor(src), l1 = src - i0, l0 = 1 - l1, out = fma(l0, x[i0], l1 * x[i1])
+// (the l1*x1 product is rounded on its own, then fused with l0*x0 — verified against torch 2.10 on CPU,
+// tests/test_gpu_matching.py::test_device_resample_bitexact).  HBM-bound: reads N*Tin*F*4 B once.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wavlm_resample_kernel(const float* __restrict__ x, int64_t N, int Tin, int F,
+                                                             int Tout, float scale, float* __restrict__ out) {
+  const int64_t row = blockIdx.x;                   // (n, t_out)
+  const int64_t n = row / Tout;
+  const int t = (int)(row - n * Tout);
+  const float src = f_mul(scale, (float)t);
+  int i0 = (int)src;                                 // src >= 0: truncation == floor
+  if (i0 > Tin - 1) i0 = Tin - 1;
+  const int i1 = i0 + 1 < Tin ? i0 + 1 : Tin - 1;
+  const float l1 = f_sub(src, (float)i0), l0 = f_sub(1.f, l1);
+  const float* p0 = x + (n * Tin + i0) * F;
+  const float* p1 = x + (n * Tin + i1) * F;
+  float* o = out + row * F;
+  for (int e = threadIdx.x; e < F; e += blockDim.x) o[e] = fmaf(l0, p0[e], f_mul(l1, p1[e]));
+}
+
+extern "C" int qpg_wavlm_resample_f32(qpg_ctx* ctx, void* stream, const float* x, int64_t N, int Tin, int F, int Tout,
+                                      float* out) {
+  QPG_REQUIRE(ctx && x && out && N >= 0 && Tin > 0 && F > 0 && Tout > 0, "qpg_wavlm_resample_f32: bad argument");
+  QPG_REQUIRE(N * Tout < 0x7fffffffll, "qpg_wavlm_resample_f32: too many rows for one launch");
+  if (N == 0) return QPG_OK;
+  // torch: area_pixel_compute_scale<float>(in, out, align_corners=true) = (in-1)/(out-1) in float (0 if out == 1)
+  const float scale = Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
+  hipLaunchKernelGGL(wavlm_resample_kernel, dim3((unsigned)(N * Tout)), dim3(256), 0, qpg_stream(stream), x, N, Tin, F,
+                     Tout, scale, out);
+  QPG_LAUNCH_CHECK("wavlm_resample_kernel");
+  return QPG_OK;
+}

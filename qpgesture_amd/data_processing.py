@@ -25,6 +25,21 @@ def interp_wavlm(wavlm, n_code=num_frames_code):
     return np.ascontiguousarray(y.numpy())
 
 
+def interp_wavlm_device(wavlm, device, n_code=num_frames_code, chunk=256):
+    """Same resampling on the MI355X (qpg_wavlm_resample_f32, bit-exact with `interp_wavlm`): the raw
+    (N,199,F) track is uploaded in chunks and only the (N,180,F) result stays resident.  Returns a device
+    tensor, which GestureDB takes as-is (no host copy of the interpolated database)."""
+    from . import _lib
+    dev = torch.device(device)
+    N, Tin, Fd = wavlm.shape
+    Tout = Tin // n_code * n_code
+    out = torch.empty((N, Tout, Fd), dtype=torch.float32, device=dev)
+    for i in range(0, N, chunk):
+        x = torch.from_numpy(np.ascontiguousarray(wavlm[i:i + chunk], np.float32)).to(dev)
+        _lib.call("qpg_wavlm_resample_f32", dev, x, x.shape[0], Tin, Fd, Tout, out[i:i + chunk])
+    return out
+
+
 def densify_phase(phase):
     """The reference stores `phase` as an object array (n,240,4) of torch tensors shaped (1,8,1)
     (PAE.py:505-508, process/fix_device_bug.py:14-22).  Returns float32 (n,240,4,8); a dense
@@ -45,16 +60,22 @@ class LoadedDB(dict):
     __getattr__ = dict.__getitem__
 
 
-def load_db_codebook(data_file, codepath, test_data_path, train_wavlm, test_wavlm, train_wavvq, test_wavvq):
-    """Same arguments as the reference's load_db_codebook.  Returns the arrays the matcher needs:
+def load_db_codebook(data_file, codepath, test_data_path, train_wavlm, test_wavlm, train_wavvq, test_wavvq,
+                     device=None):
+    """Same arguments as the reference's load_db_codebook (+ `device`: resample the WavLM tracks on that GPU
+    and return device tensors for them).  Returns the arrays the matcher needs:
     code (N,30); train/test interpolated WavLM (·,180,1024) f32; train/test context (·,30,384) f32;
     train/test phase (·,240,4,8) f32; train/test wavvq (·,398,2) ints."""
     tr = np.load(data_file, allow_pickle=True)
     te = np.load(test_data_path, allow_pickle=True)
     out = LoadedDB()
     out["code"] = np.load(codepath)["code"]
-    out["train_wavlm"] = interp_wavlm(np.load(train_wavlm)["wavlm"])
-    out["test_wavlm"] = interp_wavlm(np.load(test_wavlm)["wavlm"])
+    if device is None:
+        out["train_wavlm"] = interp_wavlm(np.load(train_wavlm)["wavlm"])
+        out["test_wavlm"] = interp_wavlm(np.load(test_wavlm)["wavlm"])
+    else:
+        out["train_wavlm"] = interp_wavlm_device(np.load(train_wavlm)["wavlm"], device)
+        out["test_wavlm"] = interp_wavlm_device(np.load(test_wavlm)["wavlm"], device)
     out["train_wavvq"] = np.load(train_wavvq)["wavvq"]
     out["test_wavvq"] = np.load(test_wavvq)["wavvq"]
     out["train_phase"] = densify_phase(tr["phase"])

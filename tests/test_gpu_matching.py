@@ -176,3 +176,16 @@ def test_wavvq_invalid_init_draw_raises():
     knn = CodeKNN(db, use_wavlm=False, use_wavvq=True, rng=np.random.RandomState(123456))
     with pytest.raises(ValueError, match="phase slice"):
         knn.init_code_phase()
+
+
+def test_device_resample_bitexact():
+    """qpg_wavlm_resample_f32 == torch's CPU F.interpolate(linear, align_corners=True), bit for bit
+    (data_processing.py:258-261: 199 -> 180 frames), incl. other lengths."""
+    import torch
+    from qpgesture_amd.data_processing import interp_wavlm, interp_wavlm_device
+    rng = np.random.default_rng(5)
+    for N, Tin, F in ((3, 199, 1024), (2, 60, 8), (1, 199, 6), (2, 398, 64)):
+        x = (rng.standard_normal((N, Tin, F)) * 3).astype(np.float32)
+        want = interp_wavlm(x)
+        got = interp_wavlm_device(x, "cuda:0", chunk=2).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want)
