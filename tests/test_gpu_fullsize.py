@@ -138,3 +138,39 @@ def test_empty_inputs():
     with pytest.raises(RuntimeError, match="F % 128"):
         _lib.call("qpg_audio_cosine_f64", dev, z, 1, 180, 100, zi, 26, 6, 2, z.double(), z, z.double(), 1,
                   z.double(), 26)
+
+
+def test_batch16_clips_tables_vs_c_oracle():
+    """BASELINE.json configs[4] shape: 16 concurrent clips x 6 windows = 768 query steps in ONE pair of
+    sweeps (query tiles loop over grid.y) — tables equal the C port's; each clip's walk equals the walk of
+    that clip matched alone."""
+    import torch
+    from oracle import cref, knn_oracle as O
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    from qpgesture_amd.data_processing import interp_wavlm
+    N, clips, M = 256, 16, 6
+    A = _db(N, 700)
+    te = synth.make_db(clips * M, 701)
+    te_i = interp_wavlm(te["wavlm"])
+    te_c = np.ascontiguousarray(te["context"].squeeze(2))
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    ti, tc = torch.from_numpy(te_i).cuda(), torch.from_numpy(te_c).cuda()
+    T = knn.sweep_tables(ti, tc, clips * M)
+    assert T["aud_d"].shape == (768, 512)
+    cores = os.cpu_count() or 1
+    q = np.stack([O.wavlm_feat_rows(te_i, w, [24 * s])[0] for w in range(clips * M) for s in range(8)])
+    d_ref, i_ref = cref.audio_scan(A["interp"], np.arange(26) * 6, A["code"], np.arange(26), q, n_threads=cores)
+    assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref)
+    assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+    qt = np.stack([te_c[w][int(24 * s / 180 * 30)] for w in range(clips * M) for s in range(8)])
+    dt_ref, it_ref = cref.text_scan(A["ctx"], np.arange(26), A["code"], np.arange(26), qt, n_threads=cores)
+    assert np.array_equal(T["txt_d"].cpu().numpy(), dt_ref) and np.array_equal(T["txt_idx"].cpu().numpy(), it_ref)
+    seed_code, seed_phase = knn.init_code_phase()
+    for c in (0, 7, 15):
+        got, _, _ = knn.walk(T, M, window_offset=c * M, seed_code=seed_code, seed_phase=seed_phase)
+        alone = CodeKNN(db, rng=np.random.RandomState(1))
+        want, _, _ = alone.match_clip(ti[c * M:(c + 1) * M], tc[c * M:(c + 1) * M], M, seed_code=seed_code,
+                                      seed_phase=seed_phase)
+        assert np.array_equal(got, want)
