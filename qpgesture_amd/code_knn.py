@@ -414,6 +414,17 @@ class CodeKNN:
         Returns a dict of device tensors: aud_d/aud_idx/aud_rank, txt_d/txt_idx/txt_rank."""
         db, dev = self.db, self.db.device
         M, steps = n_windows, self.n_steps()
+        if test_interp.shape[0] < M or (mode != MODE_AUD and test_context.shape[0] < M):
+            # the reference indexes test_wavlm_feat[i] / test_context[i] for i < n_test_seq (GestureKNN.py:788-800)
+            raise IndexError("n_windows=%d but the test arrays hold %d audio / %d context windows"
+                             % (M, test_interp.shape[0], test_context.shape[0]))
+        if self.use_wavvq:
+            ok = tuple(test_interp.shape[1:]) == (db.Tv, 2)
+        else:
+            ok = tuple(test_interp.shape[1:]) == (db.T, db.F)
+        if not ok:
+            raise ValueError("test audio windows have shape %s, database expects %s"
+                             % (tuple(test_interp.shape[1:]), (db.Tv, 2) if self.use_wavvq else (db.T, db.F)))
         pos = self.query_positions()
         q_win = np.repeat(np.arange(M), steps)
         q_t = np.tile(np.array([int(i) for i in pos]), M)                    # clip_test[int(i)]  (:559, :565)

@@ -174,3 +174,19 @@ def test_batch16_clips_tables_vs_c_oracle():
         want, _, _ = alone.match_clip(ti[c * M:(c + 1) * M], tc[c * M:(c + 1) * M], M, seed_code=seed_code,
                                       seed_phase=seed_phase)
         assert np.array_equal(got, want)
+
+
+def test_input_validation():
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    A = _db(4, 800, F=128)
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    ti = torch.from_numpy(A["interp"][:2].copy()).cuda()
+    tc = torch.from_numpy(A["ctx"][:2].copy()).cuda()
+    with pytest.raises(IndexError):
+        knn.match_clip(ti, tc, 3)                       # more windows requested than supplied (reference: IndexError)
+    with pytest.raises(ValueError):
+        knn.match_clip(ti[:, :, :64].contiguous(), tc, 2)   # feature width differs from the database's
+    with pytest.raises(ValueError):
+        CodeKNN(db, use_wavlm=False, use_wavvq=True)    # DB built without a wavvq track
