@@ -25,7 +25,11 @@
 // ds_read_b128), candidate digits stream straight from HBM (16 B per lane per plane).
 #include <stdlib.h>
 
-#include "qpg_common.h"
+#include "qpg_common.h"   // from qpgesture_amd/csrc (see check_i8.py for the build line)
+
+extern "C" int qpg_i8_slice_rows(qpg_ctx*, void*, const float*, int64_t, int, int8_t*, double*, double*);
+extern "C" int qpg_audio_cosine_i8(qpg_ctx*, void*, const int8_t*, const double*, int, int, int, const int32_t*, int, int,
+                                   int, const double*, const int8_t*, const double*, const double*, int, double*, int64_t);
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 

@@ -96,24 +96,6 @@ int qpg_audio_cosine_f64(qpg_ctx*, void* stream, const float* base, int N, int T
 int qpg_text_pack_candidates_f32(qpg_ctx*, void* stream, const float* x, int N, int R, int Dm,
                                  const int32_t* cand_r, int G, float* xt);
 
-/* ------------------------------------------------------------------------------------------
- * Audio sweep on the int8 matrix cores (exact integer arithmetic; see csrc/qpg_audio_i8.hip and DESIGN.md §4).
- * ---------------------------------------------------------------------------------------- */
-
-/* Block-exponent fixed point of f32 rows: X = rint(x * 2^(30-E)), 2^(E-1) <= max|row| < 2^E, split into four balanced
- * base-256 digit planes.  x: [dev] f32 [rows][F]; planes: [dev] i8 [4][rows][F]; scale: [dev] f64 [rows] = 2^(E-30)
- * (0 for an all-zero row); norm2: optional [dev] f64 [rows] = sum x^2. */
-int qpg_i8_slice_rows(qpg_ctx*, void* stream, const float* x, int64_t rows, int F, int8_t* planes, double* scale,
-                      double* norm2);
-
-/* Same contract as qpg_audio_cosine_f64 (same D layout, same candidate addressing), computed from digit planes:
- * A/sA = planes/scales of the base [N][T][F] rows, Bq/sQ = planes/scales of the packed queries [Q][n_taps][F].
- * D differs from the exact distance only by the fixed-point rounding of the operands (|err| <= the bound of
- * qpg_audio_refine_f64, ~1e-11 in practice). */
-int qpg_audio_cosine_i8(qpg_ctx*, void* stream, const int8_t* A, const double* sA, int N, int T, int F,
-                        const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2, const int8_t* Bq,
-                        const double* sQ, const double* qn2, int Q, double* D, int64_t ldD);
-
 /* Cosine distance with scikit-learn's float32 arithmetic, bit-exact (GestureKNN.py:716 keeps f32):
  *   D[q][c] = 0.5 * einsum_sq(qn[q] - xn_c)     (NumPy einsum summation order)
  * xt: tiled normalised candidates from qpg_text_pack_candidates_f32 (C = N*G of them);

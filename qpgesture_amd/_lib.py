@@ -28,8 +28,6 @@ _SIGS = {
     "qpg_l2_normalize_rows_f32": [P, L, I, P],
     "qpg_audio_pack_queries": [P, I, I, I, P, P, I, I, I, P, P],
     "qpg_audio_cosine_f64": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
-    "qpg_i8_slice_rows": [P, L, I, P, P, P],
-    "qpg_audio_cosine_i8": [P, P, I, I, I, P, I, I, I, P, P, P, P, I, P, L],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
     "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
     "qpg_percode_resolve_f32": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P],

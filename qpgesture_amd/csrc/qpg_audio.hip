@@ -252,3 +252,4 @@ extern "C" int qpg_audio_cosine_f64(qpg_ctx* ctx, void* stream, const float* bas
 #undef QPG_AUDIO_TAIL
 #undef QPG_AUDIO_ARGS
 }
+
