@@ -57,6 +57,8 @@ def wavvq_tap_offsets(T):
 
 
 def _i32(x, dev):
+    if isinstance(x, torch.Tensor):
+        return x
     return torch.as_tensor(np.asarray(x, np.int32), device=dev)
 
 
@@ -230,7 +232,7 @@ class CodeKNN:
         with global candidate indices j*26+g (-1 = code absent), min-reduced across ranks; with
         want_rank also the stable ranks i16 [Q,512]."""
         db, dev = self.db, self.db.device
-        Q = len(q_win)
+        Q = int(q_win.shape[0]) if isinstance(q_win, torch.Tensor) else len(q_win)
         qbase = qbase.contiguous()
         M, T, F = qbase.shape
         ts = db.tap_stride if tap_stride is None else tap_stride
@@ -292,7 +294,7 @@ class CodeKNN:
         db, dev = self.db, self.db.device
         tw = torch.as_tensor(test_wavvq).to(dev)
         sym_q = (tw[..., 0].to(torch.int64) * WAVVQ_GROUP_SIZE + tw[..., 1].to(torch.int64)).to(torch.int32).contiguous()
-        Q = len(q_win)
+        Q = int(q_win.shape[0]) if isinstance(q_win, torch.Tensor) else len(q_win)
         C = db.n_local * db.Gv
         D = torch.empty((Q, max(C, 1)), dtype=torch.float32, device=dev)
         taps = (ctypes.c_int32 * len(db.vq_taps))(*db.vq_taps)
@@ -316,7 +318,7 @@ class CodeKNN:
         """Same result through the stand-alone entry points (distance matrix, then qpg_percode_argmin_f64);
         kept for the parity tests of those entry points."""
         db, dev = self.db, self.db.device
-        Q = len(q_win)
+        Q = int(q_win.shape[0]) if isinstance(q_win, torch.Tensor) else len(q_win)
         qbase = qbase.contiguous()
         M, T, F = qbase.shape
         q32 = torch.empty((Q, NUM_AUDIO_FEAT_FRAMES * F), dtype=torch.float32, device=dev)
@@ -426,8 +428,14 @@ class CodeKNN:
             raise ValueError("test audio windows have shape %s, database expects %s"
                              % (tuple(test_interp.shape[1:]), (db.Tv, 2) if self.use_wavvq else (db.T, db.F)))
         pos = self.query_positions()
-        q_win = np.repeat(np.arange(M), steps)
-        q_t = np.tile(np.array([int(i) for i in pos]), M)                    # clip_test[int(i)]  (:559, :565)
+        cache = self.__dict__.setdefault("_qcache", {})
+        if M not in cache:          # index tensors are built once per clip length (also keeps H2D copies out of graphs)
+            qw = np.repeat(np.arange(M), steps)
+            qt = np.tile(np.array([int(i) for i in pos]), M)                  # clip_test[int(i)]  (:559, :565)
+            rows_ = [int(i / self.n_db_frm * 30) for i in pos] * M           # GestureKNN.py:549, 551
+            cache[M] = (_i32(qw, dev), _i32(qt, dev), torch.as_tensor(qw, device=dev),
+                        torch.as_tensor(np.asarray(rows_), device=dev))
+        q_win, q_t, gw, gr = cache[M]
         T = dict(aud_d=None, aud_idx=None, aud_rank=None, txt_d=None, txt_idx=None, txt_rank=None)
         if mode in (MODE_AUD_TXT, MODE_AUD):
             if self.use_wavvq:
@@ -436,12 +444,7 @@ class CodeKNN:
             else:
                 T["aud_d"], T["aud_idx"], T["aud_rank"] = self.sweep_audio(test_interp, q_win, q_t, want_rank=True)
         if mode in (MODE_AUD_TXT, MODE_TXT):
-            rows = [int(i / self.n_db_frm * 30) for i in pos] * M              # GestureKNN.py:549, 551
-            key = (M, steps)
-            if getattr(self, "_txt_gather_key", None) != key:
-                self._txt_gather = (torch.as_tensor(q_win, device=dev), torch.as_tensor(rows, device=dev))
-                self._txt_gather_key = key
-            qtxt = test_context[self._txt_gather[0], self._txt_gather[1]].contiguous()
+            qtxt = test_context[gw, gr].contiguous()
             T["txt_d"], T["txt_idx"], T["txt_rank"] = self.sweep_text(qtxt, want_rank=True)
         return T
 
@@ -477,6 +480,13 @@ class CodeKNN:
                              "(the reference raises IndexError at GestureKNN.py:631-632)")
         return codes, out_phase.cpu().numpy(), out_vote.cpu().numpy()
 
+    def capture_clip_graph(self, n_windows, mode=MODE_AUD_TXT, n_sweep_windows=None, window_offset=0):
+        """Capture the whole per-clip launch sequence (pack, both sweeps, per-code argmin passes, ranks,
+        rank-fusion tables, walk) into one HIP graph for a fixed clip shape.  Returns a ClipGraph whose
+        run(test_audio, test_context, seed_code, seed_phase) replays it; results are device tensors.
+        n_sweep_windows > n_windows sweeps more windows than it walks (several clips per sweep: bench.py N>1)."""
+        return ClipGraph(self, n_windows, mode, n_sweep_windows or n_windows, window_offset)
+
     def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
                    seed_phase=None, return_tables=False):
         """All windows of one clip: two batched sweeps + rank kernels + one device-side tail walk.
@@ -485,6 +495,58 @@ class CodeKNN:
         if return_tables:
             self.tables = T
         return self.walk(T, n_windows, 0, mode, seed_code, seed_phase)
+
+
+class ClipGraph:
+    """A captured clip: static input buffers + one hipGraph (torch.cuda.CUDAGraph is the HIP graph wrapper;
+    every node is one of this library's kernels or a memset).  The seed code is a kernel ARGUMENT of the walk,
+    so a graph is tied to the seed code it was captured with; the seed phase block is a buffer."""
+
+    def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset):
+        db, dev = knn.db, knn.db.device
+        if db.world != 1:
+            raise NotImplementedError("graph capture of the sharded path (collectives inside) is not supported")
+        self.knn, self.M, self.mode = knn, n_windows, mode
+        Ms = n_sweep_windows
+        if knn.use_wavvq:
+            self.audio = torch.zeros((Ms, db.Tv, 2), dtype=torch.int64, device=dev)
+        else:
+            self.audio = torch.zeros((Ms, db.T, db.F), dtype=torch.float32, device=dev)
+        self.context = torch.zeros((Ms, db.R, db.Dt), dtype=torch.float32, device=dev)
+        self.seed_phase = torch.zeros((8, 16), dtype=torch.float32, device=dev)
+        self.seed_code = None
+        self._n_sweep, self._off = Ms, window_offset
+        self.graph = None
+
+    def _capture(self, seed_code):
+        knn = self.knn
+        dev = knn.db.device
+
+        def body():
+            T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode)
+            return knn.walk(T, self.M, self._off, self.mode, seed_code, self.seed_phase, sync=False)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(2):                       # warm-up: caches, lazy module loads
+                body()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.out = body()
+        self.graph, self.seed_code = g, seed_code
+
+    def run(self, test_audio, test_context, seed_code, seed_phase):
+        """Copies the clip into the static buffers and replays.  Returns (codes i32 [M,30], phases, votes,
+        status) device tensors (valid until the next run)."""
+        self.audio.copy_(test_audio, non_blocking=True)
+        self.context.copy_(test_context, non_blocking=True)
+        self.seed_phase.copy_(torch.as_tensor(seed_phase), non_blocking=True)
+        if self.graph is None or int(seed_code) != self.seed_code:
+            self._capture(int(seed_code))
+        self.graph.replay()
+        return self.out
 
 
 def predict_code_from_audio(db, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, rng=None):

@@ -185,19 +185,36 @@ __device__ __forceinline__ CandRegs load_cand(const TailArgs& A, int which, int 
   return r;
 }
 
+// einsum_sq of a 128-vector stored TRANSPOSED in LDS (vt[l*32 + i] = v[4*i + l]): lane l's chain elements
+// are contiguous, read as 8 x 16 B.  Order inside the chain: 16-element groups g = i>>2 ascending, within a
+// group u = i&3 visited 3,2,1,0 (NumPy einsum's unrolled order).
+__device__ __forceinline__ float einsum_sq_128_t(const float* vt, int l) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(vt + l * 32);
+  float a = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const f32x4 x = p[g];                       // u = 0..3 of group g
+    a = f_add(f_mul(x.w, x.w), a);
+    a = f_add(f_mul(x.z, x.z), a);
+    a = f_add(f_mul(x.y, x.y), a);
+    a = f_add(f_mul(x.x, x.x), a);
+  }
+  return lane4_sum(a, l);
+}
+
+__device__ __forceinline__ int tpos(int e) { return (e & 3) * 32 + (e >> 2); }   // transposed slot of element e
+
 __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
   extern __shared__ __attribute__((aligned(16))) int32_t tab[];   // [2][steps][K] gate candidates of this window
-  __shared__ float prev[128];          // running phase block (8 frames x [8 phase | 8 amp])
-  __shared__ float blk[2][2][128];     // [candidate][head|tail][8 x 16]
-  __shared__ float va[2][128], vb[2][128];
+  __shared__ __attribute__((aligned(16))) float va[2][128], vb[2][128];   // gate vectors, transposed layout
   __shared__ float nrm[4];
   __shared__ float score[2];
   __shared__ int wincodes[64];
   __shared__ int s_cidx[128], s_pslot[128];
 
   const int lane = threadIdx.x, K = A.K;
-  prev[lane] = A.seed_phase[lane];
-  prev[lane + 64] = A.seed_phase[lane + 64];
+  // the running phase block (8 frames x [8 phase | 8 amp] = 128 floats) lives in registers: 2 floats per lane
+  float2 prev = reinterpret_cast<const float2*>(A.seed_phase)[lane];
   if (lane < A.G0) {
     s_cidx[lane] = A.cidx0[lane];
     s_pslot[lane] = A.pslot0[lane];
@@ -210,6 +227,7 @@ __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
   int bad = 0;
   const float eps10 = 10.f * 1.1920928955078125e-07f;
   const int last_idx = A.codes_per_window - 1;                 // the next window is seeded by this kept code
+  const int e0 = 2 * lane;                                      // this lane's two block elements
 
   for (int w = 0; w < A.M; ++w) {
     // this window's gate tables -> LDS (steps*K*2 i32, 16-B loads)
@@ -227,10 +245,29 @@ __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
 
     for (int s = 0; s < A.steps; ++s) {
       bad |= cur[0].absent | cur[1].absent;
-      reinterpret_cast<float2*>(blk[0][0])[lane] = cur[0].head;
-      reinterpret_cast<float2*>(blk[0][1])[lane] = cur[0].tail;
-      reinterpret_cast<float2*>(blk[1][0])[lane] = cur[1].head;
-      reinterpret_cast<float2*>(blk[1][1])[lane] = cur[1].tail;
+      // gate vectors straight from registers (GestureKNN.py:636):
+      //   a = [prev[-5:], head[:3]] -> a[e] = prev[48+e] (e < 80), head[e-80] (e >= 80)
+      //   b = [prev[-3:], head[:5]] -> b[e] = prev[80+e] (e < 48), head[e-48] (e >= 48)
+      // lane owns block elements e0, e0+1: prev element e0 lands at a[e0-48] / b[e0-80], head at a[e0+80] / b[e0+48]
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (e0 >= 48) {
+          va[k][tpos(e0 - 48)] = prev.x;
+          va[k][tpos(e0 - 47)] = prev.y;
+        }
+        if (e0 >= 80) {
+          vb[k][tpos(e0 - 80)] = prev.x;
+          vb[k][tpos(e0 - 79)] = prev.y;
+        }
+        if (e0 < 48) {
+          va[k][tpos(e0 + 80)] = cur[k].head.x;
+          va[k][tpos(e0 + 81)] = cur[k].head.y;
+        }
+        if (e0 < 80) {
+          vb[k][tpos(e0 + 48)] = cur[k].head.x;
+          vb[k][tpos(e0 + 49)] = cur[k].head.y;
+        }
+      }
       // speculation: the last payload code of either candidate is the next step's previous code
       CandRegs nxt[2][2];
       const bool spec = s + 1 < A.steps;
@@ -243,47 +280,36 @@ __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
         }
       }
       __syncthreads();
-      // gate vectors: a = [prev[-5:], head[:3]], b = [prev[-3:], head[:5]]  (GestureKNN.py:636)
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int e = lane + 64 * h;
-          va[k][e] = (e < 80) ? prev[48 + e] : blk[k][0][e - 80];
-          vb[k][e] = (e < 48) ? prev[80 + e] : blk[k][0][e - 48];
-        }
-      __syncthreads();
       // norms: lanes 0-3 |a0|, 4-7 |b0|, 8-11 |a1|, 12-15 |b1|
       if (lane < 16) {
         const int l = lane & 3, grp = lane >> 2;
         const float* v = (grp & 1) ? vb[grp >> 1] : va[grp >> 1];
-        float n = f_sqrt(einsum_sq_128(v, l));
+        float n = f_sqrt(einsum_sq_128_t(v, l));
         if (n < eps10) n = 1.f;
         if (l == 0) nrm[grp] = n;
       }
       __syncthreads();
+      // normalised difference, every lane 2 slots of each vector (slot order is irrelevant here), in place
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int e = lane + 64 * h;
-          va[k][e] = f_sub(f_div(va[k][e], nrm[2 * k]), f_div(vb[k][e], nrm[2 * k + 1]));
-        }
+      for (int k = 0; k < 2; ++k) {
+        const float na = nrm[2 * k], nb = nrm[2 * k + 1];
+        const float2 xa = reinterpret_cast<const float2*>(va[k])[lane], xb = reinterpret_cast<const float2*>(vb[k])[lane];
+        float2 d;
+        d.x = f_sub(f_div(xa.x, na), f_div(xb.x, nb));
+        d.y = f_sub(f_div(xa.y, na), f_div(xb.y, nb));
+        reinterpret_cast<float2*>(va[k])[lane] = d;
+      }
       __syncthreads();
       if (lane < 8) {
         const int l = lane & 3, k = lane >> 2;
-        const float sc = f_mul(0.5f, einsum_sq_128(va[k], l));
+        const float sc = f_mul(0.5f, einsum_sq_128_t(va[k], l));
         if (l == 0) score[k] = sc;
       }
       __syncthreads();
       const int fi = (score[1] < score[0]) ? 1 : 0;            // list.index(min): first on ties
       // append the winner's 4 codes, carry its last-8-frame block (GestureKNN.py:648-657)
-      const float t0 = blk[fi][1][lane], t1 = blk[fi][1][lane + 64];
-      prev[lane] = t0;
-      prev[lane + 64] = t1;
-      float* op = A.out_phase + ((int64_t)w * A.steps + s) * 128;
-      op[lane] = t0;
-      op[lane + 64] = t1;
+      prev = fi ? cur[1].tail : cur[0].tail;
+      reinterpret_cast<float2*>(A.out_phase + ((int64_t)w * A.steps + s) * 128)[lane] = prev;
       const int wpay = fi ? cur[1].pay : cur[0].pay;
       if (lane < A.step_codes) wincodes[s * A.step_codes + lane] = wpay;
       if (lane == 0) A.out_vote[w * A.steps + s] = fi;
@@ -292,8 +318,8 @@ __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
         cur[0] = fi ? nxt[1][0] : nxt[0][0];
         cur[1] = fi ? nxt[1][1] : nxt[0][1];
       }
-      __syncthreads();
     }
+    __syncthreads();
     // window result = first codes_per_window codes; the next window is seeded by the LAST KEPT code
     // (motion_output[-1][-1], GestureKNN.py:800) and the last phase block.
     if (lane < A.codes_per_window) A.out_codes[(int64_t)w * A.codes_per_window + lane] = wincodes[lane];

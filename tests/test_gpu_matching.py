@@ -189,3 +189,18 @@ def test_device_resample_bitexact():
         want = interp_wavlm(x)
         got = interp_wavlm_device(x, "cuda:0", chunk=2).cpu().numpy()
         assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_clip_graph_replay_equals_eager():
+    """The per-clip launch sequence captured as one HIP graph replays to the same codes / phases / votes."""
+    import torch
+    g = load_golden(GOLDENS[1])
+    A, db, knn, te_i, te_c, M = _build(g["meta"], freq_rank=g["step_freq_score"])
+    sc, sp = knn.init_code_phase()
+    cg = knn.capture_clip_graph(M)
+    for rep in range(2):                    # second run reuses the captured graph
+        codes, phases, votes, status = cg.run(te_i, te_c, sc, sp)
+        assert int(status.item()) == 0
+        assert np.array_equal(codes.cpu().numpy().astype(np.int64), g["knn_pred"])
+        assert np.array_equal(phases.cpu().numpy(), g["phase_out"])
+        assert np.array_equal(votes.cpu().numpy(), g["vote"])
