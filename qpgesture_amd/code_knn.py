@@ -227,7 +227,7 @@ class CodeKNN:
         return code, np.concatenate((P[:, 0], P[:, 1]), axis=1).astype(np.float32)
 
     # -- batched sweeps ------------------------------------------------------------------------
-    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None, want_rank=False):
+    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None, want_rank=False, reduce=True):
         """Per-code best audio candidate for every query: returns (dist f64 [Q,512], idx i32 [Q,512])
         with global candidate indices j*26+g (-1 = code absent), min-reduced across ranks; with
         want_rank also the stable ranks i16 [Q,512]."""
@@ -261,12 +261,14 @@ class CodeKNN:
         rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
         _lib.call("qpg_percode_finalize_f64", dev, key, bidx, Q, db.K, float(ABSENT_DIST), dist, idx, rank)
         self._last_D_aud = D
+        if not reduce:              # sharded caller combines several tables in one exchange (sweep_tables)
+            return dist, idx
         dist, idx = self._reduce_min(dist, idx)
         if want_rank:
             return dist, idx, (rank if fused_rank else self.rank_rows(dist))
         return dist, idx
 
-    def sweep_text(self, queries, want_rank=False):
+    def sweep_text(self, queries, want_rank=False, reduce=True):
         """queries: f32 [Q,384] on the device.  Returns (dist f32 [Q,512], idx i32 [Q,512][, rank])."""
         db, dev = self.db, self.db.device
         Q = queries.shape[0]
@@ -283,12 +285,14 @@ class CodeKNN:
         fused_rank = want_rank and db.world == 1
         rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
         _lib.call("qpg_percode_finalize_f32", dev, packed, Q, db.K, float(ABSENT_DIST), dist, idx, rank)
+        if not reduce:              # sharded caller combines several tables in one exchange (sweep_tables)
+            return dist, idx
         dist, idx = self._reduce_min(dist, idx)
         if want_rank:
             return dist, idx, (rank if fused_rank else self.rank_rows(dist))
         return dist, idx
 
-    def sweep_audio_wavvq(self, test_wavvq, q_win, q_t, want_rank=False):
+    def sweep_audio_wavvq(self, test_wavvq, q_win, q_t, want_rank=False, reduce=True):
         """vq-wav2vec audio sweep: test_wavvq (M,398,2) ints (device tensor or array).  Distances are exact
         small integers (Levenshtein), returned as f32 [Q,512] with the winners' global candidate indices."""
         db, dev = self.db, self.db.device
@@ -309,6 +313,8 @@ class CodeKNN:
         rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
         _lib.call("qpg_percode_finalize_f32", dev, packed, Q, db.K, float(ABSENT_DIST), dist, idx, rank)
         self._last_D_aud = D
+        if not reduce:              # sharded caller combines several tables in one exchange (sweep_tables)
+            return dist, idx
         dist, idx = self._reduce_min(dist, idx)
         if want_rank:
             return dist, idx, (rank if fused_rank else self.rank_rows(dist))
@@ -437,15 +443,31 @@ class CodeKNN:
                         torch.as_tensor(np.asarray(rows_), device=dev))
         q_win, q_t, gw, gr = cache[M]
         T = dict(aud_d=None, aud_idx=None, aud_rank=None, txt_d=None, txt_idx=None, txt_rank=None)
+        sharded = db.world > 1
         if mode in (MODE_AUD_TXT, MODE_AUD):
-            if self.use_wavvq:
-                T["aud_d"], T["aud_idx"], T["aud_rank"] = self.sweep_audio_wavvq(test_interp, q_win, q_t,
-                                                                                 want_rank=True)
-            else:
-                T["aud_d"], T["aud_idx"], T["aud_rank"] = self.sweep_audio(test_interp, q_win, q_t, want_rank=True)
+            fn = self.sweep_audio_wavvq if self.use_wavvq else self.sweep_audio
+            r = fn(test_interp, q_win, q_t, want_rank=not sharded, reduce=not sharded)
+            T["aud_d"], T["aud_idx"] = r[0], r[1]
+            if not sharded:
+                T["aud_rank"] = r[2]
         if mode in (MODE_AUD_TXT, MODE_TXT):
             qtxt = test_context[gw, gr].contiguous()
-            T["txt_d"], T["txt_idx"], T["txt_rank"] = self.sweep_text(qtxt, want_rank=True)
+            r = self.sweep_text(qtxt, want_rank=not sharded, reduce=not sharded)
+            T["txt_d"], T["txt_idx"] = r[0], r[1]
+            if not sharded:
+                T["txt_rank"] = r[2]
+        if sharded:
+            # ONE min+index exchange for both modalities: the f32 text minima are widened to f64 (exact) and ride
+            # in the same all-reduce(MIN) as the audio minima; one more all-reduce(MIN) for the candidate indices
+            parts = [k for k in ("aud", "txt") if T[k + "_d"] is not None]
+            dcat = torch.cat([T[k + "_d"].to(torch.float64) for k in parts], dim=1)
+            icat = torch.cat([T[k + "_idx"] for k in parts], dim=1)
+            dcat, icat = allreduce_min_index(dcat, icat)
+            for n_, k in enumerate(parts):
+                d = dcat[:, n_ * db.K:(n_ + 1) * db.K]
+                T[k + "_d"] = d.to(T[k + "_d"].dtype).contiguous()
+                T[k + "_idx"] = icat[:, n_ * db.K:(n_ + 1) * db.K].contiguous()
+                T[k + "_rank"] = self.rank_rows(T[k + "_d"])
         return T
 
     def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True):
