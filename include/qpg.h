@@ -197,11 +197,13 @@ int qpg_match_steps(qpg_ctx*, void* stream, const int16_t* aud_rank, const int32
  * nn.Conv1d(k3) (encdec.py:24,39,113), the x.k^T GEMM of BottleneckBlock.quantise (bottleneck.py:123) and
  * nn.ConvTranspose1d(k4,s2,p1) (encdec.py:45) as two 2-tap launches, one per output parity.
  * w: [dev] f32 [taps][Cin_pad][Cout_pad] repacked weights (Cin_pad % 16 == 0, Cout_pad % 128 == 0, zero padded);
- * bias: [dev] f32 [Cout_pad] or NULL; residual: indexed like y, or NULL; y: [dev] f32 [B][T_y][Cout]. */
+ * bias: [dev] f32 [Cout_pad] or NULL; residual: indexed like y, or NULL; y: [dev] f32 [B][T_y][Cout].
+ * ws / ws_floats: optional [dev] f32 scratch; when given and the launch would not fill the chip (short sequences),
+ * the contraction is split over up to 8 block groups whose partial sums are added in a fixed order. */
 int qpg_conv1d_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, int Cin, const float* w,
                    const float* bias, int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride, int in_offset,
                    int dil, int T_out, int out_stride, int out_offset, int T_y, const float* residual, int relu_in,
-                   int relu_out, float* y);
+                   int relu_out, float* y, float* ws, int64_t ws_floats);
 
 /* BottleneckBlock.quantise (bottleneck.py:120-126) after the GEMM: ids[r] = argmin_c (|z_r|^2 - 2 dot[r][c]) + kk[c]
  * (f32, that operation order, lowest index on ties).  z: [dev] f32 [R][E]; dot: [dev] f32 [R][K]; kk: [dev] f32 [K];

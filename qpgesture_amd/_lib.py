@@ -40,7 +40,7 @@ _SIGS = {
     "qpg_rank_rows_f32": [P, I, I, P],
     "qpg_l2_table_f32": [P, I, I, P],
     "qpg_wavvq_lev_f32": [P, I, I, P, I, P, I, P, I, I, P, P, I, P, L],
-    "qpg_conv1d_f32": [P, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, P],
+    "qpg_conv1d_f32": [P, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, P, P, L],
     "qpg_vq_argmin_f32": [P, P, P, L, I, I, P, P, P],
     "qpg_vq_gather_f32": [P, P, L, I, I, P, P],
     "qpg_vq_encode_f32": [P, P, I, I, P, L, P, P, P],

@@ -33,6 +33,8 @@ struct ConvArgs {
   int T_out;                       // output positions computed per batch item in this launch
   int out_stride, out_offset, T_y; // y row = t*out_stride + out_offset, T_y rows per batch item
   int relu_in, relu_out;
+  int ksplit;          // > 1: blockIdx.z owns a contiguous range of K slices and writes raw partial sums to ws
+  float* ws;           // [ksplit][M][Cout_pad]
 };
 
 // MT = 32-row MFMA tiles per wave along M (block tile = 64*MT positions x 128 channels); VEC = 16-B loads of
@@ -104,15 +106,22 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
     b1 = *reinterpret_cast<const f32x4*>(wp + 4);
   };
 
-  fetch(0);
-  for (int it = 0; it < total; ++it) {
+  // split-K (short sequences: a handful of blocks would otherwise walk the whole contraction alone)
+  int it0 = 0, it1 = total;
+  if (a.ksplit > 1) {
+    const int per = (total + a.ksplit - 1) / a.ksplit;
+    it0 = blockIdx.z * per;
+    it1 = it0 + per < total ? it0 + per : total;
+  }
+  if (it0 < it1) fetch(it0);
+  for (int it = it0; it < it1; ++it) {
     __syncthreads();   // previous slice fully consumed
 #pragma unroll
     for (int i = 0; i < AR; ++i) As[ar][ak + i] = av[i];
     *reinterpret_cast<f32x4*>(&Bs[bk][bn]) = b0;
     *reinterpret_cast<f32x4*>(&Bs[bk][bn + 4]) = b1;
     __syncthreads();
-    if (it + 1 < total) fetch(it + 1);   // in flight during the MFMAs below
+    if (it + 1 < it1) fetch(it + 1);     // in flight during the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < CV_BK / 2; ++ks) {
       const int k = ks * 2 + (lane >> 5);
@@ -127,6 +136,21 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
   }
 
   // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (a.ksplit > 1) {
+    float* wsz = a.ws + (int64_t)blockIdx.z * M * a.Cout_pad;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int n = n0 + wn * 64 + half * 32 + (lane & 31);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M) wsz[m * a.Cout_pad + n] = acc[mt][half][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int n = n0 + wn * 64 + half * 32 + (lane & 31);
@@ -151,10 +175,29 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
   }
 }
 
+// split-K epilogue: partial sums added in slice order (fixed), then bias / ReLU / residual as in the fused path
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a) {
+  const int64_t M = (int64_t)a.B * a.T_out;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * a.Cout) return;
+  const int64_t m = i / a.Cout;
+  const int n = (int)(i - m * a.Cout);
+  float v = 0.f;
+  for (int z = 0; z < a.ksplit; ++z) v += a.ws[((int64_t)z * M + m) * a.Cout_pad + n];
+  v += a.bias ? a.bias[n] : 0.f;
+  const int b = (int)(m / a.T_out);
+  const int t = (int)(m - (int64_t)b * a.T_out);
+  const int64_t o = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout + n;
+  if (a.relu_out) v = fmaxf(v, 0.f);
+  if (a.res) v = a.res[o] + v;
+  a.y[o] = v;
+}
+
 extern "C" int qpg_conv1d_f32(qpg_ctx* ctx, void* stream, const float* x, int B, int T_in, int Cin, const float* w,
                               const float* bias, int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride,
                               int in_offset, int dil, int T_out, int out_stride, int out_offset, int T_y,
-                              const float* residual, int relu_in, int relu_out, float* y) {
+                              const float* residual, int relu_in, int relu_out, float* y, float* ws,
+                              int64_t ws_floats) {
   QPG_REQUIRE(ctx && x && w && y, "qpg_conv1d_f32: null pointer");
   QPG_REQUIRE(B >= 0 && T_in > 0 && Cin > 0 && taps > 0 && Cout > 0 && T_out >= 0 && T_y > 0 && out_stride > 0 &&
                   in_stride > 0 && dil > 0,
@@ -172,13 +215,32 @@ extern "C" int qpg_conv1d_f32(qpg_ctx* ctx, void* stream, const float* x, int B,
   // 128-row tiles once there are enough rows to fill the chip with them, 64-row tiles for short sequences
   const bool big = M * (Cout_pad / CV_BN) >= (int64_t)128 * 2 * ctx->n_cu;
   const int BM = big ? 128 : 64;
-  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(Cout_pad / CV_BN));
+  const int64_t blocks = ((M + BM - 1) / BM) * (Cout_pad / CV_BN);
+  const int total = taps * (Cin_pad / CV_BK);
+  // short sequences (one clip's decode: 180..1440 rows): split the contraction over blockIdx.z so that the
+  // launch fills the chip, partial sums go through the caller's scratch and are added in a fixed order
+  int ks = 1;
+  if (ws && blocks < ctx->n_cu && total >= 16) {
+    ks = (int)((ctx->n_cu + blocks - 1) / blocks);
+    if (ks > 8) ks = 8;
+    if (ks > total / 8) ks = total / 8;
+    if ((int64_t)ks * M * Cout_pad > ws_floats) ks = (int)(ws_floats / (M * Cout_pad));
+    if (ks < 2) ks = 1;
+  }
+  a.ksplit = ks;
+  a.ws = ws;
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(Cout_pad / CV_BN), (unsigned)ks);
   hipStream_t st = qpg_stream(stream);
   if (big && vec) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<2, true>), grid, dim3(256), 0, st, a);
   else if (big) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<2, false>), grid, dim3(256), 0, st, a);
   else if (vec) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<1, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv1d_mfma_f32_kernel<1, false>), grid, dim3(256), 0, st, a);
   QPG_LAUNCH_CHECK("conv1d_mfma_f32_kernel");
+  if (ks > 1) {
+    const int64_t n = M * Cout;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    QPG_LAUNCH_CHECK("conv_splitk_reduce_kernel");
+  }
   return QPG_OK;
 }
 
@@ -272,11 +334,17 @@ extern "C" int qpg_vq_gather_f32(qpg_ctx* ctx, void* stream, const float* k, con
 // Whole-network orchestration (host C++): the layer sequences of Encoder / Decoder (encdec.py:53-136)
 // issued back to back on the caller's stream.  Scratch = three [B][T_max][width] buffers.
 // ---------------------------------------------------------------------------------------------
+// split-K scratch of the whole-network calls: the 4th region of the workspace
+#define VQ_SPLITK_ROWS 2048
+struct SplitWs {
+  float* p;
+  int64_t n;
+};
 static int conv_call(qpg_ctx* ctx, void* stream, const qpg_conv_desc& c, const float* x, int B, int T_in, int in_stride,
                      int in_offset, int dil, int T_out, int out_stride, int out_offset, int T_y, const float* res,
-                     int relu_in, int relu_out, float* y) {
+                     int relu_in, int relu_out, float* y, SplitWs sw = SplitWs{nullptr, 0}) {
   return qpg_conv1d_f32(ctx, stream, x, B, T_in, c.cin, c.w, c.b, c.taps, c.cin_pad, c.cout, c.cout_pad, in_stride,
-                        in_offset, dil, T_out, out_stride, out_offset, T_y, res, relu_in, relu_out, y);
+                        in_offset, dil, T_out, out_stride, out_offset, T_y, res, relu_in, relu_out, y, sw.p, sw.n);
 }
 
 static int ipow(int b, int e) {
@@ -294,17 +362,18 @@ extern "C" int64_t qpg_vq_workspace_floats(const qpg_vq_model* m, int B, int T) 
   if (!model_ok(m) || B < 0 || T < 0) return -1;
   int64_t cmax = m->width > m->emb ? m->width : m->emb;
   if (m->bins > cmax) cmax = m->bins;
-  return 3 * (int64_t)B * T * cmax + 64;
+  const int64_t cpad = ((cmax + CV_BN - 1) / CV_BN) * CV_BN;
+  return 3 * (((int64_t)B * T * cmax + 3) / 4 * 4) + 8 * (int64_t)VQ_SPLITK_ROWS * cpad + 64;
 }
 
 // x + conv1x1(relu(conv3_dil(relu(x)))) for each block; ping-pongs between cur and alt, h is the hidden buffer
 static int resnet_run(qpg_ctx* ctx, void* stream, const qpg_conv_desc (*blocks)[2], int depth, int growth, bool reverse,
-                      int B, int T, float*& cur, float*& alt, float* h) {
+                      int B, int T, float*& cur, float*& alt, float* h, SplitWs sw) {
   for (int d = 0; d < depth; ++d) {
     const int dil = ipow(growth, reverse ? depth - 1 - d : d);                       // resnet.py:57-62
-    int rc = conv_call(ctx, stream, blocks[d][0], cur, B, T, 1, -dil, dil, T, 1, 0, T, nullptr, 1, 1, h);
+    int rc = conv_call(ctx, stream, blocks[d][0], cur, B, T, 1, -dil, dil, T, 1, 0, T, nullptr, 1, 1, h, sw);
     if (rc) return rc;
-    rc = conv_call(ctx, stream, blocks[d][1], h, B, T, 1, 0, 1, T, 1, 0, T, cur, 0, 0, alt);
+    rc = conv_call(ctx, stream, blocks[d][1], h, B, T, 1, 0, 1, T, 1, 0, T, cur, 0, 0, alt, sw);
     if (rc) return rc;
     float* t = cur; cur = alt; alt = t;
   }
@@ -322,26 +391,27 @@ extern "C" int qpg_vq_encode_f32(qpg_ctx* ctx, void* stream, const qpg_vq_model*
   if (m->bins > cmax) cmax = m->bins;
   const int64_t slab = (((int64_t)B * T * cmax + 3) / 4) * 4;                          // T/2 rows suffice; keep simple
   float *cur = ws, *alt = ws + slab, *h = ws + 2 * slab;
+  const SplitWs sw{ws + 3 * slab, ws_floats - 3 * slab};
   const float* in = x;
   int Tc = T;
   for (int i = 0; i < m->down_t; ++i) {
     const int To = Tc / 2;
-    int rc = conv_call(ctx, stream, m->enc_down[i], in, B, Tc, 2, -1, 1, To, 1, 0, To, nullptr, 0, 0, alt);
+    int rc = conv_call(ctx, stream, m->enc_down[i], in, B, Tc, 2, -1, 1, To, 1, 0, To, nullptr, 0, 0, alt, sw);
     if (rc) return rc;
     { float* t = cur; cur = alt; alt = t; }
     Tc = To;
-    rc = resnet_run(ctx, stream, m->enc_res[i], m->depth, m->growth, false, B, Tc, cur, alt, h);
+    rc = resnet_run(ctx, stream, m->enc_res[i], m->depth, m->growth, false, B, Tc, cur, alt, h, sw);
     if (rc) return rc;
     in = cur;
   }
   float* z = latent ? latent : alt;
-  int rc = conv_call(ctx, stream, m->enc_out, cur, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, z);
+  int rc = conv_call(ctx, stream, m->enc_out, cur, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, z, sw);
   if (rc) return rc;
   // quantise: dot = z . k^T (1-tap conv over the flattened rows), then the argmin kernel
   const int64_t R = (int64_t)B * Tc;
   QPG_REQUIRE(R < 0x7fffffffll, "qpg_vq_encode_f32: too many latent rows");
   float* dot = h;
-  rc = conv_call(ctx, stream, m->kT, z, 1, (int)R, 1, 0, 1, (int)R, 1, 0, (int)R, nullptr, 0, 0, dot);
+  rc = conv_call(ctx, stream, m->kT, z, 1, (int)R, 1, 0, 1, (int)R, 1, 0, (int)R, nullptr, 0, 0, dot, sw);
   if (rc) return rc;
   float* dmin = margin ? cur : nullptr;                                               // cur is free now
   rc = qpg_vq_argmin_f32(ctx, stream, z, dot, m->kk, R, m->emb, m->bins, ids, dmin, margin);
@@ -374,21 +444,22 @@ extern "C" int qpg_vq_decode_f32(qpg_ctx* ctx, void* stream, const qpg_vq_model*
   if (m->bins > cmax) cmax = m->bins;
   const int64_t slab = (((int64_t)B * T * cmax + 3) / 4) * 4;
   float *cur = ws, *alt = ws + slab, *h = ws + 2 * slab;
+  const SplitWs sw{ws + 3 * slab, ws_floats - 3 * slab};
   int rc = qpg_vq_gather_f32(ctx, stream, m->k, ids, (int64_t)B * L, m->emb, m->bins, alt, status);   // dequantise
   if (rc) return rc;
   int Tc = L;
-  rc = conv_call(ctx, stream, m->dec_in, alt, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, cur);
+  rc = conv_call(ctx, stream, m->dec_in, alt, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, cur, sw);
   if (rc) return rc;
   for (int i = 0; i < m->down_t; ++i) {
-    rc = resnet_run(ctx, stream, m->dec_res[i], m->depth, m->growth, m->reverse_dec != 0, B, Tc, cur, alt, h);
+    rc = resnet_run(ctx, stream, m->dec_res[i], m->depth, m->growth, m->reverse_dec != 0, B, Tc, cur, alt, h, sw);
     if (rc) return rc;
     // ConvTranspose1d(k4,s2,p1): y[2m] = x[m-1].W3 + x[m].W1 ; y[2m+1] = x[m].W2 + x[m+1].W0
-    rc = conv_call(ctx, stream, m->dec_up_even[i], cur, B, Tc, 1, -1, 1, Tc, 2, 0, 2 * Tc, nullptr, 0, 0, alt);
+    rc = conv_call(ctx, stream, m->dec_up_even[i], cur, B, Tc, 1, -1, 1, Tc, 2, 0, 2 * Tc, nullptr, 0, 0, alt, sw);
     if (rc) return rc;
-    rc = conv_call(ctx, stream, m->dec_up_odd[i], cur, B, Tc, 1, 0, 1, Tc, 2, 1, 2 * Tc, nullptr, 0, 0, alt);
+    rc = conv_call(ctx, stream, m->dec_up_odd[i], cur, B, Tc, 1, 0, 1, Tc, 2, 1, 2 * Tc, nullptr, 0, 0, alt, sw);
     if (rc) return rc;
     { float* t = cur; cur = alt; alt = t; }
     Tc *= 2;
   }
-  return conv_call(ctx, stream, m->dec_out, cur, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, out);
+  return conv_call(ctx, stream, m->dec_out, cur, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, out, sw);
 }

@@ -104,6 +104,9 @@ class VQVAE:
         self.kT = _Conv(k.t().contiguous()[None], torch.zeros(self.bins), dev)      # x.k^T as a 1-tap "conv"
         self.kk = torch.sum(k.t() ** 2, dim=0).to(dev).contiguous()                # bottleneck.py:123
         self._desc = self._build_descriptor()
+        # split-K scratch of the per-layer path (the whole-network calls carve theirs out of the workspace)
+        self._split_ws = torch.empty((8 * 2048 * _pad(max(self.width, self.emb, self.bins), BN),), dtype=torch.float32,
+                                     device=dev)
         self._loaded = True
         return self
 
@@ -172,7 +175,7 @@ class VQVAE:
             out = torch.empty((B, T_y, c.cout), dtype=torch.float32, device=self.device)
         _lib.call("qpg_conv1d_f32", self.device, x, B, T_in, c.cin, c.w, c.b, c.taps, c.cin_pad, c.cout, c.cout_pad,
                   in_stride, in_offset, dil, T_out, out_stride, out_offset, T_y, residual, int(relu_in), int(relu_out),
-                  out)
+                  out, self._split_ws, self._split_ws.numel())
         return out
 
     def _resnet(self, blocks, x, B, T, reverse):
