@@ -168,18 +168,26 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
   Buf u0, u1;
   load(u0, eBeg, 0);
   for (int e0 = eBeg; e0 < eEnd; e0 += 32) {
+    // sched_barrier(0) pins the issue order: all loads of the NEXT group are issued before the 48 MFMAs of the
+    // current one (left alone, hipcc sinks them to ~10 MFMAs before their use: less than the HBM latency)
     load(u1, e0, 1);
+    __builtin_amdgcn_sched_barrier(0);
     mma(u0);
     load(u0, e0, 2);
+    __builtin_amdgcn_sched_barrier(0);
     mma(u1);
     load(u1, e0, 3);
+    __builtin_amdgcn_sched_barrier(0);
     mma(u0);
     load(u0, e0, 4);
+    __builtin_amdgcn_sched_barrier(0);
     mma(u1);
     load(u1, e0, 5);
+    __builtin_amdgcn_sched_barrier(0);
     mma(u0);
     const int en = (e0 + 32 < eEnd) ? e0 + 32 : eBeg;   // last prefetch wraps to a valid address, unused
     load(u0, en, 0);
+    __builtin_amdgcn_sched_barrier(0);
     mma(u1);
   }
 
