@@ -252,6 +252,72 @@ int qpg_vq_encode_f32(qpg_ctx*, void* stream, const qpg_vq_model* m, const float
 int qpg_vq_decode_f32(qpg_ctx*, void* stream, const qpg_vq_model* m, const int64_t* ids, int B, int L, float* ws,
                       int64_t ws_floats, float* out, int32_t* status);
 
+/* ---- VQ-VAE training step (codebook/train.py:120-148): VQVAE.forward's loss terms, the bottleneck statistics,
+ * the EMA codebook update, the loss gradient and Adam.  Reductions are ordered two-stage sums in f64
+ * (deterministic).  `ws` is a caller-owned scratch of at least qpg_vq_reduce_ws_bytes() bytes. ---- */
+int64_t qpg_vq_reduce_ws_bytes(void);
+
+/* vqvae.py:244-267.  x_out, x_target: [dev] f32 [B][T][C].  commit_loss: optional [dev] f32 scalar.
+ * out6 [dev] f32 = {loss, recons (L1), regularization, velocity, acceleration, commit} with
+ * loss = recons + w_commit*commit + w_reg*regularization + w_vel*velocity + w_acc*acceleration. */
+int qpg_vq_loss_f32(qpg_ctx*, void* stream, const float* x_out, const float* x_target, int B, int T, int C,
+                    const float* commit_loss, float w_commit, float w_reg, float w_vel, float w_acc, void* ws,
+                    int64_t ws_bytes, float* out6);
+/* d loss / d x_out of the same terms (what autograd produces for vqvae.py:244-267; sign(0) = 0), times `upstream`. */
+int qpg_vq_loss_grad_f32(qpg_ctx*, void* stream, const float* x_out, const float* x_target, int B, int T, int C,
+                         float w_reg, float w_vel, float w_acc, float upstream, float* d_x_out);
+
+/* BottleneckBlock.forward statistics (bottleneck.py:96-118, 125, 176): z [dev] f32 [R][E] encoder output rows,
+ * zq [dev] f32 [R][E] their dequantised codes (qpg_vq_gather_f32, taken BEFORE the EMA update like :169), dmin
+ * optional [dev] f32 [R] (from qpg_vq_argmin_f32).
+ * out3 [dev] f32 = {commit_loss = |zq-z|^2/(R E), fit = mean(dmin), prenorm = |z-mean(z)|/sqrt(R E)}. */
+int qpg_vq_latent_stats_f32(qpg_ctx*, void* stream, const float* z, const float* zq, const float* dmin, int64_t R,
+                            int E, void* ws, int64_t ws_bytes, float* out3);
+/* d_z = d_zq (straight-through, bottleneck.py:179; optional) + scale * d commit_loss / d z (zq detached). */
+int qpg_vq_commit_grad_f32(qpg_ctx*, void* stream, const float* z, const float* zq, int64_t R, int E, float scale,
+                           const float* d_zq, float* d_z);
+
+/* BottleneckBlock.update_k (bottleneck.py:63-94) in two halves so that the caller can all-reduce the batch sums
+ * across ranks in between (bottleneck.py:73-75):
+ *   qpg_vq_code_sums_f32: batch_sum[c][:] = sum of z rows assigned to c (ascending row order), batch_elem[c] = count;
+ *   qpg_vq_ema_update_f32: k_sum/k_elem EMA (mu), k = k_sum/k_elem where k_elem >= threshold else k_rand; also
+ *   refreshes kT ([E][ldkT] transposed copy, optional) and kk ([K] squared norms, optional) used by the quantiser,
+ *   out4 [dev] f32 = {entropy, used_curr, usage, dk}.  ws: >= K doubles. */
+int qpg_vq_code_sums_f32(qpg_ctx*, void* stream, const float* z, const int64_t* ids, int64_t R, int E, int K,
+                         float* batch_sum, float* batch_elem);
+int qpg_vq_ema_update_f32(qpg_ctx*, void* stream, float* k, float* k_sum, float* k_elem, const float* batch_sum,
+                          const float* batch_elem, const float* k_rand, float mu, float threshold, int K, int E,
+                          float* kT, int ldkT, float* kk, void* ws, int64_t ws_bytes, float* out4);
+
+/* torch.optim.Adam single step as train.py:71 configures it (no weight decay / amsgrad), over a flat buffer. */
+int qpg_adam_step_f32(qpg_ctx*, void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                      int64_t n, float lr, float beta1, float beta2, float eps, int64_t step);
+
+/* Backward of the convolution layers (what autograd computes for nn.Conv1d / nn.ConvTranspose1d in
+ * encdec.py:20-45,113 and resnet.py:31-46), on the same channels-last activations and packed weights.
+ *
+ * qpg_conv1d_bwd_data_f32: dx = conv(dy, W^T) with the forward layer's packed weights read in place.
+ *   dy [dev] f32 [B][T_in][C_dy] (C_dy = the forward layer's Cout); w_fwd [taps_fwd][fwd_Cin_pad][fwd_Cout_pad];
+ *   input tap j of THIS convolution uses weight tap tap_base + j*tap_step (a stride-1 layer: taps, base taps-1,
+ *   step -1; the strided down-convolution: one call per output parity with 2 taps, base 3 / 2, step -2; the
+ *   transposed convolution's parity sets: base 1, step -1, dilation 2).  Geometry arguments as qpg_conv1d_f32.
+ *   gate: optional, indexed like dx — result zeroed where gate <= 0 (the ReLU in front of the forward layer);
+ *   residual: optional, added after the gate (skip connection / accumulation of a second parity set).
+ * qpg_conv1d_bwd_weight_f32: dw [taps][Cin_pad][Cout_pad] (packed like the weights, fully overwritten) and
+ *   db [Cout_pad] (optional; accumulate_bias != 0 adds to it: the two parity sets of a transposed convolution
+ *   share one bias) from the layer input x (relu_in as in the forward call) and dy.  The position axis is
+ *   split over thread blocks; ws holds the partial sums (qpg_conv1d_wgrad_ws_floats(taps,Cin_pad,Cout_pad,splits)
+ *   floats for `splits` partials; more workspace = more parallelism, 1 partial is the minimum). */
+int qpg_conv1d_bwd_data_f32(qpg_ctx*, void* stream, const float* dy, int B, int T_in, int C_dy, const float* w_fwd,
+                            int taps, int fwd_Cin, int fwd_Cin_pad, int fwd_Cout_pad, int tap_base, int tap_step,
+                            int in_stride, int in_offset, int dil, int T_out, int out_stride, int out_offset, int T_y,
+                            const float* gate, const float* residual, float* dx, float* ws, int64_t ws_floats);
+int64_t qpg_conv1d_wgrad_ws_floats(int taps, int Cin_pad, int Cout_pad, int splits);
+int qpg_conv1d_bwd_weight_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, int Cin, const float* dy,
+                              int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride, int in_offset, int dil,
+                              int T_out, int out_stride, int out_offset, int T_y, int relu_in, float* dw, float* db,
+                              int accumulate_bias, float* ws, int64_t ws_floats);
+
 #ifdef __cplusplus
 }
 #endif

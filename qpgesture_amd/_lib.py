@@ -45,6 +45,15 @@ _SIGS = {
     "qpg_vq_gather_f32": [P, P, L, I, I, P, P],
     "qpg_vq_encode_f32": [P, P, I, I, P, L, P, P, P],
     "qpg_vq_decode_f32": [P, P, I, I, P, L, P, P],
+    "qpg_vq_loss_f32": [P, P, I, I, I, P, c_float, c_float, c_float, c_float, P, L, P],
+    "qpg_vq_loss_grad_f32": [P, P, I, I, I, c_float, c_float, c_float, c_float, P],
+    "qpg_vq_latent_stats_f32": [P, P, P, L, I, P, L, P],
+    "qpg_vq_commit_grad_f32": [P, P, L, I, c_float, P, P],
+    "qpg_vq_code_sums_f32": [P, P, L, I, I, P, P],
+    "qpg_vq_ema_update_f32": [P, P, P, P, P, P, c_float, c_float, I, I, P, I, P, P, L, P],
+    "qpg_conv1d_bwd_data_f32": [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, L],
+    "qpg_conv1d_bwd_weight_f32": [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, L],
+    "qpg_adam_step_f32": [P, P, P, P, L, c_float, c_float, c_float, c_float, L],
     "qpg_match_steps": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P],
 }
 
@@ -94,6 +103,10 @@ def load():
     lib.qpg_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     lib.qpg_vq_workspace_floats.argtypes = [c_void_p, c_int, c_int]
     lib.qpg_vq_workspace_floats.restype = c_int64
+    lib.qpg_conv1d_wgrad_ws_floats.argtypes = [c_int, c_int, c_int, c_int]
+    lib.qpg_conv1d_wgrad_ws_floats.restype = c_int64
+    lib.qpg_vq_reduce_ws_bytes.argtypes = []
+    lib.qpg_vq_reduce_ws_bytes.restype = c_int64
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = [c_void_p, c_void_p] + sig

@@ -33,6 +33,9 @@ struct ConvArgs {
   int T_out;                       // output positions computed per batch item in this launch
   int out_stride, out_offset, T_y; // y row = t*out_stride + out_offset, T_y rows per batch item
   int relu_in, relu_out;
+  const float* gate;   // backward-data only: same indexing as y, result is zeroed where gate <= 0 (ReLU backward)
+  int wt_rows, wt_pitch;   // backward-data only: the forward layer's Cin_pad (rows per tap) and Cout_pad (row pitch)
+  int tap_base, tap_step;  // weight tap used for input tap j = tap_base + j*tap_step (flips / parity subsets)
   int ksplit;          // > 1: blockIdx.z owns a contiguous range of K slices and writes raw partial sums to ws
   float* ws;           // [ksplit][M][Cout_pad]
 };
@@ -41,7 +44,9 @@ struct ConvArgs {
 // the activation rows (needs Cin % 4 == 0; the 135-channel input layer takes the scalar path).
 // The next K slice's global loads are issued into registers before the current slice's MFMAs (register
 // double-buffer), so HBM/L2 latency overlaps the matrix pipe with a single LDS buffer.
-template <int MT, bool VEC>
+// WT = backward-data: the contraction runs over the packed weights' OUTPUT-channel axis and the result is indexed
+// by their input-channel axis (B tile = W[tap]^T read in place, no transposed copy of the weights is kept).
+template <int MT, bool VEC, bool WT = false>
 __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
   constexpr int BM = 64 * MT;
   constexpr int AR = BM * CV_BK / 256;                 // A floats per thread per slice: 4 (MT=1) or 8 (MT=2)
@@ -60,8 +65,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
   const bool a_live = am < M;
   const int ab = a_live ? (int)(am / a.T_out) : 0;
   const int at = a_live ? (int)(am - (int64_t)ab * a.T_out) : 0;
-  // B staging: thread -> (k row, 8 consecutive n)
-  const int bk = tid >> 4, bn = (tid & 15) * 8;
+  // B staging: thread -> (k row, 8 consecutive n); transposed: thread -> (n, 8 consecutive k)
+  const int bk = WT ? (tid & 1) * 8 : tid >> 4, bn = WT ? tid >> 1 : (tid & 15) * 8;
 
   f32x16 acc[MT][2];
 #pragma unroll
@@ -101,9 +106,18 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < AR; ++i) av[i] = fmaxf(av[i], 0.f);
     }
-    const float* wp = a.w + ((int64_t)tap * a.Cin_pad + c0 + bk) * a.Cout_pad + n0 + bn;
-    b0 = *reinterpret_cast<const f32x4*>(wp);
-    b1 = *reinterpret_cast<const f32x4*>(wp + 4);
+    const int wtap = a.tap_base + tap * a.tap_step;
+    // WT: rows of the packed weights are the forward layer's input channels (this launch's n axis), the
+    // contraction index k runs along a row; a.Cout (this launch's output channels) rows per tap, pitch a.Cout_pad
+    const float* wp = WT ? a.w + ((int64_t)wtap * a.wt_rows + n0 + bn) * a.wt_pitch + c0 + bk
+                         : a.w + ((int64_t)wtap * a.Cin_pad + c0 + bk) * a.Cout_pad + n0 + bn;
+    if (WT && n0 + bn >= a.wt_rows) {
+      b0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      b1 = b0;
+    } else {
+      b0 = *reinterpret_cast<const f32x4*>(wp);
+      b1 = *reinterpret_cast<const f32x4*>(wp + 4);
+    }
   };
 
   // split-K (short sequences: a handful of blocks would otherwise walk the whole contraction alone)
@@ -118,8 +132,16 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
     __syncthreads();   // previous slice fully consumed
 #pragma unroll
     for (int i = 0; i < AR; ++i) As[ar][ak + i] = av[i];
-    *reinterpret_cast<f32x4*>(&Bs[bk][bn]) = b0;
-    *reinterpret_cast<f32x4*>(&Bs[bk][bn + 4]) = b1;
+    if (WT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Bs[bk + i][bn] = b0[i];
+        Bs[bk + 4 + i][bn] = b1[i];
+      }
+    } else {
+      *reinterpret_cast<f32x4*>(&Bs[bk][bn]) = b0;
+      *reinterpret_cast<f32x4*>(&Bs[bk][bn + 4]) = b1;
+    }
     __syncthreads();
     if (it + 1 < it1) fetch(it + 1);     // in flight during the MFMAs below
 #pragma unroll
@@ -168,6 +190,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
         const int64_t o = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout + n;
         float v = acc[mt][half][r] + bias;
         if (a.relu_out) v = fmaxf(v, 0.f);
+        if (a.gate) v = a.gate[o] > 0.f ? v : 0.f;
         if (a.res) v = a.res[o] + v;
         a.y[o] = v;
       }
@@ -189,8 +212,51 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a) {
   const int t = (int)(m - (int64_t)b * a.T_out);
   const int64_t o = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout + n;
   if (a.relu_out) v = fmaxf(v, 0.f);
+  if (a.gate) v = a.gate[o] > 0.f ? v : 0.f;
   if (a.res) v = a.res[o] + v;
   a.y[o] = v;
+}
+
+static int conv_launch(qpg_ctx* ctx, void* stream, ConvArgs& a, bool wt, float* ws, int64_t ws_floats) {
+  const int64_t M = (int64_t)a.B * a.T_out;
+  const bool vec = (a.Cin % 4) == 0 && (reinterpret_cast<uintptr_t>(a.x) % 16) == 0;
+  // 128-row tiles once there are enough rows to fill the chip with them, 64-row tiles for short sequences
+  const bool big = M * (a.Cout_pad / CV_BN) >= (int64_t)128 * 2 * ctx->n_cu;
+  const int BM = big ? 128 : 64;
+  const int64_t blocks = ((M + BM - 1) / BM) * (a.Cout_pad / CV_BN);
+  const int total = a.taps * (a.Cin_pad / CV_BK);
+  // short sequences (one clip's decode: 180..1440 rows): split the contraction over blockIdx.z so that the
+  // launch fills the chip, partial sums go through the caller's scratch and are added in a fixed order
+  int ks = 1;
+  if (ws && blocks < ctx->n_cu && total >= 16) {
+    ks = (int)((ctx->n_cu + blocks - 1) / blocks);
+    if (ks > 8) ks = 8;
+    if (ks > total / 8) ks = total / 8;
+    if ((int64_t)ks * M * a.Cout_pad > ws_floats) ks = (int)(ws_floats / (M * a.Cout_pad));
+    if (ks < 2) ks = 1;
+  }
+  a.ksplit = ks;
+  a.ws = ws;
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.Cout_pad / CV_BN), (unsigned)ks);
+  hipStream_t st = qpg_stream(stream);
+  if (wt) {
+    if (big && vec) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<2, true, true>), grid, dim3(256), 0, st, a);
+    else if (big) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<2, false, true>), grid, dim3(256), 0, st, a);
+    else if (vec) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<1, true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv1d_mfma_f32_kernel<1, false, true>), grid, dim3(256), 0, st, a);
+  } else {
+    if (big && vec) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<2, true>), grid, dim3(256), 0, st, a);
+    else if (big) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<2, false>), grid, dim3(256), 0, st, a);
+    else if (vec) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<1, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv1d_mfma_f32_kernel<1, false>), grid, dim3(256), 0, st, a);
+  }
+  QPG_LAUNCH_CHECK("conv1d_mfma_f32_kernel");
+  if (ks > 1) {
+    const int64_t n = M * a.Cout;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    QPG_LAUNCH_CHECK("conv_splitk_reduce_kernel");
+  }
+  return QPG_OK;
 }
 
 extern "C" int qpg_conv1d_f32(qpg_ctx* ctx, void* stream, const float* x, int B, int T_in, int Cin, const float* w,
@@ -210,38 +276,32 @@ extern "C" int qpg_conv1d_f32(qpg_ctx* ctx, void* stream, const float* x, int B,
   a.B = B; a.T_in = T_in; a.Cin = Cin; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad; a.taps = taps;
   a.in_stride = in_stride; a.in_offset = in_offset; a.dil = dil; a.T_out = T_out;
   a.out_stride = out_stride; a.out_offset = out_offset; a.T_y = T_y; a.relu_in = relu_in; a.relu_out = relu_out;
-  const int64_t M = (int64_t)B * T_out;
-  const bool vec = (Cin % 4) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0;
-  // 128-row tiles once there are enough rows to fill the chip with them, 64-row tiles for short sequences
-  const bool big = M * (Cout_pad / CV_BN) >= (int64_t)128 * 2 * ctx->n_cu;
-  const int BM = big ? 128 : 64;
-  const int64_t blocks = ((M + BM - 1) / BM) * (Cout_pad / CV_BN);
-  const int total = taps * (Cin_pad / CV_BK);
-  // short sequences (one clip's decode: 180..1440 rows): split the contraction over blockIdx.z so that the
-  // launch fills the chip, partial sums go through the caller's scratch and are added in a fixed order
-  int ks = 1;
-  if (ws && blocks < ctx->n_cu && total >= 16) {
-    ks = (int)((ctx->n_cu + blocks - 1) / blocks);
-    if (ks > 8) ks = 8;
-    if (ks > total / 8) ks = total / 8;
-    if ((int64_t)ks * M * Cout_pad > ws_floats) ks = (int)(ws_floats / (M * Cout_pad));
-    if (ks < 2) ks = 1;
-  }
-  a.ksplit = ks;
-  a.ws = ws;
-  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(Cout_pad / CV_BN), (unsigned)ks);
-  hipStream_t st = qpg_stream(stream);
-  if (big && vec) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<2, true>), grid, dim3(256), 0, st, a);
-  else if (big) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<2, false>), grid, dim3(256), 0, st, a);
-  else if (vec) hipLaunchKernelGGL((conv1d_mfma_f32_kernel<1, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv1d_mfma_f32_kernel<1, false>), grid, dim3(256), 0, st, a);
-  QPG_LAUNCH_CHECK("conv1d_mfma_f32_kernel");
-  if (ks > 1) {
-    const int64_t n = M * Cout;
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
-    QPG_LAUNCH_CHECK("conv_splitk_reduce_kernel");
-  }
-  return QPG_OK;
+  a.gate = nullptr; a.tap_base = 0; a.tap_step = 1; a.wt_rows = 0; a.wt_pitch = 0;
+  return conv_launch(ctx, stream, a, false, ws, ws_floats);
+}
+
+/* Backward-data of the same convolutions (autograd of nn.Conv1d / ConvTranspose1d, encdec.py / resnet.py): a
+ * convolution of dy with the transposed weights, read in place from the forward layer's packed tensor. */
+extern "C" int qpg_conv1d_bwd_data_f32(qpg_ctx* ctx, void* stream, const float* dy, int B, int T_in, int C_dy,
+                                       const float* w_fwd, int taps, int fwd_Cin, int fwd_Cin_pad, int fwd_Cout_pad,
+                                       int tap_base, int tap_step, int in_stride, int in_offset, int dil, int T_out,
+                                       int out_stride, int out_offset, int T_y, const float* gate,
+                                       const float* residual, float* dx, float* ws, int64_t ws_floats) {
+  QPG_REQUIRE(ctx && dy && w_fwd && dx, "qpg_conv1d_bwd_data_f32: null pointer");
+  QPG_REQUIRE(B >= 0 && T_in > 0 && C_dy > 0 && taps > 0 && fwd_Cin > 0 && T_out >= 0 && T_y > 0 && out_stride > 0 &&
+                  in_stride > 0 && dil > 0,
+              "qpg_conv1d_bwd_data_f32: bad size");
+  QPG_REQUIRE(fwd_Cin_pad % CV_BK == 0 && fwd_Cin_pad >= fwd_Cin && fwd_Cout_pad % CV_BN == 0 && fwd_Cout_pad >= C_dy,
+              "qpg_conv1d_bwd_data_f32: the forward layer's packing (Cin %% %d, Cout %% %d) is required", CV_BK, CV_BN);
+  if (B == 0 || T_out == 0) return QPG_OK;
+  ConvArgs a;
+  a.x = dy; a.w = w_fwd; a.bias = nullptr; a.res = residual; a.y = dx;
+  a.B = B; a.T_in = T_in; a.Cin = C_dy; a.Cin_pad = (C_dy + CV_BK - 1) / CV_BK * CV_BK;
+  a.Cout = fwd_Cin; a.Cout_pad = (fwd_Cin_pad + CV_BN - 1) / CV_BN * CV_BN; a.taps = taps;
+  a.in_stride = in_stride; a.in_offset = in_offset; a.dil = dil; a.T_out = T_out;
+  a.out_stride = out_stride; a.out_offset = out_offset; a.T_y = T_y; a.relu_in = 0; a.relu_out = 0;
+  a.gate = gate; a.tap_base = tap_base; a.tap_step = tap_step; a.wt_rows = fwd_Cin_pad; a.wt_pitch = fwd_Cout_pad;
+  return conv_launch(ctx, stream, a, true, ws, ws_floats);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -16,7 +16,8 @@ import torch
 from . import _lib
 
 DEFAULT_HPS = dict(width=512, emb_width=512, l_bins=512, downs_t=[3], strides_t=[2], depth=3, m_conv=1.0,
-                   dilation_growth_rate=3, vqvae_reverse_decoder_dilation=True, levels=1)
+                   dilation_growth_rate=3, vqvae_reverse_decoder_dilation=True, levels=1,
+                   l_mu=0.99, commit=0.02, reg=0, vel=0, acc=0)      # vqvae.py:63-64, 132-135 (absent -> 0)
 
 BK, BN = 16, 128          # K / N padding the conv kernel's tile needs (csrc/qpg_vqvae.hip)
 
@@ -65,6 +66,11 @@ class VQVAE:
         self.growth = _get(hps, "dilation_growth_rate")
         self.reverse = bool(_get(hps, "vqvae_reverse_decoder_dilation"))
         self.hop = self.stride_t ** self.down_t
+        self.mu, self.commit = float(_get(hps, "l_mu")), float(_get(hps, "commit"))
+        self.reg, self.vel, self.acc = float(_get(hps, "reg")), float(_get(hps, "vel")), float(_get(hps, "acc"))
+        self.threshold = 1.0                                        # bottleneck.py:18
+        self.training = False
+        self.k_init, self.k_sum, self.k_elem = False, None, None    # BottleneckBlock.reset_k (bottleneck.py:20-24)
         self._loaded = False
 
     # ------------------------------------------------------------------------------------------
@@ -103,12 +109,53 @@ class VQVAE:
         self.k = k.to(dev).contiguous()
         self.kT = _Conv(k.t().contiguous()[None], torch.zeros(self.bins), dev)      # x.k^T as a 1-tap "conv"
         self.kk = torch.sum(k.t() ** 2, dim=0).to(dev).contiguous()                # bottleneck.py:123
+        self._flatten_parameters()
         self._desc = self._build_descriptor()
         # split-K scratch of the per-layer path (the whole-network calls carve theirs out of the workspace)
         self._split_ws = torch.empty((8 * 2048 * _pad(max(self.width, self.emb, self.bins), BN),), dtype=torch.float32,
                                      device=dev)
         self._loaded = True
         return self
+
+    def _flatten_parameters(self):
+        """All trainable tensors (packed weights + biases) live in ONE flat buffer `self.param` with a matching
+        `self.grad`: one Adam launch and one gradient all-reduce per step.  The two parity sets of a transposed
+        convolution share their bias (ConvTranspose1d has one)."""
+        convs = []
+        for c, res in self.enc_down:
+            convs.append(c)
+            for c3, c1 in res:
+                convs += [c3, c1]
+        convs += [self.enc_out, self.dec_in]
+        for res, even, odd in self.dec_up:
+            for c3, c1 in res:
+                convs += [c3, c1]
+            convs += [even, odd]
+        convs.append(self.dec_out)
+        shared = {id(odd): even for _, even, odd in self.dec_up}
+        total = 0
+        for c in convs:
+            total += c.w.numel() + (0 if id(c) in shared else c.b.numel())
+        self.param = torch.zeros((total,), dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros((total,), dtype=torch.float32, device=self.device)
+        o = 0
+        for c in convs:
+            n = c.w.numel()
+            self.param[o:o + n].copy_(c.w.view(-1))
+            c.w, c.dw = self.param[o:o + n].view(c.w.shape), self.grad[o:o + n].view(c.w.shape)
+            o += n
+            if id(c) in shared:
+                c.b, c.db = shared[id(c)].b, shared[id(c)].db
+            else:
+                n = c.b.numel()
+                self.param[o:o + n].copy_(c.b)
+                c.b, c.db = self.param[o:o + n], self.grad[o:o + n]
+                o += n
+        self._convs = convs
+
+    def parameters(self):
+        """(param, grad) flat buffers — what optim.Adam(model.parameters()) iterates in the reference (train.py:71)."""
+        return self.param, self.grad
 
     def _build_descriptor(self):
         """qpg_vq_model (include/qpg.h): pointers into the packed tensors kept alive by this object."""
@@ -254,8 +301,285 @@ class VQVAE:
                 raise IndexError("code id out of range [0,%d)" % self.bins)
         return torch.cat(outs, dim=0)
 
-    # convenience used by dataset_to_code / cal_distance equivalents -----------------------------
+    # ------------------------------------------------------------------------------------------
+    # VQVAE.forward (vqvae.py:183-302): training / validation step
+    # ------------------------------------------------------------------------------------------
+    def _red_ws(self):
+        ws = getattr(self, "_rws", None)
+        if ws is None:
+            n = max(int(_lib.load().qpg_vq_reduce_ws_bytes()), 8 * self.bins)
+            self._rws = ws = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        return ws
+
+    def _gather_rows(self, table, idx):
+        idx = idx.to(self.device, torch.int64).contiguous()
+        out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=self.device)
+        _lib.call("qpg_vq_gather_f32", self.device, table, idx, idx.numel(), table.shape[1], table.shape[0], out, None)
+        return out
+
+    def _refresh_quantiser(self):
+        """kT / kk follow k (after init_k or a checkpoint restore)."""
+        self.kT.w[0, :self.emb, :self.bins].copy_(self.k.t())
+        self.kk.copy_(torch.sum(self.k.t() ** 2, dim=0))
+
+    def _init_k(self, z2):
+        """BottleneckBlock.init_k (bottleneck.py:39-49): k <- random rows of the first batch (tiled with noise when the
+        batch has fewer rows than codes, bottleneck.py:26-37).  The permutation comes from torch's CPU generator, as
+        in the reference, and is broadcast from rank 0 (bottleneck.py:44)."""
+        import torch.distributed as dist
+        R, E = z2.shape
+        y = z2
+        if R < self.bins:
+            n_rep = (self.bins + R - 1) // R
+            y = z2.repeat(n_rep, 1)
+            y = y + torch.randn_like(y) * (0.01 / np.sqrt(E))
+        perm = torch.randperm(y.shape[0])[:self.bins]
+        k = self._gather_rows(y.contiguous(), perm)
+        if dist.is_available() and dist.is_initialized():
+            dist.broadcast(k, 0)
+        self.k.copy_(k)
+        self.k_sum = self.k.clone()
+        self.k_elem = torch.ones((self.bins,), dtype=torch.float32, device=self.device)
+        self.k_init = True
+        self._refresh_quantiser()
+
+    def _update_k(self, z2, ids):
+        """BottleneckBlock.update_k (bottleneck.py:63-94); the batch sums are all-reduced across ranks
+        (bottleneck.py:73-75) between the two kernels."""
+        import torch.distributed as dist
+        R, E = z2.shape
+        bsum = torch.empty((self.bins, E), dtype=torch.float32, device=self.device)
+        belem = torch.empty((self.bins,), dtype=torch.float32, device=self.device)
+        _lib.call("qpg_vq_code_sums_f32", self.device, z2, ids, R, E, self.bins, bsum, belem)
+        y = z2
+        if R < self.bins:
+            n_rep = (self.bins + R - 1) // R
+            y = z2.repeat(n_rep, 1)
+            y = y + torch.randn_like(y) * (0.01 / np.sqrt(E))
+        k_rand = self._gather_rows(y.contiguous(), torch.randperm(y.shape[0])[:self.bins])
+        if dist.is_available() and dist.is_initialized():
+            dist.broadcast(k_rand, 0)
+            dist.all_reduce(bsum)
+            dist.all_reduce(belem)
+        out = torch.empty((4,), dtype=torch.float32, device=self.device)
+        ws = self._red_ws()
+        _lib.call("qpg_vq_ema_update_f32", self.device, self.k, self.k_sum, self.k_elem, bsum, belem, k_rand, self.mu,
+                  self.threshold, self.bins, E, self.kT.w, self.kT.cout_pad, self.kk, ws, ws.numel(), out)
+        return out
+
+    def _res_fwd(self, blocks, x, B, T, reverse, tape):
+        for d, (c3, c1) in enumerate(blocks):
+            dil = self.growth ** (self.depth - 1 - d if reverse else d)              # resnet.py:57-62
+            h = self._conv(c3, x, B, T, T, in_offset=-dil, dil=dil, relu_in=True, relu_out=True)
+            y = self._conv(c1, h, B, T, T, residual=x)
+            tape.append(("res", c3, c1, x, h, dil, T))
+            x = y
+        return x
+
+    def _encoder_fwd(self, x, B, T, tape):
+        """Encoder.forward (encdec.py:75-90), recording what the backward pass needs."""
+        for c, res in self.enc_down:
+            T_out = T // self.stride_t
+            y = self._conv(c, x, B, T, T_out, in_stride=self.stride_t, in_offset=-(self.stride_t // 2))
+            tape.append(("down", c, x, T))
+            x, T = self._res_fwd(res, y, B, T_out, False, tape), T_out
+        z = self._conv(self.enc_out, x, B, T, T, in_offset=-1)
+        tape.append(("conv3", self.enc_out, x, T))
+        return z
+
+    def decode_latent(self, zq, B, L, tape=None):
+        """Decoder.forward (encdec.py:115-136) on a channels-last quantised latent (B,L,emb) -> (B, 8L, C)."""
+        tape = [] if tape is None else tape
+        T = L
+        x = self._conv(self.dec_in, zq, B, T, T, in_offset=-1)
+        tape.append(("conv3", self.dec_in, zq, T))
+        for res, even, odd in self.dec_up:
+            x = self._res_fwd(res, x, B, T, self.reverse, tape)
+            y = torch.empty((B, 2 * T, even.cout), dtype=torch.float32, device=self.device)
+            self._conv(even, x, B, T, T, in_offset=-1, out=y, out_stride=2, out_offset=0, T_y=2 * T)
+            self._conv(odd, x, B, T, T, in_offset=0, out=y, out_stride=2, out_offset=1, T_y=2 * T)
+            tape.append(("up", even, odd, x, T))
+            x, T = y, 2 * T
+        out = self._conv(self.dec_out, x, B, T, T, in_offset=-1)
+        tape.append(("conv3", self.dec_out, x, T))
+        return out
+
+    def forward(self, x):
+        """VQVAE.forward (vqvae.py:183-302): x (B,T,C) -> (x_out (B,T,C), loss, metrics).  In training mode the
+        bottleneck also runs init_k / update_k (bottleneck.py:162-174) and reports its floor-averaged metrics
+        (models/utils/logger.py:50), and the activations are kept for backward().  loss and metrics are 0-d device
+        tensors (no host sync here)."""
+        assert self._loaded, "load_state_dict first"
+        x = torch.as_tensor(x).to(self.device, torch.float32).contiguous()
+        B, T, C = x.shape
+        enc_tape, dec_tape = [], []
+        z = self._encoder_fwd(x, B, T, enc_tape)                    # (B,L,E) channels-last
+        L, E = z.shape[1], z.shape[2]
+        R = B * L
+        z2 = z.view(R, E)
+        if self.training and not self.k_init:
+            self._init_k(z2)
+        # quantise with the current codebook (bottleneck.py:166), dequantise BEFORE the EMA update (:169)
+        dot = self._conv(self.kT, z2.view(1, R, E), 1, R, R)
+        ids = torch.empty((R,), dtype=torch.int64, device=self.device)
+        dmin = torch.empty((R,), dtype=torch.float32, device=self.device)
+        _lib.call("qpg_vq_argmin_f32", self.device, z2, dot, self.kk, R, E, self.bins, ids, dmin, None)
+        zq = self._gather_rows(self.k, ids)
+        stats = torch.empty((3,), dtype=torch.float32, device=self.device)      # commit, fit, prenorm
+        ws = self._red_ws()
+        _lib.call("qpg_vq_latent_stats_f32", self.device, z2, zq, dmin, R, E, ws, ws.numel(), stats)
+        ema = self._update_k(z2, ids) if self.training else None
+        x_out = self.decode_latent(zq.view(B, L, E), B, L, dec_tape)
+        out6 = torch.empty((6,), dtype=torch.float32, device=self.device)
+        _lib.call("qpg_vq_loss_f32", self.device, x_out, x, B, T, C, stats[0:1], self.commit, self.reg, self.vel,
+                  self.acc, ws, ws.numel(), out6)
+        metrics = dict(recons_loss_l1=out6[1], recons_loss=out6[1], l1_loss=out6[1], commit_loss=out6[5],
+                       regularization=out6[2], velocity_loss=out6[3], acceleration_loss=out6[4])
+        if self.training:
+            q = dict(fit=stats[1], pn=stats[2], entropy=ema[0], used_curr=ema[1], usage=ema[2], dk=ema[3])
+            metrics.update({kk: torch.floor(v) for kk, v in q.items()})        # sum(..) // len(..) with one level
+        self._saved = dict(x=x, z2=z2, zq=zq, ids=ids.view(B, L), x_out=x_out, enc=enc_tape, dec=dec_tape,
+                           B=B, T=T, L=L) if self.training else None
+        return x_out, out6[0], metrics
+
+    # ------------------------------------------------------------------------------------------
+    # backward of forward(): what `loss.backward()` (train.py:128) computes, into the flat gradient buffer
+    # ------------------------------------------------------------------------------------------
+    def _wgrad_ws(self):
+        ws = getattr(self, "_gws", None)
+        if ws is None:
+            big = max(c.taps * c.cin_pad * c.cout_pad + c.cout_pad for c in self._convs)
+            self._gws = ws = torch.empty((32 * big,), dtype=torch.float32, device=self.device)
+        return ws
+
+    def _wgrad(self, c, x, dy, B, T_in, T_out, in_stride=1, in_offset=0, dil=1, out_stride=1, out_offset=0, T_y=None,
+               relu_in=False, acc_bias=False):
+        ws = self._wgrad_ws()
+        _lib.call("qpg_conv1d_bwd_weight_f32", self.device, x, B, T_in, c.cin, dy, c.taps, c.cin_pad, c.cout,
+                  c.cout_pad, in_stride, in_offset, dil, T_out, out_stride, out_offset, T_out if T_y is None else T_y,
+                  int(relu_in), c.dw, c.db, int(acc_bias), ws, ws.numel())
+
+    def _dgrad(self, c, dy, B, T_in, T_out, taps, tap_base, tap_step, in_stride=1, in_offset=0, dil=1, out_stride=1,
+               out_offset=0, T_y=None, gate=None, residual=None, out=None):
+        T_y = T_out if T_y is None else T_y
+        if out is None:
+            out = torch.empty((B, T_y, c.cin), dtype=torch.float32, device=self.device)
+        _lib.call("qpg_conv1d_bwd_data_f32", self.device, dy, B, T_in, c.cout, c.w, taps, c.cin, c.cin_pad, c.cout_pad,
+                  tap_base, tap_step, in_stride, in_offset, dil, T_out, out_stride, out_offset, T_y, gate, residual,
+                  out, self._split_ws, self._split_ws.numel())
+        return out
+
+    def _bwd_tape(self, tape, dy, B, need_input_grad=True):
+        """Walk a forward tape backwards; dy = gradient w.r.t. the tape's last output."""
+        for i in range(len(tape) - 1, -1, -1):
+            op = tape[i]
+            last = i == 0 and not need_input_grad
+            if op[0] == "conv3":                                    # k3 s1 p1 convolution
+                _, c, x, T = op
+                self._wgrad(c, x, dy, B, T, T, in_offset=-1)
+                if not last:
+                    dy = self._dgrad(c, dy, B, T, T, 3, 2, -1, in_offset=-1)
+            elif op[0] == "res":                                    # y = x + conv1(relu(conv3_dil(relu(x))))
+                _, c3, c1, x, h, dil, T = op
+                self._wgrad(c1, h, dy, B, T, T)
+                dh = self._dgrad(c1, dy, B, T, T, 1, 0, 1, gate=h)
+                self._wgrad(c3, x, dh, B, T, T, in_offset=-dil, dil=dil, relu_in=True)
+                dy = self._dgrad(c3, dh, B, T, T, 3, 2, -1, in_offset=-dil, dil=dil, gate=x, residual=dy)
+            elif op[0] == "down":                                   # k4 s2 p1 convolution, T -> T/2
+                _, c, x, T = op
+                To = T // 2
+                self._wgrad(c, x, dy, B, T, To, in_stride=2, in_offset=-1)
+                if not last:
+                    dx = torch.empty((B, T, c.cin), dtype=torch.float32, device=self.device)
+                    self._dgrad(c, dy, B, To, To, 2, 3, -2, in_offset=-1, out_stride=2, out_offset=0, T_y=T, out=dx)
+                    self._dgrad(c, dy, B, To, To, 2, 2, -2, in_offset=0, out_stride=2, out_offset=1, T_y=T, out=dx)
+                    dy = dx
+            elif op[0] == "up":                                     # ConvTranspose1d k4 s2 p1 as two parity sets
+                _, even, odd, x, T = op
+                self._wgrad(even, x, dy, B, T, T, in_offset=-1, out_stride=2, out_offset=0, T_y=2 * T)
+                self._wgrad(odd, x, dy, B, T, T, in_offset=0, out_stride=2, out_offset=1, T_y=2 * T, acc_bias=True)
+                dx = self._dgrad(even, dy, B, 2 * T, T, 2, 1, -1, in_stride=2, in_offset=0, dil=2)
+                dy = self._dgrad(odd, dy, B, 2 * T, T, 2, 1, -1, in_stride=2, in_offset=-1, dil=2, residual=dx, out=dx)
+            else:
+                raise AssertionError(op[0])
+        return dy
+
+    def loss_grad(self, x_out, x, upstream=1.0):
+        """d loss / d x_out of the reconstruction + velocity + acceleration (+ regularisation) terms."""
+        B, T, C = x_out.shape
+        dxo = torch.empty_like(x_out)
+        _lib.call("qpg_vq_loss_grad_f32", self.device, x_out, x, B, T, C, self.reg, self.vel, self.acc,
+                  float(upstream), dxo)
+        return dxo
+
+    def backward(self, upstream=1.0, d_x_out=None):
+        """Gradients of the last training-mode forward()'s loss w.r.t. every parameter, written to self.grad (flat,
+        same layout as self.param).  The codebook is a buffer updated by EMA, not by gradient (bottleneck.py:13).
+        d_x_out: optional replacement for the loss terms' own d loss / d x_out."""
+        sv = self._saved
+        assert sv is not None, "backward() needs a training-mode forward() first"
+        B, T, L = sv["B"], sv["T"], sv["L"]
+        C = self.input_dim
+        dxo = self.loss_grad(sv["x_out"], sv["x"], upstream) if d_x_out is None else d_x_out.contiguous()
+        dzq = self._bwd_tape(sv["dec"], dxo, B)
+        dz = torch.empty_like(dzq)
+        R, E = B * L, self.emb
+        _lib.call("qpg_vq_commit_grad_f32", self.device, sv["z2"], sv["zq"], R, E, float(upstream) * self.commit, dzq, dz)
+        self._bwd_tape(sv["enc"], dz, B, need_input_grad=False)
+        self._saved = None
+        return self.grad
+
+    __call__ = forward
+
+    def state_dict(self, prefix=""):
+        """The reference's `model.state_dict()` layout (train.py:114-116) rebuilt from the packed tensors: Conv1d
+        weight (Cout,Cin,k), ConvTranspose1d weight (Cin,Cout,4), bottleneck buffer k.  `prefix="module."` gives the
+        DataParallel-wrapped names the reference's checkpoints carry."""
+        return self._export(prefix, False)
+
+    def named_gradients(self, prefix=""):
+        """Gradients of the last backward() under the reference's parameter names (`p.grad` of named_parameters())."""
+        return self._export(prefix, True)
+
+    def _export(self, prefix, grads):
+        from collections import OrderedDict
+        out = OrderedDict()
+        W = (lambda c: c.dw) if grads else (lambda c: c.w)
+        Bv = (lambda c: c.db) if grads else (lambda c: c.b)
+
+        def put(name, c):
+            out[prefix + name + ".weight"] = W(c)[:, :c.cin, :c.cout].permute(2, 1, 0).contiguous().cpu()
+            out[prefix + name + ".bias"] = Bv(c)[:c.cout].clone().cpu()
+
+        def put_res(name, blocks):
+            for d, (c3, c1) in enumerate(blocks):
+                put("%s.model.%d.model.1" % (name, d), c3)
+                put("%s.model.%d.model.3" % (name, d), c1)
+
+        enc = "encoders.0.level_blocks.0.model"
+        for i, (c, res) in enumerate(self.enc_down):
+            put("%s.%d.0" % (enc, i), c)
+            put_res("%s.%d.1" % (enc, i), res)
+        put("%s.%d" % (enc, self.down_t), self.enc_out)
+        dec = "decoders.0.level_blocks.0.model"
+        put(dec + ".0", self.dec_in)
+        for i, (res, even, odd) in enumerate(self.dec_up):
+            put_res("%s.%d.0" % (dec, i + 1), res)
+            e = W(even)[:, :even.cin, :even.cout]
+            o = W(odd)[:, :odd.cin, :odd.cout]
+            out["%s%s.%d.1.weight" % (prefix, dec, i + 1)] = torch.stack((o[1], e[1], o[0], e[0]), dim=2).contiguous().cpu()
+            out["%s%s.%d.1.bias" % (prefix, dec, i + 1)] = Bv(even)[:even.cout].clone().cpu()
+        put("decoders.0.out", self.dec_out)
+        if not grads:
+            out[prefix + "bottleneck.level_blocks.0.k"] = self.k.clone().cpu()
+        return out
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
     def eval(self):
+        self.training = False
         return self
 
     @property

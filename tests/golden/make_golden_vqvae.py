@@ -72,5 +72,57 @@ def main():
           "latent absmax", np.abs(out["latent"]).max(), "poses absmax", np.abs(out["poses"]).max())
 
 
+TRAIN_B, TRAIN_SEED, TRAIN_LR, TRAIN_BETAS, SUB = 20, 1234, 3e-5, (0.5, 0.999), 997
+
+
+def main_train():
+    """One validation forward + two training steps of the reference (codebook/train.py:120-131: zero_grad, forward,
+    backward, Adam step) on seeded weights/inputs.  Committed: losses, metrics, code ids, strided samples of every
+    parameter gradient and of the codebook after each EMA update."""
+    sd = synth.make_vqvae_state_dict(7)
+    model = reference_model(sd)
+    rng = np.random.Generator(np.random.PCG64(8))
+    x = torch.from_numpy(rng.standard_normal((TRAIN_B, 240, 135)).astype(np.float32))
+    out = {}
+
+    def put(tag, loss, met):
+        out[tag + "_loss"] = np.float32(loss.item())
+        for k, v in met.items():
+            out["%s_%s" % (tag, k)] = np.float32(float(v))
+
+    with torch.no_grad():
+        model.eval()
+        xo, loss, met = model(x)
+        put("eval", loss, met)
+        out["eval_ids"] = model.module.encode(x)[0].numpy()
+        out["eval_xout_sub"] = xo.numpy().reshape(-1)[::SUB].copy()
+    model.train()
+    opt = torch.optim.Adam(model.module.parameters(), lr=TRAIN_LR, betas=TRAIN_BETAS)
+    torch.manual_seed(TRAIN_SEED)
+    names = [n for n, _ in model.module.named_parameters()]
+    for step in (1, 2):
+        opt.zero_grad()
+        xo, loss, met = model(x)
+        loss.backward()
+        tag = "step%d" % step
+        put(tag, loss, met)
+        out[tag + "_k_sub"] = model.module.bottleneck.level_blocks[0].k.detach().numpy().reshape(-1)[::SUB].copy()
+        out[tag + "_grad_norm"] = np.array([p.grad.norm().item() for _, p in model.module.named_parameters()], np.float32)
+        for i, (n, p) in enumerate(model.module.named_parameters()):
+            out["%s_grad_%03d" % (tag, i)] = p.grad.numpy().reshape(-1)[::SUB].copy()
+        opt.step()
+        for i, (n, p) in enumerate(model.module.named_parameters()):
+            out["%s_param_%03d" % (tag, i)] = p.detach().numpy().reshape(-1)[::SUB].copy()
+    out["param_names"] = np.array(names)
+    out["meta"] = np.array([7, 8, TRAIN_B, TRAIN_SEED], np.int64)
+    np.savez_compressed(os.path.join(HERE, "vqvae_train_w512_s7.npz"), **out)
+    print("eval loss", out["eval_loss"], "step1", out["step1_loss"], "step2", out["step2_loss"], len(names), "params",
+          os.path.getsize(os.path.join(HERE, "vqvae_train_w512_s7.npz")), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        sys.argv = sys.argv[:1]
+        main_train()
+    else:
+        main()
