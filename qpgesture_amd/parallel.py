@@ -27,3 +27,44 @@ def allreduce_min_index(dist, idx, group=None):
     dist_.all_reduce(cand, op=dist_.ReduceOp.MIN, group=group)
     cand = torch.where(cand == INT_MAX, torch.full_like(cand, -1), cand)
     return best, cand
+
+
+# ---- data-parallel VQ-VAE training (codebook/train.py; bottleneck.py:44,73-75 collectives) ----------------------
+def _active():
+    import torch.distributed as dist_
+    return dist_.is_available() and dist_.is_initialized() and dist_.get_world_size() > 1
+
+
+def _host_staged():
+    """gloo has no device-side transport here: stage through the host (the RCCL backend reduces in place)."""
+    import torch.distributed as dist_
+    return dist_.get_backend() == "gloo"
+
+
+def allreduce_sum_(t, average=False):
+    """In-place SUM (or mean) all-reduce of a device tensor; a no-op without an initialised process group."""
+    if not _active():
+        return t
+    import torch.distributed as dist_
+    if _host_staged():
+        h = t.cpu()
+        dist_.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist_.all_reduce(t)
+    if average:
+        t.div_(dist_.get_world_size())
+    return t
+
+
+def broadcast_(t, src=0):
+    if not _active():
+        return t
+    import torch.distributed as dist_
+    if _host_staged():
+        h = t.cpu()
+        dist_.broadcast(h, src)
+        t.copy_(h)
+    else:
+        dist_.broadcast(t, src)
+    return t

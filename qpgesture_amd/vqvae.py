@@ -13,7 +13,7 @@ HIP kernel launch.  No torch.nn / cuDNN / MIOpen call, no CPU fallback.
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, parallel
 
 DEFAULT_HPS = dict(width=512, emb_width=512, l_bins=512, downs_t=[3], strides_t=[2], depth=3, m_conv=1.0,
                    dilation_growth_rate=3, vqvae_reverse_decoder_dilation=True, levels=1,
@@ -326,7 +326,6 @@ class VQVAE:
         """BottleneckBlock.init_k (bottleneck.py:39-49): k <- random rows of the first batch (tiled with noise when the
         batch has fewer rows than codes, bottleneck.py:26-37).  The permutation comes from torch's CPU generator, as
         in the reference, and is broadcast from rank 0 (bottleneck.py:44)."""
-        import torch.distributed as dist
         R, E = z2.shape
         y = z2
         if R < self.bins:
@@ -334,9 +333,7 @@ class VQVAE:
             y = z2.repeat(n_rep, 1)
             y = y + torch.randn_like(y) * (0.01 / np.sqrt(E))
         perm = torch.randperm(y.shape[0])[:self.bins]
-        k = self._gather_rows(y.contiguous(), perm)
-        if dist.is_available() and dist.is_initialized():
-            dist.broadcast(k, 0)
+        k = parallel.broadcast_(self._gather_rows(y.contiguous(), perm), 0)
         self.k.copy_(k)
         self.k_sum = self.k.clone()
         self.k_elem = torch.ones((self.bins,), dtype=torch.float32, device=self.device)
@@ -346,7 +343,6 @@ class VQVAE:
     def _update_k(self, z2, ids):
         """BottleneckBlock.update_k (bottleneck.py:63-94); the batch sums are all-reduced across ranks
         (bottleneck.py:73-75) between the two kernels."""
-        import torch.distributed as dist
         R, E = z2.shape
         bsum = torch.empty((self.bins, E), dtype=torch.float32, device=self.device)
         belem = torch.empty((self.bins,), dtype=torch.float32, device=self.device)
@@ -357,10 +353,9 @@ class VQVAE:
             y = z2.repeat(n_rep, 1)
             y = y + torch.randn_like(y) * (0.01 / np.sqrt(E))
         k_rand = self._gather_rows(y.contiguous(), torch.randperm(y.shape[0])[:self.bins])
-        if dist.is_available() and dist.is_initialized():
-            dist.broadcast(k_rand, 0)
-            dist.all_reduce(bsum)
-            dist.all_reduce(belem)
+        parallel.broadcast_(k_rand, 0)
+        parallel.allreduce_sum_(bsum)
+        parallel.allreduce_sum_(belem)
         out = torch.empty((4,), dtype=torch.float32, device=self.device)
         ws = self._red_ws()
         _lib.call("qpg_vq_ema_update_f32", self.device, self.k, self.k_sum, self.k_elem, bsum, belem, k_rand, self.mu,
@@ -613,3 +608,43 @@ def cal_distance(model, n_codes=512, n_rep=30):
     code = np.tile(np.arange(n_codes, dtype=np.int64)[:, None], (1, n_rep))
     poses = model.decode([torch.from_numpy(code)]).cpu().numpy()
     return dict(code=code, poses=poses, signature=np.mean(poses, axis=1))
+
+
+def init_state_dict(hps=None, input_dim=135, seed=None):
+    """A freshly constructed reference model's `state_dict()` (train.py:75): the layer set of encdec.py / resnet.py
+    with torch.nn's default initialisation (Conv1d / ConvTranspose1d.reset_parameters: weight and bias uniform in
+    +-1/sqrt(fan_in), fan_in = weight.size(1) * kernel_size) and a zero codebook buffer (bottleneck.py:21), which the
+    first training batch overwrites (init_k).  Draws come from torch's CPU generator (seeded if `seed` is given)."""
+    from collections import OrderedDict
+    hps = hps or {}
+    width, emb, bins = _get(hps, "width"), _get(hps, "emb_width"), _get(hps, "l_bins")
+    down_t, depth = _get(hps, "downs_t")[0], _get(hps, "depth")
+    gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
+    sd = OrderedDict()
+
+    def put(name, shape):
+        bound = 1.0 / float(np.sqrt(shape[1] * shape[2]))
+        sd[name + ".weight"] = (torch.rand(shape, generator=gen) * 2 - 1) * bound
+        sd[name + ".bias"] = (torch.rand((shape[0],), generator=gen) * 2 - 1) * bound
+
+    def put_res(name):
+        n_state = int(_get(hps, "m_conv") * width)
+        for d in range(depth):
+            put("%s.model.%d.model.1" % (name, d), (n_state, width, 3))
+            put("%s.model.%d.model.3" % (name, d), (width, n_state, 1))
+
+    enc = "encoders.0.level_blocks.0.model"
+    for i in range(down_t):
+        put("%s.%d.0" % (enc, i), (width, input_dim if i == 0 else width, 4))
+        put_res("%s.%d.1" % (enc, i))
+    put("%s.%d" % (enc, down_t), (emb, width, 3))
+    dec = "decoders.0.level_blocks.0.model"
+    put(dec + ".0", (width, emb, 3))
+    for i in range(down_t):
+        put_res("%s.%d.0" % (dec, i + 1))
+        bound = 1.0 / float(np.sqrt(width * 4))                     # ConvTranspose1d weight (Cin, Cout, 4): size(1)*k
+        sd["%s.%d.1.weight" % (dec, i + 1)] = (torch.rand((width, width, 4), generator=gen) * 2 - 1) * bound
+        sd["%s.%d.1.bias" % (dec, i + 1)] = (torch.rand((width,), generator=gen) * 2 - 1) * bound
+    put("decoders.0.out", (input_dim, emb, 3))
+    sd["bottleneck.level_blocks.0.k"] = torch.zeros((bins, emb))
+    return sd
