@@ -219,7 +219,24 @@ def vqvae_bench(dev, a, world, rank):
     te = timed(lambda: model.encode(x), 10)
     td = timed(lambda: model.decode([ids]), 10)
     enc_flop = 1.639e9 * Bw                                        # 1.639 GFLOP per 240-frame window
-    return {"vqvae_encode_frames_per_s": round(240 * Bw * world / te, 1),
+    # training step (codebook/train.py:120-131) at the reference's batch size of 256 windows per rank: forward with
+    # EMA codebook update, backward, flat-gradient all-reduce (N > 1), Adam
+    from qpgesture_amd import parallel
+    from qpgesture_amd.optim import Adam
+    tm = VQVAE(dict(vel=1, acc=1), 135, device=dev).load_state_dict(synth.make_vqvae_state_dict(7)).train()
+    opt = Adam(tm.parameters(), lr=3e-5, betas=(0.5, 0.999))
+
+    def train_step():
+        tm(x)
+        tm.backward()
+        parallel.allreduce_sum_(tm.grad, average=True)
+        opt.step()
+    tt = timed(train_step, 5)
+    train_flop = 3 * (1.639e9 + 1.908e9) * Bw                      # forward + data-gradient + weight-gradient GEMMs
+    return {"vqvae_train_windows_per_s": round(Bw * world / tt, 1),
+            "vqvae_train_ms_per_step_b256": round(tt * 1e3, 3),
+            "vqvae_train_tflops_f32": round(train_flop / tt / 1e12, 2),
+            "vqvae_encode_frames_per_s": round(240 * Bw * world / te, 1),
             "vqvae_encode_ms_per_batch256": round(te * 1e3, 3),
             "vqvae_encode_tflops_f32": round(enc_flop / te / 1e12, 2),
             "vqvae_decode_frames_per_s": round(1440 * world / td, 1),

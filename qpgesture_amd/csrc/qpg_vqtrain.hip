@@ -196,33 +196,40 @@ __global__ __launch_bounds__(256) void vq_commit_grad_kernel(const float* __rest
 // EMA codebook update (bottleneck.py:63-94)
 // ---------------------------------------------------------------------------------------------
 // _k_sum[c][:] = sum_{r: ids[r]==c} z[r][:], _k_elem[c] = count — one block per code, rows visited in ascending r
-// (ordered, deterministic; the id list is read through the scalar cache since every lane reads the same element).
+// (ordered, deterministic).  Per 1024-row chunk every thread tests 8 consecutive ids, a block-wide exclusive scan of
+// the hit counts gives each thread its slot in the ordered row list, then all threads add the listed rows.
 __global__ __launch_bounds__(128) void vq_code_sums_kernel(const float* __restrict__ z, const int64_t* __restrict__ ids,
                                                            int64_t R, int E, float* __restrict__ ksum,
                                                            float* __restrict__ kelem) {
   const int c = blockIdx.x;
   __shared__ int rows[1024];
-  __shared__ int n_rows;
+  __shared__ int wave_tot[2];
   const int e4 = E >> 2;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};   // E <= 1024
   int count = 0;
   for (int64_t r0 = 0; r0 < R; r0 += 1024) {
-    // ordered compaction of this chunk's matching rows: one wave scans 1024 ids with ballots
-    if (threadIdx.x == 0) n_rows = 0;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      int base = 0;
-      for (int j = 0; j < 1024; j += 64) {
-        const int64_t r = r0 + j + threadIdx.x;
-        const bool hit = r < R && ids[r] == c;
-        const unsigned long long m = __ballot(hit);
-        if (hit) rows[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = (int)(r - r0);
-        base += __popcll(m);
-      }
-      if (threadIdx.x == 0) n_rows = base;
+    const int64_t rb = r0 + (int64_t)threadIdx.x * 8;
+    unsigned hits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (rb + j < R && ids[rb + j] == c) hits |= 1u << j;
+    const int n = __popc(hits);
+    // exclusive scan over the 128 threads: wave-level shuffle scan + the other wave's total
+    int incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
     }
+    if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
-    const int nr = n_rows;
+    int pos = incl - n + (wv ? wave_tot[0] : 0);
+    const int nr = wave_tot[0] + wave_tot[1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (hits & (1u << j)) rows[pos++] = threadIdx.x * 8 + j;
+    __syncthreads();
     for (int j = 0; j < nr; ++j) {
       const float* row = z + (r0 + rows[j]) * E;
 #pragma unroll
