@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--windows", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="DB windows in the CPU baseline sample")
+    ap.add_argument("--no-overlap", action="store_true", help="run the text sweep after the audio sweep (one stream)")
     ap.add_argument("--check", action="store_true", help="verify the matched codes against a 1-rank run")
     a = ap.parse_args()
 
@@ -94,6 +95,7 @@ def main():
     ctx_full = _ShardView(ctx_shard, lo, hi, N)
     db = GestureDB(code, interp_full, ctx_full, phase, sig, device=dev, rank=rank, world=world)
     knn = CodeKNN(db, rng=np.random.RandomState(123456))
+    knn.overlap_sweeps = not a.no_overlap
 
     # one clip per rank; every rank holds all clips' windows (they are small: M*180*1024 f32 = 4.4 MB)
     clips = [synth.make_db(M, 1000 + r) for r in range(world)]

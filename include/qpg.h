@@ -159,6 +159,7 @@ int qpg_l2_table_f32(qpg_ctx*, void* stream, const float* sig, int K, int Dm, fl
 #define QPG_MODE_AUD_TXT 0 /* shipped flags: audio top-1 vs text top-1, phase gate (GestureKNN.py:627-657) */
 #define QPG_MODE_AUD 1     /* audio only: top-2 audio candidates through the phase gate (:593-608)          */
 #define QPG_MODE_TXT 2     /* text only: top-2 text candidates through the phase gate (:610-625)            */
+#define QPG_MODE_SERIAL_WALK 0x100 /* OR-ed into mode: force the one-wave sequential walk (validation of the tabulated one) */
 
 /* Walk all M windows x `steps` matching steps of a clip on the device.
  *   aud_rank/txt_rank: [dev] i16 [Q][K] stable ranks of the per-code minima (Q = M*steps);
@@ -169,8 +170,9 @@ int qpg_l2_table_f32(qpg_ctx*, void* stream, const float* sig, int K, int Dm, fl
  *   *_pslot [G]:       phase start frame int(k/398*240) of a grid position (GestureKNN.py:632);
  *   phase:             [dev] f32 [N][Tp][2][8] (phase shift, amplitude);
  *   seed_code/seed_phase [dev f32 8x16]: init_code_phase() draw (GestureKNN.py:462-473);
- *   gate_tables:       [dev] i32 [2][Q][K] scratch: the two phase-gate candidates for every (step, previous
- *                      code), tabulated in parallel before the sequential walk;
+ *   gate_tables:       [dev] i32 [3][Q][K] scratch: the two phase-gate candidates for every (step, previous
+ *                      code), and the gate outcome for every (step, previous code, previous vote) — both
+ *                      tabulated in parallel, so that the sequential part is Q dependent 2-byte lookups;
  *   out_codes [dev] i32 [M][30]; out_phase [dev] f32 [M][steps][8][16]; out_vote [dev] i32 [M][steps];
  *   out_status [dev] i32 [1]: 1 if a code absent from the DB won a rank fusion (the reference raises
  *   IndexError there, GestureKNN.py:631-632).

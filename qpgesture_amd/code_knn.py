@@ -196,6 +196,8 @@ class CodeKNN:
         self.n_db_seq = db.N
         self.use_phase, self.use_txt = use_phase, use_txt
         self.rng = rng if rng is not None else np.random
+        self.overlap_sweeps = True          # text sweep on a second HIP stream underneath the audio sweep
+        self.serial_walk = False            # True: force the one-wave sequential walk (tests compare the two)
 
     def _audio_grid(self):
         db = self.db
@@ -444,18 +446,35 @@ class CodeKNN:
         q_win, q_t, gw, gr = cache[M]
         T = dict(aud_d=None, aud_idx=None, aud_rank=None, txt_d=None, txt_idx=None, txt_rank=None)
         sharded = db.world > 1
+        # The two sweeps are independent until the walk and lean on different pipes (f64 matrix cores vs f32
+        # VALU): with both modalities on, the text side runs on a second HIP stream underneath the audio sweep.
+        overlap = mode == MODE_AUD_TXT and self.overlap_sweeps and not torch.cuda.is_current_stream_capturing()
+        main = torch.cuda.current_stream(dev)
+        if overlap:
+            side = self.__dict__.get("_side_stream")
+            if side is None:
+                side = self.__dict__["_side_stream"] = torch.cuda.Stream(dev)
+            side.wait_stream(main)
+
+        def text_side():
+            qtxt = test_context[gw, gr].contiguous()
+            r = self.sweep_text(qtxt, want_rank=not sharded, reduce=not sharded)
+            T["txt_d"], T["txt_idx"] = r[0], r[1]
+            if not sharded:
+                T["txt_rank"] = r[2]
+        if overlap:
+            with torch.cuda.stream(side):
+                text_side()
         if mode in (MODE_AUD_TXT, MODE_AUD):
             fn = self.sweep_audio_wavvq if self.use_wavvq else self.sweep_audio
             r = fn(test_interp, q_win, q_t, want_rank=not sharded, reduce=not sharded)
             T["aud_d"], T["aud_idx"] = r[0], r[1]
             if not sharded:
                 T["aud_rank"] = r[2]
-        if mode in (MODE_AUD_TXT, MODE_TXT):
-            qtxt = test_context[gw, gr].contiguous()
-            r = self.sweep_text(qtxt, want_rank=not sharded, reduce=not sharded)
-            T["txt_d"], T["txt_idx"] = r[0], r[1]
-            if not sharded:
-                T["txt_rank"] = r[2]
+        if overlap:
+            main.wait_stream(side)
+        elif mode in (MODE_AUD_TXT, MODE_TXT):
+            text_side()
         if sharded:
             # ONE min+index exchange for both modalities: the f32 text minima are widened to f64 (exact) and ride
             # in the same all-reduce(MIN) as the audio minima; one more all-reduce(MIN) for the candidate indices
@@ -484,7 +503,7 @@ class CodeKNN:
         out_phase = torch.empty((M, steps, 8, 16), dtype=torch.float32, device=dev)
         out_vote = torch.empty((M, steps), dtype=torch.int32, device=dev)
         status = torch.zeros((1,), dtype=torch.int32, device=dev)
-        gate = torch.empty((2, M * steps, db.K), dtype=torch.int32, device=dev)
+        gate = torch.empty((3, M * steps, db.K), dtype=torch.int32, device=dev)
         q0 = window_offset * steps
 
         def sl(t):
@@ -492,7 +511,8 @@ class CodeKNN:
         a_cidx, a_pslot, a_G = self._audio_grid()
         _lib.call("qpg_match_steps", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]), sl(T["txt_idx"]),
                   db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
-                  db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode, M, steps, db.K, int(seed_code), sp,
+                  db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode | (0x100 if self.serial_walk else 0), M, steps,
+                  db.K, int(seed_code), sp,
                   gate, out_codes, out_phase, out_vote, status)
         if not sync:
             return out_codes, out_phase, out_vote, status

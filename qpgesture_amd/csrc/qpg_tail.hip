@@ -328,6 +328,140 @@ __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
   if (lane == 0) A.out_status[0] = bad;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Tabulated walk.  The running state entering step q is (previous code, previous phase block), and BOTH are
+// functions of the previous step's winning candidate, which is one of the two gate candidates of the previous
+// code before it: at most 2K states sigma = (p', vote) per step.  So the phase gate is evaluated for EVERY
+// reachable state of EVERY step in parallel (gate_table_kernel: 8 lanes per evaluation, same f32 arithmetic in
+// the same order as match_walk_kernel), and the sequential part shrinks to Q dependent 2-byte LDS lookups
+// (gate_chase_kernel), followed by a parallel gather of the winners' codes / phase blocks.
+//   G[q][sigma] = (p << 1) | vote, p = the previous code seen by step q in state sigma; G[0][0] = the seed's step.
+// ---------------------------------------------------------------------------------------------
+struct GateGeom {
+  int s_last, off_last;   // the kept code that seeds the next window: step and offset inside its payload
+};
+
+__device__ __forceinline__ const float* cand_block(const TailArgs& A, int which, int ci, int* pay_base) {
+  const int G = which ? A.G1 : A.G0;
+  const int cc = ci < 0 ? 0 : ci;
+  const int j = cc / G, g = cc - j * G;
+  const int ps = (which ? A.pslot1 : A.pslot0)[g];
+  *pay_base = j * A.code_ld + (which ? A.cidx1 : A.cidx0)[g];
+  return A.phase + ((int64_t)j * A.Tp + ps) * 16;
+}
+
+__global__ __launch_bounds__(256) void gate_table_kernel(TailArgs A, GateGeom geo, uint16_t* __restrict__ Gt) {
+  const int K = A.K, Q = A.M * A.steps;
+  const int lane = threadIdx.x & 63;
+  const int k = (lane >> 2) & 1, l = lane & 3;
+  const int64_t task = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;          // (q, sigma)
+  const int64_t n_task = (int64_t)Q * 2 * K;
+  const bool live = task < n_task;
+  const int q = live ? (int)(task / (2 * K)) : 0;
+  const int sigma = live ? (int)(task - (int64_t)q * 2 * K) : 0;
+  if (q == 0 && sigma != 0) return;                     // uniform per 8-lane group; the shuffles below are group-local
+  const int s = q % A.steps;
+  int p;
+  const float* prev;                                    // 128 floats: the previous phase block
+  if (q == 0) {
+    p = A.seed_code;
+    prev = A.seed_phase;
+  } else {
+    const int pp = sigma >> 1, kp = sigma & 1;
+    const int ci = (kp ? A.T1 : A.T0)[(int64_t)(q - 1) * K + pp];
+    int pb;
+    prev = cand_block(A, kp, ci, &pb) + 384;            // rows [ps+24, ps+32): the winner's last 8 frames
+    p = A.code[pb + (s == 0 ? geo.off_last : A.step_codes - 1)];
+  }
+  const int ck = (k ? A.T1 : A.T0)[(int64_t)q * K + p];
+  int pb_unused;
+  const float* head = cand_block(A, k, ck, &pb_unused);
+  // a = [prev[48:], head[:80]], b = [prev[80:], head[:48]]  (GestureKNN.py:636); lane l owns e = 16g + 4u + l
+  float xa[32], xb[32];
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+#pragma unroll
+    for (int u = 3; u >= 0; --u) {
+      const int e = g * 16 + u * 4 + l;
+      const float va = e < 80 ? prev[48 + e] : head[e - 80];
+      const float vb = e < 48 ? prev[80 + e] : head[e - 48];
+      xa[g * 4 + u] = va;
+      xb[g * 4 + u] = vb;
+      sa = f_add(f_mul(va, va), sa);
+      sb = f_add(f_mul(vb, vb), sb);
+    }
+  }
+  const float eps10 = 10.f * 1.1920928955078125e-07f;
+  float na = f_sqrt(lane4_sum(sa, l)), nb = f_sqrt(lane4_sum(sb, l));
+  if (na < eps10) na = 1.f;
+  if (nb < eps10) nb = 1.f;
+  float sd = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+#pragma unroll
+    for (int u = 3; u >= 0; --u) {
+      const float d = f_sub(f_div(xa[g * 4 + u], na), f_div(xb[g * 4 + u], nb));
+      sd = f_add(f_mul(d, d), sd);
+    }
+  }
+  const float score = f_mul(0.5f, lane4_sum(sd, l));
+  const float other = __shfl_xor(score, 4, 64);
+  const float s0 = k ? other : score, s1 = k ? score : other;
+  const int fi = (s1 < s0) ? 1 : 0;                     // list.index(min): first on ties
+  if (live && (lane & 7) == 0) Gt[task] = (uint16_t)((p << 1) | fi);
+}
+
+#define QPG_CHASE_QMAX 2048
+__global__ __launch_bounds__(256) void gate_chase_kernel(TailArgs A, const uint16_t* __restrict__ Gt) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t gl[];     // [steps][2K] of the current window
+  __shared__ uint16_t sig[QPG_CHASE_QMAX];
+  __shared__ int bad_s;
+  const int K = A.K, Q = A.M * A.steps, tid = threadIdx.x;
+  const int per_w = A.steps * 2 * K;                                // u16 per window
+  if (tid == 0) bad_s = 0;
+  int sigma = 0;
+  for (int w = 0; w < A.M; ++w) {
+    __syncthreads();
+    const int4* src = reinterpret_cast<const int4*>(Gt + (int64_t)w * per_w);
+    int4* dst = reinterpret_cast<int4*>(gl);
+    for (int v = tid; v < per_w / 8; v += 256) dst[v] = src[v];
+    __syncthreads();
+    if (tid == 0) {
+      for (int s = 0; s < A.steps; ++s) {
+        sigma = (w == 0 && s == 0) ? gl[0] : gl[s * 2 * K + sigma];
+        sig[w * A.steps + s] = (uint16_t)sigma;
+      }
+    }
+  }
+  __syncthreads();
+  // parallel epilogue: the winners' phase blocks, votes, codes; absent-candidate check of every visited gate
+  for (int i = tid; i < Q * 32; i += 256) {                         // 32 x 16 B per phase block
+    const int q = i >> 5, v = i & 31;
+    const int sg = sig[q], p = sg >> 1, fi = sg & 1;
+    const int ci = (fi ? A.T1 : A.T0)[(int64_t)q * K + p];
+    int pb;
+    const float* blk = cand_block(A, fi, ci, &pb) + 384;
+    reinterpret_cast<f32x4*>(A.out_phase + (int64_t)q * 128)[v] = reinterpret_cast<const f32x4*>(blk)[v];
+    if (v == 0) {
+      A.out_vote[q] = fi;
+      if (A.T0[(int64_t)q * K + p] < 0 || A.T1[(int64_t)q * K + p] < 0) bad_s = 1;
+    }
+  }
+  for (int i = tid; i < A.M * A.codes_per_window; i += 256) {
+    const int w = i / A.codes_per_window, c = i - w * A.codes_per_window;
+    const int q = w * A.steps + c / A.step_codes;
+    const int sg = sig[q], p = sg >> 1, fi = sg & 1;
+    const int ci = (fi ? A.T1 : A.T0)[(int64_t)q * K + p];
+    int pb;
+    cand_block(A, fi, ci, &pb);
+    A.out_codes[i] = A.code[pb + c % A.step_codes];
+  }
+  __syncthreads();
+  if (tid == 0) A.out_status[0] = bad_s;
+}
+
 extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
                                const int16_t* txt_rank, const int32_t* txt_idx, const int16_t* pos_rank,
                                const int16_t* freq_rank, const int32_t* code, int code_ld, const int32_t* aud_cidx,
@@ -338,6 +472,8 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   QPG_REQUIRE(ctx && pos_rank && freq_rank && code && phase && seed_phase && gate_tables && out_codes && out_phase &&
                   out_vote && out_status,
               "qpg_match_steps: null pointer");
+  const bool serial_walk = (mode & QPG_MODE_SERIAL_WALK) != 0;
+  mode &= ~QPG_MODE_SERIAL_WALK;
   QPG_REQUIRE(mode >= 0 && mode <= 2, "qpg_match_steps: bad mode %d", mode);
   QPG_REQUIRE(mode == QPG_MODE_TXT || (aud_rank && aud_idx && aud_cidx && aud_pslot && Ga > 0),
               "qpg_match_steps: audio tables missing");
@@ -365,7 +501,24 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   A.codes_per_window = (steps * 4 < 30) ? steps * 4 : 30;
   A.K = K; A.seed_code = seed_code; A.seed_phase = seed_phase;
   A.out_codes = out_codes; A.out_phase = out_phase; A.out_vote = out_vote; A.out_status = out_status;
-  hipLaunchKernelGGL(match_walk_kernel, dim3(1), dim3(64), lds, qpg_stream(stream), A);
-  QPG_LAUNCH_CHECK("match_walk_kernel");
+  // tabulated walk when the code that seeds the next window comes from the window's LAST step (always true for the
+  // reference's grids: 8 steps x 4 codes, 30 kept) and the state fits 16 bits; the one-wave sequential walk otherwise
+  const int last_idx = A.codes_per_window - 1;
+  GateGeom geo{last_idx / A.step_codes, last_idx % A.step_codes};
+  const size_t lds_g = (size_t)steps * 2 * K * sizeof(uint16_t);
+  const bool tabulated = !serial_walk && geo.s_last == steps - 1 && 2 * K <= 65536 && Q <= QPG_CHASE_QMAX &&
+                         lds_g <= 64 * 1024 && ((steps * 2 * K) % 8) == 0;
+  if (!tabulated) {
+    hipLaunchKernelGGL(match_walk_kernel, dim3(1), dim3(64), lds, qpg_stream(stream), A);
+    QPG_LAUNCH_CHECK("match_walk_kernel");
+    return QPG_OK;
+  }
+  uint16_t* gtab = reinterpret_cast<uint16_t*>(gate_tables + (int64_t)2 * Q * K);     // third [Q][K] i32 region
+  const int64_t lanes = (int64_t)Q * 2 * K * 8;
+  hipLaunchKernelGGL(gate_table_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, qpg_stream(stream), A,
+                     geo, gtab);
+  QPG_LAUNCH_CHECK("gate_table_kernel");
+  hipLaunchKernelGGL(gate_chase_kernel, dim3(1), dim3(256), lds_g, qpg_stream(stream), A, (const uint16_t*)gtab);
+  QPG_LAUNCH_CHECK("gate_chase_kernel");
   return QPG_OK;
 }

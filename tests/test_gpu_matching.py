@@ -204,3 +204,33 @@ def test_clip_graph_replay_equals_eager():
         assert np.array_equal(codes.cpu().numpy().astype(np.int64), g["knn_pred"])
         assert np.array_equal(phases.cpu().numpy(), g["phase_out"])
         assert np.array_equal(votes.cpu().numpy(), g["vote"])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_tabulated_walk_equals_sequential_walk(mode):
+    """qpg_match_steps' tabulated walk (gate evaluated for every reachable (step, previous code, previous vote) in
+    parallel, then Q two-byte lookups) vs the one-wave sequential walk (QPG_MODE_SERIAL_WALK): codes, carried phase
+    blocks and votes bit-identical, for many seeds and in all three modality modes."""
+    g = load_golden(GOLDENS[1])
+    A, db, knn, te_i, te_c, M = _build(g["meta"], freq_rank=g["step_freq_score"])
+    T = knn.sweep_tables(te_i, te_c, M, mode=mode)
+    rs = np.random.RandomState(7)
+    n_diff_votes = 0
+    for trial in range(12):
+        seed_code = int(rs.randint(0, 512))
+        seed_phase = rs.standard_normal((8, 16)).astype(np.float32)
+        knn.serial_walk = True
+        try:
+            ref = knn.walk(T, M, mode=mode, seed_code=seed_code, seed_phase=seed_phase)
+        except IndexError:
+            ref = None
+        knn.serial_walk = False
+        if ref is None:
+            with pytest.raises(IndexError):
+                knn.walk(T, M, mode=mode, seed_code=seed_code, seed_phase=seed_phase)
+            continue
+        got = knn.walk(T, M, mode=mode, seed_code=seed_code, seed_phase=seed_phase)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2])
+        assert np.array_equal(got[1], ref[1])
+        n_diff_votes += int(ref[2].sum() > 0 and ref[2].sum() < ref[2].size)
+    assert n_diff_votes > 0                                     # both gate outcomes occur in the sample
