@@ -285,8 +285,9 @@ int qpg_vq_commit_grad_f32(qpg_ctx*, void* stream, const float* z, const float* 
  *   qpg_vq_ema_update_f32: k_sum/k_elem EMA (mu), k = k_sum/k_elem where k_elem >= threshold else k_rand; also
  *   refreshes kT ([E][ldkT] transposed copy, optional) and kk ([K] squared norms, optional) used by the quantiser,
  *   out4 [dev] f32 = {entropy, used_curr, usage, dk}.  ws: >= K doubles. */
+int64_t qpg_vq_code_sums_ws_bytes(int64_t R, int E, int K);
 int qpg_vq_code_sums_f32(qpg_ctx*, void* stream, const float* z, const int64_t* ids, int64_t R, int E, int K,
-                         float* batch_sum, float* batch_elem);
+                         float* batch_sum, float* batch_elem, void* ws, int64_t ws_bytes);
 int qpg_vq_ema_update_f32(qpg_ctx*, void* stream, float* k, float* k_sum, float* k_elem, const float* batch_sum,
                           const float* batch_elem, const float* k_rand, float mu, float threshold, int K, int E,
                           float* kT, int ldkT, float* kk, void* ws, int64_t ws_bytes, float* out4);

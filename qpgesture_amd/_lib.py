@@ -49,7 +49,7 @@ _SIGS = {
     "qpg_vq_loss_grad_f32": [P, P, I, I, I, c_float, c_float, c_float, c_float, P],
     "qpg_vq_latent_stats_f32": [P, P, P, L, I, P, L, P],
     "qpg_vq_commit_grad_f32": [P, P, L, I, c_float, P, P],
-    "qpg_vq_code_sums_f32": [P, P, L, I, I, P, P],
+    "qpg_vq_code_sums_f32": [P, P, L, I, I, P, P, P, L],
     "qpg_vq_ema_update_f32": [P, P, P, P, P, P, c_float, c_float, I, I, P, I, P, P, L, P],
     "qpg_conv1d_bwd_data_f32": [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, L],
     "qpg_conv1d_bwd_weight_f32": [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, L],
@@ -105,6 +105,8 @@ def load():
     lib.qpg_vq_workspace_floats.restype = c_int64
     lib.qpg_conv1d_wgrad_ws_floats.argtypes = [c_int, c_int, c_int, c_int]
     lib.qpg_conv1d_wgrad_ws_floats.restype = c_int64
+    lib.qpg_vq_code_sums_ws_bytes.argtypes = [c_int64, c_int, c_int]
+    lib.qpg_vq_code_sums_ws_bytes.restype = c_int64
     lib.qpg_vq_reduce_ws_bytes.argtypes = []
     lib.qpg_vq_reduce_ws_bytes.restype = c_int64
     for name, sig in _SIGS.items():

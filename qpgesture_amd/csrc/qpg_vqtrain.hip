@@ -195,58 +195,90 @@ __global__ __launch_bounds__(256) void vq_commit_grad_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 // EMA codebook update (bottleneck.py:63-94)
 // ---------------------------------------------------------------------------------------------
-// _k_sum[c][:] = sum_{r: ids[r]==c} z[r][:], _k_elem[c] = count — one block per code, rows visited in ascending r
-// (ordered, deterministic).  Per 1024-row chunk every thread tests 8 consecutive ids, a block-wide exclusive scan of
-// the hit counts gives each thread its slot in the ordered row list, then all threads add the listed rows.
+// _k_sum[c][:] = sum_{r: ids[r]==c} z[r][:], _k_elem[c] = count.  Block (c, s) handles rows [1024 s, 1024 s + 1024)
+// of code c: every thread tests 8 consecutive ids, a block-wide exclusive scan of the hit counts gives each thread
+// its slot in the ordered row list, then all threads add the listed rows in ascending order.  The chunk partials
+// are added in chunk order by vq_code_sums_reduce_kernel: a fixed summation order (deterministic), and a popular
+// code's rows are spread over R/1024 blocks instead of serialising in one.
 __global__ __launch_bounds__(128) void vq_code_sums_kernel(const float* __restrict__ z, const int64_t* __restrict__ ids,
-                                                           int64_t R, int E, float* __restrict__ ksum,
-                                                           float* __restrict__ kelem) {
-  const int c = blockIdx.x;
+                                                           int64_t R, int E, int K, float* __restrict__ part,
+                                                           int* __restrict__ part_n) {
+  const int c = blockIdx.x, sidx = blockIdx.y;
   __shared__ int rows[1024];
   __shared__ int wave_tot[2];
   const int e4 = E >> 2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)sidx * 1024;
+  const int64_t rb = r0 + (int64_t)threadIdx.x * 8;
+  unsigned hits = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (rb + j < R && ids[rb + j] == c) hits |= 1u << j;
+  const int n = __popc(hits);
+  int incl = n;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int pos = incl - n + (wv ? wave_tot[0] : 0);
+  const int nr = wave_tot[0] + wave_tot[1];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (hits & (1u << j)) rows[pos++] = threadIdx.x * 8 + j;
+  __syncthreads();
   f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};   // E <= 1024
-  int count = 0;
-  for (int64_t r0 = 0; r0 < R; r0 += 1024) {
-    const int64_t rb = r0 + (int64_t)threadIdx.x * 8;
-    unsigned hits = 0;
+  int j = 0;
+  for (; j + 4 <= nr; j += 4) {                            // 4 rows in flight, added in row order
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (rb + j < R && ids[rb + j] == c) hits |= 1u << j;
-    const int n = __popc(hits);
-    // exclusive scan over the 128 threads: wave-level shuffle scan + the other wave's total
-    int incl = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    int pos = incl - n + (wv ? wave_tot[0] : 0);
-    const int nr = wave_tot[0] + wave_tot[1];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (hits & (1u << j)) rows[pos++] = threadIdx.x * 8 + j;
-    __syncthreads();
-    for (int j = 0; j < nr; ++j) {
-      const float* row = z + (r0 + rows[j]) * E;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int q = threadIdx.x + u * 128;
-        if (q < e4) acc[u] += reinterpret_cast<const f32x4*>(row)[q];
+    for (int u = 0; u < 2; ++u) {
+      const int q = threadIdx.x + u * 128;
+      if (q < e4) {
+        const f32x4 a0 = reinterpret_cast<const f32x4*>(z + (r0 + rows[j]) * E)[q];
+        const f32x4 a1 = reinterpret_cast<const f32x4*>(z + (r0 + rows[j + 1]) * E)[q];
+        const f32x4 a2 = reinterpret_cast<const f32x4*>(z + (r0 + rows[j + 2]) * E)[q];
+        const f32x4 a3 = reinterpret_cast<const f32x4*>(z + (r0 + rows[j + 3]) * E)[q];
+        acc[u] = (((acc[u] + a0) + a1) + a2) + a3;
       }
     }
-    count += nr;
-    __syncthreads();
   }
+  for (; j < nr; ++j) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = threadIdx.x + u * 128;
+      if (q < e4) acc[u] += reinterpret_cast<const f32x4*>(z + (r0 + rows[j]) * E)[q];
+    }
+  }
+  float* dst = part + ((size_t)sidx * K + c) * E;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int q = threadIdx.x + u * 128;
-    if (q < e4) reinterpret_cast<f32x4*>(ksum + (size_t)c * E)[q] = acc[u];
+    if (q < e4) reinterpret_cast<f32x4*>(dst)[q] = acc[u];
   }
-  if (threadIdx.x == 0) kelem[c] = (float)count;
+  if (threadIdx.x == 0) part_n[(size_t)sidx * K + c] = nr;
+}
+
+__global__ __launch_bounds__(256) void vq_code_sums_reduce_kernel(const float* __restrict__ part,
+                                                                  const int* __restrict__ part_n, int S, int K, int E,
+                                                                  float* __restrict__ ksum, float* __restrict__ kelem) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = (int64_t)K * E;
+  if (i < n) {
+    // chunks that hold no row of the code contribute an exact +0: skipping them keeps the sum identical to the
+    // plain ascending-row sum
+    float v = 0.f;
+    const int c = (int)(i / E);
+    for (int s = 0; s < S; ++s)
+      if (part_n[(size_t)s * K + c]) v += part[(size_t)s * n + i];
+    ksum[i] = v;
+  } else if (i < n + K) {
+    const int c = (int)(i - n);
+    int t = 0;
+    for (int s = 0; s < S; ++s) t += part_n[(size_t)s * K + c];
+    kelem[c] = (float)t;
+  }
 }
 
 // per code: EMA of k_sum / k_elem, new k (or the random-restart row), refresh of the transposed copy kT and |k|^2
@@ -581,13 +613,28 @@ extern "C" int qpg_vq_commit_grad_f32(qpg_ctx* ctx, void* stream, const float* z
   return QPG_OK;
 }
 
+extern "C" int64_t qpg_vq_code_sums_ws_bytes(int64_t R, int E, int K) {
+  const int64_t S = (R + 1023) / 1024;
+  return S * K * ((int64_t)E * sizeof(float) + sizeof(int));
+}
+
 extern "C" int qpg_vq_code_sums_f32(qpg_ctx* ctx, void* stream, const float* z, const int64_t* ids, int64_t R, int E,
-                                    int K, float* batch_sum, float* batch_elem) {
-  QPG_REQUIRE(ctx && z && ids && batch_sum && batch_elem && R >= 0 && K > 0, "qpg_vq_code_sums_f32: bad argument");
+                                    int K, float* batch_sum, float* batch_elem, void* ws, int64_t ws_bytes) {
+  QPG_REQUIRE(ctx && z && ids && batch_sum && batch_elem && ws && R >= 0 && K > 0, "qpg_vq_code_sums_f32: bad argument");
   QPG_REQUIRE(E > 0 && (E % 4) == 0 && E <= 1024, "qpg_vq_code_sums_f32: emb_width must be a multiple of 4, <= 1024");
-  hipLaunchKernelGGL(vq_code_sums_kernel, dim3(K), dim3(128), 0, qpg_stream(stream), z, ids, R, E, batch_sum,
-                     batch_elem);
-  QPG_LAUNCH_CHECK("vq_code_sums_kernel");
+  QPG_REQUIRE(ws_bytes >= qpg_vq_code_sums_ws_bytes(R, E, K), "qpg_vq_code_sums_f32: workspace too small");
+  const int S = (int)((R + 1023) / 1024);
+  float* part = (float*)ws;
+  int* part_n = (int*)(part + (size_t)S * K * E);
+  if (S > 0) {
+    hipLaunchKernelGGL(vq_code_sums_kernel, dim3(K, S), dim3(128), 0, qpg_stream(stream), z, ids, R, E, K, part,
+                       part_n);
+    QPG_LAUNCH_CHECK("vq_code_sums_kernel");
+  }
+  const int64_t n = (int64_t)K * E + K;
+  hipLaunchKernelGGL(vq_code_sums_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, qpg_stream(stream),
+                     (const float*)part, (const int*)part_n, S, K, E, batch_sum, batch_elem);
+  QPG_LAUNCH_CHECK("vq_code_sums_reduce_kernel");
   return QPG_OK;
 }
 

@@ -346,7 +346,11 @@ class VQVAE:
         R, E = z2.shape
         bsum = torch.empty((self.bins, E), dtype=torch.float32, device=self.device)
         belem = torch.empty((self.bins,), dtype=torch.float32, device=self.device)
-        _lib.call("qpg_vq_code_sums_f32", self.device, z2, ids, R, E, self.bins, bsum, belem)
+        need = int(_lib.load().qpg_vq_code_sums_ws_bytes(R, E, self.bins))
+        cws = getattr(self, "_cws", None)
+        if cws is None or cws.numel() < need:
+            self._cws = cws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        _lib.call("qpg_vq_code_sums_f32", self.device, z2, ids, R, E, self.bins, bsum, belem, cws, cws.numel())
         y = z2
         if R < self.bins:
             n_rep = (self.bins + R - 1) // R
