@@ -432,7 +432,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // raw prefetch registers + validity bits (x: bits 0..7, y: bits 8..15); selects / ReLU happen at the LDS commit so
+  // that the loads of the next chunk stay in flight across the MFMA block
   float xv[8], yv[8];
+  unsigned okm = 0;
 
   auto fetch = [&](int64_t r0) {
     const int64_t r = r0 + kr;
@@ -443,40 +446,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WgradArgs a) {
     const bool x_ok = live && t_in >= 0 && t_in < a.T_in;
     const float* xrow = a.x + ((int64_t)b * a.T_in + (x_ok ? t_in : 0)) * a.Cin + ci0 + c8;
     const float* yrow = a.dy + ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout + co0 + c8;
+    okm = 0;
     if (VECX) {
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const bool ok = x_ok && (ci0 + c8 + 4 * v) < a.Cin;
         const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? xrow + 4 * v : a.x);
+        okm |= ok ? (0xFu << (4 * v)) : 0u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xv[4 * v + i] = ok ? q[i] : 0.f;
+        for (int i = 0; i < 4; ++i) xv[4 * v + i] = q[i];
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bool ok = x_ok && (ci0 + c8 + i) < a.Cin;
-        const float q = *(ok ? xrow + i : a.x);
-        xv[i] = ok ? q : 0.f;
+        xv[i] = *(ok ? xrow + i : a.x);
+        okm |= ok ? (1u << i) : 0u;
       }
-    }
-    if (a.relu_in) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) xv[i] = fmaxf(xv[i], 0.f);
     }
     if (VECY) {
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const bool ok = live && (co0 + c8 + 4 * v) < a.Cout;
         const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? yrow + 4 * v : a.dy);
+        okm |= ok ? (0xF00u << (4 * v)) : 0u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) yv[4 * v + i] = ok ? q[i] : 0.f;
+        for (int i = 0; i < 4; ++i) yv[4 * v + i] = q[i];
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bool ok = live && (co0 + c8 + i) < a.Cout;
-        const float q = *(ok ? yrow + i : a.dy);
-        yv[i] = ok ? q : 0.f;
+        yv[i] = *(ok ? yrow + i : a.dy);
+        okm |= ok ? (0x100u << i) : 0u;
       }
     }
   };
@@ -484,6 +486,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WgradArgs a) {
   if (r_begin < r_end) fetch(r_begin);
   for (int64_t r0 = r_begin; r0 < r_end; r0 += WG_BK) {
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float x = ((okm >> i) & 1u) ? xv[i] : 0.f;
+      if (a.relu_in) x = fmaxf(x, 0.f);
+      xv[i] = x;
+      yv[i] = ((okm >> (8 + i)) & 1u) ? yv[i] : 0.f;
+    }
     *reinterpret_cast<f32x4*>(&Xs[kr][c8]) = f32x4{xv[0], xv[1], xv[2], xv[3]};
     *reinterpret_cast<f32x4*>(&Xs[kr][c8 + 4]) = f32x4{xv[4], xv[5], xv[6], xv[7]};
     *reinterpret_cast<f32x4*>(&Ys[kr][c8]) = f32x4{yv[0], yv[1], yv[2], yv[3]};
@@ -494,15 +503,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WgradArgs a) {
     }
     __syncthreads();
     if (r0 + WG_BK < r_end) fetch(r0 + WG_BK);
+    float aq[2][2], bq[2][2];
+    auto lds_read = [&](int ks, int slot) {
+      const int k = ks * 2 + (lane >> 5);
+      aq[slot][0] = Xs[k][wm * 64 + (lane & 31)];
+      aq[slot][1] = Xs[k][wm * 64 + 32 + (lane & 31)];
+      bq[slot][0] = Ys[k][wn * 64 + (lane & 31)];
+      bq[slot][1] = Ys[k][wn * 64 + 32 + (lane & 31)];
+    };
+    lds_read(0, 0);
 #pragma unroll
     for (int ks = 0; ks < WG_BK / 2; ++ks) {
-      const int k = ks * 2 + (lane >> 5);
-      const float a0 = Xs[k][wm * 64 + (lane & 31)], a1 = Xs[k][wm * 64 + 32 + (lane & 31)];
-      const float b0 = Ys[k][wn * 64 + (lane & 31)], b1 = Ys[k][wn * 64 + 32 + (lane & 31)];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      const int cur = ks & 1;
+      if (ks + 1 < WG_BK / 2) lds_read(ks + 1, cur ^ 1);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][0], bq[cur][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][0], bq[cur][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][1], bq[cur][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][1], bq[cur][1], acc[1][1], 0, 0, 0);
     }
   }
 
