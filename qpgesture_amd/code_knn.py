@@ -462,6 +462,11 @@ class CodeKNN:
             T["txt_d"], T["txt_idx"] = r[0], r[1]
             if not sharded:
                 T["txt_rank"] = r[2]
+        # Host launch order matters: the text side is enqueued FIRST.  Its kernels start while the host is still
+        # enqueueing the audio side (the GPU would otherwise idle through that launch latency), and they are mostly
+        # done when the audio sweep begins: measured 0.855 ms/clip, against 0.862 ms with the audio side first (the
+        # text sweep then runs underneath the audio sweep and slows it by its own duration: the two kernels contend
+        # for the same CUs rather than overlap) and 0.891 ms on a single stream.
         if overlap:
             with torch.cuda.stream(side):
                 text_side()
