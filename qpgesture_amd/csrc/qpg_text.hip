@@ -71,6 +71,15 @@ extern "C" int qpg_text_pack_candidates_f32(qpg_ctx* ctx, void* stream, const fl
 }
 
 // QB queries per lane, NG waves per block (all on the same 64-candidate tile, different query groups).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// q - x on a pair: one v_pk_add_f32 with the (wave-uniform) query pair read directly from an SGPR pair and the
+// candidate pair negated by the instruction's source modifiers — IEEE add of q and -x, i.e. exactly q - x.
+__device__ __forceinline__ f32x2 pk_sub_sv(f32x2 q, f32x2 x) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "s"(q), "v"(x));
+  return d;
+}
+
 template <int QB, int NG>
 __global__ __launch_bounds__(64 * NG) void text_cosine_f32_kernel(const float* __restrict__ xt, int64_t C, int Dm,
                                                                   const float* __restrict__ qn, int Q,
@@ -89,9 +98,11 @@ __global__ __launch_bounds__(64 * NG) void text_cosine_f32_kernel(const float* _
   }
   const f32x4* xp = reinterpret_cast<const f32x4*>(xt + tile * (int64_t)Dm * 64) + lane;
 
-  float acc[QB][4];
+  // accumulators as two packed pairs (einsum lanes 0,1 and 2,3): every step is 3 packed VALU ops per 2 elements
+  // (v_pk_add_f32 with the query pair straight from SGPRs and a negated candidate pair, v_pk_mul_f32, v_pk_add_f32)
+  f32x2 acc[QB][2];
 #pragma unroll
-  for (int i = 0; i < QB; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+  for (int i = 0; i < QB; ++i) acc[i][0] = acc[i][1] = f32x2{0.f, 0.f};
 
   // Software pipeline: the 64-B scalar load of the NEXT query row segment is issued before the 48 VALU ops
   // of the current one (two 16-SGPR buffers); element order per accumulator stays u = 3,2,1,0.
@@ -112,15 +123,17 @@ __global__ __launch_bounds__(64 * NG) void text_cosine_f32_kernel(const float* _
     for (int i = 0; i < QB; ++i) {
       const int kn = (i + 1 < QB) ? k : (k + 1 < nk ? k + 1 : 0);
       const f32x16 qnext = *reinterpret_cast<const f32x16*>(qrow[(i + 1) % QB] + kn * 16);
-#pragma unroll
-      for (int u = 3; u >= 0; --u) {
-        const float d0 = f_sub(qv[u * 4 + 0], x[u].x), d1 = f_sub(qv[u * 4 + 1], x[u].y),
-                    d2 = f_sub(qv[u * 4 + 2], x[u].z), d3 = f_sub(qv[u * 4 + 3], x[u].w);
-        acc[i][0] = f_add(f_mul(d0, d0), acc[i][0]);
-        acc[i][1] = f_add(f_mul(d1, d1), acc[i][1]);
-        acc[i][2] = f_add(f_mul(d2, d2), acc[i][2]);
-        acc[i][3] = f_add(f_mul(d3, d3), acc[i][3]);
-      }
+#define QPG_TEXT_STEP(U)                                                                              \
+  {                                                                                                   \
+    const f32x2 d01 = pk_sub_sv(__builtin_shufflevector(qv, qv, (U) * 4 + 0, (U) * 4 + 1),            \
+                                __builtin_shufflevector(x[U], x[U], 0, 1));                           \
+    const f32x2 d23 = pk_sub_sv(__builtin_shufflevector(qv, qv, (U) * 4 + 2, (U) * 4 + 3),            \
+                                __builtin_shufflevector(x[U], x[U], 2, 3));                           \
+    acc[i][0] = d01 * d01 + acc[i][0];                                                                \
+    acc[i][1] = d23 * d23 + acc[i][1];                                                                \
+  }
+      QPG_TEXT_STEP(3) QPG_TEXT_STEP(2) QPG_TEXT_STEP(1) QPG_TEXT_STEP(0)
+#undef QPG_TEXT_STEP
       qv = qnext;
     }
   }
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(64 * NG) void text_cosine_f32_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < QB; ++i) {
       if (q0 + i < Q) {
-        const float s = f_add(f_add(acc[i][0], acc[i][1]), f_add(acc[i][2], acc[i][3]));
+        const float s = f_add(f_add(acc[i][0].x, acc[i][0].y), f_add(acc[i][1].x, acc[i][1].y));
         D[(int64_t)(q0 + i) * ldD + c] = f_mul(0.5f, s);
       }
     }
