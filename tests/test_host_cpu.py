@@ -107,3 +107,54 @@ def test_reference_config_loads():
                      "codebook.yml")
     cfg = load_config(p)
     assert cfg.VQVAE.width == 512 and cfg.VQVAE.downs_t == [3] and len(cfg.data_mean) == 135
+
+
+def test_training_host_logic_without_gpu():
+    """Host-side pieces of the training loop that need no device: the reference-shaped initial state_dict
+    (names/shapes of a fresh reference model, torch default init bounds), MultiStepLR, the CLI parser and config."""
+    import torch
+    from qpgesture_amd import synth, train
+    from qpgesture_amd.checkpoint import load_config
+    from qpgesture_amd.optim import MultiStepLR
+    from qpgesture_amd.vqvae import init_state_dict
+    sd = init_state_dict(seed=3)
+    ref = {k[7:]: tuple(np.asarray(v).shape) for k, v in synth.make_vqvae_state_dict(7).items()}
+    assert {k: tuple(v.shape) for k, v in sd.items()} == ref and len(sd) == 91
+    w = sd["encoders.0.level_blocks.0.model.0.0.weight"]              # Conv1d(135, 512, 4): bound 1/sqrt(135*4)
+    assert float(w.abs().max()) <= 1.0 / np.sqrt(135 * 4) and float(w.abs().max()) > 0.9 / np.sqrt(135 * 4)
+    wt = sd["decoders.0.level_blocks.0.model.1.1.weight"]             # ConvTranspose1d(512, 512, 4): size(1)*k
+    assert tuple(wt.shape) == (512, 512, 4) and float(wt.abs().max()) <= 1.0 / np.sqrt(512 * 4)
+    assert float(sd["bottleneck.level_blocks.0.k"].abs().sum()) == 0.0
+    assert torch.equal(init_state_dict(seed=3)["decoders.0.out.bias"], sd["decoders.0.out.bias"])
+
+    class Opt:
+        lr = 3e-5
+    o = Opt()
+    s = MultiStepLR(o, [100, 200], 0.1)
+    lrs = []
+    for _ in range(201):
+        s.step()
+        lrs.append(o.lr)
+    assert lrs[98] == 3e-5 and abs(lrs[99] - 3e-6) < 1e-18 and abs(lrs[199] - 3e-7) < 1e-18
+
+    a = train.parse_args(["--gpu", "1", "--synthetic", "8", "--epochs", "2"])
+    assert a.gpu == "1" and a.synthetic == 8 and a.epochs == 2 and a.config.endswith("codebook.yml")
+    cfg = load_config(a.config)
+    assert cfg.batch_size == 256 and cfg.lr == 3e-5 and list(cfg.betas) == [0.5, 0.999] and cfg.VQVAE.l_mu == 0.99
+
+
+def test_oracle_forward_loss_terms():
+    """oracle/vqvae_oracle.losses against hand-computed values on a tiny sequence (vqvae.py:244-267)."""
+    import torch
+    from oracle import vqvae_oracle as VO
+    xt = torch.tensor([[[0.0], [1.0], [3.0], [6.0]]])
+    xo = torch.tensor([[[0.5], [1.0], [2.0], [6.0]]])
+    loss, m = VO.losses(xt, xo, torch.tensor(2.0), hps_commit=0.02, vel=1.0, acc=1.0, reg=0.5)
+    assert abs(float(m["recons_loss"]) - (0.5 + 0 + 1 + 0) / 4) < 1e-7
+    # velocities: target [1,2,3], out [0.5,1,4] -> |diff| = [0.5,1,1]
+    assert abs(float(m["velocity_loss"]) - 2.5 / 3) < 1e-7
+    # accelerations: target [1,1], out [0.5,3] -> |diff| = [0.5,2]; regularisation = mean(out_acc^2)
+    assert abs(float(m["acceleration_loss"]) - 1.25) < 1e-7
+    assert abs(float(m["regularization"]) - (0.25 + 9.0) / 2) < 1e-6
+    want = 0.375 + 2.0 * 0.02 + 0.5 * 4.625 + 2.5 / 3 + 1.25
+    assert abs(float(loss) - want) < 1e-6
