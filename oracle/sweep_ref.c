@@ -118,6 +118,7 @@ void qpg_ref_audio_scan(const float* base, int N, int T, int F, const int32_t* c
     for (int j = 0; j < N; ++j)
       for (int g = 0; g < G; ++g) {
         int cd = code[(int64_t)j * code_ld + cand_cidx[g]];
+        if (cd < 0 || cd >= K) continue;   /* masked / invalid candidate (the product kernels skip these too) */
         double d = dist[(size_t)qi * N * G + (size_t)j * G + g];
         if (d < out_dist[(size_t)qi * K + cd]) { out_dist[(size_t)qi * K + cd] = d; out_idx[(size_t)qi * K + cd] = j * G + g; }
       }
@@ -151,6 +152,7 @@ void qpg_ref_text_scan(const float* ctx, int N, int R, int Dm, const int32_t* ca
     for (int j = 0; j < N; ++j)
       for (int g = 0; g < G; ++g) {
         int cd = code[(int64_t)j * code_ld + cand_cidx[g]];
+        if (cd < 0 || cd >= K) continue;   /* masked / invalid candidate */
         float d = dist[(size_t)qi * N * G + (size_t)j * G + g];
         if (d < out_dist[(size_t)qi * K + cd]) { out_dist[(size_t)qi * K + cd] = d; out_idx[(size_t)qi * K + cd] = j * G + g; }
       }

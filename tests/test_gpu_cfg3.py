@@ -1,0 +1,84 @@
+"""BASELINE.json configs[2]: synthetic DB of 100 000 codes x 512-d, 1 000 query windows, code ids
+uniform in [0,512), validity mask Bernoulli(0.9) — the generic cosine per-code-min kernel pair (qpg_text_pack_candidates_f32
+/ qpg_text_cosine_f32 / qpg_percode_resolve_f32 / qpg_percode_finalize_f32, sklearn-exact f32 arithmetic) at that size.
+Parity: a slice of the queries bit-exact against the C oracle (the oracle needs ~0.3 s per query on one core);
+all 1 000 queries through size-independent properties (planted exact matches win their code with distance 0 and the
+lowest index, masked rows never win, the global argmin is the planted row)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, D, Q, K = 100_000, 512, 1000, 512
+
+
+def _inputs():
+    X = np.random.Generator(np.random.PCG64(0)).standard_normal((N, D), dtype=np.float32)
+    code = np.random.Generator(np.random.PCG64(1)).integers(0, K, size=N).astype(np.int32)
+    valid = np.random.Generator(np.random.PCG64(2)).random(N) < 0.9
+    q = np.random.Generator(np.random.PCG64(3)).standard_normal((Q, D), dtype=np.float32)
+    # plant: query i (i < 200) is a positive multiple of valid row r_i, and an identical copy of that row sits at a
+    # HIGHER index with the same code (first-wins must return the lower one)
+    vidx = np.flatnonzero(valid)
+    rows = vidx[np.random.Generator(np.random.PCG64(4)).choice(len(vidx) // 2, size=200, replace=False)]
+    for i, r in enumerate(rows):
+        q[i] = X[r] * np.float32(2.0)
+        dup = vidx[len(vidx) // 2 + i]
+        X[dup] = X[r]
+        code[dup] = code[r]
+    return X, code, valid, q, rows
+
+
+def _run(X, code, valid, q):
+    import torch
+    from qpgesture_amd import _lib
+    dev = torch.device("cuda:0")
+    n, d = X.shape
+    nq = q.shape[0]
+    xd = torch.from_numpy(X).to(dev).view(n, 1, d)
+    cand_r = torch.zeros((1,), dtype=torch.int32, device=dev)
+    xt = torch.zeros((((n + 63) // 64) * 64 * d,), dtype=torch.float32, device=dev)
+    _lib.call("qpg_text_pack_candidates_f32", dev, xd, n, 1, d, cand_r, 1, xt)
+    cm = torch.from_numpy(np.where(valid, code, -1).astype(np.int32)).to(dev).view(n, 1).contiguous()
+    qd = torch.from_numpy(q).to(dev)
+    qn = torch.empty_like(qd)
+    _lib.call("qpg_l2_normalize_rows_f32", dev, qd, nq, d, qn)
+    Dm = torch.empty((nq, n), dtype=torch.float32, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    _lib.call("qpg_text_cosine_f32", dev, xt, n, d, qn, nq, Dm, Dm.stride(0))
+    ev[1].record()
+    packed = torch.empty((nq, K), dtype=torch.int64, device=dev)
+    _lib.call("qpg_percode_resolve_f32", dev, Dm, Dm.stride(0), nq, cm, 1, n, cand_r, 1, K, 0, packed)
+    dist = torch.empty((nq, K), dtype=torch.float32, device=dev)
+    idx = torch.empty((nq, K), dtype=torch.int32, device=dev)
+    _lib.call("qpg_percode_finalize_f32", dev, packed, nq, K, 1000.0, dist, idx, None)
+    ev[2].record()
+    torch.cuda.synchronize()
+    return dist.cpu().numpy(), idx.cpu().numpy(), ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+
+
+def test_cfg3_100k_by_512_per_code_min():
+    from oracle import cref
+    X, code, valid, q, rows = _inputs()
+    dist, idx, t_sweep, t_min = _run(X, code, valid, q)
+    assert dist.shape == (Q, K) and idx.dtype == np.int32
+    # (1) bit-exact slice vs the C restatement of the reference arithmetic (planted + plain queries)
+    sel = np.r_[0:4, 200:204, Q - 2:Q]
+    cm = np.where(valid, code, -1).astype(np.int32).reshape(N, 1)
+    od, oi = cref.text_scan(X.reshape(N, 1, D), [0], cm, [0], q[sel], K=K, n_threads=8)
+    assert np.array_equal(idx[sel], oi)
+    assert np.array_equal(dist[sel], od)
+    # (2) properties over all queries
+    assert valid[idx[idx >= 0]].all()                                    # a masked row never wins
+    assert np.array_equal(code[idx[idx >= 0]], np.nonzero(idx >= 0)[1])  # winners carry the code of their column
+    for i, r in enumerate(rows):
+        c = code[r]
+        assert idx[i, c] == r, (i, idx[i, c], r)                         # lower index of the two identical rows
+        assert dist[i, c] <= 2e-7 and dist[i].argmin() == c              # cos distance of a positive multiple ~ 0
+    present = np.bincount(code[valid], minlength=K) > 0
+    assert np.array_equal(idx >= 0, np.broadcast_to(present, (Q, K)))
+    assert np.all(dist[:, ~present] == 1000.0)
+    flops = 2.0 * Q * N * D
+    print("cfg-3: sweep %.2f ms (%.1f TFLOP-equivalent/s, D write %.0f GB/s), per-code min+finalize %.2f ms" % (
+        t_sweep, flops / t_sweep / 1e9, Q * N * 4 / t_sweep / 1e6, t_min))
