@@ -67,8 +67,13 @@ def load_checkpoint(path):
 
 def load_config(path):
     """codebook/configs/codebook.yml -> AttrDict (VQVAE hparams, data_mean/std)."""
+    import os
     with open(path) as f:
-        return AttrDict(yaml.safe_load(f))
+        cfg = AttrDict(yaml.safe_load(f))
+    if "data_mean" not in cfg and "pose_stats" in cfg:            # (2,135) array [mean, std] next to the config
+        stats = np.load(os.path.join(os.path.dirname(os.path.abspath(path)), cfg["pose_stats"]))
+        cfg["data_mean"], cfg["data_std"] = [float(v) for v in stats[0]], [float(v) for v in stats[1]]
+    return cfg
 
 
 def denormalize_poses(poses, data_mean, data_std):
