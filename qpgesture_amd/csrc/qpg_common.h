@@ -10,6 +10,7 @@
 struct qpg_ctx {
   int device;
   int n_cu;
+  float* zeros;   // 256 B of device zeros: out-of-range tile loads are redirected here instead of being selected to 0
 };
 
 void qpg_set_error(const char* fmt, ...);

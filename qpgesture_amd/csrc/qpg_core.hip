@@ -36,11 +36,23 @@ extern "C" int qpg_ctx_create(int device, qpg_ctx** out) {
   qpg_ctx* c = new qpg_ctx;
   c->device = device;
   c->n_cu = p.multiProcessorCount;
+  c->zeros = nullptr;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  const bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&c->zeros), 256) == hipSuccess &&
+                  hipMemset(c->zeros, 0, 256) == hipSuccess;
+  (void)hipSetDevice(prev);
+  if (!ok) {
+    qpg_set_error("qpg_ctx_create: could not allocate the context's zero page on device %d", device);
+    delete c;
+    return QPG_EHIP;
+  }
   *out = c;
   return QPG_OK;
 }
 
 extern "C" int qpg_ctx_destroy(qpg_ctx* ctx) {
+  if (ctx && ctx->zeros) (void)hipFree(ctx->zeros);
   delete ctx;
   return QPG_OK;
 }

@@ -33,6 +33,7 @@ struct ConvArgs {
   int T_out;                       // output positions computed per batch item in this launch
   int out_stride, out_offset, T_y; // y row = t*out_stride + out_offset, T_y rows per batch item
   int relu_in, relu_out;
+  const float* zeros;  // >= 64 B of zeros (ctx): where out-of-range 16-B tile loads are pointed
   const float* gate;   // backward-data only: same indexing as y, result is zeroed where gate <= 0 (ReLU backward)
   int wt_rows, wt_pitch;   // backward-data only: the forward layer's Cin_pad (rows per tap) and Cout_pad (row pitch)
   int tap_base, tap_step;  // weight tap used for input tap j = tap_base + j*tap_step (flips / parity subsets)
@@ -84,26 +85,40 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
   float av[AR];
   f32x4 b0, b1;
   unsigned okm = 0;
-  // slice iterator (tap, c0) advanced incrementally: no integer division in the loop
+  // slice iterator (tap, c0) advanced incrementally; everything that depends only on the tap (row pointer, range
+  // check, weight tap pointer) is recomputed at tap boundaries, not per slice
   int f_tap = 0, f_c0 = 0;
+  const float* xrow_tap = a.x;
+  const float* w_tap = a.w;
+  bool t_ok = false;
+  const float* xbase = a.x + (int64_t)ab * a.T_in * a.Cin + ak;
+  const bool w_ok = !WT || n0 + bn < a.wt_rows;
+  auto set_tap = [&](int tap) {
+    const int t_in = at * a.in_stride + a.in_offset + tap * a.dil;
+    t_ok = a_live && t_in >= 0 && t_in < a.T_in;
+    xrow_tap = xbase + (int64_t)(t_ok ? t_in : 0) * a.Cin;
+    const int wtap = a.tap_base + tap * a.tap_step;
+    // WT: rows of the packed weights are the forward layer's input channels (this launch's n axis), the
+    // contraction index k runs along a row; a.wt_rows rows per tap, pitch a.wt_pitch
+    w_tap = WT ? a.w + ((int64_t)wtap * a.wt_rows + (w_ok ? n0 + bn : 0)) * a.wt_pitch + bk
+               : a.w + ((int64_t)wtap * a.Cin_pad + bk) * a.Cout_pad + n0 + bn;
+  };
   auto seek = [&](int it) {
     f_tap = it / nslice;
     f_c0 = (it - f_tap * nslice) * CV_BK;
+    set_tap(f_tap);
   };
-  const float* xbase = a.x + (int64_t)ab * a.T_in * a.Cin + ak;
   auto fetch = [&]() {
-    const int tap = f_tap, c0 = f_c0;
-    const int t_in = at * a.in_stride + a.in_offset + tap * a.dil;
-    const bool t_ok = a_live && t_in >= 0 && t_in < a.T_in;
-    const float* xrow = xbase + (int64_t)(t_ok ? t_in : 0) * a.Cin + c0;
+    const int c0 = f_c0;
+    const float* xrow = xrow_tap + c0;
     okm = 0;
     if (VEC) {
-      // Cin % 4 == 0 and Cin_pad == round_up(Cin,16): a 4-group is either fully inside or fully outside
+      // Cin % 4 == 0 and Cin_pad == round_up(Cin,16): a 4-group is either fully inside or fully outside; an
+      // outside group is read from the context's zero page, so the loaded value needs no select at all
 #pragma unroll
       for (int v = 0; v < AR / 4; ++v) {
         const bool ok = t_ok && (c0 + ak + 4 * v) < a.Cin;
-        const f32x4 x4 = *reinterpret_cast<const f32x4*>(ok ? xrow + 4 * v : a.x);
-        okm |= ok ? (1u << v) : 0u;
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(ok ? xrow + 4 * v : a.zeros);
 #pragma unroll
         for (int i = 0; i < 4; ++i) av[4 * v + i] = x4[i];
       }
@@ -111,31 +126,25 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         const bool ok = t_ok && (c0 + ak + i) < a.Cin;
-        av[i] = *(ok ? xrow + i : a.x);
-        okm |= ok ? (1u << i) : 0u;
+        av[i] = *(ok ? xrow + i : a.zeros);
       }
     }
-    const int wtap = a.tap_base + tap * a.tap_step;
-    // WT: rows of the packed weights are the forward layer's input channels (this launch's n axis), the
-    // contraction index k runs along a row; a.wt_rows rows per tap, pitch a.wt_pitch
-    const bool w_ok = !WT || n0 + bn < a.wt_rows;
-    const float* wp = WT ? a.w + ((int64_t)wtap * a.wt_rows + (w_ok ? n0 + bn : 0)) * a.wt_pitch + c0 + bk
-                         : a.w + ((int64_t)wtap * a.Cin_pad + c0 + bk) * a.Cout_pad + n0 + bn;
+    const float* wp = WT ? w_tap + c0 : w_tap + (int64_t)c0 * a.Cout_pad;
     b0 = *reinterpret_cast<const f32x4*>(wp);
     b1 = *reinterpret_cast<const f32x4*>(wp + 4);
-    if (WT && !w_ok) okm |= 0x80000000u;
+    if (WT && !w_ok) okm = 0x80000000u;
     f_c0 += CV_BK;
     if (f_c0 == a.Cin_pad) {
       f_c0 = 0;
       ++f_tap;
+      set_tap(f_tap);
     }
   };
   auto commit = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const bool ok = VEC ? ((okm >> (i >> 2)) & 1u) : ((okm >> i) & 1u);
-      float v = ok ? av[i] : 0.f;
-      if (a.relu_in) v = fmaxf(v, 0.f);
+      float v = av[i];
+      if (a.relu_in) v = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());   // one v_med3_f32 = max(v, 0)
       As[buf][ar][ak + i] = v;
     }
     if (WT) {
@@ -312,7 +321,7 @@ extern "C" int qpg_conv1d_f32(qpg_ctx* ctx, void* stream, const float* x, int B,
   a.B = B; a.T_in = T_in; a.Cin = Cin; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad; a.taps = taps;
   a.in_stride = in_stride; a.in_offset = in_offset; a.dil = dil; a.T_out = T_out;
   a.out_stride = out_stride; a.out_offset = out_offset; a.T_y = T_y; a.relu_in = relu_in; a.relu_out = relu_out;
-  a.gate = nullptr; a.tap_base = 0; a.tap_step = 1; a.wt_rows = 0; a.wt_pitch = 0;
+  a.gate = nullptr; a.tap_base = 0; a.tap_step = 1; a.wt_rows = 0; a.wt_pitch = 0; a.zeros = ctx->zeros;
   return conv_launch(ctx, stream, a, false, ws, ws_floats);
 }
 
@@ -336,7 +345,7 @@ extern "C" int qpg_conv1d_bwd_data_f32(qpg_ctx* ctx, void* stream, const float* 
   a.Cout = fwd_Cin; a.Cout_pad = (fwd_Cin_pad + CV_BN - 1) / CV_BN * CV_BN; a.taps = taps;
   a.in_stride = in_stride; a.in_offset = in_offset; a.dil = dil; a.T_out = T_out;
   a.out_stride = out_stride; a.out_offset = out_offset; a.T_y = T_y; a.relu_in = 0; a.relu_out = 0;
-  a.gate = gate; a.tap_base = tap_base; a.tap_step = tap_step; a.wt_rows = fwd_Cin_pad; a.wt_pitch = fwd_Cout_pad;
+  a.zeros = ctx->zeros; a.gate = gate; a.tap_base = tap_base; a.tap_step = tap_step; a.wt_rows = fwd_Cin_pad; a.wt_pitch = fwd_Cout_pad;
   return conv_launch(ctx, stream, a, true, ws, ws_floats);
 }
 
