@@ -1,11 +1,30 @@
 """f32-MFMA approximate audio sweep vs the f64 sweep: time and max |difference|."""
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes, subprocess, sys, os
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
 import numpy as np, torch
 from qpgesture_amd import _lib
+MT = os.environ.get("F32MM_MT", "2")
+SO = os.path.join(HERE, "libqpg_f32mm_exp_mt%s.so" % MT)
+if not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(os.path.join(HERE, "qpg_audio_f32mm.hip")):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                           "-ffp-contract=off", "-DF32MM_MT=" + MT, "-I", os.path.join(ROOT, "qpgesture_amd", "csrc"),
+                           os.path.join(HERE, "qpg_audio_f32mm.hip"),
+                           os.path.join(ROOT, "qpgesture_amd", "csrc", "qpg_core.hip"), "-o", SO])
+exp = ctypes.CDLL(SO)
+P_, I_, L_ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+exp.qpg_ctx_create.argtypes = [I_, ctypes.POINTER(P_)]
+exp.qpg_audio_cosine_approx_f32.argtypes = [P_, P_, P_, I_, I_, I_, P_, I_, I_, I_, P_, P_, P_, I_, P_, L_]
+_ectx = P_(); assert exp.qpg_ctx_create(0, ctypes.byref(_ectx)) == 0
+def ecall(name, dev, *args):
+    st = P_(torch.cuda.current_stream(dev).cuda_stream)
+    conv = [P_(a.data_ptr()) if isinstance(a, torch.Tensor) else a for a in args]
+    assert getattr(exp, name)(_ectx, st, *conv) == 0, name
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 Q = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+torch.manual_seed(0)
 dev = torch.device("cuda:0")
 T, F, G = 180, 1024, 26
 base = torch.randn((N, T, F), device=dev)
@@ -21,7 +40,7 @@ D32 = torch.empty((Q, N * G), device=dev, dtype=torch.float32)
 def run64():
     _lib.call("qpg_audio_cosine_f64", dev, base, N, T, F, cand_t, G, 6, 2, cn2, q32, qn2, Q, D, D.stride(0))
 def run32():
-    _lib.call("qpg_audio_cosine_approx_f32", dev, base, N, T, F, cand_t, G, 6, 2, cn2, q32, qn2, Q, D32, D32.stride(0))
+    ecall("qpg_audio_cosine_approx_f32", dev, base, N, T, F, cand_t, G, 6, 2, cn2, q32, qn2, Q, D32, D32.stride(0))
 def t(fn):
     for _ in range(3): fn()
     torch.cuda.synchronize()

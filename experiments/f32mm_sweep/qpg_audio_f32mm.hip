@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f32mm_kernel(const float
     const int ql = o / CR, cr = o - ql * CR;
     const int nt = ql >> 4, qc = ql & 15;
     const int mt = cr >> 4, crr = cr & 15;
-    const int r = crr >> 2, l = ((crr & 3) << 4) | qc;
+    const int r = crr & 3, l = ((crr >> 2) << 4) | qc;   // f32 16x16x4 C/D: row = 4*(l>>4) + r
     const int t = mt * NT + nt;
     double dot = red[0][t][r][l];
 #pragma unroll
@@ -453,7 +453,10 @@ extern "C" int qpg_audio_cosine_approx_f32(qpg_ctx* ctx, void* stream, const flo
   if (N == 0 || Q == 0) return QPG_OK;
   const int qt = (Q + 15) / 16;
 #define QPG_AUDIO_ARGS ctx, stream, base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q
-  if (qt % 3 == 0) return launch_audio_f32mm<2, 3>(QPG_AUDIO_ARGS, qt / 3, D32, ldD);
+#ifndef F32MM_MT
+#define F32MM_MT 2
+#endif
+  if (qt % 3 == 0) return launch_audio_f32mm<F32MM_MT, 3>(QPG_AUDIO_ARGS, qt / 3, D32, ldD);
   if (qt % 4 == 0) return launch_audio_f32mm<2, 4>(QPG_AUDIO_ARGS, qt / 4, D32, ldD);
   if (qt % 2 == 0) return launch_audio_f32mm<2, 2>(QPG_AUDIO_ARGS, qt / 2, D32, ldD);
   return launch_audio_f32mm<2, 1>(QPG_AUDIO_ARGS, qt, D32, ldD);
