@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .parallel import allreduce_min_index, shard_rows
+from .parallel import allreduce_min_index, alltoall_min_index, shard_rows
 import ctypes
 
 from .constant import (ABSENT_DIST, NUM_AUDIO_FEAT_FRAMES, STEP_SZ, WAVVQ_GROUP_SIZE, codebook_size, num_frames,
@@ -418,10 +418,13 @@ class CodeKNN:
     def n_steps(self):
         return len(self.query_positions())
 
-    def sweep_tables(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT):
+    def sweep_tables(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, owner_blocks=False):
         """Both batched sweeps + ranks for all Q = n_windows*steps query positions (the windows may
         belong to several clips).  test_interp: f32 [M,180,F]; test_context: f32 [M,30,384] (device).
-        Returns a dict of device tensors: aud_d/aud_idx/aud_rank, txt_d/txt_idx/txt_rank."""
+        Returns a dict of device tensors: aud_d/aud_idx/aud_rank, txt_d/txt_idx/txt_rank.
+        owner_blocks (sharded DB only): the windows are `world` equal blocks and this rank only needs the final
+        tables of block `rank` — one all-to-all instead of two all-reduces; the returned tables then hold only that
+        block's Q/world rows."""
         db, dev = self.db, self.db.device
         M, steps = n_windows, self.n_steps()
         if test_interp.shape[0] < M or (mode != MODE_AUD and test_context.shape[0] < M):
@@ -486,7 +489,10 @@ class CodeKNN:
             parts = [k for k in ("aud", "txt") if T[k + "_d"] is not None]
             dcat = torch.cat([T[k + "_d"].to(torch.float64) for k in parts], dim=1)
             icat = torch.cat([T[k + "_idx"] for k in parts], dim=1)
-            dcat, icat = allreduce_min_index(dcat, icat)
+            if owner_blocks:
+                dcat, icat = alltoall_min_index(dcat, icat, db.world)
+            else:
+                dcat, icat = allreduce_min_index(dcat, icat)
             for n_, k in enumerate(parts):
                 d = dcat[:, n_ * db.K:(n_ + 1) * db.K]
                 T[k + "_d"] = d.to(T[k + "_d"].dtype).contiguous()

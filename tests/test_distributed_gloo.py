@@ -76,3 +76,48 @@ def test_shard_rows_cover_and_order():
             cuts = [shard_rows(n, r, w) for r in range(w)]
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+
+
+def _worker_a2a(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cref
+    from qpgesture_amd.parallel import alltoall_min_index, shard_rows
+    base, ctx, code, q, qt = _data()
+    q = np.concatenate([q, q[::-1][:1]])                # 6 query rows = 3 blocks of 2 / 2 blocks of 3
+    qt = np.concatenate([qt, qt[::-1][:1]])
+    lo, hi = shard_rows(base.shape[0], rank, world)
+    g = np.arange(26)
+    d, ix = cref.audio_scan(base[lo:hi], g * 6, code[lo:hi], g, q)
+    ix = np.where(ix >= 0, ix + lo * 26, -1).astype(np.int32)
+    dt, it = cref.text_scan(ctx[lo:hi], g, code[lo:hi], g, qt)
+    it = np.where(it >= 0, it + lo * 26, -1).astype(np.int32)
+    # both modalities ride in one exchange, text widened to f64 (as CodeKNN.sweep_tables does)
+    dcat = torch.cat([torch.from_numpy(d), torch.from_numpy(dt).double()], dim=1)
+    icat = torch.cat([torch.from_numpy(ix), torch.from_numpy(it)], dim=1)
+    D, I = alltoall_min_index(dcat, icat, world)
+    np.savez(out % rank, d=D.numpy(), i=I.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_owner_partitioned_alltoall_exchange(tmp_path):
+    """parallel.alltoall_min_index (one all-to-all; rank r ends with the final tables of query block r only) against the
+    single-process scan: distances and first-wins indices of every block, worlds 2 and 3, ties across shards."""
+    from oracle import cref
+    base, ctx, code, q, qt = _data()
+    q = np.concatenate([q, q[::-1][:1]])
+    qt = np.concatenate([qt, qt[::-1][:1]])
+    g = np.arange(26)
+    d, ix = cref.audio_scan(base, g * 6, code, g, q)
+    dt, it = cref.text_scan(ctx, g, code, g, qt)
+    for world in (2, 3):
+        out = str(tmp_path / ("a2a_w%d_r%%d.npz" % world))
+        mp.spawn(_worker_a2a, args=(world, _free_port(), out), nprocs=world, join=True)
+        qc = q.shape[0] // world
+        for r in range(world):
+            got = np.load(out % r)
+            rows = slice(r * qc, (r + 1) * qc)
+            assert np.array_equal(got["d"][:, :512], d[rows]) and np.array_equal(got["i"][:, :512], ix[rows])
+            assert np.array_equal(got["d"][:, 512:], dt[rows].astype(np.float64))
+            assert np.array_equal(got["i"][:, 512:], it[rows])
