@@ -233,8 +233,7 @@ def vqvae_bench(dev, a, world, rank):
 
     def train_step():
         tm(x)
-        tm.backward()
-        parallel.allreduce_sum_(tm.grad, average=True)
+        tm.backward(sync_grads=True)
         opt.step()
     tt = timed(train_step, 5)
     train_flop = 3 * (1.639e9 + 1.908e9) * Bw                      # forward + data-gradient + weight-gradient GEMMs

@@ -95,3 +95,31 @@ def broadcast_(t, src=0):
     else:
         dist_.broadcast(t, src)
     return t
+
+
+class GradBucket:
+    """One in-flight SUM all-reduce of a contiguous slice of the flat gradient buffer (RCCL: asynchronous, ordered
+    after the kernels already enqueued on the current stream, so the rest of backward overlaps it; gloo: host-staged
+    and synchronous).  wait() makes the current stream wait for the result."""
+
+    def __init__(self, t):
+        import torch.distributed as dist_
+        self.t, self.work = t, None
+        if not _active():
+            return
+        if _host_staged():
+            h = t.cpu()
+            dist_.all_reduce(h)
+            t.copy_(h)
+        else:
+            self.work = dist_.all_reduce(t, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+
+def world_size():
+    import torch.distributed as dist_
+    return dist_.get_world_size() if _active() else 1

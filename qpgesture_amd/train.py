@@ -150,8 +150,7 @@ def main(argv=None):
             x = train[idx].to(dev, non_blocking=True)
             opt.zero_grad()
             _, loss, metrics = model(x)
-            model.backward()
-            parallel.allreduce_sum_(model.grad, average=True)
+            model.backward(sync_grads=True)          # decoder-half all-reduce overlaps the encoder half of backward
             opt.step()
             updates += 1
             if rank == 0:

@@ -126,7 +126,9 @@ class VQVAE:
             convs.append(c)
             for c3, c1 in res:
                 convs += [c3, c1]
-        convs += [self.enc_out, self.dec_in]
+        convs.append(self.enc_out)
+        n_enc_convs = len(convs)
+        convs.append(self.dec_in)
         for res, even, odd in self.dec_up:
             for c3, c1 in res:
                 convs += [c3, c1]
@@ -139,7 +141,9 @@ class VQVAE:
         self.param = torch.zeros((total,), dtype=torch.float32, device=self.device)
         self.grad = torch.zeros((total,), dtype=torch.float32, device=self.device)
         o = 0
-        for c in convs:
+        for ci, c in enumerate(convs):
+            if ci == n_enc_convs:
+                self.n_enc_params = o                              # [0, n_enc_params) encoder, the rest decoder
             n = c.w.numel()
             self.param[o:o + n].copy_(c.w.view(-1))
             c.w, c.dw = self.param[o:o + n].view(c.w.shape), self.grad[o:o + n].view(c.w.shape)
@@ -511,20 +515,30 @@ class VQVAE:
                   float(upstream), dxo)
         return dxo
 
-    def backward(self, upstream=1.0, d_x_out=None):
+    def backward(self, upstream=1.0, d_x_out=None, sync_grads=False):
         """Gradients of the last training-mode forward()'s loss w.r.t. every parameter, written to self.grad (flat,
         same layout as self.param).  The codebook is a buffer updated by EMA, not by gradient (bottleneck.py:13).
-        d_x_out: optional replacement for the loss terms' own d loss / d x_out."""
+        d_x_out: optional replacement for the loss terms' own d loss / d x_out.
+        sync_grads: data-parallel averaging of the gradients in two buckets — the decoder half is all-reduced while
+        the encoder half is still being computed (backward produces the decoder's gradients first)."""
         sv = self._saved
         assert sv is not None, "backward() needs a training-mode forward() first"
         B, T, L = sv["B"], sv["T"], sv["L"]
         C = self.input_dim
         dxo = self.loss_grad(sv["x_out"], sv["x"], upstream) if d_x_out is None else d_x_out.contiguous()
         dzq = self._bwd_tape(sv["dec"], dxo, B)
+        buckets = [parallel.GradBucket(self.grad[self.n_enc_params:])] if sync_grads else []
         dz = torch.empty_like(dzq)
         R, E = B * L, self.emb
         _lib.call("qpg_vq_commit_grad_f32", self.device, sv["z2"], sv["zq"], R, E, float(upstream) * self.commit, dzq, dz)
         self._bwd_tape(sv["enc"], dz, B, need_input_grad=False)
+        if sync_grads:
+            buckets.append(parallel.GradBucket(self.grad[:self.n_enc_params]))
+            for b in buckets:
+                b.wait()
+            w = parallel.world_size()
+            if w > 1:
+                self.grad.div_(w)
         self._saved = None
         return self.grad
 

@@ -52,8 +52,7 @@ def main():
     opt = Adam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
     for step in range(2):
         _, loss, met = m(x_all[rank * per:(rank + 1) * per])
-        m.backward()
-        parallel.allreduce_sum_(m.grad, average=True)
+        m.backward(sync_grads=True)
         opt.step()
     sig = torch.stack([m.param.double().sum(), m.param.double().abs().sum(), m.k.double().sum(),
                        m.k_elem.double().sum(), m.k_sum.double().abs().sum()]).cpu()
