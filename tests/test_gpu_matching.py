@@ -234,3 +234,29 @@ def test_tabulated_walk_equals_sequential_walk(mode):
         assert np.array_equal(got[1], ref[1])
         n_diff_votes += int(ref[2].sum() > 0 and ref[2].sum() < ref[2].size)
     assert n_diff_votes > 0                                     # both gate outcomes occur in the sample
+
+
+def test_long_clip_walk_tabulated_equals_sequential_and_oracle():
+    """A 160 s clip (M = 40 windows, Q = 320 steps, window chaining 39 times): the tabulated walk, the sequential walk
+    and the oracle's literal restatement of search_code_knn agree on every code."""
+    import torch
+    from oracle import knn_oracle as O
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    A = fixture_arrays(40, 40, 31, 32, 33, 34, wavlm_dim=128)
+    db = GestureDB(A["code"], A["tr_interp"], A["tr_ctx"], A["tr_phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(5))
+    te_i = torch.from_numpy(A["te_interp"]).cuda()
+    te_c = torch.from_numpy(np.ascontiguousarray(A["te_ctx"])).cuda()
+    M = 40
+    T = knn.sweep_tables(te_i, te_c, M)
+    seed_code, seed_phase = knn.init_code_phase()
+    got = knn.walk(T, M, seed_code=seed_code, seed_phase=seed_phase)
+    knn.serial_walk = True
+    ref = knn.walk(T, M, seed_code=seed_code, seed_phase=seed_phase)
+    assert got[0].shape == (M, 30)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    orc = O.CodeKNNOracle(A["code"], A["sig"], A["tr_phase"], A["tr_ctx"], wavlm_interp=A["tr_interp"], scan="c",
+                          rank_kind="stable", rng=np.random.RandomState(5))
+    want, wph, wv = O.predict_code_from_audio(orc, test_interp=A["te_interp"], test_ctx=A["te_ctx"], n_windows=M)
+    assert np.array_equal(got[0], want) and np.array_equal(got[2], wv)
