@@ -111,6 +111,16 @@ extern "C" int qpg_percode_argmin_f32(qpg_ctx* ctx, void* stream, const float* D
 // ---------------------------------------------------------------------------------------------
 #define RS_CHUNK 4096   // candidates per block in the two resolve passes
 
+// Table initialisation as a KERNEL, not hipMemsetAsync: inside a captured hipGraph the memset nodes of ROCm 7.2 were
+// observed to complete after the kernels that follow them on the capturing stream once other work had run between
+// replays (tables came back all 0xFF; tools/dbg_graph3.py) — kernel -> kernel edges are honoured.
+__global__ __launch_bounds__(256) void fill_ff_kernel(unsigned long long* __restrict__ a, int64_t na,
+                                                      unsigned int* __restrict__ b, int64_t nb) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < na) a[i] = ~0ull;
+  if (b && i < nb) b[i] = ~0u;
+}
+
 __global__ __launch_bounds__(256) void percode_min_f64_kernel(const double* __restrict__ D, int64_t ldD,
                                                               const int32_t* __restrict__ code, int code_ld, int N,
                                                               const int32_t* __restrict__ cand_cidx, int G, int K,
@@ -161,10 +171,11 @@ extern "C" int qpg_percode_resolve_f64(qpg_ctx* ctx, void* stream, const double*
               "qpg_percode_resolve_f64: bad size");
   if (Q == 0) return QPG_OK;
   hipStream_t st = qpg_stream(stream);
-  if (hipMemsetAsync(best_key, 0xFF, sizeof(uint64_t) * (size_t)Q * K, st) != hipSuccess ||
-      hipMemsetAsync(best_idx, 0xFF, sizeof(uint32_t) * (size_t)Q * K, st) != hipSuccess) {
-    qpg_set_error("qpg_percode_resolve_f64: hipMemsetAsync failed");
-    return QPG_EHIP;
+  {
+    const int64_t n = (int64_t)Q * K;
+    hipLaunchKernelGGL(fill_ff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned long long*>(best_key), n, best_idx, n);
+    QPG_LAUNCH_CHECK("fill_ff_kernel");
   }
   if (N == 0) return QPG_OK;
   const int64_t C = (int64_t)N * G;
@@ -213,9 +224,11 @@ extern "C" int qpg_percode_resolve_f32(qpg_ctx* ctx, void* stream, const float* 
               "qpg_percode_resolve_f32: bad size");
   if (Q == 0) return QPG_OK;
   hipStream_t st = qpg_stream(stream);
-  if (hipMemsetAsync(packed, 0xFF, sizeof(uint64_t) * (size_t)Q * K, st) != hipSuccess) {
-    qpg_set_error("qpg_percode_resolve_f32: hipMemsetAsync failed");
-    return QPG_EHIP;
+  {
+    const int64_t n = (int64_t)Q * K;
+    hipLaunchKernelGGL(fill_ff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned long long*>(packed), n, (unsigned int*)nullptr, (int64_t)0);
+    QPG_LAUNCH_CHECK("fill_ff_kernel");
   }
   if (N == 0) return QPG_OK;
   const int64_t C = (int64_t)N * G;

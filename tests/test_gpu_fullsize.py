@@ -190,3 +190,38 @@ def test_input_validation():
         knn.match_clip(ti[:, :, :64].contiguous(), tc, 2)   # feature width differs from the database's
     with pytest.raises(ValueError):
         CodeKNN(db, use_wavlm=False, use_wavvq=True)    # DB built without a wavvq track
+
+
+def test_graph_replays_stay_valid_after_eager_clips():
+    """Regression (round 1): a captured clip replayed after eager clips of the same process returned all-absent tables
+    / faulted, because the table initialisations were hipMemsetAsync nodes, which ROCm 7.2's graph replay let complete
+    AFTER the kernels that followed them once other work had run in between.  They are fill kernels now.  Full-size DB
+    (the failure needed the ~0.8 ms clip), eager clips on two streams, replays before and after."""
+    import torch
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    N, M = 2048, 6
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    interp = torch.randn((N, 180, 1024), device=dev)
+    ctx = rng.standard_normal((N, 30, 384)).astype(np.float32)
+    phase = rng.standard_normal((N, 240, 4, 8)).astype(np.float32)
+    db = GestureDB(synth.make_codes(N, 2), interp, ctx, phase, synth.make_signature(3), device=dev)
+    knn = CodeKNN(db, rng=np.random.RandomState(123456))
+    te_i = torch.randn((M, 180, 1024), device=dev)
+    te_c = torch.randn((M, 30, 384), device=dev)
+    sc, sp = knn.init_code_phase()
+    spd = torch.from_numpy(sp).to(dev)
+
+    def eager():
+        T = knn.sweep_tables(te_i, te_c, M)
+        return knn.walk(T, M, 0, seed_code=sc, seed_phase=spd, sync=False)[0].cpu()
+    want = eager()
+    g = knn.capture_clip_graph(M)
+    assert torch.equal(g.run(te_i, te_c, sc, spd)[0].cpu(), want)
+    for _ in range(40):
+        assert torch.equal(eager(), want)
+    torch.cuda.synchronize()
+    for _ in range(20):
+        out = g.run(te_i, te_c, sc, spd)
+        assert torch.equal(out[0].cpu(), want) and int(out[3].item()) == 0
