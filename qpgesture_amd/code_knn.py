@@ -481,6 +481,9 @@ class CodeKNN:
                 T["aud_rank"] = r[2]
         if overlap:
             main.wait_stream(side)
+            for k in ("txt_d", "txt_idx", "txt_rank"):      # allocated on `side`, consumed on `main`: tell the allocator
+                if T[k] is not None:
+                    T[k].record_stream(main)
         elif mode in (MODE_AUD_TXT, MODE_TXT):
             text_side()
         if sharded:
