@@ -481,9 +481,9 @@ class CodeKNN:
                 T["aud_rank"] = r[2]
         if overlap:
             main.wait_stream(side)
-            for k in ("txt_d", "txt_idx", "txt_rank"):      # allocated on `side`, consumed on `main`: tell the allocator
-                if T[k] is not None:
-                    T[k].record_stream(main)
+            # The text tables are allocated on `side` and consumed on `main`.  No record_stream() (measured +15 us per
+            # clip for the allocator's events): a freed block can only be reused by a later `side` allocation, and every
+            # use of `side` starts with side.wait_stream(main) above, i.e. after main's consumers of the block.
         elif mode in (MODE_AUD_TXT, MODE_TXT):
             text_side()
         if sharded:
