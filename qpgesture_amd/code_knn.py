@@ -555,7 +555,7 @@ class CodeKNN:
 
 class ClipGraph:
     """A captured clip: static input buffers + one hipGraph (torch.cuda.CUDAGraph is the HIP graph wrapper;
-    every node is one of this library's kernels or a memset).  The seed code is a kernel ARGUMENT of the walk,
+    every node is one of this library's kernels or a torch indexing kernel; no memset nodes, see fill_ff_kernel).  The seed code is a kernel ARGUMENT of the walk,
     so a graph is tied to the seed code it was captured with; the seed phase block is a buffer."""
 
     def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset):
