@@ -176,13 +176,22 @@ __global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
   }
   for (int it = it0; it < it1; ++it) {
     constexpr int buf = 0;
+#if !defined(QPG_CONV_PROBE) || QPG_CONV_PROBE == 1
     __syncthreads();   // previous slice fully consumed
     commit(buf);
     __syncthreads();
+#endif
+#if !defined(QPG_CONV_PROBE)
     if (it + 1 < it1) fetch();           // in flight during the MFMAs below
+#endif
     // LDS operand reads run one k-pair ahead of the MFMAs that consume them
     float bq[2][2], aq[2][MT];
     auto lds_read = [&](int ks, int slot) {
+#if defined(QPG_CONV_PROBE) && QPG_CONV_PROBE == 3
+      bq[slot][0] = bq[slot][1] = 1.0f;
+      for (int mt = 0; mt < MT; ++mt) aq[slot][mt] = 1.0f;
+      return;
+#endif
       const int k = ks * 2 + (lane >> 5);
       bq[slot][0] = Bs[buf][k][wn * 64 + (lane & 31)];
       bq[slot][1] = Bs[buf][k][wn * 64 + 32 + (lane & 31)];
