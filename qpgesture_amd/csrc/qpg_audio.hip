@@ -126,6 +126,11 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
     f32x4 a[MT][2], b[NT][2];
   };
   auto load = [&](Buf& u, int e0, int tap) {
+#if defined(QPG_AUDIO_PROBE)     // experiments/conv_probe: operands from constants, no loads
+    for (int mt = 0; mt < MT; ++mt) u.a[mt][0] = u.a[mt][1] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    for (int nt = 0; nt < NT; ++nt) u.b[nt][0] = u.b[nt][1] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    return;
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       // taps past the end of the window are zero padding (data_processing.py:266): load from a valid
@@ -167,29 +172,29 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
   const int eBeg = w * (F / KS), eEnd = eBeg + (F / KS);
   Buf u0, u1;
   load(u0, eBeg, 0);
+  // Issue pattern of one (load next group, 8*MT*NT MFMAs of the current group) stage: the (MT+NT)*2 16-B loads are
+  // spread between the MFMAs — 2 MFMAs, 1 load, ... — instead of being issued as one burst in front of them, so the
+  // matrix pipe is never left waiting behind a queue of address computations and the loads still lead their use by
+  // a whole stage.  sched_barrier(0) closes the region.
+#define QPG_AUDIO_STAGE(LOADSTMT, MMASTMT)                                   \
+  LOADSTMT;                                                                  \
+  MMASTMT;                                                                   \
+  _Pragma("unroll") for (int sg = 0; sg < (MT + NT) * 2; ++sg) {             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                       \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       \
+  }                                                                          \
+  __builtin_amdgcn_sched_group_barrier(0x008, 8 * MT * NT - 4 * (MT + NT), 0); \
+  __builtin_amdgcn_sched_barrier(0);
   for (int e0 = eBeg; e0 < eEnd; e0 += 32) {
-    // sched_barrier(0) pins the issue order: all loads of the NEXT group are issued before the 48 MFMAs of the
-    // current one (left alone, hipcc sinks them to ~10 MFMAs before their use: less than the HBM latency)
-    load(u1, e0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(u0);
-    load(u0, e0, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(u1);
-    load(u1, e0, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(u0);
-    load(u0, e0, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(u1);
-    load(u1, e0, 5);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(u0);
+    QPG_AUDIO_STAGE(load(u1, e0, 1), mma(u0))
+    QPG_AUDIO_STAGE(load(u0, e0, 2), mma(u1))
+    QPG_AUDIO_STAGE(load(u1, e0, 3), mma(u0))
+    QPG_AUDIO_STAGE(load(u0, e0, 4), mma(u1))
+    QPG_AUDIO_STAGE(load(u1, e0, 5), mma(u0))
     const int en = (e0 + 32 < eEnd) ? e0 + 32 : eBeg;   // last prefetch wraps to a valid address, unused
-    load(u0, en, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(u1);
+    QPG_AUDIO_STAGE(load(u0, en, 0), mma(u1))
   }
+#undef QPG_AUDIO_STAGE
 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
