@@ -7,7 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 variant = sys.argv[1]
 import qpgesture_amd._lib as L
-if variant not in ("0", "a0"):
+if variant.endswith(".so"):
+    L.LIB_PATH = os.path.abspath(variant)
+elif variant not in ("0", "a0"):
     so = os.path.join(HERE, "libqpg_probe%s.so" % variant)
     csrc = os.path.join(ROOT, "qpgesture_amd", "csrc")
     srcs = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hip"))

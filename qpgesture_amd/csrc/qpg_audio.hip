@@ -176,14 +176,17 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
   // spread between the MFMAs — 2 MFMAs, 1 load, ... — instead of being issued as one burst in front of them, so the
   // matrix pipe is never left waiting behind a queue of address computations and the loads still lead their use by
   // a whole stage.  sched_barrier(0) closes the region.
+#ifndef QPG_MPL
+#define QPG_MPL 2
+#endif
 #define QPG_AUDIO_STAGE(LOADSTMT, MMASTMT)                                   \
   LOADSTMT;                                                                  \
   MMASTMT;                                                                   \
   _Pragma("unroll") for (int sg = 0; sg < (MT + NT) * 2; ++sg) {             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, QPG_MPL, 0);                 \
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       \
   }                                                                          \
-  __builtin_amdgcn_sched_group_barrier(0x008, 8 * MT * NT - 4 * (MT + NT), 0); \
+  __builtin_amdgcn_sched_group_barrier(0x008, 8 * MT * NT - QPG_MPL * 2 * (MT + NT), 0); \
   __builtin_amdgcn_sched_barrier(0);
   for (int e0 = eBeg; e0 < eEnd; e0 += 32) {
     QPG_AUDIO_STAGE(load(u1, e0, 1), mma(u0))
