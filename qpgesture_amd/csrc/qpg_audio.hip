@@ -82,7 +82,8 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
                                                                int tap_stride, const double* __restrict__ cn2,
                                                                const float* __restrict__ q32,
                                                                const double* __restrict__ qn2, int Q,
-                                                               double* __restrict__ D, int64_t ldD) {
+                                                               double* __restrict__ D, int64_t ldD,
+                                                               const float* __restrict__ zeros) {
   __shared__ double red[KS][MT * NT][4][64];  // [wave][tile][acc reg][lane]
 
   const int64_t C = (int64_t)N * G;
@@ -133,15 +134,13 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
 #endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      // taps past the end of the window are zero padding (data_processing.py:266): load from a valid
-      // address unconditionally and select afterwards — a conditional load makes hipcc branch around it
-      // and drain vmcnt(0), which serialises the prefetch
+      // taps past the end of the window are zero padding (data_processing.py:266): the load is unconditional (a
+      // conditional load makes hipcc branch around it and drain vmcnt(0), which serialises the prefetch) and a
+      // padded tap reads the context's zero page instead of being selected to zero afterwards
       const bool ok = at0[mt] + tap * tap_stride < T;
-      const float* p = arow[mt] + (ok ? (int64_t)tap * tap_stride * F : 0) + e0;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
-      const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-      u.a[mt][0] = ok ? v0 : z;
-      u.a[mt][1] = ok ? v1 : z;
+      const float* p = ok ? arow[mt] + (int64_t)tap * tap_stride * F + e0 : zeros;
+      u.a[mt][0] = *reinterpret_cast<const f32x4*>(p);
+      u.a[mt][1] = *reinterpret_cast<const f32x4*>(p + 4);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -241,7 +240,7 @@ static int launch_audio(qpg_ctx* ctx, void* stream, const float* base, int N, in
   // 4 waves (one per SIMD) split the feature axis.  An 8-wave split (finer work units, 6.5 instead of
   // 3.25 rounds of blocks at N_db=2048) measured slower on MI355X: 703 vs 629 us (r01 notes).
   hipLaunchKernelGGL((audio_cosine_f64_kernel<MT, NT, 6, 4>), grid, dim3(256), 0, qpg_stream(stream), base, N, T, F,
-                     cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD);
+                     cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros);
   QPG_LAUNCH_CHECK("audio_cosine_f64_kernel");
   return QPG_OK;
 }
