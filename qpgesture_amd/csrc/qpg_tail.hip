@@ -96,9 +96,30 @@ __global__ __launch_bounds__(256) void fuse_best_kernel(const int16_t* __restric
   const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (q, p)
   if (task >= (int64_t)Q * K) return;
   const int q = (int)(task / K), p = (int)(task - (int64_t)q * K);
-  const int which = blockIdx.y;                                       // mode 0: 0 = audio table, 1 = text table
-  const int16_t* rk = (mode == 0 ? (which ? rank1 : rank0) : (mode == 1 ? rank0 : rank1)) + (int64_t)q * K;
-  const int32_t* ix = (mode == 0 ? (which ? idx1 : idx0) : (mode == 1 ? idx0 : idx1)) + (int64_t)q * K;
+  if (mode == 0) {
+    // both modalities in one wave: the pose / frequency part of the score is shared, only the last addend differs
+    const int16_t* ra = rank0 + (int64_t)q * K;
+    const int16_t* rt = rank1 + (int64_t)q * K;
+    ArgMin ma{__builtin_inf(), 0x7fffffff}, mt{__builtin_inf(), 0x7fffffff};
+#pragma unroll
+    for (int i = 0; i < QPG_KMAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      if (c < K) {
+        const double pos_score = (double)pos_rank[(int64_t)p * K + c] + (double)freq_rank[c] * 0.05;
+        ma = amin(ma, ArgMin{pos_score + (double)ra[c], c});
+        mt = amin(mt, ArgMin{pos_score + (double)rt[c], c});
+      }
+    }
+    ma = wave_argmin(ma);
+    mt = wave_argmin(mt);
+    if (lane == 0) {
+      T0[task] = idx0[(int64_t)q * K + ma.i];
+      T1[task] = idx1[(int64_t)q * K + mt.i];
+    }
+    return;
+  }
+  const int16_t* rk = (mode == 1 ? rank0 : rank1) + (int64_t)q * K;
+  const int32_t* ix = (mode == 1 ? idx0 : idx1) + (int64_t)q * K;
   ArgMin m{__builtin_inf(), 0x7fffffff};
   double vals[QPG_KMAX_PER_LANE];
 #pragma unroll
@@ -112,10 +133,6 @@ __global__ __launch_bounds__(256) void fuse_best_kernel(const int16_t* __restric
     }
   }
   m = wave_argmin(m);
-  if (mode == 0) {
-    if (lane == 0) (which ? T1 : T0)[task] = ix[m.i];
-    return;
-  }
   // single-modality modes: the two best codes go through the phase gate (GestureKNN.py:596, 613)
   ArgMin m2{__builtin_inf(), 0x7fffffff};
 #pragma unroll
@@ -488,7 +505,7 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   const int Q = M * steps;
   int32_t* T0 = gate_tables;
   int32_t* T1 = gate_tables + (int64_t)Q * K;
-  dim3 grid((unsigned)(((int64_t)Q * K + 3) / 4), mode == QPG_MODE_AUD_TXT ? 2 : 1);
+  dim3 grid((unsigned)(((int64_t)Q * K + 3) / 4), 1);
   hipLaunchKernelGGL(fuse_best_kernel, grid, dim3(256), 0, qpg_stream(stream), aud_rank, aud_idx, txt_rank, txt_idx,
                      pos_rank, freq_rank, Q, K, mode, T0, T1);
   QPG_LAUNCH_CHECK("fuse_best_kernel");
