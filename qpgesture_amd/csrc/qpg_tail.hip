@@ -432,27 +432,32 @@ __global__ __launch_bounds__(256) void gate_table_kernel(TailArgs A, GateGeom ge
 
 #define QPG_CHASE_QMAX 2048
 __global__ __launch_bounds__(256) void gate_chase_kernel(TailArgs A, const uint16_t* __restrict__ Gt) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t gl[];     // [steps][2K] of the current window
+  extern __shared__ __attribute__((aligned(16))) uint16_t gl[];     // 2 x [steps][2K]: current window + the next being staged
   __shared__ uint16_t sig[QPG_CHASE_QMAX];
   __shared__ int bad_s;
   const int K = A.K, Q = A.M * A.steps, tid = threadIdx.x;
   const int per_w = A.steps * 2 * K;                                // u16 per window
   if (tid == 0) bad_s = 0;
   int sigma = 0;
-  for (int w = 0; w < A.M; ++w) {
-    __syncthreads();
+  // two LDS buffers: waves 1..3 stage window w+1's table while lane 0 of wave 0 chases window w
+  auto stage = [&](int w, int first, int step) {
     const int4* src = reinterpret_cast<const int4*>(Gt + (int64_t)w * per_w);
-    int4* dst = reinterpret_cast<int4*>(gl);
-    for (int v = tid; v < per_w / 8; v += 256) dst[v] = src[v];
-    __syncthreads();
+    int4* dst = reinterpret_cast<int4*>(gl + (size_t)(w & 1) * per_w);
+    for (int v = first; v < per_w / 8; v += step) dst[v] = src[v];
+  };
+  stage(0, tid, 256);
+  __syncthreads();
+  for (int w = 0; w < A.M; ++w) {
+    if (tid >= 64 && w + 1 < A.M) stage(w + 1, tid - 64, 192);
     if (tid == 0) {
+      const uint16_t* g = gl + (size_t)(w & 1) * per_w;
       for (int s = 0; s < A.steps; ++s) {
-        sigma = (w == 0 && s == 0) ? gl[0] : gl[s * 2 * K + sigma];
+        sigma = (w == 0 && s == 0) ? g[0] : g[s * 2 * K + sigma];
         sig[w * A.steps + s] = (uint16_t)sigma;
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
   // parallel epilogue: the winners' phase blocks, votes, codes; absent-candidate check of every visited gate
   for (int i = tid; i < Q * 32; i += 256) {                         // 32 x 16 B per phase block
     const int q = i >> 5, v = i & 31;
@@ -522,7 +527,7 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   // reference's grids: 8 steps x 4 codes, 30 kept) and the state fits 16 bits; the one-wave sequential walk otherwise
   const int last_idx = A.codes_per_window - 1;
   GateGeom geo{last_idx / A.step_codes, last_idx % A.step_codes};
-  const size_t lds_g = (size_t)steps * 2 * K * sizeof(uint16_t);
+  const size_t lds_g = (size_t)2 * steps * 2 * K * sizeof(uint16_t);     // two window tables (double buffer)
   const bool tabulated = !serial_walk && geo.s_last == steps - 1 && 2 * K <= 65536 && Q <= QPG_CHASE_QMAX &&
                          lds_g <= 64 * 1024 && ((steps * 2 * K) % 8) == 0;
   if (!tabulated) {
