@@ -1,0 +1,69 @@
+"""Randomised VQ-VAE parity stress (not in the suite): encode ids / decode poses / training gradients vs the torch-fp32
+oracle over random batch sizes, sequence lengths and widths.  python tools/stress_vqvae.py [trials]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import vqvae_oracle as VO
+from qpgesture_amd import synth
+from qpgesture_amd.vqvae import VQVAE
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+rs = np.random.RandomState(7)
+bad = 0
+for t in range(trials):
+    width = int(rs.choice([64, 64, 128, 512]))
+    bins = int(rs.choice([96, 512])) if width != 512 else 512
+    hps = dict(width=width, emb_width=width, l_bins=bins)
+    B = int(rs.randint(1, 7)); T = 8 * int(rs.randint(1, 40))
+    seed = int(rs.randint(0, 1000))
+    sd = synth.make_vqvae_state_dict(seed, hps)
+    m = VQVAE(dict(hps, vel=1, acc=1, commit=0.02, reg=0.1), 135, device="cuda:0").load_state_dict(sd)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 1)).standard_normal((B, T, 135)).astype(np.float32))
+    # encode: ids exact wherever the reference's own top-2 margin is above f32 noise
+    lat = VO.encode_latent(sd, x, hps)
+    z = lat.permute(0, 2, 1).reshape(-1, width)
+    k = torch.from_numpy(np.asarray(sd["module.bottleneck.level_blocks.0.k"]))
+    d = (z ** 2).sum(-1, keepdim=True) - 2 * z @ k.t() + (k.t() ** 2).sum(0, keepdim=True)
+    top2 = torch.topk(d, 2, dim=-1, largest=False)
+    want_ids = top2.indices[:, 0].reshape(B, -1).numpy()
+    margin = (top2.values[:, 1] - top2.values[:, 0]).reshape(B, -1).numpy()
+    scale = float(d.abs().max())
+    ids = m.encode(x.cuda())[0].cpu().numpy()
+    safe = margin > 1e-5 * scale
+    ok_enc = np.array_equal(ids[safe], want_ids[safe])
+    # decode of random ids
+    rid = torch.from_numpy(rs.randint(0, bins, size=(B, T // 8)).astype(np.int64))
+    want_pose = VO.decode(sd, rid, hps).numpy()
+    got_pose = m.decode([rid]).cpu().numpy()
+    err_dec = float(np.abs(got_pose - want_pose).max())
+    # training gradients with a shared upstream gradient (tight check, see tests/test_gpu_vqvae_train.py)
+    sdt = {kk: torch.from_numpy(np.asarray(v)).clone().requires_grad_(not kk.endswith(".k")) for kk, v in sd.items()}
+    xo_ref, loss_ref, met_ref, _, ids_ref = VO.forward(sdt, x, hps=hps, training=False, commit=0.02, reg=0.1)
+    m.train(); m.k_init = True; m.k_sum, m.k_elem = m.k.clone(), torch.ones(bins, device="cuda"); m.mu = 1.0
+    xo, loss, met = m(x.cuda())
+    same_ids = np.array_equal(m._saved["ids"].cpu().numpy(), ids_ref.numpy())
+    gerr, worst = 0.0, []
+    if same_ids:
+        dxo = m.loss_grad(xo, x.cuda())
+        (torch.sum(xo_ref * dxo.cpu()) + 0.02 * met_ref["commit_loss"]).backward()
+        m.backward(d_x_out=dxo)
+        grads = m.named_gradients(prefix="module.")
+        for n, gt in sdt.items():
+            if gt.grad is not None:
+                e = float((grads[n] - gt.grad).abs().max()) / max(float(gt.grad.abs().max()), 1e-12)
+                gerr = max(gerr, e)
+                if e > 5e-4:
+                    worst.append((n.replace("module.", "").replace("level_blocks.0.model.", ""), "%.1e" % e))
+    ok = ok_enc and err_dec < 1e-4 and (not same_ids or gerr < 5e-2) and abs(float(loss) - float(loss_ref)) < 1e-4 * abs(float(loss_ref)) + (0 if same_ids else 1e9)
+    bad += not ok
+    print("trial %2d width=%3d bins=%3d B=%d T=%3d: ids %s (%d/%d above margin) decode err %.1e grad rel err %.1e %s" % (
+        t, width, bins, B, T, "ok" if ok_enc else "MISMATCH", int(safe.sum()), safe.size, err_dec, gerr,
+        "" if same_ids else "(forward ids differ within margin: gradient check skipped)"), flush=True)
+    if worst:
+        print("      tensors above 5e-4:", worst[:6], "... %d total" % len(worst), flush=True)
+        # A gradient error of 1e-3..1e-2 (relative to the tensor's maximum) that starts at some layer and covers
+        # everything upstream of it is what ONE flipped ReLU mask looks like: the two f32 forwards differ by ~1e-6, and
+        # with ~2 M pre-activations per pass a few land within that distance of zero on either side.  A wrong tap /
+        # stride / transpose shows up as an O(1) error, which is what this tool fails on.
+print("done: %d trials, %d failures" % (trials, bad))
+sys.exit(1 if bad else 0)
