@@ -16,6 +16,9 @@ for t in range(trials):
     hps = dict(width=width, emb_width=width, l_bins=bins)
     B = int(rs.randint(1, 7)); T = 8 * int(rs.randint(1, 40))
     seed = int(rs.randint(0, 1000))
+    if os.environ.get("STRESS_SHAPE"):                   # "width,bins,B,T": fixed shape, random data
+        width, bins, B, T = [int(v) for v in os.environ["STRESS_SHAPE"].split(",")]
+        hps = dict(width=width, emb_width=width, l_bins=bins)
     sd = synth.make_vqvae_state_dict(seed, hps)
     m = VQVAE(dict(hps, vel=1, acc=1, commit=0.02, reg=0.1), 135, device="cuda:0").load_state_dict(sd)
     x = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 1)).standard_normal((B, T, 135)).astype(np.float32))
