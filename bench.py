@@ -148,7 +148,7 @@ def main():
                 "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4),
                 # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
                 # measured for exactly this launch shape only: profiles/r01_pmc_audio.md
-                "traffic": 942_000_000 if (world == 1 and N == 2048 and M == 6) else None,
+                "traffic": 925_000_000 if (world == 1 and N == 2048 and M == 6) else None,
                 "kernel": "audio_cosine_f64_kernel", "kernel_ms": round(k_ms, 4),
                 "algorithmic_gflop": round(flops / 1e9, 3),
                 "algorithmic_bytes": int(alg_bytes),
