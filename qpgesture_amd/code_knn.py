@@ -530,11 +530,15 @@ class CodeKNN:
                   gate, out_codes, out_phase, out_vote, status)
         if not sync:
             return out_codes, out_phase, out_vote, status
-        codes = out_codes.cpu().numpy().astype(np.int64)
-        if int(status.item()) != 0:
+        # one D2H copy for the integer results (codes | votes | status) instead of three synchronous ones
+        ints = torch.cat((out_codes.reshape(-1), out_vote.reshape(-1), status)).cpu().numpy()
+        n_c = out_codes.numel()
+        if int(ints[-1]) != 0:
             raise IndexError("a code that never occurs in the database won a rank fusion "
                              "(the reference raises IndexError at GestureKNN.py:631-632)")
-        return codes, out_phase.cpu().numpy(), out_vote.cpu().numpy()
+        codes = ints[:n_c].reshape(tuple(out_codes.shape)).astype(np.int64)
+        votes = ints[n_c:-1].reshape(tuple(out_vote.shape)).copy()
+        return codes, out_phase.cpu().numpy(), votes
 
     def capture_clip_graph(self, n_windows, mode=MODE_AUD_TXT, n_sweep_windows=None, window_offset=0):
         """Capture the whole per-clip launch sequence (pack, both sweeps, per-code argmin passes, ranks,
