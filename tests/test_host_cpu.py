@@ -158,3 +158,37 @@ def test_oracle_forward_loss_terms():
     assert abs(float(m["regularization"]) - (0.25 + 9.0) / 2) < 1e-6
     want = 0.375 + 2.0 * 0.02 + 0.5 * 4.625 + 2.5 / 3 + 1.25
     assert abs(float(loss) - want) < 1e-6
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every binding in qpgesture_amd/_lib._SIGS has the argument count and the pointer / integer / float kinds of
+    its prototype in include/qpg.h (a drifted ctypes signature would corrupt the call silently)."""
+    import ctypes
+    import re
+    hdr = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|int64_t|void)\s+(qpg_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        protos[m.group(1)] = [re.sub(r"\s+", " ", a.strip()) for a in m.group(2).split(",")]
+
+    def kind_of_c(arg):
+        if "*" in arg:
+            return "ptr"
+        t = arg.split()[0] if " " in arg else arg
+        if t in ("float",):
+            return "f32"
+        if t in ("double",):
+            return "f64"
+        if t in ("int64_t",):
+            return "i64"
+        return "i32"                                  # int, int32_t
+
+    def kind_of_ct(t):
+        if t is ctypes.c_void_p:
+            return "ptr"
+        return {ctypes.c_float: "f32", ctypes.c_double: "f64", ctypes.c_int64: "i64"}.get(t, "i32")
+    for name, sig in _lib._SIGS.items():
+        args = protos[name]
+        assert [kind_of_c(a) for a in args[:2]] == ["ptr", "ptr"], name          # qpg_ctx*, void* stream
+        want = [kind_of_c(a) for a in args[2:]]
+        got = [kind_of_ct(t) for t in sig]
+        assert got == want, (name, got, want)
