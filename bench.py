@@ -163,8 +163,8 @@ def main():
                                   "N_db=%d windows (%d candidates), shipped mode wavlm_feat(f64)+text(f32)+phase"
                                   % (M, M * 8, 240 * M, N, N * 26),
                       "n_db": N, "windows_per_clip": M, "clips": world,
-                      "parallelism": "db-row-shard x%d + %s" % (world, "all-to-all(min,index)" if world > 1
-                                                                 else "single shard")},
+                      "parallelism": ("db-row-shard x%d + all-to-all(min,index)" % world) if world > 1
+                      else "single GPU, unsharded DB"},
            "roofline": roofline,
            "realtime_factor": round(value / 60.0 / world, 1)}
 
