@@ -207,6 +207,26 @@ int qpg_conv1d_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, int 
                    int dil, int T_out, int out_stride, int out_offset, int T_y, const float* residual, int relu_in,
                    int relu_out, float* y, float* ws, int64_t ws_floats);
 
+/* The same convolution in the TRANSPOSED formulation (csrc/qpg_convt.hip): y^T = W^T . x^T on v_mfma_f32_16x16x4_f32,
+ * a wave owns 16 positions, activations go straight from the channels-last rows to registers, the weights stream
+ * through LDS by LDS-DMA from a pre-packed image.  Same argument meaning as qpg_conv1d_f32 except:
+ *   x rows have pitch Cx floats (Cx % 4 == 0, Cx >= Cin_pad, 16-byte aligned base): pad 135-channel pose rows
+ *   with qpg_pad_channels_f32 first;
+ *   wt: [dev] f32 T-pack  wt[nb][kb][g][nl][j] = W[k = 16 kb + 4 g + j][n = 128 nb + nl],  k = tap*Cin_pad + ci,
+ *   zero padded, (taps*Cin_pad) % 64 == 0, Cout_pad % 128 == 0. */
+int qpg_convt_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, int Cx, const float* wt, const float* bias,
+                  int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride, int in_offset, int dil, int T_out,
+                  int out_stride, int out_offset, int T_y, const float* residual, int relu_in, int relu_out, float* y);
+/* y[r][0..Cp) = x[r][0..C) zero-extended (rows of 135 floats are not 16-byte aligned). */
+int qpg_pad_channels_f32(qpg_ctx*, void* stream, const float* x, int64_t R, int C, int Cp, float* y);
+/* One ResConv1DBlock of width 512 in ONE launch (resnet.py:31-46):  y = x + W2 . relu(W1 (*) relu(x) + b1) + b2,
+ * W1 the dilated k3 convolution, W2 the 1x1 one; the hidden activation stays in the MFMA accumulators (the C/D
+ * register layout of the first GEMM is the B-operand layout of the second).  x, y: [dev] f32 [B][T][512], x != y;
+ * wpack: [dev] f32, 96 stages (T-pack NB = 512 of W1, k = tap*512 + ci) then 32 stages (T-pack NB = 128 of W2) of
+ * 8192 floats each; b1, b2: [dev] f32 [512]; hidden: optional [dev] f32 [B][T][512] copy of relu(W1(*)relu(x)+b1). */
+int qpg_resblock_f32(qpg_ctx*, void* stream, const float* x, int B, int T, int dil, const float* wpack,
+                     const float* b1, const float* b2, float* y, float* hidden);
+
 /* BottleneckBlock.quantise (bottleneck.py:120-126) after the GEMM: ids[r] = argmin_c (|z_r|^2 - 2 dot[r][c]) + kk[c]
  * (f32, that operation order, lowest index on ties).  z: [dev] f32 [R][E]; dot: [dev] f32 [R][K]; kk: [dev] f32 [K];
  * ids: [dev] i64 [R]; dmin / dsecond: optional [dev] f32 [R] best and runner-up distance (parity margin). */
@@ -228,6 +248,7 @@ typedef struct {
   const float* w;    /* [dev] [taps][cin_pad][cout_pad] */
   const float* b;    /* [dev] [cout_pad] or NULL */
   int32_t taps, cin, cin_pad, cout, cout_pad;
+  const float* wt;   /* [dev] optional T-pack (NB = 128) of the same weights for qpg_convt_f32, or NULL */
 } qpg_conv_desc;
 typedef struct {
   int32_t in_dim, width, emb, bins, down_t, depth, growth, reverse_dec;
@@ -242,6 +263,9 @@ typedef struct {
   qpg_conv_desc kT;                                              /* codebook^T as a 1-tap conv   (bottleneck.py:123) */
   const float* k;                                                /* [dev] [bins][emb] */
   const float* kk;                                               /* [dev] [bins] sum_e k^2 */
+  /* optional (width == emb == 512): fused ResConv1DBlock weight images for qpg_resblock_f32, or NULL */
+  const float* enc_res_pack[QPG_VQ_MAX_DOWN][QPG_VQ_MAX_DEPTH];
+  const float* dec_res_pack[QPG_VQ_MAX_DOWN][QPG_VQ_MAX_DEPTH];
 } qpg_vq_model;
 
 /* floats of scratch the two calls below need for a batch of B sequences of T pose frames */

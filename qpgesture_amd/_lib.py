@@ -41,6 +41,9 @@ _SIGS = {
     "qpg_l2_table_f32": [P, I, I, P],
     "qpg_wavvq_lev_f32": [P, I, I, P, I, P, I, P, I, I, P, P, I, P, L],
     "qpg_conv1d_f32": [P, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, P, P, L],
+    "qpg_convt_f32": [P, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, P],
+    "qpg_pad_channels_f32": [P, L, I, I, P],
+    "qpg_resblock_f32": [P, I, I, I, P, P, P, P, P],
     "qpg_vq_argmin_f32": [P, P, P, L, I, I, P, P, P],
     "qpg_vq_gather_f32": [P, P, L, I, I, P, P],
     "qpg_vq_encode_f32": [P, P, I, I, P, L, P, P, P],
@@ -63,7 +66,8 @@ QPG_VQ_MAX_DOWN, QPG_VQ_MAX_DEPTH = 4, 4
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [("w", c_void_p), ("b", c_void_p), ("taps", ctypes.c_int32), ("cin", ctypes.c_int32),
-                ("cin_pad", ctypes.c_int32), ("cout", ctypes.c_int32), ("cout_pad", ctypes.c_int32)]
+                ("cin_pad", ctypes.c_int32), ("cout", ctypes.c_int32), ("cout_pad", ctypes.c_int32),
+                ("wt", c_void_p)]
 
 
 class VqModel(ctypes.Structure):
@@ -76,7 +80,9 @@ class VqModel(ctypes.Structure):
                 ("enc_out", ConvDesc), ("dec_in", ConvDesc),
                 ("dec_res", ((ConvDesc * 2) * QPG_VQ_MAX_DEPTH) * QPG_VQ_MAX_DOWN),
                 ("dec_up_even", ConvDesc * QPG_VQ_MAX_DOWN), ("dec_up_odd", ConvDesc * QPG_VQ_MAX_DOWN),
-                ("dec_out", ConvDesc), ("kT", ConvDesc), ("k", c_void_p), ("kk", c_void_p)]
+                ("dec_out", ConvDesc), ("kT", ConvDesc), ("k", c_void_p), ("kk", c_void_p),
+                ("enc_res_pack", (c_void_p * QPG_VQ_MAX_DEPTH) * QPG_VQ_MAX_DOWN),
+                ("dec_res_pack", (c_void_p * QPG_VQ_MAX_DEPTH) * QPG_VQ_MAX_DOWN)]
 
 
 def declared_symbols():
@@ -145,8 +151,16 @@ def ptr(t):
 
 
 def call(name, device, *args):
-    """Invoke a C-ABI entry point on torch's current stream of `device`; raise on error."""
+    """Invoke a C-ABI entry point on torch's current stream of `device`; raise on error.
+
+    HIP launches go to the CURRENT device (a stream handle of 0 means "the current device's default stream"),
+    so when `device` is not the calling thread's current device the call is made under torch.cuda.device(device):
+    a GestureDB / VQVAE built on cuda:1 works whatever device the caller has selected."""
     lib = load()
+    idx = torch.device(device).index
+    if idx is not None and idx != torch.cuda.current_device():
+        with torch.cuda.device(idx):
+            return call(name, device, *args)
     stream = torch.cuda.current_stream(device).cuda_stream
     conv = [ptr(a) if isinstance(a, torch.Tensor) else (ctypes.byref(a) if isinstance(a, ctypes.Structure) else a)
             for a in args]

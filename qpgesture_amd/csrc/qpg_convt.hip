@@ -1,0 +1,384 @@
+// Transposed-formulation convolution kernels of the gesture VQ-VAE (round 2).
+//
+// The layer-per-launch kernel of qpg_vqvae.hip stages BOTH operands through LDS and spends its time around the
+// K loop (measured per layer, profiles/r02_encode_layers_before.md: dilated k3 layers 0.64-0.70 of the f32 matrix
+// rate, 1x1 layers 0.46-0.55 - prologue / epilogue bound).  Here every convolution is computed TRANSPOSED,
+//     yT[n][m] = sum_k  W^T[n][k] * xT[k][m]         (n = output channel, m = (batch, time) position),
+// with v_mfma_f32_16x16x4_f32 (A = 16 channels x 4 k, B = 4 k x 16 positions, exact f32 FMA chains):
+//   * a wave owns 16 positions and ALL output channels of its block: the activation operand is ONE float4 load
+//     per lane per 16 contraction steps, straight from the channels-last rows into registers (no LDS, no
+//     transposes); the weights - shared by the block's four waves - stream through LDS in 32 KB stages by LDS-DMA
+//     (global_load_lds) from a pre-packed image, one s_barrier per 128 MFMAs per wave;
+//   * the C/D layout of the MFMA (lane: column m = lane&15, rows n = 4*(lane>>4)+r) IS the B-operand layout of a
+//     following GEMM over those rows (lane group g supplies k = 16*tile + 4g + r for step r), so the hidden
+//     activation of a ResConv1DBlock (resnet.py:31-46:  x + conv1x1(relu(conv3_dil(relu(x)))))  never leaves the
+//     accumulator registers: the 1x1 convolution consumes them directly.  One launch per block, no hidden
+//     activation in memory, one epilogue instead of two.
+//
+// Weight image ("T-pack", built once by qpgesture_amd/vqvae.py):  Wt[nb][kb][g][nl][j] = W[k = 16 kb + 4 g + j]
+// [n = nb*NB + nl]  with k = tap*Cin_pad + ci:  a lane's ds_read_b128 yields its channel's four consecutive k,
+// 16 lanes of a group read 16 distinct 16-B bank slots (conflict-free), and a stage is one contiguous 32 KB run.
+#include "qpg_common.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+#define CT_ROWS 64              // positions per block: 4 waves x 16
+#define CT_STAGE_FLOATS 8192    // 32 KB of packed weights per pipeline stage
+#define CT_STAGE_BYTES 32768
+#define CT_RES_LDS (2 * CT_STAGE_BYTES + 4096)   // two stage slots + the two bias vectors
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// one 32 KB stage: 32 wave-instructions of 1 KB (lane-linear in LDS), 8 per wave
+__device__ __forceinline__ void ct_issue_stage(const float* src, unsigned char* slot, int w, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = i * 4 + w;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + p * 256 + lane * 4), (lds_ptr_t)(slot + p * 1024), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], 0.f, __builtin_inff());
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused ResConv1DBlock, width 512:  y = x + W2 . relu(W1 (*) relu(x) + b1) + b2      (resnet.py:31-46)
+// wpack: 96 stages of the k3 convolution (T-pack NB = 512: one 16-k block x 512 channels per stage) followed by
+// 32 stages of the 1x1 convolution (T-pack NB = 128: four 16-k blocks x 128 channels per stage, chunk-major).
+// ---------------------------------------------------------------------------------------------------------------
+struct ResArgs {
+  const float* x;       // [B][T][512]
+  const float* wpack;   // 128 stages x 32 KB
+  const float* b1;      // [512]
+  const float* b2;      // [512]
+  float* y;             // [B][T][512]
+  float* h;             // optional [B][T][512]: relu(conv3(relu(x)) + b1), what the training step records
+  int B, T, dil;
+  const float* zeros;
+};
+
+template <bool SAVE_H>
+__global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, ml = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t M = (int64_t)a.B * a.T;
+  const int64_t m = (int64_t)blockIdx.x * CT_ROWS + w * 16 + ml;
+  const bool live = m < M;
+  const int b = live ? (int)(m / a.T) : 0;
+  const int t = live ? (int)(m - (int64_t)b * a.T) : 0;
+  const float* xb = a.x + (int64_t)b * a.T * 512 + 4 * g;
+  auto rowptr = [&](int tap) -> const float* {
+    const int t_in = t + (tap - 1) * a.dil;
+    return (live && t_in >= 0 && t_in < a.T) ? xb + (int64_t)t_in * 512 : nullptr;
+  };
+
+  f32x4 acc1[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // biases -> LDS behind the two stage slots (read back as one ds_read_b128 per 16-channel tile)
+  float* bl = reinterpret_cast<float*>(lds + 2 * CT_STAGE_BYTES);
+  bl[tid] = a.b1[tid];
+  bl[256 + tid] = a.b1[256 + tid];
+  bl[512 + tid] = a.b2[tid];
+  bl[768 + tid] = a.b2[256 + tid];
+  ct_issue_stage(a.wpack, lds, w, lane);
+  const float* xp = rowptr(0);
+  int tap = 0, ci0 = 0;
+  f32x4 bnext = *reinterpret_cast<const f32x4*>(xp ? xp : a.zeros);
+
+  // ---- phase 1: hidden^T[512][16 positions per wave] over K = 3 taps x 512 channels, one 16-k block per stage
+  for (int it = 0; it < 96; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // stage `it` landed for every wave; every wave is done reading stage it-1
+    // The activation fragment loaded during the previous stage is consumed HERE, before this stage's loads are
+    // issued: hipcc waits vmcnt(0) at the first use of an ordinary load that has LDS-DMA behind it in the queue
+    // (the DMA issued below would be drained every stage otherwise).  The sched_barriers pin that order.
+    f32x4 bcur = relu4(bnext);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bcur[j]));     // opaque use: the compiler's wait lands here
+    __builtin_amdgcn_sched_barrier(0);
+    ct_issue_stage(a.wpack + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((it + 1) & 1) * CT_STAGE_BYTES, w, lane);
+    ci0 += 16;
+    if (ci0 == 512) {
+      ci0 = 0;
+      ++tap;
+      xp = rowptr(tap);      // tap == 3 after the last stage: unused
+    }
+    if (it + 1 < 96) bnext = *reinterpret_cast<const f32x4*>(xp ? xp + ci0 : a.zeros);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* S = lds + (it & 1) * CT_STAGE_BYTES + (g * 512 + ml) * 16;
+#pragma unroll
+    for (int grp = 0; grp < 8; ++grp) {
+      f32x4 a4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(S + (grp * 4 + q) * 256);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc1[grp * 4 + q] = mfma16(a4[q][j], bcur[j], acc1[grp * 4 + q]);
+    }
+  }
+  // hidden = relu(acc + b1): register r of tile nt is channel 16 nt + 4 g + r
+#pragma unroll
+  for (int nt = 0; nt < 32; ++nt) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bl + 16 * nt + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc1[nt][r] = fmaxf(acc1[nt][r] + bb[r], 0.f);
+    if (SAVE_H && live) *reinterpret_cast<f32x4*>(a.h + m * 512 + 16 * nt + 4 * g) = acc1[nt];
+  }
+
+  // ---- phase 2: y^T[128-channel chunk][16 positions] = W2^T . hidden^T, the B operand is acc1 itself
+  const float* xres = a.x + m * 512 + 4 * g;
+  float* yrow = a.y + m * 512 + 4 * g;
+  for (int c = 0; c < 4; ++c) {
+    f32x4 acc2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 res[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int it = 96 + c * 8 + s;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (it + 1 < 128)
+        ct_issue_stage(a.wpack + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((s + 1) & 1) * CT_STAGE_BYTES, w, lane);
+      if (s == 7) {   // residual + bias of this chunk: in flight under the last stage's MFMAs
+#pragma unroll
+        for (int t2 = 0; t2 < 8; ++t2)
+          res[t2] = *reinterpret_cast<const f32x4*>(live ? xres + 128 * c + 16 * t2 : a.zeros);
+      }
+      const unsigned char* S = lds + (s & 1) * CT_STAGE_BYTES + (g * 128 + ml) * 16;
+#pragma unroll
+      for (int kbl = 0; kbl < 4; ++kbl) {
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
+          f32x4 a4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            a4[q] = *reinterpret_cast<const f32x4*>(S + (kbl * 512 + (tg * 4 + q) * 16) * 16);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc2[tg * 4 + q] = mfma16(a4[q][j], acc1[4 * s + kbl][j], acc2[tg * 4 + q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 8; ++t2) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bl + 512 + 128 * c + 16 * t2 + 4 * g);
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = res[t2][r] + (acc2[t2][r] + bb[r]);
+      if (live) *reinterpret_cast<f32x4*>(yrow + 128 * c + 16 * t2) = o;
+    }
+  }
+}
+
+extern "C" int qpg_resblock_f32(qpg_ctx* ctx, void* stream, const float* x, int B, int T, int dil, const float* wpack,
+                                const float* b1, const float* b2, float* y, float* hidden) {
+  QPG_REQUIRE(ctx && x && wpack && b1 && b2 && y, "qpg_resblock_f32: null pointer");
+  QPG_REQUIRE(B >= 0 && T > 0 && dil > 0, "qpg_resblock_f32: bad size");
+  QPG_REQUIRE(x != y, "qpg_resblock_f32: in-place operation is not supported (rows are re-read as taps)");
+  if (B == 0) return QPG_OK;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_fused_f32_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, CT_RES_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_fused_f32_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, CT_RES_LDS) != hipSuccess) {
+      qpg_set_error("qpg_resblock_f32: cannot reserve %d bytes of LDS", CT_RES_LDS);
+      return QPG_EHIP;
+    }
+    attr_set = true;
+  }
+  ResArgs a;
+  a.x = x; a.wpack = wpack; a.b1 = b1; a.b2 = b2; a.y = y; a.h = hidden; a.B = B; a.T = T; a.dil = dil;
+  a.zeros = ctx->zeros;
+  const int64_t M = (int64_t)B * T;
+  const dim3 grid((unsigned)((M + CT_ROWS - 1) / CT_ROWS));
+  if (hidden) hipLaunchKernelGGL(resblock_fused_f32_kernel<true>, grid, dim3(256), CT_RES_LDS, qpg_stream(stream), a);
+  else hipLaunchKernelGGL(resblock_fused_f32_kernel<false>, grid, dim3(256), CT_RES_LDS, qpg_stream(stream), a);
+  QPG_LAUNCH_CHECK("resblock_fused_f32_kernel");
+  return QPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generic convolution, transposed formulation: a block = 64 positions x 128 output channels, stage = four 16-k
+// blocks x 128 channels (T-pack NB = 128).  Same argument meaning as qpg_conv1d_f32.
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvTArgs {
+  const float* x;      // [B][T_in][Cx] (Cx = row pitch in floats, multiple of 4; channels >= Cin_pad read as zero
+                       //                 only through zero WEIGHTS: the rows must hold Cin_pad readable floats)
+  const float* wt;     // T-pack NB=128: [Cout_pad/128][K/16][4][128][4]
+  const float* bias;   // [Cout_pad] or null
+  const float* res;    // indexed like y, or null
+  float* y;            // [B][T_y][Cout]
+  int B, T_in, Cx, Cin_pad, taps, in_stride, in_offset, dil;
+  int T_out, out_stride, out_offset, T_y, Cout, relu_in, relu_out;
+  int nstage;          // K / 64
+  const float* zeros;
+};
+
+__global__ __launch_bounds__(256, 2) void convt_f32_kernel(ConvTArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, ml = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t M = (int64_t)a.B * a.T_out;
+  const int64_t m = (int64_t)blockIdx.x * CT_ROWS + w * 16 + ml;
+  const int nb = blockIdx.y;
+  const bool live = m < M;
+  const int b = live ? (int)(m / a.T_out) : 0;
+  const int t = live ? (int)(m - (int64_t)b * a.T_out) : 0;
+  const float* xb = a.x + (int64_t)b * a.T_in * a.Cx + 4 * g;
+  auto rowptr = [&](int tap) -> const float* {
+    const int t_in = t * a.in_stride + a.in_offset + tap * a.dil;
+    return (live && t_in >= 0 && t_in < a.T_in && tap < a.taps) ? xb + (int64_t)t_in * a.Cx : nullptr;
+  };
+  const float* wsrc = a.wt + (int64_t)nb * a.nstage * CT_STAGE_FLOATS;
+
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // iterator over 16-k blocks: (tap, ci0)
+  int tap = 0, ci0 = 0;
+  const float* xp = rowptr(0);
+  auto next_b = [&]() -> f32x4 {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xp ? xp + ci0 : a.zeros);
+    ci0 += 16;
+    if (ci0 == a.Cin_pad) {
+      ci0 = 0;
+      ++tap;
+      xp = rowptr(tap);
+    }
+    return v;
+  };
+  ct_issue_stage(wsrc, lds, w, lane);
+  f32x4 bnext[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bnext[i] = next_b();
+
+  for (int it = 0; it < a.nstage; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4 bcur[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bcur[i] = a.relu_in ? relu4(bnext[i]) : bnext[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bcur[i][j]));     // an opaque use: the wait lands here
+    }
+    __builtin_amdgcn_sched_barrier(0);     // consume last stage's fragments before this stage's loads (see above)
+    if (it + 1 < a.nstage) {
+      ct_issue_stage(wsrc + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((it + 1) & 1) * CT_STAGE_BYTES, w, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bnext[i] = next_b();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* S = lds + (it & 1) * CT_STAGE_BYTES + (g * 128 + ml) * 16;
+#pragma unroll
+    for (int kbl = 0; kbl < 4; ++kbl) {
+#pragma unroll
+      for (int tg = 0; tg < 2; ++tg) {
+        f32x4 a4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(S + (kbl * 512 + (tg * 4 + q) * 16) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[tg * 4 + q] = mfma16(a4[q][j], bcur[kbl][j], acc[tg * 4 + q]);
+      }
+    }
+  }
+
+  if (!live) return;
+  const int64_t orow = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout;
+#pragma unroll
+  for (int t2 = 0; t2 < 8; ++t2) {
+    const int n = nb * 128 + 16 * t2 + 4 * g;
+    if (n >= a.Cout) continue;
+    f32x4 o = acc[t2];
+    if (a.bias) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] += bb[r];
+    }
+    if (a.relu_out) o = relu4(o);
+    if (n + 4 <= a.Cout && (a.Cout & 3) == 0) {
+      if (a.res) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + orow + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = rr[r] + o[r];
+      }
+      *reinterpret_cast<f32x4*>(a.y + orow + n) = o;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.Cout) a.y[orow + n + r] = a.res ? a.res[orow + n + r] + o[r] : o[r];
+    }
+  }
+}
+
+extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, int T_in, int Cx, const float* wt,
+                             const float* bias, int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride,
+                             int in_offset, int dil, int T_out, int out_stride, int out_offset, int T_y,
+                             const float* residual, int relu_in, int relu_out, float* y) {
+  QPG_REQUIRE(ctx && x && wt && y, "qpg_convt_f32: null pointer");
+  QPG_REQUIRE(B >= 0 && T_in > 0 && Cx > 0 && taps > 0 && Cout > 0 && T_out >= 0 && T_y > 0 && out_stride > 0 &&
+                  in_stride > 0 && dil > 0,
+              "qpg_convt_f32: bad size");
+  QPG_REQUIRE((Cx % 4) == 0 && Cx >= Cin_pad && (reinterpret_cast<uintptr_t>(x) % 16) == 0,
+              "qpg_convt_f32: input rows must be 16-byte aligned and hold Cin_pad floats (pad the channels first)");
+  QPG_REQUIRE(Cin_pad % 16 == 0 && (taps * Cin_pad) % 64 == 0 && Cout_pad % 128 == 0 && Cout_pad >= Cout,
+              "qpg_convt_f32: T-pack needs Cin_pad %% 16 == 0, taps*Cin_pad %% 64 == 0, Cout_pad %% 128 == 0");
+  if (B == 0 || T_out == 0) return QPG_OK;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(convt_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * CT_STAGE_BYTES) != hipSuccess) {
+      qpg_set_error("qpg_convt_f32: cannot reserve %d bytes of LDS", 2 * CT_STAGE_BYTES);
+      return QPG_EHIP;
+    }
+    attr_set = true;
+  }
+  ConvTArgs a;
+  a.x = x; a.wt = wt; a.bias = bias; a.res = residual; a.y = y;
+  a.B = B; a.T_in = T_in; a.Cx = Cx; a.Cin_pad = Cin_pad; a.taps = taps; a.in_stride = in_stride;
+  a.in_offset = in_offset; a.dil = dil; a.T_out = T_out; a.out_stride = out_stride; a.out_offset = out_offset;
+  a.T_y = T_y; a.Cout = Cout; a.relu_in = relu_in; a.relu_out = relu_out; a.nstage = taps * Cin_pad / 64;
+  a.zeros = ctx->zeros;
+  const int64_t M = (int64_t)B * T_out;
+  hipLaunchKernelGGL(convt_f32_kernel, dim3((unsigned)((M + CT_ROWS - 1) / CT_ROWS), (unsigned)(Cout_pad / 128)),
+                     dim3(256), 2 * CT_STAGE_BYTES, qpg_stream(stream), a);
+  QPG_LAUNCH_CHECK("convt_f32_kernel");
+  return QPG_OK;
+}
+
+// [R][C] -> [R][Cp] with zero fill (the 135-channel pose rows are 540 B: not 16-byte aligned per row)
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ x, int64_t R, int C, int Cp,
+                                                           float* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * Cp) return;
+  const int64_t r = i / Cp;
+  const int c = (int)(i - r * Cp);
+  y[i] = c < C ? x[r * C + c] : 0.f;
+}
+
+extern "C" int qpg_pad_channels_f32(qpg_ctx* ctx, void* stream, const float* x, int64_t R, int C, int Cp, float* y) {
+  QPG_REQUIRE(ctx && x && y && R >= 0 && C > 0 && Cp >= C, "qpg_pad_channels_f32: bad argument");
+  if (R == 0) return QPG_OK;
+  const int64_t n = R * Cp;
+  hipLaunchKernelGGL(pad_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, qpg_stream(stream), x, R, C,
+                     Cp, y);
+  QPG_LAUNCH_CHECK("pad_channels_kernel");
+  return QPG_OK;
+}

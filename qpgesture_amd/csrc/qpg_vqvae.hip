@@ -19,6 +19,8 @@
 // (ResConv1DBlock = x + conv1x1(relu(conv3_dil(relu(x)))), resnet.py:31-46).
 #include "qpg_common.h"
 
+void qpg_launch_sub_inplace(void* stream, float* a, const float* b, int64_t n);
+
 #define CV_BN 128
 #define CV_BK 16
 
@@ -497,6 +499,91 @@ static int resnet_run(qpg_ctx* ctx, void* stream, const qpg_conv_desc (*blocks)[
   return QPG_OK;
 }
 
+// ---- transposed-formulation path (csrc/qpg_convt.hip): taken when the descriptor carries the T-packed images ----
+extern "C" int qpg_convt_f32(qpg_ctx*, void*, const float*, int, int, int, const float*, const float*, int, int, int, int,
+                             int, int, int, int, int, int, int, const float*, int, int, float*);
+extern "C" int qpg_pad_channels_f32(qpg_ctx*, void*, const float*, int64_t, int, int, float*);
+extern "C" int qpg_resblock_f32(qpg_ctx*, void*, const float*, int, int, int, const float*, const float*, const float*,
+                                float*, float*);
+
+static bool tpath_ok(const qpg_vq_model* m, bool enc) {
+  if (m->width != 512 || m->emb != 512) return false;
+  for (int i = 0; i < m->down_t; ++i) {
+    if (enc ? !m->enc_down[i].wt : (!m->dec_up_even[i].wt || !m->dec_up_odd[i].wt)) return false;
+    for (int d = 0; d < m->depth; ++d) {
+      if (!(enc ? m->enc_res_pack[i][d] : m->dec_res_pack[i][d])) return false;
+      const qpg_conv_desc* r = enc ? m->enc_res[i][d] : m->dec_res[i][d];
+      if (!r[0].wt || !r[1].wt) return false;
+    }
+  }
+  return enc ? (m->enc_out.wt && m->kT.wt) : (m->dec_in.wt && m->dec_out.wt);
+}
+
+static int convt_call(qpg_ctx* ctx, void* stream, const qpg_conv_desc& c, const float* x, int Cx, int B, int T_in,
+                      int in_stride, int in_offset, int dil, int T_out, int out_stride, int out_offset, int T_y,
+                      const float* res, int relu_in, int relu_out, float* y) {
+  return qpg_convt_f32(ctx, stream, x, B, T_in, Cx, c.wt, c.b, c.taps, c.cin_pad, c.cout, c.cout_pad, in_stride,
+                       in_offset, dil, T_out, out_stride, out_offset, T_y, res, relu_in, relu_out, y);
+}
+
+// Resnet1D with the fused block kernel where a launch of 64-row tiles fills the chip, the two-launch form below that
+static int resnet_tpath(qpg_ctx* ctx, void* stream, const qpg_conv_desc (*blocks)[2], const float* const* packs, int depth,
+                        int growth, bool reverse, int B, int T, float*& cur, float*& alt, float* h) {
+  const int64_t tiles = ((int64_t)B * T + 63) / 64;
+  const bool fused = tiles * 4 >= (int64_t)ctx->n_cu * 3;
+  for (int d = 0; d < depth; ++d) {
+    const int dil = ipow(growth, reverse ? depth - 1 - d : d);
+    int rc;
+    if (fused) {
+      rc = qpg_resblock_f32(ctx, stream, cur, B, T, dil, packs[d], blocks[d][0].b, blocks[d][1].b, alt, nullptr);
+    } else {
+      rc = convt_call(ctx, stream, blocks[d][0], cur, 512, B, T, 1, -dil, dil, T, 1, 0, T, nullptr, 1, 1, h);
+      if (rc) return rc;
+      rc = convt_call(ctx, stream, blocks[d][1], h, 512, B, T, 1, 0, 1, T, 1, 0, T, cur, 0, 0, alt);
+    }
+    if (rc) return rc;
+    float* t = cur; cur = alt; alt = t;
+  }
+  return QPG_OK;
+}
+
+static int encode_tpath(qpg_ctx* ctx, void* stream, const qpg_vq_model* m, const float* x, int B, int T, float* cur,
+                        float* alt, float* h, int64_t* ids, float* latent, float* margin) {
+  // pose rows (135 floats = 540 B) -> 16-byte aligned rows of cin_pad floats
+  const int cp = m->enc_down[0].cin_pad;
+  int rc = qpg_pad_channels_f32(ctx, stream, x, (int64_t)B * T, m->in_dim, cp, h);
+  if (rc) return rc;
+  const float* in = h;
+  int Cx = cp, Tc = T;
+  for (int i = 0; i < m->down_t; ++i) {
+    const int To = Tc / 2;
+    rc = convt_call(ctx, stream, m->enc_down[i], in, Cx, B, Tc, 2, -1, 1, To, 1, 0, To, nullptr, 0, 0, alt);
+    if (rc) return rc;
+    { float* t = cur; cur = alt; alt = t; }
+    Tc = To;
+    rc = resnet_tpath(ctx, stream, m->enc_res[i], m->enc_res_pack[i], m->depth, m->growth, false, B, Tc, cur, alt, h);
+    if (rc) return rc;
+    in = cur;
+    Cx = 512;
+  }
+  float* z = latent ? latent : alt;
+  rc = convt_call(ctx, stream, m->enc_out, cur, 512, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, z);
+  if (rc) return rc;
+  const int64_t R = (int64_t)B * Tc;
+  QPG_REQUIRE(R < 0x7fffffffll, "qpg_vq_encode_f32: too many latent rows");
+  float* dot = h;
+  rc = convt_call(ctx, stream, m->kT, z, 512, 1, (int)R, 1, 0, 1, (int)R, 1, 0, (int)R, nullptr, 0, 0, dot);
+  if (rc) return rc;
+  float* dmin = margin ? cur : nullptr;
+  rc = qpg_vq_argmin_f32(ctx, stream, z, dot, m->kk, R, m->emb, m->bins, ids, dmin, margin);
+  if (rc) return rc;
+  if (margin) {
+    qpg_launch_sub_inplace(stream, margin, dmin, R);
+    QPG_LAUNCH_CHECK("sub_inplace_kernel");
+  }
+  return QPG_OK;
+}
+
 extern "C" int qpg_vq_encode_f32(qpg_ctx* ctx, void* stream, const qpg_vq_model* m, const float* x, int B, int T,
                                  float* ws, int64_t ws_floats, int64_t* ids, float* latent, float* margin) {
   QPG_REQUIRE(ctx && model_ok(m) && x && ws && ids, "qpg_vq_encode_f32: bad argument");
@@ -509,6 +596,7 @@ extern "C" int qpg_vq_encode_f32(qpg_ctx* ctx, void* stream, const qpg_vq_model*
   const int64_t slab = (((int64_t)B * T * cmax + 3) / 4) * 4;                          // T/2 rows suffice; keep simple
   float *cur = ws, *alt = ws + slab, *h = ws + 2 * slab;
   const SplitWs sw{ws + 3 * slab, ws_floats - 3 * slab};
+  if (tpath_ok(m, true)) return encode_tpath(ctx, stream, m, x, B, T, cur, alt, h, ids, latent, margin);
   const float* in = x;
   int Tc = T;
   for (int i = 0; i < m->down_t; ++i) {
@@ -534,7 +622,6 @@ extern "C" int qpg_vq_encode_f32(qpg_ctx* ctx, void* stream, const qpg_vq_model*
   rc = qpg_vq_argmin_f32(ctx, stream, z, dot, m->kk, R, m->emb, m->bins, ids, dmin, margin);
   if (rc) return rc;
   if (margin) {   // margin currently holds the runner-up distance: subtract the minimum in place
-    extern void qpg_launch_sub_inplace(void* stream, float* a, const float* b, int64_t n);
     qpg_launch_sub_inplace(stream, margin, dmin, R);
     QPG_LAUNCH_CHECK("sub_inplace_kernel");
   }

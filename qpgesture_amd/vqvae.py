@@ -32,6 +32,18 @@ def _pad(n, m):
     return (n + m - 1) // m * m
 
 
+def tpack(w_tap_ci_co, cin_pad, nb):
+    """T-pack of a convolution's weights for the transposed-formulation kernels (csrc/qpg_convt.hip):
+    out[n // nb][kb][g][n % nb][j] = W[k = 16 kb + 4 g + j][n],  k = tap * cin_pad + ci, zero padded
+    (a lane's 16-byte LDS read is its channel's four consecutive k; one pipeline stage is one contiguous run)."""
+    taps, cin, cout = w_tap_ci_co.shape
+    cout_pad = _pad(cout, nb)
+    W = torch.zeros((taps, cin_pad, cout_pad), dtype=torch.float32, device=w_tap_ci_co.device)
+    W[:, :cin, :cout] = w_tap_ci_co
+    K = taps * cin_pad
+    return W.view(K // 16, 4, 4, cout_pad // nb, nb).permute(3, 0, 1, 4, 2).contiguous().view(-1)
+
+
 class _Conv:
     """One packed convolution: weights [taps][Cin_pad][Cout_pad], bias [Cout_pad]."""
 
@@ -110,6 +122,7 @@ class VQVAE:
         self.kT = _Conv(k.t().contiguous()[None], torch.zeros(self.bins), dev)      # x.k^T as a 1-tap "conv"
         self.kk = torch.sum(k.t() ** 2, dim=0).to(dev).contiguous()                # bottleneck.py:123
         self._flatten_parameters()
+        self._tpack_all()
         self._desc = self._build_descriptor()
         # split-K scratch of the per-layer path (the whole-network calls carve theirs out of the workspace)
         self._split_ws = torch.empty((8 * 2048 * _pad(max(self.width, self.emb, self.bins), BN),), dtype=torch.float32,
@@ -157,6 +170,29 @@ class VQVAE:
                 o += n
         self._convs = convs
 
+    def _tpack_all(self):
+        """T-packed images of every convolution (inference kernels of csrc/qpg_convt.hip) and the fused
+        ResConv1DBlock images [k3 image NB=512 | 1x1 image NB=128].  They are copies: after a training step has
+        changed `self.param` call this again (encode()/decode() do so when `_tpack_stale` is set)."""
+        self._tpack_stale = False
+        self._tpack_on = self.width == 512 and self.emb == 512
+        if not self._tpack_on:
+            return
+        for c in self._convs + [self.kT]:
+            ok = (c.taps * c.cin_pad) % 64 == 0
+            c.wt = tpack(c.w[:, :c.cin, :c.cout], c.cin_pad, 128) if ok else None
+
+        def fused(res):
+            return [torch.cat((tpack(c3.w[:, :c3.cin, :c3.cout], c3.cin_pad, 512),
+                               tpack(c1.w[:, :c1.cin, :c1.cout], c1.cin_pad, 128))).contiguous() for c3, c1 in res]
+        self._enc_packs = [fused(res) for _, res in self.enc_down]
+        self._dec_packs = [fused(res) for res, _, _ in self.dec_up]
+
+    def _refresh_tpack(self):
+        if getattr(self, "_tpack_stale", False):
+            self._tpack_all()
+            self._desc = self._build_descriptor()
+
     def parameters(self):
         """(param, grad) flat buffers — what optim.Adam(model.parameters()) iterates in the reference (train.py:71)."""
         return self.param, self.grad
@@ -172,6 +208,13 @@ class VQVAE:
         def fill(d, c):
             d.w, d.b = c.w.data_ptr(), c.b.data_ptr()
             d.taps, d.cin, d.cin_pad, d.cout, d.cout_pad = c.taps, c.cin, c.cin_pad, c.cout, c.cout_pad
+            wt = getattr(c, "wt", None) if self._tpack_on else None
+            d.wt = wt.data_ptr() if wt is not None else None
+        if self._tpack_on:
+            for i in range(self.down_t):
+                for d in range(self.depth):
+                    m.enc_res_pack[i][d] = self._enc_packs[i][d].data_ptr()
+                    m.dec_res_pack[i][d] = self._dec_packs[i][d].data_ptr()
         for i, (c, res) in enumerate(self.enc_down):
             fill(m.enc_down[i], c)
             for d, (c3, c1) in enumerate(res):
@@ -203,6 +246,7 @@ class VQVAE:
     def encode_fused(self, x, return_latent=False, return_margin=False):
         """One C call for the whole encoder + quantiser (qpg_vq_encode_f32)."""
         assert self._loaded, "load_state_dict first"
+        self._refresh_tpack()
         x = x.to(self.device, torch.float32).contiguous()
         B, T, _ = x.shape
         L = T // self.hop
@@ -291,6 +335,7 @@ class VQVAE:
         The whole sequence is decoded in ONE convolutional pass like the reference
         (VisualizeCodebook.py:139-140): the dilated convolutions see across window seams."""
         assert self._loaded, "load_state_dict first"
+        self._refresh_tpack()
         outs = []
         for ids in torch.chunk(torch.as_tensor(zs[0]), bs_chunks, dim=0):
             ids = ids.to(self.device, torch.int64).contiguous()
@@ -323,6 +368,7 @@ class VQVAE:
 
     def _refresh_quantiser(self):
         """kT / kk follow k (after init_k or a checkpoint restore)."""
+        self._tpack_stale = True
         self.kT.w[0, :self.emb, :self.bins].copy_(self.k.t())
         self.kk.copy_(torch.sum(self.k.t() ** 2, dim=0))
 
@@ -366,6 +412,7 @@ class VQVAE:
         parallel.allreduce_sum_(belem)
         out = torch.empty((4,), dtype=torch.float32, device=self.device)
         ws = self._red_ws()
+        self._tpack_stale = True
         _lib.call("qpg_vq_ema_update_f32", self.device, self.k, self.k_sum, self.k_elem, bsum, belem, k_rand, self.mu,
                   self.threshold, self.bins, E, self.kT.w, self.kT.cout_pad, self.kk, ws, ws.numel(), out)
         return out
@@ -521,6 +568,7 @@ class VQVAE:
         d_x_out: optional replacement for the loss terms' own d loss / d x_out.
         sync_grads: data-parallel averaging of the gradients in two buckets — the decoder half is all-reduced while
         the encoder half is still being computed (backward produces the decoder's gradients first)."""
+        self._tpack_stale = True          # an optimiser step follows: the T-packed inference images go stale
         sv = self._saved
         assert sv is not None, "backward() needs a training-mode forward() first"
         B, T, L = sv["B"], sv["T"], sv["L"]

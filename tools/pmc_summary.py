@@ -1,14 +1,28 @@
-"""Summarise a rocprofv3 --pmc counter_collection.csv: mean per-dispatch counter value per kernel."""
-import csv, sys, collections, glob
+"""Summarise a rocprofv3 --pmc counter_collection.csv: mean per-dispatch counter value per (kernel, grid size),
+with the mean dispatch duration.  Usage: python tools/pmc_summary.py <dir> [name-filter]"""
+import collections
+import csv
+import glob
+import sys
+
 path = sys.argv[1]
-files = glob.glob(path + "/**/*counter_collection.csv", recursive=True)
+flt = sys.argv[2] if len(sys.argv) > 2 else ""
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in files:
+dur = collections.defaultdict(list)
+for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
     per = collections.defaultdict(float)
+    t = {}
     for r in csv.DictReader(open(f)):
-        per[(r["Dispatch_Id"], r["Kernel_Name"][:60], r["Counter_Name"])] += float(r["Counter_Value"])
+        k = (r["Kernel_Name"][:48], int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
+        per[(r["Dispatch_Id"], k, r["Counter_Name"])] += float(r["Counter_Value"])
+        t[(r["Dispatch_Id"], k)] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     for (d, k, c), v in per.items():
         acc[k][c].append(v)
-for k, cs in acc.items():
+    for (d, k), v in t.items():
+        dur[k].append(v)
+for k, cs in sorted(acc.items()):
+    if flt and flt not in k[0]:
+        continue
     n = max(len(v) for v in cs.values())
-    print("%-62s n=%d" % (k, n), " ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(cs.items())))
+    print("%-50s blocks=%-6d n=%-3d us=%.1f " % (k[0], k[1], n, sum(dur[k]) / len(dur[k])),
+          " ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(cs.items())))
