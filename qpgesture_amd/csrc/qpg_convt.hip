@@ -90,9 +90,12 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
   bl[512 + tid] = a.b2[tid];
   bl[768 + tid] = a.b2[256 + tid];
   ct_issue_stage(a.wpack, lds, w, lane);
-  const float* xp = rowptr(0);
-  int tap = 0, ci0 = 0;
-  f32x4 bnext = *reinterpret_cast<const f32x4*>(xp ? xp : a.zeros);
+  // the three tap rows of this lane's position (zero page where the tap falls outside the sequence); the stage
+  // loop below must stay ONE basic block (sched_group_barrier), so the tap switch is a select, not a branch
+  const float* xr0 = rowptr(0);
+  const float* xr1 = rowptr(1);
+  const float* xr2 = rowptr(2);
+  f32x4 bnext = *reinterpret_cast<const f32x4*>(xr0 ? xr0 : a.zeros);
 
   // ---- phase 1: hidden^T[512][16 positions per wave] over K = 3 taps x 512 channels, one 16-k block per stage
   for (int it = 0; it < 96; ++it) {
@@ -100,31 +103,51 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
     __builtin_amdgcn_s_barrier();       // stage `it` landed for every wave; every wave is done reading stage it-1
     // The activation fragment loaded during the previous stage is consumed HERE, before this stage's loads are
     // issued: hipcc waits vmcnt(0) at the first use of an ordinary load that has LDS-DMA behind it in the queue
-    // (the DMA issued below would be drained every stage otherwise).  The sched_barriers pin that order.
+    // (the DMA issued below would be drained every stage otherwise).
     f32x4 bcur = relu4(bnext);
 #pragma unroll
     for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bcur[j]));     // opaque use: the compiler's wait lands here
     __builtin_amdgcn_sched_barrier(0);
-    ct_issue_stage(a.wpack + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((it + 1) & 1) * CT_STAGE_BYTES, w, lane);
-    ci0 += 16;
-    if (ci0 == 512) {
-      ci0 = 0;
-      ++tap;
-      xp = rowptr(tap);      // tap == 3 after the last stage: unused
-    }
-    if (it + 1 < 96) bnext = *reinterpret_cast<const f32x4*>(xp ? xp + ci0 : a.zeros);
-    __builtin_amdgcn_sched_barrier(0);
     const unsigned char* S = lds + (it & 1) * CT_STAGE_BYTES + (g * 512 + ml) * 16;
+    f32x4 a4[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a4[0][q] = *reinterpret_cast<const f32x4*>(S + q * 256);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a4[1][q] = *reinterpret_cast<const f32x4*>(S + (4 + q) * 256);
+    ct_issue_stage(a.wpack + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((it + 1) & 1) * CT_STAGE_BYTES, w, lane);
+    {
+      const int nx = it + 1, ntap = nx >> 5, nci = (nx & 31) * 16;
+      const float* xp = ntap == 0 ? xr0 : (ntap == 1 ? xr1 : xr2);
+      bnext = *reinterpret_cast<const f32x4*>((xp && nx < 96) ? xp + nci : a.zeros);
+    }
 #pragma unroll
     for (int grp = 0; grp < 8; ++grp) {
-      f32x4 a4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(S + (grp * 4 + q) * 256);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc1[grp * 4 + q] = mfma16(a4[q][j], bcur[j], acc1[grp * 4 + q]);
+        for (int q = 0; q < 4; ++q) acc1[grp * 4 + q] = mfma16(a4[grp & 1][q][j], bcur[j], acc1[grp * 4 + q]);
+      if (grp + 2 < 8) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[grp & 1][q] = *reinterpret_cast<const f32x4*>(S + ((grp + 2) * 4 + q) * 256);
+      }
     }
+    // issue pattern: the first two groups' fragment reads, then the matrix pipe starts at once and the next stage's
+    // nine loads (8 LDS-DMA pieces + the activation fragment) go out one per MFMA underneath it; every later
+    // group's reads are issued a whole group (16 MFMAs = 512 cycles) ahead of their use
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+#pragma unroll
+    for (int grp = 1; grp < 7; ++grp) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // hidden = relu(acc + b1): register r of tile nt is channel 16 nt + 4 g + r
 #pragma unroll
@@ -135,50 +158,78 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
     if (SAVE_H && live) *reinterpret_cast<f32x4*>(a.h + m * 512 + 16 * nt + 4 * g) = acc1[nt];
   }
 
-  // ---- phase 2: y^T[128-channel chunk][16 positions] = W2^T . hidden^T, the B operand is acc1 itself
+  // ---- phase 2: y^T[128-channel chunk][16 positions] = W2^T . hidden^T, the B operand is acc1 itself.  The
+  // accumulators start from residual + bias, so the epilogue is the store alone.
   const float* xres = a.x + m * 512 + 4 * g;
   float* yrow = a.y + m * 512 + 4 * g;
   for (int c = 0; c < 4; ++c) {
     f32x4 acc2[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 res[8];
+    for (int t2 = 0; t2 < 8; ++t2) {
+      const f32x4 rr = *reinterpret_cast<const f32x4*>(live ? xres + 128 * c + 16 * t2 : a.zeros);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bl + 512 + 128 * c + 16 * t2 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc2[t2][r] = rr[r] + bb[r];
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int it = 96 + c * 8 + s;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (it + 1 < 128)
-        ct_issue_stage(a.wpack + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((s + 1) & 1) * CT_STAGE_BYTES, w, lane);
-      if (s == 7) {   // residual + bias of this chunk: in flight under the last stage's MFMAs
+      if (s == 0) {
 #pragma unroll
         for (int t2 = 0; t2 < 8; ++t2)
-          res[t2] = *reinterpret_cast<const f32x4*>(live ? xres + 128 * c + 16 * t2 : a.zeros);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(acc2[t2][r]));   // residual landed: wait here, not later
       }
+      __builtin_amdgcn_sched_barrier(0);
       const unsigned char* S = lds + (s & 1) * CT_STAGE_BYTES + (g * 128 + ml) * 16;
+      // group gi = (kbl, tg): fragment reads at S + (kbl*512 + (tg*4+q)*16)*16
+      f32x4 a4[2][4];
 #pragma unroll
-      for (int kbl = 0; kbl < 4; ++kbl) {
+      for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-          f32x4 a4[4];
+        for (int q = 0; q < 4; ++q)
+          a4[gi][q] = *reinterpret_cast<const f32x4*>(S + ((gi >> 1) * 512 + ((gi & 1) * 4 + q) * 16) * 16);
+      if (it + 1 < 128)
+        ct_issue_stage(a.wpack + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((s + 1) & 1) * CT_STAGE_BYTES, w, lane);
+#pragma unroll
+      for (int gi = 0; gi < 8; ++gi) {
+        const int kbl = gi >> 1, tg = gi & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            a4[q] = *reinterpret_cast<const f32x4*>(S + (kbl * 512 + (tg * 4 + q) * 16) * 16);
+            acc2[tg * 4 + q] = mfma16(a4[gi & 1][q][j], acc1[4 * s + kbl][j], acc2[tg * 4 + q]);
+        if (gi + 2 < 8) {
+          const int g2 = gi + 2;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc2[tg * 4 + q] = mfma16(a4[q][j], acc1[4 * s + kbl][j], acc2[tg * 4 + q]);
+          for (int q = 0; q < 4; ++q)
+            a4[gi & 1][q] = *reinterpret_cast<const f32x4*>(S + ((g2 >> 1) * 512 + ((g2 & 1) * 4 + q) * 16) * 16);
         }
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      if (it + 1 < 128) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
+#pragma unroll
+      for (int gi = 1; gi < 7; ++gi) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (live) {
 #pragma unroll
-    for (int t2 = 0; t2 < 8; ++t2) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(bl + 512 + 128 * c + 16 * t2 + 4 * g);
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = res[t2][r] + (acc2[t2][r] + bb[r]);
-      if (live) *reinterpret_cast<f32x4*>(yrow + 128 * c + 16 * t2) = o;
+      for (int t2 = 0; t2 < 8; ++t2) *reinterpret_cast<f32x4*>(yrow + 128 * c + 16 * t2) = acc2[t2];
     }
   }
 }
@@ -228,6 +279,7 @@ struct ConvTArgs {
   const float* zeros;
 };
 
+template <bool RELU_IN>
 __global__ __launch_bounds__(256, 2) void convt_f32_kernel(ConvTArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, ml = lane & 15, g = lane >> 4;
@@ -249,23 +301,29 @@ __global__ __launch_bounds__(256, 2) void convt_f32_kernel(ConvTArgs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // iterator over 16-k blocks: (tap, ci0)
+  // iterator over 16-k blocks: (tap, ci0), branch-free (the stage loop must stay ONE basic block for the issue
+  // pattern below): tap rows are base + tap*step, their validity one bit per tap in a lane mask
+  unsigned vmask = 0;
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp) vmask |= rowptr(tp) ? (1u << tp) : 0u;
+  const float* xrow0 = xb + (int64_t)(t * a.in_stride + a.in_offset) * a.Cx;
+  const int64_t tstep = (int64_t)a.dil * a.Cx;
   int tap = 0, ci0 = 0;
-  const float* xp = rowptr(0);
-  auto next_b = [&]() -> f32x4 {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(xp ? xp + ci0 : a.zeros);
+  auto next_b = [&](bool on) -> f32x4 {
+    const bool ok = ((vmask >> tap) & 1u) != 0 && on;
+    int64_t off = tap * tstep + ci0;
+    asm volatile("" : "+s"(off));       // keep the address arithmetic unconditional (no exec-masked region)
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? xrow0 + off : a.zeros);
     ci0 += 16;
-    if (ci0 == a.Cin_pad) {
-      ci0 = 0;
-      ++tap;
-      xp = rowptr(tap);
-    }
+    const int wrap = ci0 == a.Cin_pad ? 1 : 0;
+    ci0 = ci0 * (1 - wrap);
+    tap += wrap;
     return v;
   };
   ct_issue_stage(wsrc, lds, w, lane);
   f32x4 bnext[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) bnext[i] = next_b();
+  for (int i = 0; i < 4; ++i) bnext[i] = next_b(true);
 
   for (int it = 0; it < a.nstage; ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -273,32 +331,53 @@ __global__ __launch_bounds__(256, 2) void convt_f32_kernel(ConvTArgs a) {
     f32x4 bcur[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      bcur[i] = a.relu_in ? relu4(bnext[i]) : bnext[i];
+      bcur[i] = RELU_IN ? relu4(bnext[i]) : bnext[i];
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bcur[i][j]));     // an opaque use: the wait lands here
     }
-    __builtin_amdgcn_sched_barrier(0);     // consume last stage's fragments before this stage's loads (see above)
-    if (it + 1 < a.nstage) {
-      ct_issue_stage(wsrc + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((it + 1) & 1) * CT_STAGE_BYTES, w, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bnext[i] = next_b();
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);     // consume last stage's fragments before this stage's loads are issued
     const unsigned char* S = lds + (it & 1) * CT_STAGE_BYTES + (g * 128 + ml) * 16;
+    f32x4 a4[2][4];
 #pragma unroll
-    for (int kbl = 0; kbl < 4; ++kbl) {
+    for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
-      for (int tg = 0; tg < 2; ++tg) {
-        f32x4 a4[4];
+      for (int q = 0; q < 4; ++q)
+        a4[gi][q] = *reinterpret_cast<const f32x4*>(S + ((gi >> 1) * 512 + ((gi & 1) * 4 + q) * 16) * 16);
+    const bool more = it + 1 < a.nstage;
+    // past the last stage the DMA re-reads the last stage (never consumed): the issue pattern stays uniform
+    ct_issue_stage(wsrc + (int64_t)(more ? it + 1 : it) * CT_STAGE_FLOATS, lds + ((it + 1) & 1) * CT_STAGE_BYTES, w, lane);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(S + (kbl * 512 + (tg * 4 + q) * 16) * 16);
+    for (int i = 0; i < 4; ++i) bnext[i] = next_b(more);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int gi = 0; gi < 8; ++gi) {
+      const int kbl = gi >> 1, tg = gi & 1;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[tg * 4 + q] = mfma16(a4[q][j], bcur[kbl][j], acc[tg * 4 + q]);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[tg * 4 + q] = mfma16(a4[gi & 1][q][j], bcur[kbl][j], acc[tg * 4 + q]);
+      if (gi + 2 < 8) {
+        const int g2 = gi + 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          a4[gi & 1][q] = *reinterpret_cast<const f32x4*>(S + ((g2 >> 1) * 512 + ((g2 & 1) * 4 + q) * 16) * 16);
       }
     }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+    for (int gi = 1; gi < 7; ++gi) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the surplus DMA of the last stage must not outlive the block
 
   if (!live) return;
   const int64_t orow = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout;
@@ -333,9 +412,9 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
                              int in_offset, int dil, int T_out, int out_stride, int out_offset, int T_y,
                              const float* residual, int relu_in, int relu_out, float* y) {
   QPG_REQUIRE(ctx && x && wt && y, "qpg_convt_f32: null pointer");
-  QPG_REQUIRE(B >= 0 && T_in > 0 && Cx > 0 && taps > 0 && Cout > 0 && T_out >= 0 && T_y > 0 && out_stride > 0 &&
-                  in_stride > 0 && dil > 0,
-              "qpg_convt_f32: bad size");
+  QPG_REQUIRE(B >= 0 && T_in > 0 && Cx > 0 && taps > 0 && taps <= 4 && Cout > 0 && T_out >= 0 && T_y > 0 &&
+                  out_stride > 0 && in_stride > 0 && dil > 0,
+              "qpg_convt_f32: bad size (1..4 taps)");
   QPG_REQUIRE((Cx % 4) == 0 && Cx >= Cin_pad && (reinterpret_cast<uintptr_t>(x) % 16) == 0,
               "qpg_convt_f32: input rows must be 16-byte aligned and hold Cin_pad floats (pad the channels first)");
   QPG_REQUIRE(Cin_pad % 16 == 0 && (taps * Cin_pad) % 64 == 0 && Cout_pad % 128 == 0 && Cout_pad >= Cout,
@@ -343,8 +422,10 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
   if (B == 0 || T_out == 0) return QPG_OK;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(convt_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * CT_STAGE_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(convt_f32_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CT_STAGE_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(convt_f32_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CT_STAGE_BYTES) != hipSuccess) {
       qpg_set_error("qpg_convt_f32: cannot reserve %d bytes of LDS", 2 * CT_STAGE_BYTES);
       return QPG_EHIP;
     }
@@ -357,8 +438,9 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
   a.T_y = T_y; a.Cout = Cout; a.relu_in = relu_in; a.relu_out = relu_out; a.nstage = taps * Cin_pad / 64;
   a.zeros = ctx->zeros;
   const int64_t M = (int64_t)B * T_out;
-  hipLaunchKernelGGL(convt_f32_kernel, dim3((unsigned)((M + CT_ROWS - 1) / CT_ROWS), (unsigned)(Cout_pad / 128)),
-                     dim3(256), 2 * CT_STAGE_BYTES, qpg_stream(stream), a);
+  const dim3 grid((unsigned)((M + CT_ROWS - 1) / CT_ROWS), (unsigned)(Cout_pad / 128));
+  if (relu_in) hipLaunchKernelGGL(convt_f32_kernel<true>, grid, dim3(256), 2 * CT_STAGE_BYTES, qpg_stream(stream), a);
+  else hipLaunchKernelGGL(convt_f32_kernel<false>, grid, dim3(256), 2 * CT_STAGE_BYTES, qpg_stream(stream), a);
   QPG_LAUNCH_CHECK("convt_f32_kernel");
   return QPG_OK;
 }
