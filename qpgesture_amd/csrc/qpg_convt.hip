@@ -63,6 +63,17 @@ struct ResArgs {
   const float* zeros;
 };
 
+// ablation hooks (experiments/resblock_probe): -DQPG_RES_PROBE=<bits> compiles parts of the stage out; the product
+// build defines nothing.  1: no LDS-DMA after the prologue; 2: no wait / barrier; 4: no fragment reads after the first
+// two groups of a stage; 8: no activation-fragment loads.
+#ifndef QPG_RES_PROBE
+#define QPG_RES_PROBE 0
+#endif
+#define RP_DMA (!(QPG_RES_PROBE & 1))
+#define RP_BAR (!(QPG_RES_PROBE & 2))
+#define RP_LDS (!(QPG_RES_PROBE & 4))
+#define RP_FRAG (!(QPG_RES_PROBE & 8))
+
 template <bool SAVE_H>
 __global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -99,8 +110,10 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
 
   // ---- phase 1: hidden^T[512][16 positions per wave] over K = 3 taps x 512 channels, one 16-k block per stage
   for (int it = 0; it < 96; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();       // stage `it` landed for every wave; every wave is done reading stage it-1
+    if (RP_BAR) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();       // stage `it` landed for every wave; every wave is done reading stage it-1
+    }
     // The activation fragment loaded during the previous stage is consumed HERE, before this stage's loads are
     // issued: hipcc waits vmcnt(0) at the first use of an ordinary load that has LDS-DMA behind it in the queue
     // (the DMA issued below would be drained every stage otherwise).
@@ -114,8 +127,9 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
     for (int q = 0; q < 4; ++q) a4[0][q] = *reinterpret_cast<const f32x4*>(S + q * 256);
 #pragma unroll
     for (int q = 0; q < 4; ++q) a4[1][q] = *reinterpret_cast<const f32x4*>(S + (4 + q) * 256);
-    ct_issue_stage(a.wpack + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((it + 1) & 1) * CT_STAGE_BYTES, w, lane);
-    {
+    if (RP_DMA)
+      ct_issue_stage(a.wpack + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((it + 1) & 1) * CT_STAGE_BYTES, w, lane);
+    if (RP_FRAG) {
       const int nx = it + 1, ntap = nx >> 5, nci = (nx & 31) * 16;
       const float* xp = ntap == 0 ? xr0 : (ntap == 1 ? xr1 : xr2);
       bnext = *reinterpret_cast<const f32x4*>((xp && nx < 96) ? xp + nci : a.zeros);
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc1[grp * 4 + q] = mfma16(a4[grp & 1][q][j], bcur[j], acc1[grp * 4 + q]);
-      if (grp + 2 < 8) {
+      if (grp + 2 < 8 && RP_LDS) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) a4[grp & 1][q] = *reinterpret_cast<const f32x4*>(S + ((grp + 2) * 4 + q) * 256);
       }
@@ -174,8 +188,10 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int it = 96 + c * 8 + s;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (RP_BAR) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
       if (s == 0) {
 #pragma unroll
         for (int t2 = 0; t2 < 8; ++t2)
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           a4[gi][q] = *reinterpret_cast<const f32x4*>(S + ((gi >> 1) * 512 + ((gi & 1) * 4 + q) * 16) * 16);
-      if (it + 1 < 128)
+      if (it + 1 < 128 && RP_DMA)
         ct_issue_stage(a.wpack + (int64_t)(it + 1) * CT_STAGE_FLOATS, lds + ((s + 1) & 1) * CT_STAGE_BYTES, w, lane);
 #pragma unroll
       for (int gi = 0; gi < 8; ++gi) {
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_f32_kernel(ResArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             acc2[tg * 4 + q] = mfma16(a4[gi & 1][q][j], acc1[4 * s + kbl][j], acc2[tg * 4 + q]);
-        if (gi + 2 < 8) {
+        if (gi + 2 < 8 && RP_LDS) {
           const int g2 = gi + 2;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
