@@ -141,6 +141,18 @@ int qpg_percode_finalize_f64(qpg_ctx*, void* stream, const uint64_t* best_key, c
 int qpg_percode_finalize_f32(qpg_ctx*, void* stream, const uint64_t* packed, int Q, int K, float absent,
                              float* out_dist, int32_t* out_idx, int16_t* out_rank);
 
+/* One-launch form of resolve + finalize (the fast path since round 2): per query row the per-code minimum, its
+ * first-wins candidate (lowest index among equal distances == the strict `<` scan of GestureKNN.py:686-689, 717-720),
+ * `absent` / -1 for codes with no candidate, and optionally the stable ranks of the 512 minima.
+ * D: [dev] [Q][ldD] distances; cand_code: [dev] i16 [C] code of candidate c (values outside [0,K) are skipped);
+ * out_dist [Q][K], out_idx i32 [Q][K] = c + idx_base, out_rank i16 [Q][K] or NULL.  K <= 2048. */
+int qpg_percode_select_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int16_t* cand_code,
+                           int64_t C, int K, double absent, int32_t idx_base, double* out_dist, int32_t* out_idx,
+                           int16_t* out_rank);
+int qpg_percode_select_f32(qpg_ctx*, void* stream, const float* D, int64_t ldD, int Q, const int16_t* cand_code,
+                           int64_t C, int K, float absent, int32_t idx_base, float* out_dist, int32_t* out_idx,
+                           int16_t* out_rank);
+
 /* Stable ranks of each row: rank[q][c] = #{c' : d[c'] < d[c] or (d[c'] == d[c] and c' < c)}
  * (== np.argsort(kind='stable').argsort(); the reference calls the unstable default,
  * GestureKNN.py:553,574).  out: [dev] i16 [Q][K]. */

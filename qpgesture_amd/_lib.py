@@ -34,6 +34,8 @@ _SIGS = {
     "qpg_percode_resolve_f64": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P, P],
     "qpg_percode_finalize_f64": [P, P, I, I, c_double, P, P, P],
     "qpg_percode_finalize_f32": [P, I, I, c_float, P, P, P],
+    "qpg_percode_select_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P],
+    "qpg_percode_select_f32": [P, L, I, P, L, I, c_float, ctypes.c_int32, P, P, P],
     "qpg_percode_argmin_f64": [P, L, I, P, I, I, P, I, I, c_double, ctypes.c_int32, P, P],
     "qpg_percode_argmin_f32": [P, L, I, P, I, I, P, I, I, c_float, ctypes.c_int32, P, P],
     "qpg_rank_rows_f64": [P, I, I, P],

@@ -167,8 +167,9 @@ extern "C" int qpg_percode_resolve_f64(qpg_ctx* ctx, void* stream, const double*
                                        const int32_t* code, int code_ld, int N, const int32_t* cand_cidx, int G,
                                        int K, int32_t idx_base, uint64_t* best_key, uint32_t* best_idx) {
   QPG_REQUIRE(ctx && D && code && cand_cidx && best_key && best_idx, "qpg_percode_resolve_f64: null pointer");
-  QPG_REQUIRE(Q >= 0 && N >= 0 && G > 0 && K > 0 && K <= 4096 && code_ld > 0 && ldD >= (int64_t)N * G,
-              "qpg_percode_resolve_f64: bad size");
+  QPG_REQUIRE(Q >= 0 && N >= 0 && G > 0 && K > 0 && K <= 4096 && code_ld > 0 && ldD >= (int64_t)N * G &&
+                  (int64_t)N * G + (int64_t)idx_base < 0x7fffffffll,
+              "qpg_percode_resolve_f64: bad size (candidate indices must stay below 2^31)");
   if (Q == 0) return QPG_OK;
   hipStream_t st = qpg_stream(stream);
   {
@@ -220,8 +221,9 @@ extern "C" int qpg_percode_resolve_f32(qpg_ctx* ctx, void* stream, const float* 
                                        const int32_t* code, int code_ld, int N, const int32_t* cand_cidx, int G,
                                        int K, int32_t idx_base, uint64_t* packed) {
   QPG_REQUIRE(ctx && D && code && cand_cidx && packed, "qpg_percode_resolve_f32: null pointer");
-  QPG_REQUIRE(Q >= 0 && N >= 0 && G > 0 && K > 0 && K <= 4096 && code_ld > 0 && ldD >= (int64_t)N * G,
-              "qpg_percode_resolve_f32: bad size");
+  QPG_REQUIRE(Q >= 0 && N >= 0 && G > 0 && K > 0 && K <= 4096 && code_ld > 0 && ldD >= (int64_t)N * G &&
+                  (int64_t)N * G + (int64_t)idx_base < 0x7fffffffll,
+              "qpg_percode_resolve_f32: bad size (candidate indices must stay below 2^31)");
   if (Q == 0) return QPG_OK;
   hipStream_t st = qpg_stream(stream);
   {
@@ -305,6 +307,130 @@ extern "C" int qpg_percode_finalize_f32(qpg_ctx* ctx, void* stream, const uint64
                      out_rank);
   QPG_LAUNCH_CHECK("percode_finalize_kernel<f32>");
   return QPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-launch select (round 2): per query row, per-code minimum + first-wins index + distances + stable ranks in ONE
+// kernel, one 1024-thread block per query.  Replaces the chain fill_ff -> percode_min -> percode_resolve ->
+// percode_finalize (4 launches, 624 blocks doing ~320 k global 64-bit atomics per clip): the whole row (C candidates,
+// L2/MALL-resident: the sweep has just written it) is streamed by one block with 16-byte loads, the minima live in
+// LDS only, and the candidates' codes come from a precomputed int16 array (no division by the grid size, no double
+// indirection).  f64: two passes over the row (minimum of the ordered keys, then lowest index among the entries
+// equal to it == the reference's strict-`<` scan); f32: one pass on (key << 32 | index).
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename KeyT, bool PACKED>
+__global__ __launch_bounds__(1024) void percode_select_kernel(const T* __restrict__ D, int64_t ldD,
+                                                              const int16_t* __restrict__ cand_code, int64_t C, int K,
+                                                              T absent, int32_t idx_base, T* __restrict__ out_dist,
+                                                              int32_t* __restrict__ out_idx,
+                                                              int16_t* __restrict__ out_rank) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
+  unsigned int* besti = reinterpret_cast<unsigned int*>(smem + 8 * (size_t)K);
+  T* v = reinterpret_cast<T*>(smem + 12 * (size_t)K);
+  constexpr int VEC = 16 / sizeof(T);                      // elements per 16-byte load
+  typedef T vecT __attribute__((ext_vector_type(VEC)));
+  typedef int16_t vecC __attribute__((ext_vector_type(VEC)));
+  const int q = blockIdx.x;
+  const T* row = D + (int64_t)q * ldD;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    best[k] = ~0ull;
+    besti[k] = 0xffffffffu;
+  }
+  __syncthreads();
+  const bool vec_ok = (ldD % VEC) == 0 && (reinterpret_cast<uintptr_t>(D) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(cand_code) % (2 * VEC)) == 0;
+  const int64_t Cv = vec_ok ? (C / VEC) * VEC : 0;
+  for (int64_t c = (int64_t)threadIdx.x * VEC; c < Cv; c += (int64_t)blockDim.x * VEC) {
+    const vecT d = *reinterpret_cast<const vecT*>(row + c);
+    const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      if ((unsigned)cd[e] >= (unsigned)K) continue;
+      const unsigned long long key = PACKED ? (((unsigned long long)order_key(d[e]) << 32) | (unsigned int)(c + e + idx_base))
+                                            : (unsigned long long)order_key(d[e]);
+      atomicMin(&best[cd[e]], key);
+    }
+  }
+  for (int64_t c = Cv + threadIdx.x; c < C; c += blockDim.x) {
+    const int cd = cand_code[c];
+    if ((unsigned)cd >= (unsigned)K) continue;
+    const unsigned long long key = PACKED ? (((unsigned long long)order_key(row[c]) << 32) | (unsigned int)(c + idx_base))
+                                          : (unsigned long long)order_key(row[c]);
+    atomicMin(&best[cd], key);
+  }
+  __syncthreads();
+  if (!PACKED) {
+    for (int64_t c = (int64_t)threadIdx.x * VEC; c < Cv; c += (int64_t)blockDim.x * VEC) {
+      const vecT d = *reinterpret_cast<const vecT*>(row + c);
+      const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if ((unsigned)cd[e] < (unsigned)K && (unsigned long long)order_key(d[e]) == best[cd[e]])
+          atomicMin(&besti[cd[e]], (unsigned int)(c + e + idx_base));
+    }
+    for (int64_t c = Cv + threadIdx.x; c < C; c += blockDim.x) {
+      const int cd = cand_code[c];
+      if ((unsigned)cd < (unsigned)K && (unsigned long long)order_key(row[c]) == best[cd])
+        atomicMin(&besti[cd], (unsigned int)(c + idx_base));
+    }
+    __syncthreads();
+  }
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const unsigned long long kv = best[k];
+    const bool have = kv != ~0ull;
+    T d;
+    int32_t ix;
+    if (PACKED) {
+      d = have ? key_value((KeyT)(kv >> 32), T(0)) : absent;
+      ix = have ? (int32_t)(kv & 0xffffffffu) : -1;
+    } else {
+      d = have ? key_value((KeyT)kv, T(0)) : absent;
+      ix = have ? (int32_t)besti[k] : -1;
+    }
+    v[k] = d;
+    out_dist[(int64_t)q * K + k] = d;
+    out_idx[(int64_t)q * K + k] = ix;
+  }
+  if (!out_rank) return;
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const T x = v[k];
+    int r = 0;
+    for (int o = 0; o < K; ++o) {
+      const T y = v[o];
+      r += (y < x) || (y == x && o < k);
+    }
+    out_rank[(int64_t)q * K + k] = (int16_t)r;
+  }
+}
+
+template <typename T, typename KeyT, bool PACKED>
+static int percode_select(const char* name, qpg_ctx* ctx, void* stream, const T* D, int64_t ldD, int Q,
+                          const int16_t* cand_code, int64_t C, int K, T absent, int32_t idx_base, T* out_dist,
+                          int32_t* out_idx, int16_t* out_rank) {
+  QPG_REQUIRE(ctx && D && (cand_code || C == 0) && out_dist && out_idx, "%s: null pointer", name);
+  QPG_REQUIRE(Q >= 0 && C >= 0 && K > 0 && K <= 2048 && ldD >= C && C + (int64_t)idx_base < 0x7fffffffll,
+              "%s: bad size (K <= 2048, candidate indices must stay below 2^31)", name);
+  if (Q == 0) return QPG_OK;
+  const size_t sh = (size_t)K * (12 + sizeof(T));
+  hipLaunchKernelGGL((percode_select_kernel<T, KeyT, PACKED>), dim3(Q), dim3(1024), sh, qpg_stream(stream), D, ldD,
+                     cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank);
+  QPG_LAUNCH_CHECK(name);
+  return QPG_OK;
+}
+
+extern "C" int qpg_percode_select_f64(qpg_ctx* ctx, void* stream, const double* D, int64_t ldD, int Q,
+                                      const int16_t* cand_code, int64_t C, int K, double absent, int32_t idx_base,
+                                      double* out_dist, int32_t* out_idx, int16_t* out_rank) {
+  return percode_select<double, unsigned long long, false>("qpg_percode_select_f64", ctx, stream, D, ldD, Q, cand_code,
+                                                           C, K, absent, idx_base, out_dist, out_idx, out_rank);
+}
+extern "C" int qpg_percode_select_f32(qpg_ctx* ctx, void* stream, const float* D, int64_t ldD, int Q,
+                                      const int16_t* cand_code, int64_t C, int K, float absent, int32_t idx_base,
+                                      float* out_dist, int32_t* out_idx, int16_t* out_rank) {
+  return percode_select<float, unsigned int, true>("qpg_percode_select_f32", ctx, stream, D, ldD, Q, cand_code, C, K,
+                                                   absent, idx_base, out_dist, out_idx, out_rank);
 }
 
 // ---------------------------------------------------------------------------------------------
