@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — matched gesture frames/s of the GestureKNN hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): one 24 s query clip (M = 6 windows -> Q = 48 matching steps
+Default workload (BASELINE.json configs[1]): one 24 s query clip (M = 6 windows -> Q = 48 matching steps
 -> 1440 output frames at 60 fps) matched against a full speaker-10-class database of
 N_db = 2048 windows (synthetic, real schema: SURVEY.md §8d cfg-2), shipped flags
 (WavLM cosine f64 + text cosine f32 + phase gate).  A "step" is one complete pass of the hot
@@ -9,11 +9,18 @@ path for one clip per GPU: query packing, both candidate sweeps, per-code argmin
 device-side matching walk, ending with the (M,30) code indices on the host.  The database is
 already resident in HBM when the timed region starts.
 
-N > 1 (torch.distributed.run, one rank per GPU): the DB is row-sharded across the ranks, every
-rank sweeps ALL ranks' clips (one clip per rank) against its shard, the per-(query,code) minima
-are combined with an RCCL all-reduce(MIN) + index all-reduce, and each rank walks its own clip.
-Per-GPU work is constant in N (N clips x N_db/N rows)  ->  "scaling": "weak";
-value = frames of all N clips / max-over-ranks time.
+Modes
+  --scaling weak   (default) N ranks: N clips (one per rank) vs the DB row-sharded N ways; every rank sweeps all N clips
+                   against its shard, ONE all-to-all(min,index) leaves each rank with its own clip's tables.
+                   Per-GPU work is constant in N; value = frames of all N clips / max-over-ranks time.
+  --scaling strong (BASELINE.json configs[3]) ONE clip vs a speaker-1-class DB (--n-db 8192) row-sharded N ways, ONE
+                   all-gather(min,index) + local merge (the all-reduce(min+index) of the north star), replicated walk;
+                   value = 1440 frames / latency of that one clip; realtime_factor = 24 s / latency.
+  --clips C        (BASELINE.json configs[4]) C concurrent clips per GPU in one batched sweep (Q = 48 C), optionally
+                   with --encode-batch B pose windows encoded (VQ-VAE) inside the same timed step and
+                   --feature-dtype f16 (WavLM base stored in f16, widened in registers, same f64 arithmetic on the
+                   f16-rounded values).
+  --workload cfg3  (BASELINE.json configs[2]) synthetic 100 000 codes x 512-d, 1 000 queries, per-code min + argmin.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 2048 flop / 64 cycles / SIMD x 1024 SIMDs x 2.4 GHz
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2 / 16x16x4, 64 flop/clk/SIMD
 
 
 def chunked_db(n_db, lo, hi, seed, F=1024):
@@ -51,11 +59,18 @@ def chunked_db(n_db, lo, hi, seed, F=1024):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n-db", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n-db", type=int, default=None, help="DB windows (default 2048; 8192 with --scaling strong)")
     ap.add_argument("--windows", type=int, default=6)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--clips", type=int, default=1, help="concurrent clips per GPU in one batched sweep")
+    ap.add_argument("--encode-batch", type=int, default=0, help="pose windows VQ-VAE-encoded inside the timed step")
+    ap.add_argument("--feature-dtype", choices=["f32", "f16"], default="f32")
+    ap.add_argument("--workload", choices=["match", "cfg3"], default="match")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vqvae", action="store_true", help="skip the VQ-VAE legs")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold (H2D-inclusive) measurements")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="DB windows in the CPU baseline sample")
     ap.add_argument("--no-overlap", action="store_true", help="run the text sweep after the audio sweep (one stream)")
     ap.add_argument("--check", action="store_true", help="verify the matched codes against a 1-rank run")
@@ -73,17 +88,28 @@ def main():
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     # QPG_BENCH_ONE_GPU=1 (testing only): all ranks share cuda:0 and exchange through gloo, so that the
     # N>1 code path can be exercised on a 1-GPU box; the driver's runs use one GPU per rank over RCCL.
-    one_gpu = os.environ.get("QPG_BENCH_ONE_GPU") == "1"
+    # QPG_BENCH_ONE_GPU=nccl: the same, but over backend nccl (RCCL) if it accepts two ranks on one device.
+    one_gpu = os.environ.get("QPG_BENCH_ONE_GPU", "")
     dev = torch.device("cuda", 0 if one_gpu else local)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu:
+        if one_gpu == "1":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    N, M = a.n_db, a.windows
+    if a.workload == "cfg3":
+        out = cfg3_bench(a, dev, world, rank)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    strong = a.scaling == "strong"
+    N = a.n_db if a.n_db is not None else (8192 if strong else 2048)
+    M, CL = a.windows, a.clips
     per = (N + world - 1) // world
     lo, hi = min(rank * per, N), min((rank + 1) * per, N)
     code = synth.make_codes(N, 2)
@@ -93,24 +119,41 @@ def main():
     # GestureDB slices rows [lo,hi) of what it is given: hand it full-height views without the copies
     interp_full = _ShardView(interp_shard, lo, hi, N)
     ctx_full = _ShardView(ctx_shard, lo, hi, N)
-    db = GestureDB(code, interp_full, ctx_full, phase, sig, device=dev, rank=rank, world=world)
+    db = GestureDB(code, interp_full, ctx_full, phase, sig, device=dev, rank=rank, world=world,
+                   feature_dtype=a.feature_dtype)
     knn = CodeKNN(db, rng=np.random.RandomState(123456))
     knn.overlap_sweeps = not a.no_overlap
 
-    # one clip per rank; every rank holds all clips' windows (they are small: M*180*1024 f32 = 4.4 MB)
-    clips = [synth.make_db(M, 1000 + r) for r in range(world)]
+    # clips: weak = CL per rank (every rank holds all of them: M*180*1024 f32 = 4.4 MB each); strong = ONE clip in all
+    n_clips = CL if strong else CL * world
+    clips = [synth.make_db(M, 1000 + r) for r in range(n_clips)]
     te_interp = torch.from_numpy(np.concatenate([interp_wavlm(c["wavlm"]) for c in clips])).to(dev)
     te_ctx = torch.from_numpy(np.concatenate([c["context"].squeeze(2) for c in clips])).to(dev)
     seed_code, seed_phase = knn.init_code_phase()
     seed_phase_d = torch.from_numpy(seed_phase).to(dev)
+    enc = None
+    if a.encode_batch:
+        from qpgesture_amd.vqvae import VQVAE
+        enc = VQVAE(None, 135, device=dev).load_state_dict(synth.make_vqvae_state_dict(7))
+        enc_x = torch.randn((a.encode_batch, 240, 135), device=dev)
+        enc.encode(enc_x)
+
+    my_clips = CL                       # clips whose tables this rank ends up with (and walks)
 
     def step():
-        # N > 1: every rank sweeps all clips' queries against its DB shard; the per-(query, code) minima are exchanged
-        # with ONE all-to-all that leaves each rank with the final tables of its own clip only
-        T = knn.sweep_tables(te_interp, te_ctx, M * world, owner_blocks=world > 1)
-        out_codes, _, _, status = knn.walk(T, M, window_offset=0, seed_code=seed_code,
-                                           seed_phase=seed_phase_d, sync=False)
-        return out_codes.cpu()          # the step ends with the indices on the host (drop-in: np.savez)
+        # weak, N > 1: every rank sweeps all clips' queries against its DB shard; ONE all-to-all leaves each rank with
+        # the final tables of its own clips.  strong: ONE all-gather + merge, every rank holds the clip's tables.
+        if enc is not None:
+            ids = enc.encode(enc_x)[0]
+        T = knn.sweep_tables(te_interp, te_ctx, M * n_clips, owner_blocks=world > 1 and not strong)
+        outs = []
+        for c in range(my_clips):      # each clip is an independent chain (its own seed / window chaining)
+            oc, _, _, _ = knn.walk(T, M, window_offset=c * M, seed_code=seed_code, seed_phase=seed_phase_d, sync=False)
+            outs.append(oc)
+        res = (torch.cat(outs) if len(outs) > 1 else outs[0]).cpu()   # the step ends with the indices on the host
+        if enc is not None:
+            ids.cpu()
+        return res
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -135,53 +178,71 @@ def main():
     knn.kernel_events = None
     k_ms = float(np.mean(ms))
 
-    frames_per_step = 240 * M * world
+    frames_per_step = 240 * M * n_clips
     value = frames_per_step * a.steps / dt
 
     # ---- roofline of the dominant kernel (audio_cosine_f64_kernel), per launch on this rank --------------
-    Q = M * world * 8
+    Q = M * n_clips * 8
     C = db.n_local * db.Ga
+    fb = 2 if a.feature_dtype == "f16" else 4
     flops = 2.0 * Q * C * 6 * db.F                                  # 2*Q*N*26*6144
     achieved = flops / (k_ms * 1e-3) / 1e12
-    alg_bytes = db.n_local * 81 * db.F * 4 + C * 8 + Q * 6 * db.F * 8 + Q * C * 8
+    alg_bytes = db.n_local * 81 * db.F * fb + C * 8 + Q * 6 * db.F * 4 + Q * C * 8
+    default_shape = world == 1 and N == 2048 and M == 6 and CL == 1 and fb == 4
     roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4),
                 # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
-                # measured for exactly this launch shape only: profiles/r01_pmc_audio.md
-                "traffic": 925_000_000 if (world == 1 and N == 2048 and M == 6) else None,
+                # measured for exactly this launch shape only: profiles/r02_pmc_audio.md
+                "traffic": AUDIO_TRAFFIC_BYTES if default_shape else None,
                 "kernel": "audio_cosine_f64_kernel", "kernel_ms": round(k_ms, 4),
+                "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_launches_timed": len(ms),
                 "algorithmic_gflop": round(flops / 1e9, 3),
                 "algorithmic_bytes": int(alg_bytes),
                 "hbm_gbs_algorithmic": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1),
                 "hbm_frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
+    if strong:
+        par = ("db-row-shard x%d + all-gather(min,index) + local merge, replicated walk" % world) if world > 1 \
+            else "single GPU, unsharded DB"
+    else:
+        par = ("db-row-shard x%d + all-to-all(min,index)" % world) if world > 1 else "single GPU, unsharded DB"
     out = {"metric": "matched gesture frames/sec (GestureKNN)", "value": round(value, 1), "unit": "frames/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
-           "config": {"workload": "24 s clip (M=%d windows, Q=%d steps, %d frames) per GPU vs speaker-10-class DB "
-                                  "N_db=%d windows (%d candidates), shipped mode wavlm_feat(f64)+text(f32)+phase"
-                                  % (M, M * 8, 240 * M, N, N * 26),
-                      "n_db": N, "windows_per_clip": M, "clips": world,
-                      "parallelism": ("db-row-shard x%d + all-to-all(min,index)" % world) if world > 1
-                      else "single GPU, unsharded DB"},
+           "config": {"workload": "%d x 24 s clip%s (M=%d windows, Q=%d steps, %d frames each) %s vs speaker-%s-class DB "
+                                  "N_db=%d windows (%d candidates), shipped mode wavlm_feat(f64)+text(f32)+phase%s%s"
+                                  % (n_clips, "s" if n_clips > 1 else "", M, M * 8, 240 * M,
+                                     "in all" if strong else "per job", "1" if N >= 8192 else "10", N, N * 26,
+                                     ", WavLM base stored f16" if fb == 2 else "",
+                                     (", + VQ-VAE encode of %d pose windows in the step" % a.encode_batch)
+                                     if a.encode_batch else ""),
+                      "n_db": N, "windows_per_clip": M, "clips": n_clips, "clips_per_gpu": CL,
+                      "feature_dtype": a.feature_dtype, "encode_batch": a.encode_batch, "parallelism": par},
            "roofline": roofline,
-           "realtime_factor": round(value / 60.0 / world, 1)}
+           "realtime_factor": round(24.0 * M / 6 / (dt / a.steps), 1) if strong
+           else round(value / 60.0 / world, 1)}
 
-    out.update(vqvae_bench(dev, a, world, rank))
-
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if not a.no_vqvae:
+        out.update(vqvae_bench(dev, a, world, rank))
+    if rank == 0 and world == 1 and CL == 1 and not a.no_cold and fb == 4:
+        out["cold"] = cold_bench(dev, N, M)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and fb == 4:
         out["cpu_baseline"] = cpu_baseline(a, code, clips[0], M, N)
         out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
     if a.check:
-        # every rank re-matches ITS clip against the WHOLE database on its own (world=1 semantics) and must
-        # get the same codes as the sharded + all-reduced run above
+        # every rank re-matches ITS clips against the WHOLE database on its own (world=1 semantics) and must
+        # get the same codes as the sharded + exchanged run above
         full_i, full_c = chunked_db(N, 0, N, seed=0)
-        db1 = GestureDB(code, full_i, full_c, phase, sig, device=dev)
+        db1 = GestureDB(code, full_i, full_c, phase, sig, device=dev, feature_dtype=a.feature_dtype)
         k1 = CodeKNN(db1, rng=np.random.RandomState(123456))
-        T1 = k1.sweep_tables(te_interp[rank * M:(rank + 1) * M], te_ctx[rank * M:(rank + 1) * M], M)
-        want, _, _ = k1.walk(T1, M, 0, seed_code=seed_code, seed_phase=seed_phase_d)
-        ok = bool(np.array_equal(want, codes.numpy().astype(np.int64)))
+        first = 0 if strong else rank * CL
+        want = []
+        for c in range(my_clips):
+            w0 = (first + c) * M
+            T1 = k1.sweep_tables(te_interp[w0:w0 + M], te_ctx[w0:w0 + M], M)
+            want.append(k1.walk(T1, M, 0, seed_code=seed_code, seed_phase=seed_phase_d)[0])
+        ok = bool(np.array_equal(np.concatenate(want), codes.numpy().astype(np.int64)))
         out["check"] = ok
         assert ok, "rank %d: sharded result differs from the single-rank result" % rank
     if rank == 0:
@@ -190,12 +251,18 @@ def main():
         dist.destroy_process_group()
 
 
+# HBM bytes per audio_cosine_f64_kernel launch at the default shape (N_db=2048, Q=48), rocprofv3 PMC, separate
+# --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 correction on FETCH_SIZE: profiles/r02_pmc_audio.md
+AUDIO_TRAFFIC_BYTES = 925_000_000
+
+
 def vqvae_bench(dev, a, world, rank):
     """Second half of BASELINE.json's metric: gesture VQ-VAE encode (and decode) frames/s.  Each rank encodes
     its own batch of 256 pose windows (240 frames x 135: dataset_to_code over a speaker DB runs in such
-    batches) — pure data parallel, no collective — with the
-    full-size codebook.yml architecture and seeded weights; the decode leg decodes one 24 s clip's worth of
-    codes per rank in one pass (1440 frames)."""
+    batches) — pure data parallel, no collective — with the full-size codebook.yml architecture and seeded
+    weights; the decode leg decodes one 24 s clip's worth of codes per rank in one pass (1440 frames).
+    Timing: workspaces are allocated by the warm-up calls; 50 encode iterations, each bracketed by HIP events on the
+    launch stream (min / median reported) inside one wall-clocked loop (the frames/s figure)."""
     import torch
     import torch.distributed as dist
     from qpgesture_amd import synth
@@ -205,28 +272,47 @@ def vqvae_bench(dev, a, world, rank):
     x = torch.randn((Bw, 240, 135), device=dev)
     ids = torch.randint(0, 512, (1, 180), device=dev)
 
-    def timed(fn, iters):
-        for _ in range(2):
+    def timed(fn, iters, warm):
+        for _ in range(warm):
             fn()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
         t0 = time.perf_counter()
-        for _ in range(iters):
+        for e0, e1 in ev:
+            e0.record()
             fn()
+            e1.record()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt / iters
-    te = timed(lambda: model.encode(x), 10)
-    td = timed(lambda: model.decode([ids]), 10)
+        per = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+        return dt / iters, per[0], per[len(per) // 2]
+    te, te_min, te_med = timed(lambda: model.encode(x), 50, 8)
+    td, td_min, td_med = timed(lambda: model.decode([ids]), 50, 8)
     enc_flop = 1.639e9 * Bw                                        # 1.639 GFLOP per 240-frame window
+    dec_flop = 1.908e9 * 6                                         # 1.908 GFLOP per 240 output frames
+    res = {"vqvae_encode_frames_per_s": round(240 * Bw * world / te, 1),
+           "vqvae_encode_ms_per_batch256": round(te * 1e3, 3),
+           "vqvae_encode_tflops_f32": round(enc_flop / te / 1e12, 2),
+           # roofline of the encode leg: flops of SURVEY §8d over the HIP-event time of the whole launch sequence
+           # (19 kernels: csrc/qpg_convt.hip + the quantiser argmin) against the f32 matrix peak
+           "vqvae_roofline": {"bound": "mfma", "achieved": round(enc_flop / (te_med * 1e-3) / 1e12, 2),
+                              "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(enc_flop / (te_med * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                              "kernel": "resblock_fused_f32_kernel + convt_f32_kernel (encode, B=256)",
+                              "ms_median": round(te_med, 3), "ms_min": round(te_min, 3), "iters": 50,
+                              "algorithmic_gflop": round(enc_flop / 1e9, 1)},
+           "vqvae_decode_frames_per_s": round(1440 * world / td, 1),
+           "vqvae_decode_ms_per_24s_clip": round(td * 1e3, 3),
+           "vqvae_decode_ms_median": round(td_med, 3),
+           "vqvae_decode_tflops_f32": round(dec_flop / td / 1e12, 2)}
     # training step (codebook/train.py:120-131) at the reference's batch size of 256 windows per rank: forward with
     # EMA codebook update, backward, flat-gradient all-reduce (N > 1), Adam
-    from qpgesture_amd import parallel
     from qpgesture_amd.optim import Adam
     tm = VQVAE(dict(vel=1, acc=1), 135, device=dev).load_state_dict(synth.make_vqvae_state_dict(7)).train()
     opt = Adam(tm.parameters(), lr=3e-5, betas=(0.5, 0.999))
@@ -235,16 +321,65 @@ def vqvae_bench(dev, a, world, rank):
         tm(x)
         tm.backward(sync_grads=True)
         opt.step()
-    tt = timed(train_step, 5)
+    tt, _, _ = timed(train_step, 8, 3)
     train_flop = 3 * (1.639e9 + 1.908e9) * Bw                      # forward + data-gradient + weight-gradient GEMMs
-    return {"vqvae_train_windows_per_s": round(Bw * world / tt, 1),
-            "vqvae_train_ms_per_step_b256": round(tt * 1e3, 3),
-            "vqvae_train_tflops_f32": round(train_flop / tt / 1e12, 2),
-            "vqvae_encode_frames_per_s": round(240 * Bw * world / te, 1),
-            "vqvae_encode_ms_per_batch256": round(te * 1e3, 3),
-            "vqvae_encode_tflops_f32": round(enc_flop / te / 1e12, 2),
-            "vqvae_decode_frames_per_s": round(1440 * world / td, 1),
-            "vqvae_decode_ms_per_24s_clip": round(td * 1e3, 3)}
+    res.update({"vqvae_train_windows_per_s": round(Bw * world / tt, 1),
+                "vqvae_train_ms_per_step_b256": round(tt * 1e3, 3),
+                "vqvae_train_tflops_f32": round(train_flop / tt / 1e12, 2)})
+    return res
+
+
+def cold_bench(dev, N, M):
+    """SURVEY §8d 'report both cold and hot': (a) host arrays as load_db_codebook leaves them -> resident GestureDB
+    (chunked H2D of the raw (N,199,1024) WavLM track, device-side 199->180 resample, norms / packing / rank tables);
+    (b) one clip handed over as HOST arrays (raw WavLM + context, pageable memory) -> codes back on the host.
+    PCIe-inclusive figures: never `value`."""
+    import torch
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    from qpgesture_amd.data_processing import interp_wavlm_device
+    rng = np.random.default_rng(0)
+    wavlm = rng.standard_normal((N, 199, 1024), dtype=np.float32)
+    ctx = rng.standard_normal((N, 30, 384), dtype=np.float32)
+    phase = rng.standard_normal((N, 240, 4, 8), dtype=np.float32)
+    code, sig = synth.make_codes(N, 2), synth.make_signature(3)
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        interp = interp_wavlm_device(wavlm, dev)
+        db = GestureDB(code, interp, ctx, phase, sig, device=dev)
+        torch.cuda.synchronize(dev)
+        t = (time.perf_counter() - t0) * 1e3
+        best = t if best is None else min(best, t)
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    clip_w = rng.standard_normal((M, 199, 1024), dtype=np.float32)
+    clip_c = rng.standard_normal((M, 30, 384), dtype=np.float32)
+    sc, sp = knn.init_code_phase()
+    ts = []
+    for _ in range(5):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ti = interp_wavlm_device(clip_w, dev)
+        tc = torch.from_numpy(clip_c).to(dev)
+        knn.match_clip(ti, tc, M, seed_code=sc, seed_phase=sp)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    del db, interp
+    return {"db_build_ms": round(best, 1), "db_build_gbs_h2d_inclusive": round(wavlm.nbytes / best / 1e6, 1),
+            "clip_pcie_inclusive_ms": round(min(ts[1:]), 3),
+            "clip_pcie_inclusive_frames_per_s": round(240 * M / (min(ts[1:]) * 1e-3), 1),
+            "note": "host arrays (pageable) -> device: DB = raw (N,199,1024) WavLM track + context + phase; clip = raw "
+                    "WavLM + context in, (M,30) codes out"}
+
+
+def cfg3_bench(a, dev, world, rank):
+    """BASELINE.json configs[2] / SURVEY §8d cfg-3: DB X f32 (100 000, 512) ~N(0,1) seed 0, code ids uniform [0,512)
+    seed 1, validity mask Bernoulli(0.9) seed 2, queries (1000, 512) seed 3; per (query, code) min cosine distance +
+    argmin.  Runs the exact-f32 (sklearn-order) sweep with the per-code min fused into its epilogue: the Q x C
+    distance matrix never reaches HBM."""
+    import torch
+    from qpgesture_amd import cfg3
+    return cfg3.bench(a, dev, world, rank, HBM_PEAK_GBS)
 
 
 class _ShardView:
@@ -262,7 +397,8 @@ class _ShardView:
 def cpu_baseline(a, code, clip, M, N):
     """The oracle's C port of the two reference scans (bit-identical results, OpenMP over DB windows)
     on a bounded sample: the same 48 queries against the first `cpu_sample` DB windows; both scans
-    are linear in DB windows, so frames/s at full N_db = 1440 / (t * N_db/sample)."""
+    are linear in DB windows, so frames/s at full N_db = 1440 / (t * N_db/sample).
+    Three repeats, the fastest is reported (OpenMP on a few hundred cores is noisy)."""
     from oracle import cref, knn_oracle as O
     from qpgesture_amd.data_processing import interp_wavlm
     cref.build()
@@ -272,15 +408,19 @@ def cpu_baseline(a, code, clip, M, N):
     q = np.stack([O.wavlm_feat_rows(te, w, [24 * s])[0] for w in range(M) for s in range(8)])
     qt = np.stack([clip["context"].squeeze(2)[w][int(24 * s / 180 * 30)] for w in range(M) for s in range(8)])
     cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    cref.audio_scan(interp, np.arange(26) * 6, code[:ns], np.arange(26), q, n_threads=cores)
-    cref.text_scan(ctx, np.arange(26), code[:ns], np.arange(26), qt, n_threads=cores)
-    t = time.perf_counter() - t0
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        cref.audio_scan(interp, np.arange(26) * 6, code[:ns], np.arange(26), q, n_threads=cores)
+        cref.text_scan(ctx, np.arange(26), code[:ns], np.arange(26), qt, n_threads=cores)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts)
     full = t * N / ns
     return {"value": round(240 * M / full, 2), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "audio+text scans of the same %d queries vs the first %d of %d DB windows "
-                      "(%.2f s measured, scaled linearly to N_db); C port of the reference arithmetic "
-                      "(oracle/sweep_ref.c), OpenMP; matching walk excluded (<1%% of CPU time)" % (8 * M, ns, N, t),
+                      "(best of 3: %.2f s, all three %s; scaled linearly to N_db); C port of the reference arithmetic "
+                      "(oracle/sweep_ref.c), OpenMP; matching walk excluded (<1%% of CPU time)"
+                      % (8 * M, ns, N, t, ["%.2f" % x for x in ts]),
             "sample_seconds": round(t, 3)}
 
 

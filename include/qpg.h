@@ -62,6 +62,11 @@ int qpg_audio_cand_norm2(qpg_ctx*, void* stream, const double* fn2, int N, int T
  * (sklearn.preprocessing.normalize as used by paired_cosine_distances; zero rows stay zero).
  * x, out: [dev] f32 [rows][D]. */
 int qpg_l2_normalize_rows_f32(qpg_ctx*, void* stream, const float* x, int64_t rows, int D, float* out);
+/* The text queries of a clip, gathered and normalised in one launch: out[r] = normalise(x[q_win[r]][q_row[r]][:])
+ * (clip_context[int(i / n_db_frm * 30)] of window q_win[r], GestureKNN.py:549-551).  x: [dev] f32 [M][R][D];
+ * q_win, q_row: [dev] i32 [Q] (caller guarantees 0 <= q_win < M, 0 <= q_row < R); out: [dev] f32 [Q][D]. */
+int qpg_text_pack_queries_f32(qpg_ctx*, void* stream, const float* x, int M, int R, int D, const int32_t* q_win,
+                              const int32_t* q_row, int Q, float* out);
 
 /* ------------------------------------------------------------------------------------------
  * Candidate sweeps.  Replace CodeKNN.search_audio_cands(mode='wavlm_feat') and
@@ -145,13 +150,27 @@ int qpg_percode_finalize_f32(qpg_ctx*, void* stream, const uint64_t* packed, int
  * first-wins candidate (lowest index among equal distances == the strict `<` scan of GestureKNN.py:686-689, 717-720),
  * `absent` / -1 for codes with no candidate, and optionally the stable ranks of the 512 minima.
  * D: [dev] [Q][ldD] distances; cand_code: [dev] i16 [C] code of candidate c (values outside [0,K) are skipped);
- * out_dist [Q][K], out_idx i32 [Q][K] = c + idx_base, out_rank i16 [Q][K] or NULL.  K <= 2048. */
+ * out_dist [Q][K], out_idx i32 [Q][K] = c + idx_base, out_rank i16 [Q][K] or NULL.  K <= 2048.
+ * q_block > 0 (sharded database): the outputs are written in EXCHANGE layout - row q goes to row q % q_block of block
+ * q / q_block, blocks `block_stride` BYTES apart starting at out_dist / out_idx (one block per destination rank of the
+ * all-to-all, several arrays per block); out_rank must then be NULL (ranks are taken after the merge). */
 int qpg_percode_select_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int16_t* cand_code,
                            int64_t C, int K, double absent, int32_t idx_base, double* out_dist, int32_t* out_idx,
-                           int16_t* out_rank);
+                           int16_t* out_rank, int q_block, int64_t block_stride);
 int qpg_percode_select_f32(qpg_ctx*, void* stream, const float* D, int64_t ldD, int Q, const int16_t* cand_code,
                            int64_t C, int K, float absent, int32_t idx_base, float* out_dist, int32_t* out_idx,
-                           int16_t* out_rank);
+                           int16_t* out_rank, int q_block, int64_t block_stride);
+
+/* Cross-shard min + index merge after the RCCL exchange (the all-reduce(min, index) `north_star`
+ * names, as all-gather / all-to-all + this kernel): source w's tables start at recv + w*src_stride (+ dist_off for the
+ * [Q][K] distances, + idx_off for the [Q][K] i32 global candidate indices, -1 = absent in that shard).  Winner per
+ * (query, code): minimum distance, lowest index among equals.  out_rank (optional): stable ranks of the merged row. */
+int qpg_merge_select_f64(qpg_ctx*, void* stream, const void* recv, int W, int64_t src_stride, int64_t dist_off,
+                         int64_t idx_off, int Q, int K, double absent, double* out_dist, int32_t* out_idx,
+                         int16_t* out_rank);
+int qpg_merge_select_f32(qpg_ctx*, void* stream, const void* recv, int W, int64_t src_stride, int64_t dist_off,
+                         int64_t idx_off, int Q, int K, float absent, float* out_dist, int32_t* out_idx,
+                         int16_t* out_rank);
 
 /* Stable ranks of each row: rank[q][c] = #{c' : d[c'] < d[c] or (d[c'] == d[c] and c' < c)}
  * (== np.argsort(kind='stable').argsort(); the reference calls the unstable default,

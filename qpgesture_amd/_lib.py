@@ -26,6 +26,7 @@ _SIGS = {
     "qpg_frame_norm2_f64": [P, L, I, P],
     "qpg_audio_cand_norm2": [P, I, I, P, I, I, I, P],
     "qpg_l2_normalize_rows_f32": [P, L, I, P],
+    "qpg_text_pack_queries_f32": [P, I, I, I, P, P, I, P],
     "qpg_audio_pack_queries": [P, I, I, I, P, P, I, I, I, P, P],
     "qpg_audio_cosine_f64": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
@@ -34,8 +35,10 @@ _SIGS = {
     "qpg_percode_resolve_f64": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P, P],
     "qpg_percode_finalize_f64": [P, P, I, I, c_double, P, P, P],
     "qpg_percode_finalize_f32": [P, I, I, c_float, P, P, P],
-    "qpg_percode_select_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P],
-    "qpg_percode_select_f32": [P, L, I, P, L, I, c_float, ctypes.c_int32, P, P, P],
+    "qpg_percode_select_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L],
+    "qpg_percode_select_f32": [P, L, I, P, L, I, c_float, ctypes.c_int32, P, P, P, I, L],
+    "qpg_merge_select_f64": [P, I, L, L, L, I, I, c_double, P, P, P],
+    "qpg_merge_select_f32": [P, I, L, L, L, I, I, c_float, P, P, P],
     "qpg_percode_argmin_f64": [P, L, I, P, I, I, P, I, I, c_double, ctypes.c_int32, P, P],
     "qpg_percode_argmin_f32": [P, L, I, P, I, I, P, I, I, c_float, ctypes.c_int32, P, P],
     "qpg_rank_rows_f64": [P, I, I, P],

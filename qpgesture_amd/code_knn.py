@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .parallel import allreduce_min_index, alltoall_min_index, shard_rows
+from .parallel import allreduce_min_index, exchange_bytes, shard_rows
 import ctypes
 
 from .constant import (ABSENT_DIST, NUM_AUDIO_FEAT_FRAMES, STEP_SZ, WAVVQ_GROUP_SIZE, codebook_size, num_frames,
@@ -62,6 +62,35 @@ def _i32(x, dev):
     return torch.as_tensor(np.asarray(x, np.int32), device=dev)
 
 
+class ExchangeLayout:
+    """Byte layout of the (minimum, index) tables a rank contributes to the cross-shard exchange: `nblk` blocks (one
+    per destination rank for the owner-partitioned all-to-all, one in all for the all-gather) of `Qb` query rows,
+    each block = [aud_d f64 | aud_i i32 | txt_d f32 | txt_i i32] (the modalities in use), every array Qb*K entries.
+    The select kernels write straight into it (no packing pass); qpg_merge_select_* reads the received copy."""
+
+    def __init__(self, Qtot, K, nblk, parts, audio_f64, device):
+        assert Qtot % nblk == 0, "query rows must split evenly over the ranks"
+        self.Qb, self.K, self.nblk, self.parts = Qtot // nblk, K, nblk, list(parts)
+        n = self.Qb * K
+        self.off, o = {}, 0
+        for p in self.parts:
+            dsz = 8 if (p == "aud" and audio_f64) else 4
+            self.off[p + "_d"], o = o, o + n * dsz
+            self.off[p + "_i"], o = o, o + n * 4
+            o = (o + 7) // 8 * 8
+        self.block_bytes = o
+        self.dtype = {p: (torch.float64 if (p == "aud" and audio_f64) else torch.float32) for p in self.parts}
+        self.send = torch.empty((nblk * self.block_bytes,), dtype=torch.uint8, device=device)
+
+    def views(self, p):
+        """(dist, idx) tensors aliasing block 0's arrays of modality p + the select kernel's layout arguments."""
+        n = self.Qb * self.K
+        dsz = 8 if self.dtype[p] == torch.float64 else 4
+        d = self.send[self.off[p + "_d"]:self.off[p + "_d"] + n * dsz].view(self.dtype[p])
+        i = self.send[self.off[p + "_i"]:self.off[p + "_i"] + n * 4].view(torch.int32)
+        return d, i, (self.Qb if self.nblk > 1 else 0), (self.block_bytes if self.nblk > 1 else 0)
+
+
 class GestureDB:
     """A speaker database resident in HBM (what load_db_codebook + CodeKNN.__init__ build).
 
@@ -76,8 +105,11 @@ class GestureDB:
     """
 
     def __init__(self, code, wavlm_interp, context, phase_dense, signature, device="cuda:0",
-                 freq_rank=None, pos_rank=None, rank=0, world=1, wavvq=None):
+                 freq_rank=None, pos_rank=None, rank=0, world=1, wavvq=None, feature_dtype="f32"):
         dev = torch.device(device)
+        if feature_dtype not in ("f32", "f16"):
+            raise ValueError("feature_dtype must be 'f32' or 'f16'")
+        self.feature_dtype = feature_dtype
         if dev.type != "cuda":
             raise RuntimeError("GestureDB needs a HIP device (got %s); there is no CPU path" % dev)
         _lib.load()
@@ -105,6 +137,9 @@ class GestureDB:
         self.aud_cidx = _i32(cidx, dev)
         self.aud_pslot = _i32([phase_slot(k) for k in kint], dev)
         self.tap_stride = 2                                           # FRAME_INTERVAL-2, data_processing.py:266
+        # code of every local candidate c = j*G + g in scan order (i16): what the one-launch select kernels index
+        local = code[self.lo:self.hi]
+        self.aud_cand_code = self._cand_code(local, cidx, dev)
 
         # vq-wav2vec track (optional; the mode the paper describes): symbols g1*320+g2, float grid of 398/30
         self.has_wavvq = wavvq is not None
@@ -120,6 +155,7 @@ class GestureDB:
             self.vq_cidx = _i32(vc, dev)
             self.vq_pslot = _i32([phase_slot(k) for k in vk], dev)
             self.vq_taps = wavvq_tap_offsets(self.Tv)
+            self.vq_cand_code = self._cand_code(local, vc, dev)
 
         ks, rows = text_grid()
         self.txt_k, self.txt_rows_host = ks, rows
@@ -127,6 +163,7 @@ class GestureDB:
         self.txt_r = _i32(rows, dev)
         self.txt_cidx = self.txt_r
         self.txt_pslot = _i32([phase_slot(k) for k in ks], dev)
+        self.txt_cand_code = self._cand_code(local, rows, dev)
 
         # per-candidate squared norms (f64) without materialising the 6144-d windows
         fn2 = torch.empty((self.n_local, self.T), dtype=torch.float64, device=dev)
@@ -173,6 +210,12 @@ class GestureDB:
             self.freq_rank = self.freq_rank[0].contiguous()
         else:
             self.freq_rank = torch.as_tensor(np.asarray(freq_rank, np.int16), device=dev).contiguous()
+
+    @staticmethod
+    def _cand_code(code_local, cidx, dev):
+        cc = np.ascontiguousarray(code_local[:, np.asarray(cidx, np.int64)].reshape(-1))
+        cc = np.where((cc >= 0) & (cc < 32767), cc, -1).astype(np.int16)        # out-of-range ids are skipped
+        return torch.from_numpy(cc if cc.size else np.zeros((1,), np.int16)).to(dev)
 
     @property
     def idx_base(self):
@@ -229,7 +272,7 @@ class CodeKNN:
         return code, np.concatenate((P[:, 0], P[:, 1]), axis=1).astype(np.float32)
 
     # -- batched sweeps ------------------------------------------------------------------------
-    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None, want_rank=False, reduce=True):
+    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None, want_rank=False, reduce=True, out=None):
         """Per-code best audio candidate for every query: returns (dist f64 [Q,512], idx i32 [Q,512])
         with global candidate indices j*26+g (-1 = code absent), min-reduced across ranks; with
         want_rank also the stable ranks i16 [Q,512]."""
@@ -244,8 +287,6 @@ class CodeKNN:
                   NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2)
         C = db.n_local * db.Ga
         D = torch.empty((Q, max(C, 1)), dtype=torch.float64, device=dev)
-        key = torch.empty((Q, db.K), dtype=torch.int64, device=dev)      # u64 ordered-distance keys
-        bidx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)     # u32 candidate indices
         ev = getattr(self, "kernel_events", None)       # bench.py: HIP events around the dominant kernel
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -255,13 +296,16 @@ class CodeKNN:
         if ev is not None:
             e1.record(torch.cuda.current_stream(dev))
             ev.append((e0, e1))
-        _lib.call("qpg_percode_resolve_f64", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
-                  db.aud_cidx, db.Ga, db.K, db.idx_base * db.Ga, key, bidx)
-        dist = torch.empty((Q, db.K), dtype=torch.float64, device=dev)
-        idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+        if out is not None:          # exchange layout of the sharded path: written in place, merged after the collective
+            dist, idx, qb, bs = out
+        else:
+            dist = torch.empty((Q, db.K), dtype=torch.float64, device=dev)
+            idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+            qb = bs = 0
         fused_rank = want_rank and db.world == 1
         rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
-        _lib.call("qpg_percode_finalize_f64", dev, key, bidx, Q, db.K, float(ABSENT_DIST), dist, idx, rank)
+        _lib.call("qpg_percode_select_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K, float(ABSENT_DIST),
+                  db.idx_base * db.Ga, dist, idx, rank, qb, bs)
         self._last_D_aud = D
         if not reduce:              # sharded caller combines several tables in one exchange (sweep_tables)
             return dist, idx
@@ -270,23 +314,29 @@ class CodeKNN:
             return dist, idx, (rank if fused_rank else self.rank_rows(dist))
         return dist, idx
 
-    def sweep_text(self, queries, want_rank=False, reduce=True):
-        """queries: f32 [Q,384] on the device.  Returns (dist f32 [Q,512], idx i32 [Q,512][, rank])."""
+    def sweep_text(self, queries, want_rank=False, reduce=True, normalised=False, out=None):
+        """queries: f32 [Q,384] on the device (already sklearn-normalised if `normalised`).
+        Returns (dist f32 [Q,512], idx i32 [Q,512][, rank])."""
         db, dev = self.db, self.db.device
         Q = queries.shape[0]
-        qn = torch.empty_like(queries)
-        _lib.call("qpg_l2_normalize_rows_f32", dev, queries, Q, db.Dt, qn)
+        if normalised:
+            qn = queries
+        else:
+            qn = torch.empty_like(queries)
+            _lib.call("qpg_l2_normalize_rows_f32", dev, queries, Q, db.Dt, qn)
         D = torch.empty((Q, max(db.Ct, 1)), dtype=torch.float32, device=dev)
         _lib.call("qpg_text_cosine_f32", dev, db.ctxt, db.Ct, db.Dt, qn, Q, D, D.stride(0))
-        packed = torch.empty((Q, db.K), dtype=torch.int64, device=dev)   # u64 (ordered dist << 32 | index)
-        _lib.call("qpg_percode_resolve_f32", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
-                  db.txt_cidx, db.Gt, db.K, db.idx_base * db.Gt, packed)
         self._last_D_txt = D
-        dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
-        idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+        if out is not None:
+            dist, idx, qb, bs = out
+        else:
+            dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
+            idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+            qb = bs = 0
         fused_rank = want_rank and db.world == 1
         rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
-        _lib.call("qpg_percode_finalize_f32", dev, packed, Q, db.K, float(ABSENT_DIST), dist, idx, rank)
+        _lib.call("qpg_percode_select_f32", dev, D, D.stride(0), Q, db.txt_cand_code, db.Ct, db.K, float(ABSENT_DIST),
+                  db.idx_base * db.Gt, dist, idx, rank, qb, bs)
         if not reduce:              # sharded caller combines several tables in one exchange (sweep_tables)
             return dist, idx
         dist, idx = self._reduce_min(dist, idx)
@@ -294,7 +344,7 @@ class CodeKNN:
             return dist, idx, (rank if fused_rank else self.rank_rows(dist))
         return dist, idx
 
-    def sweep_audio_wavvq(self, test_wavvq, q_win, q_t, want_rank=False, reduce=True):
+    def sweep_audio_wavvq(self, test_wavvq, q_win, q_t, want_rank=False, reduce=True, out=None):
         """vq-wav2vec audio sweep: test_wavvq (M,398,2) ints (device tensor or array).  Distances are exact
         small integers (Levenshtein), returned as f32 [Q,512] with the winners' global candidate indices."""
         db, dev = self.db, self.db.device
@@ -306,14 +356,16 @@ class CodeKNN:
         taps = (ctypes.c_int32 * len(db.vq_taps))(*db.vq_taps)
         _lib.call("qpg_wavvq_lev_f32", dev, db.vq_sym, db.n_local, db.Tv, db.vq_t, db.Gv, taps, len(db.vq_taps),
                   sym_q, sym_q.shape[0], sym_q.shape[1], _i32(q_win, dev), _i32(q_t, dev), Q, D, D.stride(0))
-        packed = torch.empty((Q, db.K), dtype=torch.int64, device=dev)
-        _lib.call("qpg_percode_resolve_f32", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
-                  db.vq_cidx, db.Gv, db.K, db.idx_base * db.Gv, packed)
-        dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
-        idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+        if out is not None:
+            dist, idx, qb, bs = out
+        else:
+            dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
+            idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
+            qb = bs = 0
         fused_rank = want_rank and db.world == 1
         rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
-        _lib.call("qpg_percode_finalize_f32", dev, packed, Q, db.K, float(ABSENT_DIST), dist, idx, rank)
+        _lib.call("qpg_percode_select_f32", dev, D, D.stride(0), Q, db.vq_cand_code, C, db.K, float(ABSENT_DIST),
+                  db.idx_base * db.Gv, dist, idx, rank, qb, bs)
         self._last_D_aud = D
         if not reduce:              # sharded caller combines several tables in one exchange (sweep_tables)
             return dist, idx
@@ -444,14 +496,19 @@ class CodeKNN:
             qw = np.repeat(np.arange(M), steps)
             qt = np.tile(np.array([int(i) for i in pos]), M)                  # clip_test[int(i)]  (:559, :565)
             rows_ = [int(i / self.n_db_frm * 30) for i in pos] * M           # GestureKNN.py:549, 551
-            cache[M] = (_i32(qw, dev), _i32(qt, dev), torch.as_tensor(qw, device=dev),
-                        torch.as_tensor(np.asarray(rows_), device=dev))
-        q_win, q_t, gw, gr = cache[M]
+            cache[M] = (_i32(qw, dev), _i32(qt, dev), _i32(np.asarray(rows_), dev))
+        q_win, q_t, q_row = cache[M]
         T = dict(aud_d=None, aud_idx=None, aud_rank=None, txt_d=None, txt_idx=None, txt_rank=None)
         sharded = db.world > 1
+        lay = None
+        if sharded:
+            # per-shard tables go straight into the exchange buffer (ExchangeLayout); merged after ONE collective
+            parts = [p_ for p_, on in (("aud", mode in (MODE_AUD_TXT, MODE_AUD)), ("txt", mode in (MODE_AUD_TXT, MODE_TXT)))
+                     if on]
+            lay = ExchangeLayout(M * steps, db.K, db.world if owner_blocks else 1, parts, not self.use_wavvq, dev)
         # The two sweeps are independent until the walk and lean on different pipes (f64 matrix cores vs f32
         # VALU): with both modalities on, the text side runs on a second HIP stream underneath the audio sweep.
-        overlap = mode == MODE_AUD_TXT and self.overlap_sweeps and not torch.cuda.is_current_stream_capturing()
+        overlap = mode == MODE_AUD_TXT and self.overlap_sweeps
         main = torch.cuda.current_stream(dev)
         if overlap:
             side = self.__dict__.get("_side_stream")
@@ -460,8 +517,12 @@ class CodeKNN:
             side.wait_stream(main)
 
         def text_side():
-            qtxt = test_context[gw, gr].contiguous()
-            r = self.sweep_text(qtxt, want_rank=not sharded, reduce=not sharded)
+            # gather clip_context[int(i/n*30)] of every step + sklearn normalisation in one launch
+            tc = test_context.contiguous()
+            qn = torch.empty((M * steps, db.Dt), dtype=torch.float32, device=dev)
+            _lib.call("qpg_text_pack_queries_f32", dev, tc, tc.shape[0], tc.shape[1], db.Dt, q_win, q_row, M * steps, qn)
+            r = self.sweep_text(qn, want_rank=not sharded, reduce=not sharded, normalised=True,
+                                out=lay.views("txt") if sharded else None)
             T["txt_d"], T["txt_idx"] = r[0], r[1]
             if not sharded:
                 T["txt_rank"] = r[2]
@@ -470,15 +531,20 @@ class CodeKNN:
         # done when the audio sweep begins: measured 0.855 ms/clip, against 0.862 ms with the audio side first (the
         # text sweep then runs underneath the audio sweep and slows it by its own duration: the two kernels contend
         # for the same CUs rather than overlap) and 0.891 ms on a single stream.
-        if overlap:
+        audio_first = getattr(self, "audio_first", False)
+        if overlap and not audio_first:
             with torch.cuda.stream(side):
                 text_side()
         if mode in (MODE_AUD_TXT, MODE_AUD):
             fn = self.sweep_audio_wavvq if self.use_wavvq else self.sweep_audio
-            r = fn(test_interp, q_win, q_t, want_rank=not sharded, reduce=not sharded)
+            r = fn(test_interp, q_win, q_t, want_rank=not sharded, reduce=not sharded,
+                   out=lay.views("aud") if sharded else None)
             T["aud_d"], T["aud_idx"] = r[0], r[1]
             if not sharded:
                 T["aud_rank"] = r[2]
+        if overlap and audio_first:
+            with torch.cuda.stream(side):
+                text_side()
         if overlap:
             main.wait_stream(side)
             # The text tables are allocated on `side` and consumed on `main`.  No record_stream() (measured +15 us per
@@ -487,20 +553,18 @@ class CodeKNN:
         elif mode in (MODE_AUD_TXT, MODE_TXT):
             text_side()
         if sharded:
-            # ONE min+index exchange for both modalities: the f32 text minima are widened to f64 (exact) and ride
-            # in the same all-reduce(MIN) as the audio minima; one more all-reduce(MIN) for the candidate indices
-            parts = [k for k in ("aud", "txt") if T[k + "_d"] is not None]
-            dcat = torch.cat([T[k + "_d"].to(torch.float64) for k in parts], dim=1)
-            icat = torch.cat([T[k + "_idx"] for k in parts], dim=1)
-            if owner_blocks:
-                dcat, icat = alltoall_min_index(dcat, icat, db.world)
-            else:
-                dcat, icat = allreduce_min_index(dcat, icat)
-            for n_, k in enumerate(parts):
-                d = dcat[:, n_ * db.K:(n_ + 1) * db.K]
-                T[k + "_d"] = d.to(T[k + "_d"].dtype).contiguous()
-                T[k + "_idx"] = icat[:, n_ * db.K:(n_ + 1) * db.K].contiguous()
-                T[k + "_rank"] = self.rank_rows(T[k + "_d"])
+            # ONE collective for both modalities (all-to-all when every rank only needs its own clip's rows, all-gather
+            # otherwise), then one merge launch per modality: min distance, lowest global index among equals, ranks
+            recv = exchange_bytes(lay.send, db.world, owner_blocks)
+            src_stride = lay.block_bytes if owner_blocks else lay.send.numel()
+            for p_ in lay.parts:
+                f64 = lay.dtype[p_] == torch.float64
+                d = torch.empty((lay.Qb, db.K), dtype=lay.dtype[p_], device=dev)
+                ix = torch.empty((lay.Qb, db.K), dtype=torch.int32, device=dev)
+                rk = torch.empty((lay.Qb, db.K), dtype=torch.int16, device=dev)
+                _lib.call("qpg_merge_select_f64" if f64 else "qpg_merge_select_f32", dev, recv, db.world, src_stride,
+                          lay.off[p_ + "_d"], lay.off[p_ + "_i"], lay.Qb, db.K, float(ABSENT_DIST), d, ix, rk)
+                T[p_ + "_d"], T[p_ + "_idx"], T[p_ + "_rank"] = d, ix, rk
         return T
 
     def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True):
@@ -516,7 +580,7 @@ class CodeKNN:
         out_codes = torch.empty((M, num_frames_code), dtype=torch.int32, device=dev)
         out_phase = torch.empty((M, steps, 8, 16), dtype=torch.float32, device=dev)
         out_vote = torch.empty((M, steps), dtype=torch.int32, device=dev)
-        status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        status = torch.empty((1,), dtype=torch.int32, device=dev)        # always written by the walk kernels
         gate = torch.empty((3, M * steps, db.K), dtype=torch.int32, device=dev)
         q0 = window_offset * steps
 

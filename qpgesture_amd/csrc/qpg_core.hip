@@ -122,14 +122,19 @@ extern "C" int qpg_audio_cand_norm2(qpg_ctx* ctx, void* stream, const double* fn
 // independent, so a row is handled by 4 adjacent threads (one per einsum lane) and the horizontal
 // sum is two shuffles; every thread then divides its quarter of the row.
 // ---------------------------------------------------------------------------------------------
+// GATHER: row r is read from x[(win[r]*R + row[r])*D] (the text queries of a clip: clip_context[int(i/n*30)] of
+// window win[r], GestureKNN.py:549-551) instead of x[r*D].
+template <bool GATHER>
 __global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __restrict__ x, int64_t rows, int D,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out,
+                                                                const int32_t* __restrict__ win,
+                                                                const int32_t* __restrict__ row, int R) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t r = t >> 2;
   const int l = (int)(t & 3);
   const bool live = r < rows;
   if (!live) r = rows - 1;          // keep the whole aligned group of 4 in the shuffles
-  const float* p = x + r * D;
+  const float* p = GATHER ? x + ((int64_t)win[r] * R + row[r]) * D : x + r * D;
   float a = 0.f;
   const int nfull = D >> 4;
   for (int g = 0; g < nfull; ++g) {
@@ -157,9 +162,20 @@ __global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __r
 extern "C" int qpg_l2_normalize_rows_f32(qpg_ctx* ctx, void* stream, const float* x, int64_t rows, int D, float* out) {
   QPG_REQUIRE(ctx && x && out && rows >= 0 && D > 0, "qpg_l2_normalize_rows_f32: bad argument");
   if (rows == 0) return QPG_OK;
-  hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0,
-                     qpg_stream(stream), x, rows, D, out);
+  hipLaunchKernelGGL(l2_normalize_rows_kernel<false>, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0,
+                     qpg_stream(stream), x, rows, D, out, (const int32_t*)nullptr, (const int32_t*)nullptr, 0);
   QPG_LAUNCH_CHECK("l2_normalize_rows_kernel");
+  return QPG_OK;
+}
+
+extern "C" int qpg_text_pack_queries_f32(qpg_ctx* ctx, void* stream, const float* x, int M, int R, int D,
+                                         const int32_t* q_win, const int32_t* q_row, int Q, float* out) {
+  QPG_REQUIRE(ctx && x && q_win && q_row && out && M > 0 && R > 0 && D > 0 && Q >= 0,
+              "qpg_text_pack_queries_f32: bad argument");
+  if (Q == 0) return QPG_OK;
+  hipLaunchKernelGGL(l2_normalize_rows_kernel<true>, dim3((unsigned)(((int64_t)Q * 4 + 255) / 256)), dim3(256), 0,
+                     qpg_stream(stream), x, (int64_t)Q, D, out, q_win, q_row, R);
+  QPG_LAUNCH_CHECK("l2_normalize_rows_kernel<gather>");
   return QPG_OK;
 }
 

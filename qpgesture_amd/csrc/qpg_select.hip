@@ -323,7 +323,8 @@ __global__ __launch_bounds__(1024) void percode_select_kernel(const T* __restric
                                                               const int16_t* __restrict__ cand_code, int64_t C, int K,
                                                               T absent, int32_t idx_base, T* __restrict__ out_dist,
                                                               int32_t* __restrict__ out_idx,
-                                                              int16_t* __restrict__ out_rank) {
+                                                              int16_t* __restrict__ out_rank, int q_block,
+                                                              int64_t block_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
   unsigned int* besti = reinterpret_cast<unsigned int*>(smem + 8 * (size_t)K);
@@ -332,6 +333,14 @@ __global__ __launch_bounds__(1024) void percode_select_kernel(const T* __restric
   typedef T vecT __attribute__((ext_vector_type(VEC)));
   typedef int16_t vecC __attribute__((ext_vector_type(VEC)));
   const int q = blockIdx.x;
+  // exchange layout (sharded DB): row q lives in block q / q_block of a byte buffer whose blocks are block_stride
+  // bytes apart (one block per destination rank, several arrays per block); q_block == 0: plain [Q][K] tables
+  if (q_block > 0) {
+    const int64_t shift = (int64_t)(q / q_block) * block_stride;
+    const int64_t rowoff = (int64_t)(q % q_block) * K - (int64_t)q * K;
+    out_dist = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(out_dist) + shift) + rowoff;
+    out_idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(out_idx) + shift) + rowoff;
+  }
   const T* row = D + (int64_t)q * ldD;
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     best[k] = ~0ull;
@@ -408,29 +417,109 @@ __global__ __launch_bounds__(1024) void percode_select_kernel(const T* __restric
 template <typename T, typename KeyT, bool PACKED>
 static int percode_select(const char* name, qpg_ctx* ctx, void* stream, const T* D, int64_t ldD, int Q,
                           const int16_t* cand_code, int64_t C, int K, T absent, int32_t idx_base, T* out_dist,
-                          int32_t* out_idx, int16_t* out_rank) {
+                          int32_t* out_idx, int16_t* out_rank, int q_block, int64_t block_stride) {
   QPG_REQUIRE(ctx && D && (cand_code || C == 0) && out_dist && out_idx, "%s: null pointer", name);
   QPG_REQUIRE(Q >= 0 && C >= 0 && K > 0 && K <= 2048 && ldD >= C && C + (int64_t)idx_base < 0x7fffffffll,
               "%s: bad size (K <= 2048, candidate indices must stay below 2^31)", name);
+  QPG_REQUIRE(q_block >= 0 && (q_block == 0 || (!out_rank && Q % q_block == 0 && block_stride % 8 == 0)),
+              "%s: block layout needs Q %% q_block == 0, an 8-byte multiple stride and no rank output", name);
   if (Q == 0) return QPG_OK;
   const size_t sh = (size_t)K * (12 + sizeof(T));
   hipLaunchKernelGGL((percode_select_kernel<T, KeyT, PACKED>), dim3(Q), dim3(1024), sh, qpg_stream(stream), D, ldD,
-                     cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank);
+                     cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block, block_stride);
   QPG_LAUNCH_CHECK(name);
   return QPG_OK;
 }
 
 extern "C" int qpg_percode_select_f64(qpg_ctx* ctx, void* stream, const double* D, int64_t ldD, int Q,
                                       const int16_t* cand_code, int64_t C, int K, double absent, int32_t idx_base,
-                                      double* out_dist, int32_t* out_idx, int16_t* out_rank) {
+                                      double* out_dist, int32_t* out_idx, int16_t* out_rank, int q_block,
+                                      int64_t block_stride) {
   return percode_select<double, unsigned long long, false>("qpg_percode_select_f64", ctx, stream, D, ldD, Q, cand_code,
-                                                           C, K, absent, idx_base, out_dist, out_idx, out_rank);
+                                                           C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block,
+                                                           block_stride);
 }
 extern "C" int qpg_percode_select_f32(qpg_ctx* ctx, void* stream, const float* D, int64_t ldD, int Q,
                                       const int16_t* cand_code, int64_t C, int K, float absent, int32_t idx_base,
-                                      float* out_dist, int32_t* out_idx, int16_t* out_rank) {
+                                      float* out_dist, int32_t* out_idx, int16_t* out_rank, int q_block,
+                                      int64_t block_stride) {
   return percode_select<float, unsigned int, true>("qpg_percode_select_f32", ctx, stream, D, ldD, Q, cand_code, C, K,
-                                                   absent, idx_base, out_dist, out_idx, out_rank);
+                                                   absent, idx_base, out_dist, out_idx, out_rank, q_block, block_stride);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-shard merge (the reduction is an associative min-with-index per (query, code)): after the
+// exchange (RCCL all-gather or all-to-all of the ranks' byte buffers) row q's W candidate (distance, index) pairs
+// sit W blocks apart; the winner is the minimum distance and, among equal distances, the lowest GLOBAL candidate
+// index (shards are ascending row blocks, so that is the reference's first-wins scan); -1 marks "code absent in
+// that shard".  One block per query row; the stable ranks of the merged row are produced in the same launch.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void merge_select_kernel(const unsigned char* __restrict__ recv, int W,
+                                                           int64_t src_stride, int64_t dist_off, int64_t idx_off, int K,
+                                                           T absent, T* __restrict__ out_dist,
+                                                           int32_t* __restrict__ out_idx,
+                                                           int16_t* __restrict__ out_rank) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* v = reinterpret_cast<T*>(smem);
+  const int q = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    T bd = absent;
+    int32_t bi = -1;
+    for (int w = 0; w < W; ++w) {
+      const unsigned char* src = recv + (int64_t)w * src_stride;
+      const T d = reinterpret_cast<const T*>(src + dist_off)[(int64_t)q * K + k];
+      const int32_t i = reinterpret_cast<const int32_t*>(src + idx_off)[(int64_t)q * K + k];
+      if (i < 0) continue;
+      if (bi < 0 || d < bd || (d == bd && i < bi)) {
+        bd = d;
+        bi = i;
+      }
+    }
+    v[k] = bd;
+    out_dist[(int64_t)q * K + k] = bd;
+    out_idx[(int64_t)q * K + k] = bi;
+  }
+  if (!out_rank) return;
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const T x = v[k];
+    int r = 0;
+    for (int o = 0; o < K; ++o) {
+      const T y = v[o];
+      r += (y < x) || (y == x && o < k);
+    }
+    out_rank[(int64_t)q * K + k] = (int16_t)r;
+  }
+}
+
+template <typename T>
+static int merge_select(const char* name, qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
+                        int64_t dist_off, int64_t idx_off, int Q, int K, T absent, T* out_dist, int32_t* out_idx,
+                        int16_t* out_rank) {
+  QPG_REQUIRE(ctx && recv && out_dist && out_idx, "%s: null pointer", name);
+  QPG_REQUIRE(W > 0 && Q >= 0 && K > 0 && K <= 8192 && src_stride >= 0 && dist_off >= 0 && idx_off >= 0 &&
+                  dist_off % (int64_t)sizeof(T) == 0 && idx_off % 4 == 0 && src_stride % 8 == 0,
+              "%s: bad size / alignment", name);
+  if (Q == 0) return QPG_OK;
+  hipLaunchKernelGGL((merge_select_kernel<T>), dim3(Q), dim3(512), sizeof(T) * (size_t)K, qpg_stream(stream),
+                     static_cast<const unsigned char*>(recv), W, src_stride, dist_off, idx_off, K, absent, out_dist,
+                     out_idx, out_rank);
+  QPG_LAUNCH_CHECK(name);
+  return QPG_OK;
+}
+
+extern "C" int qpg_merge_select_f64(qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
+                                    int64_t dist_off, int64_t idx_off, int Q, int K, double absent, double* out_dist,
+                                    int32_t* out_idx, int16_t* out_rank) {
+  return merge_select<double>("qpg_merge_select_f64", ctx, stream, recv, W, src_stride, dist_off, idx_off, Q, K, absent,
+                              out_dist, out_idx, out_rank);
+}
+extern "C" int qpg_merge_select_f32(qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
+                                    int64_t dist_off, int64_t idx_off, int Q, int K, float absent, float* out_dist,
+                                    int32_t* out_idx, int16_t* out_rank) {
+  return merge_select<float>("qpg_merge_select_f32", ctx, stream, recv, W, src_stride, dist_off, idx_off, Q, K, absent,
+                             out_dist, out_idx, out_rank);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -2,8 +2,10 @@
 contiguous row blocks, one per rank (one process per GPU, torch.distributed over RCCL/xGMI); each
 rank sweeps its block and the per-(query, code) minima are combined with a min + index exchange.
 
-The message is tiny (Q*512*(8+4) B = 295 KB for a 24 s clip), so the exchange is latency- not
-link-bound: two all-reduces on the packed tables, no per-candidate traffic."""
+The message is tiny (Q*512*20 B = 492 KB per 24 s clip for both modalities), so the exchange is latency- not
+link-bound: ONE collective on a byte buffer of packed tables (exchange_bytes) and one HIP merge kernel per modality
+(qpg_merge_select_*), no per-candidate traffic.  allreduce_min_index / alltoall_min_index are the round-1 ATen forms,
+kept as host-tensor references for the CPU (gloo) tests."""
 import torch
 
 INT_MAX = 2 ** 31 - 1
@@ -54,6 +56,44 @@ def alltoall_min_index(dist, idx, world, group=None):
     ibest = cand.min(dim=0).values
     ibest = torch.where(ibest == big, torch.full_like(ibest, -1.0), ibest)
     return best.contiguous(), ibest.to(torch.int32).contiguous()
+
+
+def exchange_bytes(send, world, owner_blocks, group=None):
+    """The one collective of the sharded matcher.  `send` is this rank's byte buffer of per-shard (minimum, index)
+    tables in exchange layout (code_knn.ExchangeLayout).  owner_blocks: the buffer is `world` equal blocks, block r
+    goes to rank r (ONE all-to-all; every rank ends up with the `world` shards' tables of ITS query block) - else
+    every rank receives every rank's whole buffer (ONE all-gather: the all-reduce(min, index) of SURVEY.md §8e with
+    the reduction done locally by qpg_merge_select_*).  Returns the receive buffer: `world` source chunks, chunk w
+    from rank w.  RCCL (backend nccl) moves device buffers in place; gloo is staged through the host."""
+    import torch.distributed as dist_
+    host = send.is_cuda and dist_.get_backend(group) == "gloo"
+    s_ = send.cpu() if host else send
+    if owner_blocks:
+        r_ = torch.empty_like(s_)
+        dist_.all_to_all_single(r_, s_, group=group)
+    else:
+        parts = [torch.empty_like(s_) for _ in range(world)]
+        if dist_.get_backend(group) == "gloo":
+            dist_.all_gather(parts, s_, group=group)
+            r_ = torch.cat(parts)
+        else:
+            r_ = torch.empty((world * s_.numel(),), dtype=s_.dtype, device=s_.device)
+            dist_.all_gather_into_tensor(r_, s_, group=group)
+    return r_.to(send.device) if host else r_
+
+
+def merge_reference(dists, idxs, absent):
+    """ATen statement of qpg_merge_select_* for HOST tensors (CPU tests of the exchange protocol; the product path
+    on a GPU uses the HIP kernel): dists / idxs [W, Q, K]; winner = minimum distance, lowest index among equals,
+    idx < 0 = absent in that shard."""
+    big = torch.iinfo(torch.int32).max
+    d = torch.where(idxs >= 0, dists, torch.full_like(dists, float("inf")))
+    best = d.min(dim=0).values
+    cand = torch.where((d == best) & (idxs >= 0), idxs, torch.full_like(idxs, big))
+    ibest = cand.min(dim=0).values
+    have = ibest != big
+    return (torch.where(have, best, torch.full_like(best, absent)),
+            torch.where(have, ibest, torch.full_like(ibest, -1)))
 
 
 # ---- data-parallel VQ-VAE training (codebook/train.py; bottleneck.py:44,73-75 collectives) ----------------------

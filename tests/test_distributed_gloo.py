@@ -121,3 +121,68 @@ def test_owner_partitioned_alltoall_exchange(tmp_path):
             assert np.array_equal(got["d"][:, :512], d[rows]) and np.array_equal(got["i"][:, :512], ix[rows])
             assert np.array_equal(got["d"][:, 512:], dt[rows].astype(np.float64))
             assert np.array_equal(got["i"][:, 512:], it[rows])
+
+
+def _worker_bytes(rank, world, port, out, owner):
+    """Round-2 exchange protocol on host tensors: tables written into code_knn.ExchangeLayout, ONE collective
+    (parallel.exchange_bytes: all-to-all or all-gather), merge = parallel.merge_reference (the ATen statement of the
+    qpg_merge_select_* HIP kernels, which tests/test_gpu_bench_sharded.py and test_gpu_matching.py run on the GPU)."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cref
+    from qpgesture_amd.code_knn import ExchangeLayout
+    from qpgesture_amd.parallel import exchange_bytes, merge_reference, shard_rows
+    base, ctx, code, q, qt = _data()
+    q = np.concatenate([q, q[::-1][:1]])
+    qt = np.concatenate([qt, qt[::-1][:1]])
+    Q, K = q.shape[0], 512
+    lo, hi = shard_rows(base.shape[0], rank, world)
+    g = np.arange(26)
+    d, ix = cref.audio_scan(base[lo:hi], g * 6, code[lo:hi], g, q)
+    ix = np.where(ix >= 0, ix + lo * 26, -1).astype(np.int32)
+    dt, it = cref.text_scan(ctx[lo:hi], g, code[lo:hi], g, qt)
+    it = np.where(it >= 0, it + lo * 26, -1).astype(np.int32)
+    lay = ExchangeLayout(Q, K, world if owner else 1, ["aud", "txt"], True, "cpu")
+    blocks = lay.send.view(lay.nblk, lay.block_bytes)
+    n = lay.Qb * K
+    for b in range(lay.nblk):                       # what the select kernels do with (q_block, block_stride)
+        rows = slice(b * lay.Qb, (b + 1) * lay.Qb)
+        for name, arr, dt_ in (("aud_d", d, torch.float64), ("aud_i", ix, torch.int32), ("txt_d", dt, torch.float32),
+                               ("txt_i", it, torch.int32)):
+            sz = n * torch.empty((), dtype=dt_).element_size()
+            blocks[b, lay.off[name]:lay.off[name] + sz].view(dt_).copy_(torch.from_numpy(arr[rows].reshape(-1)))
+    recv = exchange_bytes(lay.send, world, owner)
+    stride = lay.block_bytes if owner else lay.send.numel()
+    src = recv.view(world, stride)
+    res = {}
+    for p_, dt_ in (("aud", torch.float64), ("txt", torch.float32)):
+        sz = n * torch.empty((), dtype=dt_).element_size()
+        dd = torch.stack([src[w, lay.off[p_ + "_d"]:lay.off[p_ + "_d"] + sz].view(dt_).view(lay.Qb, K) for w in range(world)])
+        ii = torch.stack([src[w, lay.off[p_ + "_i"]:lay.off[p_ + "_i"] + n * 4].view(torch.int32).view(lay.Qb, K)
+                          for w in range(world)])
+        res[p_ + "_d"], res[p_ + "_i"] = [t.numpy() for t in merge_reference(dd, ii, 1e3)]
+    np.savez(out % rank, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_byte_exchange_protocol(tmp_path):
+    """One collective on the ExchangeLayout byte buffer + min/index merge == the single-process scan, for the
+    all-gather form (every rank gets all rows) and the owner-partitioned all-to-all, worlds 2 and 3."""
+    from oracle import cref
+    base, ctx, code, q, qt = _data()
+    q = np.concatenate([q, q[::-1][:1]])
+    qt = np.concatenate([qt, qt[::-1][:1]])
+    g = np.arange(26)
+    d, ix = cref.audio_scan(base, g * 6, code, g, q)
+    dt, it = cref.text_scan(ctx, g, code, g, qt)
+    for world in (2, 3):
+        for owner in (False, True):
+            out = str(tmp_path / ("bx_w%d_o%d_r%%d.npz" % (world, owner)))
+            mp.spawn(_worker_bytes, args=(world, _free_port(), out, owner), nprocs=world, join=True)
+            qc = q.shape[0] // world
+            for r in range(world):
+                got = np.load(out % r)
+                rows = slice(r * qc, (r + 1) * qc) if owner else slice(None)
+                assert np.array_equal(got["aud_d"], d[rows]) and np.array_equal(got["aud_i"], ix[rows])
+                assert np.array_equal(got["txt_d"], dt[rows]) and np.array_equal(got["txt_i"], it[rows])

@@ -1,6 +1,8 @@
-"""The N>1 path of bench.py (row-sharded DB, min+index all-reduce, one clip per rank) on a single GPU:
-2 ranks share cuda:0 and exchange through gloo (QPG_BENCH_ONE_GPU=1); every rank checks its matched codes
-against an unsharded match of the same clip (--check)."""
+"""The N>1 paths of bench.py (row-sharded DB + one min/index exchange + the HIP merge kernel) on a single GPU:
+the ranks share cuda:0 and exchange through gloo (QPG_BENCH_ONE_GPU=1); every rank checks its matched codes
+against an unsharded match of the same clip(s) (--check).  weak = one clip per rank, owner-partitioned all-to-all;
+strong = ONE clip, all-gather + merge on every rank (BASELINE.json configs[3]'s shape); 2 clips per rank = the batched
+multi-clip sweep of configs[4]."""
 import json
 import os
 import socket
@@ -27,7 +29,7 @@ def test_bench_sharded_matches_unsharded(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--n-db", "200", "--windows", "2", "--check",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--no-vqvae"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -35,3 +37,47 @@ def test_bench_sharded_matches_unsharded(world):
     assert out["n_gpus"] == world and out["check"] is True and out["scaling"] == "weak"
     assert out["config"]["clips"] == world and out["value"] > 0
     assert "roofline" in out and out["roofline"]["bound"] == "mfma"
+
+
+@pytest.mark.parametrize("extra,scaling,clips", [(["--scaling", "strong", "--n-db", "300"], "strong", 1),
+                                                 (["--clips", "2", "--n-db", "200"], "weak", 4)])
+def test_bench_strong_and_multiclip(extra, scaling, clips):
+    env = dict(os.environ, QPG_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "2", "--check", "--no-cpu-baseline",
+           "--no-vqvae"] + extra
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["check"] is True and out["scaling"] == scaling and out["config"]["clips"] == clips
+
+
+def test_merge_kernel_vs_reference():
+    """qpg_merge_select_f64 / _f32 == parallel.merge_reference on random tables with planted ties and absent codes."""
+    import numpy as np
+    import torch
+    from qpgesture_amd import _lib
+    from qpgesture_amd.parallel import merge_reference
+    g = torch.Generator().manual_seed(3)
+    W, Q, K = 5, 7, 512
+    for dt, name in ((torch.float64, "qpg_merge_select_f64"), (torch.float32, "qpg_merge_select_f32")):
+        d = torch.rand((W, Q, K), generator=g).to(dt)
+        i = torch.randint(0, 10 ** 6, (W, Q, K), generator=g, dtype=torch.int32)
+        d[1] = d[3]                                             # exact ties across shards: lowest index wins
+        i[torch.rand((W, Q, K), generator=g) < 0.2] = -1        # code absent in that shard
+        i[:, :, 17] = -1                                        # absent everywhere
+        want_d, want_i = merge_reference(d, i, 1e3)
+        dev = torch.device("cuda:0")
+        buf = torch.cat((d.reshape(W, -1).view(torch.uint8).reshape(W, -1), i.reshape(W, -1).view(torch.uint8).reshape(W, -1)),
+                        dim=1).contiguous().to(dev)
+        n = Q * K
+        dsz = d.element_size()
+        od = torch.empty((Q, K), dtype=dt, device=dev)
+        oi = torch.empty((Q, K), dtype=torch.int32, device=dev)
+        ork = torch.empty((Q, K), dtype=torch.int16, device=dev)
+        _lib.call(name, dev, buf, W, buf.shape[1], 0, n * dsz, Q, K, 1e3, od, oi, ork)
+        assert torch.equal(od.cpu(), want_d) and torch.equal(oi.cpu(), want_i)
+        assert (oi.cpu()[:, 17] == -1).all() and (od.cpu()[:, 17] == 1e3).all()
+        rk = np.argsort(np.argsort(want_d.numpy(), axis=1, kind="stable"), axis=1, kind="stable")
+        assert np.array_equal(ork.cpu().numpy(), rk)

@@ -1,0 +1,43 @@
+"""The bench.py matching step (N_db=2048, M=6) in a bare loop: 5 warm-up + <steps> iterations, eager or graph replay."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from qpgesture_amd import synth
+from qpgesture_amd.code_knn import CodeKNN, GestureDB
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+graph = len(sys.argv) > 2 and sys.argv[2] == "graph"
+N, M = 2048, 6
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+interp = torch.randn((N, 180, 1024), device=dev)
+ctx = rng.standard_normal((N, 30, 384)).astype(np.float32)
+phase = rng.standard_normal((N, 240, 4, 8)).astype(np.float32)
+db = GestureDB(synth.make_codes(N, 2), interp, ctx, phase, synth.make_signature(3), device=dev)
+knn = CodeKNN(db, rng=np.random.RandomState(123456))
+knn.audio_first = os.environ.get("QPG_AUDIO_FIRST") == "1"
+te_i = torch.randn((M, 180, 1024), device=dev)
+te_c = torch.randn((M, 30, 384), device=dev)
+sc, sp = knn.init_code_phase()
+spd = torch.from_numpy(sp).to(dev)
+g = knn.capture_clip_graph(M) if graph else None
+
+
+def step():
+    if graph:
+        return g.run(te_i, te_c, sc, spd)[0].cpu()
+    T = knn.sweep_tables(te_i, te_c, M)
+    return knn.walk(T, M, 0, seed_code=sc, seed_phase=spd, sync=False)[0].cpu()
+
+
+import time
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    step()
+torch.cuda.synchronize()
+print("%s: %.4f ms/step" % ("graph" if graph else "eager", (time.perf_counter() - t0) / steps * 1e3))
