@@ -161,6 +161,21 @@ int qpg_percode_select_f32(qpg_ctx*, void* stream, const float* D, int64_t ldD, 
                            int64_t C, int K, float absent, int32_t idx_base, float* out_dist, int32_t* out_idx,
                            int16_t* out_rank, int q_block, int64_t block_stride);
 
+/* qpg_percode_select_f64 with the NEAR-TIE GUARD (SURVEY.md §7 hard part 2).  The sweep's distances (dot-product
+ * form on the f64 matrix cores) and the reference's (sklearn: 0.5*|q/|q| - c/|c||^2, NumPy einsum order,
+ * GestureKNN.py:685) agree to ~1e-16 but can order two distances closer than that differently.  Candidates within `eps`
+ * of their code's minimum (two or more) are re-evaluated in the reference's exact arithmetic and the winner taken by
+ * (reference distance, index); minima of different codes within `eps` of each other are replaced by the
+ * reference-arithmetic value of their winner before ranking.  All inside the launch; nothing is flagged on ordinary data.
+ * base [dev] f32 [N][T][F], cand_t [dev] i32 [G], q32 [dev] f32 [Q][n_taps*F]: the sweep's own operands (C == N*G);
+ * stats [dev] i32 [2]: [0] += re-evaluated (query, candidate) pairs, [1] = 1 if more than 256 were flagged in one row
+ * (the surplus keeps its sweep value). */
+int qpg_percode_select_guarded_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int16_t* cand_code,
+                                   int64_t C, int K, double absent, int32_t idx_base, double* out_dist, int32_t* out_idx,
+                                   int16_t* out_rank, int q_block, int64_t block_stride, const float* base, int T, int F,
+                                   const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32, double eps,
+                                   int32_t* stats);
+
 /* Cross-shard min + index merge after the RCCL exchange (the all-reduce(min, index) `north_star`
  * names, as all-gather / all-to-all + this kernel): source w's tables start at recv + w*src_stride (+ dist_off for the
  * [Q][K] distances, + idx_off for the [Q][K] i32 global candidate indices, -1 = absent in that shard).  Winner per

@@ -9,8 +9,10 @@ Additive flags: --device (default cuda:0), --mode (default `shipped` = the flags
 GestureKNN.py:842-843: wavlm_feat + text + phase; `audio` / `text` = the single-modality phase
 branches :593-625; `wavvq` / `wavvq_audio` = vq-wav2vec Levenshtein audio, the flags the paper describes,
 with / without text), --seed (default 123456 as :19; in wavvq modes that seed draws an invalid initial
-phase slice in the reference as well), --tie_rule (how equal code frequencies are ranked: `numpy` = the reference's
-own `argsort().argsort()` call on the host, `stable` = lowest code first, deterministic).
+phase slice in the reference as well), --tie_rule (how EQUAL values are ranked - code frequencies, and the per-code
+audio / text minima, which tie exactly on real text data where silent frames share one embedding: `numpy` = the
+reference's own `argsort().argsort()` call on the host (NumPy's unstable sort, like the reference), `stable` = lowest
+code first, deterministic, ranks taken on the device).
 """
 import argparse
 import os
@@ -66,6 +68,7 @@ def main_codebook(args, maxFrames=0):
     db = GestureDB(L.code, L.train_wavlm, L.train_context, L.train_phase, signature, device=args.device,
                    freq_rank=freq_rank, wavvq=L.train_wavvq if vq else None)
     knn = CodeKNN(db, use_wavlm=not vq, use_wavvq=vq)                            # draws from np.random like :463-464
+    knn.host_ranks = args.tie_rule == "numpy"        # audio / text minima ranked by the reference's own NumPy call
     n_test_seq = maxFrames if maxFrames != 0 else L.test_wavvq.shape[0]          # :740
     dev = db.device
     te_i = (torch.from_numpy(np.ascontiguousarray(L.test_wavvq[:n_test_seq])).to(dev) if vq

@@ -37,6 +37,8 @@ _SIGS = {
     "qpg_percode_finalize_f32": [P, I, I, c_float, P, P, P],
     "qpg_percode_select_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L],
     "qpg_percode_select_f32": [P, L, I, P, L, I, c_float, ctypes.c_int32, P, P, P, I, L],
+    "qpg_percode_select_guarded_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
+                                       c_double, P],
     "qpg_merge_select_f64": [P, I, L, L, L, I, I, c_double, P, P, P],
     "qpg_merge_select_f32": [P, I, L, L, L, I, I, c_float, P, P, P],
     "qpg_percode_argmin_f64": [P, L, I, P, I, I, P, I, I, c_double, ctypes.c_int32, P, P],

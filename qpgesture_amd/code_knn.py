@@ -241,6 +241,14 @@ class CodeKNN:
         self.rng = rng if rng is not None else np.random
         self.overlap_sweeps = True          # text sweep on a second HIP stream underneath the audio sweep
         self.serial_walk = False            # True: force the one-wave sequential walk (tests compare the two)
+        # Near-tie guard of the audio select (qpg_percode_select_guarded_f64): candidates / code minima closer than
+        # tie_eps are re-evaluated in the reference's own arithmetic inside the select launch.  0 disables it.
+        self.tie_eps = 1e-12
+        self._guard_stats = torch.zeros((2,), dtype=torch.int32, device=db.device)
+        # host_ranks (the CLI's --tie_rule numpy): rank the (Q,512) audio / text minima with the reference's own
+        # `np.array(x).argsort().argsort()` on the host, so that EXACT ties between codes (structural in real text
+        # embeddings: silent frames share one vector) get NumPy's unstable-sort order like the reference's.
+        self.host_ranks = False
 
     def _audio_grid(self):
         db = self.db
@@ -304,8 +312,13 @@ class CodeKNN:
             qb = bs = 0
         fused_rank = want_rank and db.world == 1
         rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
-        _lib.call("qpg_percode_select_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K, float(ABSENT_DIST),
-                  db.idx_base * db.Ga, dist, idx, rank, qb, bs)
+        if self.tie_eps > 0 and C > 0 and db.feature_dtype == "f32":
+            _lib.call("qpg_percode_select_guarded_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K,
+                      float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
+                      db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, float(self.tie_eps), self._guard_stats)
+        else:
+            _lib.call("qpg_percode_select_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K, float(ABSENT_DIST),
+                      db.idx_base * db.Ga, dist, idx, rank, qb, bs)
         self._last_D_aud = D
         if not reduce:              # sharded caller combines several tables in one exchange (sweep_tables)
             return dist, idx
@@ -414,6 +427,19 @@ class CodeKNN:
         if self.db.world == 1:
             return dist, idx
         return allreduce_min_index(dist, idx)
+
+    def guard_stats(self):
+        """(re-evaluated (query, candidate) pairs so far, overflow flag) of the near-tie guard."""
+        v = self._guard_stats.cpu().numpy()
+        return int(v[0]), bool(v[1])
+
+    @staticmethod
+    def numpy_ranks(dist):
+        """The reference's rank expression (GestureKNN.py:553, 574) on the host: np.array(list).argsort().argsort() of a
+        float64 array (its lists mix Python floats and NumPy scalars, so the array is float64 for both modalities)."""
+        d = dist.detach().cpu().numpy().astype(np.float64)
+        r = np.stack([np.array(list(row)).argsort().argsort() for row in d]).astype(np.int16)
+        return torch.from_numpy(r).to(dist.device)
 
     def rank_rows(self, dist):
         out = torch.empty(dist.shape, dtype=torch.int16, device=dist.device)
@@ -565,6 +591,10 @@ class CodeKNN:
                 _lib.call("qpg_merge_select_f64" if f64 else "qpg_merge_select_f32", dev, recv, db.world, src_stride,
                           lay.off[p_ + "_d"], lay.off[p_ + "_i"], lay.Qb, db.K, float(ABSENT_DIST), d, ix, rk)
                 T[p_ + "_d"], T[p_ + "_idx"], T[p_ + "_rank"] = d, ix, rk
+        if self.host_ranks:
+            for p_ in ("aud", "txt"):
+                if T[p_ + "_d"] is not None:
+                    T[p_ + "_rank"] = self.numpy_ranks(T[p_ + "_d"])
         return T
 
     def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True):

@@ -50,3 +50,8 @@ __device__ __forceinline__ float f_add(float a, float b) { return a + b; }
 __device__ __forceinline__ float f_sub(float a, float b) { return a - b; }
 __device__ __forceinline__ float f_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float f_sqrt(float a) { return __builtin_sqrtf(a); }
+// the same for float64 (the near-tie guard re-evaluates audio distances in the reference's f64 arithmetic)
+__device__ __forceinline__ double f_mul(double a, double b) { return a * b; }
+__device__ __forceinline__ double f_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double f_sub(double a, double b) { return a - b; }
+__device__ __forceinline__ double f_div(double a, double b) { return a / b; }

@@ -423,6 +423,102 @@ __global__ __launch_bounds__(256, 2) void convt_f32_kernel(ConvTArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Short sequences (one clip's decode: 180..1440 rows; a single window's encode): a launch of 64-row x 128-channel
+// blocks would leave most of the chip idle and each block would walk the whole contraction alone (latency-bound).
+// Here a block = 16 positions x 64 output channels and its four waves SPLIT THE CONTRACTION (each a quarter of the
+// 16-k blocks); nothing is shared between the waves, so the weights go straight from the T-pack (L2-resident, 1 KB
+// coalesced per tile and 16-k block) into registers, three 16-k blocks ahead, with no LDS staging and no barrier in
+// the loop; the eight partial tiles meet in LDS once, are added in wave order (deterministic) and each wave finishes
+// one 16-channel tile (bias, ReLU, residual, 16-byte stores).
+// ---------------------------------------------------------------------------------------------------------------
+#define CTS_NW 8     // waves per block = ways the contraction is split
+template <bool RELU_IN>
+__global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs a) {
+  __shared__ __attribute__((aligned(16))) float part[CTS_NW][4][64][4];     // [wave][tile][lane][r]
+  const int tid = threadIdx.x, lane = tid & 63, ml = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t M = (int64_t)a.B * a.T_out;
+  const int64_t m = (int64_t)blockIdx.x * 16 + ml;
+  const int nb = blockIdx.y >> 1, half = blockIdx.y & 1;             // 128-channel T-pack block, 64-channel half
+  if (nb * 128 + half * 64 >= a.Cout) return;                          // padding-only chunk (135-channel output layer)
+  const bool live = m < M;
+  const int b = live ? (int)(m / a.T_out) : 0;
+  const int t = live ? (int)(m - (int64_t)b * a.T_out) : 0;
+  const float* xb = a.x + (int64_t)b * a.T_in * a.Cx + 4 * g;
+  const int nkb = a.nstage * 4;                                        // 16-k blocks in the contraction
+  const int per = (nkb + CTS_NW - 1) / CTS_NW;
+  const int kb0 = w * per, kb1 = kb0 + per < nkb ? kb0 + per : nkb;
+  const int kpt = a.Cin_pad / 16;                                      // 16-k blocks per tap
+  const float* wbase = a.wt + ((int64_t)nb * nkb * 4 + g) * 512 + (half * 64 + ml) * 4;   // + kb*2048 + tile*64
+  auto bfrag = [&](int kb) -> f32x4 {
+    const int tap = kb / kpt, ci0 = (kb - tap * kpt) * 16;
+    const int t_in = t * a.in_stride + a.in_offset + tap * a.dil;
+    const bool ok = live && kb < kb1 && t_in >= 0 && t_in < a.T_in;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ok ? xb + (int64_t)t_in * a.Cx + ci0 : a.zeros);
+    return RELU_IN ? relu4(v) : v;
+  };
+  struct Frag {
+    f32x4 a[4], b;
+  };
+  auto load = [&](int kb) -> Frag {
+    Frag f;
+    const float* wp = wbase + (int64_t)(kb < kb1 ? kb : 0) * 2048;       // past the range: a valid address, zero B
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f.a[q] = *reinterpret_cast<const f32x4*>(wp + q * 64);
+    f.b = bfrag(kb);
+    return f;
+  };
+  f32x4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  Frag f0 = load(kb0), f1 = load(kb0 + 1), f2 = load(kb0 + 2);
+  for (int kb = kb0; kb < kb1; ++kb) {
+    const Frag f3 = load(kb + 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = mfma16(f0.a[q][j], f0.b[j], acc[q]);
+    f0 = f1;
+    f1 = f2;
+    f2 = f3;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&part[w][q][lane][0]) = acc[q];
+  __syncthreads();
+  // waves 0..3 finish tile w: channel n = nb*128 + half*64 + 16 w + 4 g + r, position m (partials added in wave order)
+  if (w >= 4) return;
+  f32x4 o = *reinterpret_cast<const f32x4*>(&part[0][w][lane][0]);
+#pragma unroll
+  for (int s2 = 1; s2 < CTS_NW; ++s2) {
+    const f32x4 p2 = *reinterpret_cast<const f32x4*>(&part[s2][w][lane][0]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] += p2[r];
+  }
+  if (!live) return;
+  const int n = nb * 128 + half * 64 + 16 * w + 4 * g;
+  if (n >= a.Cout) return;
+  const int64_t orow = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout;
+  if (a.bias) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] += bb[r];
+  }
+  if (a.relu_out) o = relu4(o);
+  if (n + 4 <= a.Cout && (a.Cout & 3) == 0) {
+    if (a.res) {
+      const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + orow + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = rr[r] + o[r];
+    }
+    *reinterpret_cast<f32x4*>(a.y + orow + n) = o;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < a.Cout) a.y[orow + n + r] = a.res ? a.res[orow + n + r] + o[r] : o[r];
+  }
+}
+
 extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, int T_in, int Cx, const float* wt,
                              const float* bias, int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride,
                              int in_offset, int dil, int T_out, int out_stride, int out_offset, int T_y,
@@ -454,6 +550,14 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
   a.T_y = T_y; a.Cout = Cout; a.relu_in = relu_in; a.relu_out = relu_out; a.nstage = taps * Cin_pad / 64;
   a.zeros = ctx->zeros;
   const int64_t M = (int64_t)B * T_out;
+  // short sequences: 16-position x 64-channel blocks whose waves split the contraction (see convt_small_f32_kernel)
+  if (((M + CT_ROWS - 1) / CT_ROWS) * (Cout_pad / 128) * 2 < 3 * (int64_t)ctx->n_cu) {
+    const dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / 64));
+    if (relu_in) hipLaunchKernelGGL(convt_small_f32_kernel<true>, sgrid, dim3(64 * CTS_NW), 0, qpg_stream(stream), a);
+    else hipLaunchKernelGGL(convt_small_f32_kernel<false>, sgrid, dim3(64 * CTS_NW), 0, qpg_stream(stream), a);
+    QPG_LAUNCH_CHECK("convt_small_f32_kernel");
+    return QPG_OK;
+  }
   const dim3 grid((unsigned)((M + CT_ROWS - 1) / CT_ROWS), (unsigned)(Cout_pad / 128));
   if (relu_in) hipLaunchKernelGGL(convt_f32_kernel<true>, grid, dim3(256), 2 * CT_STAGE_BYTES, qpg_stream(stream), a);
   else hipLaunchKernelGGL(convt_f32_kernel<false>, grid, dim3(256), 2 * CT_STAGE_BYTES, qpg_stream(stream), a);

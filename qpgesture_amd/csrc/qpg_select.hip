@@ -414,6 +414,266 @@ __global__ __launch_bounds__(1024) void percode_select_kernel(const T* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Near-tie guard of the audio select (SURVEY.md §7 hard part 2).  The sweep computes 1 - q.c/(|q||c|) on the f64
+// matrix cores; the reference computes 0.5*|q/|q| - c/|c||^2 with NumPy's einsum summation order
+// (GestureKNN.py:685 -> sklearn paired_cosine_distances).  The two agree to ~1e-16, so they can only ORDER two
+// distances differently when those are closer than that - rare, but "bit-exact indices" is the bar.  The guarded
+// select therefore
+//   1. counts, per (query, code), the candidates within `eps` of the code's minimum; where there are two or more
+//      it re-evaluates exactly those candidates with the reference's own arithmetic (refine_pair_f64 below: sklearn's
+//      normalise + einsum-order sum of squares, separately rounded multiplies and adds, IEEE sqrt and divide) and
+//      picks the winner by (reference distance, index);
+//   2. finds the codes whose minima lie within `eps` of another code's minimum and replaces those minima by the
+//      reference-arithmetic value of their winner before ranking, so the rank order is the reference's.
+// Nothing is flagged on ordinary data and the extra cost is one compare per candidate; flagged work happens inside
+// the same launch (no host round trip).  stats[0] += re-evaluated pairs, stats[1] = 1 if a list overflowed.
+// ---------------------------------------------------------------------------------------------
+struct GuardArgs {
+  const float* base;      // [N][T][F] interpolated WavLM frames of this shard (f32)
+  const float* q32;       // [Q][n_taps*F] packed queries
+  const int32_t* cand_t;  // [G] start frame of grid position g
+  int T, F, G, n_taps, tap_stride;
+  double eps;
+  int32_t* stats;         // [2]
+};
+#define GUARD_LIST 256
+
+// One (query, candidate) distance in the reference's arithmetic, by FOUR cooperating lanes (an aligned quad):
+// lanes 0/1 run the two einsum accumulator chains of the query's squared norm, lanes 2/3 those of the candidate's;
+// then lanes 0/1 run the chains of the normalised difference.  NumPy's f64 einsum kernel: 2 SIMD lanes, groups of
+// 8 elements visited as pairs 3,2,1,0, acc = v*v + acc with separate roundings (oracle/knn_oracle.py::einsum_sq).
+__device__ __forceinline__ double refine_pair_f64(const GuardArgs& A, int q, int64_t c_local, int sub) {
+  const int D = A.n_taps * A.F;
+  const int j = (int)(c_local / A.G), g = (int)(c_local - (int64_t)j * A.G);
+  const int t0 = A.cand_t[g];
+  const float* qrow = A.q32 + (int64_t)q * D;
+  const float* crow = A.base + (int64_t)j * A.T * A.F;
+  auto cval = [&](int e) -> double {
+    const int tap = e / A.F, f = e - tap * A.F;
+    const int t = t0 + tap * A.tap_stride;
+    return t < A.T ? (double)crow[(int64_t)t * A.F + f] : 0.0;
+  };
+  const int l = sub & 1;
+  const bool is_c = sub >= 2;
+  auto chain = [&](auto val) -> double {
+    double acc = 0.0;
+    const int nfull = D / 8;
+    for (int gq = 0; gq < nfull; ++gq) {
+#pragma unroll
+      for (int u = 3; u >= 0; --u) {
+        const double v = val(8 * gq + 2 * u + l);
+        acc = f_add(f_mul(v, v), acc);
+      }
+    }
+    for (int i = nfull * 8; i < D; i += 2) {
+      const double v = (i + l < D) ? val(i + l) : 0.0;
+      acc = f_add(f_mul(v, v), acc);
+    }
+    return acc;
+  };
+  const double a1 = is_c ? chain(cval) : chain([&](int e) -> double { return (double)qrow[e]; });
+  const double o1 = __shfl_xor(a1, 1, 64);
+  double n = sqrt(l == 0 ? f_add(a1, o1) : f_add(o1, a1));             // acc[0] + acc[1]
+  if (n < 10.0 * 2.220446049250313e-16) n = 1.0;                        // sklearn _handle_zeros_in_scale
+  const double n_other = __shfl_xor(n, 2, 64);                          // quad: lanes 0,1 <-> 2,3
+  const double nq = is_c ? n_other : n, nc = is_c ? n : n_other;
+  const double a2 = chain([&](int e) -> double { return f_sub(f_div((double)qrow[e], nq), f_div(cval(e), nc)); });
+  const double o2 = __shfl_xor(a2, 1, 64);
+  return f_mul(0.5, l == 0 ? f_add(a2, o2) : f_add(o2, a2));
+}
+
+__global__ __launch_bounds__(1024) void percode_select_guarded_f64_kernel(
+    const double* __restrict__ D, int64_t ldD, const int16_t* __restrict__ cand_code, int64_t C, int K, double absent,
+    int32_t idx_base, double* __restrict__ out_dist, int32_t* __restrict__ out_idx, int16_t* __restrict__ out_rank,
+    int q_block, int64_t block_stride, GuardArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
+  unsigned int* besti = reinterpret_cast<unsigned int*>(smem + 8 * (size_t)K);
+  double* v = reinterpret_cast<double*>(smem + 12 * (size_t)K + 4 * (size_t)K);     // keep 8-byte alignment
+  unsigned int* near_ = reinterpret_cast<unsigned int*>(smem + 12 * (size_t)K);
+  unsigned char* tail = smem + 24 * (size_t)K;
+  double* l_d = reinterpret_cast<double*>(tail);                                    // [GUARD_LIST]
+  int* l_c = reinterpret_cast<int*>(tail + 8 * GUARD_LIST);                         // [GUARD_LIST] local candidate
+  int* l_k = l_c + GUARD_LIST;                                                      // [GUARD_LIST] code
+  int* ctl = l_k + GUARD_LIST;                                                      // [0] list length, [1] any flag
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const double* row = D + (int64_t)q * ldD;
+  if (q_block > 0) {
+    const int64_t shift = (int64_t)(q / q_block) * block_stride;
+    const int64_t rowoff = (int64_t)(q % q_block) * K - (int64_t)q * K;
+    out_dist = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(out_dist) + shift) + rowoff;
+    out_idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(out_idx) + shift) + rowoff;
+  }
+  for (int k = tid; k < K; k += blockDim.x) {
+    best[k] = ~0ull;
+    besti[k] = 0xffffffffu;
+    near_[k] = 0;
+  }
+  if (tid < 2) ctl[tid] = 0;
+  __syncthreads();
+  // the two streaming passes of percode_select_kernel (16-byte loads), pass 2 also counting the band population
+  typedef double vecD __attribute__((ext_vector_type(2)));
+  typedef int16_t vecC __attribute__((ext_vector_type(2)));
+  const bool vec_ok = (ldD % 2) == 0 && (reinterpret_cast<uintptr_t>(D) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(cand_code) % 4) == 0;
+  const int64_t Cv = vec_ok ? (C / 2) * 2 : 0;
+  for (int64_t c = (int64_t)tid * 2; c < Cv; c += (int64_t)blockDim.x * 2) {
+    const vecD d = *reinterpret_cast<const vecD*>(row + c);
+    const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if ((unsigned)cd[e] < (unsigned)K) atomicMin(&best[cd[e]], (unsigned long long)order_key(d[e]));
+  }
+  for (int64_t c = Cv + tid; c < C; c += blockDim.x) {
+    const int cd = cand_code[c];
+    if ((unsigned)cd < (unsigned)K) atomicMin(&best[cd], (unsigned long long)order_key(row[c]));
+  }
+  __syncthreads();
+  auto pass2 = [&](int64_t c, double d, int cd) {
+    if ((unsigned)cd >= (unsigned)K) return;
+    const unsigned long long bk = best[cd];
+    if ((unsigned long long)order_key(d) == bk) atomicMin(&besti[cd], (unsigned int)(c + idx_base));
+    else if (d > key_value(bk, 0.0) + A.eps) return;
+    if (atomicAdd(&near_[cd], 1u) == 1u) ctl[1] = 1;                  // a second candidate inside the band
+  };
+  for (int64_t c = (int64_t)tid * 2; c < Cv; c += (int64_t)blockDim.x * 2) {
+    const vecD d = *reinterpret_cast<const vecD*>(row + c);
+    const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
+    pass2(c, d[0], cd[0]);
+    pass2(c + 1, d[1], cd[1]);
+  }
+  for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass2(c, row[c], cand_code[c]);
+  __syncthreads();
+  // ---- 1. candidate-level near ties: re-evaluate the band of every flagged code in the reference's arithmetic
+  if (ctl[1]) {
+    for (int64_t c = tid; c < C; c += blockDim.x) {
+      const int cd = cand_code[c];
+      if ((unsigned)cd >= (unsigned)K || near_[cd] < 2) continue;
+      if (row[c] <= key_value(best[cd], 0.0) + A.eps) {
+        const int pos = atomicAdd(&ctl[0], 1);
+        if (pos < GUARD_LIST) {
+          l_c[pos] = (int)c;
+          l_k[pos] = cd;
+        }
+      }
+    }
+    __syncthreads();
+    int n = ctl[0];
+    if (n > GUARD_LIST) {
+      n = GUARD_LIST;
+      if (tid == 0) A.stats[1] = 1;
+    }
+    for (int e0 = 0; e0 < n; e0 += blockDim.x / 4) {
+      const int e = e0 + (tid >> 2);
+      const double dr = refine_pair_f64(A, q, l_c[e < n ? e : 0], tid & 3);
+      if (e < n && (tid & 3) == 0) l_d[e] = dr;
+    }
+    for (int k = tid; k < K; k += blockDim.x)
+      if (near_[k] >= 2) {
+        best[k] = ~0ull;
+        besti[k] = 0xffffffffu;
+      }
+    __syncthreads();
+    for (int e = tid; e < n; e += blockDim.x) atomicMin(&best[l_k[e]], (unsigned long long)order_key(l_d[e]));
+    __syncthreads();
+    for (int e = tid; e < n; e += blockDim.x)
+      if ((unsigned long long)order_key(l_d[e]) == best[l_k[e]])
+        atomicMin(&besti[l_k[e]], (unsigned int)(l_c[e] + idx_base));
+    if (tid == 0) atomicAdd(&A.stats[0], n);
+    __syncthreads();
+  }
+  for (int k = tid; k < K; k += blockDim.x) {
+    const bool have = besti[k] != 0xffffffffu;
+    v[k] = have ? key_value(best[k], 0.0) : absent;
+  }
+  if (tid < 2) ctl[tid] = 0;
+  __syncthreads();
+  // ---- 2. ranks; rank-level near ties: minima of DIFFERENT codes closer than eps are compared in reference
+  // arithmetic.  Two values are that close iff they are neighbours in the sorted order, so the check is one look at
+  // each rank neighbour (the sorted copy is scattered by rank), not another K x K sweep.
+  for (int k = tid; k < K; k += blockDim.x) {
+    const bool have = besti[k] != 0xffffffffu;
+    out_dist[(int64_t)q * K + k] = v[k];
+    out_idx[(int64_t)q * K + k] = have ? (int32_t)besti[k] : -1;
+  }
+  if (!out_rank) return;
+  int* s_code = reinterpret_cast<int*>(best);                 // the key table is no longer needed: [K] code at rank r
+  auto rank_pass = [&]() {
+    for (int k = tid; k < K; k += blockDim.x) {
+      const double x = v[k];
+      int r = 0;
+      for (int o = 0; o < K; ++o) {
+        const double y = v[o];
+        r += (y < x) || (y == x && o < k);
+      }
+      out_rank[(int64_t)q * K + k] = (int16_t)r;
+      s_code[r] = k;
+    }
+  };
+  rank_pass();
+  __syncthreads();
+  for (int r = tid; r + 1 < K; r += blockDim.x) {
+    const int ka = s_code[r], kb = s_code[r + 1];
+    if (besti[ka] == 0xffffffffu || besti[kb] == 0xffffffffu) continue;      // absent codes tie at `absent` by design
+    if (v[kb] - v[ka] < A.eps) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = h ? kb : ka;
+        if (near_[k] >= 2) continue;                                          // already a reference-arithmetic value
+        if (atomicExch(&near_[k], 2u) >= 2u) continue;                        // listed once
+        const int pos = atomicAdd(&ctl[0], 1);
+        if (pos < GUARD_LIST) {
+          l_c[pos] = (int)(besti[k] - (unsigned int)idx_base);
+          l_k[pos] = k;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  int n2 = ctl[0];
+  if (n2 == 0) return;
+  if (n2 > GUARD_LIST) {
+    n2 = GUARD_LIST;
+    if (tid == 0) A.stats[1] = 1;
+  }
+  for (int e0 = 0; e0 < n2; e0 += blockDim.x / 4) {
+    const int e = e0 + (tid >> 2);
+    const double dr = refine_pair_f64(A, q, l_c[e < n2 ? e : 0], tid & 3);
+    if (e < n2 && (tid & 3) == 0) {
+      v[l_k[e]] = dr;
+      out_dist[(int64_t)q * K + l_k[e]] = dr;
+    }
+  }
+  if (tid == 0) atomicAdd(&A.stats[0], n2);
+  __syncthreads();
+  rank_pass();
+}
+
+extern "C" int qpg_percode_select_guarded_f64(qpg_ctx* ctx, void* stream, const double* D, int64_t ldD, int Q,
+                                              const int16_t* cand_code, int64_t C, int K, double absent,
+                                              int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
+                                              int q_block, int64_t block_stride, const float* base, int T, int F,
+                                              const int32_t* cand_t, int G, int n_taps, int tap_stride,
+                                              const float* q32, double eps, int32_t* stats) {
+  QPG_REQUIRE(ctx && D && (cand_code || C == 0) && out_dist && out_idx && base && cand_t && q32 && stats,
+              "qpg_percode_select_guarded_f64: null pointer");
+  QPG_REQUIRE(Q >= 0 && C >= 0 && K > 0 && K <= 2048 && ldD >= C && C + (int64_t)idx_base < 0x7fffffffll && T > 0 &&
+                  F > 0 && G > 0 && n_taps > 0 && tap_stride > 0 && eps >= 0.0 && C % G == 0,
+              "qpg_percode_select_guarded_f64: bad size");
+  QPG_REQUIRE(q_block >= 0 && (q_block == 0 || (!out_rank && Q % q_block == 0 && block_stride % 8 == 0)),
+              "qpg_percode_select_guarded_f64: block layout needs Q %% q_block == 0 and no rank output");
+  if (Q == 0) return QPG_OK;
+  GuardArgs A;
+  A.base = base; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
+  A.tap_stride = tap_stride; A.eps = eps; A.stats = stats;
+  const size_t sh = 24 * (size_t)K + GUARD_LIST * 16 + 16;
+  hipLaunchKernelGGL(percode_select_guarded_f64_kernel, dim3(Q), dim3(1024), sh, qpg_stream(stream), D, ldD, cand_code,
+                     C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block, block_stride, A);
+  QPG_LAUNCH_CHECK("percode_select_guarded_f64_kernel");
+  return QPG_OK;
+}
+
 template <typename T, typename KeyT, bool PACKED>
 static int percode_select(const char* name, qpg_ctx* ctx, void* stream, const T* D, int64_t ldD, int Q,
                           const int16_t* cand_code, int64_t C, int K, T absent, int32_t idx_base, T* out_dist,

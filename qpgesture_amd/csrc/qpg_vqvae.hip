@@ -636,6 +636,28 @@ void qpg_launch_sub_inplace(void* stream, float* a, const float* b, int64_t n) {
   hipLaunchKernelGGL(sub_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, qpg_stream(stream), a, b, n);
 }
 
+static int decode_tpath(qpg_ctx* ctx, void* stream, const qpg_vq_model* m, const int64_t* ids, int B, int L, float* cur,
+                        float* alt, float* h, float* out, int32_t* status) {
+  int rc = qpg_vq_gather_f32(ctx, stream, m->k, ids, (int64_t)B * L, m->emb, m->bins, alt, status);   // dequantise
+  if (rc) return rc;
+  int Tc = L;
+  rc = convt_call(ctx, stream, m->dec_in, alt, 512, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, cur);
+  if (rc) return rc;
+  for (int i = 0; i < m->down_t; ++i) {
+    rc = resnet_tpath(ctx, stream, m->dec_res[i], m->dec_res_pack[i], m->depth, m->growth, m->reverse_dec != 0, B, Tc,
+                      cur, alt, h);
+    if (rc) return rc;
+    // ConvTranspose1d(k4,s2,p1): y[2m] = x[m-1].W3 + x[m].W1 ; y[2m+1] = x[m].W2 + x[m+1].W0
+    rc = convt_call(ctx, stream, m->dec_up_even[i], cur, 512, B, Tc, 1, -1, 1, Tc, 2, 0, 2 * Tc, nullptr, 0, 0, alt);
+    if (rc) return rc;
+    rc = convt_call(ctx, stream, m->dec_up_odd[i], cur, 512, B, Tc, 1, 0, 1, Tc, 2, 1, 2 * Tc, nullptr, 0, 0, alt);
+    if (rc) return rc;
+    { float* t = cur; cur = alt; alt = t; }
+    Tc *= 2;
+  }
+  return convt_call(ctx, stream, m->dec_out, cur, 512, B, Tc, 1, -1, 1, Tc, 1, 0, Tc, nullptr, 0, 0, out);
+}
+
 extern "C" int qpg_vq_decode_f32(qpg_ctx* ctx, void* stream, const qpg_vq_model* m, const int64_t* ids, int B, int L,
                                  float* ws, int64_t ws_floats, float* out, int32_t* status) {
   QPG_REQUIRE(ctx && model_ok(m) && ids && ws && out, "qpg_vq_decode_f32: bad argument");
@@ -649,6 +671,7 @@ extern "C" int qpg_vq_decode_f32(qpg_ctx* ctx, void* stream, const qpg_vq_model*
   const int64_t slab = (((int64_t)B * T * cmax + 3) / 4) * 4;
   float *cur = ws, *alt = ws + slab, *h = ws + 2 * slab;
   const SplitWs sw{ws + 3 * slab, ws_floats - 3 * slab};
+  if (tpath_ok(m, false)) return decode_tpath(ctx, stream, m, ids, B, L, cur, alt, h, out, status);
   int rc = qpg_vq_gather_f32(ctx, stream, m->k, ids, (int64_t)B * L, m->emb, m->bins, alt, status);   // dequantise
   if (rc) return rc;
   int Tc = L;

@@ -67,14 +67,55 @@ def phase_dense_to_object(phase_dense):
     return out
 
 
+def apply_variant(tr, te, code, variant):
+    """Planted structure on top of the seeded arrays (in place), shared by the golden generator and the tests.
+
+    'neartie': audio near-ties below the rounding noise of any distance formula (SURVEY.md §7 hard part 2).  The two
+        test windows are DB windows 5 and 9, so every query has a candidate at distance exactly 0; DB windows 20 / 30
+        are copies of 5 / 9 with a few elements moved by one float32 ulp and the SAME code row (two candidates of one
+        code within ~1e-19 of each other), 21 / 31 the same with their own code rows (minima of two different codes
+        within ~1e-19), 22 an exact duplicate of 5 with the same codes (exact tie: first index wins).
+    'texttie': repeated context rows, as real BEAT data has (every silent code frame carries the identical
+        encode(['']) embedding, make_beat_dataset.py:556-565): many codes tie EXACTLY in txt_dist, often at distance 0,
+        and the reference ranks them with NumPy's unstable argsort."""
+    if variant is None:
+        return
+    if variant == "neartie":
+        w = tr["wavlm"]
+        te["wavlm"][0], te["wavlm"][1] = w[5], w[9]
+
+        def ulp(src, stride):
+            x = src.copy()
+            flat = x.reshape(x.shape[0], -1)
+            flat[:, ::stride] = np.nextafter(flat[:, ::stride], np.float32(np.inf))
+            return x
+        w[20], w[21] = ulp(w[5], 97), ulp(w[5], 89)
+        w[30], w[31] = ulp(w[9], 97), ulp(w[9], 89)
+        w[22] = w[5]
+        code[20], code[30], code[22] = code[5], code[9], code[5]
+    elif variant == "texttie":
+        rng = _rng(777)
+        sil = rng.standard_normal((384,)).astype(np.float32)           # the "silence" embedding
+        ctx = tr["context"]
+        mask = rng.random(ctx.shape[:2]) < 0.35
+        ctx[mask] = sil
+        for j in range(0, ctx.shape[0], 3):                            # words spanning several code frames
+            ctx[j, 10:14] = ctx[j, 10]
+        tq = te["context"]
+        tq[:, ::4] = sil                                               # silent query frames: distance exactly 0
+    else:
+        raise ValueError(variant)
+
+
 def write_npz_set(outdir, n_train, n_test, seed_train=0, seed_test=1, seed_code=2, seed_sig=3,
-                  wavlm_dim=1024):
+                  wavlm_dim=1024, variant=None):
     """Write the 8 npz files GestureKNN.py's CLI takes; returns the path dict (flag -> path)."""
     os.makedirs(outdir, exist_ok=True)
     tr = make_db(n_train, seed_train, wavlm_dim)
     te = make_db(n_test, seed_test, wavlm_dim)
     code = make_codes(n_train, seed_code)
     sig = make_signature(seed_sig)
+    apply_variant(tr, te, code, variant)
     p = {k: os.path.join(outdir, v) for k, v in dict(
         train_database="train_240_txt_2.npz", test_data="test_240_txt_2.npz",
         train_codebook="train_240_code.npz", codebook_signature="code.npz",

@@ -92,7 +92,7 @@ def run_reference(paths, mode, max_frames=0):
                 L = frame.f_locals
                 cap["steps"].append({k: np.array(L[k]).copy() for k in
                                      ("pos_score", "freq_score", "combined_score", "combined_score_",
-                                      "final_index") if k in L})
+                                      "final_index", "aud_score", "txt_score") if k in L})
             return local_trace
 
         def global_trace(frame, event, arg):
@@ -173,7 +173,12 @@ def run_reference(paths, mode, max_frames=0):
         res.update(aud_dist=d, aud_pay=p.astype(np.int16), aud_aux=a.astype(np.int32))
     if cap["txt"]:
         d, p, a = pack(cap["txt"])
-        assert d.dtype == np.float32, d.dtype
+        if d.dtype != np.float32:
+            # codes absent from the DB keep the Python float 1e+3 placeholder (GestureKNN.py:709), which makes
+            # np.array(list) float64; every real entry is still a float32 value
+            d32 = d.astype(np.float32)
+            assert np.array_equal(d32.astype(np.float64), d), "text distances are not float32 values"
+            d = d32
         res.update(txt_dist=d, txt_pay=p.astype(np.int16), txt_aux=a.astype(np.int32))
     if cap["steps"]:
         for k in cap["steps"][0]:
@@ -189,9 +194,12 @@ def run_reference(paths, mode, max_frames=0):
 
 
 FIXTURES = {
-    # name: (n_train, n_test, seeds(train,test,code,sig), max_frames, mode)
+    # name: (n_train, n_test, seeds(train,test,code,sig), max_frames, mode[, variant of synth.apply_variant])
     "shipped_n48_m2_s0": (48, 2, (0, 1, 2, 3), 0, "shipped"),
     "shipped_n64_m3_s10": (64, 3, (10, 11, 12, 13), 0, "shipped"),
+    # planted audio near-ties (ulp-perturbed duplicate windows) / exact text ties (repeated context rows)
+    "shipped_neartie_n48_m2_s30": (48, 2, (30, 31, 32, 33), 0, "shipped", "neartie"),
+    "shipped_texttie_n48_m2_s40": (48, 2, (40, 41, 42, 43), 0, "shipped", "texttie"),
     # vq-wav2vec + Levenshtein audio (the mode the paper describes); wavlm_dim=8 keeps the unused WavLM small
     "wavvq_aud_txt_n40_m2_s20": (40, 2, (20, 21, 22, 23), 0, "wavvq_aud_txt"),
     "wavvq_aud_n40_m2_s20": (40, 2, (20, 21, 22, 23), 0, "wavvq_aud"),
@@ -202,13 +210,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    for name, (ntr, nte, seeds, mf, mode) in FIXTURES.items():
+    for name, spec in FIXTURES.items():
+        ntr, nte, seeds, mf, mode = spec[:5]
+        variant = spec[5] if len(spec) > 5 else None
         if a.only and a.only != name:
             continue
         with tempfile.TemporaryDirectory() as td:
-            paths = synth.write_npz_set(td, ntr, nte, *seeds, wavlm_dim=1024 if mode == "shipped" else 8)
+            paths = synth.write_npz_set(td, ntr, nte, *seeds, wavlm_dim=1024 if mode == "shipped" else 8,
+                                        variant=variant)
             res = run_reference(paths, mode, mf)
         res["meta"] = np.array([ntr, nte, *seeds, mf], np.int64)
+        res["variant"] = np.array(variant or "")
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
         print(name, "knn_pred", res["knn_pred"].shape, "ref wall %.1fs" % res["ref_wall_s"],
               {k: (v.shape, str(v.dtype)) for k, v in res.items()})

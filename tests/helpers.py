@@ -13,14 +13,16 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
-def fixture_arrays(n_train, n_test, s_train, s_test, s_code, s_sig, wavlm_dim=1024):
+def fixture_arrays(n_train, n_test, s_train, s_test, s_code, s_sig, wavlm_dim=1024, variant=None):
     """In-memory version of synth.write_npz_set (same seeds -> same bytes), already windowed the way
     data_processing.load_db_codebook leaves them: interpolated WavLM, squeezed context, dense phase."""
     from oracle import knn_oracle as O
     tr = synth.make_db(n_train, s_train, wavlm_dim)
     te = synth.make_db(n_test, s_test, wavlm_dim)
+    code = synth.make_codes(n_train, s_code)
+    synth.apply_variant(tr, te, code, variant)
     return dict(
-        code=synth.make_codes(n_train, s_code), sig=synth.make_signature(s_sig),
+        code=code, sig=synth.make_signature(s_sig),
         tr_interp=O.interp_wavlm(tr["wavlm"]), te_interp=O.interp_wavlm(te["wavlm"]),
         tr_ctx=tr["context"].squeeze(2), te_ctx=te["context"].squeeze(2),
         tr_phase=tr["phase_dense"], te_phase=te["phase_dense"],

@@ -260,3 +260,82 @@ def test_long_clip_walk_tabulated_equals_sequential_and_oracle():
                           rank_kind="stable", rng=np.random.RandomState(5))
     want, wph, wv = O.predict_code_from_audio(orc, test_interp=A["te_interp"], test_ctx=A["te_ctx"], n_windows=M)
     assert np.array_equal(got[0], want) and np.array_equal(got[2], wv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: planted ties (fixtures captured from the reference by tests/golden/make_golden.py, variants of
+# qpgesture_amd.synth.apply_variant)
+# ---------------------------------------------------------------------------------------------------------------
+def _build_variant(g, dev="cuda:0"):
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    ntr, nte, s0, s1, s2, s3, mf = [int(v) for v in g["meta"]]
+    A = fixture_arrays(ntr, nte, s0, s1, s2, s3, variant=str(g["variant"]))
+    db = GestureDB(A["code"], A["tr_interp"], A["tr_ctx"], A["tr_phase"], A["sig"], device=dev,
+                   freq_rank=g["step_freq_score"])
+    knn = CodeKNN(db, rng=np.random.RandomState(123456))
+    te_i = torch.from_numpy(A["te_interp"]).to(dev)
+    te_c = torch.from_numpy(np.ascontiguousarray(A["te_ctx"])).to(dev)
+    return A, db, knn, te_i, te_c, nte
+
+
+def test_audio_near_ties_vs_reference_golden():
+    """ulp-perturbed duplicate DB windows (and a query that IS a DB window): the reference sees distances 0 and
+    ~6e-17, below the rounding noise of the sweep's dot-product form.  The near-tie guard re-evaluates the flagged
+    pairs in the reference's arithmetic: winners, the full rank order of the 512 minima and knn_pred are the
+    reference's; the refined distances are BIT-EXACT where the guard ran."""
+    g = load_golden("shipped_neartie_n48_m2_s30")
+    A, db, knn, te_i, te_c, M = _build_variant(g)
+    codes, phases, votes = knn.match_clip(te_i, te_c, M, return_tables=True)
+    n_ref, overflow = knn.guard_stats()
+    assert n_ref > 0 and not overflow
+    T = knn.tables
+    aud_d, aud_idx = T["aud_d"].cpu().numpy(), T["aud_idx"].cpu().numpy()
+    gj, gk = g["aud_aux"][..., 0], g["aud_aux"][..., 1]
+    want_idx = np.where(gj >= 0, gj * 26 + gk // 6, -1)
+    assert np.array_equal(aud_idx, want_idx)                                           # winners incl. absent codes
+    assert np.abs(aud_d - g["aud_dist"]).max() < 1e-13
+    small = g["aud_dist"] < 1e-12
+    assert small.sum() >= 2 * 14 and np.array_equal(aud_d[small], g["aud_dist"][small])   # refined values: bit-exact
+    present = g["aud_dist"] != 1e3           # the 6 absent codes tie at 1e+3: NumPy's unstable order, not compared
+    assert np.array_equal(T["aud_rank"].cpu().numpy()[present], g["step_aud_score"][present])   # the reference's ranks
+    assert np.array_equal(T["txt_d"].cpu().numpy(), g["txt_dist"])
+    assert np.array_equal(codes, g["knn_pred"]) and np.array_equal(votes, g["vote"])
+    # without the guard the same clip is decided by rounding noise somewhere (recorded, not asserted: it is noise)
+    knn2 = type(knn)(db, rng=np.random.RandomState(123456))
+    knn2.tie_eps = 0.0
+    knn2.match_clip(te_i, te_c, M, return_tables=True)
+    r2 = knn2.tables["aud_rank"].cpu().numpy()
+    print("rank rows differing without the guard: %d of %d"
+          % (((r2 != g["step_aud_score"]) & present).any(axis=1).sum(), r2.shape[0]))
+
+
+def test_text_exact_ties_vs_reference_golden():
+    """Repeated context rows (silent frames share one embedding): 296 of 512 codes tie at distance exactly 0 in every
+    step.  The reference ranks them with NumPy's unstable argsort; `host_ranks` (= the CLI's --tie_rule numpy) calls
+    the same expression on the host, so on a machine whose NumPy sorts like the golden's the final codes are the
+    reference's (checked first; otherwise the test is skipped - that order is CPU-dispatch dependent upstream)."""
+    from qpgesture_amd.code_knn import CodeKNN
+    g = load_golden("shipped_texttie_n48_m2_s40")
+    here = np.stack([np.array(list(r.astype(np.float64))).argsort().argsort() for r in g["txt_dist"]])
+    if not np.array_equal(here, g["step_txt_score"]):
+        pytest.skip("this host's NumPy orders exact ties differently from the machine that captured the golden")
+    A, db, knn, te_i, te_c, M = _build_variant(g)
+    knn.host_ranks = True
+    codes, phases, votes = knn.match_clip(te_i, te_c, M, return_tables=True)
+    T = knn.tables
+    assert np.array_equal(T["txt_d"].cpu().numpy(), g["txt_dist"]) and (g["txt_dist"] == 0).sum(axis=1).min() > 200
+    gj, gk = g["txt_aux"][..., 0], g["txt_aux"][..., 1]
+    assert np.array_equal(T["txt_idx"].cpu().numpy(), np.where(gj >= 0, gj * 26 + gk // 8, -1))
+    assert np.array_equal(T["txt_rank"].cpu().numpy(), g["step_txt_score"])
+    assert np.array_equal(T["aud_rank"].cpu().numpy(), g["step_aud_score"])
+    assert np.array_equal(codes, g["knn_pred"]) and np.array_equal(votes, g["vote"])
+    # the deterministic rule gives the same minima and winners, only the tied ranks differ
+    knn2 = CodeKNN(db, rng=np.random.RandomState(123456))
+    knn2.match_clip(te_i, te_c, M, return_tables=True)
+    assert np.array_equal(knn2.tables["txt_idx"].cpu().numpy(), T["txt_idx"].cpu().numpy())
+    r2 = knn2.tables["txt_rank"].cpu().numpy()
+    uniq = np.stack([np.isin(r, np.unique(r)[np.unique(r, return_counts=True)[1] == 1]) for r in g["txt_dist"]])
+    assert uniq.sum() > 0 and np.array_equal(r2[uniq], g["step_txt_score"][uniq])
+    zero = g["txt_dist"] == 0
+    assert (r2[zero] < zero.sum(axis=1).max()).all()

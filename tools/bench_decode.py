@@ -1,0 +1,33 @@
+"""Decode of one 24 s clip (180 codes -> 1440 frames, one pass) and a single-window encode: HIP-event timings."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from qpgesture_amd import synth
+from qpgesture_amd.vqvae import VQVAE
+
+dev = torch.device("cuda:0")
+m = VQVAE(None, 135, device=dev).load_state_dict(synth.make_vqvae_state_dict(7))
+ids = torch.randint(0, 512, (1, 180), device=dev)
+x1 = torch.randn((1, 240, 135), device=dev)
+
+
+def t(fn, n=50):
+    for _ in range(8):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for e0, e1 in ev:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return ms[0], ms[len(ms) // 2]
+
+
+print("decode 24 s clip: min %.3f median %.3f ms" % t(lambda: m.decode([ids])))
+print("encode 1 window:  min %.3f median %.3f ms" % t(lambda: m.encode(x1)))
+for L in (30, 60, 720):
+    idl = torch.randint(0, 512, (1, L), device=dev)
+    print("decode L=%d: min %.3f median %.3f ms" % ((L,) + t(lambda: m.decode([idl]))))

@@ -61,7 +61,8 @@ def table(d, B, iters):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                              int(r.get("Grid_Size", 0) or 0) // max(int(r.get("Workgroup_Size", 1) or 1), 1)))
     rows.sort()
-    names = ("conv1d_mfma", "vq_argmin", "conv_splitk", "resblock", "sub_inplace", "convt_f32", "pad_channels")
+    names = ("conv1d_mfma", "vq_argmin", "conv_splitk", "resblock", "sub_inplace", "convt_f32", "convt_small", "pad_channels",
+             "vq_gather")
     rows = [r for r in rows if any(n in r[2] for n in names)]
     per = len(rows) // (iters + 3)
     rows = rows[-per * iters:]
@@ -79,8 +80,22 @@ def table(d, B, iters):
     print("sum (kernels + gaps): %.3f ms  ->  %.1f TFLOP/s" % (tot / 1e3, 1.639 * B / (tot / 1e3)))
 
 
+def run_decode(L, iters):
+    import torch
+    from qpgesture_amd import synth
+    from qpgesture_amd.vqvae import VQVAE
+    dev = torch.device("cuda", 0)
+    model = VQVAE(None, 135, device=dev).load_state_dict(synth.make_vqvae_state_dict(7))
+    ids = torch.randint(0, 512, (1, L), device=dev)
+    for _ in range(3 + iters):
+        model.decode([ids])
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "run":
+    if sys.argv[1] == "decode":
+        run_decode(int(sys.argv[2]), int(sys.argv[3]))
+    elif sys.argv[1] == "run":
         run(int(sys.argv[2]), int(sys.argv[3]))
     else:
         table(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
