@@ -108,6 +108,19 @@ int qpg_text_pack_candidates_f32(qpg_ctx*, void* stream, const float* x, int N, 
 int qpg_text_cosine_f32(qpg_ctx*, void* stream, const float* xt, int64_t C, int Dm, const float* qn, int Q,
                         float* D, int64_t ldD);
 
+/* The same sweep with the per-code minimum FUSED into it (large query counts, BASELINE.json configs[2]: 1 000 queries x
+ * 100 000 candidates): the Q x C distance matrix never reaches HBM.  Distances are bit-identical to
+ * qpg_text_cosine_f32's; winner per (query, code) = minimum distance, lowest candidate index among equals.
+ * cand_code: [dev] i16 [C] code of candidate c (outside [0,K): skipped, e.g. masked rows); tiles_per_chunk: 64-candidate
+ * tiles per block (work granularity); `ws`: scratch of `qpg_text_percode_ws_bytes` bytes (one packed [Q][K] table);
+ * out_dist [dev] f32 [Q][K] (`absent` where a code has no candidate), out_idx [dev] i32 [Q][K] = c + idx_base or -1,
+ * out_rank optional [dev] i16 [Q][K] stable ranks; out_nn optional [dev] i32 [Q] the query's global nearest
+ * neighbour over all codes (candidate index, -1 if there is no valid candidate).  K <= 1024. */
+int64_t qpg_text_percode_ws_bytes(int64_t C, int Q, int K, int tiles_per_chunk);
+int qpg_text_percode_f32(qpg_ctx*, void* stream, const float* xt, int64_t C, int Dm, const int16_t* cand_code, int K,
+                         const float* qn, int Q, int tiles_per_chunk, int32_t idx_base, float absent, void* ws,
+                         int64_t ws_bytes, float* out_dist, int32_t* out_idx, int16_t* out_rank, int32_t* out_nn);
+
 /* vq-wav2vec audio sweep (the mode the paper describes; flags use_wavvq/use_feature of GestureKNN.py:557-560):
  * D[q][c] = Levenshtein distance (unit costs, python-Levenshtein distance()) between the 11-symbol strings of
  * query q and candidate c, symbol = g1*320+g2 (wavvq_distances(mode='combine'), GestureKNN.py:57-67).  Strings

@@ -31,6 +31,7 @@ _SIGS = {
     "qpg_audio_cosine_f64": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
     "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
+    "qpg_text_percode_f32": [P, L, I, P, I, P, I, I, ctypes.c_int32, c_float, P, L, P, P, P, P],
     "qpg_percode_resolve_f32": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P],
     "qpg_percode_resolve_f64": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P, P],
     "qpg_percode_finalize_f64": [P, P, I, I, c_double, P, P, P],
@@ -120,6 +121,8 @@ def load():
     lib.qpg_conv1d_wgrad_ws_floats.restype = c_int64
     lib.qpg_vq_code_sums_ws_bytes.argtypes = [c_int64, c_int, c_int]
     lib.qpg_vq_code_sums_ws_bytes.restype = c_int64
+    lib.qpg_text_percode_ws_bytes.argtypes = [c_int64, c_int, c_int, c_int]
+    lib.qpg_text_percode_ws_bytes.restype = c_int64
     lib.qpg_vq_reduce_ws_bytes.argtypes = []
     lib.qpg_vq_reduce_ws_bytes.restype = c_int64
     for name, sig in _SIGS.items():

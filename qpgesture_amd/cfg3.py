@@ -1,0 +1,126 @@
+"""BASELINE.json configs[2] / SURVEY.md §8d cfg-3: the generic "distance matrix + per-code minimum" kernel at scale.
+
+Synthetic DB of 100 000 code vectors x 512-d (f32, ~N(0,1), seed 0), code ids uniform in [0,512) (seed 1), validity
+mask Bernoulli(0.9) (seed 2), 1 000 queries (seed 3).  Output per query: the per-code minimum cosine distance and its
+candidate (512 of each) and the global nearest neighbour.  The arithmetic is the reference's for this distance
+(GestureKNN.py:716 -> sklearn paired_distances(metric='cosine') on float32: normalise, einsum-order sum of squares),
+bit for bit, which rules out FMA and the matrix cores; the kernel is VALU-bound, not HBM-bound, and says so.
+
+`CosineIndex` is the host-side mirror: build once (normalise + tile the candidates), `query()` per batch."""
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+
+N_DB, DIM, N_Q, K_CODES = 100_000, 512, 1000, 512
+ABSENT = 1000.0
+
+
+def make_inputs(n=N_DB, d=DIM, nq=N_Q, k=K_CODES):
+    X = np.random.Generator(np.random.PCG64(0)).standard_normal((n, d), dtype=np.float32)
+    code = np.random.Generator(np.random.PCG64(1)).integers(0, k, size=n).astype(np.int32)
+    valid = np.random.Generator(np.random.PCG64(2)).random(n) < 0.9
+    q = np.random.Generator(np.random.PCG64(3)).standard_normal((nq, d), dtype=np.float32)
+    return X, code, valid, q
+
+
+class CosineIndex:
+    """Candidates resident in HBM, sklearn-normalised and tiled for lane-per-candidate access
+    (qpg_text_pack_candidates_f32); masked rows carry code -1 and can never win."""
+
+    def __init__(self, X, code, valid=None, n_codes=K_CODES, device="cuda:0", tiles_per_chunk=1):
+        dev = torch.device(device)
+        n, d = X.shape
+        self.device, self.n, self.d, self.K = dev, n, d, n_codes
+        self.tiles_per_chunk = tiles_per_chunk
+        xd = torch.as_tensor(X, dtype=torch.float32).to(dev).contiguous().view(n, 1, d)
+        self.xt = torch.zeros((((n + 63) // 64) * 64 * d,), dtype=torch.float32, device=dev)
+        cand_r = torch.zeros((1,), dtype=torch.int32, device=dev)
+        _lib.call("qpg_text_pack_candidates_f32", dev, xd, n, 1, d, cand_r, 1, self.xt)
+        cm = np.asarray(code, np.int64)
+        if valid is not None:
+            cm = np.where(np.asarray(valid), cm, -1)
+        self.cand_code = torch.from_numpy(cm.astype(np.int16)).to(dev)
+        self._ws = None
+
+    def query(self, q, want_nn=True):
+        """q: f32 [Q][d] device tensor.  Returns (dist f32 [Q][K], idx i32 [Q][K], nn i32 [Q])."""
+        dev = self.device
+        Q = q.shape[0]
+        qn = torch.empty_like(q)
+        _lib.call("qpg_l2_normalize_rows_f32", dev, q, Q, self.d, qn)
+        need = int(_lib.load().qpg_text_percode_ws_bytes(self.n, Q, self.K, self.tiles_per_chunk))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        dist = torch.empty((Q, self.K), dtype=torch.float32, device=dev)
+        idx = torch.empty((Q, self.K), dtype=torch.int32, device=dev)
+        nn = torch.empty((Q,), dtype=torch.int32, device=dev) if want_nn else None
+        _lib.call("qpg_text_percode_f32", dev, self.xt, self.n, self.d, self.cand_code, self.K, qn, Q,
+                  self.tiles_per_chunk, 0, ABSENT, self._ws, self._ws.numel(), dist, idx, None, nn)
+        return dist, idx, nn
+
+
+def bench(a, dev, world, rank, hbm_peak_gbs):
+    """bench.py --workload cfg3: one step = normalise the 1 000 queries + the fused sweep / per-code minimum + merge.
+    N > 1: the DB is row-sharded (replicas of the query set), no exchange is timed (each rank reports its shard's
+    tables; the min+index merge across shards is the same qpg_merge_select_f32 as the matcher's)."""
+    import torch.distributed as dist
+    X, code, valid, q = make_inputs()
+    per = (N_DB + world - 1) // world
+    lo, hi = min(rank * per, N_DB), min((rank + 1) * per, N_DB)
+    import os
+    index = CosineIndex(X[lo:hi], code[lo:hi], valid[lo:hi], device=dev,
+                        tiles_per_chunk=int(os.environ.get("QPG_CFG3_TPC", "1")))
+    qd = torch.from_numpy(q).to(dev)
+    steps = min(a.steps, 50)
+    for _ in range(max(a.warmup, 3)):
+        index.query(qd)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in ev:
+        e0.record()
+        out = index.query(qd)
+        e1.record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    k_ms = ms[len(ms) // 2]
+    n_loc = hi - lo
+    alg_bytes = n_loc * DIM * 4 + n_loc * 4 + N_Q * DIM * 4 + N_Q * K_CODES * 8
+    lane_ops = 3.0 * N_Q * n_loc * DIM                                                   # sub, mul, add per element pair
+    valu_peak = 1024 * 2.4e9 * 32                                                        # packed f32 non-FMA lane-ops/s
+    return {"metric": "per-code min cosine sweep, query-candidate pairs/sec (cfg-3)", "value": round(N_Q * N_DB * steps / dt, 1),
+            "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": max(a.warmup, 3),
+            "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg-3: DB 100000 x 512 f32, 512 codes, Bernoulli(0.9) validity mask, 1000 queries; "
+                                   "sklearn-exact f32 cosine, per-code min + argmin + global nearest neighbour",
+                       "n_db": N_DB, "dim": DIM, "queries": N_Q, "parallelism": "db rows / %d" % world},
+            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": hbm_peak_gbs,
+                         "unit": "GB/s", "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / hbm_peak_gbs, 4),
+                         "traffic": CFG3_TRAFFIC_BYTES if world == 1 else None,
+                         "kernel": "text_cosine_gmin_f32_kernel (+ fill, merge)", "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes": int(alg_bytes),
+                         "note": "the distance is sklearn's separately rounded f32 arithmetic (bit-exact indices are the "
+                                 "bar), so neither FMA nor the matrix cores are admissible: the kernel is VALU-bound",
+                         "valu": {"lane_ops": lane_ops, "peak_lane_ops_per_s": valu_peak,
+                                  "floor_ms": round(lane_ops / valu_peak * 1e3, 3),
+                                  "frac": round(lane_ops / valu_peak / (k_ms * 1e-3), 4)}}}
+
+
+# Fabric-side bytes per step from rocprofv3 PMC (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate passes):
+# profiles/r02_cfg3_pmc.md.  ~0.2 GB of it is the candidate array (once per XCD-local group of query blocks); the rest
+# is the 8-byte look-before-atomicMin reads of the [Q][K] table, which must bypass the per-XCD (non-coherent) L2s.
+CFG3_TRAFFIC_BYTES = 6_440_000_000

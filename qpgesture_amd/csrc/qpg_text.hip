@@ -80,24 +80,10 @@ __device__ __forceinline__ f32x2 pk_sub_sv(f32x2 q, f32x2 x) {
   return d;
 }
 
-template <int QB, int NG>
-__global__ __launch_bounds__(64 * NG) void text_cosine_f32_kernel(const float* __restrict__ xt, int64_t C, int Dm,
-                                                                  const float* __restrict__ qn, int Q,
-                                                                  float* __restrict__ D, int64_t ldD) {
-  const int lane = threadIdx.x & 63;
-  const int qg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
-  const int64_t tile = blockIdx.x;
-  const int q0 = blockIdx.y * (NG * QB) + qg * QB;
-  if (q0 >= Q) return;
-  const float* qrow[QB];
-#pragma unroll
-  for (int i = 0; i < QB; ++i) {
-    int q = q0 + i;
-    if (q >= Q) q = Q - 1;
-    qrow[i] = qn + (int64_t)q * Dm;
-  }
-  const f32x4* xp = reinterpret_cast<const f32x4*>(xt + tile * (int64_t)Dm * 64) + lane;
-
+// Distances of ONE 64-candidate tile (lane = candidate) against QB wave-uniform query rows, sklearn/einsum f32 order.
+template <int QB>
+__device__ __forceinline__ void text_tile_dists(const f32x4* __restrict__ xp, const float* const (&qrow)[QB], int nk,
+                                                float (&dist)[QB]) {
   // accumulators as two packed pairs (einsum lanes 0,1 and 2,3): every step is 3 packed VALU ops per 2 elements
   // (v_pk_add_f32 with the query pair straight from SGPRs and a negated candidate pair, v_pk_mul_f32, v_pk_add_f32)
   f32x2 acc[QB][2];
@@ -106,7 +92,6 @@ __global__ __launch_bounds__(64 * NG) void text_cosine_f32_kernel(const float* _
 
   // Software pipeline: the 64-B scalar load of the NEXT query row segment is issued before the 48 VALU ops
   // of the current one (two 16-SGPR buffers); element order per accumulator stays u = 3,2,1,0.
-  const int nk = Dm >> 4;
   f32x16 qv = *reinterpret_cast<const f32x16*>(qrow[0]);
   f32x4 xnext[4];
 #pragma unroll
@@ -137,17 +122,248 @@ __global__ __launch_bounds__(64 * NG) void text_cosine_f32_kernel(const float* _
       qv = qnext;
     }
   }
+#pragma unroll
+  for (int i = 0; i < QB; ++i)
+    dist[i] = f_mul(0.5f, f_add(f_add(acc[i][0].x, acc[i][0].y), f_add(acc[i][1].x, acc[i][1].y)));
+}
 
+template <int QB, int NG>
+__global__ __launch_bounds__(64 * NG) void text_cosine_f32_kernel(const float* __restrict__ xt, int64_t C, int Dm,
+                                                                  const float* __restrict__ qn, int Q,
+                                                                  float* __restrict__ D, int64_t ldD) {
+  const int lane = threadIdx.x & 63;
+  const int qg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+  const int64_t tile = blockIdx.x;
+  const int q0 = blockIdx.y * (NG * QB) + qg * QB;
+  if (q0 >= Q) return;
+  const float* qrow[QB];
+#pragma unroll
+  for (int i = 0; i < QB; ++i) {
+    int q = q0 + i;
+    if (q >= Q) q = Q - 1;
+    qrow[i] = qn + (int64_t)q * Dm;
+  }
+  const f32x4* xp = reinterpret_cast<const f32x4*>(xt + tile * (int64_t)Dm * 64) + lane;
+  float dist[QB];
+  text_tile_dists<QB>(xp, qrow, Dm >> 4, dist);
   const int64_t c = tile * 64 + lane;
   if (c < C) {
 #pragma unroll
-    for (int i = 0; i < QB; ++i) {
-      if (q0 + i < Q) {
-        const float s = f_add(f_add(acc[i][0].x, acc[i][0].y), f_add(acc[i][1].x, acc[i][1].y));
-        D[(int64_t)(q0 + i) * ldD + c] = f_mul(0.5f, s);
-      }
+    for (int i = 0; i < QB; ++i)
+      if (q0 + i < Q) D[(int64_t)(q0 + i) * ldD + c] = dist[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sweep with the per-code minimum FUSED (large query counts: BASELINE.json configs[2], 1 000 queries x 100 000
+// candidates).  The Q x C distance matrix (400 MB there) never reaches HBM: a block = NG waves on the SAME QB queries,
+// each wave walking every NG-th 64-candidate tile of the block's chunk; every lane folds its QB distances into an
+// LDS table [QB][K] of packed (ordered distance << 32 | candidate index) with ds_min_u64 (first-wins = lowest index
+// among equal distances, as the reference's strict `<` scan), and the block folds its table into ONE global [Q][K]
+// table (filtered atomicMin, see the flush); a last launch decodes it.  min is associative and commutative, so the
+// result does not depend on the order the blocks arrive in.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int text_order_key(float d) {
+  const unsigned int b = __float_as_uint(d);
+  return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+
+template <int QB, int NG>
+__global__ __launch_bounds__(64 * NG) void text_cosine_percode_f32_kernel(
+    const float* __restrict__ xt, int64_t C, int Dm, const int16_t* __restrict__ cand_code, int K,
+    const float* __restrict__ qn, int Q, int tiles_per_chunk, int32_t idx_base, unsigned long long* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* tab = reinterpret_cast<unsigned long long*>(smem);          // [QB][K]
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int chunk = blockIdx.x;
+  const int q0 = blockIdx.y * QB;
+  const float* qrow[QB];
+#pragma unroll
+  for (int i = 0; i < QB; ++i) {
+    int q = q0 + i;
+    if (q >= Q) q = Q - 1;
+    qrow[i] = qn + (int64_t)q * Dm;
+  }
+  for (int i = threadIdx.x; i < QB * K; i += 64 * NG) tab[i] = ~0ull;
+  __syncthreads();
+  const int64_t ntile = (C + 63) / 64;
+  const int64_t t0 = (int64_t)chunk * tiles_per_chunk;
+  const int64_t t1 = t0 + tiles_per_chunk < ntile ? t0 + tiles_per_chunk : ntile;
+  for (int64_t tile = t0 + wv; tile < t1; tile += NG) {
+    const f32x4* xp = reinterpret_cast<const f32x4*>(xt + tile * (int64_t)Dm * 64) + lane;
+    float dist[QB];
+    text_tile_dists<QB>(xp, qrow, Dm >> 4, dist);
+    const int64_t c = tile * 64 + lane;
+    const int cd = c < C ? cand_code[c] : -1;
+    if ((unsigned)cd < (unsigned)K) {
+      const unsigned int ci = (unsigned int)(c + idx_base);
+#pragma unroll
+      for (int i = 0; i < QB; ++i)
+        atomicMin(&tab[i * K + cd], ((unsigned long long)text_order_key(dist[i]) << 32) | ci);
     }
   }
+  __syncthreads();
+  // Flush into the ONE global [Q][K] table (4 MB, L2-resident) with atomicMin - but look first: the running minimum of
+  // a (query, code) pair is improved by the i-th chunk with probability ~1/i, so nearly all atomics are skipped after
+  // the first few chunks (a stale, i.e. larger, value read through L1 only costs a redundant atomic: values only fall).
+  for (int i = threadIdx.x; i < QB * K; i += 64 * NG) {
+    const int q = q0 + i / K;
+    const unsigned long long key = tab[i];
+    if (q < Q && key != ~0ull) {
+      unsigned long long* g = partial + (int64_t)q * K + (i % K);
+      if (key < *g) atomicMin(g, key);
+    }
+  }
+}
+
+// Variant without any LDS: the NG waves of a block take DIFFERENT query groups on the SAME candidate tile (as the
+// plain sweep does, so a tile is fetched once per NG*QB queries instead of once per QB) and every lane folds its QB
+// distances straight into the global [Q][K] table with the same look-first atomicMin.  The look is an L1-bypassing
+// load (a stale value could only be larger, i.e. cost a redundant atomic).  Per (query, code) the n-th candidate is a
+// new minimum with probability 1/n, so the atomics are ~H(C/K) per pair (about 6 of 195 here), not one per candidate.
+template <int QB, int NG>
+__global__ __launch_bounds__(64 * NG) void text_cosine_gmin_f32_kernel(const float* __restrict__ xt, int64_t C, int Dm,
+                                                                       const int16_t* __restrict__ cand_code, int K,
+                                                                       const float* __restrict__ qn, int Q,
+                                                                       int32_t idx_base,
+                                                                       unsigned long long* __restrict__ table) {
+  const int lane = threadIdx.x & 63;
+  const int qg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware work mapping (blocks are dealt round-robin to the 8 XCDs, each with its own L2): all the query-group
+  // blocks of one candidate tile get ids that are equal mod 8, i.e. run on ONE XCD at about the same time, so the
+  // tile (64 x Dm floats) crosses the fabric once and is served to the other query groups from that XCD's L2.
+  // Placement is a speed matter only; any mapping gives the same table.
+  const int nqb = (Q + NG * QB - 1) / (NG * QB);
+  const int64_t slot = blockIdx.x >> 3;
+  const int64_t tile = (slot / nqb) * 8 + (blockIdx.x & 7);
+  const int q0 = (int)(slot % nqb) * (NG * QB) + qg * QB;
+  if (tile * 64 >= C || q0 >= Q) return;
+  const float* qrow[QB];
+#pragma unroll
+  for (int i = 0; i < QB; ++i) {
+    int q = q0 + i;
+    if (q >= Q) q = Q - 1;
+    qrow[i] = qn + (int64_t)q * Dm;
+  }
+  const f32x4* xp = reinterpret_cast<const f32x4*>(xt + tile * (int64_t)Dm * 64) + lane;
+  float dist[QB];
+  text_tile_dists<QB>(xp, qrow, Dm >> 4, dist);
+  const int64_t c = tile * 64 + lane;
+  const int cd = c < C ? cand_code[c] : -1;
+  if ((unsigned)cd >= (unsigned)K) return;
+  const unsigned int ci = (unsigned int)(c + idx_base);
+#pragma unroll
+  for (int i = 0; i < QB; ++i) {
+    if (q0 + i >= Q) break;
+    unsigned long long* g = table + (int64_t)(q0 + i) * K + cd;
+    const unsigned long long key = ((unsigned long long)text_order_key(dist[i]) << 32) | ci;
+    const unsigned long long cur = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (key < cur) atomicMin(g, key);
+  }
+}
+
+__global__ __launch_bounds__(256) void text_fill_ff_kernel(unsigned long long* __restrict__ a, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = ~0ull;
+}
+
+// min over the chunk partials + decode: one block per query row (optionally the stable ranks too)
+__global__ __launch_bounds__(512) void text_percode_merge_kernel(const unsigned long long* __restrict__ partial,
+                                                                 int nchunk, int Q, int K, float absent,
+                                                                 float* __restrict__ out_dist,
+                                                                 int32_t* __restrict__ out_idx,
+                                                                 int16_t* __restrict__ out_rank,
+                                                                 int32_t* __restrict__ out_nn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* v = reinterpret_cast<float*>(smem);
+  __shared__ unsigned long long gbest;
+  const int q = blockIdx.x;
+  if (threadIdx.x == 0) gbest = ~0ull;
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    unsigned long long m = ~0ull;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const unsigned long long p = partial[((int64_t)ch * Q + q) * K + k];
+      m = p < m ? p : m;
+    }
+    const bool have = m != ~0ull;
+    const unsigned int kb = (unsigned int)(m >> 32);
+    const unsigned int fb = (kb >> 31) ? (kb & 0x7fffffffu) : ~kb;
+    const float d = have ? __uint_as_float(fb) : absent;
+    v[k] = d;
+    out_dist[(int64_t)q * K + k] = d;
+    out_idx[(int64_t)q * K + k] = have ? (int32_t)(m & 0xffffffffu) : -1;
+    if (out_nn && have) atomicMin(&gbest, m);
+  }
+  __syncthreads();
+  // the query's global nearest neighbour over all codes (minimum distance, lowest candidate index among equals)
+  if (out_nn && threadIdx.x == 0) out_nn[q] = gbest != ~0ull ? (int32_t)(gbest & 0xffffffffu) : -1;
+  if (!out_rank) return;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float x = v[k];
+    int r = 0;
+    for (int o = 0; o < K; ++o) {
+      const float y = v[o];
+      r += (y < x) || (y == x && o < k);
+    }
+    out_rank[(int64_t)q * K + k] = (int16_t)r;
+  }
+}
+
+extern "C" int64_t qpg_text_percode_ws_bytes(int64_t C, int Q, int K, int tiles_per_chunk) {
+  if (C < 0 || Q < 0 || K <= 0 || tiles_per_chunk <= 0) return -1;
+  return (int64_t)Q * K * 8;
+}
+
+extern "C" int qpg_text_percode_f32(qpg_ctx* ctx, void* stream, const float* xt, int64_t C, int Dm,
+                                    const int16_t* cand_code, int K, const float* qn, int Q, int tiles_per_chunk,
+                                    int32_t idx_base, float absent, void* ws, int64_t ws_bytes, float* out_dist,
+                                    int32_t* out_idx, int16_t* out_rank, int32_t* out_nn) {
+  QPG_REQUIRE(ctx && xt && (cand_code || C == 0) && qn && ws && out_dist && out_idx, "qpg_text_percode_f32: null pointer");
+  QPG_REQUIRE(C >= 0 && Q >= 0 && K > 0 && K <= 1024 && tiles_per_chunk > 0 && C + (int64_t)idx_base < 0xffffffffll,
+              "qpg_text_percode_f32: bad size (K <= 1024)");
+  if (Dm <= 0 || (Dm % 16) != 0) {
+    qpg_set_error("qpg_text_percode_f32: compiled for Dm %% 16 == 0 (got %d)", Dm);
+    return QPG_EUNSUP;
+  }
+  QPG_REQUIRE(ws_bytes >= qpg_text_percode_ws_bytes(C, Q, K, tiles_per_chunk), "qpg_text_percode_f32: workspace too small");
+  if (Q == 0) return QPG_OK;
+  constexpr int QB = 12, NG = 8;      // 8 waves share one 48 KB table: 3 blocks = 24 waves per CU
+  const int64_t ntile = (C + 63) / 64;
+  const int nchunk = (int)((ntile + tiles_per_chunk - 1) / tiles_per_chunk);
+  unsigned long long* partial = static_cast<unsigned long long*>(ws);
+  const size_t sh = (size_t)QB * K * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(text_cosine_percode_f32_kernel<QB, NG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 1024 * 8) != hipSuccess) {
+      qpg_set_error("qpg_text_percode_f32: cannot reserve LDS");
+      return QPG_EHIP;
+    }
+    attr_set = true;
+  }
+  {
+    const int64_t n = (int64_t)Q * K;
+    hipLaunchKernelGGL(text_fill_ff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, qpg_stream(stream), partial, n);
+    QPG_LAUNCH_CHECK("text_fill_ff_kernel");
+  }
+  if (tiles_per_chunk == 1) {      // LDS-free organisation: one tile per block, NG query groups share it
+    constexpr int QG = 12, NW = 8;
+    const int64_t nqb = (Q + QG * NW - 1) / (QG * NW);
+    hipLaunchKernelGGL((text_cosine_gmin_f32_kernel<QG, NW>), dim3((unsigned)(((ntile + 7) / 8) * nqb * 8)), dim3(64 * NW), 0,
+                       qpg_stream(stream), xt, C, Dm, cand_code, K, qn, Q, idx_base, partial);
+    QPG_LAUNCH_CHECK("text_cosine_gmin_f32_kernel");
+  } else if (nchunk > 0) {
+    hipLaunchKernelGGL((text_cosine_percode_f32_kernel<QB, NG>), dim3((unsigned)nchunk, (unsigned)((Q + QB - 1) / QB)),
+                       dim3(64 * NG), sh, qpg_stream(stream), xt, C, Dm, cand_code, K, qn, Q, tiles_per_chunk, idx_base,
+                       partial);
+    QPG_LAUNCH_CHECK("text_cosine_percode_f32_kernel");
+  }
+  hipLaunchKernelGGL(text_percode_merge_kernel, dim3(Q), dim3(512), sizeof(float) * (size_t)K, qpg_stream(stream),
+                     partial, 1, Q, K, absent, out_dist, out_idx, out_rank, out_nn);
+  QPG_LAUNCH_CHECK("text_percode_merge_kernel");
+  return QPG_OK;
 }
 
 template <int QB, int NG>

@@ -80,5 +80,31 @@ def test_cfg3_100k_by_512_per_code_min():
     assert np.array_equal(idx >= 0, np.broadcast_to(present, (Q, K)))
     assert np.all(dist[:, ~present] == 1000.0)
     flops = 2.0 * Q * N * D
-    print("cfg-3: sweep %.2f ms (%.1f TFLOP-equivalent/s, D write %.0f GB/s), per-code min+finalize %.2f ms" % (
-        t_sweep, flops / t_sweep / 1e9, Q * N * 4 / t_sweep / 1e6, t_min))
+    print("cfg-3 (matrix path): sweep %.2f ms (%.1f TFLOP-equivalent/s, D write %.0f GB/s), per-code min+finalize %.2f ms"
+          % (t_sweep, flops / t_sweep / 1e9, Q * N * 4 / t_sweep / 1e6, t_min))
+    # (3) the fused path (qpg_text_percode_f32: no Q x C matrix in HBM) returns the SAME tables, bit for bit, plus the
+    # global nearest neighbour of every query
+    import torch
+    from qpgesture_amd.cfg3 import CosineIndex
+    index = CosineIndex(X, code, valid, n_codes=K)
+    qd = torch.from_numpy(q).cuda()
+    fd, fi, nn = index.query(qd)
+    for tpc in (64, 7, 2000, 1):                                   # work granularity must not matter
+        index.tiles_per_chunk = tpc
+        index._ws = None
+        d2, i2, n2 = index.query(qd)
+        assert torch.equal(d2, fd) and torch.equal(i2, fi) and torch.equal(n2, nn)
+    assert np.array_equal(fd.cpu().numpy(), dist) and np.array_equal(fi.cpu().numpy(), idx)
+    nnh = nn.cpu().numpy()
+    best_code = dist.argmin(axis=1)
+    assert np.array_equal(nnh, idx[np.arange(Q), best_code])     # (ties between codes at the global minimum: none here)
+    assert np.array_equal(nnh[:200], rows)                       # the planted rows are the nearest neighbours
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    index.tiles_per_chunk = 64
+    index.query(qd)
+    ev[0].record()
+    for _ in range(5):
+        index.query(qd)
+    ev[1].record()
+    torch.cuda.synchronize()
+    print("cfg-3 (fused path): %.2f ms per 1000-query batch" % (ev[0].elapsed_time(ev[1]) / 5))
