@@ -93,6 +93,13 @@ int qpg_audio_pack_queries(qpg_ctx*, void* stream, const float* qbase, int M, in
 int qpg_audio_cosine_f64(qpg_ctx*, void* stream, const float* base, int N, int T, int F,
                          const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
                          const float* q32, const double* qn2, int Q, double* D, int64_t ldD);
+/* The same sweep over a base track stored in IEEE f16 (BASELINE.json configs[4] "fp16 features": half the HBM bytes of
+ * the dominant array).  Values are widened f16 -> f32 -> f64 in registers and the arithmetic is the same f64 as above,
+ * i.e. the result is the reference's distance on the f16-ROUNDED track (cn2 must be computed from the rounded values
+ * too).  base_f16: [dev] f16 [N][T][F], 16-byte aligned. */
+int qpg_audio_cosine_f64_h(qpg_ctx*, void* stream, const void* base_f16, int N, int T, int F,
+                           const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
+                           const float* q32, const double* qn2, int Q, double* D, int64_t ldD);
 
 /* One-off DB preparation for the text sweep: sklearn-normalise the grid rows x[j][cand_r[g]] (bit-exact,
  * as qpg_l2_normalize_rows_f32) and store them tiled for lane-per-candidate access:

@@ -29,6 +29,7 @@ _SIGS = {
     "qpg_text_pack_queries_f32": [P, I, I, I, P, P, I, P],
     "qpg_audio_pack_queries": [P, I, I, I, P, P, I, I, I, P, P],
     "qpg_audio_cosine_f64": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
+    "qpg_audio_cosine_f64_h": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
     "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
     "qpg_text_percode_f32": [P, L, I, P, I, P, I, I, ctypes.c_int32, c_float, P, L, P, P, P, P],

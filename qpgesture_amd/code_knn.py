@@ -168,8 +168,14 @@ class GestureDB:
         # per-candidate squared norms (f64) without materialising the 6144-d windows
         fn2 = torch.empty((self.n_local, self.T), dtype=torch.float64, device=dev)
         self.cn2 = torch.empty((self.n_local, self.Ga), dtype=torch.float64, device=dev)
+        if feature_dtype == "f16":
+            # f16 storage of the dominant array (half the HBM bytes); norms are those of the ROUNDED values, which the
+            # sweep widens in registers (qpg_audio_cosine_f64_h): the distances are the reference's on the rounded track
+            self.base = self.base.to(torch.float16).contiguous()
         if self.n_local:
-            _lib.call("qpg_frame_norm2_f64", dev, self.base, self.n_local * self.T, self.F, fn2)
+            src = self.base if feature_dtype == "f32" else self.base.float()
+            _lib.call("qpg_frame_norm2_f64", dev, src, self.n_local * self.T, self.F, fn2)
+            del src
             _lib.call("qpg_audio_cand_norm2", dev, fn2, self.n_local, self.T, self.aud_t, self.Ga,
                       NUM_AUDIO_FEAT_FRAMES, self.tap_stride, self.cn2)
 
@@ -299,8 +305,9 @@ class CodeKNN:
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
-        _lib.call("qpg_audio_cosine_f64", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
-                  NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, D.stride(0))
+        _lib.call("qpg_audio_cosine_f64" if db.feature_dtype == "f32" else "qpg_audio_cosine_f64_h", dev, db.base,
+                  db.n_local, db.T, db.F, db.aud_t, db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D,
+                  D.stride(0))
         if ev is not None:
             e1.record(torch.cuda.current_stream(dev))
             ev.append((e0, e1))

@@ -96,8 +96,12 @@ __device__ __forceinline__ double cosine_from_dot(double dot, double qn2, double
 // issues 4*MT*NT MFMAs, i.e. (MT+NT)*16 B of L1/L2 traffic per 4*MT*NT*64 matrix-pipe cycles.  At
 // MT=1, NT=3 with f64 queries the kernel was L2->L1 bound (37 B/clk/CU, r01 v1 profile: 31 TF);
 // MT=2, NT=3 with f32 queries needs 13 B/clk/CU.
-template <int MT, int NT, int NTAPS, int KS>
-__global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* __restrict__ base, int N, int T, int F,
+// HALF: the base track is stored in f16 (BASELINE.json configs[4] "fp16 features"): one 16-byte load brings the lane's 8
+// features, widened f16 -> f32 -> f64 in registers; the arithmetic is the same f64 as for an f32 base, applied to the
+// f16-rounded values (so results match the oracle run on the rounded track, not on the original one).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int MT, int NT, int NTAPS, int KS, bool HALF>
+__global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const void* __restrict__ base_, int N, int T, int F,
                                                                const int32_t* __restrict__ cand_t, int G,
                                                                int tap_stride, const double* __restrict__ cn2,
                                                                const float* __restrict__ q32,
@@ -112,8 +116,10 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
   const int64_t c0 = (int64_t)blockIdx.x * (16 * MT);
   const int q0 = blockIdx.y * (NT * 16);
 
-  // A side: this lane's candidate row in each of the MT tiles
-  const float* arow[MT];
+  // A side: this lane's candidate row in each of the MT tiles (element offsets into the base track)
+  const float* base = static_cast<const float*>(base_);
+  const _Float16* baseh = static_cast<const _Float16*>(base_);
+  int64_t aoff[MT];
   int at0[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
     if (c >= C) c = C - 1;
     const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
     at0[mt] = cand_t[g];
-    arow[mt] = base + ((int64_t)j * T + at0[mt]) * F + 8 * kq;
+    aoff[mt] = ((int64_t)j * T + at0[mt]) * F + 8 * kq;
   }
   // B side: this lane's query column in each of the NT tiles
   const int KQ = NTAPS * F;
@@ -158,9 +164,20 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
       // conditional load makes hipcc branch around it and drain vmcnt(0), which serialises the prefetch) and a
       // padded tap reads the context's zero page instead of being selected to zero afterwards
       const bool ok = at0[mt] + tap * tap_stride < T;
-      const float* p = ok ? arow[mt] + (int64_t)tap * tap_stride * F + e0 : zeros;
-      u.a[mt][0] = *reinterpret_cast<const f32x4*>(p);
-      u.a[mt][1] = *reinterpret_cast<const f32x4*>(p + 4);
+      const int64_t o = aoff[mt] + (int64_t)tap * tap_stride * F + e0;
+      if (HALF) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(ok ? reinterpret_cast<const void*>(baseh + o)
+                                                           : reinterpret_cast<const void*>(zeros));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u.a[mt][0][i] = (float)h[i];
+          u.a[mt][1][i] = (float)h[4 + i];
+        }
+      } else {
+        const float* p = ok ? base + o : zeros;
+        u.a[mt][0] = *reinterpret_cast<const f32x4*>(p);
+        u.a[mt][1] = *reinterpret_cast<const f32x4*>(p + 4);
+      }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -252,33 +269,36 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const float* 
 }
 
 template <int MT, int NT>
-static int launch_audio(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F, const int32_t* cand_t,
-                        int G, int tap_stride, const double* cn2, const float* q32, const double* qn2, int Q,
-                        int qtiles_y, double* D, int64_t ldD) {
+static int launch_audio(qpg_ctx* ctx, void* stream, const void* base, bool half, int N, int T, int F,
+                        const int32_t* cand_t, int G, int tap_stride, const double* cn2, const float* q32,
+                        const double* qn2, int Q, int qtiles_y, double* D, int64_t ldD) {
   int64_t C = (int64_t)N * G;
   dim3 grid((unsigned)((C + 16 * MT - 1) / (16 * MT)), (unsigned)qtiles_y);
   // 4 waves (one per SIMD) split the feature axis.  An 8-wave split (finer work units, 6.5 instead of
   // 3.25 rounds of blocks at N_db=2048) measured slower on MI355X: 703 vs 629 us (r01 notes).
-  hipLaunchKernelGGL((audio_cosine_f64_kernel<MT, NT, 6, 4>), grid, dim3(256), 0, qpg_stream(stream), base, N, T, F,
-                     cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros);
+  if (half)
+    hipLaunchKernelGGL((audio_cosine_f64_kernel<MT, NT, 6, 4, true>), grid, dim3(256), 0, qpg_stream(stream), base, N, T,
+                       F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros);
+  else
+    hipLaunchKernelGGL((audio_cosine_f64_kernel<MT, NT, 6, 4, false>), grid, dim3(256), 0, qpg_stream(stream), base, N, T,
+                       F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros);
   QPG_LAUNCH_CHECK("audio_cosine_f64_kernel");
   return QPG_OK;
 }
 
-extern "C" int qpg_audio_cosine_f64(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F,
-                                    const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
-                                    const float* q32, const double* qn2, int Q, double* D, int64_t ldD) {
-  QPG_REQUIRE(ctx && base && cand_t && cn2 && q32 && qn2 && D, "qpg_audio_cosine_f64: null pointer");
-  QPG_REQUIRE(N >= 0 && T > 0 && G > 0 && Q >= 0 && tap_stride > 0 && ldD >= (int64_t)N * G,
-              "qpg_audio_cosine_f64: bad size");
+static int audio_cosine(const char* name, qpg_ctx* ctx, void* stream, const void* base, bool half, int N, int T, int F,
+                        const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2, const float* q32,
+                        const double* qn2, int Q, double* D, int64_t ldD) {
+  QPG_REQUIRE(ctx && base && cand_t && cn2 && q32 && qn2 && D, "%s: null pointer", name);
+  QPG_REQUIRE(N >= 0 && T > 0 && G > 0 && Q >= 0 && tap_stride > 0 && ldD >= (int64_t)N * G, "%s: bad size", name);
   if (n_taps != 6 || F <= 0 || (F % 128) != 0) {
-    qpg_set_error("qpg_audio_cosine_f64: compiled for n_taps=6 and F %% 128 == 0 (got n_taps=%d F=%d)", n_taps, F);
+    qpg_set_error("%s: compiled for n_taps=6 and F %% 128 == 0 (got n_taps=%d F=%d)", name, n_taps, F);
     return QPG_EUNSUP;
   }
   if (N == 0 || Q == 0) return QPG_OK;
   const int qt = (Q + 15) / 16;  // 16-query tiles
   // widest query tile that divides the work without an empty tail: prefer 3 (a 24 s clip is 48 queries)
-#define QPG_AUDIO_ARGS ctx, stream, base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q
+#define QPG_AUDIO_ARGS ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q
 #define QPG_AUDIO_TAIL D, ldD
   if (qt % 3 == 0) return launch_audio<2, 3>(QPG_AUDIO_ARGS, qt / 3, QPG_AUDIO_TAIL);
   if (qt % 4 == 0) return launch_audio<2, 4>(QPG_AUDIO_ARGS, qt / 4, QPG_AUDIO_TAIL);
@@ -288,3 +308,17 @@ extern "C" int qpg_audio_cosine_f64(qpg_ctx* ctx, void* stream, const float* bas
 #undef QPG_AUDIO_ARGS
 }
 
+extern "C" int qpg_audio_cosine_f64(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F,
+                                    const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
+                                    const float* q32, const double* qn2, int Q, double* D, int64_t ldD) {
+  return audio_cosine("qpg_audio_cosine_f64", ctx, stream, base, false, N, T, F, cand_t, G, n_taps, tap_stride, cn2, q32,
+                      qn2, Q, D, ldD);
+}
+
+extern "C" int qpg_audio_cosine_f64_h(qpg_ctx* ctx, void* stream, const void* base_f16, int N, int T, int F,
+                                      const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
+                                      const float* q32, const double* qn2, int Q, double* D, int64_t ldD) {
+  QPG_REQUIRE((reinterpret_cast<uintptr_t>(base_f16) % 16) == 0, "qpg_audio_cosine_f64_h: base must be 16-byte aligned");
+  return audio_cosine("qpg_audio_cosine_f64_h", ctx, stream, base_f16, true, N, T, F, cand_t, G, n_taps, tap_stride, cn2,
+                      q32, qn2, Q, D, ldD);
+}

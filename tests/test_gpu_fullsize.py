@@ -176,6 +176,37 @@ def test_batch16_clips_tables_vs_c_oracle():
         assert np.array_equal(got, want)
 
 
+def test_f16_feature_storage_vs_c_oracle_on_rounded_track():
+    """BASELINE.json configs[4] 'fp16 features': the interpolated WavLM base is stored in f16 and widened in registers
+    (qpg_audio_cosine_f64_h).  Same f64 arithmetic on the ROUNDED values: the tables equal the C oracle run on the
+    f16-rounded track (winners exact, distances <= 1e-13), for a 16-clip batch; and they differ from the f32 tables
+    only through the rounding of the inputs."""
+    import torch
+    from oracle import cref, knn_oracle as O
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    from qpgesture_amd.data_processing import interp_wavlm
+    N, clips, M = 256, 16, 6
+    A = _db(N, 710)
+    te = synth.make_db(clips * M, 711)
+    te_i = interp_wavlm(te["wavlm"])
+    te_c = np.ascontiguousarray(te["context"].squeeze(2))
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0", feature_dtype="f16")
+    assert db.base.dtype == torch.float16
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    ti, tc = torch.from_numpy(te_i).cuda(), torch.from_numpy(te_c).cuda()
+    T = knn.sweep_tables(ti, tc, clips * M)
+    rounded = A["interp"].astype(np.float16).astype(np.float32)
+    q = np.stack([O.wavlm_feat_rows(te_i, w, [24 * s])[0] for w in range(clips * M) for s in range(8)])
+    d_ref, i_ref = cref.audio_scan(rounded, np.arange(26) * 6, A["code"], np.arange(26), q, n_threads=os.cpu_count() or 1)
+    assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref)
+    assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+    db32 = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    T32 = CodeKNN(db32, rng=np.random.RandomState(1)).sweep_tables(ti, tc, clips * M)
+    assert 1e-9 < float((T32["aud_d"] - T["aud_d"]).abs().max()) < 1e-2          # input rounding, nothing else
+    assert torch.equal(T32["txt_d"], T["txt_d"])                                   # the text side is untouched
+
+
 def test_input_validation():
     import torch
     from qpgesture_amd.code_knn import CodeKNN, GestureDB
