@@ -344,6 +344,16 @@ int qpg_vq_encode_f32(qpg_ctx*, void* stream, const qpg_vq_model* m, const float
 int qpg_vq_decode_f32(qpg_ctx*, void* stream, const qpg_vq_model* m, const int64_t* ids, int B, int L, float* ws,
                       int64_t ws_floats, float* out, int32_t* status);
 
+/* Post-decode pose conversion (VisualizeCodebook.py:148-149 + process/process_bvh.py:57-76): poses [dev]
+ * f32 [T][J*9] normalised decoder output (J joints x row-major 3x3) -> de-normalise `p * stdc + mean` (f64; stdc already
+ * clipped at 0.01) -> optional Savitzky-Golay smoothing in time (sg_mid [W], sg_head / sg_tail [W/2][W] coefficient tables
+ * of scipy.signal.savgol_filter(x, W, 2, mode='interp'); NULL = no smoothing) -> orthogonalise each 3x3 like
+ * scipy's Rotation.from_matrix (orthogonal polar factor) -> intrinsic Z-X-Y Euler angles in degrees, euler [dev] f64
+ * [T][J*3].  status [dev] i32: raised to 1 if a matrix has a non-positive determinant (scipy raises ValueError). */
+int qpg_pose_to_euler_f64(qpg_ctx*, void* stream, const float* poses, int64_t T, int J, const double* mean,
+                          const double* stdc, const double* sg_mid, const double* sg_head, const double* sg_tail, int W,
+                          double* euler, int32_t* status);
+
 /* ---- VQ-VAE training step (codebook/train.py:120-148): VQVAE.forward's loss terms, the bottleneck statistics,
  * the EMA codebook update, the loss gradient and Adam.  Reductions are ordered two-stage sums in f64
  * (deterministic).  `ws` is a caller-owned scratch of at least qpg_vq_reduce_ws_bytes() bytes. ---- */

@@ -4,8 +4,13 @@
   --stage inference  visualize_code (:119-154): decode `knn_pred.flatten()` in ONE pass, de-normalise,
                      save <save_path>/<prefix>/generate<prefix>.npy and code<prefix>.npy
 
-Same flags as codebook/configs/parse_args.py:4-18.  BVH / mp4 rendering (the rest of visualizeCodeAndWrite)
-is out of scope.  Run: python -m qpgesture_amd.VisualizeCodebook --config ... --stage inference
+                     then (make_bvh_GENEA2020_BT's own arithmetic, process_bvh.py:57-76, on the device) the ZXY Euler
+                     channel table <prefix>_euler.npy and a minimal <prefix>_generated.bvh carrying it
+                     (--smoothing = its Savitzky-Golay option).
+
+Same flags as codebook/configs/parse_args.py:4-18.  The pymo inverse pipeline (the recorded skeleton) and mp4
+rendering stay out of scope (see qpgesture_amd/bvh.py).
+Run: python -m qpgesture_amd.VisualizeCodebook --config ... --stage inference
 """
 import argparse
 import os
@@ -27,6 +32,8 @@ def build_parser():
     p.add_argument('--step', type=str, default="1")
     p.add_argument('--stage', type=str, default="train")
     p.add_argument('--signature_out', type=str, default='./output/code.npz')      # additive
+    p.add_argument('--smoothing', action='store_true')                            # additive: process_bvh.py:62-68
+    p.add_argument('--no_bvh', action='store_true')                               # additive: stop after the .npy files
     return p
 
 
@@ -62,6 +69,13 @@ def main(argv=None):
         np.save(os.path.join(save_path, 'generate' + args.prefix + '.npy'), out_poses)
         print(out_poses.shape)
         print(out_code.shape)
+        if args.no_bvh:
+            return out_poses, out_code
+        from . import bvh                                                          # :365 make_bvh_GENEA2020_BT
+        euler = bvh.poses_to_euler(poses, cfg.data_mean, cfg.data_std, smoothing=args.smoothing,
+                                   device="cuda:%s" % args.gpu)
+        np.save(os.path.join(save_path, args.prefix + '_euler.npy'), euler)
+        bvh.write_bvh(os.path.join(save_path, args.prefix + '_generated.bvh'), euler)
         return out_poses, out_code
     raise ValueError("stage must be train or inference")
 

@@ -53,6 +53,7 @@ _SIGS = {
     "qpg_convt_f32": [P, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, P],
     "qpg_pad_channels_f32": [P, L, I, I, P],
     "qpg_resblock_f32": [P, I, I, I, P, P, P, P, P],
+    "qpg_pose_to_euler_f64": [P, L, I, P, P, P, P, P, I, P, P],
     "qpg_vq_argmin_f32": [P, P, P, L, I, I, P, P, P],
     "qpg_vq_gather_f32": [P, P, L, I, I, P, P],
     "qpg_vq_encode_f32": [P, P, I, I, P, L, P, P, P],
