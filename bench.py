@@ -416,12 +416,50 @@ def cpu_baseline(a, code, clip, M, N):
         ts.append(time.perf_counter() - t0)
     t = min(ts)
     full = t * N / ns
+    faithful = faithful_loop(interp, ctx, code[:ns], te, clip["context"].squeeze(2), q, qt)
     return {"value": round(240 * M / full, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "faithful_loop": faithful,
             "sample": "audio+text scans of the same %d queries vs the first %d of %d DB windows "
                       "(best of 3: %.2f s, all three %s; scaled linearly to N_db); C port of the reference arithmetic "
                       "(oracle/sweep_ref.c), OpenMP; matching walk excluded (<1%% of CPU time)"
                       % (8 * M, ns, N, t, ["%.2f" % x for x in ts]),
             "sample_seconds": round(t, 3)}
+
+
+def faithful_loop(interp, ctx, code, te_interp, te_ctx, q, qt, n_win=4):
+    """SURVEY §8d CPU baseline (2): the reference's OWN cost structure on this host - a Python loop over candidates that
+    calls sklearn.metrics.pairwise.paired_distances(metric='cosine') once per (query step, candidate), as
+    CodeKNN.search_audio_cands / search_text_cands do (GestureKNN.py:672-690, 713-720) - on a reduced DB of `n_win`
+    windows for the 8 steps of ONE query window.  Ties the C port back to reference-as-is semantics: its distances must
+    equal the port's bit for bit, and its time per (DB window x query window) is what the extrapolation in BASELINE.md
+    §2 is built on."""
+    from sklearn.metrics.pairwise import paired_distances
+    from oracle import cref, knn_oracle as O
+    n = min(n_win, interp.shape[0])
+    g = np.arange(26)
+    t0 = time.perf_counter()
+    da = np.full((8, n * 26), np.nan)
+    dt_ = np.full((8, n * 26), np.nan, np.float32)
+    feat = [O.wavlm_feat_rows(interp, j, list(g * 6)) for j in range(n)]            # (26, 6144) f64 per window
+    for s in range(8):
+        qa, qx = q[s].astype(np.float64), qt[s]
+        for j in range(n):
+            for k in range(26):
+                da[s, j * 26 + k] = paired_distances(qa[None], feat[j][k][None], metric="cosine")[0]
+                dt_[s, j * 26 + k] = paired_distances(qx[None], ctx[j][k][None], metric="cosine")[0]
+    sec = time.perf_counter() - t0
+    # the C port on the same pairs: per-code minima of both must agree exactly
+    d_c, i_c = cref.audio_scan(interp[:n], g * 6, code[:n], g, q[:8], n_threads=1)
+    t_c, j_c = cref.text_scan(ctx[:n], g, code[:n], g, qt[:8], n_threads=1)
+    ok = True
+    for s in range(8):
+        for c_ in range(512):
+            if i_c[s, c_] >= 0:
+                ok &= bool(da[s, i_c[s, c_]] == d_c[s, c_]) and bool(dt_[s, j_c[s, c_]] == t_c[s, c_])
+    per = sec / n                                                                     # s per (DB window x query window)
+    return {"seconds_per_dbwindow_x_querywindow": round(per, 4), "db_windows": n, "sklearn_calls": 8 * n * 26 * 2,
+            "matches_c_port_bit_for_bit": ok,
+            "note": "reference-as-is throughput at N_db windows = 240 frames / (this x N_db) per query window"}
 
 
 if __name__ == "__main__":

@@ -69,7 +69,7 @@ extern "C" int qpg_wavvq_lev_f32(qpg_ctx* ctx, void* stream, const int32_t* sym_
                                  const int32_t* sym_q, int Mq, int Tq, const int32_t* q_win, const int32_t* q_t,
                                  int Q, float* D, int64_t ldD) {
   QPG_REQUIRE(ctx && sym_db && cand_t && tap_off && sym_q && q_win && q_t && D, "qpg_wavvq_lev_f32: null pointer");
-  QPG_REQUIRE(N >= 0 && T > 0 && G > 0 && Mq > 0 && Tq > 0 && Q >= 0 && Q <= 4096 && ldD >= (int64_t)N * G,
+  QPG_REQUIRE(N >= 0 && T > 0 && G > 0 && Mq > 0 && Tq > 0 && Q >= 0 && ldD >= (int64_t)N * G,
               "qpg_wavvq_lev_f32: bad size");
   if (n_taps != LEV_L) {
     qpg_set_error("qpg_wavvq_lev_f32: compiled for %d-symbol strings (got %d)", LEV_L, n_taps);
@@ -79,8 +79,14 @@ extern "C" int qpg_wavvq_lev_f32(qpg_ctx* ctx, void* stream, const int32_t* sym_
   LevTaps taps;   // tap_off is a HOST array of 11 ints (tiny, part of the call like the scalar arguments)
   for (int i = 0; i < LEV_L; ++i) taps.off[i] = tap_off[i];
   const int64_t C = (int64_t)N * G;
-  hipLaunchKernelGGL(wavvq_lev_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), sizeof(int) * (size_t)Q * LEV_L,
-                     qpg_stream(stream), sym_db, N, T, cand_t, G, taps, sym_q, Tq, q_win, q_t, Q, D, ldD);
-  QPG_LAUNCH_CHECK("wavvq_lev_kernel");
+  // the query strings of a launch live in LDS (44 B each): long clips go in chunks of 1024 queries (45 KB)
+  constexpr int QCH = 1024;
+  for (int q0 = 0; q0 < Q; q0 += QCH) {
+    const int qn = Q - q0 < QCH ? Q - q0 : QCH;
+    hipLaunchKernelGGL(wavvq_lev_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), sizeof(int) * (size_t)qn * LEV_L,
+                       qpg_stream(stream), sym_db, N, T, cand_t, G, taps, sym_q, Tq, q_win + q0, q_t + q0, qn,
+                       D + (int64_t)q0 * ldD, ldD);
+    QPG_LAUNCH_CHECK("wavvq_lev_kernel");
+  }
   return QPG_OK;
 }

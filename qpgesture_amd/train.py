@@ -114,6 +114,7 @@ def main(argv=None):
             model.k_elem = ck["k_elem"].to(dev) if "k_elem" in ck else torch.ones(model.bins, device=dev)
         start_epoch = int(ck.get("epoch") or 0) + 1
     else:
+        ck = None
         model.load_state_dict(init_state_dict(cfg.VQVAE, 15 * 9, seed=seed))
     opt = Adam(model.parameters(), lr=cfg.lr, betas=cfg.betas)
     sched = MultiStepLR(opt, milestones=cfg.milestones, gamma=cfg.gamma)
@@ -122,6 +123,14 @@ def main(argv=None):
     if rank == 0:
         os.makedirs(save_dir, exist_ok=True)
     best = (1e2, 0)
+    if ck is not None:
+        # additive checkpoint keys of this implementation (a reference checkpoint has none of them: weights-only resume)
+        if ck.get("optimizer") is not None:
+            lr_now = opt.lr
+            opt.load_state_dict(ck["optimizer"])
+            opt.lr = lr_now                                      # the schedule above is authoritative
+        if ck.get("best") is not None:
+            best = (float(ck["best"][0]), int(ck["best"][1]))
     updates = 0
     per_rank = batch // world
     n_batches = train.shape[0] // batch                          # drop_last=True (train.py:62)
@@ -138,9 +147,13 @@ def main(argv=None):
         if rank == 0 and (is_best or epoch % cfg.save_per_epochs == 0):
             name = ("%s/%s_checkpoint_best.bin" if is_best else "%s/%s_checkpoint_%03d.bin")
             name = name % ((save_dir, cfg.name) if is_best else (save_dir, cfg.name, epoch))
-            torch.save({"args": dict(cfg), "epoch": epoch, "model_dict": model.state_dict(prefix="module."),
+            # 'args' as PLAIN nested dicts / lists (no class of this package inside the pickle), so that the reference's
+            # own VisualizeCodebook / make_beat_dataset can torch.load the file; optimizer moments and the best-so-far
+            # record ride along for --resume
+            torch.save({"args": _plain(cfg), "epoch": epoch, "model_dict": model.state_dict(prefix="module."),
                         "k_init": model.k_init, "k_sum": None if model.k_sum is None else model.k_sum.cpu(),
-                        "k_elem": None if model.k_elem is None else model.k_elem.cpu()}, name)
+                        "k_elem": None if model.k_elem is None else model.k_elem.cpu(),
+                        "optimizer": opt.state_dict(), "best": [float(best[0]), int(best[1])]}, name)
             logging.info("Saved the checkpoint")
         model.train()
         perm = torch.randperm(train.shape[0])                    # shuffle=True; identical on every rank (same seed)
@@ -169,6 +182,19 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     return model
+
+
+def _plain(x):
+    """AttrDict / tuples / NumPy scalars -> plain dict / list / Python scalars, recursively."""
+    if isinstance(x, dict):
+        return {str(k): _plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_plain(v) for v in x]
+    if isinstance(x, np.generic):
+        return x.item()
+    if isinstance(x, np.ndarray):
+        return x.tolist()
+    return x
 
 
 if __name__ == "__main__":

@@ -51,6 +51,62 @@ def test_fullsize_tables_vs_c_oracle():
     assert np.array_equal(T["aud_rank"].cpu().numpy(), want)
 
 
+def test_speaker1_class_db_8192_windows_vs_c_oracle():
+    """BASELINE.json configs[3]'s workload on ONE GPU: N_db = 8192 windows (212 992 candidates, 6 GB resident base), one
+    24 s clip.  Per-code winners of both sweeps equal the C port's, text distances bit-exact, audio <= 1e-13, ranks equal;
+    and the two-way row-sharded tables merged by qpg_merge_select_* equal the unsharded ones (what --scaling strong does
+    across GPUs, minus the collective)."""
+    import torch
+    from oracle import cref, knn_oracle as O
+    from qpgesture_amd import _lib, synth
+    from qpgesture_amd.code_knn import ABSENT_DIST, CodeKNN, GestureDB
+    from qpgesture_amd.data_processing import interp_wavlm
+    import bench
+    N, M = 8192, 6
+    interp, ctx = bench.chunked_db(N, 0, N, seed=0)
+    code = synth.make_codes(N, 2)
+    phase = np.zeros((N, 240, 4, 8), np.float32)
+    sig = synth.make_signature(3)
+    te = synth.make_db(M, 1000)
+    te_i = interp_wavlm(te["wavlm"])
+    te_c = np.ascontiguousarray(te["context"].squeeze(2))
+    db = GestureDB(code, interp, ctx, phase, sig, device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    ti, tc = torch.from_numpy(te_i).cuda(), torch.from_numpy(te_c).cuda()
+    T = knn.sweep_tables(ti, tc, M)
+    cores = os.cpu_count() or 1
+    q = np.stack([O.wavlm_feat_rows(te_i, w, [24 * s])[0] for w in range(M) for s in range(8)])
+    d_ref, i_ref = cref.audio_scan(interp, np.arange(26) * 6, code, np.arange(26), q, n_threads=cores)
+    assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref) and np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+    qt = np.stack([te_c[w][int(24 * s / 180 * 30)] for w in range(M) for s in range(8)])
+    dt_ref, it_ref = cref.text_scan(ctx, np.arange(26), code, np.arange(26), qt, n_threads=cores)
+    assert np.array_equal(T["txt_d"].cpu().numpy(), dt_ref) and np.array_equal(T["txt_idx"].cpu().numpy(), it_ref)
+    assert np.array_equal(T["aud_rank"].cpu().numpy(), np.argsort(np.argsort(d_ref, axis=1, kind="stable"), axis=1, kind="stable"))
+    del db, knn
+    torch.cuda.empty_cache()
+    # two row shards on the same GPU, merged by the HIP kernel (no collective: both halves are local here)
+    parts = []
+    for r in range(2):
+        dbr = GestureDB(code, bench._ShardView(interp[r * 4096:(r + 1) * 4096], r * 4096, (r + 1) * 4096, N),
+                        bench._ShardView(ctx[r * 4096:(r + 1) * 4096], r * 4096, (r + 1) * 4096, N), phase, sig,
+                        device="cuda:0", rank=r, world=2)
+        kr = CodeKNN(dbr, rng=np.random.RandomState(1))
+        steps = kr.n_steps()
+        q_win = np.repeat(np.arange(M), steps)
+        q_t = np.tile(np.arange(steps) * 24, M)
+        d_, i_ = kr.sweep_audio(ti, q_win, q_t, reduce=False)
+        parts.append((d_.clone(), i_.clone()))
+        del dbr, kr
+        torch.cuda.empty_cache()
+    Q, K = parts[0][0].shape
+    buf = torch.cat([torch.cat((d_.reshape(-1).view(torch.uint8), i_.reshape(-1).view(torch.uint8))) for d_, i_ in parts])
+    od = torch.empty((Q, K), dtype=torch.float64, device="cuda:0")
+    oi = torch.empty((Q, K), dtype=torch.int32, device="cuda:0")
+    _lib.call("qpg_merge_select_f64", torch.device("cuda:0"), buf, 2, buf.numel() // 2, 0, Q * K * 8, Q, K,
+              float(ABSENT_DIST), od, oi, None)
+    assert torch.equal(oi, T["aud_idx"]) and torch.equal(od, T["aud_d"])
+
+
 def test_planted_match_and_duplicates():
     """A query that IS a database candidate gets distance ~0 for that candidate's code and wins it; an exact
     duplicate of that window later in the DB ties and must lose (first wins == lowest index)."""

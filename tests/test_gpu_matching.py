@@ -339,3 +339,38 @@ def test_text_exact_ties_vs_reference_golden():
     assert uniq.sum() > 0 and np.array_equal(r2[uniq], g["step_txt_score"][uniq])
     zero = g["txt_dist"] == 0
     assert (r2[zero] < zero.sum(axis=1).max()).all()
+
+
+def test_second_device_when_present():
+    """a GestureDB on cuda:1 while the caller's current device is cuda:0 (every C entry point launches on
+    the CURRENT device: _lib.call switches).  Skipped on 1-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    g = load_golden(GOLDENS[0])
+    torch.cuda.set_device(0)
+    A, db, knn, te_i, te_c, M = _build(g["meta"], dev="cuda:1", freq_rank=g["step_freq_score"])
+    assert torch.cuda.current_device() == 0
+    codes, _, _ = knn.match_clip(te_i, te_c, M)
+    assert np.array_equal(codes, g["knn_pred"]) and torch.cuda.current_device() == 0
+
+
+def test_long_wavvq_clip_chunks_the_query_strings():
+    """more than 1489 query strings used to exceed the LDS of one launch; qpg_wavvq_lev_f32 now walks the
+    queries in chunks of 1024.  2000 queries against a small DB: identical to the same queries issued 500 at a time."""
+    import torch
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    tr = synth.make_db(24, 90, 8)
+    te = synth.make_db(250, 91, 8)
+    from oracle import knn_oracle as O
+    db = GestureDB(synth.make_codes(24, 92), O.interp_wavlm(tr["wavlm"]), tr["context"].squeeze(2), tr["phase_dense"],
+                   synth.make_signature(93), device="cuda:0", wavvq=tr["wavvq"])
+    knn = CodeKNN(db, use_wavlm=False, use_wavvq=True, rng=np.random.RandomState(2))
+    q_win = np.repeat(np.arange(250), 8)
+    q_t = np.tile(np.array([int(i) for i in knn.query_positions()]), 250)
+    d_all, i_all = knn.sweep_audio_wavvq(te["wavvq"], q_win, q_t)
+    assert d_all.shape == (2000, 512)
+    for lo in range(0, 2000, 500):
+        d, i = knn.sweep_audio_wavvq(te["wavvq"], q_win[lo:lo + 500], q_t[lo:lo + 500])
+        assert torch.equal(d, d_all[lo:lo + 500]) and torch.equal(i, i_all[lo:lo + 500])

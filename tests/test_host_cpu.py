@@ -23,7 +23,8 @@ def test_bindings_cover_the_header():
     declared = set(_lib.declared_symbols())
     bound = set(_lib._SIGS) | {"qpg_version", "qpg_ctx_create", "qpg_ctx_destroy", "qpg_last_error",
                                "qpg_vq_workspace_floats", "qpg_vq_reduce_ws_bytes",
-                               "qpg_conv1d_wgrad_ws_floats", "qpg_vq_code_sums_ws_bytes"}
+                               "qpg_conv1d_wgrad_ws_floats", "qpg_vq_code_sums_ws_bytes",
+                               "qpg_text_percode_ws_bytes"}
     assert declared == bound
 
 
@@ -192,3 +193,84 @@ def test_ctypes_signatures_match_the_header():
         want = [kind_of_c(a) for a in args[2:]]
         got = [kind_of_ct(t) for t in sig]
         assert got == want, (name, got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2 host logic
+# ---------------------------------------------------------------------------------------------------------------
+def test_tpack_layout_matches_its_definition():
+    """vqvae.tpack: out[n // nb][kb][g][n % nb][j] = W[k = 16 kb + 4 g + j][n], k = tap * cin_pad + ci, zero padded
+    (what csrc/qpg_convt.hip's fragment reads and LDS-DMA stages assume)."""
+    import torch
+    from qpgesture_amd.vqvae import tpack
+    g = torch.Generator().manual_seed(0)
+    taps, cin, cout, cin_pad, nb = 3, 20, 135, 32, 128
+    w = torch.randn((taps, cin, cout), generator=g)
+    p = tpack(w, cin_pad, nb).view(2, taps * cin_pad // 16, 4, nb, 4)
+    for (n, tap, ci) in [(0, 0, 0), (134, 2, 19), (127, 1, 7), (128, 0, 16), (5, 2, 3)]:
+        k = tap * cin_pad + ci
+        assert p[n // nb, k // 16, (k % 16) // 4, n % nb, k % 4] == w[tap, ci, n]
+    assert float(p[1, :, :, 7:, :].abs().max()) == 0.0                      # channels >= 135 are padding
+    k = 0 * cin_pad + 25                                                     # input channel >= cin is padding
+    assert float(p[:, k // 16, (k % 16) // 4, :, k % 4].abs().max()) == 0.0
+
+
+def test_exchange_layout_offsets():
+    from qpgesture_amd.code_knn import ExchangeLayout
+    lay = ExchangeLayout(96, 512, 4, ["aud", "txt"], True, "cpu")
+    n = 24 * 512
+    assert lay.Qb == 24 and lay.off == {"aud_d": 0, "aud_i": 8 * n, "txt_d": 12 * n, "txt_i": 16 * n}
+    assert lay.block_bytes == 20 * n and lay.send.numel() == 4 * 20 * n
+    d, i, qb, bs = lay.views("aud")
+    assert d.dtype.is_floating_point and d.element_size() == 8 and d.numel() == n and (qb, bs) == (24, 20 * n)
+    one = ExchangeLayout(48, 512, 1, ["aud"], False, "cpu")                 # wavvq audio: f32 distances, all-gather
+    assert one.views("aud")[0].element_size() == 4 and one.views("aud")[2:] == (0, 0)
+    with pytest.raises(AssertionError):
+        ExchangeLayout(50, 512, 4, ["aud"], True, "cpu")
+
+
+def test_savgol_tables_and_bvh_writer(tmp_path):
+    """bvh.savgol_tables == scipy.signal.savgol_filter(x, 15, 2) (mode='interp'), and the minimal BVH round-trips its
+    channel table."""
+    from scipy.signal import savgol_filter
+    from qpgesture_amd import bvh
+    mid, head, tail = bvh.savgol_tables(15, 2)
+    x = np.random.default_rng(0).standard_normal(40)
+    want = savgol_filter(x, 15, 2)
+    got = np.array([head[t] @ x[:15] if t < 7 else (tail[t - 33] @ x[25:] if t >= 33 else mid @ x[t - 7:t + 8])
+                    for t in range(40)])
+    assert np.abs(got - want).max() < 1e-12
+    e = np.random.default_rng(1).uniform(-170, 170, size=(5, 45))
+    order = bvh.write_bvh(str(tmp_path / "x.bvh"), e)
+    txt = open(str(tmp_path / "x.bvh")).read().splitlines()
+    assert sorted(order) == list(range(15)) and order[0] == 0
+    m = txt.index("MOTION")
+    rows = np.array([l.split() for l in txt[m + 3:]], float)
+    cols = np.concatenate([np.arange(3 * i, 3 * i + 3) for i in order])
+    assert rows.shape == (5, 45) and np.abs(rows - e[:, cols]).max() < 1e-5
+    assert txt[m + 1] == "Frames: 5" and txt.count("\tEnd Site") + sum("End Site" in l for l in txt) >= 3
+
+
+def test_synth_variants_plant_what_they_say():
+    from qpgesture_amd import synth
+    tr, te, code = synth.make_db(48, 30), synth.make_db(2, 31), synth.make_codes(48, 32)
+    synth.apply_variant(tr, te, code, "neartie")
+    assert np.array_equal(te["wavlm"][0], tr["wavlm"][5]) and np.array_equal(tr["wavlm"][22], tr["wavlm"][5])
+    d = tr["wavlm"][20] != tr["wavlm"][5]
+    assert 0 < d.mean() < 0.02 and np.array_equal(code[20], code[5]) and not np.array_equal(code[21], code[5])
+    assert np.abs(tr["wavlm"][20][d] / tr["wavlm"][5][d] - 1).max() < 2e-7          # one float32 ulp
+    tr2, te2, code2 = synth.make_db(48, 40), synth.make_db(2, 41), synth.make_codes(48, 42)
+    synth.apply_variant(tr2, te2, code2, "texttie")
+    ctx = tr2["context"].reshape(-1, 384)
+    assert len(np.unique(ctx, axis=0)) < 0.7 * len(ctx)                              # many identical rows
+    with pytest.raises(ValueError):
+        synth.apply_variant(tr, te, code, "nope")
+
+
+def test_numpy_ranks_is_the_reference_expression():
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN
+    d = torch.tensor([[0.5, 0.0, 0.0, 1e3, 0.25], [3.0, 2.0, 1.0, 0.0, 1e3]], dtype=torch.float32)
+    r = CodeKNN.numpy_ranks(d).numpy()
+    for row, got in zip(d.numpy(), r):
+        assert np.array_equal(got, np.array(list(row.astype(np.float64))).argsort().argsort())
