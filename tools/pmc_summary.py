@@ -20,6 +20,20 @@ for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
         acc[k][c].append(v)
     for (d, k), v in t.items():
         dur[k].append(v)
+for f in glob.glob(path + "/**/*_results.db", recursive=True):      # rocpd SQLite output (no --output-format csv)
+    import sqlite3
+    per = collections.defaultdict(float)
+    t = {}
+    for did, name, grid, wg, cname, val, a, b in sqlite3.connect(f).execute(
+            "select dispatch_id, kernel_name, grid_size, workgroup_size, counter_name, value, start, end "
+            "from counters_collection"):
+        k = (name[:48], int(grid) // max(int(wg), 1))
+        per[(did, k, cname)] += float(val)
+        t[(did, k)] = (b - a) / 1e3
+    for (d, k, c), v in per.items():
+        acc[k][c].append(v)
+    for (d, k), v in t.items():
+        dur[k].append(v)
 for k, cs in sorted(acc.items()):
     if flt and flt not in k[0]:
         continue
