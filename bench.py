@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--n-db", type=int, default=None, help="DB windows (default 2048; 8192 with --scaling strong)")
     ap.add_argument("--windows", type=int, default=6)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--audio-precision", choices=["mixed", "f64"], default="mixed",
+                    help="mixed (default, the product default): f32 matrix-core sweep with an a-priori error bound + f64 / "
+                         "reference-arithmetic re-evaluation of every undecided comparison; f64: the f64 matrix-core sweep")
     ap.add_argument("--clips", type=int, default=1, help="concurrent clips per GPU in one batched sweep")
     ap.add_argument("--encode-batch", type=int, default=0, help="pose windows VQ-VAE-encoded inside the timed step")
     ap.add_argument("--feature-dtype", choices=["f32", "f16"], default="f32")
@@ -123,6 +126,9 @@ def main():
                    feature_dtype=a.feature_dtype)
     knn = CodeKNN(db, rng=np.random.RandomState(123456))
     knn.overlap_sweeps = not a.no_overlap
+    knn.audio_precision = a.audio_precision
+    # the mixed-precision sweep is taken where CodeKNN.sweep_audio can take it (one GPU, f32 base); see its comment
+    mixed = a.audio_precision == "mixed" and world == 1 and a.feature_dtype == "f32"
 
     # clips: weak = CL per rank (every rank holds all of them: M*180*1024 f32 = 4.4 MB each); strong = ONE clip in all
     n_clips = CL if strong else CL * world
@@ -189,12 +195,16 @@ def main():
     achieved = flops / (k_ms * 1e-3) / 1e12
     alg_bytes = db.n_local * 81 * db.F * fb + C * 8 + Q * 6 * db.F * 4 + Q * C * 8
     default_shape = world == 1 and N == 2048 and M == 6 and CL == 1 and fb == 4
-    roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4),
+    peak = F32_MFMA_PEAK_TFLOPS if mixed else F64_MFMA_PEAK_TFLOPS
+    roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4),
                 # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
                 # measured for exactly this launch shape only: profiles/r02_pmc_audio.md
-                "traffic": AUDIO_TRAFFIC_BYTES if default_shape else None,
-                "kernel": "audio_cosine_f64_kernel", "kernel_ms": round(k_ms, 4),
+                "traffic": (AUDIO_MX_TRAFFIC_BYTES if mixed else AUDIO_TRAFFIC_BYTES) if default_shape else None,
+                "kernel": ("audio_cosine_mx2_kernel + audio_cosine_mx_kernel (one sweep: LDS-shared-query blocks + "
+                           "split-K remainder; f32 matrix cores, error bounded a priori, f64 re-evaluation in the select)")
+                if mixed else "audio_cosine_f64_kernel",
+                "kernel_ms": round(k_ms, 4),
                 "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_launches_timed": len(ms),
                 "algorithmic_gflop": round(flops / 1e9, 3),
                 "algorithmic_bytes": int(alg_bytes),
@@ -208,21 +218,45 @@ def main():
         par = ("db-row-shard x%d + all-to-all(min,index)" % world) if world > 1 else "single GPU, unsharded DB"
     out = {"metric": "matched gesture frames/sec (GestureKNN)", "value": round(value, 1), "unit": "frames/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-           "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
+           "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+           "dtype": "f32 sweep + f64 re-evaluation" if mixed else "f64",
            "data": "synthetic",
            "config": {"workload": "%d x 24 s clip%s (M=%d windows, Q=%d steps, %d frames each) %s vs speaker-%s-class DB "
-                                  "N_db=%d windows (%d candidates), shipped mode wavlm_feat(f64)+text(f32)+phase%s%s"
+                                  "N_db=%d windows (%d candidates), shipped mode wavlm_feat(%s)+text(f32)+phase%s%s"
                                   % (n_clips, "s" if n_clips > 1 else "", M, M * 8, 240 * M,
                                      "in all" if strong else "per job", "1" if N >= 8192 else "10", N, N * 26,
-                                     ", WavLM base stored f16" if fb == 2 else "",
+                                     "f32-bounded/f64-exact" if mixed else "f64", ", WavLM base stored f16" if fb == 2 else "",
                                      (", + VQ-VAE encode of %d pose windows in the step" % a.encode_batch)
                                      if a.encode_batch else ""),
                       "n_db": N, "windows_per_clip": M, "clips": n_clips, "clips_per_gpu": CL,
-                      "feature_dtype": a.feature_dtype, "encode_batch": a.encode_batch, "parallelism": par},
+                      "feature_dtype": a.feature_dtype, "audio_precision": "mixed" if mixed else "f64",
+                      "encode_batch": a.encode_batch, "parallelism": par},
            "roofline": roofline,
            "realtime_factor": round(24.0 * M / 6 / (dt / a.steps), 1) if strong
            else round(value / 60.0 / world, 1)}
 
+    if mixed:
+        # re-evaluation activity of the timed steps (+ warm-up) and the same clip through the f64 sweep: the mixed path
+        # must return the same codes (its tables differ only inside the sweep's error bound)
+        st = knn.mixed_stats()
+        n_run = a.steps + a.warmup
+        k64 = CodeKNN(db, rng=np.random.RandomState(123456))
+        k64.audio_precision = "f64"
+        T64 = k64.sweep_tables(te_interp, te_ctx, M * n_clips)
+        same = True
+        for c in range(my_clips):
+            w64 = k64.walk(T64, M, window_offset=c * M, seed_code=seed_code, seed_phase=seed_phase_d)[0]
+            same = same and bool(np.array_equal(np.asarray(w64).reshape(-1),
+                                                codes.numpy().reshape(my_clips, -1)[c].astype(np.int64)))
+        Tm = knn.sweep_tables(te_interp, te_ctx, M * n_clips)
+        out["mixed_precision"] = {
+            "f64_dot_pairs_per_step": round(st["tier1_pairs"] / n_run, 1),
+            "reference_arithmetic_pairs_per_step": round(st["tier2_pairs"] / n_run, 2),
+            "flags": st["flags"], "error_bound": 1.92e-6,
+            "max_table_difference_vs_f64_sweep": float((Tm["aud_d"] - T64["aud_d"]).abs().max()),
+            "winners_equal_f64_sweep": bool(torch.equal(Tm["aud_idx"], T64["aud_idx"])),
+            "ranks_equal_f64_sweep": bool(torch.equal(Tm["aud_rank"], T64["aud_rank"])),
+            "codes_equal_f64_sweep": same}
     if not a.no_vqvae:
         out.update(vqvae_bench(dev, a, world, rank))
     if rank == 0 and world == 1 and CL == 1 and not a.no_cold and fb == 4:
@@ -254,6 +288,7 @@ def main():
 # HBM bytes per audio_cosine_f64_kernel launch at the default shape (N_db=2048, Q=48), rocprofv3 PMC, separate
 # --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 correction on FETCH_SIZE: profiles/r02_pmc_audio.md
 AUDIO_TRAFFIC_BYTES = 923_000_000
+AUDIO_MX_TRAFFIC_BYTES = None      # mixed-precision sweep: not measured yet
 
 
 def vqvae_bench(dev, a, world, rank):

@@ -101,6 +101,18 @@ int qpg_audio_cosine_f64_h(qpg_ctx*, void* stream, const void* base_f16, int N, 
                            const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
                            const float* q32, const double* qn2, int Q, double* D, int64_t ldD);
 
+/* MIXED-PRECISION form of qpg_audio_cosine_f64 (round 2; the default single-GPU path of CodeKNN.sweep_audio): the same
+ * sweep on the f32 matrix cores, with every f32 accumulation chain limited to 32 products and summed in f64, which
+ * bounds the result's error A PRIORI: |D[q][c] - exact| <= QPG_AUDIO_MX_ERR for every pair, whatever the data
+ * (derivation: qpgesture_amd/csrc/qpg_audio.hip).  Meant to be consumed by qpg_percode_select_mixed_f64, which
+ * re-evaluates every comparison the bound leaves undecided, so the selected candidates and ranks are those of the
+ * f64 path.  stats: [dev] i32 [4] (may be NULL): [1] |= 2 if a pair with 0 < |q||c| < 1e-16 was met (operand products
+ * could underflow f32, which the bound excludes). */
+#define QPG_AUDIO_MX_ERR 1.92e-6
+int qpg_audio_cosine_mx(qpg_ctx*, void* stream, const float* base, int N, int T, int F, const int32_t* cand_t, int G,
+                        int n_taps, int tap_stride, const double* cn2, const float* q32, const double* qn2, int Q,
+                        double* D, int64_t ldD, int32_t* stats);
+
 /* One-off DB preparation for the text sweep: sklearn-normalise the grid rows x[j][cand_r[g]] (bit-exact,
  * as qpg_l2_normalize_rows_f32) and store them tiled for lane-per-candidate access:
  *   xt[c/64][e/4][c%64][e%4],  c = j*G + g   (a wave's 64 lanes read 64 consecutive 16-B pieces).
@@ -195,6 +207,27 @@ int qpg_percode_select_guarded_f64(qpg_ctx*, void* stream, const double* D, int6
                                    int16_t* out_rank, int q_block, int64_t block_stride, const float* base, int T, int F,
                                    const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32, double eps,
                                    int32_t* stats);
+
+/* Select for the matrix of qpg_audio_cosine_mx.  Same outputs as qpg_percode_select_guarded_f64.  Two sweep values
+ * further apart than eps1 (>= 2 x QPG_AUDIO_MX_ERR) are ordered like the exact distances; inside that band
+ *   tier 1: all candidates within eps1 of their code's minimum (if two or more) and the winners of codes whose minima
+ *           are rank neighbours within eps1 get an f64 dot product (error ~1e-15, like qpg_audio_cosine_f64);
+ *   tier 2: on those values, the near-tie guard above with band eps2 (the reference's own arithmetic; 0 = off).
+ * out_dist holds the sweep value (error <= QPG_AUDIO_MX_ERR) for untouched codes, the re-evaluated one otherwise.
+ * Pass out_rank: without it the minima of different codes are not protected against each other.
+ * qn2 [dev] f64 [Q], cn2 [dev] f64 [C]: the sweep's squared norms.  stats [dev] i32 [4]: [0] += tier-2 pairs,
+ * [1] |= 1 if a list overflowed (2048 tier-1 / 256 tier-2 entries per query; results then unguarded), [2] += tier-1
+ * pairs.  K <= 512. */
+int qpg_percode_select_mixed_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int16_t* cand_code,
+                                 int64_t C, int K, double absent, int32_t idx_base, double* out_dist, int32_t* out_idx,
+                                 int16_t* out_rank, int q_block, int64_t block_stride, const float* base, int T, int F,
+                                 const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32,
+                                 const double* qn2, const double* cn2, double eps1, double eps2, int32_t* stats,
+                                 void* ws, int64_t ws_bytes);
+/* ws: [dev] scratch of qpg_percode_select_mixed_ws_bytes(Q, K) bytes, 16-byte aligned — with it the call is three
+ * launches (lists | tier-1 dot products on every CU | merge, tier 2, ranks); NULL: one launch, each query's tier-1 work
+ * on its own CU (slower when the lists are long). */
+int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K);
 
 /* Cross-shard min + index merge after the RCCL exchange (the all-reduce(min, index) `north_star`
  * names, as all-gather / all-to-all + this kernel): source w's tables start at recv + w*src_stride (+ dist_off for the

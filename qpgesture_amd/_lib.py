@@ -10,7 +10,8 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqpg_hip.so")
+# QPG_LIB_PATH: kernel experiments only (a variant build of the same sources); the product is the in-tree library
+LIB_PATH = os.environ.get("QPG_LIB_PATH") or os.path.join(_HERE, "libqpg_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "qpg.h")
 
 _lib = None
@@ -30,6 +31,7 @@ _SIGS = {
     "qpg_audio_pack_queries": [P, I, I, I, P, P, I, I, I, P, P],
     "qpg_audio_cosine_f64": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
     "qpg_audio_cosine_f64_h": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
+    "qpg_audio_cosine_mx": [P, I, I, I, P, I, I, I, P, P, P, I, P, L, P],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
     "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
     "qpg_text_percode_f32": [P, L, I, P, I, P, I, I, ctypes.c_int32, c_float, P, L, P, P, P, P],
@@ -41,6 +43,8 @@ _SIGS = {
     "qpg_percode_select_f32": [P, L, I, P, L, I, c_float, ctypes.c_int32, P, P, P, I, L],
     "qpg_percode_select_guarded_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
                                        c_double, P],
+    "qpg_percode_select_mixed_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
+                                     P, P, c_double, c_double, P, P, L],
     "qpg_merge_select_f64": [P, I, L, L, L, I, I, c_double, P, P, P],
     "qpg_merge_select_f32": [P, I, L, L, L, I, I, c_float, P, P, P],
     "qpg_percode_argmin_f64": [P, L, I, P, I, I, P, I, I, c_double, ctypes.c_int32, P, P],
@@ -125,6 +129,8 @@ def load():
     lib.qpg_vq_code_sums_ws_bytes.restype = c_int64
     lib.qpg_text_percode_ws_bytes.argtypes = [c_int64, c_int, c_int, c_int]
     lib.qpg_text_percode_ws_bytes.restype = c_int64
+    lib.qpg_percode_select_mixed_ws_bytes.argtypes = [c_int, c_int]
+    lib.qpg_percode_select_mixed_ws_bytes.restype = c_int64
     lib.qpg_vq_reduce_ws_bytes.argtypes = []
     lib.qpg_vq_reduce_ws_bytes.restype = c_int64
     for name, sig in _SIGS.items():

@@ -19,6 +19,11 @@ from .constant import (ABSENT_DIST, NUM_AUDIO_FEAT_FRAMES, STEP_SZ, WAVVQ_GROUP_
                        num_frames_code)
 
 MODE_AUD_TXT, MODE_AUD, MODE_TXT = 0, 1, 2
+# mixed-precision audio sweep: a-priori error bound of qpg_audio_cosine_mx (QPG_AUDIO_MX_ERR of include/qpg.h) and the
+# band inside which qpg_percode_select_mixed_f64 re-evaluates (two values further apart than 2 x the bound are ordered
+# like the exact distances; 5 % margin on top)
+AUDIO_MX_ERR = 1.92e-6
+AUDIO_MX_BAND = 2.1 * AUDIO_MX_ERR
 
 
 # ----------------------------------------------------------------------------------------------
@@ -250,7 +255,14 @@ class CodeKNN:
         # Near-tie guard of the audio select (qpg_percode_select_guarded_f64): candidates / code minima closer than
         # tie_eps are re-evaluated in the reference's own arithmetic inside the select launch.  0 disables it.
         self.tie_eps = 1e-12
-        self._guard_stats = torch.zeros((2,), dtype=torch.int32, device=db.device)
+        self._guard_stats = torch.zeros((4,), dtype=torch.int32, device=db.device)
+        # audio_precision "mixed" (default): the sweep runs on the f32 matrix cores with an a-priori error bound
+        # (qpg_audio_cosine_mx, |error| <= AUDIO_MX_ERR) and the select re-evaluates every comparison the bound leaves
+        # open with f64 dot products, then the near-tie guard (qpg_percode_select_mixed_f64): same candidates and ranks
+        # as "f64", the sweep at twice the matrix rate.  Taken only where the select sees every comparison that
+        # follows (single-GPU DB, ranks fused, f32 base, guard on); everything else runs the f64 sweep.
+        self.audio_precision = "mixed"
+        self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
         # host_ranks (the CLI's --tie_rule numpy): rank the (Q,512) audio / text minima with the reference's own
         # `np.array(x).argsort().argsort()` on the host, so that EXACT ties between codes (structural in real text
         # embeddings: silent frames share one vector) get NumPy's unstable-sort order like the reference's.
@@ -305,9 +317,16 @@ class CodeKNN:
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
-        _lib.call("qpg_audio_cosine_f64" if db.feature_dtype == "f32" else "qpg_audio_cosine_f64_h", dev, db.base,
-                  db.n_local, db.T, db.F, db.aud_t, db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D,
-                  D.stride(0))
+        fused_rank = want_rank and db.world == 1
+        mixed = (self.audio_precision == "mixed" and fused_rank and reduce and out is None and self.tie_eps > 0
+                 and db.feature_dtype == "f32" and C > 0 and db.K <= 512)
+        if mixed:
+            _lib.call("qpg_audio_cosine_mx", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
+                      NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, D.stride(0), self._guard_stats)
+        else:
+            _lib.call("qpg_audio_cosine_f64" if db.feature_dtype == "f32" else "qpg_audio_cosine_f64_h", dev, db.base,
+                      db.n_local, db.T, db.F, db.aud_t, db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2,
+                      Q, D, D.stride(0))
         if ev is not None:
             e1.record(torch.cuda.current_stream(dev))
             ev.append((e0, e1))
@@ -317,9 +336,18 @@ class CodeKNN:
             dist = torch.empty((Q, db.K), dtype=torch.float64, device=dev)
             idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
             qb = bs = 0
-        fused_rank = want_rank and db.world == 1
         rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if fused_rank else None
-        if self.tie_eps > 0 and C > 0 and db.feature_dtype == "f32":
+        if mixed:
+            need = int(_lib.load().qpg_percode_select_mixed_ws_bytes(Q, db.K))
+            ws = getattr(self, "_mix_ws", None)
+            if ws is None or ws.numel() < need:
+                ws = self._mix_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+            _lib.call("qpg_percode_select_mixed_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K,
+                      float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
+                      db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2, AUDIO_MX_BAND, float(self.tie_eps),
+                      self._guard_stats, None if self.mixed_single_launch else ws,
+                      0 if self.mixed_single_launch else ws.numel())
+        elif self.tie_eps > 0 and C > 0 and db.feature_dtype == "f32":
             _lib.call("qpg_percode_select_guarded_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K,
                       float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
                       db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, float(self.tie_eps), self._guard_stats)
@@ -436,9 +464,16 @@ class CodeKNN:
         return allreduce_min_index(dist, idx)
 
     def guard_stats(self):
-        """(re-evaluated (query, candidate) pairs so far, overflow flag) of the near-tie guard."""
+        """(pairs re-evaluated in the reference's arithmetic so far, trouble flag) of the near-tie guard; the flag is
+        set by a list overflow or, on the mixed-precision path, by operand norms small enough to void its error bound."""
         v = self._guard_stats.cpu().numpy()
         return int(v[0]), bool(v[1])
+
+    def mixed_stats(self):
+        """Mixed-precision audio path: pairs re-evaluated with an f64 dot product so far (tier 1), pairs re-evaluated
+        in the reference's arithmetic (tier 2), raw flag word (1 = list overflow, 2 = norms below the bound's range)."""
+        v = self._guard_stats.cpu().numpy()
+        return {"tier1_pairs": int(v[2]), "tier2_pairs": int(v[0]), "flags": int(v[1])}
 
     @staticmethod
     def numpy_ranks(dist):

@@ -11,6 +11,7 @@ struct qpg_ctx {
   int device;
   int n_cu;
   float* zeros;   // 256 B of device zeros: out-of-range tile loads are redirected here instead of being selected to 0
+  bool select_lds_raised;   // percode_select_mixed_f64_kernel's dynamic-LDS limit has been raised on this device
 };
 
 void qpg_set_error(const char* fmt, ...);
@@ -55,3 +56,23 @@ __device__ __forceinline__ double f_mul(double a, double b) { return a * b; }
 __device__ __forceinline__ double f_add(double a, double b) { return a + b; }
 __device__ __forceinline__ double f_sub(double a, double b) { return a - b; }
 __device__ __forceinline__ double f_div(double a, double b) { return a / b; }
+
+// sklearn semantics for degenerate rows: a row whose norm is < 10*eps is left unscaled by
+// normalize(); for an all-zero row that gives 0.5*|other unit vector|^2 = 0.5 (0 if both are zero).
+__device__ __forceinline__ double cosine_from_dot(double dot, double qn2, double cn2) {
+  const double tiny = 10.0 * 2.220446049250313e-16;
+  double nq = sqrt(qn2), nc = sqrt(cn2);
+  bool zq = nq < tiny, zc = nc < tiny;
+  if (zq || zc) {
+    // unscaled row contributes its own squared norm; exact only for all-zero rows, which is
+    // the case that occurs (zero padding); both-degenerate -> 0.5*(qn2 + cn2 - 2 dot)
+    double a = zq ? qn2 : 1.0, b = zc ? cn2 : 1.0;
+    double cross = dot / ((zq ? 1.0 : nq) * (zc ? 1.0 : nc));
+    return 0.5 * (a + b - 2.0 * cross);
+  }
+  return 1.0 - dot / (nq * nc);
+}
+
+// A-priori error bound of the mixed-precision audio sweep (qpg_audio_cosine_mx, derivation in qpg_audio.hip):
+// |D_mx[q][c] - D_f64[q][c]| <= gamma_32 (f32 FMA chains of 32 products) + f64 noise, for every pair.
+// (the value is QPG_AUDIO_MX_ERR of include/qpg.h)

@@ -37,6 +37,7 @@ extern "C" int qpg_ctx_create(int device, qpg_ctx** out) {
   c->device = device;
   c->n_cu = p.multiProcessorCount;
   c->zeros = nullptr;
+  c->select_lds_raised = false;
   int prev = 0;
   (void)hipGetDevice(&prev);
   const bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&c->zeros), 256) == hipSuccess &&

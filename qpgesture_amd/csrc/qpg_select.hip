@@ -603,6 +603,7 @@ __global__ __launch_bounds__(1024) void percode_select_guarded_f64_kernel(
     for (int k = tid; k < K; k += blockDim.x) {
       const double x = v[k];
       int r = 0;
+#pragma unroll 8
       for (int o = 0; o < K; ++o) {
         const double y = v[o];
         r += (y < x) || (y == x && o < k);
@@ -671,6 +672,511 @@ extern "C" int qpg_percode_select_guarded_f64(qpg_ctx* ctx, void* stream, const 
   hipLaunchKernelGGL(percode_select_guarded_f64_kernel, dim3(Q), dim3(1024), sh, qpg_stream(stream), D, ldD, cand_code,
                      C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block, block_stride, A);
   QPG_LAUNCH_CHECK("percode_select_guarded_f64_kernel");
+  return QPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Select for the MIXED-PRECISION sweep (qpg_audio_cosine_mx): the matrix holds distances with a guaranteed error
+// <= E = QPG_AUDIO_MX_ERR.  Two values further apart than eps1 = 2E (+ margin) are ordered like the exact values, so
+// only comparisons inside an eps1 band can be wrong, and those are re-evaluated before they are used:
+//   tier 1  every candidate within eps1 of its code's minimum (when there are two or more) and the winner of every
+//           code whose minimum lies within eps1 of its rank neighbour gets an f64 dot product (one wave per pair,
+//           accurate to ~1e-15 like the f64 sweep's value);
+//   tier 2  the near-tie guard of qpg_percode_select_guarded_f64 on those f64 values (band eps2, the reference's own
+//           arithmetic) — anything closer than eps2 in exact terms was inside the eps1 band and is in the list.
+// A tier-1 value and an untouched sweep value are always >= eps1 - E apart, so mixing them in one ranking is safe.
+// out_dist therefore carries the sweep value (error <= E) for untouched codes and the refined value otherwise;
+// out_idx / out_rank are what the f64 path returns.
+// ---------------------------------------------------------------------------------------------------------------
+#define MIX_LIST 2048
+#define MIX_LIST2 256
+
+// f64 dot product of (query q, local candidate c) by one wave; every lane returns the sum.  F % 256 == 0 (the WavLM
+// width) and n_taps == 6: a lane owns the 16-byte piece lane + 64*j of every tap; ALL candidate loads of the pair
+// (24 at F = 1024) are issued before the first use — one wave per pair is latency-bound otherwise (measured: 18 us per
+// pair with a tap's loads at a time) — and the query row is read from LDS (`qlds`, staged once per block).
+template <int NPER>
+__device__ __forceinline__ double pair_dot_fast_f64(const GuardArgs& A, const float* qlds, int64_t c_local, int lane) {
+  const int j = (int)(c_local / A.G), g = (int)(c_local - (int64_t)j * A.G);
+  const int t0 = A.cand_t[g];
+  const float* crow = A.base + (int64_t)j * A.T * A.F + lane * 4;
+  f32x4 cv[6][NPER];
+#pragma unroll
+  for (int tap = 0; tap < 6; ++tap) {
+    const int t = t0 + tap * A.tap_stride;
+    const bool ok = t < A.T;
+    const float* cp = crow + (int64_t)(ok ? t : t0) * A.F;
+#pragma unroll
+    for (int u = 0; u < NPER; ++u) {
+      cv[tap][u] = *reinterpret_cast<const f32x4*>(cp + 256 * u);
+      if (!ok) cv[tap][u] = (f32x4){0.f, 0.f, 0.f, 0.f};      // zero padding past the end of the window
+    }
+  }
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int tap = 0; tap < 6; ++tap)
+#pragma unroll
+    for (int u = 0; u < NPER; ++u) {
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(qlds + tap * A.F + 256 * u + lane * 4);
+      s0 += (double)qv.x * (double)cv[tap][u].x;
+      s1 += (double)qv.y * (double)cv[tap][u].y;
+      s0 += (double)qv.z * (double)cv[tap][u].z;
+      s1 += (double)qv.w * (double)cv[tap][u].w;
+    }
+  double s = s0 + s1;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+
+__device__ __forceinline__ double pair_dot_wave_f64(const GuardArgs& A, int q, int64_t c_local, int lane) {
+  const int D = A.n_taps * A.F;
+  const int j = (int)(c_local / A.G), g = (int)(c_local - (int64_t)j * A.G);
+  const int t0 = A.cand_t[g];
+  const float* qrow = A.q32 + (int64_t)q * D;
+  const float* crow = A.base + (int64_t)j * A.T * A.F;
+  double s0 = 0.0, s1 = 0.0;
+  for (int e = lane * 4; e < D; e += 256) {                   // F % 4 == 0: a 16-byte piece never straddles a tap
+    const int tap = e / A.F, f = e - tap * A.F;
+    const int t = t0 + tap * A.tap_stride;
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + e);
+    f32x4 cv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t < A.T) cv = *reinterpret_cast<const f32x4*>(crow + (int64_t)t * A.F + f);
+    s0 += (double)qv.x * (double)cv.x;
+    s1 += (double)qv.y * (double)cv.y;
+    s0 += (double)qv.z * (double)cv.z;
+    s1 += (double)qv.w * (double)cv.w;
+  }
+  double s = s0 + s1;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+
+__host__ __device__ __forceinline__ size_t mix_ws_stride(int K) {          // bytes of one query's parking space
+  return 24 * (size_t)K + 16 + 8 * (size_t)MIX_LIST + 8 * (size_t)MIX_LIST;
+}
+
+// Tier-1 dot products of every query's list, on the whole GPU: grid (Q, RB), 4 waves per block, wave g of the
+// 4*RB of a query takes list entries g, g + 4*RB, ...
+template <int NPER>
+__global__ __launch_bounds__(256) void select_refine_kernel(GuardArgs A, int K, const double* __restrict__ cn2,
+                                                            const double* __restrict__ qn2, unsigned char* __restrict__ ws,
+                                                            int fast) {
+  const int q = blockIdx.x, lane = threadIdx.x & 63;
+  const int g = blockIdx.y * 4 + (threadIdx.x >> 6), ng = gridDim.y * 4;
+  unsigned char* wq = ws + (size_t)q * mix_ws_stride(K);
+  const int* w_n = reinterpret_cast<const int*>(wq + 24 * (size_t)K);
+  const int* w_lc = w_n + 4;
+  double* w_ld = reinterpret_cast<double*>(const_cast<int*>(w_lc) + 2 * MIX_LIST);
+  const int n = w_n[0];
+  if (g >= n) return;
+  const double qq = qn2[q];
+  const float* qrow = A.q32 + (int64_t)q * A.n_taps * A.F;
+  for (int e = g; e < n; e += ng) {
+    const int c = w_lc[e];
+    const double dot = fast ? pair_dot_fast_f64<NPER>(A, qrow, c, lane) : pair_dot_wave_f64(A, q, c, lane);
+    if (lane == 0) w_ld[e] = cosine_from_dot(dot, qq, cn2[c]);
+  }
+}
+
+#ifndef QPG_SEL_TIMING
+#define QPG_SEL_TIMING 0     // experiments: block 0 writes s_memtime ticks of its phases to stats[8..] (u64 each)
+#endif
+#if QPG_SEL_TIMING
+#define SEL_MARK(i)                                                                                              \
+  do {                                                                                                           \
+    __syncthreads();                                                                                             \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                                                                     \
+      reinterpret_cast<unsigned long long*>(A.stats + 8)[i] = __builtin_amdgcn_s_memtime();                      \
+  } while (0)
+#else
+#define SEL_MARK(i)
+#endif
+__global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
+    const double* __restrict__ D, int64_t ldD, const int16_t* __restrict__ cand_code, int64_t C, int K, double absent,
+    int32_t idx_base, double* __restrict__ out_dist, int32_t* __restrict__ out_idx, int16_t* __restrict__ out_rank,
+    int q_block, int64_t block_stride, GuardArgs A, double eps1, const double* __restrict__ cn2,
+    const double* __restrict__ qn2, int use_qlds, int phase, unsigned char* __restrict__ ws) {
+  // phase 0: everything in this launch (tier-1 dot products by this block's 16 waves: one CU per query).
+  // phase 1 / 2: the launch is cut at the tier-1 list — phase 1 parks its state in `ws`, select_refine_kernel computes
+  // the listed dot products on ALL CUs (a single CU pulls ~26 GB/s; the list of a 48-query clip is ~110 MB of rows),
+  // phase 2 picks the state up again.
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);               // [K] order key of the minimum
+  double* v = reinterpret_cast<double*>(smem + 8 * (size_t)K);                          // [K] value table being ranked
+  unsigned int* besti = reinterpret_cast<unsigned int*>(smem + 16 * (size_t)K);         // [K] global candidate index
+  unsigned int* near_ = besti + K;            // [K] band population; >= 2: "touched" (all band members are listed)
+  int* s_code = reinterpret_cast<int*>(near_ + K);                                      // [K] code at rank r / scratch
+  unsigned char* refd = reinterpret_cast<unsigned char*>(s_code + K);                   // [K] value is reference-arithmetic
+  unsigned char* tail = smem + 32 * (size_t)K;
+  double* l_d = reinterpret_cast<double*>(tail);                                        // [MIX_LIST]
+  int* l_c = reinterpret_cast<int*>(tail + 8 * MIX_LIST);                               // [MIX_LIST] local candidate
+  int* l_k = l_c + MIX_LIST;                                                            // [MIX_LIST] code
+  int* l2 = l_k + MIX_LIST;                                                             // [MIX_LIST2] tier-2 entries
+  int* ctl = l2 + MIX_LIST2;                 // [0] list length, [1] multi-member band seen, [2] tier-2 n, [3] band size
+  int* p_c = ctl + 4;                                        // [MIX_LIST] every band member seen by pass 2 (candidate)
+  int16_t* p_k = reinterpret_cast<int16_t*>(p_c + MIX_LIST);                            // [MIX_LIST] its code
+  float* qlds = reinterpret_cast<float*>(p_k + MIX_LIST);    // [n_taps*F] this query's row (fast tier-1 path only)
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
+  const double* row = D + (int64_t)q * ldD;
+  if (q_block > 0) {
+    const int64_t shift = (int64_t)(q / q_block) * block_stride;
+    const int64_t rowoff = (int64_t)(q % q_block) * K - (int64_t)q * K;
+    out_dist = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(out_dist) + shift) + rowoff;
+    out_idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(out_idx) + shift) + rowoff;
+  }
+  unsigned char* wq = ws ? ws + (size_t)q * mix_ws_stride(K) : nullptr;       // this query's parking space
+  for (int k = tid; k < K; k += blockDim.x) {
+    best[k] = ~0ull;
+    besti[k] = 0xffffffffu;
+    near_[k] = 0;
+    refd[k] = 0;
+  }
+  if (tid < 4) ctl[tid] = 0;
+  __syncthreads();
+  // rank of every code in the value table v (stable: value, then code); s_code[r] = code at rank r
+  auto rank_pass = [&](bool store) {
+    for (int k = tid; k < K; k += blockDim.x) {
+      const double x = v[k];
+      int r = 0;
+#pragma unroll 8
+      for (int o = 0; o < K; ++o) {
+        const double y = v[o];
+        r += (y < x) || (y == x && o < k);
+      }
+      if (store && out_rank) out_rank[(int64_t)q * K + k] = (int16_t)r;
+      s_code[r] = k;
+    }
+  };
+  int n = 0;
+  if (phase != 2) {
+  SEL_MARK(0);
+  typedef double vecD __attribute__((ext_vector_type(2)));
+  typedef int16_t vecC __attribute__((ext_vector_type(2)));
+  const bool vec_ok = (ldD % 2) == 0 && (reinterpret_cast<uintptr_t>(D) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(cand_code) % 4) == 0;
+  const int64_t Cv = vec_ok ? (C / 2) * 2 : 0;
+#pragma unroll 4
+  for (int64_t c = (int64_t)tid * 2; c < Cv; c += (int64_t)blockDim.x * 2) {
+    const vecD d = *reinterpret_cast<const vecD*>(row + c);
+    const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if ((unsigned)cd[e] < (unsigned)K) atomicMin(&best[cd[e]], (unsigned long long)order_key(d[e]));
+  }
+  for (int64_t c = Cv + tid; c < C; c += blockDim.x) {
+    const int cd = cand_code[c];
+    if ((unsigned)cd < (unsigned)K) atomicMin(&best[cd], (unsigned long long)order_key(row[c]));
+  }
+  __syncthreads();
+  SEL_MARK(1);
+  auto pass2 = [&](int64_t c, double d, int cd) {
+    if ((unsigned)cd >= (unsigned)K) return;
+    const unsigned long long bk = best[cd];
+    if ((unsigned long long)order_key(d) == bk) atomicMin(&besti[cd], (unsigned int)(c + idx_base));
+    else if (d > key_value(bk, 0.0) + eps1) return;
+    if (atomicAdd(&near_[cd], 1u) == 1u) ctl[1] = 1;
+    const int pp = atomicAdd(&ctl[3], 1);                               // remember the band member (K winners + the rest)
+    if (pp < MIX_LIST) {
+      p_c[pp] = (int)c;
+      p_k[pp] = (int16_t)cd;
+    }
+  };
+#pragma unroll 4
+  for (int64_t c = (int64_t)tid * 2; c < Cv; c += (int64_t)blockDim.x * 2) {
+    const vecD d = *reinterpret_cast<const vecD*>(row + c);
+    const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
+    pass2(c, d[0], cd[0]);
+    pass2(c + 1, d[1], cd[1]);
+  }
+  for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass2(c, row[c], cand_code[c]);
+  __syncthreads();
+  SEL_MARK(2);
+  // ---- list (a): every member of a band with two or more members — from the members pass 2 remembered, or, if there
+  // were more than it could hold, by a third pass over the row
+  if (ctl[1] && ctl[3] <= MIX_LIST) {
+    const int np = ctl[3];
+    for (int e = tid; e < np; e += blockDim.x) {
+      const int cd = p_k[e];
+      if (near_[cd] < 2) continue;
+      const int pos = atomicAdd(&ctl[0], 1);
+      if (pos < MIX_LIST) {
+        l_c[pos] = p_c[e];
+        l_k[pos] = cd;
+      }
+    }
+  } else if (ctl[1]) {
+    for (int64_t c = tid; c < C; c += blockDim.x) {
+      const int cd = cand_code[c];
+      if ((unsigned)cd >= (unsigned)K || near_[cd] < 2) continue;
+      if (row[c] <= key_value(best[cd], 0.0) + eps1) {
+        const int pos = atomicAdd(&ctl[0], 1);
+        if (pos < MIX_LIST) {
+          l_c[pos] = (int)c;
+          l_k[pos] = cd;
+        }
+      }
+    }
+  }
+  for (int k = tid; k < K; k += blockDim.x) v[k] = besti[k] != 0xffffffffu ? key_value(best[k], 0.0) : absent;
+  __syncthreads();
+  SEL_MARK(3);
+  // ---- list (b): winners of codes whose minima are rank neighbours within eps1 (only needed when ranks are wanted:
+  // without them the minima of different codes are never compared here)
+  if (out_rank) {
+    rank_pass(false);
+    __syncthreads();
+    for (int r = tid; r + 1 < K; r += blockDim.x) {
+      const int ka = s_code[r], kb = s_code[r + 1];
+      if (besti[ka] == 0xffffffffu || besti[kb] == 0xffffffffu) continue;
+      if (v[kb] - v[ka] < eps1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = h ? kb : ka;
+          if (atomicMax(&near_[k], 2u) >= 2u) continue;                  // band-listed, or listed once already
+          const int pos = atomicAdd(&ctl[0], 1);
+          if (pos < MIX_LIST) {
+            l_c[pos] = (int)(besti[k] - (unsigned int)idx_base);
+            l_k[pos] = k;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  SEL_MARK(4);
+#if QPG_SEL_TIMING
+  if (tid == 0 && q < 64) A.stats[64 + q] = ctl[0];
+#endif
+  n = ctl[0];
+  if (n > MIX_LIST) {
+    n = MIX_LIST;
+    if (tid == 0) atomicOr(&A.stats[1], 1);
+  }
+  }   // phase != 2
+  if (phase == 1) {            // park: [best u64 K][v f64 K][besti u32 K][near u32 K][n, pad][l_c i32 L][l_k i32 L][l_d f64 L]
+    unsigned long long* w_best = reinterpret_cast<unsigned long long*>(wq);
+    double* w_v = reinterpret_cast<double*>(wq + 8 * (size_t)K);
+    unsigned int* w_bi = reinterpret_cast<unsigned int*>(wq + 16 * (size_t)K);
+    unsigned int* w_nr = w_bi + K;
+    int* w_n = reinterpret_cast<int*>(wq + 24 * (size_t)K);
+    int* w_lc = w_n + 4;
+    int* w_lk = w_lc + MIX_LIST;
+    for (int k = tid; k < K; k += blockDim.x) {
+      w_best[k] = best[k];
+      w_v[k] = v[k];
+      w_bi[k] = besti[k];
+      w_nr[k] = near_[k];
+    }
+    for (int e = tid; e < n; e += blockDim.x) {
+      w_lc[e] = l_c[e];
+      w_lk[e] = l_k[e];
+    }
+    if (tid == 0) w_n[0] = n;
+    return;
+  }
+  if (phase == 2) {
+    const unsigned long long* w_best = reinterpret_cast<const unsigned long long*>(wq);
+    const double* w_v = reinterpret_cast<const double*>(wq + 8 * (size_t)K);
+    const unsigned int* w_bi = reinterpret_cast<const unsigned int*>(wq + 16 * (size_t)K);
+    const unsigned int* w_nr = w_bi + K;
+    const int* w_n = reinterpret_cast<const int*>(wq + 24 * (size_t)K);
+    const int* w_lc = w_n + 4;
+    const int* w_lk = w_lc + MIX_LIST;
+    const double* w_ld = reinterpret_cast<const double*>(w_lk + MIX_LIST);
+    n = w_n[0];
+    for (int k = tid; k < K; k += blockDim.x) {
+      best[k] = w_best[k];
+      v[k] = w_v[k];
+      besti[k] = w_bi[k];
+      near_[k] = w_nr[k];
+    }
+    for (int e = tid; e < n; e += blockDim.x) {
+      l_c[e] = w_lc[e];
+      l_k[e] = w_lk[e];
+      l_d[e] = w_ld[e];
+    }
+    __syncthreads();
+  }
+  if (n > 0) {
+    // ---- tier 1: f64 dot products, one wave per listed pair (phase 2: already done by select_refine_kernel)
+    const double qq = qn2[q];
+    const bool fast = use_qlds != 0;
+    if (phase == 0 && fast) {
+      const int D4 = (A.n_taps * A.F) >> 2;
+      const f32x4* src = reinterpret_cast<const f32x4*>(A.q32 + (int64_t)q * A.n_taps * A.F);
+      for (int i = tid; i < D4; i += blockDim.x) reinterpret_cast<f32x4*>(qlds)[i] = src[i];
+      __syncthreads();
+    }
+    for (int e = wv; e < n && phase == 0; e += nwv) {
+      const int c = l_c[e];
+      const double dot = fast ? pair_dot_fast_f64<4>(A, qlds, c, lane) : pair_dot_wave_f64(A, q, c, lane);
+      if (lane == 0) l_d[e] = cosine_from_dot(dot, qq, cn2[c]);
+    }
+    SEL_MARK(5);
+    for (int k = tid; k < K; k += blockDim.x)
+      if (near_[k] >= 2) {
+        best[k] = ~0ull;
+        besti[k] = 0xffffffffu;
+        s_code[k] = 0;                                         // scratch: members within eps2 of the refined minimum
+      }
+    __syncthreads();
+    for (int e = tid; e < n; e += blockDim.x) atomicMin(&best[l_k[e]], (unsigned long long)order_key(l_d[e]));
+    __syncthreads();
+    // ---- tier 2 (candidate level): two or more members of one code within eps2 of its refined minimum
+    if (A.eps > 0.0) {
+      for (int e = tid; e < n; e += blockDim.x)
+        if (l_d[e] <= key_value(best[l_k[e]], 0.0) + A.eps) atomicAdd(&s_code[l_k[e]], 1);
+      __syncthreads();
+      for (int e = tid; e < n; e += blockDim.x)
+        if (s_code[l_k[e]] >= 2 && l_d[e] <= key_value(best[l_k[e]], 0.0) + A.eps) {
+          const int pos = atomicAdd(&ctl[2], 1);
+          if (pos < MIX_LIST2) l2[pos] = e;
+        }
+      __syncthreads();
+      int n2 = ctl[2];
+      if (n2 > MIX_LIST2) {
+        n2 = MIX_LIST2;
+        if (tid == 0) atomicOr(&A.stats[1], 1);
+      }
+      if (n2 > 0) {
+        for (int i0 = 0; i0 < n2; i0 += blockDim.x / 4) {
+          const int i = i0 + (tid >> 2);
+          const int e = l2[i < n2 ? i : 0];
+          const double dr = refine_pair_f64(A, q, l_c[e], tid & 3);
+          if (i < n2 && (tid & 3) == 0) {
+            l_d[e] = dr;
+            refd[l_k[e]] = 1;
+          }
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += blockDim.x)
+          if (refd[k]) best[k] = ~0ull;
+        __syncthreads();
+        // only the re-evaluated members can win such a code (the rest are > eps2 above them)
+        for (int i = tid; i < n2; i += blockDim.x)
+          atomicMin(&best[l_k[l2[i]]], (unsigned long long)order_key(l_d[l2[i]]));
+        __syncthreads();
+        if (tid == 0) atomicAdd(&A.stats[0], n2);
+      }
+    }
+    for (int e = tid; e < n; e += blockDim.x)
+      if ((unsigned long long)order_key(l_d[e]) == best[l_k[e]])
+        atomicMin(&besti[l_k[e]], (unsigned int)(l_c[e] + idx_base));
+    __syncthreads();
+    for (int k = tid; k < K; k += blockDim.x)
+      if (near_[k] >= 2) v[k] = key_value(best[k], 0.0);
+    if (tid == 0) atomicAdd(&A.stats[2], n);
+    __syncthreads();
+  }
+  SEL_MARK(6);
+  for (int k = tid; k < K; k += blockDim.x) {
+    const bool have = besti[k] != 0xffffffffu;
+    out_dist[(int64_t)q * K + k] = v[k];
+    out_idx[(int64_t)q * K + k] = have ? (int32_t)besti[k] : -1;
+  }
+  if (!out_rank) return;
+  if (tid == 0) ctl[2] = 0;
+  __syncthreads();
+  rank_pass(true);
+  SEL_MARK(7);
+  if (A.eps <= 0.0) return;
+  __syncthreads();
+  // ---- tier 2 (rank level): refined minima of different codes within eps2 -> reference arithmetic for their winners
+  for (int r = tid; r + 1 < K; r += blockDim.x) {
+    const int ka = s_code[r], kb = s_code[r + 1];
+    if (besti[ka] == 0xffffffffu || besti[kb] == 0xffffffffu) continue;
+    if (v[kb] - v[ka] < A.eps) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = h ? kb : ka;
+        if (atomicExch(&near_[k], 0xffffffffu) == 0xffffffffu || refd[k]) continue;
+        const int pos = atomicAdd(&ctl[2], 1);
+        if (pos < MIX_LIST2) {
+          l2[pos] = k;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  int n3 = ctl[2];
+  if (n3 == 0) return;
+  if (n3 > MIX_LIST2) {
+    n3 = MIX_LIST2;
+    if (tid == 0) atomicOr(&A.stats[1], 1);
+  }
+  for (int i0 = 0; i0 < n3; i0 += blockDim.x / 4) {
+    const int i = i0 + (tid >> 2);
+    const int k = l2[i < n3 ? i : 0];
+    const double dr = refine_pair_f64(A, q, (int64_t)(besti[k] - (unsigned int)idx_base), tid & 3);
+    if (i < n3 && (tid & 3) == 0) {
+      v[k] = dr;
+      out_dist[(int64_t)q * K + k] = dr;
+    }
+  }
+  if (tid == 0) atomicAdd(&A.stats[0], n3);
+  __syncthreads();
+  rank_pass(true);
+}
+
+extern "C" int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K) {
+  return (Q <= 0 || K <= 0) ? 0 : (int64_t)((size_t)Q * mix_ws_stride(K));
+}
+
+extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const double* D, int64_t ldD, int Q,
+                                            const int16_t* cand_code, int64_t C, int K, double absent,
+                                            int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
+                                            int q_block, int64_t block_stride, const float* base, int T, int F,
+                                            const int32_t* cand_t, int G, int n_taps, int tap_stride,
+                                            const float* q32, const double* qn2, const double* cn2, double eps1,
+                                            double eps2, int32_t* stats, void* ws, int64_t ws_bytes) {
+  const char* name = "qpg_percode_select_mixed_f64";
+  QPG_REQUIRE(ctx && D && (cand_code || C == 0) && out_dist && out_idx && base && cand_t && q32 && qn2 && cn2 && stats,
+              "%s: null pointer", name);
+  QPG_REQUIRE(Q >= 0 && C >= 0 && K > 0 && K <= 512 && ldD >= C && C + (int64_t)idx_base < 0x7fffffffll,
+              "%s: bad size (K <= 512)", name);
+  QPG_REQUIRE(T > 0 && F > 0 && (F % 4) == 0 && G > 0 && n_taps > 0 && tap_stride > 0 && C % G == 0 &&
+                  eps1 >= 2.0 * QPG_AUDIO_MX_ERR && eps2 >= 0.0 && eps2 < eps1,
+              "%s: bad geometry (F %% 4 == 0) or eps (eps1 >= 2 x the sweep's error bound %g, 0 <= eps2 < eps1)", name,
+              (double)QPG_AUDIO_MX_ERR);
+  QPG_REQUIRE(q_block >= 0 && (q_block == 0 || (!out_rank && Q % q_block == 0 && block_stride % 8 == 0)),
+              "%s: block layout needs Q %% q_block == 0, an 8-byte multiple stride and no rank output", name);
+  if (Q == 0) return QPG_OK;
+  GuardArgs A;
+  A.base = base; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
+  A.tap_stride = tap_stride; A.eps = eps2; A.stats = stats;
+  // fast tier-1 path (WavLM geometry: 6 taps x 1024 features): the query row is staged in LDS (+24 KB: 85 KB in all)
+  const int use_qlds = (n_taps == 6 && F == 1024) ? 1 : 0;
+  const size_t sh = 32 * (size_t)K + 16 * MIX_LIST + 4 * MIX_LIST2 + 16 + 6 * MIX_LIST +
+                    (use_qlds ? (size_t)n_taps * F * 4 : 0);
+  if (!ctx->select_lds_raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(percode_select_mixed_f64_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+      qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
+      return QPG_EHIP;
+    }
+    ctx->select_lds_raised = true;
+  }
+  if (!ws) {
+    hipLaunchKernelGGL(percode_select_mixed_f64_kernel, dim3(Q), dim3(1024), sh, qpg_stream(stream), D, ldD, cand_code,
+                       C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block, block_stride, A, eps1, cn2, qn2,
+                       use_qlds, 0, (unsigned char*)nullptr);
+    QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel");
+    return QPG_OK;
+  }
+  QPG_REQUIRE(ws_bytes >= (int64_t)((size_t)Q * mix_ws_stride(K)) && (reinterpret_cast<uintptr_t>(ws) % 16) == 0,
+              "%s: workspace too small or misaligned (qpg_percode_select_mixed_ws_bytes)", name);
+  unsigned char* w = static_cast<unsigned char*>(ws);
+  hipLaunchKernelGGL(percode_select_mixed_f64_kernel, dim3(Q), dim3(1024), sh - (use_qlds ? (size_t)n_taps * F * 4 : 0),
+                     qpg_stream(stream), D, ldD, cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block,
+                     block_stride, A, eps1, cn2, qn2, use_qlds, 1, w);
+  QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (lists)");
+  const int rb = Q >= 256 ? 4 : 16;          // waves per query = 4*rb; ~100 list entries per query on dense data
+  hipLaunchKernelGGL((select_refine_kernel<4>), dim3(Q, rb), dim3(256), 0, qpg_stream(stream), A, K, cn2, qn2, w, use_qlds);
+  QPG_LAUNCH_CHECK("select_refine_kernel");
+  hipLaunchKernelGGL(percode_select_mixed_f64_kernel, dim3(Q), dim3(1024), sh - (use_qlds ? (size_t)n_taps * F * 4 : 0),
+                     qpg_stream(stream), D, ldD, cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block,
+                     block_stride, A, eps1, cn2, qn2, use_qlds, 2, w);
+  QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (merge)");
   return QPG_OK;
 }
 

@@ -9,6 +9,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.helpers import aud_tol
+
 pytestmark = pytest.mark.gpu
 
 
@@ -42,7 +44,7 @@ def test_fullsize_tables_vs_c_oracle():
     q = np.stack([O.wavlm_feat_rows(te_i, w, [24 * s])[0] for w in range(M) for s in range(8)])
     d_ref, i_ref = cref.audio_scan(A["interp"], np.arange(26) * 6, A["code"], np.arange(26), q, n_threads=cores)
     assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref)
-    assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+    assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < aud_tol(knn)
     qt = np.stack([te_c[w][int(24 * s / 180 * 30)] for w in range(M) for s in range(8)])
     dt_ref, it_ref = cref.text_scan(A["ctx"], np.arange(26), A["code"], np.arange(26), qt, n_threads=cores)
     assert np.array_equal(T["txt_d"].cpu().numpy(), dt_ref)
@@ -77,11 +79,12 @@ def test_speaker1_class_db_8192_windows_vs_c_oracle():
     cores = os.cpu_count() or 1
     q = np.stack([O.wavlm_feat_rows(te_i, w, [24 * s])[0] for w in range(M) for s in range(8)])
     d_ref, i_ref = cref.audio_scan(interp, np.arange(26) * 6, code, np.arange(26), q, n_threads=cores)
-    assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref) and np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+    assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref) and np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < aud_tol(knn)
     qt = np.stack([te_c[w][int(24 * s / 180 * 30)] for w in range(M) for s in range(8)])
     dt_ref, it_ref = cref.text_scan(ctx, np.arange(26), code, np.arange(26), qt, n_threads=cores)
     assert np.array_equal(T["txt_d"].cpu().numpy(), dt_ref) and np.array_equal(T["txt_idx"].cpu().numpy(), it_ref)
     assert np.array_equal(T["aud_rank"].cpu().numpy(), np.argsort(np.argsort(d_ref, axis=1, kind="stable"), axis=1, kind="stable"))
+    tol = aud_tol(knn)
     del db, knn
     torch.cuda.empty_cache()
     # two row shards on the same GPU, merged by the HIP kernel (no collective: both halves are local here)
@@ -104,7 +107,8 @@ def test_speaker1_class_db_8192_windows_vs_c_oracle():
     oi = torch.empty((Q, K), dtype=torch.int32, device="cuda:0")
     _lib.call("qpg_merge_select_f64", torch.device("cuda:0"), buf, 2, buf.numel() // 2, 0, Q * K * 8, Q, K,
               float(ABSENT_DIST), od, oi, None)
-    assert torch.equal(oi, T["aud_idx"]) and torch.equal(od, T["aud_d"])
+    # (the shards ran the f64 sweep — the sharded path always does — the unsharded tables the mixed-precision one)
+    assert torch.equal(oi, T["aud_idx"]) and float((od - T["aud_d"]).abs().max()) < tol
 
 
 def test_planted_match_and_duplicates():
@@ -157,7 +161,7 @@ def test_ragged_and_small_shapes():
         absent = i_ref < 0
         assert absent.any() == (N * 26 < 512)                            # few windows: most codes never occur
         assert np.all(T["aud_d"].cpu().numpy()[absent] == 1e3)           # the reference's placeholder (:668)
-        assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+        assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < aud_tol(knn)
         qt = np.stack([te_c[0][int(24 * s / 180 * 30)] for s in range(8)])
         dt_ref, it_ref = cref.text_scan(A["ctx"], np.arange(26), A["code"], np.arange(26), qt)
         assert np.array_equal(T["txt_d"].cpu().numpy(), dt_ref) and np.array_equal(T["txt_idx"].cpu().numpy(), it_ref)
@@ -219,7 +223,7 @@ def test_batch16_clips_tables_vs_c_oracle():
     q = np.stack([O.wavlm_feat_rows(te_i, w, [24 * s])[0] for w in range(clips * M) for s in range(8)])
     d_ref, i_ref = cref.audio_scan(A["interp"], np.arange(26) * 6, A["code"], np.arange(26), q, n_threads=cores)
     assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref)
-    assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+    assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < aud_tol(knn)
     qt = np.stack([te_c[w][int(24 * s / 180 * 30)] for w in range(clips * M) for s in range(8)])
     dt_ref, it_ref = cref.text_scan(A["ctx"], np.arange(26), A["code"], np.arange(26), qt, n_threads=cores)
     assert np.array_equal(T["txt_d"].cpu().numpy(), dt_ref) and np.array_equal(T["txt_idx"].cpu().numpy(), it_ref)

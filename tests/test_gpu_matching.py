@@ -24,13 +24,17 @@ def _build(meta, dev="cuda:0", freq_rank=None):
     return A, db, knn, te_i, te_c, nte
 
 
+@pytest.mark.parametrize("prec", ["f64", "mixed"])
 @pytest.mark.parametrize("name", GOLDENS)
-def test_tables_vs_reference_golden(name):
+def test_tables_vs_reference_golden(name, prec):
     """Per-(query, code) minima of both sweeps against what the REFERENCE returned:
     winners (argmin candidate) exact; text distances bit-exact (f32 arithmetic reproduced);
-    audio distances to 1e-13 (f64, different but equivalent formula) with identical ordering."""
+    audio distances to 1e-13 (f64, different but equivalent formula) with identical ordering — on the mixed-precision
+    path (the default) the untouched minima carry the sweep's bounded error instead, winners and ordering unchanged."""
+    from qpgesture_amd.code_knn import AUDIO_MX_ERR
     g = load_golden(name)
     A, db, knn, te_i, te_c, M = _build(g["meta"], freq_rank=g["step_freq_score"])
+    knn.audio_precision = prec
     codes, phases, votes = knn.match_clip(te_i, te_c, M, return_tables=True)
     T = knn.tables
     aud_d = T["aud_d"].cpu().numpy()
@@ -43,7 +47,7 @@ def test_tables_vs_reference_golden(name):
     gj, gk = g["txt_aux"][..., 0], g["txt_aux"][..., 1]
     assert np.array_equal(txt_idx, gj * 26 + gk // 8)
     assert txt_d.dtype == np.float32 and np.array_equal(txt_d, g["txt_dist"])        # bit-exact
-    assert np.abs(aud_d - g["aud_dist"]).max() < 1e-13
+    assert np.abs(aud_d - g["aud_dist"]).max() < (1e-13 if prec == "f64" else AUDIO_MX_ERR)
     assert np.array_equal(np.argsort(aud_d, axis=1, kind="stable"),
                           np.argsort(g["aud_dist"], axis=1, kind="stable"))
 
@@ -68,10 +72,14 @@ def test_unfused_entry_points_agree_with_fused():
     A, db, knn, te_i, te_c, M = _build(g["meta"])
     steps = knn.n_steps()
     q_win, q_t = np.repeat(np.arange(M), steps), np.tile(np.arange(steps) * 24, M)
+    knn.audio_precision = "f64"
     d0, i0, r0 = knn.sweep_audio(te_i, q_win, q_t, want_rank=True)
     d1, i1, D = knn.sweep_audio_unfused(te_i, q_win, q_t)
     assert torch.equal(d0, d1) and torch.equal(i0, i1)
     assert torch.equal(r0, knn.rank_rows(d1))
+    knn.audio_precision = "mixed"           # the default: same winners and ranks, values inside the sweep's bound
+    dm, im, rm = knn.sweep_audio(te_i, q_win, q_t, want_rank=True)
+    assert torch.equal(im, i1) and torch.equal(rm, r0) and float((dm - d1).abs().max()) <= 1.92e-6
     rows = [int(i / 180 * 30) for i in q_t]
     qt = te_c[torch.as_tensor(q_win, device=te_c.device), torch.as_tensor(rows, device=te_c.device)].contiguous()
     t0, j0, s0 = knn.sweep_text(qt, want_rank=True)
@@ -286,6 +294,7 @@ def test_audio_near_ties_vs_reference_golden():
     reference's; the refined distances are BIT-EXACT where the guard ran."""
     g = load_golden("shipped_neartie_n48_m2_s30")
     A, db, knn, te_i, te_c, M = _build_variant(g)
+    knn.audio_precision = "f64"              # the f64 sweep + guard; the mixed path on this clip: test_gpu_mixed.py
     codes, phases, votes = knn.match_clip(te_i, te_c, M, return_tables=True)
     n_ref, overflow = knn.guard_stats()
     assert n_ref > 0 and not overflow
