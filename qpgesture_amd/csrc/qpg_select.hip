@@ -815,7 +815,8 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   int* ctl = l2 + MIX_LIST2;                 // [0] list length, [1] multi-member band seen, [2] tier-2 n, [3] band size
   int* p_c = ctl + 4;                                        // [MIX_LIST] every band member seen by pass 2 (candidate)
   int16_t* p_k = reinterpret_cast<int16_t*>(p_c + MIX_LIST);                            // [MIX_LIST] its code
-  float* qlds = reinterpret_cast<float*>(p_k + MIX_LIST);    // [n_taps*F] this query's row (fast tier-1 path only)
+  int* rk = reinterpret_cast<int*>(p_k + MIX_LIST);          // [K] rank counters
+  float* qlds = reinterpret_cast<float*>(rk + K);            // [n_taps*F] this query's row (fast tier-1 path only)
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
   const double* row = D + (int64_t)q * ldD;
   if (q_block > 0) {
@@ -834,15 +835,40 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   if (tid < 4) ctl[tid] = 0;
   __syncthreads();
   // rank of every code in the value table v (stable: value, then code); s_code[r] = code at rank r
+  // (the K x K count is VALU-bound, ~35 cycles per comparison step per wave: P = blockDim / K threads share a code)
   auto rank_pass = [&](bool store) {
-    for (int k = tid; k < K; k += blockDim.x) {
+    const int P = (int)blockDim.x >= 2 * K ? (int)blockDim.x / K : 1;
+    if (P == 1) {
+      for (int k = tid; k < K; k += blockDim.x) {
+        const double x = v[k];
+        int r = 0;
+#pragma unroll 8
+        for (int o = 0; o < K; ++o) {
+          const double y = v[o];
+          r += (y < x) || (y == x && o < k);
+        }
+        if (store && out_rank) out_rank[(int64_t)q * K + k] = (int16_t)r;
+        s_code[r] = k;
+      }
+      return;
+    }
+    for (int k = tid; k < K; k += blockDim.x) rk[k] = 0;
+    __syncthreads();
+    if (tid < P * K) {
+      const int k = tid % K, part = tid / K;
+      const int o0 = (int)((int64_t)part * K / P), o1 = (int)((int64_t)(part + 1) * K / P);
       const double x = v[k];
       int r = 0;
 #pragma unroll 8
-      for (int o = 0; o < K; ++o) {
+      for (int o = o0; o < o1; ++o) {
         const double y = v[o];
         r += (y < x) || (y == x && o < k);
       }
+      atomicAdd(&rk[k], r);
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += blockDim.x) {
+      const int r = rk[k];
       if (store && out_rank) out_rank[(int64_t)q * K + k] = (int16_t)r;
       s_code[r] = k;
     }
@@ -1146,7 +1172,7 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const do
   A.tap_stride = tap_stride; A.eps = eps2; A.stats = stats;
   // fast tier-1 path (WavLM geometry: 6 taps x 1024 features): the query row is staged in LDS (+24 KB: 85 KB in all)
   const int use_qlds = (n_taps == 6 && F == 1024) ? 1 : 0;
-  const size_t sh = 32 * (size_t)K + 16 * MIX_LIST + 4 * MIX_LIST2 + 16 + 6 * MIX_LIST +
+  const size_t sh = 32 * (size_t)K + 16 * MIX_LIST + 4 * MIX_LIST2 + 16 + 6 * MIX_LIST + 4 * (size_t)K +
                     (use_qlds ? (size_t)n_taps * F * 4 : 0);
   if (!ctx->select_lds_raised) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(percode_select_mixed_f64_kernel),
