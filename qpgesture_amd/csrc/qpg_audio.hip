@@ -91,13 +91,14 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const void* _
                                                                const float* __restrict__ q32,
                                                                const double* __restrict__ qn2, int Q,
                                                                double* __restrict__ D, int64_t ldD,
-                                                               const float* __restrict__ zeros) {
+                                                               const float* __restrict__ zeros, int64_t c_begin,
+                                                               int64_t c_end) {
   __shared__ double red[KS][MT * NT][4][64];  // [wave][tile][acc reg][lane]
 
-  const int64_t C = (int64_t)N * G;
+  const int64_t C = c_end;                     // candidates [c_begin, c_end) of the N*G
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = lane & 15, kq = lane >> 4;
-  const int64_t c0 = (int64_t)blockIdx.x * (16 * MT);
+  const int64_t c0 = c_begin + (int64_t)blockIdx.x * (16 * MT);
   const int q0 = blockIdx.y * (NT * 16);
 
   // A side: this lane's candidate row in each of the MT tiles (element offsets into the base track)
@@ -524,7 +525,9 @@ typedef __attribute__((address_space(1))) const void* mx_gbl_ptr_t;
 // slot = piece ^ row both eights land on disjoint slot sets ({4..11} is closed under ^1), i.e. conflict-free.
 __device__ __forceinline__ int mx2_g(int r) { return r; }
 
-template <int NT, int NTAPS>
+// F64 = true: the SAME organisation on the f64 matrix cores (v_mfma_f64_16x16x4_f64, operands widened in registers, no
+// chains to cut): the f64 sweep of qpg_audio_cosine_f64 for whole rounds of blocks.
+template <int NT, int NTAPS, bool F64>
 __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
     const float* __restrict__ base, int N, int T, int F, const int32_t* __restrict__ cand_t, int G, int tap_stride,
     const double* __restrict__ cn2, const float* __restrict__ q32, const double* __restrict__ qn2, int Q,
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    sum[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    sum[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};      // F64: the accumulator itself
     acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const int ng = F / 64;                           // feature groups of 64; stage s = (group s / 6, tap s % 6)
@@ -639,6 +642,11 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
+            if (F64) {
+              sum[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[2 * half + i][e], (double)b[nt][i][e], sum[nt],
+                                                             0, 0, 0);
+              continue;
+            }
             f32x4 cin = acc[nt];
             if (i == 0 && e == 0 && !(QPG_MX2_PROBE & 8)) {   // a 32-product chain is complete: into the f64 sum
 #pragma unroll
@@ -674,9 +682,10 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
     const double a2 = qn2[q];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t cc = c0 + 4 * kq + r;
+      // C/D rows: f32 instruction 4*(l>>4) + r, f64 instruction (l>>4) + 4*r
+      const int64_t cc = c0 + (F64 ? kq + 4 * r : 4 * kq + r);
       if (cc >= c_end) continue;
-      const double dot = sum[nt][r] + (double)acc[nt][r];
+      const double dot = F64 ? sum[nt][r] : sum[nt][r] + (double)acc[nt][r];
       const double b2 = cn2[cc];
       const double p = a2 * b2;
       if (p > 0.0 && p < 1e-32 && stats) atomicOr(&stats[1], 2);
@@ -752,7 +761,7 @@ extern "C" int qpg_audio_cosine_mx(qpg_ctx* ctx, void* stream, const float* base
   const int64_t c_mid = main_x * 64;
   if (main_x > 0) {
     dim3 grid((unsigned)main_x, (unsigned)ny);
-    hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6>), grid, dim3(256), 0, qpg_stream(stream), base, N, T, F, cand_t, G,
+    hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, false>), grid, dim3(256), 0, qpg_stream(stream), base, N, T, F, cand_t, G,
                        tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros, stats, (int64_t)0, c_mid);
     QPG_LAUNCH_CHECK("audio_cosine_mx2_kernel");
   }
@@ -766,21 +775,39 @@ extern "C" int qpg_audio_cosine_mx(qpg_ctx* ctx, void* stream, const float* base
 template <int MT, int NT>
 static int launch_audio(qpg_ctx* ctx, void* stream, const void* base, bool half, int N, int T, int F,
                         const int32_t* cand_t, int G, int tap_stride, const double* cn2, const float* q32,
-                        const double* qn2, int Q, int qtiles_y, double* D, int64_t ldD) {
-  int64_t C = (int64_t)N * G;
-  dim3 grid((unsigned)((C + 16 * MT - 1) / (16 * MT)), (unsigned)qtiles_y);
+                        const double* qn2, int Q, int qtiles_y, double* D, int64_t ldD, int64_t c_begin, int64_t c_end) {
+  dim3 grid((unsigned)((c_end - c_begin + 16 * MT - 1) / (16 * MT)), (unsigned)qtiles_y);
   // 4 waves (one per SIMD) split the feature axis.  An 8-wave split (finer work units, 6.5 instead of
   // 3.25 rounds of blocks at N_db=2048) measured slower on MI355X: 703 vs 629 us (r01 notes).
   if (half)
     hipLaunchKernelGGL((audio_cosine_f64_kernel<MT, NT, 6, 4, true>), grid, dim3(256), 0, qpg_stream(stream), base, N, T,
-                       F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros);
+                       F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros, c_begin, c_end);
   else
     hipLaunchKernelGGL((audio_cosine_f64_kernel<MT, NT, 6, 4, false>), grid, dim3(256), 0, qpg_stream(stream), base, N, T,
-                       F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros);
+                       F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros, c_begin, c_end);
   QPG_LAUNCH_CHECK("audio_cosine_f64_kernel");
   return QPG_OK;
 }
 
+template <int MT>
+static int launch_audio_q(qpg_ctx* ctx, void* stream, const void* base, bool half, int N, int T, int F,
+                          const int32_t* cand_t, int G, int tap_stride, const double* cn2, const float* q32,
+                          const double* qn2, int Q, double* D, int64_t ldD, int64_t c_begin, int64_t c_end) {
+  const int qt = (Q + 15) / 16;  // widest query tile that divides the work without an empty tail (48 queries = 3)
+#define QPG_AUDIO_ARGS ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q
+  if (qt % 3 == 0) return launch_audio<MT, 3>(QPG_AUDIO_ARGS, qt / 3, D, ldD, c_begin, c_end);
+  if (qt % 4 == 0) return launch_audio<MT, 4>(QPG_AUDIO_ARGS, qt / 4, D, ldD, c_begin, c_end);
+  if (qt % 2 == 0) return launch_audio<MT, 2>(QPG_AUDIO_ARGS, qt / 2, D, ldD, c_begin, c_end);
+  return launch_audio<MT, 1>(QPG_AUDIO_ARGS, qt, D, ldD, c_begin, c_end);
+#undef QPG_AUDIO_ARGS
+}
+
+// 1 (default): split-K only.  2: LDS-shared-query blocks (mx2<F64>) for whole rounds + split-K remainder — correct (the
+// whole GPU suite passes with it) but NOT faster for f64: at 64 cycles per MFMA the split-K kernel is already at the
+// matrix pipe's pace (MI355X: 594 vs 590 us at Q = 48, 0.83 vs 0.81 of the roof at Q = 768, 0.79 vs 0.76 ms per step).
+#ifndef QPG_F64_ORG
+#define QPG_F64_ORG 1
+#endif
 static int audio_cosine(const char* name, qpg_ctx* ctx, void* stream, const void* base, bool half, int N, int T, int F,
                         const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2, const float* q32,
                         const double* qn2, int Q, double* D, int64_t ldD) {
@@ -791,16 +818,25 @@ static int audio_cosine(const char* name, qpg_ctx* ctx, void* stream, const void
     return QPG_EUNSUP;
   }
   if (N == 0 || Q == 0) return QPG_OK;
-  const int qt = (Q + 15) / 16;  // 16-query tiles
-  // widest query tile that divides the work without an empty tail: prefer 3 (a 24 s clip is 48 queries)
-#define QPG_AUDIO_ARGS ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q
-#define QPG_AUDIO_TAIL D, ldD
-  if (qt % 3 == 0) return launch_audio<2, 3>(QPG_AUDIO_ARGS, qt / 3, QPG_AUDIO_TAIL);
-  if (qt % 4 == 0) return launch_audio<2, 4>(QPG_AUDIO_ARGS, qt / 4, QPG_AUDIO_TAIL);
-  if (qt % 2 == 0) return launch_audio<2, 2>(QPG_AUDIO_ARGS, qt / 2, QPG_AUDIO_TAIL);
-  return launch_audio<2, 1>(QPG_AUDIO_ARGS, qt, QPG_AUDIO_TAIL);
-#undef QPG_AUDIO_TAIL
-#undef QPG_AUDIO_ARGS
+  const int64_t C = (int64_t)N * G;
+  // same work split as qpg_audio_cosine_mx (f32 base only: the f16 base keeps the split-K kernel throughout)
+  const int ny = (Q + 47) / 48;
+  const int64_t nbx = C / 64;
+  int64_t main_x = 0;
+  if (QPG_F64_ORG == 2 && !half) main_x = ny >= 4 ? nbx : (nbx * ny / ctx->n_cu) * ctx->n_cu / ny;
+  const int64_t c_mid = main_x * 64;
+  if (main_x > 0) {
+    dim3 grid((unsigned)main_x, (unsigned)ny);
+    hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, true>), grid, dim3(256), 0, qpg_stream(stream),
+                       static_cast<const float*>(base), N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD,
+                       (const float*)ctx->zeros, (int32_t*)nullptr, (int64_t)0, c_mid);
+    QPG_LAUNCH_CHECK("audio_cosine_mx2_kernel<f64>");
+  }
+  if (c_mid == C) return QPG_OK;
+  const int64_t tail_tiles = (C - c_mid + 15) / 16;
+  if (main_x > 0 && tail_tiles * ny <= 4 * (int64_t)ctx->n_cu)
+    return launch_audio_q<1>(ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, c_mid, C);
+  return launch_audio_q<2>(ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, c_mid, C);
 }
 
 extern "C" int qpg_audio_cosine_f64(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F,
