@@ -288,7 +288,7 @@ def main():
 # HBM bytes per audio_cosine_f64_kernel launch at the default shape (N_db=2048, Q=48), rocprofv3 PMC, separate
 # --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 correction on FETCH_SIZE: profiles/r02_pmc_audio.md
 AUDIO_TRAFFIC_BYTES = 923_000_000
-AUDIO_MX_TRAFFIC_BYTES = None      # mixed-precision sweep: not measured yet
+AUDIO_MX_TRAFFIC_BYTES = 979_000_000      # mixed-precision sweep (both launches), same file
 
 
 def vqvae_bench(dev, a, world, rank):
