@@ -46,6 +46,9 @@ def build_parser():
     p.add_argument('--mode', choices=["shipped", "audio", "text", "wavvq", "wavvq_audio"], default="shipped")
     p.add_argument('--seed', type=int, default=seed_value)
     p.add_argument('--tie_rule', choices=["numpy", "stable"], default="numpy")
+    p.add_argument('--audio_precision', choices=["mixed", "f64"], default="mixed",
+                   help="mixed: f32 matrix-core sweep with an a-priori error bound + exact re-evaluation of every "
+                        "undecided comparison (same output); f64: the f64 matrix-core sweep")
     return p
 
 
@@ -68,6 +71,7 @@ def main_codebook(args, maxFrames=0):
     db = GestureDB(L.code, L.train_wavlm, L.train_context, L.train_phase, signature, device=args.device,
                    freq_rank=freq_rank, wavvq=L.train_wavvq if vq else None)
     knn = CodeKNN(db, use_wavlm=not vq, use_wavvq=vq)                            # draws from np.random like :463-464
+    knn.audio_precision = args.audio_precision
     knn.host_ranks = args.tie_rule == "numpy"        # audio / text minima ranked by the reference's own NumPy call
     n_test_seq = maxFrames if maxFrames != 0 else L.test_wavvq.shape[0]          # :740
     dev = db.device
