@@ -293,11 +293,11 @@ struct MxIC {
 // and are prefetched AD-1 stages (of 8*MT*NT MFMAs = 256*MT*NT matrix-pipe cycles) ahead; the query operand sits in
 // the XCD's L2 (the whole query set is 1.2 MB) and is prefetched one stage ahead.
 template <int MT, int NT, int NTAPS, int KS, int GS, int AD, int BD>
-__global__ __launch_bounds__(64 * KS * GS, QPG_MX_OCC) void audio_cosine_mx_kernel(
+__device__ __forceinline__ void mx_ksplit_body(
     const float* __restrict__ base, int N, int T, int F, const int32_t* __restrict__ cand_t, int G, int tap_stride,
     const double* __restrict__ cn2, const float* __restrict__ q32, const double* __restrict__ qn2, int Q,
     double* __restrict__ D, int64_t ldD, const float* __restrict__ zeros, int32_t* __restrict__ stats, int64_t c_begin,
-    int64_t c_end) {
+    int64_t c_end, const unsigned bx, const unsigned by) {
   // candidates [c_begin, c_end) of the N*G; block = GS candidate groups x KS contraction slices (one wave each); the KS waves of a group are reduced through LDS
   __shared__ double red[GS][KS][MT * NT][4][64];  // [group][slice][tile][acc reg][lane]
 
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(64 * KS * GS, QPG_MX_OCC) void audio_cosine_mx_kern
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int w = wave % KS, gs = wave / KS;
   const int row = lane & 15, kq = lane >> 4;
-  const int64_t c0 = c_begin + ((int64_t)blockIdx.x * GS + gs) * (16 * MT);
-  const int q0 = blockIdx.y * (NT * 16);
+  const int64_t c0 = c_begin + ((int64_t)bx * GS + gs) * (16 * MT);
+  const int q0 = by * (NT * 16);
 
   int64_t aoff[MT];
   int at0[MT];
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64 * KS * GS, QPG_MX_OCC) void audio_cosine_mx_kern
 #endif
   // blocks start their walk over the feature groups at different offsets: all blocks read the SAME query rows, and in
   // lockstep they would all hit the same few L2 channels at any moment (only the order of the f64 additions changes)
-  const int rot = QPG_MX_ROT ? (int)(blockIdx.x % (unsigned)ne) : 0;
+  const int rot = QPG_MX_ROT ? (int)(bx % (unsigned)ne) : 0;
   auto eof = [&](int g) {                               // g in [0, 2*ne)
     g += rot;
     g = g >= ne ? g - ne : g;
@@ -502,6 +502,16 @@ __global__ __launch_bounds__(64 * KS * GS, QPG_MX_OCC) void audio_cosine_mx_kern
   }
 }
 
+template <int MT, int NT, int NTAPS, int KS, int GS, int AD, int BD>
+__global__ __launch_bounds__(64 * KS * GS, QPG_MX_OCC) void audio_cosine_mx_kernel(
+    const float* __restrict__ base, int N, int T, int F, const int32_t* __restrict__ cand_t, int G, int tap_stride,
+    const double* __restrict__ cn2, const float* __restrict__ q32, const double* __restrict__ qn2, int Q,
+    double* __restrict__ D, int64_t ldD, const float* __restrict__ zeros, int32_t* __restrict__ stats, int64_t c_begin,
+    int64_t c_end) {
+  mx_ksplit_body<MT, NT, NTAPS, KS, GS, AD, BD>(base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, zeros, stats,
+                                                c_begin, c_end, blockIdx.x, blockIdx.y);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // mx2: the mixed-precision sweep with the QUERY tile shared through LDS.  Measured on MI355X (experiments/audio_mx):
 // the split-K organisation above issues 40 row-scattered 16-B/lane loads per CU per 1536 matrix-pipe cycles and is
@@ -532,7 +542,14 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
     const float* __restrict__ base, int N, int T, int F, const int32_t* __restrict__ cand_t, int G, int tap_stride,
     const double* __restrict__ cn2, const float* __restrict__ q32, const double* __restrict__ qn2, int Q,
     double* __restrict__ D, int64_t ldD, const float* __restrict__ zeros, int32_t* __restrict__ stats, int64_t c_begin,
-    int64_t c_end) {
+    int64_t c_end, int main_blocks, int64_t c_tail_end) {
+  // blocks past `main_blocks` are the split-K remainder (one 16-candidate tile each, candidates from c_end on): they
+  // ride in the same launch so that they fill the CUs while the last round of 64-candidate blocks drains
+  if (!F64 && blockIdx.x >= (unsigned)main_blocks) {
+    mx_ksplit_body<1, NT, NTAPS, 4, 1, 2, 2>(base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, zeros, stats,
+                                             c_end, c_tail_end, blockIdx.x - (unsigned)main_blocks, blockIdx.y);
+    return;
+  }
   constexpr int ROWB = 256;                       // bytes of one query row per stage (64 features)
   constexpr int STAGE_BYTES = NT * 16 * ROWB;     // 12 KB at NT = 3
   constexpr int PIECES = STAGE_BYTES / 1024;      // 1-KB DMA pieces (4 rows each)
@@ -736,6 +753,9 @@ static int launch_audio_mx_q(qpg_ctx* ctx, void* stream, const float* base, int 
 #ifndef QPG_MX_ORG
 #define QPG_MX_ORG 2       // 2: query tile through LDS (mx2) + split-K remainder; 1: split-K only (experiments)
 #endif
+#ifndef QPG_MX_TAIL_RIDES
+#define QPG_MX_TAIL_RIDES 1   // 1: the split-K remainder blocks are appended to the mx2 launch; 0: a launch of their own
+#endif
 extern "C" int qpg_audio_cosine_mx(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F,
                                    const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
                                    const float* q32, const double* qn2, int Q, double* D, int64_t ldD, int32_t* stats) {
@@ -759,14 +779,17 @@ extern "C" int qpg_audio_cosine_mx(qpg_ctx* ctx, void* stream, const float* base
     else main_x = (nbx * ny / ctx->n_cu) * ctx->n_cu / ny;
   }
   const int64_t c_mid = main_x * 64;
+  const int64_t tail_tiles = (C - c_mid + 15) / 16;
+  // a short remainder rides in the SAME launch (blocks main_x .. main_x + tail_tiles - 1: split-K, one tile each)
+  const bool ride = main_x > 0 && tail_tiles > 0 && tail_tiles <= 4 * (int64_t)ctx->n_cu && ny == 1 && QPG_MX_TAIL_RIDES;
   if (main_x > 0) {
-    dim3 grid((unsigned)main_x, (unsigned)ny);
+    dim3 grid((unsigned)(main_x + (ride ? tail_tiles : 0)), (unsigned)ny);
     hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, false>), grid, dim3(256), 0, qpg_stream(stream), base, N, T, F, cand_t, G,
-                       tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros, stats, (int64_t)0, c_mid);
+                       tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros, stats, (int64_t)0, c_mid, (int)main_x,
+                       C);
     QPG_LAUNCH_CHECK("audio_cosine_mx2_kernel");
   }
-  if (c_mid == C) return QPG_OK;
-  const int64_t tail_tiles = (C - c_mid + 15) / 16;
+  if (c_mid == C || ride) return QPG_OK;
   if (QPG_MX_ORG == 2 && tail_tiles * ny <= 4 * (int64_t)ctx->n_cu)
     return launch_audio_mx_q<1>(ctx, stream, base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, stats, c_mid, C);
   return launch_audio_mx_q<2>(ctx, stream, base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, stats, c_mid, C);
@@ -829,7 +852,7 @@ static int audio_cosine(const char* name, qpg_ctx* ctx, void* stream, const void
     dim3 grid((unsigned)main_x, (unsigned)ny);
     hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, true>), grid, dim3(256), 0, qpg_stream(stream),
                        static_cast<const float*>(base), N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD,
-                       (const float*)ctx->zeros, (int32_t*)nullptr, (int64_t)0, c_mid);
+                       (const float*)ctx->zeros, (int32_t*)nullptr, (int64_t)0, c_mid, (int)main_x, c_mid);
     QPG_LAUNCH_CHECK("audio_cosine_mx2_kernel<f64>");
   }
   if (c_mid == C) return QPG_OK;
