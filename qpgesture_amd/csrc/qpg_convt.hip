@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void convt_f32_kernel(ConvTArgs a) {
 // one 16-channel tile (bias, ReLU, residual, 16-byte stores).
 // ---------------------------------------------------------------------------------------------------------------
 #define CTS_NW 8     // waves per block = ways the contraction is split
-template <bool RELU_IN>
+template <bool RELU_IN, int PD>
 __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs a) {
   __shared__ __attribute__((aligned(16))) float part[CTS_NW][4][64][4];     // [wave][tile][lane][r]
   const int tid = threadIdx.x, lane = tid & 63, ml = lane & 15, g = lane >> 4;
@@ -472,16 +472,43 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
   f32x4 acc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  Frag f0 = load(kb0), f1 = load(kb0 + 1), f2 = load(kb0 + 2);
-  for (int kb = kb0; kb < kb1; ++kb) {
-    const Frag f3 = load(kb + 3);
+  // A block is bound by how fast ONE CU pulls its 64-channel weight slice (393 KB for a k3 layer) out of L2, not by its
+  // 2.6 us of MFMAs.  PD = 16-k blocks (5 KB per wave each) in flight; when the wave's share is a whole number of
+  // PD-chunks the loop is peeled so that no chunk prefetches past the end (branch-free inside: a conditional load
+  // makes hipcc drain vmcnt); PD = 0 is the general 3-deep rotation.
+  if (PD > 0 && (kb1 - kb0) == per && per % (PD > 0 ? PD : 1) == 0) {
+    constexpr int P = PD > 0 ? PD : 1;
+    Frag f[P];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int d = 0; d < P; ++d) f[d] = load(kb0 + d);
+    for (int kb = kb0; kb + P < kb1; kb += P) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = mfma16(f0.a[q][j], f0.b[j], acc[q]);
-    f0 = f1;
-    f1 = f2;
-    f2 = f3;
+      for (int d = 0; d < P; ++d) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = mfma16(f[d].a[q][j], f[d].b[j], acc[q]);
+        f[d] = load(kb + d + P);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < P; ++d)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = mfma16(f[d].a[q][j], f[d].b[j], acc[q]);
+  } else {
+    Frag f0 = load(kb0), f1 = load(kb0 + 1), f2 = load(kb0 + 2);
+    for (int kb = kb0; kb < kb1; ++kb) {
+      const Frag f3 = load(kb + 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = mfma16(f0.a[q][j], f0.b[j], acc[q]);
+      f0 = f1;
+      f1 = f2;
+      f2 = f3;
+    }
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&part[w][q][lane][0]) = acc[q];
@@ -553,8 +580,15 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
   // short sequences: 16-position x 64-channel blocks whose waves split the contraction (see convt_small_f32_kernel)
   if (((M + CT_ROWS - 1) / CT_ROWS) * (Cout_pad / 128) * 2 < 3 * (int64_t)ctx->n_cu) {
     const dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / 64));
-    if (relu_in) hipLaunchKernelGGL(convt_small_f32_kernel<true>, sgrid, dim3(64 * CTS_NW), 0, qpg_stream(stream), a);
-    else hipLaunchKernelGGL(convt_small_f32_kernel<false>, sgrid, dim3(64 * CTS_NW), 0, qpg_stream(stream), a);
+    const int per = (a.nstage * 4 + CTS_NW - 1) / CTS_NW;          // 16-k blocks per wave
+    const int pd = (a.nstage * 4) % CTS_NW ? 0 : (per % 6 == 0 ? 6 : (per % 4 == 0 ? 4 : 0));
+#define CTS_LAUNCH(R, P) hipLaunchKernelGGL((convt_small_f32_kernel<R, P>), sgrid, dim3(64 * CTS_NW), 0, qpg_stream(stream), a)
+    if (relu_in) {
+      if (pd == 6) CTS_LAUNCH(true, 6); else if (pd == 4) CTS_LAUNCH(true, 4); else CTS_LAUNCH(true, 0);
+    } else {
+      if (pd == 6) CTS_LAUNCH(false, 6); else if (pd == 4) CTS_LAUNCH(false, 4); else CTS_LAUNCH(false, 0);
+    }
+#undef CTS_LAUNCH
     QPG_LAUNCH_CHECK("convt_small_f32_kernel");
     return QPG_OK;
   }
