@@ -274,3 +274,15 @@ def test_numpy_ranks_is_the_reference_expression():
     r = CodeKNN.numpy_ranks(d).numpy()
     for row, got in zip(d.numpy(), r):
         assert np.array_equal(got, np.array(list(row.astype(np.float64))).argsort().argsort())
+
+
+def test_mixed_precision_constants_agree_with_the_header():
+    """The band the mixed-precision select re-evaluates in must cover twice the sweep's bound as the C side states it."""
+    import re
+    from qpgesture_amd import code_knn
+    txt = open(_lib.HEADER_PATH).read()
+    m = re.search(r"#define\s+QPG_AUDIO_MX_ERR\s+([0-9.eE+-]+)", txt)
+    assert m and float(m.group(1)) == code_knn.AUDIO_MX_ERR
+    assert code_knn.AUDIO_MX_BAND >= 2.0 * code_knn.AUDIO_MX_ERR
+    u = 2.0 ** -24
+    assert code_knn.AUDIO_MX_ERR >= 32 * u / (1 - 32 * u) + 1e-13        # gamma_32 + the f64 part
