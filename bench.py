@@ -201,8 +201,8 @@ def main():
                 # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
                 # measured for exactly this launch shape only: profiles/r02_pmc_audio.md
                 "traffic": (AUDIO_MX_TRAFFIC_BYTES if mixed else AUDIO_TRAFFIC_BYTES) if default_shape else None,
-                "kernel": ("audio_cosine_mx2_kernel + audio_cosine_mx_kernel (one sweep: LDS-shared-query blocks + "
-                           "split-K remainder; f32 matrix cores, error bounded a priori, f64 re-evaluation in the select)")
+                "kernel": ("audio_cosine_mx2_kernel (one launch: LDS-shared-query blocks + split-K remainder blocks; f32 "
+                           "matrix cores, error bounded a priori, f64 re-evaluation in the select)")
                 if mixed else "audio_cosine_f64_kernel",
                 "kernel_ms": round(k_ms, 4),
                 "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_launches_timed": len(ms),
@@ -288,7 +288,7 @@ def main():
 # HBM bytes per audio_cosine_f64_kernel launch at the default shape (N_db=2048, Q=48), rocprofv3 PMC, separate
 # --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 correction on FETCH_SIZE: profiles/r02_pmc_audio.md
 AUDIO_TRAFFIC_BYTES = 923_000_000
-AUDIO_MX_TRAFFIC_BYTES = 979_000_000      # mixed-precision sweep (both launches), same file
+AUDIO_MX_TRAFFIC_BYTES = 1_023_000_000    # mixed-precision sweep (one launch: mx2 blocks + split-K remainder), same file
 
 
 def vqvae_bench(dev, a, world, rank):
