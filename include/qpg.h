@@ -139,6 +139,17 @@ int64_t qpg_text_percode_ws_bytes(int64_t C, int Q, int K, int tiles_per_chunk);
 int qpg_text_percode_f32(qpg_ctx*, void* stream, const float* xt, int64_t C, int Dm, const int16_t* cand_code, int K,
                          const float* qn, int Q, int tiles_per_chunk, int32_t idx_base, float absent, void* ws,
                          int64_t ws_bytes, float* out_dist, int32_t* out_idx, int16_t* out_rank, int32_t* out_nn);
+/* fp16-STORAGE variant of the pair above (BASELINE.json "fp16 features"): qpg_text_pack_candidates_f16 stores the grid
+ * rows ROUNDED to IEEE f16 (xh: [dev] f16, ceil(N*G/64)*64*Dm elements, tiled [c/64][e/8][c%64][e%8], 16-byte aligned)
+ * and their sklearn norms computed from the rounded values (nrm: [dev] f32 [N*G]); qpg_text_percode_f16 widens,
+ * normalises with sklearn's division and continues with the same f32 arithmetic: its tables are the reference's on
+ * the f16-rounded database, bit for bit.  Half the HBM bytes of the dominant array; the sweep stays VALU-bound. */
+int qpg_text_pack_candidates_f16(qpg_ctx*, void* stream, const float* x, int N, int R, int Dm, const int32_t* cand_r,
+                                 int G, void* xh, float* nrm);
+int qpg_text_percode_f16(qpg_ctx*, void* stream, const void* xh, const float* nrm, int64_t C, int Dm,
+                         const int16_t* cand_code, int K, const float* qn, int Q, int32_t idx_base, float absent,
+                         void* ws, int64_t ws_bytes, float* out_dist, int32_t* out_idx, int16_t* out_rank,
+                         int32_t* out_nn);
 
 /* vq-wav2vec audio sweep (the mode the paper describes; flags use_wavvq/use_feature of GestureKNN.py:557-560):
  * D[q][c] = Levenshtein distance (unit costs, python-Levenshtein distance()) between the 11-symbol strings of

@@ -35,6 +35,8 @@ _SIGS = {
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
     "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
     "qpg_text_percode_f32": [P, L, I, P, I, P, I, I, ctypes.c_int32, c_float, P, L, P, P, P, P],
+    "qpg_text_pack_candidates_f16": [P, I, I, I, P, I, P, P],
+    "qpg_text_percode_f16": [P, P, L, I, P, I, P, I, ctypes.c_int32, c_float, P, L, P, P, P, P],
     "qpg_percode_resolve_f32": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P],
     "qpg_percode_resolve_f64": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P, P],
     "qpg_percode_finalize_f64": [P, P, I, I, c_double, P, P, P],

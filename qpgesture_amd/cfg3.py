@@ -31,15 +31,27 @@ class CosineIndex:
     """Candidates resident in HBM, sklearn-normalised and tiled for lane-per-candidate access
     (qpg_text_pack_candidates_f32); masked rows carry code -1 and can never win."""
 
-    def __init__(self, X, code, valid=None, n_codes=K_CODES, device="cuda:0", tiles_per_chunk=1):
+    def __init__(self, X, code, valid=None, n_codes=K_CODES, device="cuda:0", tiles_per_chunk=1, feature_dtype="f32"):
+        """feature_dtype "f16": the rows are stored ROUNDED to f16 (half the bytes) with their f32 norms; the tables are
+        then the reference's on the f16-rounded database (qpg_text_percode_f16)."""
         dev = torch.device(device)
         n, d = X.shape
         self.device, self.n, self.d, self.K = dev, n, d, n_codes
         self.tiles_per_chunk = tiles_per_chunk
+        self.feature_dtype = feature_dtype
         xd = torch.as_tensor(X, dtype=torch.float32).to(dev).contiguous().view(n, 1, d)
-        self.xt = torch.zeros((((n + 63) // 64) * 64 * d,), dtype=torch.float32, device=dev)
         cand_r = torch.zeros((1,), dtype=torch.int32, device=dev)
-        _lib.call("qpg_text_pack_candidates_f32", dev, xd, n, 1, d, cand_r, 1, self.xt)
+        if feature_dtype == "f16":
+            if tiles_per_chunk != 1:
+                raise ValueError("the f16 image is swept by the LDS-free organisation only (tiles_per_chunk=1)")
+            self.xt = torch.zeros((((n + 63) // 64) * 64 * d,), dtype=torch.float16, device=dev)
+            self.nrm = torch.empty((n,), dtype=torch.float32, device=dev)
+            _lib.call("qpg_text_pack_candidates_f16", dev, xd, n, 1, d, cand_r, 1, self.xt, self.nrm)
+        elif feature_dtype == "f32":
+            self.xt = torch.zeros((((n + 63) // 64) * 64 * d,), dtype=torch.float32, device=dev)
+            _lib.call("qpg_text_pack_candidates_f32", dev, xd, n, 1, d, cand_r, 1, self.xt)
+        else:
+            raise ValueError("feature_dtype must be 'f32' or 'f16'")
         cm = np.asarray(code, np.int64)
         if valid is not None:
             cm = np.where(np.asarray(valid), cm, -1)
@@ -58,8 +70,12 @@ class CosineIndex:
         dist = torch.empty((Q, self.K), dtype=torch.float32, device=dev)
         idx = torch.empty((Q, self.K), dtype=torch.int32, device=dev)
         nn = torch.empty((Q,), dtype=torch.int32, device=dev) if want_nn else None
-        _lib.call("qpg_text_percode_f32", dev, self.xt, self.n, self.d, self.cand_code, self.K, qn, Q,
-                  self.tiles_per_chunk, 0, ABSENT, self._ws, self._ws.numel(), dist, idx, None, nn)
+        if self.feature_dtype == "f16":
+            _lib.call("qpg_text_percode_f16", dev, self.xt, self.nrm, self.n, self.d, self.cand_code, self.K, qn, Q,
+                      0, ABSENT, self._ws, self._ws.numel(), dist, idx, None, nn)
+        else:
+            _lib.call("qpg_text_percode_f32", dev, self.xt, self.n, self.d, self.cand_code, self.K, qn, Q,
+                      self.tiles_per_chunk, 0, ABSENT, self._ws, self._ws.numel(), dist, idx, None, nn)
         return dist, idx, nn
 
 
@@ -72,8 +88,10 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
     per = (N_DB + world - 1) // world
     lo, hi = min(rank * per, N_DB), min((rank + 1) * per, N_DB)
     import os
+    f16 = getattr(a, "feature_dtype", "f32") == "f16"
     index = CosineIndex(X[lo:hi], code[lo:hi], valid[lo:hi], device=dev,
-                        tiles_per_chunk=int(os.environ.get("QPG_CFG3_TPC", "1")))
+                        tiles_per_chunk=1 if f16 else int(os.environ.get("QPG_CFG3_TPC", "1")),
+                        feature_dtype="f16" if f16 else "f32")
     qd = torch.from_numpy(q).to(dev)
     steps = min(a.steps, 50)
     for _ in range(max(a.warmup, 3)):
@@ -98,19 +116,21 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
     ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
     k_ms = ms[len(ms) // 2]
     n_loc = hi - lo
-    alg_bytes = n_loc * DIM * 4 + n_loc * 4 + N_Q * DIM * 4 + N_Q * K_CODES * 8
+    alg_bytes = n_loc * DIM * (2 if f16 else 4) + n_loc * (8 if f16 else 4) + N_Q * DIM * 4 + N_Q * K_CODES * 8
     lane_ops = 3.0 * N_Q * n_loc * DIM                                                   # sub, mul, add per element pair
     valu_peak = 1024 * 2.4e9 * 32                                                        # packed f32 non-FMA lane-ops/s
     return {"metric": "per-code min cosine sweep, query-candidate pairs/sec (cfg-3)", "value": round(N_Q * N_DB * steps / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": max(a.warmup, 3),
             "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg-3: DB 100000 x 512 f32, 512 codes, Bernoulli(0.9) validity mask, 1000 queries; "
-                                   "sklearn-exact f32 cosine, per-code min + argmin + global nearest neighbour",
+            "config": {"workload": "cfg-3: DB 100000 x 512 %s, 512 codes, Bernoulli(0.9) validity mask, 1000 queries; "
+                                   "sklearn-exact f32 cosine, per-code min + argmin + global nearest neighbour"
+                                   % ("stored f16 (rounded), widened + normalised in registers" if f16 else "f32"),
+                       "feature_dtype": "f16" if f16 else "f32",
                        "n_db": N_DB, "dim": DIM, "queries": N_Q, "parallelism": "db rows / %d" % world},
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": hbm_peak_gbs,
                          "unit": "GB/s", "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / hbm_peak_gbs, 4),
-                         "traffic": CFG3_TRAFFIC_BYTES if world == 1 else None,
+                         "traffic": CFG3_TRAFFIC_BYTES if world == 1 and not f16 else None,
                          "kernel": "text_cosine_gmin_f32_kernel (+ fill, merge)", "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes": int(alg_bytes),
                          "note": "the distance is sklearn's separately rounded f32 arithmetic (bit-exact indices are the "

@@ -70,6 +70,60 @@ extern "C" int qpg_text_pack_candidates_f32(qpg_ctx* ctx, void* stream, const fl
   return QPG_OK;
 }
 
+// fp16-STORAGE variant (BASELINE.json configs[2]/[4] "fp16 features"): the raw rows are stored in IEEE f16, tiled
+// xh[tile][Dm/8][64][8] (a lane's 16-byte piece = 8 consecutive features of its candidate), plus one f32 norm per
+// candidate computed — in the same sklearn/einsum order — from the ROUNDED values.  The sweep widens f16 -> f32,
+// divides by the norm (sklearn's `X /= norms`, a correctly rounded f32 division) and continues with the same
+// arithmetic, so its results are the reference's on the f16-rounded database, bit for bit.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void text_pack_candidates_h_kernel(const float* __restrict__ x, int N, int R, int Dm,
+                                                                     const int32_t* __restrict__ cand_r, int G,
+                                                                     _Float16* __restrict__ xh, float* __restrict__ nrm) {
+  const int64_t C = (int64_t)N * G;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t c = t >> 2;
+  const int l = (int)(t & 3);
+  const bool live = c < C;
+  if (!live) c = C - 1;
+  const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
+  const float* p = x + ((int64_t)j * R + cand_r[g]) * Dm;
+  float a = 0.f;
+  for (int k = 0; k < (Dm >> 4); ++k) {
+#pragma unroll
+    for (int u = 3; u >= 0; --u) {
+      const float v = (float)(_Float16)p[k * 16 + u * 4 + l];
+      a = f_add(f_mul(v, v), a);
+    }
+  }
+  const float o1 = __shfl_xor(a, 1, 64);
+  const float pair = f_add(a, o1);
+  const float o2 = __shfl_xor(pair, 2, 64);
+  float n = f_sqrt(f_add(pair, o2));
+  if (n < 10.f * 1.1920928955078125e-07f) n = 1.f;
+  if (live) {
+    const int64_t tile = c >> 6;
+    const int lane = (int)(c & 63);
+    _Float16* o = xh + tile * (int64_t)Dm * 64;
+    for (int e = l; e < Dm; e += 4) o[((int64_t)(e >> 3) * 64 + lane) * 8 + (e & 7)] = (_Float16)p[e];
+    if (l == 0) nrm[c] = n;
+  }
+}
+
+extern "C" int qpg_text_pack_candidates_f16(qpg_ctx* ctx, void* stream, const float* x, int N, int R, int Dm,
+                                            const int32_t* cand_r, int G, void* xh, float* nrm) {
+  QPG_REQUIRE(ctx && x && cand_r && xh && nrm && N >= 0 && R > 0 && G > 0, "qpg_text_pack_candidates_f16: bad argument");
+  if (Dm <= 0 || (Dm % 16) != 0) {
+    qpg_set_error("qpg_text_pack_candidates_f16: compiled for Dm %% 16 == 0 (got %d)", Dm);
+    return QPG_EUNSUP;
+  }
+  const int64_t C = (int64_t)N * G;
+  if (C == 0) return QPG_OK;
+  hipLaunchKernelGGL(text_pack_candidates_h_kernel, dim3((unsigned)((C * 4 + 255) / 256)), dim3(256), 0,
+                     qpg_stream(stream), x, N, R, Dm, cand_r, G, static_cast<_Float16*>(xh), nrm);
+  QPG_LAUNCH_CHECK("text_pack_candidates_h_kernel");
+  return QPG_OK;
+}
+
 // QB queries per lane, NG waves per block (all on the same 64-candidate tile, different query groups).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // q - x on a pair: one v_pk_add_f32 with the (wave-uniform) query pair read directly from an SGPR pair and the
@@ -81,9 +135,11 @@ __device__ __forceinline__ f32x2 pk_sub_sv(f32x2 q, f32x2 x) {
 }
 
 // Distances of ONE 64-candidate tile (lane = candidate) against QB wave-uniform query rows, sklearn/einsum f32 order.
-template <int QB>
+// HALF: xp points at the lane's 16-byte f16 pieces (two per 16-element group, 64 pieces apart) and `nrm` is the
+// candidate's norm: the group is widened and divided element by element before use (sklearn's normalisation).
+template <int QB, bool HALF = false>
 __device__ __forceinline__ void text_tile_dists(const f32x4* __restrict__ xp, const float* const (&qrow)[QB], int nk,
-                                                float (&dist)[QB]) {
+                                                float (&dist)[QB], float nrm = 1.f) {
   // accumulators as two packed pairs (einsum lanes 0,1 and 2,3): every step is 3 packed VALU ops per 2 elements
   // (v_pk_add_f32 with the query pair straight from SGPRs and a negated candidate pair, v_pk_mul_f32, v_pk_add_f32)
   f32x2 acc[QB][2];
@@ -94,15 +150,29 @@ __device__ __forceinline__ void text_tile_dists(const f32x4* __restrict__ xp, co
   // of the current one (two 16-SGPR buffers); element order per accumulator stays u = 3,2,1,0.
   f32x16 qv = *reinterpret_cast<const f32x16*>(qrow[0]);
   f32x4 xnext[4];
+  constexpr int NL = HALF ? 2 : 4;                // 16-byte loads per 16-element group
 #pragma unroll
-  for (int u = 0; u < 4; ++u) xnext[u] = xp[u * 64];
+  for (int u = 0; u < NL; ++u) xnext[u] = xp[u * 64];
   for (int k = 0; k < nk; ++k) {
     f32x4 x[4];
     const int kx = (k + 1 < nk) ? k + 1 : 0;      // candidate tile: prefetch the next 16-element group too
+    if (HALF) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      x[u] = xnext[u];
-      xnext[u] = xp[(kx * 4 + u) * 64];
+      for (int u = 0; u < 2; ++u) {
+        const h16x8 h = __builtin_bit_cast(h16x8, xnext[u]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[2 * u][e] = f_div((float)h[e], nrm);
+          x[2 * u + 1][e] = f_div((float)h[4 + e], nrm);
+        }
+        xnext[u] = xp[(kx * 2 + u) * 64];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = xnext[u];
+        xnext[u] = xp[(kx * 4 + u) * 64];
+      }
     }
 #pragma unroll
     for (int i = 0; i < QB; ++i) {
@@ -222,12 +292,13 @@ __global__ __launch_bounds__(64 * NG) void text_cosine_percode_f32_kernel(
 // distances straight into the global [Q][K] table with the same look-first atomicMin.  The look is an L1-bypassing
 // load (a stale value could only be larger, i.e. cost a redundant atomic).  Per (query, code) the n-th candidate is a
 // new minimum with probability 1/n, so the atomics are ~H(C/K) per pair (about 6 of 195 here), not one per candidate.
-template <int QB, int NG>
+template <int QB, int NG, bool HALF>
 __global__ __launch_bounds__(64 * NG) void text_cosine_gmin_f32_kernel(const float* __restrict__ xt, int64_t C, int Dm,
                                                                        const int16_t* __restrict__ cand_code, int K,
                                                                        const float* __restrict__ qn, int Q,
                                                                        int32_t idx_base,
-                                                                       unsigned long long* __restrict__ table) {
+                                                                       unsigned long long* __restrict__ table,
+                                                                       const float* __restrict__ nrm) {
   const int lane = threadIdx.x & 63;
   const int qg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-aware work mapping (blocks are dealt round-robin to the 8 XCDs, each with its own L2): all the query-group
@@ -246,10 +317,11 @@ __global__ __launch_bounds__(64 * NG) void text_cosine_gmin_f32_kernel(const flo
     if (q >= Q) q = Q - 1;
     qrow[i] = qn + (int64_t)q * Dm;
   }
-  const f32x4* xp = reinterpret_cast<const f32x4*>(xt + tile * (int64_t)Dm * 64) + lane;
+  // (HALF: xt is the f16 image, half as many bytes per tile)
+  const f32x4* xp = reinterpret_cast<const f32x4*>(xt + tile * (int64_t)Dm * (HALF ? 32 : 64)) + lane;
   float dist[QB];
-  text_tile_dists<QB>(xp, qrow, Dm >> 4, dist);
   const int64_t c = tile * 64 + lane;
+  text_tile_dists<QB, HALF>(xp, qrow, Dm >> 4, dist, HALF ? nrm[c < C ? c : C - 1] : 1.f);
   const int cd = c < C ? cand_code[c] : -1;
   if ((unsigned)cd >= (unsigned)K) return;
   const unsigned int ci = (unsigned int)(c + idx_base);
@@ -316,11 +388,13 @@ extern "C" int64_t qpg_text_percode_ws_bytes(int64_t C, int Q, int K, int tiles_
   return (int64_t)Q * K * 8;
 }
 
-extern "C" int qpg_text_percode_f32(qpg_ctx* ctx, void* stream, const float* xt, int64_t C, int Dm,
-                                    const int16_t* cand_code, int K, const float* qn, int Q, int tiles_per_chunk,
-                                    int32_t idx_base, float absent, void* ws, int64_t ws_bytes, float* out_dist,
-                                    int32_t* out_idx, int16_t* out_rank, int32_t* out_nn) {
+static int text_percode(qpg_ctx* ctx, void* stream, const float* xt, const float* nrm, int64_t C, int Dm,
+                        const int16_t* cand_code, int K, const float* qn, int Q, int tiles_per_chunk,
+                        int32_t idx_base, float absent, void* ws, int64_t ws_bytes, float* out_dist,
+                        int32_t* out_idx, int16_t* out_rank, int32_t* out_nn) {
   QPG_REQUIRE(ctx && xt && (cand_code || C == 0) && qn && ws && out_dist && out_idx, "qpg_text_percode_f32: null pointer");
+  QPG_REQUIRE(!nrm || tiles_per_chunk == 1, "qpg_text_percode_f16: the f16 image is swept by the LDS-free organisation only "
+                                            "(tiles_per_chunk == 1)");
   QPG_REQUIRE(C >= 0 && Q >= 0 && K > 0 && K <= 1024 && tiles_per_chunk > 0 && C + (int64_t)idx_base < 0xffffffffll,
               "qpg_text_percode_f32: bad size (K <= 1024)");
   if (Dm <= 0 || (Dm % 16) != 0) {
@@ -351,8 +425,13 @@ extern "C" int qpg_text_percode_f32(qpg_ctx* ctx, void* stream, const float* xt,
   if (tiles_per_chunk == 1) {      // LDS-free organisation: one tile per block, NG query groups share it
     constexpr int QG = 12, NW = 8;
     const int64_t nqb = (Q + QG * NW - 1) / (QG * NW);
-    hipLaunchKernelGGL((text_cosine_gmin_f32_kernel<QG, NW>), dim3((unsigned)(((ntile + 7) / 8) * nqb * 8)), dim3(64 * NW), 0,
-                       qpg_stream(stream), xt, C, Dm, cand_code, K, qn, Q, idx_base, partial);
+    const dim3 grid((unsigned)(((ntile + 7) / 8) * nqb * 8));
+    if (nrm)
+      hipLaunchKernelGGL((text_cosine_gmin_f32_kernel<QG, NW, true>), grid, dim3(64 * NW), 0, qpg_stream(stream), xt, C, Dm,
+                         cand_code, K, qn, Q, idx_base, partial, nrm);
+    else
+      hipLaunchKernelGGL((text_cosine_gmin_f32_kernel<QG, NW, false>), grid, dim3(64 * NW), 0, qpg_stream(stream), xt, C, Dm,
+                         cand_code, K, qn, Q, idx_base, partial, nrm);
     QPG_LAUNCH_CHECK("text_cosine_gmin_f32_kernel");
   } else if (nchunk > 0) {
     hipLaunchKernelGGL((text_cosine_percode_f32_kernel<QB, NG>), dim3((unsigned)nchunk, (unsigned)((Q + QB - 1) / QB)),
@@ -364,6 +443,23 @@ extern "C" int qpg_text_percode_f32(qpg_ctx* ctx, void* stream, const float* xt,
                      partial, 1, Q, K, absent, out_dist, out_idx, out_rank, out_nn);
   QPG_LAUNCH_CHECK("text_percode_merge_kernel");
   return QPG_OK;
+}
+
+extern "C" int qpg_text_percode_f32(qpg_ctx* ctx, void* stream, const float* xt, int64_t C, int Dm,
+                                    const int16_t* cand_code, int K, const float* qn, int Q, int tiles_per_chunk,
+                                    int32_t idx_base, float absent, void* ws, int64_t ws_bytes, float* out_dist,
+                                    int32_t* out_idx, int16_t* out_rank, int32_t* out_nn) {
+  return text_percode(ctx, stream, xt, nullptr, C, Dm, cand_code, K, qn, Q, tiles_per_chunk, idx_base, absent, ws, ws_bytes,
+                      out_dist, out_idx, out_rank, out_nn);
+}
+
+extern "C" int qpg_text_percode_f16(qpg_ctx* ctx, void* stream, const void* xh, const float* nrm, int64_t C, int Dm,
+                                    const int16_t* cand_code, int K, const float* qn, int Q, int32_t idx_base,
+                                    float absent, void* ws, int64_t ws_bytes, float* out_dist, int32_t* out_idx,
+                                    int16_t* out_rank, int32_t* out_nn) {
+  QPG_REQUIRE(nrm && (reinterpret_cast<uintptr_t>(xh) % 16) == 0, "qpg_text_percode_f16: norms missing or image misaligned");
+  return text_percode(ctx, stream, static_cast<const float*>(xh), nrm, C, Dm, cand_code, K, qn, Q, 1, idx_base, absent, ws,
+                      ws_bytes, out_dist, out_idx, out_rank, out_nn);
 }
 
 template <int QB, int NG>

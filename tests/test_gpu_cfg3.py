@@ -108,3 +108,37 @@ def test_cfg3_100k_by_512_per_code_min():
     ev[1].record()
     torch.cuda.synchronize()
     print("cfg-3 (fused path): %.2f ms per 1000-query batch" % (ev[0].elapsed_time(ev[1]) / 5))
+
+
+def test_cfg3_f16_storage_equals_reference_arithmetic_on_rounded_rows():
+    """fp16-storage variant: the DB rows live in HBM as f16 + an f32 norm each; the sweep widens, normalises with
+    sklearn's division and runs the same f32 arithmetic, so its tables are the C oracle's on the f16-ROUNDED database,
+    bit for bit (a 10-query slice; the oracle needs ~0.3 s per query), and every winner carries its column's code."""
+    import torch
+    from oracle import cref
+    from qpgesture_amd.cfg3 import CosineIndex
+    X, code, valid, q, rows = _inputs()
+    Xr = X.astype(np.float16).astype(np.float32)
+    index = CosineIndex(X, code, valid, n_codes=K, feature_dtype="f16")
+    assert index.xt.dtype == torch.float16 and index.xt.numel() * 2 == ((N + 63) // 64) * 64 * D * 2
+    qd = torch.from_numpy(q).cuda()
+    fd, fi, nn = index.query(qd)
+    dist, idx = fd.cpu().numpy(), fi.cpu().numpy()
+    sel = np.r_[0:4, 200:204, Q - 2:Q]
+    cm = np.where(valid, code, -1).astype(np.int32).reshape(N, 1)
+    od, oi = cref.text_scan(Xr.reshape(N, 1, D), [0], cm, [0], q[sel], K=K, n_threads=8)
+    assert np.array_equal(idx[sel], oi)
+    assert np.array_equal(dist[sel], od)
+    assert valid[idx[idx >= 0]].all()
+    assert np.array_equal(code[idx[idx >= 0]], np.nonzero(idx >= 0)[1])
+    # against the f32-stored index: same winners almost everywhere, distances moved by the rounding of the inputs only
+    d32, i32, _ = CosineIndex(X, code, valid, n_codes=K).query(qd)
+    assert 1e-6 < float((d32 - fd).abs().max()) < 1e-2
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    index.query(qd)
+    ev[0].record()
+    for _ in range(5):
+        index.query(qd)
+    ev[1].record()
+    torch.cuda.synchronize()
+    print("cfg-3 (f16 storage): %.2f ms per 1000-query batch" % (ev[0].elapsed_time(ev[1]) / 5))
