@@ -127,8 +127,8 @@ def main():
     knn = CodeKNN(db, rng=np.random.RandomState(123456))
     knn.overlap_sweeps = not a.no_overlap
     knn.audio_precision = a.audio_precision
-    # the mixed-precision sweep is taken where CodeKNN.sweep_audio can take it (one GPU, f32 base); see its comment
-    mixed = a.audio_precision == "mixed" and world == 1 and a.feature_dtype == "f32"
+    # the mixed-precision sweep is taken where CodeKNN.sweep_audio can take it (one GPU); see its comment
+    mixed = a.audio_precision == "mixed" and world == 1
 
     # clips: weak = CL per rank (every rank holds all of them: M*180*1024 f32 = 4.4 MB each); strong = ONE clip in all
     n_clips = CL if strong else CL * world

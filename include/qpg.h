@@ -113,6 +113,11 @@ int qpg_audio_cosine_mx(qpg_ctx*, void* stream, const float* base, int N, int T,
                         int n_taps, int tap_stride, const double* cn2, const float* q32, const double* qn2, int Q,
                         double* D, int64_t ldD, int32_t* stats);
 
+/* qpg_audio_cosine_mx over a base track stored in IEEE f16 (as qpg_audio_cosine_f64_h): same bound, on the rounded values. */
+int qpg_audio_cosine_mx_h(qpg_ctx*, void* stream, const void* base_f16, int N, int T, int F, const int32_t* cand_t, int G,
+                          int n_taps, int tap_stride, const double* cn2, const float* q32, const double* qn2, int Q,
+                          double* D, int64_t ldD, int32_t* stats);
+
 /* One-off DB preparation for the text sweep: sklearn-normalise the grid rows x[j][cand_r[g]] (bit-exact,
  * as qpg_l2_normalize_rows_f32) and store them tiled for lane-per-candidate access:
  *   xt[c/64][e/4][c%64][e%4],  c = j*G + g   (a wave's 64 lanes read 64 consecutive 16-B pieces).
@@ -217,7 +222,9 @@ int qpg_percode_select_guarded_f64(qpg_ctx*, void* stream, const double* D, int6
                                    int64_t C, int K, double absent, int32_t idx_base, double* out_dist, int32_t* out_idx,
                                    int16_t* out_rank, int q_block, int64_t block_stride, const float* base, int T, int F,
                                    const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32, double eps,
-                                   int32_t* stats);
+                                   int32_t* stats, int base_is_f16);
+/* base_is_f16 != 0 (here and in qpg_percode_select_mixed_f64): `base` points at an IEEE f16 track (as swept by
+ * qpg_audio_cosine_f64_h / qpg_audio_cosine_mx_h); the re-evaluation then runs on the widened, i.e. rounded, values. */
 
 /* Select for the matrix of qpg_audio_cosine_mx.  Same outputs as qpg_percode_select_guarded_f64.  Two sweep values
  * further apart than eps1 (>= 2 x QPG_AUDIO_MX_ERR) are ordered like the exact distances; inside that band
@@ -234,7 +241,7 @@ int qpg_percode_select_mixed_f64(qpg_ctx*, void* stream, const double* D, int64_
                                  int16_t* out_rank, int q_block, int64_t block_stride, const float* base, int T, int F,
                                  const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32,
                                  const double* qn2, const double* cn2, double eps1, double eps2, int32_t* stats,
-                                 void* ws, int64_t ws_bytes);
+                                 void* ws, int64_t ws_bytes, int base_is_f16);
 /* ws: [dev] scratch of qpg_percode_select_mixed_ws_bytes(Q, K) bytes, 16-byte aligned — with it the call is three
  * launches (lists | tier-1 dot products on every CU | merge, tier 2, ranks); NULL: one launch, each query's tier-1 work
  * on its own CU (slower when the lists are long). */

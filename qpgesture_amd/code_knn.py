@@ -260,7 +260,7 @@ class CodeKNN:
         # (qpg_audio_cosine_mx, |error| <= AUDIO_MX_ERR) and the select re-evaluates every comparison the bound leaves
         # open with f64 dot products, then the near-tie guard (qpg_percode_select_mixed_f64): same candidates and ranks
         # as "f64", the sweep at twice the matrix rate.  Taken only where the select sees every comparison that
-        # follows (single-GPU DB, ranks fused, f32 base, guard on); everything else runs the f64 sweep.
+        # follows (single-GPU DB, ranks fused, guard on; f32 or f16 base); everything else runs the f64 sweep.
         self.audio_precision = "mixed"
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
         # host_ranks (the CLI's --tie_rule numpy): rank the (Q,512) audio / text minima with the reference's own
@@ -318,10 +318,11 @@ class CodeKNN:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
         fused_rank = want_rank and db.world == 1
+        half = db.feature_dtype == "f16"
         mixed = (self.audio_precision == "mixed" and fused_rank and reduce and out is None and self.tie_eps > 0
-                 and db.feature_dtype == "f32" and C > 0 and db.K <= 512)
+                 and C > 0 and db.K <= 512)
         if mixed:
-            _lib.call("qpg_audio_cosine_mx", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
+            _lib.call("qpg_audio_cosine_mx_h" if half else "qpg_audio_cosine_mx", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
                       NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, D.stride(0), self._guard_stats)
         else:
             _lib.call("qpg_audio_cosine_f64" if db.feature_dtype == "f32" else "qpg_audio_cosine_f64_h", dev, db.base,
@@ -346,11 +347,11 @@ class CodeKNN:
                       float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
                       db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2, AUDIO_MX_BAND, float(self.tie_eps),
                       self._guard_stats, None if self.mixed_single_launch else ws,
-                      0 if self.mixed_single_launch else ws.numel())
-        elif self.tie_eps > 0 and C > 0 and db.feature_dtype == "f32":
+                      0 if self.mixed_single_launch else ws.numel(), int(half))
+        elif self.tie_eps > 0 and C > 0:
             _lib.call("qpg_percode_select_guarded_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K,
                       float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
-                      db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, float(self.tie_eps), self._guard_stats)
+                      db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, float(self.tie_eps), self._guard_stats, int(half))
         else:
             _lib.call("qpg_percode_select_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K, float(ABSENT_DIST),
                       db.idx_base * db.Ga, dist, idx, rank, qb, bs)

@@ -292,7 +292,7 @@ struct MxIC {
 // AD = depth of the candidate-operand register ring: the candidate rows come from HBM (~2k cycles away under load)
 // and are prefetched AD-1 stages (of 8*MT*NT MFMAs = 256*MT*NT matrix-pipe cycles) ahead; the query operand sits in
 // the XCD's L2 (the whole query set is 1.2 MB) and is prefetched one stage ahead.
-template <int MT, int NT, int NTAPS, int KS, int GS, int AD, int BD>
+template <int MT, int NT, int NTAPS, int KS, int GS, int AD, int BD, bool HALF = false>
 __device__ __forceinline__ void mx_ksplit_body(
     const float* __restrict__ base, int N, int T, int F, const int32_t* __restrict__ cand_t, int G, int tap_stride,
     const double* __restrict__ cn2, const float* __restrict__ q32, const double* __restrict__ qn2, int Q,
@@ -355,6 +355,16 @@ __device__ __forceinline__ void mx_ksplit_body(
     for (int mt = 0; mt < MT; ++mt) {
       const bool ok = at0[mt] + tap * tap_stride < T;          // padded taps read the zero page (see the f64 kernel)
       const int64_t o = aoff[mt] + (int64_t)tap * tap_stride * (F + QPG_MX_PADF) + e0;
+      if (HALF) {      // f16 base: one 16-byte load brings the lane's 8 features
+        const f16x8 h = *reinterpret_cast<const f16x8*>(ok ? reinterpret_cast<const void*>(reinterpret_cast<const _Float16*>(base) + o)
+                                                           : reinterpret_cast<const void*>(zeros));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u.a[mt][0][i] = (float)h[i];
+          u.a[mt][1][i] = (float)h[4 + i];
+        }
+        continue;
+      }
       const float* p = ok ? base + o : zeros;
       u.a[mt][0] = *reinterpret_cast<const f32x4*>(p);
       u.a[mt][1] = *reinterpret_cast<const f32x4*>(p + 4);
@@ -502,13 +512,13 @@ __device__ __forceinline__ void mx_ksplit_body(
   }
 }
 
-template <int MT, int NT, int NTAPS, int KS, int GS, int AD, int BD>
+template <int MT, int NT, int NTAPS, int KS, int GS, int AD, int BD, bool HALF>
 __global__ __launch_bounds__(64 * KS * GS, QPG_MX_OCC) void audio_cosine_mx_kernel(
     const float* __restrict__ base, int N, int T, int F, const int32_t* __restrict__ cand_t, int G, int tap_stride,
     const double* __restrict__ cn2, const float* __restrict__ q32, const double* __restrict__ qn2, int Q,
     double* __restrict__ D, int64_t ldD, const float* __restrict__ zeros, int32_t* __restrict__ stats, int64_t c_begin,
     int64_t c_end) {
-  mx_ksplit_body<MT, NT, NTAPS, KS, GS, AD, BD>(base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, zeros, stats,
+  mx_ksplit_body<MT, NT, NTAPS, KS, GS, AD, BD, HALF>(base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, zeros, stats,
                                                 c_begin, c_end, blockIdx.x, blockIdx.y);
 }
 
@@ -537,7 +547,7 @@ __device__ __forceinline__ int mx2_g(int r) { return r; }
 
 // F64 = true: the SAME organisation on the f64 matrix cores (v_mfma_f64_16x16x4_f64, operands widened in registers, no
 // chains to cut): the f64 sweep of qpg_audio_cosine_f64 for whole rounds of blocks.
-template <int NT, int NTAPS, bool F64>
+template <int NT, int NTAPS, bool F64, bool HALF>
 __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
     const float* __restrict__ base, int N, int T, int F, const int32_t* __restrict__ cand_t, int G, int tap_stride,
     const double* __restrict__ cn2, const float* __restrict__ q32, const double* __restrict__ qn2, int Q,
@@ -546,8 +556,8 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
   // blocks past `main_blocks` are the split-K remainder (one 16-candidate tile each, candidates from c_end on): they
   // ride in the same launch so that they fill the CUs while the last round of 64-candidate blocks drains
   if (!F64 && blockIdx.x >= (unsigned)main_blocks) {
-    mx_ksplit_body<1, NT, NTAPS, 4, 1, 2, 2>(base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, zeros, stats,
-                                             c_end, c_tail_end, blockIdx.x - (unsigned)main_blocks, blockIdx.y);
+    mx_ksplit_body<1, NT, NTAPS, 4, 1, 2, 2, HALF>(base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, zeros,
+                                                   stats, c_end, c_tail_end, blockIdx.x - (unsigned)main_blocks, blockIdx.y);
     return;
   }
   constexpr int ROWB = 256;                       // bytes of one query row per stage (64 features)
@@ -568,7 +578,11 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
   const int at0 = cand_t[g];
   // feature of (load i, k-quarter kq, element e) within a stage = 16*i + 4*kq + e: the four lanes of a row cover 64
   // contiguous bytes per load instruction (16 half lines per instruction; 16*kq + 4*i would touch 32)
-  const float* arow = base + ((int64_t)j * T + at0) * F + 4 * kq;
+  // f16 base (HALF): the lane's 16 features of a stage are two contiguous runs of 8 (one 16-byte load each):
+  // feature of (i, kq, e) = 32*(i>>1) + 8*kq + 4*(i&1) + e, and the query fragments follow that order (boff below)
+  const int64_t arow_off = ((int64_t)j * T + at0) * F + (HALF ? 8 : 4) * kq;
+  const float* arow = base + arow_off;
+  const _Float16* arow_h = reinterpret_cast<const _Float16*>(base) + arow_off;
   // DMA source rows of this lane: piece pi covers tile rows 4*pi .. 4*pi+3, lane l -> row 4*pi + (l>>4), slot l&15
   const float* dsrc[PIECES / 4];
 #pragma unroll
@@ -583,7 +597,8 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
   // fragment read offsets inside a stage buffer: tile nt, k-quarter i -> 16 bytes
   int boff[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) boff[i] = row * ROWB + (((4 * i + kq) ^ mx2_g(row)) << 4);
+  for (int i = 0; i < 4; ++i)
+    boff[i] = row * ROWB + (((HALF ? 8 * (i >> 1) + 2 * kq + (i & 1) : 4 * i + kq) ^ mx2_g(row)) << 4);
 
   f64x4 sum[NT];
   f32x4 acc[NT];
@@ -612,6 +627,19 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
   auto load_a = [&](f32x4 (&a)[4], int s) {
     const int tap = s % NTAPS, e0 = 64 * (s / NTAPS);
     const bool ok = at0 + tap * tap_stride < T;
+    if (HALF) {
+      const _Float16* ph = ok ? arow_h + (int64_t)tap * tap_stride * F + e0 : reinterpret_cast<const _Float16*>(zeros);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(ph + (ok ? 32 * jj : 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[2 * jj][e] = (float)h[e];
+          a[2 * jj + 1][e] = (float)h[4 + e];
+        }
+      }
+      return;
+    }
     const float* p = ok ? arow + (int64_t)tap * tap_stride * F + e0 : zeros;
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(p + 16 * i);
@@ -628,8 +656,10 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
     const int s = s0 + jj;
     f32x4 (&a)[4] = ra[jj % 3];
     if (!(QPG_MX2_PROBE & 1)) {
-      // queue, oldest first: A(s) | DMA(s) x3 | A(s+1) x4: the tile of this stage has landed at <= 4 outstanding
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      // queue, oldest first: A(s) | DMA(s) x3 | A(s+1) x4 (x2 from an f16 base): the tile of this stage has landed
+      // once no more than the A(s+1) loads are outstanding
+      if (HALF) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       __builtin_amdgcn_s_barrier();                // stage s landed for every wave; every wave is done with stage s-1
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -724,25 +754,32 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
 #define QPG_MX_GS 1      // candidate groups per block
 #endif
 template <int MT, int NT>
-static int launch_audio_mx(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F, const int32_t* cand_t,
-                           int G, int tap_stride, const double* cn2, const float* q32, const double* qn2, int Q,
-                           int qtiles_y, double* D, int64_t ldD, int32_t* stats, int64_t c_begin, int64_t c_end) {
+static int launch_audio_mx(qpg_ctx* ctx, void* stream, const float* base, bool half, int N, int T, int F,
+                           const int32_t* cand_t, int G, int tap_stride, const double* cn2, const float* q32,
+                           const double* qn2, int Q, int qtiles_y, double* D, int64_t ldD, int32_t* stats, int64_t c_begin,
+                           int64_t c_end) {
   constexpr int KS = QPG_MX_KS, GS = QPG_MX_GS;
   dim3 grid((unsigned)((c_end - c_begin + 16 * MT * GS - 1) / (16 * MT * GS)), (unsigned)qtiles_y);
   constexpr int AD = (QPG_MX_AD == 4) ? 3 : QPG_MX_AD;     // (a depth-4 ring needs an even feature-group count)
-  hipLaunchKernelGGL((audio_cosine_mx_kernel<MT, NT, 6, KS, GS, AD, QPG_MX_BD>), grid, dim3(64 * KS * GS), 0,
-                     qpg_stream(stream), base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD,
-                     (const float*)ctx->zeros, stats, c_begin, c_end);
+  if (half)
+    hipLaunchKernelGGL((audio_cosine_mx_kernel<MT, NT, 6, KS, GS, AD, QPG_MX_BD, true>), grid, dim3(64 * KS * GS), 0,
+                       qpg_stream(stream), base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD,
+                       (const float*)ctx->zeros, stats, c_begin, c_end);
+  else
+    hipLaunchKernelGGL((audio_cosine_mx_kernel<MT, NT, 6, KS, GS, AD, QPG_MX_BD, false>), grid, dim3(64 * KS * GS), 0,
+                       qpg_stream(stream), base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD,
+                       (const float*)ctx->zeros, stats, c_begin, c_end);
   QPG_LAUNCH_CHECK("audio_cosine_mx_kernel");
   return QPG_OK;
 }
 
 template <int MT>
-static int launch_audio_mx_q(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F, const int32_t* cand_t,
-                             int G, int tap_stride, const double* cn2, const float* q32, const double* qn2, int Q,
-                             double* D, int64_t ldD, int32_t* stats, int64_t c_begin, int64_t c_end) {
+static int launch_audio_mx_q(qpg_ctx* ctx, void* stream, const float* base, bool half, int N, int T, int F,
+                             const int32_t* cand_t, int G, int tap_stride, const double* cn2, const float* q32,
+                             const double* qn2, int Q, double* D, int64_t ldD, int32_t* stats, int64_t c_begin,
+                             int64_t c_end) {
   const int qt = (Q + 15) / 16;  // widest query tile that divides the work without an empty tail (48 queries = 3)
-#define QPG_MX_ARGS ctx, stream, base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q
+#define QPG_MX_ARGS ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q
   if (qt % 3 == 0) return launch_audio_mx<MT, 3>(QPG_MX_ARGS, qt / 3, D, ldD, stats, c_begin, c_end);
   if (qt % 4 == 0) return launch_audio_mx<MT, 4>(QPG_MX_ARGS, qt / 4, D, ldD, stats, c_begin, c_end);
   if (qt % 2 == 0) return launch_audio_mx<MT, 2>(QPG_MX_ARGS, qt / 2, D, ldD, stats, c_begin, c_end);
@@ -756,10 +793,9 @@ static int launch_audio_mx_q(qpg_ctx* ctx, void* stream, const float* base, int 
 #ifndef QPG_MX_TAIL_RIDES
 #define QPG_MX_TAIL_RIDES 1   // 1: the split-K remainder blocks are appended to the mx2 launch; 0: a launch of their own
 #endif
-extern "C" int qpg_audio_cosine_mx(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F,
-                                   const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
-                                   const float* q32, const double* qn2, int Q, double* D, int64_t ldD, int32_t* stats) {
-  const char* name = "qpg_audio_cosine_mx";
+static int audio_cosine_mx(const char* name, qpg_ctx* ctx, void* stream, const float* base, bool half, int N, int T, int F,
+                           const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2, const float* q32,
+                           const double* qn2, int Q, double* D, int64_t ldD, int32_t* stats) {
   QPG_REQUIRE(ctx && base && cand_t && cn2 && q32 && qn2 && D, "%s: null pointer", name);
   QPG_REQUIRE(N >= 0 && T > 0 && G > 0 && Q >= 0 && tap_stride > 0 && ldD >= (int64_t)N * G, "%s: bad size", name);
   if (n_taps != 6 || F <= 0 || (F % 128) != 0) {
@@ -784,15 +820,37 @@ extern "C" int qpg_audio_cosine_mx(qpg_ctx* ctx, void* stream, const float* base
   const bool ride = main_x > 0 && tail_tiles > 0 && tail_tiles <= 4 * (int64_t)ctx->n_cu && ny == 1 && QPG_MX_TAIL_RIDES;
   if (main_x > 0) {
     dim3 grid((unsigned)(main_x + (ride ? tail_tiles : 0)), (unsigned)ny);
-    hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, false>), grid, dim3(256), 0, qpg_stream(stream), base, N, T, F, cand_t, G,
-                       tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros, stats, (int64_t)0, c_mid, (int)main_x,
-                       C);
+    if (half)
+      hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, false, true>), grid, dim3(256), 0, qpg_stream(stream), base, N, T,
+                         F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros, stats, (int64_t)0,
+                         c_mid, (int)main_x, C);
+    else
+      hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, false, false>), grid, dim3(256), 0, qpg_stream(stream), base, N, T,
+                         F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros, stats, (int64_t)0,
+                         c_mid, (int)main_x, C);
     QPG_LAUNCH_CHECK("audio_cosine_mx2_kernel");
   }
   if (c_mid == C || ride) return QPG_OK;
   if (QPG_MX_ORG == 2 && tail_tiles * ny <= 4 * (int64_t)ctx->n_cu)
-    return launch_audio_mx_q<1>(ctx, stream, base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, stats, c_mid, C);
-  return launch_audio_mx_q<2>(ctx, stream, base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, stats, c_mid, C);
+    return launch_audio_mx_q<1>(ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, stats,
+                                c_mid, C);
+  return launch_audio_mx_q<2>(ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, stats, c_mid,
+                              C);
+}
+
+extern "C" int qpg_audio_cosine_mx(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F,
+                                   const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
+                                   const float* q32, const double* qn2, int Q, double* D, int64_t ldD, int32_t* stats) {
+  return audio_cosine_mx("qpg_audio_cosine_mx", ctx, stream, base, false, N, T, F, cand_t, G, n_taps, tap_stride, cn2, q32,
+                         qn2, Q, D, ldD, stats);
+}
+
+extern "C" int qpg_audio_cosine_mx_h(qpg_ctx* ctx, void* stream, const void* base_f16, int N, int T, int F,
+                                     const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
+                                     const float* q32, const double* qn2, int Q, double* D, int64_t ldD, int32_t* stats) {
+  QPG_REQUIRE((reinterpret_cast<uintptr_t>(base_f16) % 16) == 0, "qpg_audio_cosine_mx_h: base must be 16-byte aligned");
+  return audio_cosine_mx("qpg_audio_cosine_mx_h", ctx, stream, static_cast<const float*>(base_f16), true, N, T, F, cand_t, G,
+                         n_taps, tap_stride, cn2, q32, qn2, Q, D, ldD, stats);
 }
 
 template <int MT, int NT>
@@ -850,7 +908,7 @@ static int audio_cosine(const char* name, qpg_ctx* ctx, void* stream, const void
   const int64_t c_mid = main_x * 64;
   if (main_x > 0) {
     dim3 grid((unsigned)main_x, (unsigned)ny);
-    hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, true>), grid, dim3(256), 0, qpg_stream(stream),
+    hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, true, false>), grid, dim3(256), 0, qpg_stream(stream),
                        static_cast<const float*>(base), N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD,
                        (const float*)ctx->zeros, (int32_t*)nullptr, (int64_t)0, c_mid, (int)main_x, c_mid);
     QPG_LAUNCH_CHECK("audio_cosine_mx2_kernel<f64>");

@@ -430,7 +430,8 @@ __global__ __launch_bounds__(1024) void percode_select_kernel(const T* __restric
 // the same launch (no host round trip).  stats[0] += re-evaluated pairs, stats[1] = 1 if a list overflowed.
 // ---------------------------------------------------------------------------------------------
 struct GuardArgs {
-  const float* base;      // [N][T][F] interpolated WavLM frames of this shard (f32)
+  const float* base;      // [N][T][F] interpolated WavLM frames of this shard (f32; IEEE f16 when `half`)
+  int half;               // base is stored in f16: values are widened, i.e. the re-evaluation sees the rounded track
   const float* q32;       // [Q][n_taps*F] packed queries
   const int32_t* cand_t;  // [G] start frame of grid position g
   int T, F, G, n_taps, tap_stride;
@@ -438,6 +439,17 @@ struct GuardArgs {
   int32_t* stats;         // [2]
 };
 #define GUARD_LIST 256
+typedef _Float16 g16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float guard_val(const GuardArgs& A, int64_t off) {       // base[off] as f32
+  return A.half ? (float)reinterpret_cast<const _Float16*>(A.base)[off] : A.base[off];
+}
+__device__ __forceinline__ f32x4 guard_val4(const GuardArgs& A, int64_t off) {      // base[off .. off+3], off % 4 == 0
+  if (A.half) {
+    const g16x4 h = *reinterpret_cast<const g16x4*>(reinterpret_cast<const _Float16*>(A.base) + off);
+    return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  }
+  return *reinterpret_cast<const f32x4*>(A.base + off);
+}
 
 // One (query, candidate) distance in the reference's arithmetic, by FOUR cooperating lanes (an aligned quad):
 // lanes 0/1 run the two einsum accumulator chains of the query's squared norm, lanes 2/3 those of the candidate's;
@@ -448,11 +460,11 @@ __device__ __forceinline__ double refine_pair_f64(const GuardArgs& A, int q, int
   const int j = (int)(c_local / A.G), g = (int)(c_local - (int64_t)j * A.G);
   const int t0 = A.cand_t[g];
   const float* qrow = A.q32 + (int64_t)q * D;
-  const float* crow = A.base + (int64_t)j * A.T * A.F;
+  const int64_t crow = (int64_t)j * A.T * A.F;
   auto cval = [&](int e) -> double {
     const int tap = e / A.F, f = e - tap * A.F;
     const int t = t0 + tap * A.tap_stride;
-    return t < A.T ? (double)crow[(int64_t)t * A.F + f] : 0.0;
+    return t < A.T ? (double)guard_val(A, crow + (int64_t)t * A.F + f) : 0.0;
   };
   const int l = sub & 1;
   const bool is_c = sub >= 2;
@@ -656,7 +668,7 @@ extern "C" int qpg_percode_select_guarded_f64(qpg_ctx* ctx, void* stream, const 
                                               int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
                                               int q_block, int64_t block_stride, const float* base, int T, int F,
                                               const int32_t* cand_t, int G, int n_taps, int tap_stride,
-                                              const float* q32, double eps, int32_t* stats) {
+                                              const float* q32, double eps, int32_t* stats, int base_is_f16) {
   QPG_REQUIRE(ctx && D && (cand_code || C == 0) && out_dist && out_idx && base && cand_t && q32 && stats,
               "qpg_percode_select_guarded_f64: null pointer");
   QPG_REQUIRE(Q >= 0 && C >= 0 && K > 0 && K <= 2048 && ldD >= C && C + (int64_t)idx_base < 0x7fffffffll && T > 0 &&
@@ -666,7 +678,7 @@ extern "C" int qpg_percode_select_guarded_f64(qpg_ctx* ctx, void* stream, const 
               "qpg_percode_select_guarded_f64: block layout needs Q %% q_block == 0 and no rank output");
   if (Q == 0) return QPG_OK;
   GuardArgs A;
-  A.base = base; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
+  A.base = base; A.half = base_is_f16; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
   A.tap_stride = tap_stride; A.eps = eps; A.stats = stats;
   const size_t sh = 24 * (size_t)K + GUARD_LIST * 16 + 16;
   hipLaunchKernelGGL(percode_select_guarded_f64_kernel, dim3(Q), dim3(1024), sh, qpg_stream(stream), D, ldD, cand_code,
@@ -699,16 +711,16 @@ template <int NPER>
 __device__ __forceinline__ double pair_dot_fast_f64(const GuardArgs& A, const float* qlds, int64_t c_local, int lane) {
   const int j = (int)(c_local / A.G), g = (int)(c_local - (int64_t)j * A.G);
   const int t0 = A.cand_t[g];
-  const float* crow = A.base + (int64_t)j * A.T * A.F + lane * 4;
+  const int64_t crow = (int64_t)j * A.T * A.F + lane * 4;
   f32x4 cv[6][NPER];
 #pragma unroll
   for (int tap = 0; tap < 6; ++tap) {
     const int t = t0 + tap * A.tap_stride;
     const bool ok = t < A.T;
-    const float* cp = crow + (int64_t)(ok ? t : t0) * A.F;
+    const int64_t cp = crow + (int64_t)(ok ? t : t0) * A.F;
 #pragma unroll
     for (int u = 0; u < NPER; ++u) {
-      cv[tap][u] = *reinterpret_cast<const f32x4*>(cp + 256 * u);
+      cv[tap][u] = guard_val4(A, cp + 256 * u);
       if (!ok) cv[tap][u] = (f32x4){0.f, 0.f, 0.f, 0.f};      // zero padding past the end of the window
     }
   }
@@ -733,14 +745,14 @@ __device__ __forceinline__ double pair_dot_wave_f64(const GuardArgs& A, int q, i
   const int j = (int)(c_local / A.G), g = (int)(c_local - (int64_t)j * A.G);
   const int t0 = A.cand_t[g];
   const float* qrow = A.q32 + (int64_t)q * D;
-  const float* crow = A.base + (int64_t)j * A.T * A.F;
+  const int64_t crow = (int64_t)j * A.T * A.F;
   double s0 = 0.0, s1 = 0.0;
   for (int e = lane * 4; e < D; e += 256) {                   // F % 4 == 0: a 16-byte piece never straddles a tap
     const int tap = e / A.F, f = e - tap * A.F;
     const int t = t0 + tap * A.tap_stride;
     const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + e);
     f32x4 cv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (t < A.T) cv = *reinterpret_cast<const f32x4*>(crow + (int64_t)t * A.F + f);
+    if (t < A.T) cv = guard_val4(A, crow + (int64_t)t * A.F + f);
     s0 += (double)qv.x * (double)cv.x;
     s1 += (double)qv.y * (double)cv.y;
     s0 += (double)qv.z * (double)cv.z;
@@ -1154,7 +1166,7 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const do
                                             int q_block, int64_t block_stride, const float* base, int T, int F,
                                             const int32_t* cand_t, int G, int n_taps, int tap_stride,
                                             const float* q32, const double* qn2, const double* cn2, double eps1,
-                                            double eps2, int32_t* stats, void* ws, int64_t ws_bytes) {
+                                            double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16) {
   const char* name = "qpg_percode_select_mixed_f64";
   QPG_REQUIRE(ctx && D && (cand_code || C == 0) && out_dist && out_idx && base && cand_t && q32 && qn2 && cn2 && stats,
               "%s: null pointer", name);
@@ -1168,7 +1180,7 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const do
               "%s: block layout needs Q %% q_block == 0, an 8-byte multiple stride and no rank output", name);
   if (Q == 0) return QPG_OK;
   GuardArgs A;
-  A.base = base; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
+  A.base = base; A.half = base_is_f16; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
   A.tap_stride = tap_stride; A.eps = eps2; A.stats = stats;
   // fast tier-1 path (WavLM geometry: 6 taps x 1024 features): the query row is staged in LDS (+24 KB: 85 KB in all)
   const int use_qlds = (n_taps == 6 && F == 1024) ? 1 : 0;

@@ -34,5 +34,5 @@ def aud_tol(knn):
     a-priori bound for the mixed-precision path (untouched minima keep the sweep value; winners and ranks are exact
     either way and asserted separately)."""
     from qpgesture_amd.code_knn import AUDIO_MX_ERR
-    mixed = knn.audio_precision == "mixed" and knn.db.world == 1 and knn.db.feature_dtype == "f32" and knn.tie_eps > 0
+    mixed = knn.audio_precision == "mixed" and knn.db.world == 1 and knn.tie_eps > 0
     return AUDIO_MX_ERR if mixed else 1e-13

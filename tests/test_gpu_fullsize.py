@@ -260,7 +260,14 @@ def test_f16_feature_storage_vs_c_oracle_on_rounded_track():
     q = np.stack([O.wavlm_feat_rows(te_i, w, [24 * s])[0] for w in range(clips * M) for s in range(8)])
     d_ref, i_ref = cref.audio_scan(rounded, np.arange(26) * 6, A["code"], np.arange(26), q, n_threads=os.cpu_count() or 1)
     assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref)
-    assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+    assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < aud_tol(knn)          # mixed-precision sweep on the f16 base
+    want_rank = np.argsort(np.argsort(d_ref, axis=1, kind="stable"), axis=1, kind="stable")
+    assert np.array_equal(T["aud_rank"].cpu().numpy(), want_rank)
+    k64 = CodeKNN(db, rng=np.random.RandomState(1))
+    k64.audio_precision = "f64"                                                    # f64 sweep + guard on the f16 base
+    T64 = k64.sweep_tables(ti, tc, clips * M)
+    assert torch.equal(T64["aud_idx"], T["aud_idx"]) and torch.equal(T64["aud_rank"], T["aud_rank"])
+    assert np.abs(T64["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
     db32 = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
     T32 = CodeKNN(db32, rng=np.random.RandomState(1)).sweep_tables(ti, tc, clips * M)
     assert 1e-9 < float((T32["aud_d"] - T["aud_d"]).abs().max()) < 1e-2          # input rounding, nothing else

@@ -9,7 +9,7 @@ from tests.helpers import fixture_arrays, load_golden
 pytestmark = pytest.mark.gpu
 
 
-def _sweeps(N=96, Q=48, seed=0):
+def _sweeps(N=96, Q=48, seed=0, half=False):
     import torch
     from qpgesture_amd import _lib
     dev = torch.device("cuda:0")
@@ -26,6 +26,9 @@ def _sweeps(N=96, Q=48, seed=0):
         q32[11] *= 1e3
     cand_t = (torch.arange(G, dtype=torch.int32) * 6).to(dev)
     fn2 = torch.empty((N, T), dtype=torch.float64, device=dev)
+    if half:                                                   # f16 storage: everything is defined on the rounded track
+        base_h = base.to(torch.float16).contiguous()
+        base = base_h.float()
     _lib.call("qpg_frame_norm2_f64", dev, base, N * T, F, fn2)
     cn2 = torch.empty((N, G), dtype=torch.float64, device=dev)
     _lib.call("qpg_audio_cand_norm2", dev, fn2, N, T, cand_t, G, 6, 2, cn2)
@@ -34,7 +37,10 @@ def _sweeps(N=96, Q=48, seed=0):
     Dmx = torch.empty_like(D64)
     stats = torch.zeros((4,), dtype=torch.int32, device=dev)
     _lib.call("qpg_audio_cosine_f64", dev, base, N, T, F, cand_t, G, 6, 2, cn2, q32, qn2, Q, D64, D64.stride(0))
-    _lib.call("qpg_audio_cosine_mx", dev, base, N, T, F, cand_t, G, 6, 2, cn2, q32, qn2, Q, Dmx, Dmx.stride(0), stats)
+    if half:
+        _lib.call("qpg_audio_cosine_mx_h", dev, base_h, N, T, F, cand_t, G, 6, 2, cn2, q32, qn2, Q, Dmx, Dmx.stride(0), stats)
+    else:
+        _lib.call("qpg_audio_cosine_mx", dev, base, N, T, F, cand_t, G, 6, 2, cn2, q32, qn2, Q, Dmx, Dmx.stride(0), stats)
     torch.cuda.synchronize()
     return D64.cpu().numpy(), Dmx.cpu().numpy(), stats.cpu().numpy()
 
@@ -43,10 +49,13 @@ def test_mixed_sweep_stays_inside_its_error_bound():
     from qpgesture_amd.code_knn import AUDIO_MX_ERR
     # N = 96: split-K organisation only (four query-tile shapes + ragged); Q = 200: the LDS-shared-query organisation
     # (mx2) with a ragged last query tile; N = 700: both in one call (256 mx2 blocks + a split-K remainder)
-    for Q, N in ((48, 96), (16, 96), (64, 96), (5, 96), (200, 96), (48, 700), (100, 333)):
-        D64, Dmx, stats = _sweeps(N=N, Q=Q, seed=Q)
+    # the last three: the base stored in f16 (qpg_audio_cosine_mx_h), each organisation
+    for Q, N, half in ((48, 96, False), (16, 96, False), (64, 96, False), (5, 96, False), (200, 96, False),
+                       (48, 700, False), (100, 333, False), (48, 96, True), (200, 96, True), (48, 700, True)):
+        D64, Dmx, stats = _sweeps(N=N, Q=Q, seed=Q, half=half)
         err = np.abs(D64 - Dmx)
-        print("N=%d Q=%d: max |D_mx - D_f64| = %.3g (bound %.3g), mean %.3g" % (N, Q, err.max(), AUDIO_MX_ERR, err.mean()))
+        print("N=%d Q=%d%s: max |D_mx - D_f64| = %.3g (bound %.3g), mean %.3g"
+              % (N, Q, " f16 base" if half else "", err.max(), AUDIO_MX_ERR, err.mean()))
         assert err.max() <= AUDIO_MX_ERR
         assert stats[1] == 0
         if Q > 7:
