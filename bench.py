@@ -252,7 +252,7 @@ def main():
         out["mixed_precision"] = {
             "f64_dot_pairs_per_step": round(st["tier1_pairs"] / n_run, 1),
             "reference_arithmetic_pairs_per_step": round(st["tier2_pairs"] / n_run, 2),
-            "flags": st["flags"], "error_bound": 1.92e-6,
+            "flags": st["flags"], "error_bound": 2.05e-6,
             "max_table_difference_vs_f64_sweep": float((Tm["aud_d"] - T64["aud_d"]).abs().max()),
             "winners_equal_f64_sweep": bool(torch.equal(Tm["aud_idx"], T64["aud_idx"])),
             "ranks_equal_f64_sweep": bool(torch.equal(Tm["aud_rank"], T64["aud_rank"])),

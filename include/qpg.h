@@ -103,20 +103,23 @@ int qpg_audio_cosine_f64_h(qpg_ctx*, void* stream, const void* base_f16, int N, 
 
 /* MIXED-PRECISION form of qpg_audio_cosine_f64 (round 2; the default single-GPU path of CodeKNN.sweep_audio): the same
  * sweep on the f32 matrix cores, with every f32 accumulation chain limited to 32 products and summed in f64, which
- * bounds the result's error A PRIORI: |D[q][c] - exact| <= QPG_AUDIO_MX_ERR for every pair, whatever the data
+ * bounds the result's error A PRIORI: |D[q][c] - exact| <= QPG_AUDIO_MX_ERR for every pair (gamma_32 = 1.91e-6 for the f32 chains + 1.2e-7 for an f32-stored
+ * matrix + f64 noise), whatever the data
  * (derivation: qpgesture_amd/csrc/qpg_audio.hip).  Meant to be consumed by qpg_percode_select_mixed_f64, which
  * re-evaluates every comparison the bound leaves undecided, so the selected candidates and ranks are those of the
  * f64 path.  stats: [dev] i32 [4] (may be NULL): [1] |= 2 if a pair with 0 < |q||c| < 1e-16 was met (operand products
  * could underflow f32, which the bound excludes). */
-#define QPG_AUDIO_MX_ERR 1.92e-6
+#define QPG_AUDIO_MX_ERR 2.05e-6
 int qpg_audio_cosine_mx(qpg_ctx*, void* stream, const float* base, int N, int T, int F, const int32_t* cand_t, int G,
                         int n_taps, int tap_stride, const double* cn2, const float* q32, const double* qn2, int Q,
-                        double* D, int64_t ldD, int32_t* stats);
+                        void* D, int d_is_f32, int64_t ldD, int32_t* stats);
+/* D: [dev] [Q][N*G] with row stride ldD ELEMENTS, f64 — or f32 when d_is_f32 != 0: the matrix only feeds the select's
+ * two streaming passes, and rounding it to f32 (<= 1.2e-7 on a distance <= 2) is part of QPG_AUDIO_MX_ERR. */
 
 /* qpg_audio_cosine_mx over a base track stored in IEEE f16 (as qpg_audio_cosine_f64_h): same bound, on the rounded values. */
 int qpg_audio_cosine_mx_h(qpg_ctx*, void* stream, const void* base_f16, int N, int T, int F, const int32_t* cand_t, int G,
                           int n_taps, int tap_stride, const double* cn2, const float* q32, const double* qn2, int Q,
-                          double* D, int64_t ldD, int32_t* stats);
+                          void* D, int d_is_f32, int64_t ldD, int32_t* stats);
 
 /* One-off DB preparation for the text sweep: sklearn-normalise the grid rows x[j][cand_r[g]] (bit-exact,
  * as qpg_l2_normalize_rows_f32) and store them tiled for lane-per-candidate access:
@@ -236,7 +239,7 @@ int qpg_percode_select_guarded_f64(qpg_ctx*, void* stream, const double* D, int6
  * qn2 [dev] f64 [Q], cn2 [dev] f64 [C]: the sweep's squared norms.  stats [dev] i32 [4]: [0] += tier-2 pairs,
  * [1] |= 1 if a list overflowed (2048 tier-1 / 256 tier-2 entries per query; results then unguarded), [2] += tier-1
  * pairs.  K <= 512. */
-int qpg_percode_select_mixed_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int16_t* cand_code,
+int qpg_percode_select_mixed_f64(qpg_ctx*, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q, const int16_t* cand_code,
                                  int64_t C, int K, double absent, int32_t idx_base, double* out_dist, int32_t* out_idx,
                                  int16_t* out_rank, int q_block, int64_t block_stride, const float* base, int T, int F,
                                  const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32,

@@ -31,8 +31,8 @@ _SIGS = {
     "qpg_audio_pack_queries": [P, I, I, I, P, P, I, I, I, P, P],
     "qpg_audio_cosine_f64": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
     "qpg_audio_cosine_f64_h": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
-    "qpg_audio_cosine_mx": [P, I, I, I, P, I, I, I, P, P, P, I, P, L, P],
-    "qpg_audio_cosine_mx_h": [P, I, I, I, P, I, I, I, P, P, P, I, P, L, P],
+    "qpg_audio_cosine_mx": [P, I, I, I, P, I, I, I, P, P, P, I, P, I, L, P],
+    "qpg_audio_cosine_mx_h": [P, I, I, I, P, I, I, I, P, P, P, I, P, I, L, P],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
     "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
     "qpg_text_percode_f32": [P, L, I, P, I, P, I, I, ctypes.c_int32, c_float, P, L, P, P, P, P],
@@ -46,7 +46,7 @@ _SIGS = {
     "qpg_percode_select_f32": [P, L, I, P, L, I, c_float, ctypes.c_int32, P, P, P, I, L],
     "qpg_percode_select_guarded_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
                                        c_double, P, I],
-    "qpg_percode_select_mixed_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
+    "qpg_percode_select_mixed_f64": [P, I, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
                                      P, P, c_double, c_double, P, P, L, I],
     "qpg_merge_select_f64": [P, I, L, L, L, I, I, c_double, P, P, P],
     "qpg_merge_select_f32": [P, I, L, L, L, I, I, c_float, P, P, P],

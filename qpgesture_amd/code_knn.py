@@ -22,7 +22,7 @@ MODE_AUD_TXT, MODE_AUD, MODE_TXT = 0, 1, 2
 # mixed-precision audio sweep: a-priori error bound of qpg_audio_cosine_mx (QPG_AUDIO_MX_ERR of include/qpg.h) and the
 # band inside which qpg_percode_select_mixed_f64 re-evaluates (two values further apart than 2 x the bound are ordered
 # like the exact distances; 5 % margin on top)
-AUDIO_MX_ERR = 1.92e-6
+AUDIO_MX_ERR = 2.05e-6
 AUDIO_MX_BAND = 2.1 * AUDIO_MX_ERR
 
 
@@ -312,18 +312,19 @@ class CodeKNN:
         _lib.call("qpg_audio_pack_queries", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
                   NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2)
         C = db.n_local * db.Ga
-        D = torch.empty((Q, max(C, 1)), dtype=torch.float64, device=dev)
-        ev = getattr(self, "kernel_events", None)       # bench.py: HIP events around the dominant kernel
-        if ev is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream(dev))
         fused_rank = want_rank and db.world == 1
         half = db.feature_dtype == "f16"
         mixed = (self.audio_precision == "mixed" and fused_rank and reduce and out is None and self.tie_eps > 0
                  and C > 0 and db.K <= 512)
+        # the mixed-precision sweep stores its matrix in f32: it only feeds the select's two streaming passes
+        D = torch.empty((Q, max(C, 1)), dtype=torch.float32 if mixed else torch.float64, device=dev)
+        ev = getattr(self, "kernel_events", None)       # bench.py: HIP events around the dominant kernel
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
         if mixed:
             _lib.call("qpg_audio_cosine_mx_h" if half else "qpg_audio_cosine_mx", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
-                      NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, D.stride(0), self._guard_stats)
+                      NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, 1, D.stride(0), self._guard_stats)
         else:
             _lib.call("qpg_audio_cosine_f64" if db.feature_dtype == "f32" else "qpg_audio_cosine_f64_h", dev, db.base,
                       db.n_local, db.T, db.F, db.aud_t, db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2,
@@ -343,7 +344,7 @@ class CodeKNN:
             ws = getattr(self, "_mix_ws", None)
             if ws is None or ws.numel() < need:
                 ws = self._mix_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
-            _lib.call("qpg_percode_select_mixed_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K,
+            _lib.call("qpg_percode_select_mixed_f64", dev, D, 1, D.stride(0), Q, db.aud_cand_code, C, db.K,
                       float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
                       db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2, AUDIO_MX_BAND, float(self.tie_eps),
                       self._guard_stats, None if self.mixed_single_launch else ws,

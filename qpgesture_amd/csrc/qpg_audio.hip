@@ -260,7 +260,8 @@ __global__ __launch_bounds__(64 * KS) void audio_cosine_f64_kernel(const void* _
 //     stage), and the finished chain is added into an f64 running sum on the VALU while the next stage's MFMAs run;
 //   * an f32 FMA chain of n products has |error| <= gamma_n * sum|a_i b_i| <= gamma_n |a||b| (Cauchy-Schwarz), any
 //     summation order, gamma_n = n u / (1 - n u), u = 2^-24; the f64 sums add < 1e-13 relative;
-//   => |D_mx - D_exact| <= gamma_32 + 1e-13 < 1.92e-6 for every (query, candidate), data independent
+//   => |D_mx - D_exact| <= gamma_32 + 1e-13 < 1.92e-6 for every (query, candidate), data independent; + 1.2e-7 when
+//      the matrix is stored in f32 (distances <= 2): QPG_AUDIO_MX_ERR = 2.05e-6 covers both forms
 //      (QPG_AUDIO_MX_ERR below; tests/test_gpu_matching.py measures the actual maximum, ~1e-7).
 // qpg_percode_select_mixed_f64 consumes this matrix: every comparison that decides an output (per-code minimum,
 // rank order of the minima) and whose operands are closer than 2*QPG_AUDIO_MX_ERR is re-evaluated with an f64 dot
@@ -297,7 +298,7 @@ __device__ __forceinline__ void mx_ksplit_body(
     const float* __restrict__ base, int N, int T, int F, const int32_t* __restrict__ cand_t, int G, int tap_stride,
     const double* __restrict__ cn2, const float* __restrict__ q32, const double* __restrict__ qn2, int Q,
     double* __restrict__ D, int64_t ldD, const float* __restrict__ zeros, int32_t* __restrict__ stats, int64_t c_begin,
-    int64_t c_end, const unsigned bx, const unsigned by) {
+    int64_t c_end, const unsigned bx, const unsigned by, const int d_f32) {
   // candidates [c_begin, c_end) of the N*G; block = GS candidate groups x KS contraction slices (one wave each); the KS waves of a group are reduced through LDS
   __shared__ double red[GS][KS][MT * NT][4][64];  // [group][slice][tile][acc reg][lane]
 
@@ -507,7 +508,9 @@ __device__ __forceinline__ void mx_ksplit_body(
       const double a = qn2[q], b = cn2[cc];
       const double p = a * b;
       if (p > 0.0 && p < 1e-32 && stats) atomicOr(&stats[1], 2);     // |q||c| < 1e-16: f32 products may underflow
-      D[(int64_t)q * ldD + cc] = cosine_from_dot(dot, a, b);
+      const double dd = cosine_from_dot(dot, a, b);
+      if (d_f32) reinterpret_cast<float*>(D)[(int64_t)q * ldD + cc] = (float)dd;
+      else D[(int64_t)q * ldD + cc] = dd;
     }
   }
 }
@@ -517,9 +520,9 @@ __global__ __launch_bounds__(64 * KS * GS, QPG_MX_OCC) void audio_cosine_mx_kern
     const float* __restrict__ base, int N, int T, int F, const int32_t* __restrict__ cand_t, int G, int tap_stride,
     const double* __restrict__ cn2, const float* __restrict__ q32, const double* __restrict__ qn2, int Q,
     double* __restrict__ D, int64_t ldD, const float* __restrict__ zeros, int32_t* __restrict__ stats, int64_t c_begin,
-    int64_t c_end) {
+    int64_t c_end, int d_f32) {
   mx_ksplit_body<MT, NT, NTAPS, KS, GS, AD, BD, HALF>(base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, zeros, stats,
-                                                c_begin, c_end, blockIdx.x, blockIdx.y);
+                                                c_begin, c_end, blockIdx.x, blockIdx.y, d_f32);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -552,12 +555,12 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
     const float* __restrict__ base, int N, int T, int F, const int32_t* __restrict__ cand_t, int G, int tap_stride,
     const double* __restrict__ cn2, const float* __restrict__ q32, const double* __restrict__ qn2, int Q,
     double* __restrict__ D, int64_t ldD, const float* __restrict__ zeros, int32_t* __restrict__ stats, int64_t c_begin,
-    int64_t c_end, int main_blocks, int64_t c_tail_end) {
+    int64_t c_end, int main_blocks, int64_t c_tail_end, int d_f32) {
   // blocks past `main_blocks` are the split-K remainder (one 16-candidate tile each, candidates from c_end on): they
   // ride in the same launch so that they fill the CUs while the last round of 64-candidate blocks drains
   if (!F64 && blockIdx.x >= (unsigned)main_blocks) {
     mx_ksplit_body<1, NT, NTAPS, 4, 1, 2, 2, HALF>(base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, zeros,
-                                                   stats, c_end, c_tail_end, blockIdx.x - (unsigned)main_blocks, blockIdx.y);
+                                                   stats, c_end, c_tail_end, blockIdx.x - (unsigned)main_blocks, blockIdx.y, d_f32);
     return;
   }
   constexpr int ROWB = 256;                       // bytes of one query row per stage (64 features)
@@ -736,7 +739,9 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
       const double b2 = cn2[cc];
       const double p = a2 * b2;
       if (p > 0.0 && p < 1e-32 && stats) atomicOr(&stats[1], 2);
-      D[(int64_t)q * ldD + cc] = cosine_from_dot(dot, a2, b2);
+      const double dd = cosine_from_dot(dot, a2, b2);
+      if (d_f32) reinterpret_cast<float*>(D)[(int64_t)q * ldD + cc] = (float)dd;
+      else D[(int64_t)q * ldD + cc] = dd;
     }
   }
 }
@@ -757,18 +762,18 @@ template <int MT, int NT>
 static int launch_audio_mx(qpg_ctx* ctx, void* stream, const float* base, bool half, int N, int T, int F,
                            const int32_t* cand_t, int G, int tap_stride, const double* cn2, const float* q32,
                            const double* qn2, int Q, int qtiles_y, double* D, int64_t ldD, int32_t* stats, int64_t c_begin,
-                           int64_t c_end) {
+                           int64_t c_end, int d_f32) {
   constexpr int KS = QPG_MX_KS, GS = QPG_MX_GS;
   dim3 grid((unsigned)((c_end - c_begin + 16 * MT * GS - 1) / (16 * MT * GS)), (unsigned)qtiles_y);
   constexpr int AD = (QPG_MX_AD == 4) ? 3 : QPG_MX_AD;     // (a depth-4 ring needs an even feature-group count)
   if (half)
     hipLaunchKernelGGL((audio_cosine_mx_kernel<MT, NT, 6, KS, GS, AD, QPG_MX_BD, true>), grid, dim3(64 * KS * GS), 0,
                        qpg_stream(stream), base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD,
-                       (const float*)ctx->zeros, stats, c_begin, c_end);
+                       (const float*)ctx->zeros, stats, c_begin, c_end, d_f32);
   else
     hipLaunchKernelGGL((audio_cosine_mx_kernel<MT, NT, 6, KS, GS, AD, QPG_MX_BD, false>), grid, dim3(64 * KS * GS), 0,
                        qpg_stream(stream), base, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD,
-                       (const float*)ctx->zeros, stats, c_begin, c_end);
+                       (const float*)ctx->zeros, stats, c_begin, c_end, d_f32);
   QPG_LAUNCH_CHECK("audio_cosine_mx_kernel");
   return QPG_OK;
 }
@@ -777,13 +782,13 @@ template <int MT>
 static int launch_audio_mx_q(qpg_ctx* ctx, void* stream, const float* base, bool half, int N, int T, int F,
                              const int32_t* cand_t, int G, int tap_stride, const double* cn2, const float* q32,
                              const double* qn2, int Q, double* D, int64_t ldD, int32_t* stats, int64_t c_begin,
-                             int64_t c_end) {
+                             int64_t c_end, int d_f32) {
   const int qt = (Q + 15) / 16;  // widest query tile that divides the work without an empty tail (48 queries = 3)
 #define QPG_MX_ARGS ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q
-  if (qt % 3 == 0) return launch_audio_mx<MT, 3>(QPG_MX_ARGS, qt / 3, D, ldD, stats, c_begin, c_end);
-  if (qt % 4 == 0) return launch_audio_mx<MT, 4>(QPG_MX_ARGS, qt / 4, D, ldD, stats, c_begin, c_end);
-  if (qt % 2 == 0) return launch_audio_mx<MT, 2>(QPG_MX_ARGS, qt / 2, D, ldD, stats, c_begin, c_end);
-  return launch_audio_mx<MT, 1>(QPG_MX_ARGS, qt, D, ldD, stats, c_begin, c_end);
+  if (qt % 3 == 0) return launch_audio_mx<MT, 3>(QPG_MX_ARGS, qt / 3, D, ldD, stats, c_begin, c_end, d_f32);
+  if (qt % 4 == 0) return launch_audio_mx<MT, 4>(QPG_MX_ARGS, qt / 4, D, ldD, stats, c_begin, c_end, d_f32);
+  if (qt % 2 == 0) return launch_audio_mx<MT, 2>(QPG_MX_ARGS, qt / 2, D, ldD, stats, c_begin, c_end, d_f32);
+  return launch_audio_mx<MT, 1>(QPG_MX_ARGS, qt, D, ldD, stats, c_begin, c_end, d_f32);
 #undef QPG_MX_ARGS
 }
 
@@ -795,7 +800,8 @@ static int launch_audio_mx_q(qpg_ctx* ctx, void* stream, const float* base, bool
 #endif
 static int audio_cosine_mx(const char* name, qpg_ctx* ctx, void* stream, const float* base, bool half, int N, int T, int F,
                            const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2, const float* q32,
-                           const double* qn2, int Q, double* D, int64_t ldD, int32_t* stats) {
+                           const double* qn2, int Q, void* D_, int64_t ldD, int32_t* stats, int d_f32) {
+  double* D = static_cast<double*>(D_);          // (an f32 matrix when d_f32: the kernels cast at the store)
   QPG_REQUIRE(ctx && base && cand_t && cn2 && q32 && qn2 && D, "%s: null pointer", name);
   QPG_REQUIRE(N >= 0 && T > 0 && G > 0 && Q >= 0 && tap_stride > 0 && ldD >= (int64_t)N * G, "%s: bad size", name);
   if (n_taps != 6 || F <= 0 || (F % 128) != 0) {
@@ -823,34 +829,36 @@ static int audio_cosine_mx(const char* name, qpg_ctx* ctx, void* stream, const f
     if (half)
       hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, false, true>), grid, dim3(256), 0, qpg_stream(stream), base, N, T,
                          F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros, stats, (int64_t)0,
-                         c_mid, (int)main_x, C);
+                         c_mid, (int)main_x, C, d_f32);
     else
       hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, false, false>), grid, dim3(256), 0, qpg_stream(stream), base, N, T,
                          F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, (const float*)ctx->zeros, stats, (int64_t)0,
-                         c_mid, (int)main_x, C);
+                         c_mid, (int)main_x, C, d_f32);
     QPG_LAUNCH_CHECK("audio_cosine_mx2_kernel");
   }
   if (c_mid == C || ride) return QPG_OK;
   if (QPG_MX_ORG == 2 && tail_tiles * ny <= 4 * (int64_t)ctx->n_cu)
     return launch_audio_mx_q<1>(ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, stats,
-                                c_mid, C);
+                                c_mid, C, d_f32);
   return launch_audio_mx_q<2>(ctx, stream, base, half, N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD, stats, c_mid,
-                              C);
+                              C, d_f32);
 }
 
 extern "C" int qpg_audio_cosine_mx(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F,
                                    const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
-                                   const float* q32, const double* qn2, int Q, double* D, int64_t ldD, int32_t* stats) {
+                                   const float* q32, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD,
+                                   int32_t* stats) {
   return audio_cosine_mx("qpg_audio_cosine_mx", ctx, stream, base, false, N, T, F, cand_t, G, n_taps, tap_stride, cn2, q32,
-                         qn2, Q, D, ldD, stats);
+                         qn2, Q, D, ldD, stats, d_is_f32);
 }
 
 extern "C" int qpg_audio_cosine_mx_h(qpg_ctx* ctx, void* stream, const void* base_f16, int N, int T, int F,
                                      const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
-                                     const float* q32, const double* qn2, int Q, double* D, int64_t ldD, int32_t* stats) {
+                                     const float* q32, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD,
+                                     int32_t* stats) {
   QPG_REQUIRE((reinterpret_cast<uintptr_t>(base_f16) % 16) == 0, "qpg_audio_cosine_mx_h: base must be 16-byte aligned");
   return audio_cosine_mx("qpg_audio_cosine_mx_h", ctx, stream, static_cast<const float*>(base_f16), true, N, T, F, cand_t, G,
-                         n_taps, tap_stride, cn2, q32, qn2, Q, D, ldD, stats);
+                         n_taps, tap_stride, cn2, q32, qn2, Q, D, ldD, stats, d_is_f32);
 }
 
 template <int MT, int NT>
@@ -910,7 +918,7 @@ static int audio_cosine(const char* name, qpg_ctx* ctx, void* stream, const void
     dim3 grid((unsigned)main_x, (unsigned)ny);
     hipLaunchKernelGGL((audio_cosine_mx2_kernel<3, 6, true, false>), grid, dim3(256), 0, qpg_stream(stream),
                        static_cast<const float*>(base), N, T, F, cand_t, G, tap_stride, cn2, q32, qn2, Q, D, ldD,
-                       (const float*)ctx->zeros, (int32_t*)nullptr, (int64_t)0, c_mid, (int)main_x, c_mid);
+                       (const float*)ctx->zeros, (int32_t*)nullptr, (int64_t)0, c_mid, (int)main_x, c_mid, 0);
     QPG_LAUNCH_CHECK("audio_cosine_mx2_kernel<f64>");
   }
   if (c_mid == C) return QPG_OK;

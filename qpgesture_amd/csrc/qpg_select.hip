@@ -803,8 +803,9 @@ __global__ __launch_bounds__(256) void select_refine_kernel(GuardArgs A, int K, 
 #else
 #define SEL_MARK(i)
 #endif
+template <typename DT>
 __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
-    const double* __restrict__ D, int64_t ldD, const int16_t* __restrict__ cand_code, int64_t C, int K, double absent,
+    const DT* __restrict__ D, int64_t ldD, const int16_t* __restrict__ cand_code, int64_t C, int K, double absent,
     int32_t idx_base, double* __restrict__ out_dist, int32_t* __restrict__ out_idx, int16_t* __restrict__ out_rank,
     int q_block, int64_t block_stride, GuardArgs A, double eps1, const double* __restrict__ cn2,
     const double* __restrict__ qn2, int use_qlds, int phase, unsigned char* __restrict__ ws) {
@@ -830,8 +831,8 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   int* rk = reinterpret_cast<int*>(p_k + MIX_LIST);          // [K] rank counters
   float* qlds = reinterpret_cast<float*>(rk + K);            // [n_taps*F] this query's row (fast tier-1 path only)
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
-  const double* row = D + (int64_t)q * ldD;
-  if (q_block > 0) {
+  const DT* row = D + (int64_t)q * ldD;                       // DT = float: the sweep stored its matrix in f32 (half the bytes
+  if (q_block > 0) {                                            // of the two streaming passes, +1.2e-7 inside the bound)
     const int64_t shift = (int64_t)(q / q_block) * block_stride;
     const int64_t rowoff = (int64_t)(q % q_block) * K - (int64_t)q * K;
     out_dist = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(out_dist) + shift) + rowoff;
@@ -888,22 +889,23 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   int n = 0;
   if (phase != 2) {
   SEL_MARK(0);
-  typedef double vecD __attribute__((ext_vector_type(2)));
-  typedef int16_t vecC __attribute__((ext_vector_type(2)));
-  const bool vec_ok = (ldD % 2) == 0 && (reinterpret_cast<uintptr_t>(D) % 16) == 0 &&
-                      (reinterpret_cast<uintptr_t>(cand_code) % 4) == 0;
-  const int64_t Cv = vec_ok ? (C / 2) * 2 : 0;
+  constexpr int VE = 16 / (int)sizeof(DT);                    // matrix elements per 16-byte load
+  typedef DT vecD __attribute__((ext_vector_type(VE)));
+  typedef int16_t vecC __attribute__((ext_vector_type(VE)));
+  const bool vec_ok = (ldD % VE) == 0 && (reinterpret_cast<uintptr_t>(D) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(cand_code) % (2 * VE)) == 0;
+  const int64_t Cv = vec_ok ? (C / VE) * VE : 0;
 #pragma unroll 4
-  for (int64_t c = (int64_t)tid * 2; c < Cv; c += (int64_t)blockDim.x * 2) {
+  for (int64_t c = (int64_t)tid * VE; c < Cv; c += (int64_t)blockDim.x * VE) {
     const vecD d = *reinterpret_cast<const vecD*>(row + c);
     const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
-      if ((unsigned)cd[e] < (unsigned)K) atomicMin(&best[cd[e]], (unsigned long long)order_key(d[e]));
+    for (int e = 0; e < VE; ++e)
+      if ((unsigned)cd[e] < (unsigned)K) atomicMin(&best[cd[e]], (unsigned long long)order_key((double)d[e]));
   }
   for (int64_t c = Cv + tid; c < C; c += blockDim.x) {
     const int cd = cand_code[c];
-    if ((unsigned)cd < (unsigned)K) atomicMin(&best[cd], (unsigned long long)order_key(row[c]));
+    if ((unsigned)cd < (unsigned)K) atomicMin(&best[cd], (unsigned long long)order_key((double)row[c]));
   }
   __syncthreads();
   SEL_MARK(1);
@@ -920,13 +922,13 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     }
   };
 #pragma unroll 4
-  for (int64_t c = (int64_t)tid * 2; c < Cv; c += (int64_t)blockDim.x * 2) {
+  for (int64_t c = (int64_t)tid * VE; c < Cv; c += (int64_t)blockDim.x * VE) {
     const vecD d = *reinterpret_cast<const vecD*>(row + c);
     const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
-    pass2(c, d[0], cd[0]);
-    pass2(c + 1, d[1], cd[1]);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) pass2(c + e, (double)d[e], cd[e]);
   }
-  for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass2(c, row[c], cand_code[c]);
+  for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass2(c, (double)row[c], cand_code[c]);
   __syncthreads();
   SEL_MARK(2);
   // ---- list (a): every member of a band with two or more members — from the members pass 2 remembered, or, if there
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     for (int64_t c = tid; c < C; c += blockDim.x) {
       const int cd = cand_code[c];
       if ((unsigned)cd >= (unsigned)K || near_[cd] < 2) continue;
-      if (row[c] <= key_value(best[cd], 0.0) + eps1) {
+      if ((double)row[c] <= key_value(best[cd], 0.0) + eps1) {
         const int pos = atomicAdd(&ctl[0], 1);
         if (pos < MIX_LIST) {
           l_c[pos] = (int)c;
@@ -1160,7 +1162,7 @@ extern "C" int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K) {
   return (Q <= 0 || K <= 0) ? 0 : (int64_t)((size_t)Q * mix_ws_stride(K));
 }
 
-extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const double* D, int64_t ldD, int Q,
+extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
                                             const int16_t* cand_code, int64_t C, int K, double absent,
                                             int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
                                             int q_block, int64_t block_stride, const float* base, int T, int F,
@@ -1187,34 +1189,37 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const do
   const size_t sh = 32 * (size_t)K + 16 * MIX_LIST + 4 * MIX_LIST2 + 16 + 6 * MIX_LIST + 4 * (size_t)K +
                     (use_qlds ? (size_t)n_taps * F * 4 : 0);
   if (!ctx->select_lds_raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(percode_select_mixed_f64_kernel),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(percode_select_mixed_f64_kernel<double>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(percode_select_mixed_f64_kernel<float>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
       qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
       return QPG_EHIP;
     }
     ctx->select_lds_raised = true;
   }
+  const size_t sh1 = sh - (use_qlds ? (size_t)n_taps * F * 4 : 0);
+  unsigned char* w = static_cast<unsigned char*>(ws);
+  if (ws)
+    QPG_REQUIRE(ws_bytes >= (int64_t)((size_t)Q * mix_ws_stride(K)) && (reinterpret_cast<uintptr_t>(ws) % 16) == 0,
+                "%s: workspace too small or misaligned (qpg_percode_select_mixed_ws_bytes)", name);
+#define SEL_MIX_LAUNCH(DT, SH, PHASE)                                                                                  \
+  hipLaunchKernelGGL((percode_select_mixed_f64_kernel<DT>), dim3(Q), dim3(1024), SH, qpg_stream(stream),               \
+                     static_cast<const DT*>(D), ldD, cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank,   \
+                     q_block, block_stride, A, eps1, cn2, qn2, use_qlds, PHASE, w)
   if (!ws) {
-    hipLaunchKernelGGL(percode_select_mixed_f64_kernel, dim3(Q), dim3(1024), sh, qpg_stream(stream), D, ldD, cand_code,
-                       C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block, block_stride, A, eps1, cn2, qn2,
-                       use_qlds, 0, (unsigned char*)nullptr);
+    if (d_is_f32) SEL_MIX_LAUNCH(float, sh, 0); else SEL_MIX_LAUNCH(double, sh, 0);
     QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel");
     return QPG_OK;
   }
-  QPG_REQUIRE(ws_bytes >= (int64_t)((size_t)Q * mix_ws_stride(K)) && (reinterpret_cast<uintptr_t>(ws) % 16) == 0,
-              "%s: workspace too small or misaligned (qpg_percode_select_mixed_ws_bytes)", name);
-  unsigned char* w = static_cast<unsigned char*>(ws);
-  hipLaunchKernelGGL(percode_select_mixed_f64_kernel, dim3(Q), dim3(1024), sh - (use_qlds ? (size_t)n_taps * F * 4 : 0),
-                     qpg_stream(stream), D, ldD, cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block,
-                     block_stride, A, eps1, cn2, qn2, use_qlds, 1, w);
+  if (d_is_f32) SEL_MIX_LAUNCH(float, sh1, 1); else SEL_MIX_LAUNCH(double, sh1, 1);
   QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (lists)");
   const int rb = Q >= 256 ? 4 : 16;          // waves per query = 4*rb; ~100 list entries per query on dense data
   hipLaunchKernelGGL((select_refine_kernel<4>), dim3(Q, rb), dim3(256), 0, qpg_stream(stream), A, K, cn2, qn2, w, use_qlds);
   QPG_LAUNCH_CHECK("select_refine_kernel");
-  hipLaunchKernelGGL(percode_select_mixed_f64_kernel, dim3(Q), dim3(1024), sh - (use_qlds ? (size_t)n_taps * F * 4 : 0),
-                     qpg_stream(stream), D, ldD, cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block,
-                     block_stride, A, eps1, cn2, qn2, use_qlds, 2, w);
+  if (d_is_f32) SEL_MIX_LAUNCH(float, sh1, 2); else SEL_MIX_LAUNCH(double, sh1, 2);
   QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (merge)");
+#undef SEL_MIX_LAUNCH
   return QPG_OK;
 }
 

@@ -79,7 +79,7 @@ def test_unfused_entry_points_agree_with_fused():
     assert torch.equal(r0, knn.rank_rows(d1))
     knn.audio_precision = "mixed"           # the default: same winners and ranks, values inside the sweep's bound
     dm, im, rm = knn.sweep_audio(te_i, q_win, q_t, want_rank=True)
-    assert torch.equal(im, i1) and torch.equal(rm, r0) and float((dm - d1).abs().max()) <= 1.92e-6
+    assert torch.equal(im, i1) and torch.equal(rm, r0) and float((dm - d1).abs().max()) <= 2.05e-6
     rows = [int(i / 180 * 30) for i in q_t]
     qt = te_c[torch.as_tensor(q_win, device=te_c.device), torch.as_tensor(rows, device=te_c.device)].contiguous()
     t0, j0, s0 = knn.sweep_text(qt, want_rank=True)

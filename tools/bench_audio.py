@@ -19,7 +19,7 @@ MX = len(sys.argv) > 4 and sys.argv[4] == "mx"       # the mixed-precision sweep
 STATS = torch.zeros((8,), dtype=torch.int64, device=dev) if os.environ.get("QPG_TIMING") else None
 def run():
     if MX:
-        _lib.call("qpg_audio_cosine_mx", dev, base, N, T, F, cand_t, G, 6, 2, cn2, q32, qn2, Q, D, D.stride(0), STATS)
+        _lib.call("qpg_audio_cosine_mx", dev, base, N, T, F, cand_t, G, 6, 2, cn2, q32, qn2, Q, D, 0, D.stride(0), STATS)
     else:
         _lib.call("qpg_audio_cosine_f64", dev, base, N, T, F, cand_t, G, 6, 2, cn2, q32, qn2, Q, D, D.stride(0))
 for _ in range(3): run()
