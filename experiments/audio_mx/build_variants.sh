@@ -1,5 +1,6 @@
 #!/bin/bash
-# Variant builds of the mixed-precision audio sweep (qpg_audio.hip macros) for tools/bench_audio.py:
+# Variant builds of the mixed-precision audio sweep for tools/bench_audio.py.  The padding / rotation / timing / lane-stride
+# macros only exist in qpg_audio_instrumented.hip.txt (copy it over csrc/qpg_audio.hip to use them):
 #   QPG_LIB_PATH=experiments/audio_mx/lib_<tag>.so python tools/bench_audio.py 2048 48 10 mx
 set -e
 cd "$(dirname "$0")/../.."
