@@ -111,9 +111,10 @@ extern "C" int qpg_percode_argmin_f32(qpg_ctx* ctx, void* stream, const float* D
 // ---------------------------------------------------------------------------------------------
 #define RS_CHUNK 4096   // candidates per block in the two resolve passes
 
-// Table initialisation as a KERNEL, not hipMemsetAsync: inside a captured hipGraph the memset nodes of ROCm 7.2 were
-// observed to complete after the kernels that follow them on the capturing stream once other work had run between
-// replays (tables came back all 0xFF; tools/dbg_graph3.py) — kernel -> kernel edges are honoured.
+// Table initialisation as a KERNEL, not hipMemsetAsync: in round 1 captured-graph replays of the matcher came back with
+// all-0xFF tables when this was a memset node.  The pattern in isolation is clean (experiments/graph_memset: 3 x 400
+// replays), so the cause was above HIP (PyTorch capture pool); the fill kernel stays because it is harmless, and only
+// these stand-alone entry points still need a global table at all.
 __global__ __launch_bounds__(256) void fill_ff_kernel(unsigned long long* __restrict__ a, int64_t na,
                                                       unsigned int* __restrict__ b, int64_t nb) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
