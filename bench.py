@@ -127,8 +127,8 @@ def main():
     knn = CodeKNN(db, rng=np.random.RandomState(123456))
     knn.overlap_sweeps = not a.no_overlap
     knn.audio_precision = a.audio_precision
-    # the mixed-precision sweep is taken where CodeKNN.sweep_audio can take it (one GPU); see its comment
-    mixed = a.audio_precision == "mixed" and world == 1
+    # the mixed-precision sweep: one GPU, or row shards whose merge re-evaluates through a request / response exchange
+    mixed = a.audio_precision == "mixed"
 
     # clips: weak = CL per rank (every rank holds all of them: M*180*1024 f32 = 4.4 MB each); strong = ONE clip in all
     n_clips = CL if strong else CL * world
@@ -204,6 +204,7 @@ def main():
                 "kernel": ("audio_cosine_mx2_kernel (one launch: LDS-shared-query blocks + split-K remainder blocks; f32 "
                            "matrix cores, error bounded a priori, f64 re-evaluation in the select)")
                 if mixed else "audio_cosine_f64_kernel",
+                "precision": "mixed" if mixed else "f64",
                 "kernel_ms": round(k_ms, 4),
                 "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_launches_timed": len(ms),
                 "algorithmic_gflop": round(flops / 1e9, 3),
@@ -235,7 +236,13 @@ def main():
            "realtime_factor": round(24.0 * M / 6 / (dt / a.steps), 1) if strong
            else round(value / 60.0 / world, 1)}
 
-    if mixed:
+    if mixed and world > 1:
+        st = knn.mixed_stats()
+        fl = knn._guard_stats.cpu().numpy()
+        out["mixed_precision"] = {"shard_f64_dot_pairs_per_step": round(st["tier1_pairs"] / (a.steps + a.warmup), 1),
+                                  "cross_shard_reevaluations_per_step": round(int(fl[3]) / (a.steps + a.warmup), 1),
+                                  "flags": st["flags"], "error_bound": 2.05e-6}
+    if mixed and world == 1:
         # re-evaluation activity of the timed steps (+ warm-up) and the same clip through the f64 sweep: the mixed path
         # must return the same codes (its tables differ only inside the sweep's error bound)
         st = knn.mixed_stats()

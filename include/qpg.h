@@ -250,6 +250,31 @@ int qpg_percode_select_mixed_f64(qpg_ctx*, void* stream, const void* D, int d_is
  * on its own CU (slower when the lists are long). */
 int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K);
 
+/* Cross-shard merge when the shards swept with qpg_audio_cosine_mx (their tables are accurate to QPG_AUDIO_MX_ERR; each
+ * shard's own select has settled the near-ties inside the shard).  Three steps around two more byte exchanges:
+ *   qpg_merge_mixed_phase1_f64  (owner of a query block)  approximate merge of the W received tables (same layout
+ *       arguments as qpg_merge_select_f64); every shard within eps1 of a code's merged minimum — when there are two or
+ *       more — and the winners of codes whose merged minima are rank neighbours within eps1 become requests to the
+ *       shard holding the candidate.  req: [dev] W blocks of req_stride bytes, block w = [i64 count][R x u64
+ *       (q_local << 48 | code << 32 | global candidate)]: the send buffer of an all-to-all.  ws: [dev] scratch of
+ *       qpg_merge_mixed_ws_bytes(Q, K) bytes, kept for phase 2.  stats[1] |= 4 on request / flag-list overflow.
+ *   qpg_shard_refine_f64        (every shard)  req_recv = the W request blocks received (block o from owner o); the
+ *       exact f64 distance of every requested (query o*q_stride + q_local, candidate - cand_base) goes to resp block o
+ *       ([R x f64], resp_stride bytes apart): the send buffer of the answering all-to-all.
+ *   qpg_merge_mixed_phase2_f64  (owner)  winners among the re-evaluated contenders by (exact value, candidate), stable
+ *       ranks over re-evaluated and untouched minima.  stats[3] += re-evaluated entries. */
+int64_t qpg_merge_mixed_ws_bytes(int Q, int K);
+int qpg_merge_mixed_phase1_f64(qpg_ctx*, void* stream, const void* recv, int W, int64_t src_stride, int64_t dist_off,
+                               int64_t idx_off, int Q, int K, double absent, double eps1, int R, void* req,
+                               int64_t req_stride, void* ws, int64_t ws_bytes, int32_t* stats);
+int qpg_shard_refine_f64(qpg_ctx*, void* stream, const void* req_recv, int W, int64_t req_stride, int R, int q_stride,
+                         int64_t cand_base, const float* base, int base_is_f16, int T, int F, const int32_t* cand_t, int G,
+                         int n_taps, int tap_stride, const float* q32, const double* qn2, const double* cn2, void* resp,
+                         int64_t resp_stride);
+int qpg_merge_mixed_phase2_f64(qpg_ctx*, void* stream, const void* recv, int W, int64_t src_stride, int64_t idx_off, int Q,
+                               int K, double absent, const void* ws, int64_t ws_bytes, const void* resp_recv,
+                               int64_t resp_stride, double* out_dist, int32_t* out_idx, int16_t* out_rank, int32_t* stats);
+
 /* Cross-shard min + index merge after the RCCL exchange (the all-reduce(min, index) `north_star`
  * names, as all-gather / all-to-all + this kernel): source w's tables start at recv + w*src_stride (+ dist_off for the
  * [Q][K] distances, + idx_off for the [Q][K] i32 global candidate indices, -1 = absent in that shard).  Winner per

@@ -263,6 +263,10 @@ class CodeKNN:
         # follows (single-GPU DB, ranks fused, guard on; f32 or f16 base); everything else runs the f64 sweep.
         self.audio_precision = "mixed"
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
+        # Row-sharded DB: the shards sweep in mixed precision too and the cross-shard merge re-evaluates what their
+        # bounded tables leave open through a request / response exchange (sweep_tables; qpg_merge_mixed_*).
+        self.sharded_mixed = True
+        self.mixed_requests = 8192          # request slots per (owner, shard) pair and step
         # host_ranks (the CLI's --tie_rule numpy): rank the (Q,512) audio / text minima with the reference's own
         # `np.array(x).argsort().argsort()` on the host, so that EXACT ties between codes (structural in real text
         # embeddings: silent frames share one vector) get NumPy's unstable-sort order like the reference's.
@@ -314,8 +318,11 @@ class CodeKNN:
         C = db.n_local * db.Ga
         fused_rank = want_rank and db.world == 1
         half = db.feature_dtype == "f16"
-        mixed = (self.audio_precision == "mixed" and fused_rank and reduce and out is None and self.tie_eps > 0
-                 and C > 0 and db.K <= 512)
+        local_final = fused_rank and reduce and out is None               # one GPU: this select decides everything
+        shard_part = db.world > 1 and not reduce and out is not None        # row shard: sweep_tables merges (mixed protocol)
+        mixed = (self.audio_precision == "mixed" and (local_final or (shard_part and self.sharded_mixed))
+                 and self.tie_eps > 0 and C > 0 and db.K <= 512)
+        self._last_audio_mixed = mixed
         # the mixed-precision sweep stores its matrix in f32: it only feeds the select's two streaming passes
         D = torch.empty((Q, max(C, 1)), dtype=torch.float32 if mixed else torch.float64, device=dev)
         ev = getattr(self, "kernel_events", None)       # bench.py: HIP events around the dominant kernel
@@ -357,6 +364,7 @@ class CodeKNN:
             _lib.call("qpg_percode_select_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K, float(ABSENT_DIST),
                       db.idx_base * db.Ga, dist, idx, rank, qb, bs)
         self._last_D_aud = D
+        self._last_q32, self._last_qn2 = q32, qn2          # the sharded mixed merge re-evaluates requested pairs from these
         if not reduce:              # sharded caller combines several tables in one exchange (sweep_tables)
             return dist, idx
         dist, idx = self._reduce_min(dist, idx)
@@ -632,14 +640,42 @@ class CodeKNN:
                 d = torch.empty((lay.Qb, db.K), dtype=lay.dtype[p_], device=dev)
                 ix = torch.empty((lay.Qb, db.K), dtype=torch.int32, device=dev)
                 rk = torch.empty((lay.Qb, db.K), dtype=torch.int16, device=dev)
-                _lib.call("qpg_merge_select_f64" if f64 else "qpg_merge_select_f32", dev, recv, db.world, src_stride,
-                          lay.off[p_ + "_d"], lay.off[p_ + "_i"], lay.Qb, db.K, float(ABSENT_DIST), d, ix, rk)
+                if p_ == "aud" and not self.use_wavvq and getattr(self, "_last_audio_mixed", False):
+                    self._merge_mixed(recv, src_stride, lay, owner_blocks, d, ix, rk)
+                else:
+                    _lib.call("qpg_merge_select_f64" if f64 else "qpg_merge_select_f32", dev, recv, db.world, src_stride,
+                              lay.off[p_ + "_d"], lay.off[p_ + "_i"], lay.Qb, db.K, float(ABSENT_DIST), d, ix, rk)
                 T[p_ + "_d"], T[p_ + "_idx"], T[p_ + "_rank"] = d, ix, rk
         if self.host_ranks:
             for p_ in ("aud", "txt"):
                 if T[p_ + "_d"] is not None:
                     T[p_ + "_rank"] = self.numpy_ranks(T[p_ + "_d"])
         return T
+
+    def _merge_mixed(self, recv, src_stride, lay, owner_blocks, d, ix, rk):
+        """Cross-shard merge of mixed-precision audio tables: approximate merge + requests (owner), one
+        all-to-all, exact re-evaluation of the requested pairs (shards), one all-to-all back, final merge + ranks."""
+        db, dev = self.db, self.db.device
+        W, R, Qb, K = db.world, int(self.mixed_requests), lay.Qb, db.K
+        req_stride, resp_stride = 8 + 8 * R, 8 * R
+        bufs = self.__dict__.get("_mm_bufs")
+        need_ws = int(_lib.load().qpg_merge_mixed_ws_bytes(Qb, K))
+        if bufs is None or bufs[0].numel() != W * req_stride or bufs[2].numel() < need_ws:
+            bufs = self.__dict__["_mm_bufs"] = (torch.empty((W * req_stride,), dtype=torch.uint8, device=dev),
+                                                torch.empty((W * resp_stride,), dtype=torch.uint8, device=dev),
+                                                torch.empty((need_ws,), dtype=torch.uint8, device=dev))
+        req, resp, ws = bufs
+        _lib.call("qpg_merge_mixed_phase1_f64", dev, recv, W, src_stride, lay.off["aud_d"], lay.off["aud_i"], Qb, K,
+                  float(ABSENT_DIST), AUDIO_MX_BAND, R, req, req_stride, ws, ws.numel(), self._guard_stats)
+        req_recv = exchange_bytes(req, W, True)
+        # block o of req_recv comes from owner o: its queries are rows o*Qb .. of this rank's packed query set when every
+        # owner has its own block (all-to-all form), rows 0 .. when all ranks own the same queries (all-gather form)
+        _lib.call("qpg_shard_refine_f64", dev, req_recv, W, req_stride, R, Qb if owner_blocks else 0, db.idx_base * db.Ga,
+                  db.base, int(db.feature_dtype == "f16"), db.T, db.F, db.aud_t, db.Ga, NUM_AUDIO_FEAT_FRAMES,
+                  db.tap_stride, self._last_q32, self._last_qn2, db.cn2, resp, resp_stride)
+        resp_recv = exchange_bytes(resp, W, True)
+        _lib.call("qpg_merge_mixed_phase2_f64", dev, recv, W, src_stride, lay.off["aud_i"], Qb, K, float(ABSENT_DIST), ws,
+                  ws.numel(), resp_recv, resp_stride, d, ix, rk, self._guard_stats)
 
     def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True):
         """Device-side walk of windows [window_offset, window_offset+n_windows) of the tables."""

@@ -1308,6 +1308,275 @@ extern "C" int qpg_merge_select_f32(qpg_ctx* ctx, void* stream, const void* recv
                              out_dist, out_idx, out_rank);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-shard merge for the MIXED-PRECISION sweep (row-sharded DB).  Every shard contributes per-(query, code) minima
+// that are only accurate to E = QPG_AUDIO_MX_ERR (its own select has already settled the near-ties INSIDE the shard),
+// so the owner of a query block cannot simply take the minimum over shards.  Same rule as on one GPU, with the
+// re-evaluation done where the rows live:
+//   phase 1 (owner)   approximate merge; every shard within eps1 of a code's merged minimum (when there are two or
+//                     more) and the winners of codes whose merged minima are rank neighbours within eps1 become
+//                     REQUESTS (query, code, candidate) to the shard that holds the candidate;
+//   refine  (shards)  exact f64 distance of every requested pair (one wave per pair), sent back;
+//   phase 2 (owner)   winners among the re-evaluated contenders by (exact value, index), ranks over exact + untouched.
+// Message layout of one (owner -> shard) request block: [i64 count][R x u64 (q_local << 48 | code << 32 | candidate)];
+// response block: [R x f64].  Both travel through the same byte exchange as the tables (parallel.exchange_bytes).
+// ---------------------------------------------------------------------------------------------------------------
+#define MM_FL 1024     // flagged (code, shard) entries per query
+
+__global__ void merge_mixed_zero_counts_kernel(unsigned char* __restrict__ req, int64_t req_stride, int W) {
+  for (int w = threadIdx.x; w < W; w += blockDim.x) *reinterpret_cast<long long*>(req + (int64_t)w * req_stride) = 0;
+}
+
+__global__ __launch_bounds__(512) void merge_mixed_phase1_kernel(
+    const unsigned char* __restrict__ recv, int W, int64_t src_stride, int64_t dist_off, int64_t idx_off, int K,
+    double absent, double eps1, int R, unsigned char* __restrict__ req, int64_t req_stride,
+    double* __restrict__ prov_d, int32_t* __restrict__ prov_i, unsigned long long* __restrict__ fl,
+    int32_t* __restrict__ fl_cnt, int32_t* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* v = reinterpret_cast<double*>(smem);                   // [K] merged approximate minimum
+  int* bi = reinterpret_cast<int*>(v + K);                       // [K] its candidate
+  int* bs = bi + K;                                              // [K] its shard
+  int* cnt = bs + K;                                             // [K] shards within eps1 of the merged minimum
+  int* s_code = cnt + K;                                         // [K] code at rank r
+  int* flg = s_code + K;                                         // [K] rank-level flag
+  __shared__ int n_fl;
+  const int q = blockIdx.x;
+  if (threadIdx.x == 0) n_fl = 0;
+  auto dval = [&](int w, int k) { return reinterpret_cast<const double*>(recv + (int64_t)w * src_stride + dist_off)[(int64_t)q * K + k]; };
+  auto ival = [&](int w, int k) { return reinterpret_cast<const int32_t*>(recv + (int64_t)w * src_stride + idx_off)[(int64_t)q * K + k]; };
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    double bd = absent;
+    int b = -1, sh = -1;
+    for (int w = 0; w < W; ++w) {
+      const int i = ival(w, k);
+      if (i < 0) continue;
+      const double d = dval(w, k);
+      if (b < 0 || d < bd || (d == bd && i < b)) {
+        bd = d;
+        b = i;
+        sh = w;
+      }
+    }
+    int c = 0;
+    if (b >= 0)
+      for (int w = 0; w < W; ++w) c += ival(w, k) >= 0 && dval(w, k) <= bd + eps1;
+    v[k] = bd;
+    bi[k] = b;
+    bs[k] = sh;
+    cnt[k] = c;
+    flg[k] = 0;
+    prov_d[(int64_t)q * K + k] = bd;
+    prov_i[(int64_t)q * K + k] = b;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const double x = v[k];
+    int r = 0;
+#pragma unroll 8
+    for (int o = 0; o < K; ++o) {
+      const double y = v[o];
+      r += (y < x) || (y == x && o < k);
+    }
+    s_code[r] = k;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r + 1 < K; r += blockDim.x) {
+    const int ka = s_code[r], kb = s_code[r + 1];
+    if (bi[ka] < 0 || bi[kb] < 0) continue;
+    if (v[kb] - v[ka] < eps1) {
+      flg[ka] = 1;                                               // (benign races: only ever set to 1)
+      flg[kb] = 1;
+    }
+  }
+  __syncthreads();
+  auto emit = [&](int w, int k, int cand) {
+    int* cntp = reinterpret_cast<int*>(req + (int64_t)w * req_stride);
+    const int j = atomicAdd(cntp, 1);
+    const int pos = atomicAdd(&n_fl, 1);
+    if (j >= R || pos >= MM_FL) {
+      atomicOr(&stats[1], 4);                                    // request / flag list overflow: entry stays approximate
+      return;
+    }
+    reinterpret_cast<unsigned long long*>(req + (int64_t)w * req_stride + 8)[j] =
+        ((unsigned long long)q << 48) | ((unsigned long long)k << 32) | (unsigned int)cand;
+    fl[(int64_t)q * MM_FL + pos] = ((unsigned long long)k << 40) | ((unsigned long long)w << 32) | (unsigned int)j;
+  };
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    if (bi[k] < 0) continue;
+    if (cnt[k] >= 2) {
+      for (int w = 0; w < W; ++w) {
+        const int i = ival(w, k);
+        if (i >= 0 && dval(w, k) <= v[k] + eps1) emit(w, k, i);
+      }
+    } else if (flg[k]) {
+      emit(bs[k], k, bi[k]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) fl_cnt[q] = n_fl < MM_FL ? n_fl : MM_FL;
+}
+
+// shards: exact distance of every requested (query, candidate); one wave per request
+__global__ __launch_bounds__(256) void shard_refine_kernel(GuardArgs A, const unsigned char* __restrict__ req_recv,
+                                                           int64_t req_stride, int R, int q_stride, int64_t cand_base,
+                                                           const double* __restrict__ cn2, const double* __restrict__ qn2,
+                                                           unsigned char* __restrict__ resp, int64_t resp_stride, int fast) {
+  const int o = blockIdx.x, lane = threadIdx.x & 63;
+  const int g = blockIdx.y * 4 + (threadIdx.x >> 6), ng = gridDim.y * 4;
+  const unsigned char* blk = req_recv + (int64_t)o * req_stride;
+  int n = *reinterpret_cast<const int*>(blk);
+  n = n < R ? n : R;
+  const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(blk + 8);
+  double* out = reinterpret_cast<double*>(resp + (int64_t)o * resp_stride);
+  for (int e = g; e < n; e += ng) {
+    const unsigned long long x = ent[e];
+    const int q = o * q_stride + (int)(x >> 48);
+    const int64_t c = (int64_t)(unsigned int)(x & 0xffffffffu) - cand_base;        // local candidate
+    const float* qrow = A.q32 + (int64_t)q * A.n_taps * A.F;
+    const double dot = fast ? pair_dot_fast_f64<4>(A, qrow, c, lane) : pair_dot_wave_f64(A, q, c, lane);
+    if (lane == 0) out[e] = cosine_from_dot(dot, qn2[q], cn2[c]);
+  }
+}
+
+__global__ __launch_bounds__(512) void merge_mixed_phase2_kernel(
+    const unsigned char* __restrict__ recv, int W, int64_t src_stride, int64_t idx_off, int K, double absent,
+    const double* __restrict__ prov_d, const int32_t* __restrict__ prov_i, const unsigned long long* __restrict__ fl,
+    const int32_t* __restrict__ fl_cnt, const unsigned char* __restrict__ resp_recv, int64_t resp_stride,
+    double* __restrict__ out_dist, int32_t* __restrict__ out_idx, int16_t* __restrict__ out_rank,
+    int32_t* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* v = reinterpret_cast<double*>(smem);                                       // [K]
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(v + K);           // [K] key of the refined minimum
+  unsigned int* besti = reinterpret_cast<unsigned int*>(best + K);                   // [K]
+  int* touched = reinterpret_cast<int*>(besti + K);                                  // [K]
+  const int q = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    v[k] = prov_d[(int64_t)q * K + k];
+    besti[k] = (unsigned int)prov_i[(int64_t)q * K + k];
+    best[k] = ~0ull;
+    touched[k] = 0;
+  }
+  __syncthreads();
+  const int n = fl_cnt[q];
+  auto entry = [&](int e, int& k, double& d, unsigned int& cand) {
+    const unsigned long long x = fl[(int64_t)q * MM_FL + e];
+    k = (int)(x >> 40);
+    const int w = (int)((x >> 32) & 0xff), j = (int)(x & 0xffffffffu);
+    d = reinterpret_cast<const double*>(resp_recv + (int64_t)w * resp_stride)[j];
+    cand = (unsigned int)reinterpret_cast<const int32_t*>(recv + (int64_t)w * src_stride + idx_off)[(int64_t)q * K + k];
+  };
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    int k;
+    double d;
+    unsigned int c;
+    entry(e, k, d, c);
+    touched[k] = 1;
+    atomicMin(&best[k], (unsigned long long)order_key(d));
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x)
+    if (touched[k]) besti[k] = 0xffffffffu;
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    int k;
+    double d;
+    unsigned int c;
+    entry(e, k, d, c);
+    if ((unsigned long long)order_key(d) == best[k]) atomicMin(&besti[k], c);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    if (touched[k]) v[k] = key_value(best[k], 0.0);
+    out_dist[(int64_t)q * K + k] = v[k];
+    out_idx[(int64_t)q * K + k] = (int32_t)besti[k];
+  }
+  if (threadIdx.x == 0 && n > 0) atomicAdd(&stats[3], n);
+  if (!out_rank) return;
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const double x = v[k];
+    int r = 0;
+#pragma unroll 8
+    for (int o = 0; o < K; ++o) {
+      const double y = v[o];
+      r += (y < x) || (y == x && o < k);
+    }
+    out_rank[(int64_t)q * K + k] = (int16_t)r;
+  }
+}
+
+extern "C" int64_t qpg_merge_mixed_ws_bytes(int Q, int K) {          // prov_d | prov_i | fl | fl_cnt
+  return (Q <= 0 || K <= 0) ? 0 : (int64_t)Q * K * 12 + (int64_t)Q * MM_FL * 8 + (int64_t)Q * 4 + 64;
+}
+
+extern "C" int qpg_merge_mixed_phase1_f64(qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
+                                          int64_t dist_off, int64_t idx_off, int Q, int K, double absent, double eps1,
+                                          int R, void* req, int64_t req_stride, void* ws, int64_t ws_bytes,
+                                          int32_t* stats) {
+  const char* name = "qpg_merge_mixed_phase1_f64";
+  QPG_REQUIRE(ctx && recv && req && ws && stats, "%s: null pointer", name);
+  QPG_REQUIRE(W > 0 && W <= 255 && Q >= 0 && Q < 65536 && K > 0 && K <= 2048 && R > 0 && src_stride % 8 == 0 &&
+                  dist_off % 8 == 0 && idx_off % 4 == 0 && req_stride >= 8 + 8 * (int64_t)R && req_stride % 8 == 0 &&
+                  eps1 >= 2.0 * QPG_AUDIO_MX_ERR && ws_bytes >= qpg_merge_mixed_ws_bytes(Q, K) &&
+                  (reinterpret_cast<uintptr_t>(ws) % 8) == 0 && (reinterpret_cast<uintptr_t>(req) % 8) == 0,
+              "%s: bad size / alignment (W <= 255, Q < 65536, K <= 2048, eps1 >= 2 x the sweep's bound)", name);
+  if (Q == 0) return QPG_OK;
+  unsigned char* w = static_cast<unsigned char*>(ws);
+  double* prov_d = reinterpret_cast<double*>(w);
+  int32_t* prov_i = reinterpret_cast<int32_t*>(w + (size_t)Q * K * 8);
+  unsigned long long* fl = reinterpret_cast<unsigned long long*>(w + (((size_t)Q * K * 12 + 7) / 8) * 8);
+  int32_t* fl_cnt = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(fl) + (size_t)Q * MM_FL * 8);
+  hipLaunchKernelGGL(merge_mixed_zero_counts_kernel, dim3(1), dim3(256), 0, qpg_stream(stream),
+                     static_cast<unsigned char*>(req), req_stride, W);
+  QPG_LAUNCH_CHECK("merge_mixed_zero_counts_kernel");
+  hipLaunchKernelGGL(merge_mixed_phase1_kernel, dim3(Q), dim3(512), (size_t)K * 28, qpg_stream(stream),
+                     static_cast<const unsigned char*>(recv), W, src_stride, dist_off, idx_off, K, absent, eps1, R,
+                     static_cast<unsigned char*>(req), req_stride, prov_d, prov_i, fl, fl_cnt, stats);
+  QPG_LAUNCH_CHECK("merge_mixed_phase1_kernel");
+  return QPG_OK;
+}
+
+extern "C" int qpg_shard_refine_f64(qpg_ctx* ctx, void* stream, const void* req_recv, int W, int64_t req_stride, int R,
+                                    int q_stride, int64_t cand_base, const float* base, int base_is_f16, int T, int F,
+                                    const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32,
+                                    const double* qn2, const double* cn2, void* resp, int64_t resp_stride) {
+  const char* name = "qpg_shard_refine_f64";
+  QPG_REQUIRE(ctx && req_recv && base && cand_t && q32 && qn2 && cn2 && resp, "%s: null pointer", name);
+  QPG_REQUIRE(W > 0 && R > 0 && req_stride >= 8 + 8 * (int64_t)R && resp_stride >= 8 * (int64_t)R && T > 0 && F > 0 &&
+                  (F % 4) == 0 && G > 0 && n_taps > 0 && tap_stride > 0 && q_stride >= 0,
+              "%s: bad size", name);
+  GuardArgs A;
+  A.base = base; A.half = base_is_f16; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
+  A.tap_stride = tap_stride; A.eps = 0.0; A.stats = nullptr;
+  const int fast = (n_taps == 6 && F == 1024) ? 1 : 0;
+  hipLaunchKernelGGL(shard_refine_kernel, dim3(W, 64), dim3(256), 0, qpg_stream(stream), A,
+                     static_cast<const unsigned char*>(req_recv), req_stride, R, q_stride, cand_base, cn2, qn2,
+                     static_cast<unsigned char*>(resp), resp_stride, fast);
+  QPG_LAUNCH_CHECK("shard_refine_kernel");
+  return QPG_OK;
+}
+
+extern "C" int qpg_merge_mixed_phase2_f64(qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
+                                          int64_t idx_off, int Q, int K, double absent, const void* ws, int64_t ws_bytes,
+                                          const void* resp_recv, int64_t resp_stride, double* out_dist, int32_t* out_idx,
+                                          int16_t* out_rank, int32_t* stats) {
+  const char* name = "qpg_merge_mixed_phase2_f64";
+  QPG_REQUIRE(ctx && recv && ws && resp_recv && out_dist && out_idx && stats, "%s: null pointer", name);
+  QPG_REQUIRE(W > 0 && Q >= 0 && K > 0 && K <= 2048 && ws_bytes >= qpg_merge_mixed_ws_bytes(Q, K) && resp_stride % 8 == 0,
+              "%s: bad size", name);
+  if (Q == 0) return QPG_OK;
+  const unsigned char* w = static_cast<const unsigned char*>(ws);
+  const double* prov_d = reinterpret_cast<const double*>(w);
+  const int32_t* prov_i = reinterpret_cast<const int32_t*>(w + (size_t)Q * K * 8);
+  const unsigned long long* fl = reinterpret_cast<const unsigned long long*>(w + (((size_t)Q * K * 12 + 7) / 8) * 8);
+  const int32_t* fl_cnt = reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(fl) + (size_t)Q * MM_FL * 8);
+  hipLaunchKernelGGL(merge_mixed_phase2_kernel, dim3(Q), dim3(512), (size_t)K * 24, qpg_stream(stream),
+                     static_cast<const unsigned char*>(recv), W, src_stride, idx_off, K, absent, prov_d, prov_i, fl, fl_cnt,
+                     static_cast<const unsigned char*>(resp_recv), resp_stride, out_dist, out_idx, out_rank, stats);
+  QPG_LAUNCH_CHECK("merge_mixed_phase2_kernel");
+  return QPG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void rank_rows_kernel(const T* __restrict__ d, int K, int16_t* __restrict__ out) {

@@ -152,3 +152,77 @@ def test_mixed_on_a_crowded_database():
     x[61] = x[2]
     out = _compare(A, None, nte, want_activity=200)
     assert out["mixed"]["stats"]["tier1_pairs"] > out["mixed"]["stats"]["tier2_pairs"]
+
+
+def test_sharded_mixed_merge_protocol_on_one_gpu():
+    """The cross-shard merge of mixed-precision tables (qpg_merge_mixed_phase1 / qpg_shard_refine / qpg_merge_mixed_phase2),
+    with the two byte exchanges done by hand: two row shards of a DB whose near-ties straddle the shard boundary
+    (perturbed copies of shard-0 windows live in shard 1, half of them with the same codes).  Winners and ranks must equal
+    the unsharded f64 tables."""
+    import torch
+    from qpgesture_amd import _lib
+    from qpgesture_amd.code_knn import ABSENT_DIST, AUDIO_MX_BAND, CodeKNN, ExchangeLayout, GestureDB
+    ntr, nte, W = 120, 2, 2
+    A = fixture_arrays(ntr, nte, 70, 71, 72, 73)
+    rng = np.random.Generator(np.random.PCG64(9))
+    x, code = A["tr_interp"], A["code"]
+    for i in range(30):                                      # shard 0 = windows 0..59, shard 1 = 60..119
+        src, dst = i % 6, 60 + i
+        eps = 0.0 if i % 7 == 0 else 10.0 ** rng.uniform(-7.2, -4.0)
+        x[dst] = (x[src] * (1.0 + eps * rng.standard_normal(x[src].shape))).astype(np.float32)
+        if i % 2 == 0:
+            code[dst] = code[src]
+    dev = torch.device("cuda:0")
+    te_i = torch.from_numpy(A["te_interp"]).to(dev)
+    te_c = torch.from_numpy(np.ascontiguousarray(A["te_ctx"])).to(dev)
+    full = GestureDB(code, x, A["tr_ctx"], A["tr_phase"], A["sig"], device=dev)
+    k_full = CodeKNN(full, rng=np.random.RandomState(1))
+    k_full.audio_precision = "f64"
+    T = k_full.sweep_tables(te_i, te_c, nte)
+    want_idx, want_rank = T["aud_idx"], T["aud_rank"]
+    steps = k_full.n_steps()
+    q_win, q_t = np.repeat(np.arange(nte), steps), np.tile(np.arange(steps) * 24, nte)
+    Q, K = nte * steps, full.K
+    shards, lays = [], []
+    for r in range(W):
+        db = GestureDB(code, x, A["tr_ctx"], A["tr_phase"], A["sig"], device=dev, rank=r, world=W)
+        knn = CodeKNN(db, rng=np.random.RandomState(1))
+        lay = ExchangeLayout(Q, K, 1, ["aud"], True, dev)
+        knn.sweep_audio(te_i, q_win, q_t, reduce=False, out=lay.views("aud"))
+        assert knn._last_audio_mixed
+        shards.append(knn)
+        lays.append(lay)
+    recv = torch.cat([l.send for l in lays])                 # what the all-gather leaves on every rank
+    src_stride = lays[0].send.numel()
+    R = 4096
+    req_stride, resp_stride = 8 + 8 * R, 8 * R
+    owner = shards[0]
+    req = torch.zeros((W * req_stride,), dtype=torch.uint8, device=dev)
+    ws = torch.empty((int(_lib.load().qpg_merge_mixed_ws_bytes(Q, K)),), dtype=torch.uint8, device=dev)
+    stats = torch.zeros((4,), dtype=torch.int32, device=dev)
+    _lib.call("qpg_merge_mixed_phase1_f64", dev, recv, W, src_stride, lays[0].off["aud_d"], lays[0].off["aud_i"], Q, K,
+              float(ABSENT_DIST), AUDIO_MX_BAND, R, req, req_stride, ws, ws.numel(), stats)
+    counts = [int(req[w * req_stride:w * req_stride + 8].view(torch.int64)[0]) for w in range(W)]
+    assert min(counts) > 0 and max(counts) <= R              # both shards are asked (the near-ties straddle the boundary)
+    resp_recv = torch.zeros((W * resp_stride,), dtype=torch.uint8, device=dev)
+    for w in range(W):                                       # all-to-all by hand: owner 0's block w -> shard w's block 0
+        req_recv = torch.zeros((W * req_stride,), dtype=torch.uint8, device=dev)
+        req_recv[:req_stride] = req[w * req_stride:(w + 1) * req_stride]
+        resp = torch.zeros((W * resp_stride,), dtype=torch.uint8, device=dev)
+        k, db = shards[w], shards[w].db
+        _lib.call("qpg_shard_refine_f64", dev, req_recv, W, req_stride, R, 0, db.idx_base * db.Ga, db.base, 0, db.T, db.F,
+                  db.aud_t, db.Ga, 6, db.tap_stride, k._last_q32, k._last_qn2, db.cn2, resp, resp_stride)
+        resp_recv[w * resp_stride:(w + 1) * resp_stride] = resp[:resp_stride]
+    d = torch.empty((Q, K), dtype=torch.float64, device=dev)
+    ix = torch.empty((Q, K), dtype=torch.int32, device=dev)
+    rk = torch.empty((Q, K), dtype=torch.int16, device=dev)
+    _lib.call("qpg_merge_mixed_phase2_f64", dev, recv, W, src_stride, lays[0].off["aud_i"], Q, K, float(ABSENT_DIST), ws,
+              ws.numel(), resp_recv, resp_stride, d, ix, rk, stats)
+    torch.cuda.synchronize()
+    st = stats.cpu().numpy()
+    print("requests per shard", counts, " cross-shard re-evaluations", int(st[3]), " flags", int(st[1]))
+    assert st[1] == 0 and st[3] == sum(counts)
+    assert torch.equal(ix, want_idx)
+    assert torch.equal(rk, want_rank)
+    from qpgesture_amd.code_knn import AUDIO_MX_ERR
+    assert float((d - T["aud_d"]).abs().max()) <= AUDIO_MX_ERR

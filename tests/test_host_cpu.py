@@ -24,7 +24,8 @@ def test_bindings_cover_the_header():
     bound = set(_lib._SIGS) | {"qpg_version", "qpg_ctx_create", "qpg_ctx_destroy", "qpg_last_error",
                                "qpg_vq_workspace_floats", "qpg_vq_reduce_ws_bytes",
                                "qpg_conv1d_wgrad_ws_floats", "qpg_vq_code_sums_ws_bytes",
-                               "qpg_text_percode_ws_bytes", "qpg_percode_select_mixed_ws_bytes"}
+                               "qpg_text_percode_ws_bytes", "qpg_percode_select_mixed_ws_bytes",
+                               "qpg_merge_mixed_ws_bytes"}
     assert declared == bound
 
 
