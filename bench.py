@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--n-db", type=int, default=None, help="DB windows (default 2048; 8192 with --scaling strong)")
     ap.add_argument("--windows", type=int, default=6)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--sharded-mixed-min-gflop", type=float, default=None,
+                    help="row shards sweep in mixed precision when their sweep is at least this long (default: "
+                         "CodeKNN.sharded_mixed_min_gflop = 20; 0 = always)")
     ap.add_argument("--audio-precision", choices=["mixed", "f64"], default="mixed",
                     help="mixed (default, the product default): f32 matrix-core sweep with an a-priori error bound + f64 / "
                          "reference-arithmetic re-evaluation of every undecided comparison; f64: the f64 matrix-core sweep")
@@ -127,8 +130,12 @@ def main():
     knn = CodeKNN(db, rng=np.random.RandomState(123456))
     knn.overlap_sweeps = not a.no_overlap
     knn.audio_precision = a.audio_precision
+    if a.sharded_mixed_min_gflop is not None:
+        knn.sharded_mixed_min_gflop = a.sharded_mixed_min_gflop
     # the mixed-precision sweep: one GPU, or row shards whose merge re-evaluates through a request / response exchange
-    mixed = a.audio_precision == "mixed"
+    # (taken when the shard's sweep is long enough to pay for the two extra exchanges: CodeKNN.sharded_mixed_min_gflop)
+    shard_gflop = 2e-9 * (M * 8 * (CL if strong else CL * world)) * ((hi - lo) * 26) * 6 * 1024
+    mixed = a.audio_precision == "mixed" and (world == 1 or shard_gflop >= knn.sharded_mixed_min_gflop)
 
     # clips: weak = CL per rank (every rank holds all of them: M*180*1024 f32 = 4.4 MB each); strong = ONE clip in all
     n_clips = CL if strong else CL * world

@@ -265,8 +265,11 @@ class CodeKNN:
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
         # Row-sharded DB: the shards sweep in mixed precision too and the cross-shard merge re-evaluates what their
         # bounded tables leave open through a request / response exchange (sweep_tables; qpg_merge_mixed_*).
+        # Two more (small) exchanges buy a sweep at ~1.6x the rate, so it is used where the shard's sweep is long enough
+        # to pay for them: at least sharded_mixed_min_gflop per rank and step (24 s clip x 2048 windows = 31 GFLOP).
         self.sharded_mixed = True
-        self.mixed_requests = 8192          # request slots per (owner, shard) pair and step
+        self.sharded_mixed_min_gflop = 20.0
+        self.mixed_requests = None          # request slots per (owner, shard) pair and step; None: 16384 / world
         # host_ranks (the CLI's --tie_rule numpy): rank the (Q,512) audio / text minima with the reference's own
         # `np.array(x).argsort().argsort()` on the host, so that EXACT ties between codes (structural in real text
         # embeddings: silent frames share one vector) get NumPy's unstable-sort order like the reference's.
@@ -320,8 +323,9 @@ class CodeKNN:
         half = db.feature_dtype == "f16"
         local_final = fused_rank and reduce and out is None               # one GPU: this select decides everything
         shard_part = db.world > 1 and not reduce and out is not None        # row shard: sweep_tables merges (mixed protocol)
-        mixed = (self.audio_precision == "mixed" and (local_final or (shard_part and self.sharded_mixed))
-                 and self.tie_eps > 0 and C > 0 and db.K <= 512)
+        gflop = 2e-9 * Q * C * NUM_AUDIO_FEAT_FRAMES * db.F
+        mixed = (self.audio_precision == "mixed" and self.tie_eps > 0 and C > 0 and db.K <= 512 and
+                 (local_final or (shard_part and self.sharded_mixed and gflop >= self.sharded_mixed_min_gflop)))
         self._last_audio_mixed = mixed
         # the mixed-precision sweep stores its matrix in f32: it only feeds the select's two streaming passes
         D = torch.empty((Q, max(C, 1)), dtype=torch.float32 if mixed else torch.float64, device=dev)
@@ -656,7 +660,8 @@ class CodeKNN:
         """Cross-shard merge of mixed-precision audio tables: approximate merge + requests (owner), one
         all-to-all, exact re-evaluation of the requested pairs (shards), one all-to-all back, final merge + ranks."""
         db, dev = self.db, self.db.device
-        W, R, Qb, K = db.world, int(self.mixed_requests), lay.Qb, db.K
+        W, Qb, K = db.world, lay.Qb, db.K
+        R = int(self.mixed_requests) if self.mixed_requests else max(1024, 16384 // W)
         req_stride, resp_stride = 8 + 8 * R, 8 * R
         bufs = self.__dict__.get("_mm_bufs")
         need_ws = int(_lib.load().qpg_merge_mixed_ws_bytes(Qb, K))

@@ -29,7 +29,7 @@ def test_bench_sharded_matches_unsharded(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--n-db", "200", "--windows", "2", "--check",
-           "--no-cpu-baseline", "--no-vqvae"]
+           "--no-cpu-baseline", "--no-vqvae", "--sharded-mixed-min-gflop", "0"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -49,11 +49,26 @@ def test_bench_strong_and_multiclip(extra, scaling, clips):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "2", "--check", "--no-cpu-baseline",
-           "--no-vqvae"] + extra
+           "--no-vqvae", "--sharded-mixed-min-gflop", "0"] + extra
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["check"] is True and out["scaling"] == scaling and out["config"]["clips"] == clips
+    assert out["roofline"]["precision"] == "mixed" and out["mixed_precision"]["flags"] == 0
+
+
+def test_bench_sharded_small_shards_keep_the_f64_sweep():
+    """Below CodeKNN.sharded_mixed_min_gflop per rank the two extra exchanges would cost more than the faster sweep saves:
+    the shards run the f64 sweep and the one-exchange merge (default threshold, tiny DB)."""
+    env = dict(os.environ, QPG_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-db", "200", "--windows", "2", "--check", "--no-cpu-baseline",
+           "--no-vqvae"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["check"] is True and out["roofline"]["precision"] == "f64" and "mixed_precision" not in out
 
 
 def test_merge_kernel_vs_reference():

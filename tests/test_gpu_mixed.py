@@ -187,6 +187,7 @@ def test_sharded_mixed_merge_protocol_on_one_gpu():
     for r in range(W):
         db = GestureDB(code, x, A["tr_ctx"], A["tr_phase"], A["sig"], device=dev, rank=r, world=W)
         knn = CodeKNN(db, rng=np.random.RandomState(1))
+        knn.sharded_mixed_min_gflop = 0.0                        # (these shards are far below the default work threshold)
         lay = ExchangeLayout(Q, K, 1, ["aud"], True, dev)
         knn.sweep_audio(te_i, q_win, q_t, reduce=False, out=lay.views("aud"))
         assert knn._last_audio_mixed

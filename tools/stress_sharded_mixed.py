@@ -39,6 +39,7 @@ for t in range(trials):
     for r in range(W):
         db = GestureDB(code, x, ctx, tr["phase_dense"], sig, device=dev, rank=r, world=W, feature_dtype=fd)
         knn = CodeKNN(db, rng=np.random.RandomState(1))
+        knn.sharded_mixed_min_gflop = 0.0                        # (these shards are far below the default work threshold)
         lay = ExchangeLayout(Q, K, 1, ["aud"], True, dev)
         knn.sweep_audio(ti, q_win, q_t, reduce=False, out=lay.views("aud"))
         shards.append(knn); lays.append(lay)
