@@ -134,7 +134,7 @@ def main():
         knn.sharded_mixed_min_gflop = a.sharded_mixed_min_gflop
     # the mixed-precision sweep: one GPU, or row shards whose merge re-evaluates through a request / response exchange
     # (taken when the shard's sweep is long enough to pay for the two extra exchanges: CodeKNN.sharded_mixed_min_gflop)
-    shard_gflop = 2e-9 * (M * 8 * (CL if strong else CL * world)) * ((hi - lo) * 26) * 6 * 1024
+    shard_gflop = 2e-9 * (M * 8 * (CL if strong else CL * world)) * (per * 26) * 6 * 1024
     mixed = a.audio_precision == "mixed" and (world == 1 or shard_gflop >= knn.sharded_mixed_min_gflop)
 
     # clips: weak = CL per rank (every rank holds all of them: M*180*1024 f32 = 4.4 MB each); strong = ONE clip in all

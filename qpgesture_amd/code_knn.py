@@ -323,7 +323,9 @@ class CodeKNN:
         half = db.feature_dtype == "f16"
         local_final = fused_rank and reduce and out is None               # one GPU: this select decides everything
         shard_part = db.world > 1 and not reduce and out is not None        # row shard: sweep_tables merges (mixed protocol)
-        gflop = 2e-9 * Q * C * NUM_AUDIO_FEAT_FRAMES * db.F
+        # (the same number on every rank — the largest shard's — so that all ranks take the same path: the mixed merge
+        # has two more collectives than the f64 one)
+        gflop = 2e-9 * Q * (-(-db.N // db.world) * db.Ga) * NUM_AUDIO_FEAT_FRAMES * db.F
         mixed = (self.audio_precision == "mixed" and self.tie_eps > 0 and C > 0 and db.K <= 512 and
                  (local_final or (shard_part and self.sharded_mixed and gflop >= self.sharded_mixed_min_gflop)))
         self._last_audio_mixed = mixed
