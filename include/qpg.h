@@ -101,13 +101,12 @@ int qpg_audio_cosine_f64_h(qpg_ctx*, void* stream, const void* base_f16, int N, 
                            const int32_t* cand_t, int G, int n_taps, int tap_stride, const double* cn2,
                            const float* q32, const double* qn2, int Q, double* D, int64_t ldD);
 
-/* MIXED-PRECISION form of qpg_audio_cosine_f64 (round 2; the default single-GPU path of CodeKNN.sweep_audio): the same
- * sweep on the f32 matrix cores, with every f32 accumulation chain limited to 32 products and summed in f64, which
- * bounds the result's error A PRIORI: |D[q][c] - exact| <= QPG_AUDIO_MX_ERR for every pair (gamma_32 = 1.91e-6 for the f32 chains + 1.2e-7 for an f32-stored
- * matrix + f64 noise), whatever the data
- * (derivation: qpgesture_amd/csrc/qpg_audio.hip).  Meant to be consumed by qpg_percode_select_mixed_f64, which
- * re-evaluates every comparison the bound leaves undecided, so the selected candidates and ranks are those of the
- * f64 path.  stats: [dev] i32 [4] (may be NULL): [1] |= 2 if a pair with 0 < |q||c| < 1e-16 was met (operand products
+/* MIXED-PRECISION form of qpg_audio_cosine_f64 (round 2; the default path of CodeKNN.sweep_audio): the same sweep on
+ * the f32 matrix cores, with every f32 accumulation chain limited to 32 products and summed in f64, which bounds the
+ * result's error A PRIORI: |D[q][c] - exact| <= QPG_AUDIO_MX_ERR for every pair, whatever the data (gamma_32 = 1.91e-6
+ * for the f32 chains + 1.2e-7 for an f32-stored matrix + f64 noise; derivation: qpgesture_amd/csrc/qpg_audio.hip).
+ * Meant to be consumed by qpg_percode_select_mixed_f64 (and, across row shards, qpg_merge_mixed_*), which re-evaluate
+ * every comparison the bound leaves undecided, so the selected candidates and ranks are those of the f64 path.  stats: [dev] i32 [4] (may be NULL): [1] |= 2 if a pair with 0 < |q||c| < 1e-16 was met (operand products
  * could underflow f32, which the bound excludes). */
 #define QPG_AUDIO_MX_ERR 2.05e-6
 int qpg_audio_cosine_mx(qpg_ctx*, void* stream, const float* base, int N, int T, int F, const int32_t* cand_t, int G,
@@ -219,7 +218,7 @@ int qpg_percode_select_f32(qpg_ctx*, void* stream, const float* D, int64_t ldD, 
  * (reference distance, index); minima of different codes within `eps` of each other are replaced by the
  * reference-arithmetic value of their winner before ranking.  All inside the launch; nothing is flagged on ordinary data.
  * base [dev] f32 [N][T][F], cand_t [dev] i32 [G], q32 [dev] f32 [Q][n_taps*F]: the sweep's own operands (C == N*G);
- * stats [dev] i32 [2]: [0] += re-evaluated (query, candidate) pairs, [1] = 1 if more than 256 were flagged in one row
+ * stats [dev] i32 [4]: [0] += re-evaluated (query, candidate) pairs, [1] |= 1 if more than 256 were flagged in one row
  * (the surplus keeps its sweep value). */
 int qpg_percode_select_guarded_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int16_t* cand_code,
                                    int64_t C, int K, double absent, int32_t idx_base, double* out_dist, int32_t* out_idx,
