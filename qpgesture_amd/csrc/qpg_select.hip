@@ -1240,8 +1240,46 @@ extern "C" int qpg_percode_select_f32(qpg_ctx* ctx, void* stream, const float* D
 // index (shards are ascending row blocks, so that is the reference's first-wins scan); -1 marks "code absent in
 // that shard".  One block per query row; the stable ranks of the merged row are produced in the same launch.
 // ---------------------------------------------------------------------------------------------
+// Stable rank of every entry of the LDS row v[K] (value, then index): r[k] = #{o : v[o] < v[k] or (v[o] == v[k] and
+// o < k)}.  The K x K count is VALU-bound (~35 cycles per comparison step per wave), so P = blockDim / K threads share
+// an entry and add their partial counts in LDS (`cnt`, [K] ints).  Calls __syncthreads(); all threads must call.
+template <typename T, typename F>
+__device__ __forceinline__ void block_stable_ranks(const T* v, int K, int* cnt, F&& emit) {
+  const int tid = threadIdx.x;
+  const int P = (int)blockDim.x >= 2 * K ? (int)blockDim.x / K : 1;
+  if (P == 1) {
+    for (int k = tid; k < K; k += blockDim.x) {
+      const T x = v[k];
+      int r = 0;
+#pragma unroll 8
+      for (int o = 0; o < K; ++o) {
+        const T y = v[o];
+        r += (y < x) || (y == x && o < k);
+      }
+      emit(k, r);
+    }
+    return;
+  }
+  for (int k = tid; k < K; k += blockDim.x) cnt[k] = 0;
+  __syncthreads();
+  if (tid < P * K) {
+    const int k = tid % K, part = tid / K;
+    const int o0 = (int)((int64_t)part * K / P), o1 = (int)((int64_t)(part + 1) * K / P);
+    const T x = v[k];
+    int r = 0;
+#pragma unroll 8
+    for (int o = o0; o < o1; ++o) {
+      const T y = v[o];
+      r += (y < x) || (y == x && o < k);
+    }
+    atomicAdd(&cnt[k], r);
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += blockDim.x) emit(k, cnt[k]);
+}
+
 template <typename T>
-__global__ __launch_bounds__(512) void merge_select_kernel(const unsigned char* __restrict__ recv, int W,
+__global__ __launch_bounds__(1024) void merge_select_kernel(const unsigned char* __restrict__ recv, int W,
                                                            int64_t src_stride, int64_t dist_off, int64_t idx_off, int K,
                                                            T absent, T* __restrict__ out_dist,
                                                            int32_t* __restrict__ out_idx,
@@ -1268,15 +1306,8 @@ __global__ __launch_bounds__(512) void merge_select_kernel(const unsigned char* 
   }
   if (!out_rank) return;
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const T x = v[k];
-    int r = 0;
-    for (int o = 0; o < K; ++o) {
-      const T y = v[o];
-      r += (y < x) || (y == x && o < k);
-    }
-    out_rank[(int64_t)q * K + k] = (int16_t)r;
-  }
+  int* cnt = reinterpret_cast<int*>(v + K);
+  block_stable_ranks(v, K, cnt, [&](int k, int r) { out_rank[(int64_t)q * K + k] = (int16_t)r; });
 }
 
 template <typename T>
@@ -1288,7 +1319,7 @@ static int merge_select(const char* name, qpg_ctx* ctx, void* stream, const void
                   dist_off % (int64_t)sizeof(T) == 0 && idx_off % 4 == 0 && src_stride % 8 == 0,
               "%s: bad size / alignment", name);
   if (Q == 0) return QPG_OK;
-  hipLaunchKernelGGL((merge_select_kernel<T>), dim3(Q), dim3(512), sizeof(T) * (size_t)K, qpg_stream(stream),
+  hipLaunchKernelGGL((merge_select_kernel<T>), dim3(Q), dim3(1024), (sizeof(T) + 4) * (size_t)K, qpg_stream(stream),
                      static_cast<const unsigned char*>(recv), W, src_stride, dist_off, idx_off, K, absent, out_dist,
                      out_idx, out_rank);
   QPG_LAUNCH_CHECK(name);
@@ -1327,7 +1358,7 @@ __global__ void merge_mixed_zero_counts_kernel(unsigned char* __restrict__ req, 
   for (int w = threadIdx.x; w < W; w += blockDim.x) *reinterpret_cast<long long*>(req + (int64_t)w * req_stride) = 0;
 }
 
-__global__ __launch_bounds__(512) void merge_mixed_phase1_kernel(
+__global__ __launch_bounds__(1024) void merge_mixed_phase1_kernel(
     const unsigned char* __restrict__ recv, int W, int64_t src_stride, int64_t dist_off, int64_t idx_off, int K,
     double absent, double eps1, int R, unsigned char* __restrict__ req, int64_t req_stride,
     double* __restrict__ prov_d, int32_t* __restrict__ prov_i, unsigned long long* __restrict__ fl,
@@ -1339,6 +1370,7 @@ __global__ __launch_bounds__(512) void merge_mixed_phase1_kernel(
   int* cnt = bs + K;                                             // [K] shards within eps1 of the merged minimum
   int* s_code = cnt + K;                                         // [K] code at rank r
   int* flg = s_code + K;                                         // [K] rank-level flag
+  int* rkc = flg + K;                                            // [K] rank counters
   __shared__ int n_fl;
   const int q = blockIdx.x;
   if (threadIdx.x == 0) n_fl = 0;
@@ -1369,16 +1401,7 @@ __global__ __launch_bounds__(512) void merge_mixed_phase1_kernel(
     prov_i[(int64_t)q * K + k] = b;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const double x = v[k];
-    int r = 0;
-#pragma unroll 8
-    for (int o = 0; o < K; ++o) {
-      const double y = v[o];
-      r += (y < x) || (y == x && o < k);
-    }
-    s_code[r] = k;
-  }
+  block_stable_ranks(v, K, rkc, [&](int k, int r) { s_code[r] = k; });
   __syncthreads();
   for (int r = threadIdx.x; r + 1 < K; r += blockDim.x) {
     const int ka = s_code[r], kb = s_code[r + 1];
@@ -1438,7 +1461,7 @@ __global__ __launch_bounds__(256) void shard_refine_kernel(GuardArgs A, const un
   }
 }
 
-__global__ __launch_bounds__(512) void merge_mixed_phase2_kernel(
+__global__ __launch_bounds__(1024) void merge_mixed_phase2_kernel(
     const unsigned char* __restrict__ recv, int W, int64_t src_stride, int64_t idx_off, int K, double absent,
     const double* __restrict__ prov_d, const int32_t* __restrict__ prov_i, const unsigned long long* __restrict__ fl,
     const int32_t* __restrict__ fl_cnt, const unsigned char* __restrict__ resp_recv, int64_t resp_stride,
@@ -1493,16 +1516,7 @@ __global__ __launch_bounds__(512) void merge_mixed_phase2_kernel(
   if (threadIdx.x == 0 && n > 0) atomicAdd(&stats[3], n);
   if (!out_rank) return;
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const double x = v[k];
-    int r = 0;
-#pragma unroll 8
-    for (int o = 0; o < K; ++o) {
-      const double y = v[o];
-      r += (y < x) || (y == x && o < k);
-    }
-    out_rank[(int64_t)q * K + k] = (int16_t)r;
-  }
+  block_stable_ranks(v, K, touched, [&](int k, int r) { out_rank[(int64_t)q * K + k] = (int16_t)r; });
 }
 
 extern "C" int64_t qpg_merge_mixed_ws_bytes(int Q, int K) {          // prov_d | prov_i | fl | fl_cnt
@@ -1529,7 +1543,7 @@ extern "C" int qpg_merge_mixed_phase1_f64(qpg_ctx* ctx, void* stream, const void
   hipLaunchKernelGGL(merge_mixed_zero_counts_kernel, dim3(1), dim3(256), 0, qpg_stream(stream),
                      static_cast<unsigned char*>(req), req_stride, W);
   QPG_LAUNCH_CHECK("merge_mixed_zero_counts_kernel");
-  hipLaunchKernelGGL(merge_mixed_phase1_kernel, dim3(Q), dim3(512), (size_t)K * 28, qpg_stream(stream),
+  hipLaunchKernelGGL(merge_mixed_phase1_kernel, dim3(Q), dim3(1024), (size_t)K * 32, qpg_stream(stream),
                      static_cast<const unsigned char*>(recv), W, src_stride, dist_off, idx_off, K, absent, eps1, R,
                      static_cast<unsigned char*>(req), req_stride, prov_d, prov_i, fl, fl_cnt, stats);
   QPG_LAUNCH_CHECK("merge_mixed_phase1_kernel");
@@ -1570,7 +1584,7 @@ extern "C" int qpg_merge_mixed_phase2_f64(qpg_ctx* ctx, void* stream, const void
   const int32_t* prov_i = reinterpret_cast<const int32_t*>(w + (size_t)Q * K * 8);
   const unsigned long long* fl = reinterpret_cast<const unsigned long long*>(w + (((size_t)Q * K * 12 + 7) / 8) * 8);
   const int32_t* fl_cnt = reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(fl) + (size_t)Q * MM_FL * 8);
-  hipLaunchKernelGGL(merge_mixed_phase2_kernel, dim3(Q), dim3(512), (size_t)K * 24, qpg_stream(stream),
+  hipLaunchKernelGGL(merge_mixed_phase2_kernel, dim3(Q), dim3(1024), (size_t)K * 24, qpg_stream(stream),
                      static_cast<const unsigned char*>(recv), W, src_stride, idx_off, K, absent, prov_d, prov_i, fl, fl_cnt,
                      static_cast<const unsigned char*>(resp_recv), resp_stride, out_dist, out_idx, out_rank, stats);
   QPG_LAUNCH_CHECK("merge_mixed_phase2_kernel");
