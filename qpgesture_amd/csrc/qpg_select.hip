@@ -430,6 +430,44 @@ __global__ __launch_bounds__(1024) void percode_select_kernel(const T* __restric
 // Nothing is flagged on ordinary data and the extra cost is one compare per candidate; flagged work happens inside
 // the same launch (no host round trip).  stats[0] += re-evaluated pairs, stats[1] = 1 if a list overflowed.
 // ---------------------------------------------------------------------------------------------
+// Stable rank of every entry of the LDS row v[K] (value, then index): r[k] = #{o : v[o] < v[k] or (v[o] == v[k] and
+// o < k)}.  The K x K count is VALU-bound (~35 cycles per comparison step per wave), so P = blockDim / K threads share
+// an entry and add their partial counts in LDS (`cnt`, [K] ints).  Calls __syncthreads(); all threads must call.
+template <typename T, typename F>
+__device__ __forceinline__ void block_stable_ranks(const T* v, int K, int* cnt, F&& emit) {
+  const int tid = threadIdx.x;
+  const int P = (int)blockDim.x >= 2 * K ? (int)blockDim.x / K : 1;
+  if (P == 1) {
+    for (int k = tid; k < K; k += blockDim.x) {
+      const T x = v[k];
+      int r = 0;
+#pragma unroll 8
+      for (int o = 0; o < K; ++o) {
+        const T y = v[o];
+        r += (y < x) || (y == x && o < k);
+      }
+      emit(k, r);
+    }
+    return;
+  }
+  for (int k = tid; k < K; k += blockDim.x) cnt[k] = 0;
+  __syncthreads();
+  if (tid < P * K) {
+    const int k = tid % K, part = tid / K;
+    const int o0 = (int)((int64_t)part * K / P), o1 = (int)((int64_t)(part + 1) * K / P);
+    const T x = v[k];
+    int r = 0;
+#pragma unroll 8
+    for (int o = o0; o < o1; ++o) {
+      const T y = v[o];
+      r += (y < x) || (y == x && o < k);
+    }
+    atomicAdd(&cnt[k], r);
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += blockDim.x) emit(k, cnt[k]);
+}
+
 struct GuardArgs {
   const float* base;      // [N][T][F] interpolated WavLM frames of this shard (f32; IEEE f16 when `half`)
   int half;               // base is stored in f16: values are widened, i.e. the re-evaluation sees the rounded track
@@ -612,18 +650,12 @@ __global__ __launch_bounds__(1024) void percode_select_guarded_f64_kernel(
   }
   if (!out_rank) return;
   int* s_code = reinterpret_cast<int*>(best);                 // the key table is no longer needed: [K] code at rank r
+  int* rcnt = s_code + K;                                     // second half of the key table: rank counters
   auto rank_pass = [&]() {
-    for (int k = tid; k < K; k += blockDim.x) {
-      const double x = v[k];
-      int r = 0;
-#pragma unroll 8
-      for (int o = 0; o < K; ++o) {
-        const double y = v[o];
-        r += (y < x) || (y == x && o < k);
-      }
+    block_stable_ranks(v, K, rcnt, [&](int k, int r) {
       out_rank[(int64_t)q * K + k] = (int16_t)r;
       s_code[r] = k;
-    }
+    });
   };
   rank_pass();
   __syncthreads();
@@ -1240,44 +1272,6 @@ extern "C" int qpg_percode_select_f32(qpg_ctx* ctx, void* stream, const float* D
 // index (shards are ascending row blocks, so that is the reference's first-wins scan); -1 marks "code absent in
 // that shard".  One block per query row; the stable ranks of the merged row are produced in the same launch.
 // ---------------------------------------------------------------------------------------------
-// Stable rank of every entry of the LDS row v[K] (value, then index): r[k] = #{o : v[o] < v[k] or (v[o] == v[k] and
-// o < k)}.  The K x K count is VALU-bound (~35 cycles per comparison step per wave), so P = blockDim / K threads share
-// an entry and add their partial counts in LDS (`cnt`, [K] ints).  Calls __syncthreads(); all threads must call.
-template <typename T, typename F>
-__device__ __forceinline__ void block_stable_ranks(const T* v, int K, int* cnt, F&& emit) {
-  const int tid = threadIdx.x;
-  const int P = (int)blockDim.x >= 2 * K ? (int)blockDim.x / K : 1;
-  if (P == 1) {
-    for (int k = tid; k < K; k += blockDim.x) {
-      const T x = v[k];
-      int r = 0;
-#pragma unroll 8
-      for (int o = 0; o < K; ++o) {
-        const T y = v[o];
-        r += (y < x) || (y == x && o < k);
-      }
-      emit(k, r);
-    }
-    return;
-  }
-  for (int k = tid; k < K; k += blockDim.x) cnt[k] = 0;
-  __syncthreads();
-  if (tid < P * K) {
-    const int k = tid % K, part = tid / K;
-    const int o0 = (int)((int64_t)part * K / P), o1 = (int)((int64_t)(part + 1) * K / P);
-    const T x = v[k];
-    int r = 0;
-#pragma unroll 8
-    for (int o = o0; o < o1; ++o) {
-      const T y = v[o];
-      r += (y < x) || (y == x && o < k);
-    }
-    atomicAdd(&cnt[k], r);
-  }
-  __syncthreads();
-  for (int k = tid; k < K; k += blockDim.x) emit(k, cnt[k]);
-}
-
 template <typename T>
 __global__ __launch_bounds__(1024) void merge_select_kernel(const unsigned char* __restrict__ recv, int W,
                                                            int64_t src_stride, int64_t dist_off, int64_t idx_off, int K,
