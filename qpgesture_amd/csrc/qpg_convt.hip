@@ -433,15 +433,18 @@ __global__ __launch_bounds__(256, 2) void convt_f32_kernel(ConvTArgs a) {
 // one 16-channel tile (bias, ReLU, residual, 16-byte stores).
 // ---------------------------------------------------------------------------------------------------------------
 #define CTS_NW 8     // waves per block = ways the contraction is split
-template <bool RELU_IN, int PD>
+// NQ = 16-channel tiles per block (4: 64 channels; 2: 32 channels — twice the blocks, each pulling half the weights,
+// for launches that would otherwise leave most CUs idle)
+template <bool RELU_IN, int PD, int NQ>
 __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs a) {
-  __shared__ __attribute__((aligned(16))) float part[CTS_NW][4][64][4];     // [wave][tile][lane][r]
+  __shared__ __attribute__((aligned(16))) float part[CTS_NW][NQ][64][4];    // [wave][tile][lane][r]
   const int tid = threadIdx.x, lane = tid & 63, ml = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t M = (int64_t)a.B * a.T_out;
   const int64_t m = (int64_t)blockIdx.x * 16 + ml;
-  const int nb = blockIdx.y >> 1, half = blockIdx.y & 1;             // 128-channel T-pack block, 64-channel half
-  if (nb * 128 + half * 64 >= a.Cout) return;                          // padding-only chunk (135-channel output layer)
+  constexpr int NGRP = 8 / NQ;                                         // channel groups per 128-channel T-pack block
+  const int nb = blockIdx.y / NGRP, cg0 = (blockIdx.y % NGRP) * (16 * NQ);
+  if (nb * 128 + cg0 >= a.Cout) return;                                // padding-only chunk (135-channel output layer)
   const bool live = m < M;
   const int b = live ? (int)(m / a.T_out) : 0;
   const int t = live ? (int)(m - (int64_t)b * a.T_out) : 0;
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
   const int per = (nkb + CTS_NW - 1) / CTS_NW;
   const int kb0 = w * per, kb1 = kb0 + per < nkb ? kb0 + per : nkb;
   const int kpt = a.Cin_pad / 16;                                      // 16-k blocks per tap
-  const float* wbase = a.wt + ((int64_t)nb * nkb * 4 + g) * 512 + (half * 64 + ml) * 4;   // + kb*2048 + tile*64
+  const float* wbase = a.wt + ((int64_t)nb * nkb * 4 + g) * 512 + (cg0 + ml) * 4;         // + kb*2048 + tile*64
   auto bfrag = [&](int kb) -> f32x4 {
     const int tap = kb / kpt, ci0 = (kb - tap * kpt) * 16;
     const int t_in = t * a.in_stride + a.in_offset + tap * a.dil;
@@ -459,19 +462,19 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
     return RELU_IN ? relu4(v) : v;
   };
   struct Frag {
-    f32x4 a[4], b;
+    f32x4 a[NQ], b;
   };
   auto load = [&](int kb) -> Frag {
     Frag f;
     const float* wp = wbase + (int64_t)(kb < kb1 ? kb : 0) * 2048;       // past the range: a valid address, zero B
 #pragma unroll
-    for (int q = 0; q < 4; ++q) f.a[q] = *reinterpret_cast<const f32x4*>(wp + q * 64);
+    for (int q = 0; q < NQ; ++q) f.a[q] = *reinterpret_cast<const f32x4*>(wp + q * 64);
     f.b = bfrag(kb);
     return f;
   };
-  f32x4 acc[4];
+  f32x4 acc[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < NQ; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // A block is bound by how fast ONE CU pulls its 64-channel weight slice (393 KB for a k3 layer) out of L2, not by its
   // 2.6 us of MFMAs.  PD = 16-k blocks (5 KB per wave each) in flight; when the wave's share is a whole number of
   // PD-chunks the loop is peeled so that no chunk prefetches past the end (branch-free inside: a conditional load
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = mfma16(f[d].a[q][j], f[d].b[j], acc[q]);
+          for (int q = 0; q < NQ; ++q) acc[q] = mfma16(f[d].a[q][j], f[d].b[j], acc[q]);
         f[d] = load(kb + d + P);
       }
     }
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = mfma16(f[d].a[q][j], f[d].b[j], acc[q]);
+        for (int q = 0; q < NQ; ++q) acc[q] = mfma16(f[d].a[q][j], f[d].b[j], acc[q]);
   } else {
     Frag f0 = load(kb0), f1 = load(kb0 + 1), f2 = load(kb0 + 2);
     for (int kb = kb0; kb < kb1; ++kb) {
@@ -504,17 +507,17 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = mfma16(f0.a[q][j], f0.b[j], acc[q]);
+        for (int q = 0; q < NQ; ++q) acc[q] = mfma16(f0.a[q][j], f0.b[j], acc[q]);
       f0 = f1;
       f1 = f2;
       f2 = f3;
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&part[w][q][lane][0]) = acc[q];
+  for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(&part[w][q][lane][0]) = acc[q];
   __syncthreads();
-  // waves 0..3 finish tile w: channel n = nb*128 + half*64 + 16 w + 4 g + r, position m (partials added in wave order)
-  if (w >= 4) return;
+  // waves 0..NQ-1 finish tile w: channel n = nb*128 + cg0 + 16 w + 4 g + r, position m (partials added in wave order)
+  if (w >= NQ) return;
   f32x4 o = *reinterpret_cast<const f32x4*>(&part[0][w][lane][0]);
 #pragma unroll
   for (int s2 = 1; s2 < CTS_NW; ++s2) {
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
     for (int r = 0; r < 4; ++r) o[r] += p2[r];
   }
   if (!live) return;
-  const int n = nb * 128 + half * 64 + 16 * w + 4 * g;
+  const int n = nb * 128 + cg0 + 16 * w + 4 * g;
   if (n >= a.Cout) return;
   const int64_t orow = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout;
   if (a.bias) {
@@ -579,15 +582,32 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
   const int64_t M = (int64_t)B * T_out;
   // short sequences: 16-position x 64-channel blocks whose waves split the contraction (see convt_small_f32_kernel)
   if (((M + CT_ROWS - 1) / CT_ROWS) * (Cout_pad / 128) * 2 < 3 * (int64_t)ctx->n_cu) {
-    const dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / 64));
+    // Channels per block: 64, 32 or 16 (NQ = 4, 2, 1 tiles).  A block's time is the time ONE CU needs to pull its
+    // operands (NQ weight tiles + 1 activation tile of 16 x K floats, at ~35 GB/s whatever is in flight), a launch
+    // takes max(1, blocks / CUs) of those: pick the NQ with the smallest product (measured: decode of a 24 s clip
+    // 0.387 -> 0.35 ms, one window's encode 0.243 -> 0.169 ms).
+    int nq = 4;
+    double best_cost = 0.0;
+    for (int cand = 4; cand >= 1; cand >>= 1) {
+      const double blocks = (double)((M + 15) / 16) * (Cout_pad / (16 * cand));
+      const double rounds = blocks / ctx->n_cu > 1.0 ? blocks / ctx->n_cu : 1.0;
+      const double cost = rounds * (cand + 1);
+      if (cand == 4 || cost < best_cost * 0.97) {
+        best_cost = cost;
+        nq = cand;
+      }
+    }
+    const dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / (16 * nq)));
     const int per = (a.nstage * 4 + CTS_NW - 1) / CTS_NW;          // 16-k blocks per wave
     const int pd = (a.nstage * 4) % CTS_NW ? 0 : (per % 6 == 0 ? 6 : (per % 4 == 0 ? 4 : 0));
-#define CTS_LAUNCH(R, P) hipLaunchKernelGGL((convt_small_f32_kernel<R, P>), sgrid, dim3(64 * CTS_NW), 0, qpg_stream(stream), a)
+#define CTS_LAUNCH(R, P, Q_) hipLaunchKernelGGL((convt_small_f32_kernel<R, P, Q_>), sgrid, dim3(64 * CTS_NW), 0, qpg_stream(stream), a)
+#define CTS_LAUNCH_P(R, Q_) do { if (pd == 6) CTS_LAUNCH(R, 6, Q_); else if (pd == 4) CTS_LAUNCH(R, 4, Q_); else CTS_LAUNCH(R, 0, Q_); } while (0)
     if (relu_in) {
-      if (pd == 6) CTS_LAUNCH(true, 6); else if (pd == 4) CTS_LAUNCH(true, 4); else CTS_LAUNCH(true, 0);
+      if (nq == 1) CTS_LAUNCH_P(true, 1); else if (nq == 2) CTS_LAUNCH_P(true, 2); else CTS_LAUNCH_P(true, 4);
     } else {
-      if (pd == 6) CTS_LAUNCH(false, 6); else if (pd == 4) CTS_LAUNCH(false, 4); else CTS_LAUNCH(false, 0);
+      if (nq == 1) CTS_LAUNCH_P(false, 1); else if (nq == 2) CTS_LAUNCH_P(false, 2); else CTS_LAUNCH_P(false, 4);
     }
+#undef CTS_LAUNCH_P
 #undef CTS_LAUNCH
     QPG_LAUNCH_CHECK("convt_small_f32_kernel");
     return QPG_OK;
