@@ -19,6 +19,8 @@
 // [n = nb*NB + nl]  with k = tap*Cin_pad + ci:  a lane's ds_read_b128 yields its channel's four consecutive k,
 // 16 lanes of a group read 16 distinct 16-B bank slots (conflict-free), and a stage is one contiguous 32 KB run.
 #include "qpg_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -583,25 +585,32 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
   // short sequences: 16-position x 64-channel blocks whose waves split the contraction (see convt_small_f32_kernel)
   if (((M + CT_ROWS - 1) / CT_ROWS) * (Cout_pad / 128) * 2 < 3 * (int64_t)ctx->n_cu) {
     // Channels per block: 64, 32 or 16 (NQ = 4, 2, 1 tiles).  A block's time is the time ONE CU needs to pull its
-    // operands (NQ weight tiles + 1 activation tile of 16 x K floats, at ~35 GB/s whatever is in flight), a launch
-    // takes max(1, blocks / CUs) of those: pick the NQ with the smallest product (measured: decode of a 24 s clip
-    // 0.387 -> 0.35 ms, one window's encode 0.243 -> 0.169 ms).
+    // operands (NQ weight tiles + 1 activation tile of 16 x K floats; two blocks on one CU take twice as long, so a
+    // launch takes ceil(blocks / CUs) block times): pick the NQ with the smallest product.  tools/bench_convt_small.py
+    // measures every shape on the decoder's layers (experiments/convt_small/README.md).
     int nq = 4;
-    double best_cost = 0.0;
+    int64_t best_cost = 0;
     for (int cand = 4; cand >= 1; cand >>= 1) {
-      const double blocks = (double)((M + 15) / 16) * (Cout_pad / (16 * cand));
-      const double rounds = blocks / ctx->n_cu > 1.0 ? blocks / ctx->n_cu : 1.0;
-      const double cost = rounds * (cand + 1);
-      if (cand == 4 || cost < best_cost * 0.97) {
+      const int64_t blocks = ((M + 15) / 16) * (Cout_pad / (16 * cand));
+      const int64_t cost = ((blocks + ctx->n_cu - 1) / ctx->n_cu) * (cand + 1);
+      if (cand == 4 || cost < best_cost) {
         best_cost = cost;
         nq = cand;
       }
     }
-    const dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / (16 * nq)));
     const int per = (a.nstage * 4 + CTS_NW - 1) / CTS_NW;          // 16-k blocks per wave
-    const int pd = (a.nstage * 4) % CTS_NW ? 0 : (per % 6 == 0 ? 6 : (per % 4 == 0 ? 4 : 0));
+    int pd = (a.nstage * 4) % CTS_NW == 0 && per % 4 == 0 ? 4 : 0;   // ring of 4 (a ring of 6 measured ~6% slower)
+    if (const char* e = getenv("QPG_CTS_SHAPE")) {                  // experiments only: "nq,pd"
+      int enq = 0, epd = -1;
+      if (sscanf(e, "%d,%d", &enq, &epd) == 2 && (enq == 1 || enq == 2 || enq == 4) &&
+          (epd == 0 || (epd == 4 && (a.nstage * 4) % CTS_NW == 0 && per % 4 == 0))) {
+        nq = enq;
+        pd = epd;
+      }
+    }
+    const dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / (16 * nq)));
 #define CTS_LAUNCH(R, P, Q_) hipLaunchKernelGGL((convt_small_f32_kernel<R, P, Q_>), sgrid, dim3(64 * CTS_NW), 0, qpg_stream(stream), a)
-#define CTS_LAUNCH_P(R, Q_) do { if (pd == 6) CTS_LAUNCH(R, 6, Q_); else if (pd == 4) CTS_LAUNCH(R, 4, Q_); else CTS_LAUNCH(R, 0, Q_); } while (0)
+#define CTS_LAUNCH_P(R, Q_) do { if (pd == 4) CTS_LAUNCH(R, 4, Q_); else CTS_LAUNCH(R, 0, Q_); } while (0)
     if (relu_in) {
       if (nq == 1) CTS_LAUNCH_P(true, 1); else if (nq == 2) CTS_LAUNCH_P(true, 2); else CTS_LAUNCH_P(true, 4);
     } else {
