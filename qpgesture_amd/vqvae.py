@@ -310,7 +310,7 @@ class VQVAE:
         """VQVAE.encode (vqvae.py:174-181): returns [LongTensor (B, T/8)]."""
         x = torch.as_tensor(x)
         outs = [self.encode_fused(xc) for xc in torch.chunk(x, bs_chunks, dim=0)]
-        return [torch.cat(outs, dim=0)]
+        return [outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)]
 
     def decode_layers(self, ids):
         """Layer-by-layer decode through the per-layer entry points (qpg_vq_gather_f32 + qpg_conv1d_f32);
@@ -340,15 +340,18 @@ class VQVAE:
         for ids in torch.chunk(torch.as_tensor(zs[0]), bs_chunks, dim=0):
             ids = ids.to(self.device, torch.int64).contiguous()
             B, L = ids.shape
-            status = torch.zeros((1,), dtype=torch.int32, device=self.device)
+            status = getattr(self, "_dec_status", None)          # stays 0 between calls: cleared only after an error
+            if status is None:
+                status = self._dec_status = torch.zeros((1,), dtype=torch.int32, device=self.device)
             T = L * self.hop
             ws = self._workspace(B, T)
             out = torch.empty((B, T, self.input_dim), dtype=torch.float32, device=self.device)
             _lib.call("qpg_vq_decode_f32", self.device, self._desc, ids, B, L, ws, ws.numel(), out, status)
             outs.append(out)
             if int(status.item()):
+                status.zero_()
                 raise IndexError("code id out of range [0,%d)" % self.bins)
-        return torch.cat(outs, dim=0)
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)      # (no copy launch for the usual single chunk)
 
     # ------------------------------------------------------------------------------------------
     # VQVAE.forward (vqvae.py:183-302): training / validation step
