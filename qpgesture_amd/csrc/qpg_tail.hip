@@ -474,24 +474,24 @@ __global__ __launch_bounds__(256) void gate_table_kernel(TailArgs A, GateGeom ge
 }
 
 #define QPG_CHASE_QMAX 2048
-__global__ __launch_bounds__(256) void gate_chase_kernel(TailArgs A, const uint16_t* __restrict__ Gt) {
+__global__ __launch_bounds__(1024) void gate_chase_kernel(TailArgs A, const uint16_t* __restrict__ Gt) {
   extern __shared__ __attribute__((aligned(16))) uint16_t gl[];     // 2 x [steps][2K]: current window + the next being staged
   __shared__ uint16_t sig[QPG_CHASE_QMAX];
   __shared__ int bad_s;
-  const int K = A.K, Q = A.M * A.steps, tid = threadIdx.x;
+  const int K = A.K, Q = A.M * A.steps, tid = threadIdx.x, nt = blockDim.x;
   const int per_w = A.steps * 2 * K;                                // u16 per window
   if (tid == 0) bad_s = 0;
   int sigma = 0;
-  // two LDS buffers: waves 1..3 stage window w+1's table while lane 0 of wave 0 chases window w
+  // two LDS buffers: the other waves stage window w+1's table while lane 0 of wave 0 chases window w
   auto stage = [&](int w, int first, int step) {
     const int4* src = reinterpret_cast<const int4*>(Gt + (int64_t)w * per_w);
     int4* dst = reinterpret_cast<int4*>(gl + (size_t)(w & 1) * per_w);
     for (int v = first; v < per_w / 8; v += step) dst[v] = src[v];
   };
-  stage(0, tid, 256);
+  stage(0, tid, nt);
   __syncthreads();
   for (int w = 0; w < A.M; ++w) {
-    if (tid >= 64 && w + 1 < A.M) stage(w + 1, tid - 64, 192);
+    if (tid >= 64 && w + 1 < A.M) stage(w + 1, tid - 64, nt - 64);
     if (tid == 0) {
       const uint16_t* g = gl + (size_t)(w & 1) * per_w;
       for (int s = 0; s < A.steps; ++s) {
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void gate_chase_kernel(TailArgs A, const uint1
     __syncthreads();
   }
   // parallel epilogue: the winners' phase blocks, votes, codes; absent-candidate check of every visited gate
-  for (int i = tid; i < Q * 32; i += 256) {                         // 32 x 16 B per phase block
+  for (int i = tid; i < Q * 32; i += nt) {                         // 32 x 16 B per phase block
     const int q = i >> 5, v = i & 31;
     const int sg = sig[q], p = sg >> 1, fi = sg & 1;
     const int ci = (fi ? A.T1 : A.T0)[(int64_t)q * K + p];
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void gate_chase_kernel(TailArgs A, const uint1
       if (A.T0[(int64_t)q * K + p] < 0 || A.T1[(int64_t)q * K + p] < 0) bad_s = 1;
     }
   }
-  for (int i = tid; i < A.M * A.codes_per_window; i += 256) {
+  for (int i = tid; i < A.M * A.codes_per_window; i += nt) {
     const int w = i / A.codes_per_window, c = i - w * A.codes_per_window;
     const int q = w * A.steps + c / A.step_codes;
     const int sg = sig[q], p = sg >> 1, fi = sg & 1;
@@ -590,7 +590,7 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   hipLaunchKernelGGL(gate_table_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, qpg_stream(stream), A,
                      geo, gtab);
   QPG_LAUNCH_CHECK("gate_table_kernel");
-  hipLaunchKernelGGL(gate_chase_kernel, dim3(1), dim3(256), lds_g, qpg_stream(stream), A, (const uint16_t*)gtab);
+  hipLaunchKernelGGL(gate_chase_kernel, dim3(1), dim3(1024), lds_g, qpg_stream(stream), A, (const uint16_t*)gtab);
   QPG_LAUNCH_CHECK("gate_chase_kernel");
   return QPG_OK;
 }
