@@ -71,6 +71,11 @@ def main():
                     help="mixed (default, the product default): f32 matrix-core sweep with an a-priori error bound + f64 / "
                          "reference-arithmetic re-evaluation of every undecided comparison; f64: the f64 matrix-core sweep")
     ap.add_argument("--clips", type=int, default=1, help="concurrent clips per GPU in one batched sweep")
+    ap.add_argument("--clips-in-flight", type=int, default=1,
+                    help="lanes of independent clips in flight (code_knn.ClipPipeline; single GPU, one clip per step): the "
+                         "next clip's sweeps run under the previous clip's select / walk / D2H.  Host-launch-rate bound: "
+                         "0.49 ms per clip with 2 lanes on a fast host, slower than one at a time on a slow one, so the "
+                         "default line stays one clip at a time")
     ap.add_argument("--encode-batch", type=int, default=0, help="pose windows VQ-VAE-encoded inside the timed step")
     ap.add_argument("--feature-dtype", choices=["f32", "f16"], default="f32")
     ap.add_argument("--workload", choices=["match", "cfg3"], default="match")
@@ -174,13 +179,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
+    pipe = None
+    can_pipe = world == 1 and CL == 1 and enc is None and not a.no_overlap
+    if a.clips_in_flight > 1:
+        # throughput mode: the SAME per-clip launches, issued on `clips_in_flight` lanes; a step still ends with its
+        # clip's indices on the host (collected one lane later)
+        assert can_pipe, "--clips-in-flight: single GPU, one clip per step, no encode leg"
+        from qpgesture_amd.code_knn import ClipPipeline
+        pipe = ClipPipeline(db, depth=a.clips_in_flight, rng=np.random.RandomState(123456))
+        for ln in pipe.lanes:
+            ln["knn"].overlap_sweeps = knn.overlap_sweeps
+            ln["knn"].audio_precision = knn.audio_precision
+
+        def run_steps(n):
+            pending, res = [], None
+            for _ in range(n):
+                if len(pending) == pipe.depth:
+                    res = pipe.collect(pending.pop(0))[0]
+                pending.append(pipe.submit(te_interp, te_ctx, M, seed_code=seed_code, seed_phase=seed_phase_d))
+            while pending:
+                res = pipe.collect(pending.pop(0))[0]
+            return torch.from_numpy(res.astype(np.int32))
+    else:
+        def run_steps(n):
+            res = None
+            for _ in range(n):
+                res = step()
+            return res
+
+    run_steps(a.warmup)
     knn.kernel_events = []
+    if pipe is not None:
+        for ln in pipe.lanes:
+            ln["knn"].kernel_events = knn.kernel_events
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        codes = step()
+    codes = run_steps(a.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -189,10 +223,32 @@ def main():
         dt = float(t.item())
     ms = [e0.elapsed_time(e1) for e0, e1 in knn.kernel_events]
     knn.kernel_events = None
+    if pipe is not None:
+        for ln in pipe.lanes:
+            ln["knn"].kernel_events = None
     k_ms = float(np.mean(ms))
 
     frames_per_step = 240 * M * n_clips
     value = frames_per_step * a.steps / dt
+
+    serial = None
+    if pipe is not None:
+        # the same clip, one at a time (a step = submit + wait): the latency figure, and the sweep kernel alone on the GPU
+        n1 = min(a.steps, 100)
+        for _ in range(3):
+            step()
+        knn.kernel_events = []
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            c1 = step()
+        fence()
+        d1 = time.perf_counter() - t1
+        ms1 = [e0.elapsed_time(e1) for e0, e1 in knn.kernel_events]
+        knn.kernel_events = None
+        assert torch.equal(c1.reshape(-1).to(torch.int32), codes.reshape(-1)), "clips in flight changed the result"
+        serial = {"ms_per_clip": round(d1 / n1 * 1e3, 4), "frames_per_s": round(frames_per_step * n1 / d1, 1),
+                  "steps": n1, "kernel_ms": round(float(np.mean(ms1)), 4)}
 
     # ---- roofline of the dominant kernel (audio_cosine_f64_kernel), per launch on this rank --------------
     Q = M * n_clips * 8
@@ -212,6 +268,9 @@ def main():
                            "matrix cores, error bounded a priori, f64 re-evaluation in the select)")
                 if mixed else "audio_cosine_f64_kernel",
                 "precision": "mixed" if mixed else "f64",
+                **({"note": "kernel_ms is measured with %d clips in flight: other clips' kernels share the CUs during the "
+                            "launch (alone: one_clip_at_a_time.kernel_ms)" % a.clips_in_flight}
+                   if a.clips_in_flight > 1 else {}),
                 "kernel_ms": round(k_ms, 4),
                 "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_launches_timed": len(ms),
                 "algorithmic_gflop": round(flops / 1e9, 3),
@@ -238,11 +297,14 @@ def main():
                                      if a.encode_batch else ""),
                       "n_db": N, "windows_per_clip": M, "clips": n_clips, "clips_per_gpu": CL,
                       "feature_dtype": a.feature_dtype, "audio_precision": "mixed" if mixed else "f64",
-                      "encode_batch": a.encode_batch, "parallelism": par},
+                      "encode_batch": a.encode_batch, "clips_in_flight": a.clips_in_flight, "parallelism": par},
            "roofline": roofline,
            "realtime_factor": round(24.0 * M / 6 / (dt / a.steps), 1) if strong
            else round(value / 60.0 / world, 1)}
 
+    if serial is not None:
+        serial["roofline_frac"] = round(flops / (serial["kernel_ms"] * 1e-3) / 1e12 / peak, 4)
+        out["one_clip_at_a_time"] = serial
     if mixed and world > 1:
         st = knn.mixed_stats()
         fl = knn._guard_stats.cpu().numpy()
@@ -253,6 +315,10 @@ def main():
         # re-evaluation activity of the timed steps (+ warm-up) and the same clip through the f64 sweep: the mixed path
         # must return the same codes (its tables differ only inside the sweep's error bound)
         st = knn.mixed_stats()
+        if pipe is not None:                      # the timed clips ran on the lanes' matchers
+            ls = [ln["knn"].mixed_stats() for ln in pipe.lanes]
+            st = {"tier1_pairs": sum(x["tier1_pairs"] for x in ls), "tier2_pairs": sum(x["tier2_pairs"] for x in ls),
+                  "flags": int(np.bitwise_or.reduce([x["flags"] for x in ls]))}
         n_run = a.steps + a.warmup
         k64 = CodeKNN(db, rng=np.random.RandomState(123456))
         k64.audio_precision = "f64"

@@ -790,6 +790,95 @@ class ClipGraph:
         return self.out
 
 
+class ClipPipeline:
+    """Several independent clips in flight on one GPU (a matching service's throughput mode).
+
+    A clip's select, rank fusion, walk and D2H copy occupy a fraction of the CUs for ~25 % of its latency; with `depth`
+    lanes - one CodeKNN (its own workspaces and side stream), one HIP stream and one pinned result buffer each - the
+    next clip's sweeps run underneath them.  Every clip goes through exactly the launches of CodeKNN.match_clip, so
+    the results are the same arrays; only the host's wait moves from the end of a clip to `collect`.
+    Measured (tools/pipeline_probe.py, 24 s clip vs 2048 windows): 0.567 ms per clip serial, 0.486 with two lanes,
+    0.478 with three - when the host can enqueue a clip's ~20 launches in under 0.48 ms; on a box with a slower host the
+    same run took 0.68 ms with two lanes against 0.57 serial, which is why bench.py's default stays one clip at a time.
+    Single-GPU databases only (the sharded path's collectives stay on one stream)."""
+
+    def __init__(self, db, depth=2, rng=None, **knn_flags):
+        if db.world != 1:
+            raise NotImplementedError("clips in flight: single-GPU databases only")
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.db = db
+        self.lanes = []
+        for _ in range(depth):
+            knn = CodeKNN(db, rng=rng, **knn_flags)
+            self.lanes.append(dict(knn=knn, stream=torch.cuda.Stream(db.device), done=torch.cuda.Event(), ints=None,
+                                   phase=None, shape=None, busy=False))
+        self._next = 0
+
+    @property
+    def depth(self):
+        return len(self.lanes)
+
+    def submit(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None):
+        """Enqueue one clip on the next lane (which must have been collected) and return its ticket."""
+        t = self._next
+        ln = self.lanes[t]
+        if ln["busy"]:
+            raise RuntimeError("lane %d still holds an uncollected clip: collect() it first" % t)
+        knn, dev = ln["knn"], self.db.device
+        if seed_code is None:
+            seed_code, seed_phase = knn.init_code_phase()
+        ln["stream"].wait_stream(torch.cuda.current_stream(dev))       # the caller's inputs
+        with torch.cuda.stream(ln["stream"]):
+            T = knn.sweep_tables(test_interp.contiguous(), test_context, n_windows, mode)
+            oc, op, ov, st = knn.walk(T, n_windows, 0, mode, seed_code, seed_phase, sync=False)
+            ints = torch.cat((oc.reshape(-1), ov.reshape(-1), st))
+            if ln["ints"] is None or ln["ints"].numel() < ints.numel():
+                ln["ints"] = torch.empty((ints.numel(),), dtype=torch.int32).pin_memory()
+                ln["phase"] = torch.empty((op.numel(),), dtype=torch.float32).pin_memory()
+            ln["ints"][:ints.numel()].copy_(ints, non_blocking=True)
+            ln["phase"][:op.numel()].copy_(op.reshape(-1), non_blocking=True)
+            ln["done"].record(ln["stream"])
+            # (the device results were allocated under this lane's stream: the caching allocator hands their blocks
+            # back to this lane only, whose next submit is ordered after these copies)
+        ln["shape"] = (tuple(oc.shape), tuple(ov.shape), tuple(op.shape))
+        ln["busy"] = True
+        self._next = (t + 1) % len(self.lanes)
+        return t
+
+    def collect(self, ticket):
+        """Wait for the clip of `ticket`; returns what CodeKNN.match_clip returns: (codes int64 [M,30], phases f32,
+        votes) as NumPy arrays (copies: the lane's buffers are reused by its next clip)."""
+        ln = self.lanes[ticket]
+        if not ln["busy"]:
+            raise RuntimeError("lane %d holds no clip" % ticket)
+        ln["done"].synchronize()
+        ln["busy"] = False
+        sc, sv, sp = ln["shape"]
+        n_c, n_v = int(np.prod(sc)), int(np.prod(sv))
+        ints = ln["ints"].numpy()
+        if int(ints[n_c + n_v]) != 0:
+            raise IndexError("a code that never occurs in the database won a rank fusion "
+                             "(the reference raises IndexError at GestureKNN.py:631-632)")
+        codes = ints[:n_c].reshape(sc).astype(np.int64)
+        votes = ints[n_c:n_c + n_v].reshape(sv).copy()
+        phases = ln["phase"].numpy()[:int(np.prod(sp))].reshape(sp).copy()
+        return codes, phases, votes
+
+    def match_clips(self, clips, mode=MODE_AUD_TXT, seeds=None):
+        """clips: iterable of (test_interp, test_context, n_windows); seeds: optional list of (seed_code, seed_phase).
+        Returns the list of match_clip results, in order."""
+        out, pending = [], []
+        for i, (ti, tc, m) in enumerate(clips):
+            if len(pending) == len(self.lanes):
+                out.append(self.collect(pending.pop(0)))
+            sc, sp = seeds[i] if seeds is not None else (None, None)
+            pending.append(self.submit(ti, tc, m, mode, sc, sp))
+        while pending:
+            out.append(self.collect(pending.pop(0)))
+        return out
+
+
 def predict_code_from_audio(db, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, rng=None):
     """predict_code_from_audio (GestureKNN.py:724-813) for the shipped flags; returns (M,30) int64."""
     knn = CodeKNN(db, rng=rng)

@@ -214,6 +214,38 @@ def test_clip_graph_replay_equals_eager():
         assert np.array_equal(votes.cpu().numpy(), g["vote"])
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_clips_in_flight_equal_serial_clips(depth):
+    """ClipPipeline: several clips in flight (one lane = CodeKNN + stream + pinned buffer each) return, in order,
+    exactly what match_clip returns for each clip on its own - different clips, lengths and seeds, the golden included."""
+    import torch
+    from qpgesture_amd.code_knn import ClipPipeline
+    g = load_golden(GOLDENS[1])
+    A, db, knn, te_i, te_c, M = _build(g["meta"], freq_rank=g["step_freq_score"])
+    sc, sp = knn.init_code_phase()
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    clips, seeds = [(te_i, te_c, M)], [(sc, sp)]
+    for k in range(6):
+        m = 1 + k % M
+        perm = torch.randperm(M, generator=gen)[:m].to(te_i.device)
+        clips.append((te_i[perm] + 0.01 * k, te_c[perm], m))
+        seeds.append(((sc + 17 * k) % 512, np.roll(sp, k, axis=0)))
+    want = [knn.match_clip(ti, tc, m, seed_code=s_[0], seed_phase=s_[1]) for (ti, tc, m), s_ in zip(clips, seeds)]
+    assert np.array_equal(want[0][0], g["knn_pred"])
+    pipe = ClipPipeline(db, depth=depth, rng=np.random.RandomState(1))
+    got = pipe.match_clips(clips, seeds=seeds)
+    assert len(got) == len(want)
+    for w, r in zip(want, got):
+        for a, b in zip(w, r):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+    t = pipe.submit(*clips[0], seed_code=sc, seed_phase=sp)
+    for _ in range(depth - 1):
+        pipe.submit(*clips[1], seed_code=sc, seed_phase=sp)
+    with pytest.raises(RuntimeError):
+        pipe.submit(*clips[0], seed_code=sc, seed_phase=sp)          # every lane holds an uncollected clip
+    assert np.array_equal(pipe.collect(t)[0], g["knn_pred"])
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_tabulated_walk_equals_sequential_walk(mode):
     """qpg_match_steps' tabulated walk (gate evaluated for every reachable (step, previous code, previous vote) in
