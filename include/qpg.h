@@ -361,6 +361,14 @@ int qpg_conv1d_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, int 
 int qpg_convt_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, int Cx, const float* wt, const float* bias,
                   int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride, int in_offset, int dil, int T_out,
                   int out_stride, int out_offset, int T_y, const float* residual, int relu_in, int relu_out, float* y);
+/* Two qpg_convt_f32 convolutions of the SAME input and shape whose outputs interleave - the even / odd output frames
+ * of ConvTranspose1d(k4, s2, p1) (encdec.py:112-115: y[2m] = x[m-1].W3 + x[m].W1, y[2m+1] = x[m].W2 + x[m+1].W0) -
+ * issued together: one launch on short sequences (a clip's decode), two otherwise.  (wt0, bias0, in_offset0,
+ * out_offset0) and (wt1, ...) are the two halves; everything else as in qpg_convt_f32, no residual, no ReLU. */
+int qpg_convt_pair_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, int Cx, const float* wt0,
+                       const float* bias0, int in_offset0, int out_offset0, const float* wt1, const float* bias1,
+                       int in_offset1, int out_offset1, int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride,
+                       int dil, int T_out, int out_stride, int T_y, float* y);
 /* y[r][0..Cp) = x[r][0..C) zero-extended (rows of 135 floats are not 16-byte aligned). */
 int qpg_pad_channels_f32(qpg_ctx*, void* stream, const float* x, int64_t R, int C, int Cp, float* y);
 /* One ResConv1DBlock of width 512 in ONE launch (resnet.py:31-46):  y = x + W2 . relu(W1 (*) relu(x) + b1) + b2,

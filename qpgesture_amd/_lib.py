@@ -61,6 +61,7 @@ _SIGS = {
     "qpg_wavvq_lev_f32": [P, I, I, P, I, P, I, P, I, I, P, P, I, P, L],
     "qpg_conv1d_f32": [P, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, P, P, L],
     "qpg_convt_f32": [P, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, P],
+    "qpg_convt_pair_f32": [P, I, I, I, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "qpg_pad_channels_f32": [P, L, I, I, P],
     "qpg_resblock_f32": [P, I, I, I, P, P, P, P, P],
     "qpg_pose_to_euler_f64": [P, L, I, P, P, P, P, P, I, P, P],

@@ -295,6 +295,11 @@ struct ConvTArgs {
   int T_out, out_stride, out_offset, T_y, Cout, relu_in, relu_out;
   int nstage;          // K / 64
   const float* zeros;
+  // convt_small_f32_kernel, gridDim.z == 2 (the two output parities of a ConvTranspose1d in one launch): the second
+  // half's weights / bias / offsets
+  const float* wt1;
+  const float* bias1;
+  int in_offset1, out_offset1;
 };
 
 template <bool RELU_IN>
@@ -439,6 +444,11 @@ __global__ __launch_bounds__(256, 2) void convt_f32_kernel(ConvTArgs a) {
 // for launches that would otherwise leave most CUs idle)
 template <bool RELU_IN, int PD, int NQ>
 __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs a) {
+  // (uniform per block) which of the two parity halves this block computes
+  const float* const wt_sel = blockIdx.z ? a.wt1 : a.wt;
+  const float* const bias_sel = blockIdx.z ? a.bias1 : a.bias;
+  const int in_offset = blockIdx.z ? a.in_offset1 : a.in_offset;
+  const int out_offset = blockIdx.z ? a.out_offset1 : a.out_offset;
   __shared__ __attribute__((aligned(16))) float part[CTS_NW][NQ][64][4];    // [wave][tile][lane][r]
   const int tid = threadIdx.x, lane = tid & 63, ml = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -455,10 +465,10 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
   const int per = (nkb + CTS_NW - 1) / CTS_NW;
   const int kb0 = w * per, kb1 = kb0 + per < nkb ? kb0 + per : nkb;
   const int kpt = a.Cin_pad / 16;                                      // 16-k blocks per tap
-  const float* wbase = a.wt + ((int64_t)nb * nkb * 4 + g) * 512 + (cg0 + ml) * 4;         // + kb*2048 + tile*64
+  const float* wbase = wt_sel + ((int64_t)nb * nkb * 4 + g) * 512 + (cg0 + ml) * 4;         // + kb*2048 + tile*64
   auto bfrag = [&](int kb) -> f32x4 {
     const int tap = kb / kpt, ci0 = (kb - tap * kpt) * 16;
-    const int t_in = t * a.in_stride + a.in_offset + tap * a.dil;
+    const int t_in = t * a.in_stride + in_offset + tap * a.dil;
     const bool ok = live && kb < kb1 && t_in >= 0 && t_in < a.T_in;
     f32x4 v = *reinterpret_cast<const f32x4*>(ok ? xb + (int64_t)t_in * a.Cx + ci0 : a.zeros);
     return RELU_IN ? relu4(v) : v;
@@ -530,9 +540,9 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
   if (!live) return;
   const int n = nb * 128 + cg0 + 16 * w + 4 * g;
   if (n >= a.Cout) return;
-  const int64_t orow = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout;
-  if (a.bias) {
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+  const int64_t orow = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + out_offset) * a.Cout;
+  if (bias_sel) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_sel + n);
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] += bb[r];
   }
@@ -551,19 +561,8 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
   }
 }
 
-extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, int T_in, int Cx, const float* wt,
-                             const float* bias, int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride,
-                             int in_offset, int dil, int T_out, int out_stride, int out_offset, int T_y,
-                             const float* residual, int relu_in, int relu_out, float* y) {
-  QPG_REQUIRE(ctx && x && wt && y, "qpg_convt_f32: null pointer");
-  QPG_REQUIRE(B >= 0 && T_in > 0 && Cx > 0 && taps > 0 && taps <= 4 && Cout > 0 && T_out >= 0 && T_y > 0 &&
-                  out_stride > 0 && in_stride > 0 && dil > 0,
-              "qpg_convt_f32: bad size (1..4 taps)");
-  QPG_REQUIRE((Cx % 4) == 0 && Cx >= Cin_pad && (reinterpret_cast<uintptr_t>(x) % 16) == 0,
-              "qpg_convt_f32: input rows must be 16-byte aligned and hold Cin_pad floats (pad the channels first)");
-  QPG_REQUIRE(Cin_pad % 16 == 0 && (taps * Cin_pad) % 64 == 0 && Cout_pad % 128 == 0 && Cout_pad >= Cout,
-              "qpg_convt_f32: T-pack needs Cin_pad %% 16 == 0, taps*Cin_pad %% 64 == 0, Cout_pad %% 128 == 0");
-  if (B == 0 || T_out == 0) return QPG_OK;
+// nz = 2: the pair form (a.wt1 / bias1 / in_offset1 / out_offset1 set); the generic kernel then takes two launches
+static int convt_launch(qpg_ctx* ctx, void* stream, ConvTArgs a, int Cout_pad, int nz) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(convt_f32_kernel<false>),
@@ -575,15 +574,10 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
     }
     attr_set = true;
   }
-  ConvTArgs a;
-  a.x = x; a.wt = wt; a.bias = bias; a.res = residual; a.y = y;
-  a.B = B; a.T_in = T_in; a.Cx = Cx; a.Cin_pad = Cin_pad; a.taps = taps; a.in_stride = in_stride;
-  a.in_offset = in_offset; a.dil = dil; a.T_out = T_out; a.out_stride = out_stride; a.out_offset = out_offset;
-  a.T_y = T_y; a.Cout = Cout; a.relu_in = relu_in; a.relu_out = relu_out; a.nstage = taps * Cin_pad / 64;
-  a.zeros = ctx->zeros;
-  const int64_t M = (int64_t)B * T_out;
+  const bool relu_in = a.relu_in != 0;
+  const int64_t M = (int64_t)a.B * a.T_out;
   // short sequences: 16-position x 64-channel blocks whose waves split the contraction (see convt_small_f32_kernel)
-  if (((M + CT_ROWS - 1) / CT_ROWS) * (Cout_pad / 128) * 2 < 3 * (int64_t)ctx->n_cu) {
+  if (((M + CT_ROWS - 1) / CT_ROWS) * (Cout_pad / 128) * 2 * nz < 3 * (int64_t)ctx->n_cu) {
     // Channels per block: 64, 32 or 16 (NQ = 4, 2, 1 tiles).  A block's time is the time ONE CU needs to pull its
     // operands (NQ weight tiles + 1 activation tile of 16 x K floats; two blocks on one CU take twice as long, so a
     // launch takes ceil(blocks / CUs) block times): pick the NQ with the smallest product.  tools/bench_convt_small.py
@@ -591,7 +585,7 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
     int nq = 4;
     int64_t best_cost = 0;
     for (int cand = 4; cand >= 1; cand >>= 1) {
-      const int64_t blocks = ((M + 15) / 16) * (Cout_pad / (16 * cand));
+      const int64_t blocks = ((M + 15) / 16) * (Cout_pad / (16 * cand)) * nz;
       const int64_t cost = ((blocks + ctx->n_cu - 1) / ctx->n_cu) * (cand + 1);
       if (cand == 4 || cost < best_cost) {
         best_cost = cost;
@@ -608,7 +602,7 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
         pd = epd;
       }
     }
-    const dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / (16 * nq)));
+    const dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / (16 * nq)), (unsigned)nz);
 #define CTS_LAUNCH(R, P, Q_) hipLaunchKernelGGL((convt_small_f32_kernel<R, P, Q_>), sgrid, dim3(64 * CTS_NW), 0, qpg_stream(stream), a)
 #define CTS_LAUNCH_P(R, Q_) do { if (pd == 4) CTS_LAUNCH(R, 4, Q_); else CTS_LAUNCH(R, 0, Q_); } while (0)
     if (relu_in) {
@@ -622,10 +616,66 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
     return QPG_OK;
   }
   const dim3 grid((unsigned)((M + CT_ROWS - 1) / CT_ROWS), (unsigned)(Cout_pad / 128));
-  if (relu_in) hipLaunchKernelGGL(convt_f32_kernel<true>, grid, dim3(256), 2 * CT_STAGE_BYTES, qpg_stream(stream), a);
-  else hipLaunchKernelGGL(convt_f32_kernel<false>, grid, dim3(256), 2 * CT_STAGE_BYTES, qpg_stream(stream), a);
-  QPG_LAUNCH_CHECK("convt_f32_kernel");
+  for (int z = 0; z < nz; ++z) {
+    if (z == 1) {
+      a.wt = a.wt1; a.bias = a.bias1; a.in_offset = a.in_offset1; a.out_offset = a.out_offset1;
+    }
+    if (relu_in) hipLaunchKernelGGL(convt_f32_kernel<true>, grid, dim3(256), 2 * CT_STAGE_BYTES, qpg_stream(stream), a);
+    else hipLaunchKernelGGL(convt_f32_kernel<false>, grid, dim3(256), 2 * CT_STAGE_BYTES, qpg_stream(stream), a);
+    QPG_LAUNCH_CHECK("convt_f32_kernel");
+  }
   return QPG_OK;
+}
+
+static int convt_check(qpg_ctx* ctx, const float* x, const float* wt, const float* y, int B, int T_in, int Cx, int taps,
+                       int Cin_pad, int Cout, int Cout_pad, int in_stride, int dil, int T_out, int out_stride, int T_y) {
+  QPG_REQUIRE(ctx && x && wt && y, "qpg_convt_f32: null pointer");
+  QPG_REQUIRE(B >= 0 && T_in > 0 && Cx > 0 && taps > 0 && taps <= 4 && Cout > 0 && T_out >= 0 && T_y > 0 &&
+                  out_stride > 0 && in_stride > 0 && dil > 0,
+              "qpg_convt_f32: bad size (1..4 taps)");
+  QPG_REQUIRE((Cx % 4) == 0 && Cx >= Cin_pad && (reinterpret_cast<uintptr_t>(x) % 16) == 0,
+              "qpg_convt_f32: input rows must be 16-byte aligned and hold Cin_pad floats (pad the channels first)");
+  QPG_REQUIRE(Cin_pad % 16 == 0 && (taps * Cin_pad) % 64 == 0 && Cout_pad % 128 == 0 && Cout_pad >= Cout,
+              "qpg_convt_f32: T-pack needs Cin_pad %% 16 == 0, taps*Cin_pad %% 64 == 0, Cout_pad %% 128 == 0");
+  return QPG_OK;
+}
+
+extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, int T_in, int Cx, const float* wt,
+                             const float* bias, int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride,
+                             int in_offset, int dil, int T_out, int out_stride, int out_offset, int T_y,
+                             const float* residual, int relu_in, int relu_out, float* y) {
+  const int rc = convt_check(ctx, x, wt, y, B, T_in, Cx, taps, Cin_pad, Cout, Cout_pad, in_stride, dil, T_out, out_stride, T_y);
+  if (rc) return rc;
+  if (B == 0 || T_out == 0) return QPG_OK;
+  ConvTArgs a;
+  a.x = x; a.wt = wt; a.bias = bias; a.res = residual; a.y = y;
+  a.B = B; a.T_in = T_in; a.Cx = Cx; a.Cin_pad = Cin_pad; a.taps = taps; a.in_stride = in_stride;
+  a.in_offset = in_offset; a.dil = dil; a.T_out = T_out; a.out_stride = out_stride; a.out_offset = out_offset;
+  a.T_y = T_y; a.Cout = Cout; a.relu_in = relu_in; a.relu_out = relu_out; a.nstage = taps * Cin_pad / 64;
+  a.zeros = ctx->zeros;
+  a.wt1 = wt; a.bias1 = bias; a.in_offset1 = in_offset; a.out_offset1 = out_offset;
+  return convt_launch(ctx, stream, a, Cout_pad, 1);
+}
+
+// Two convolutions of the SAME input and shape that interleave in the output - the even / odd output frames of
+// ConvTranspose1d(k4, s2, p1) (encdec.py:112-115): y[2m] = x[m-1].W3 + x[m].W1, y[2m+1] = x[m].W2 + x[m+1].W0 -
+// as ONE launch of the short-sequence kernel (gridDim.z = 2), two launches of the generic one.
+extern "C" int qpg_convt_pair_f32(qpg_ctx* ctx, void* stream, const float* x, int B, int T_in, int Cx, const float* wt0,
+                                  const float* bias0, int in_offset0, int out_offset0, const float* wt1,
+                                  const float* bias1, int in_offset1, int out_offset1, int taps, int Cin_pad, int Cout,
+                                  int Cout_pad, int in_stride, int dil, int T_out, int out_stride, int T_y, float* y) {
+  const int rc = convt_check(ctx, x, wt0, y, B, T_in, Cx, taps, Cin_pad, Cout, Cout_pad, in_stride, dil, T_out, out_stride, T_y);
+  if (rc) return rc;
+  QPG_REQUIRE(wt1, "qpg_convt_pair_f32: null pointer");
+  if (B == 0 || T_out == 0) return QPG_OK;
+  ConvTArgs a;
+  a.x = x; a.wt = wt0; a.bias = bias0; a.res = nullptr; a.y = y;
+  a.B = B; a.T_in = T_in; a.Cx = Cx; a.Cin_pad = Cin_pad; a.taps = taps; a.in_stride = in_stride;
+  a.in_offset = in_offset0; a.dil = dil; a.T_out = T_out; a.out_stride = out_stride; a.out_offset = out_offset0;
+  a.T_y = T_y; a.Cout = Cout; a.relu_in = 0; a.relu_out = 0; a.nstage = taps * Cin_pad / 64;
+  a.zeros = ctx->zeros;
+  a.wt1 = wt1; a.bias1 = bias1; a.in_offset1 = in_offset1; a.out_offset1 = out_offset1;
+  return convt_launch(ctx, stream, a, Cout_pad, 2);
 }
 
 // [R][C] -> [R][Cp] with zero fill (the 135-channel pose rows are 540 B: not 16-byte aligned per row)

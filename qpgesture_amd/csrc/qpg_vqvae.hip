@@ -648,9 +648,9 @@ static int decode_tpath(qpg_ctx* ctx, void* stream, const qpg_vq_model* m, const
                       cur, alt, h);
     if (rc) return rc;
     // ConvTranspose1d(k4,s2,p1): y[2m] = x[m-1].W3 + x[m].W1 ; y[2m+1] = x[m].W2 + x[m+1].W0
-    rc = convt_call(ctx, stream, m->dec_up_even[i], cur, 512, B, Tc, 1, -1, 1, Tc, 2, 0, 2 * Tc, nullptr, 0, 0, alt);
-    if (rc) return rc;
-    rc = convt_call(ctx, stream, m->dec_up_odd[i], cur, 512, B, Tc, 1, 0, 1, Tc, 2, 1, 2 * Tc, nullptr, 0, 0, alt);
+    const qpg_conv_desc &ce = m->dec_up_even[i], &co = m->dec_up_odd[i];
+    rc = qpg_convt_pair_f32(ctx, stream, cur, B, Tc, 512, ce.wt, ce.b, -1, 0, co.wt, co.b, 0, 1, ce.taps, ce.cin_pad, ce.cout,
+                            ce.cout_pad, 1, 1, Tc, 2, 2 * Tc, alt);
     if (rc) return rc;
     { float* t = cur; cur = alt; alt = t; }
     Tc *= 2;
