@@ -694,10 +694,13 @@ class CodeKNN:
             sp = seed_phase.to(dev, torch.float32).contiguous()
         else:
             sp = torch.as_tensor(np.asarray(seed_phase, np.float32), device=dev).contiguous()
-        out_codes = torch.empty((M, num_frames_code), dtype=torch.int32, device=dev)
+        # codes | votes | status in ONE buffer: the integer results leave in a single D2H copy, no gather kernel before it
+        n_c, n_v = M * num_frames_code, M * steps
+        ints_d = torch.empty((n_c + n_v + 1,), dtype=torch.int32, device=dev)
+        out_codes = ints_d[:n_c].view(M, num_frames_code)
+        out_vote = ints_d[n_c:n_c + n_v].view(M, steps)
+        status = ints_d[n_c + n_v:]                                      # always written by the walk kernels
         out_phase = torch.empty((M, steps, 8, 16), dtype=torch.float32, device=dev)
-        out_vote = torch.empty((M, steps), dtype=torch.int32, device=dev)
-        status = torch.empty((1,), dtype=torch.int32, device=dev)        # always written by the walk kernels
         gate = torch.empty((3, M * steps, db.K), dtype=torch.int32, device=dev)
         q0 = window_offset * steps
 
@@ -709,11 +712,10 @@ class CodeKNN:
                   db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode | (0x100 if self.serial_walk else 0), M, steps,
                   db.K, int(seed_code), sp,
                   gate, out_codes, out_phase, out_vote, status)
+        self._last_ints = ints_d
         if not sync:
             return out_codes, out_phase, out_vote, status
-        # one D2H copy for the integer results (codes | votes | status) instead of three synchronous ones
-        ints = torch.cat((out_codes.reshape(-1), out_vote.reshape(-1), status)).cpu().numpy()
-        n_c = out_codes.numel()
+        ints = ints_d.cpu().numpy()
         if int(ints[-1]) != 0:
             raise IndexError("a code that never occurs in the database won a rank fusion "
                              "(the reference raises IndexError at GestureKNN.py:631-632)")
@@ -832,7 +834,7 @@ class ClipPipeline:
         with torch.cuda.stream(ln["stream"]):
             T = knn.sweep_tables(test_interp.contiguous(), test_context, n_windows, mode)
             oc, op, ov, st = knn.walk(T, n_windows, 0, mode, seed_code, seed_phase, sync=False)
-            ints = torch.cat((oc.reshape(-1), ov.reshape(-1), st))
+            ints = knn._last_ints                                        # codes | votes | status, one buffer (walk)
             if ln["ints"] is None or ln["ints"].numel() < ints.numel():
                 ln["ints"] = torch.empty((ints.numel(),), dtype=torch.int32).pin_memory()
                 ln["phase"] = torch.empty((op.numel(),), dtype=torch.float32).pin_memory()
