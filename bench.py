@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (H2D-inclusive) measurements")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="DB windows in the CPU baseline sample")
     ap.add_argument("--no-overlap", action="store_true", help="run the text sweep after the audio sweep (one stream)")
+    ap.add_argument("--text-first", action="store_true",
+                    help="enqueue the text side before the audio side (round-1 order) instead of after the audio sweep")
     ap.add_argument("--check", action="store_true", help="verify the matched codes against a 1-rank run")
     a = ap.parse_args()
 
@@ -134,6 +136,7 @@ def main():
                    feature_dtype=a.feature_dtype)
     knn = CodeKNN(db, rng=np.random.RandomState(123456))
     knn.overlap_sweeps = not a.no_overlap
+    knn.text_after_sweep = not a.text_first
     knn.audio_precision = a.audio_precision
     if a.sharded_mixed_min_gflop is not None:
         knn.sharded_mixed_min_gflop = a.sharded_mixed_min_gflop
@@ -209,9 +212,14 @@ def main():
 
     run_steps(a.warmup)
     knn.kernel_events = []
+    knn.kernel_events_every = int(os.environ.get("QPG_BENCH_EVENTS_EVERY", "1"))
+    # the HIP events that bracket the sweep are created before the timed region, not inside it
+    knn.kernel_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                             for _ in range(a.steps * max(1, CL if strong else 1) + 8)]
     if pipe is not None:
         for ln in pipe.lanes:
             ln["knn"].kernel_events = knn.kernel_events
+            ln["knn"].kernel_event_pool = knn.kernel_event_pool
     fence()
     t0 = time.perf_counter()
     codes = run_steps(a.steps)
