@@ -353,7 +353,9 @@ class CodeKNN:
             e1.record(torch.cuda.current_stream(dev))
             ev.append((e0, e1))
         if getattr(self, "_want_sweep_event", False):     # sweep_tables: the text side starts when the sweep has finished
-            self._sweep_done = self.__dict__.setdefault("_sweep_event", torch.cuda.Event())   # one event, re-recorded
+            if self.__dict__.get("_sweep_event") is None:
+                self._sweep_event = torch.cuda.Event()                  # one event, re-recorded by every clip
+            self._sweep_done = self._sweep_event
             self._sweep_done.record(torch.cuda.current_stream(dev))
         if out is not None:          # exchange layout of the sharded path: written in place, merged after the collective
             dist, idx, qb, bs = out
