@@ -639,9 +639,6 @@ class CodeKNN:
         # of delaying the audio sweep by its own duration at the start of the clip.
         after = overlap and self.text_after_sweep and not self.use_wavvq
         qn_early = None
-        if after:                       # (the query pack is one small block: it runs at once, next to the audio pack)
-            with torch.cuda.stream(side):
-                qn_early = text_pack()
         if overlap and not audio_first and not after:
             with torch.cuda.stream(side):
                 text_side()
@@ -655,6 +652,8 @@ class CodeKNN:
             if not sharded:
                 T["aud_rank"] = r[2]
         if after:
+            with torch.cuda.stream(side):
+                qn_early = text_pack()        # one small block: runs at once, next to the audio sweep
             if self._sweep_done is not None:
                 side.wait_event(self._sweep_done)
             with torch.cuda.stream(side):
