@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--clips-in-flight", type=int, default=1,
                     help="lanes of independent clips in flight (code_knn.ClipPipeline; single GPU, one clip per step): the "
                          "next clip's sweeps run under the previous clip's select / walk / D2H.  Host-launch-rate bound: "
-                         "0.49 ms per clip with 2 lanes on a fast host, slower than one at a time on a slow one, so the "
+                         "0.48 / 0.45 ms per clip with 2 / 3 lanes on a quiet host, slower than one at a time on a busy one, so the "
                          "default line stays one clip at a time")
     ap.add_argument("--encode-batch", type=int, default=0, help="pose windows VQ-VAE-encoded inside the timed step")
     ap.add_argument("--feature-dtype", choices=["f32", "f16"], default="f32")
