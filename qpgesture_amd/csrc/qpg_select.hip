@@ -735,6 +735,9 @@ extern "C" int qpg_percode_select_guarded_f64(qpg_ctx* ctx, void* stream, const 
 // ---------------------------------------------------------------------------------------------------------------
 #define MIX_LIST 2048
 #define MIX_LIST2 256
+#ifndef MIX_POT
+#define MIX_POT 6144    // candidates that were within the band of their code's minimum SO FAR when pass 1 visited them
+#endif                  // (-DMIX_POT=64 makes every test take the overflow path: verified once, experiments/audio_mx/README.md)
 
 // f64 dot product of (query q, local candidate c) by one wave; every lane returns the sum.  F % 256 == 0 (the WavLM
 // width) and n_taps == 6: a lane owns the 16-byte piece lane + 64*j of every tap; ALL candidate loads of the pair
@@ -845,11 +848,13 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   int* l_c = reinterpret_cast<int*>(tail + 8 * MIX_LIST);                               // [MIX_LIST] local candidate
   int* l_k = l_c + MIX_LIST;                                                            // [MIX_LIST] code
   int* l2 = l_k + MIX_LIST;                                                             // [MIX_LIST2] tier-2 entries
-  int* ctl = l2 + MIX_LIST2;                 // [0] list length, [1] multi-member band seen, [2] tier-2 n, [3] band size
-  int* p_c = ctl + 4;                                        // [MIX_LIST] every band member seen by pass 2 (candidate)
+  int* ctl = l2 + MIX_LIST2;     // [0] list length, [1] multi-member band seen, [2] tier-2 n, [3] band size, [4] potentials
+  int* p_c = ctl + 8;                                        // [MIX_LIST] every band member seen by pass 2 (candidate)
   int16_t* p_k = reinterpret_cast<int16_t*>(p_c + MIX_LIST);                            // [MIX_LIST] its code
   int* rk = reinterpret_cast<int*>(p_k + MIX_LIST);          // [K] rank counters
-  float* qlds = reinterpret_cast<float*>(rk + K);            // [n_taps*F] this query's row (fast tier-1 path only)
+  int* pot_c = rk + K;                                       // [MIX_POT] pass 1's potential band members (candidate)
+  int16_t* pot_k = reinterpret_cast<int16_t*>(pot_c + MIX_POT);                         // [MIX_POT] their codes
+  float* qlds = reinterpret_cast<float*>(pot_k + MIX_POT);   // [n_taps*F] this query's row (fast tier-1 path only)
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
   const DT* row = D + (int64_t)q * ldD;                       // DT = float: the sweep stored its matrix in f32 (half the bytes
   if (q_block > 0) {                                            // of the two streaming passes, +1.2e-7 inside the bound)
@@ -865,7 +870,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     near_[k] = 0;
     refd[k] = 0;
   }
-  if (tid < 4) ctl[tid] = 0;
+  if (tid < 8) ctl[tid] = 0;
   __syncthreads();
   // rank of every code in the value table v (stable: value, then code); s_code[r] = code at rank r
   // (the K x K count is VALU-bound, ~35 cycles per comparison step per wave: P = blockDim / K threads share a code)
@@ -914,18 +919,31 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   const bool vec_ok = (ldD % VE) == 0 && (reinterpret_cast<uintptr_t>(D) % 16) == 0 &&
                       (reinterpret_cast<uintptr_t>(cand_code) % (2 * VE)) == 0;
   const int64_t Cv = vec_ok ? (C / VE) * VE : 0;
+  // Pass 1: per-code minimum (ds_min_rtn_u64).  The value the atomic returns is the code's minimum SO FAR, which is
+  // never below the final one: a candidate further than eps1 above it cannot be in the final band, so only the others
+  // - the successive minima of a code (~ln(n) of its n candidates in random order) and what lies within eps1 of them -
+  // are remembered, and "pass 2" below visits that list instead of streaming the row a second time.  A list that
+  // overflows (adversarially ordered or crowded rows) falls back to the second pass over the row.
+  auto pass1 = [&](int64_t c, double d, int cd) {
+    if ((unsigned)cd >= (unsigned)K) return;
+    const unsigned long long key = (unsigned long long)order_key(d);
+    const unsigned long long old = atomicMin(&best[cd], key);
+    if (d <= key_value(old < key ? old : key, 0.0) + eps1) {
+      const int pp = atomicAdd(&ctl[4], 1);
+      if (pp < MIX_POT) {
+        pot_c[pp] = (int)c;
+        pot_k[pp] = (int16_t)cd;
+      }
+    }
+  };
 #pragma unroll 4
   for (int64_t c = (int64_t)tid * VE; c < Cv; c += (int64_t)blockDim.x * VE) {
     const vecD d = *reinterpret_cast<const vecD*>(row + c);
     const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
 #pragma unroll
-    for (int e = 0; e < VE; ++e)
-      if ((unsigned)cd[e] < (unsigned)K) atomicMin(&best[cd[e]], (unsigned long long)order_key((double)d[e]));
+    for (int e = 0; e < VE; ++e) pass1(c + e, (double)d[e], cd[e]);
   }
-  for (int64_t c = Cv + tid; c < C; c += blockDim.x) {
-    const int cd = cand_code[c];
-    if ((unsigned)cd < (unsigned)K) atomicMin(&best[cd], (unsigned long long)order_key((double)row[c]));
-  }
+  for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass1(c, (double)row[c], cand_code[c]);
   __syncthreads();
   auto pass2 = [&](int64_t c, double d, int cd) {
     if ((unsigned)cd >= (unsigned)K) return;
@@ -939,14 +957,19 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       p_k[pp] = (int16_t)cd;
     }
   };
+  if (ctl[4] <= MIX_POT) {
+    const int npot = ctl[4];
+    for (int e = tid; e < npot; e += blockDim.x) pass2(pot_c[e], (double)row[pot_c[e]], pot_k[e]);
+  } else {
 #pragma unroll 4
-  for (int64_t c = (int64_t)tid * VE; c < Cv; c += (int64_t)blockDim.x * VE) {
-    const vecD d = *reinterpret_cast<const vecD*>(row + c);
-    const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
+    for (int64_t c = (int64_t)tid * VE; c < Cv; c += (int64_t)blockDim.x * VE) {
+      const vecD d = *reinterpret_cast<const vecD*>(row + c);
+      const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
 #pragma unroll
-    for (int e = 0; e < VE; ++e) pass2(c + e, (double)d[e], cd[e]);
+      for (int e = 0; e < VE; ++e) pass2(c + e, (double)d[e], cd[e]);
+    }
+    for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass2(c, (double)row[c], cand_code[c]);
   }
-  for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass2(c, (double)row[c], cand_code[c]);
   __syncthreads();
   // ---- list (a): every member of a band with two or more members — from the members pass 2 remembered, or, if there
   // were more than it could hold, by a third pass over the row
@@ -1193,21 +1216,21 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
   GuardArgs A;
   A.base = base; A.half = base_is_f16; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
   A.tap_stride = tap_stride; A.eps = eps2; A.stats = stats;
-  // fast tier-1 path (WavLM geometry: 6 taps x 1024 features): the query row is staged in LDS (+24 KB: 85 KB in all)
+  // fast tier-1 path (WavLM geometry: 6 taps x 1024 features): the query row is staged in LDS (+24 KB: 123 KB in all, one block per CU)
   const int use_qlds = (n_taps == 6 && F == 1024) ? 1 : 0;
-  const size_t sh = 32 * (size_t)K + 16 * MIX_LIST + 4 * MIX_LIST2 + 16 + 6 * MIX_LIST + 4 * (size_t)K +
-                    (use_qlds ? (size_t)n_taps * F * 4 : 0);
+  const size_t sh2 = 32 * (size_t)K + 16 * MIX_LIST + 4 * MIX_LIST2 + 32 + 6 * MIX_LIST + 4 * (size_t)K;   // merge phase
+  const size_t sh1 = sh2 + 6 * MIX_POT;                                                                    // list phase
+  const size_t sh = sh1 + (use_qlds ? (size_t)n_taps * F * 4 : 0);                                         // one launch
   if (!ctx->select_lds_raised) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(percode_select_mixed_f64_kernel<double>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(percode_select_mixed_f64_kernel<float>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
       qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
       return QPG_EHIP;
     }
     ctx->select_lds_raised = true;
   }
-  const size_t sh1 = sh - (use_qlds ? (size_t)n_taps * F * 4 : 0);
   unsigned char* w = static_cast<unsigned char*>(ws);
   if (ws)
     QPG_REQUIRE(ws_bytes >= (int64_t)((size_t)Q * mix_ws_stride(K)) && (reinterpret_cast<uintptr_t>(ws) % 16) == 0,
@@ -1226,7 +1249,7 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
   const int rb = Q >= 256 ? 4 : 16;          // waves per query = 4*rb; ~100 list entries per query on dense data
   hipLaunchKernelGGL((select_refine_kernel<4>), dim3(Q, rb), dim3(256), 0, qpg_stream(stream), A, K, cn2, qn2, w, use_qlds);
   QPG_LAUNCH_CHECK("select_refine_kernel");
-  if (d_is_f32) SEL_MIX_LAUNCH(float, sh1, 2); else SEL_MIX_LAUNCH(double, sh1, 2);
+  if (d_is_f32) SEL_MIX_LAUNCH(float, sh2, 2); else SEL_MIX_LAUNCH(double, sh2, 2);
   QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (merge)");
 #undef SEL_MIX_LAUNCH
   return QPG_OK;
