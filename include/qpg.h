@@ -369,6 +369,9 @@ int qpg_convt_pair_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, 
                        const float* bias0, int in_offset0, int out_offset0, const float* wt1, const float* bias1,
                        int in_offset1, int out_offset1, int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride,
                        int dil, int T_out, int out_stride, int T_y, float* y);
+/* Measurement hook (tools/bench_convt_small.py): force the short-sequence kernel's block shape - nq in {1, 2, 4}
+ * channel tiles of 16, pd in {0, 4} fragment-ring depth; nq = 0 restores the launcher's own choice.  Process-wide. */
+int qpg_debug_convt_shape(int nq, int pd);
 /* y[r][0..Cp) = x[r][0..C) zero-extended (rows of 135 floats are not 16-byte aligned). */
 int qpg_pad_channels_f32(qpg_ctx*, void* stream, const float* x, int64_t R, int C, int Cp, float* y);
 /* One ResConv1DBlock of width 512 in ONE launch (resnet.py:31-46):  y = x + W2 . relu(W1 (*) relu(x) + b1) + b2,

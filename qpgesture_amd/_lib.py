@@ -140,6 +140,7 @@ def load():
     lib.qpg_percode_select_mixed_ws_bytes.restype = c_int64
     lib.qpg_merge_mixed_ws_bytes.argtypes = [c_int, c_int]
     lib.qpg_merge_mixed_ws_bytes.restype = c_int64
+    lib.qpg_debug_convt_shape.argtypes = [c_int, c_int]
     lib.qpg_vq_reduce_ws_bytes.argtypes = []
     lib.qpg_vq_reduce_ws_bytes.restype = c_int64
     for name, sig in _SIGS.items():

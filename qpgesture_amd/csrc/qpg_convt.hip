@@ -19,8 +19,6 @@
 // [n = nb*NB + nl]  with k = tap*Cin_pad + ci:  a lane's ds_read_b128 yields its channel's four consecutive k,
 // 16 lanes of a group read 16 distinct 16-B bank slots (conflict-free), and a stage is one contiguous 32 KB run.
 #include "qpg_common.h"
-#include <stdio.h>
-#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -561,6 +559,16 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
   }
 }
 
+// Measurement hook: force the short-sequence kernel's block shape (nq in {1, 2, 4} channel tiles, pd in {0, 4} ring
+// depth); nq = 0 restores the launcher's own choice.  Not thread-safe, not for production callers.
+static int g_force_nq = 0, g_force_pd = 0;
+extern "C" int qpg_debug_convt_shape(int nq, int pd) {
+  QPG_REQUIRE((nq == 0 || nq == 1 || nq == 2 || nq == 4) && (pd == 0 || pd == 4), "qpg_debug_convt_shape: nq in {0,1,2,4}, pd in {0,4}");
+  g_force_nq = nq;
+  g_force_pd = pd;
+  return QPG_OK;
+}
+
 // nz = 2: the pair form (a.wt1 / bias1 / in_offset1 / out_offset1 set); the generic kernel then takes two launches
 static int convt_launch(qpg_ctx* ctx, void* stream, ConvTArgs a, int Cout_pad, int nz) {
   static bool attr_set = false;
@@ -594,12 +602,10 @@ static int convt_launch(qpg_ctx* ctx, void* stream, ConvTArgs a, int Cout_pad, i
     }
     const int per = (a.nstage * 4 + CTS_NW - 1) / CTS_NW;          // 16-k blocks per wave
     int pd = (a.nstage * 4) % CTS_NW == 0 && per % 4 == 0 ? 4 : 0;   // ring of 4 (a ring of 6 measured ~6% slower)
-    if (const char* e = getenv("QPG_CTS_SHAPE")) {                  // experiments only: "nq,pd"
-      int enq = 0, epd = -1;
-      if (sscanf(e, "%d,%d", &enq, &epd) == 2 && (enq == 1 || enq == 2 || enq == 4) &&
-          (epd == 0 || (epd == 4 && (a.nstage * 4) % CTS_NW == 0 && per % 4 == 0))) {
-        nq = enq;
-        pd = epd;
+    if (g_force_nq) {                                               // tools/bench_convt_small.py (qpg_debug_convt_shape)
+      if (g_force_pd == 0 || (g_force_pd == 4 && (a.nstage * 4) % CTS_NW == 0 && per % 4 == 0)) {
+        nq = g_force_nq;
+        pd = g_force_pd;
       }
     }
     const dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / (16 * nq)), (unsigned)nz);

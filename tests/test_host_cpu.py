@@ -25,7 +25,7 @@ def test_bindings_cover_the_header():
                                "qpg_vq_workspace_floats", "qpg_vq_reduce_ws_bytes",
                                "qpg_conv1d_wgrad_ws_floats", "qpg_vq_code_sums_ws_bytes",
                                "qpg_text_percode_ws_bytes", "qpg_percode_select_mixed_ws_bytes",
-                               "qpg_merge_mixed_ws_bytes"}
+                               "qpg_merge_mixed_ws_bytes", "qpg_debug_convt_shape"}
     assert declared == bound
 
 

@@ -1,5 +1,5 @@
 """experiments: time the short-sequence convolution kernel (convt_small_f32_kernel) for every block shape
-(QPG_CTS_SHAPE = "nq,pd") on the layer shapes of a clip decode.  python tools/bench_convt_small.py"""
+(qpg_debug_convt_shape(nq, pd)) on the layer shapes of a clip decode.  python tools/bench_convt_small.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +7,8 @@ from qpgesture_amd import _lib
 from qpgesture_amd.vqvae import tpack
 dev = torch.device("cuda:0")
 def run(T, taps, dil, relu_in, shape):
-    os.environ["QPG_CTS_SHAPE"] = shape
+    nq_, pd_ = (int(v) for v in shape.split(","))
+    assert _lib.load().qpg_debug_convt_shape(nq_, pd_) == 0
     cin = cout = 512
     x = torch.randn((1, T, cin), device=dev)
     w = torch.randn((taps, cin, cout), device=dev) * 0.02
@@ -29,7 +30,6 @@ def run(T, taps, dil, relu_in, shape):
     for _ in range(5): g.replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 200 * 1e3
-os.environ.pop("QPG_CTS_SHAPE", None)
 for T in (30, 180, 360, 720, 1440):
     for taps in (3, 1):
         row = []
