@@ -215,7 +215,7 @@ def main():
             return res
 
     run_steps(a.warmup)
-    knn.kernel_events = []
+    knn.kernel_events = [] if os.environ.get("QPG_BENCH_NO_EVENTS", "") != "1" else None     # (diagnostics)
     knn.kernel_events_every = int(os.environ.get("QPG_BENCH_EVENTS_EVERY", "1"))
     # the HIP events that bracket the sweep are created before the timed region, not inside it
     knn.kernel_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -224,16 +224,32 @@ def main():
         for ln in pipe.lanes:
             ln["knn"].kernel_events = knn.kernel_events
             ln["knn"].kernel_event_pool = knn.kernel_event_pool
+    # Python's cyclic collector off during the timed region: a full (generation-2) collection of this process takes
+    # ~40 ms, and whether one falls into the 110 ms of 200 steps depends on the allocation count so far - measured as
+    # 0.73 instead of 0.54 ms per step in most runs with --steps 200 and in none with --steps 400 / 1000
+    import gc
+    gc.collect()
+    gc.disable()
     fence()
+    prof = None
+    if os.environ.get("QPG_BENCH_CPROFILE", "") == "1":       # diagnostics: where the host spends the timed region
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     codes = run_steps(a.steps)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(8)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ms = [e0.elapsed_time(e1) for e0, e1 in knn.kernel_events]
+    ms = [e0.elapsed_time(e1) for e0, e1 in knn.kernel_events] if knn.kernel_events else [float("nan")]
     knn.kernel_events = None
     if pipe is not None:
         for ln in pipe.lanes:

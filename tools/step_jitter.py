@@ -12,7 +12,13 @@ dev = torch.device("cuda:0"); N, M = 2048, 6
 code = synth.make_codes(N, 2); sig = synth.make_signature(3)
 phase = np.random.Generator(np.random.PCG64(5)).standard_normal((N, 240, 4, 8)).astype(np.float32)
 interp, ctx = bench.chunked_db(N, 0, N, seed=0)
-db = GestureDB(code, interp, ctx, phase, sig, device=dev)
+if "like-bench" in sys.argv[1:]:       # the DB built the way bench.py builds it
+    import torch.distributed as dist    # noqa: F401
+    torch.cuda.set_device(dev)
+    db = GestureDB(code, bench._ShardView(interp, 0, N, N), bench._ShardView(ctx, 0, N, N), phase, sig, device=dev, rank=0,
+                   world=1, feature_dtype="f32")
+else:
+    db = GestureDB(code, interp, ctx, phase, sig, device=dev)
 clip = synth.make_db(M, 1000)
 te_i = torch.from_numpy(interp_wavlm(clip["wavlm"])).to(dev); te_c = torch.from_numpy(clip["context"].squeeze(2)).to(dev)
 knn = CodeKNN(db, rng=np.random.RandomState(123456))
@@ -28,6 +34,8 @@ def step():
     return t1 - t0, time.perf_counter() - t1
 for _ in range(10): step()
 torch.cuda.synchronize()
+if "events" in sys.argv[1:]:
+    knn.kernel_events = []
 for rep in range(3):
     t0 = time.perf_counter()
     r = np.array([step() for _ in range(400)]) * 1e6
