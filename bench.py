@@ -7,7 +7,10 @@ N_db = 2048 windows (synthetic, real schema: SURVEY.md §8d cfg-2), shipped flag
 (WavLM cosine f64 + text cosine f32 + phase gate).  A "step" is one complete pass of the hot
 path for one clip per GPU: query packing, both candidate sweeps, per-code argmin, ranks and the
 device-side matching walk, ending with the (M,30) code indices on the host.  The database is
-already resident in HBM when the timed region starts.
+already resident in HBM when the timed region starts.  --clips-in-flight N (one GPU) issues the K steps (K independent
+clips) with up to N in flight (code_knn.ClipPipeline: each clip goes through exactly the launches above on its own
+stream, every clip's indices are on the host before the timed region ends); the same clips one at a time are then
+timed right after and reported as `one_clip_at_a_time`.
 
 Modes
   --scaling weak   (default) N ranks: N clips (one per rank) vs the DB row-sharded N ways; every rank sweeps all N clips
@@ -73,9 +76,10 @@ def main():
     ap.add_argument("--clips", type=int, default=1, help="concurrent clips per GPU in one batched sweep")
     ap.add_argument("--clips-in-flight", type=int, default=1,
                     help="lanes of independent clips in flight (code_knn.ClipPipeline; single GPU, one clip per step): the "
-                         "next clip's sweeps run under the previous clip's select / walk / D2H.  Host-launch-rate bound: "
-                         "0.48 / 0.45 ms per clip with 2 / 3 lanes on a quiet host, slower than one at a time on a busy one, so the "
-                         "default line stays one clip at a time")
+                         "next clips' sweeps run under the previous clip's select / walk / D2H - 0.51 / 0.46 ms per clip "
+                         "with 2 / 3 lanes against 0.54 one at a time.  The default line stays one clip at a time: its "
+                         "`roofline` is then the sweep kernel ALONE on the GPU (with clips in flight the kernel's "
+                         "duration includes what the other clips' kernels take from it)")
     ap.add_argument("--encode-batch", type=int, default=0, help="pose windows VQ-VAE-encoded inside the timed step")
     ap.add_argument("--feature-dtype", choices=["f32", "f16"], default="f32")
     ap.add_argument("--workload", choices=["match", "cfg3"], default="match")
@@ -217,9 +221,12 @@ def main():
     run_steps(a.warmup)
     knn.kernel_events = [] if os.environ.get("QPG_BENCH_NO_EVENTS", "") != "1" else None     # (diagnostics)
     knn.kernel_events_every = int(os.environ.get("QPG_BENCH_EVENTS_EVERY", "1"))
-    # the HIP events that bracket the sweep are created before the timed region, not inside it
+    # the HIP events that bracket the sweep exist before the timed region (torch creates an event at its first record)
     knn.kernel_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                              for _ in range(a.steps * max(1, CL if strong else 1) + 8)]
+    for e0, e1 in knn.kernel_event_pool:
+        e0.record()
+        e1.record()
     if pipe is not None:
         for ln in pipe.lanes:
             ln["knn"].kernel_events = knn.kernel_events
@@ -263,19 +270,22 @@ def main():
     if pipe is not None:
         # the same clip, one at a time (a step = submit + wait): the latency figure, and the sweep kernel alone on the GPU
         n1 = min(a.steps, 100)
-        for _ in range(3):
+        for _ in range(10):
             step()
         knn.kernel_events = []
+        gc.collect()
+        gc.disable()
         fence()
         t1 = time.perf_counter()
         for _ in range(n1):
             c1 = step()
         fence()
         d1 = time.perf_counter() - t1
+        gc.enable()
         ms1 = [e0.elapsed_time(e1) for e0, e1 in knn.kernel_events]
         knn.kernel_events = None
         assert torch.equal(c1.reshape(-1).to(torch.int32), codes.reshape(-1)), "clips in flight changed the result"
-        serial = {"ms_per_clip": round(d1 / n1 * 1e3, 4), "frames_per_s": round(frames_per_step * n1 / d1, 1),
+        serial = {"latency_ms_per_clip": round(d1 / n1 * 1e3, 4), "frames_per_s": round(frames_per_step * n1 / d1, 1),
                   "steps": n1, "kernel_ms": round(float(np.mean(ms1)), 4)}
 
     # ---- roofline of the dominant kernel (audio_cosine_f64_kernel), per launch on this rank --------------
@@ -422,6 +432,9 @@ def vqvae_bench(dev, a, world, rank):
         if world > 1:
             dist.barrier()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        import gc
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         for e0, e1 in ev:
             e0.record()
@@ -429,6 +442,7 @@ def vqvae_bench(dev, a, world, rank):
             e1.record()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -100,6 +100,9 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
     if world > 1:
         dist.barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    import gc
+    gc.collect()
+    gc.disable()                       # (a full collection inside the timed region is ~40 ms)
     t0 = time.perf_counter()
     for e0, e1 in ev:
         e0.record()
@@ -109,6 +112,7 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

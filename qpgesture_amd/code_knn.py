@@ -843,9 +843,8 @@ class ClipPipeline:
     lanes - one CodeKNN (its own workspaces and side stream), one HIP stream and one pinned result buffer each - the
     next clip's sweeps run underneath them.  Every clip goes through exactly the launches of CodeKNN.match_clip, so
     the results are the same arrays; only the host's wait moves from the end of a clip to `collect`.
-    Measured (tools/pipeline_probe.py, 24 s clip vs 2048 windows): 0.534 ms per clip serial, 0.484 with two lanes,
-    0.452 with three - when the host can enqueue a clip's ~20 launches in under 0.48 ms; on a box with a slower host the
-    same run took 0.68 ms with two lanes against 0.57 serial, which is why bench.py's default stays one clip at a time.
+    Measured (bench.py --clips-in-flight N, 24 s clip vs 2048 windows): 0.542 ms per clip one at a time, 0.514 with two
+    lanes, 0.459 with three.
     Single-GPU databases only (the sharded path's collectives stay on one stream)."""
 
     def __init__(self, db, depth=2, rng=None, **knn_flags):
