@@ -273,6 +273,11 @@ def main():
         for _ in range(10):
             step()
         knn.kernel_events = []
+        knn.kernel_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                 for _ in range(n1 + 8)]
+        for e0, e1 in knn.kernel_event_pool:
+            e0.record()
+            e1.record()
         gc.collect()
         gc.disable()
         fence()
