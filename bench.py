@@ -90,9 +90,6 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run the text sweep after the audio sweep (one stream)")
     ap.add_argument("--text-first", action="store_true",
                     help="enqueue the text side before the audio side (round-1 order) instead of after the audio sweep")
-    ap.add_argument("--text-fused", action="store_true",
-                    help="text side with the per-code minimum folded into the sweep (qpg_text_percode_f32) instead of the "
-                         "Q x C matrix + select")
     ap.add_argument("--check", action="store_true", help="verify the matched codes against a 1-rank run")
     a = ap.parse_args()
 
@@ -144,7 +141,6 @@ def main():
     knn = CodeKNN(db, rng=np.random.RandomState(123456))
     knn.overlap_sweeps = not a.no_overlap
     knn.text_after_sweep = not a.text_first
-    knn.text_fused = a.text_fused
     knn.audio_precision = a.audio_precision
     if a.sharded_mixed_min_gflop is not None:
         knn.sharded_mixed_min_gflop = a.sharded_mixed_min_gflop

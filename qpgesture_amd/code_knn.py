@@ -252,7 +252,6 @@ class CodeKNN:
         self.rng = rng if rng is not None else np.random
         self.overlap_sweeps = True          # text sweep on a second HIP stream underneath the audio sweep
         self.text_after_sweep = True        # ... started when the audio sweep ends, i.e. underneath the audio SELECT
-        self.text_fused = False             # True (one GPU): per-code minimum folded into the text sweep (qpg_text_percode_f32)
         self.serial_walk = False            # True: force the one-wave sequential walk (tests compare the two)
         # Near-tie guard of the audio select (qpg_percode_select_guarded_f64): candidates / code minima closer than
         # tie_eps are re-evaluated in the reference's own arithmetic inside the select launch.  0 disables it.
@@ -401,18 +400,6 @@ class CodeKNN:
         else:
             qn = torch.empty_like(queries)
             _lib.call("qpg_l2_normalize_rows_f32", dev, queries, Q, db.Dt, qn)
-        if out is None and db.world == 1 and self.text_fused and db.Ct > 0:
-            # one GPU: the per-code minimum is folded into the sweep (look-first atomicMin on a [Q][K] table of
-            # (distance key << 32 | candidate) words, then one decode + rank launch): no Q x C matrix, no second pass
-            dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
-            idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
-            rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if want_rank else None
-            ws = torch.empty((Q * db.K * 8,), dtype=torch.uint8, device=dev)
-            _lib.call("qpg_text_percode_f32", dev, db.ctxt, db.Ct, db.Dt, db.txt_cand_code, db.K, qn, Q, 1,
-                      db.idx_base * db.Gt, float(ABSENT_DIST), ws, ws.numel(), dist, idx, rank, None)
-            if not reduce:
-                return dist, idx
-            return (dist, idx, rank) if want_rank else (dist, idx)
         D = torch.empty((Q, max(db.Ct, 1)), dtype=torch.float32, device=dev)
         _lib.call("qpg_text_cosine_f32", dev, db.ctxt, db.Ct, db.Dt, qn, Q, D, D.stride(0))
         if out is not None:

@@ -426,11 +426,7 @@ static int text_percode(qpg_ctx* ctx, void* stream, const float* xt, const float
     constexpr int QG = 12, NW = 8;
     const int64_t nqb = (Q + QG * NW - 1) / (QG * NW);
     const dim3 grid((unsigned)(((ntile + 7) / 8) * nqb * 8));
-    if (!nrm && Q <= 96) {         // one clip's steps: 4 queries per lane, as the matrix sweep at this size (more waves)
-      const int64_t nqb4 = (Q + 15) / 16;
-      hipLaunchKernelGGL((text_cosine_gmin_f32_kernel<4, 4, false>), dim3((unsigned)(((ntile + 7) / 8) * nqb4 * 8)), dim3(256),
-                         0, qpg_stream(stream), xt, C, Dm, cand_code, K, qn, Q, idx_base, partial, nrm);
-    } else if (nrm)
+    if (nrm)
       hipLaunchKernelGGL((text_cosine_gmin_f32_kernel<QG, NW, true>), grid, dim3(64 * NW), 0, qpg_stream(stream), xt, C, Dm,
                          cand_code, K, qn, Q, idx_base, partial, nrm);
     else

@@ -1,5 +1,5 @@
 """experiments: per-step wall-time distribution of the default matching step (one clip at a time) - is a slow run a
-uniform shift or a few long steps?  python tools/step_jitter.py [text-first] [text-fused]"""
+uniform shift or a few long steps?  python tools/step_jitter.py [text-first]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,7 +23,6 @@ clip = synth.make_db(M, 1000)
 te_i = torch.from_numpy(interp_wavlm(clip["wavlm"])).to(dev); te_c = torch.from_numpy(clip["context"].squeeze(2)).to(dev)
 knn = CodeKNN(db, rng=np.random.RandomState(123456))
 knn.text_after_sweep = "text-first" not in sys.argv[1:]
-knn.text_fused = "text-fused" in sys.argv[1:]
 sc, sp = knn.init_code_phase(); spd = torch.from_numpy(sp).to(dev)
 def step():
     t0 = time.perf_counter()
@@ -41,8 +40,8 @@ for rep in range(3):
     r = np.array([step() for _ in range(400)]) * 1e6
     tot = (time.perf_counter() - t0) / 400 * 1e6
     w = r.sum(1)
-    print("%s %s rep %d: mean %.0f us (loop %.0f)  median %.0f  p90 %.0f  p99 %.0f  max %.0f | enqueue median %.0f p99 %.0f | wait median %.0f p99 %.0f | "
-          "time in steps > 1.5x median: %.0f%%" % ("after" if knn.text_after_sweep else "text-first", "fused" if knn.text_fused else "matrix", rep, w.mean(), tot, np.median(w), np.percentile(w, 90),
+    print("%s rep %d: mean %.0f us (loop %.0f)  median %.0f  p90 %.0f  p99 %.0f  max %.0f | enqueue median %.0f p99 %.0f | wait median %.0f p99 %.0f | "
+          "time in steps > 1.5x median: %.0f%%" % ("after" if knn.text_after_sweep else "text-first", rep, w.mean(), tot, np.median(w), np.percentile(w, 90),
                                                  np.percentile(w, 99), w.max(), np.median(r[:, 0]), np.percentile(r[:, 0], 99),
                                                  np.median(r[:, 1]), np.percentile(r[:, 1], 99),
                                                  100 * w[w > 1.5 * np.median(w)].sum() / w.sum()), flush=True)
