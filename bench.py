@@ -59,6 +59,24 @@ def chunked_db(n_db, lo, hi, seed, F=1024):
     return (np.concatenate([p["interp"] for p in parts]), np.concatenate([p["ctx"] for p in parts]))
 
 
+def self_launch(n, argv=None, extra_env=None):
+    """Re-exec this script as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>`
+    (127.0.0.1 rendezvous on a free port) and pass its output through.  Returns the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    cmd += list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.update(extra_env or {})
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,9 +88,10 @@ def main():
     ap.add_argument("--sharded-mixed-min-gflop", type=float, default=None,
                     help="row shards sweep in mixed precision when their sweep is at least this long (default: "
                          "CodeKNN.sharded_mixed_min_gflop = 20; 0 = always)")
-    ap.add_argument("--audio-precision", choices=["mixed", "f64"], default="mixed",
+    ap.add_argument("--audio-precision", choices=["mixed", "f64", "exact"], default="mixed",
                     help="mixed (default, the product default): f32 matrix-core sweep with an a-priori error bound + f64 / "
-                         "reference-arithmetic re-evaluation of every undecided comparison; f64: the f64 matrix-core sweep")
+                         "reference-arithmetic re-evaluation of every undecided comparison; f64: the f64 matrix-core sweep; "
+                         "exact: f64 sweep + the uncapped near-tie guard (the path flagged clips are re-matched on)")
     ap.add_argument("--clips", type=int, default=1, help="concurrent clips per GPU in one batched sweep")
     ap.add_argument("--clips-in-flight", type=int, default=1,
                     help="lanes of independent clips in flight (code_knn.ClipPipeline; single GPU, one clip per step): the "
@@ -86,12 +105,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vqvae", action="store_true", help="skip the VQ-VAE legs")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (H2D-inclusive) measurements")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the time-based pre-warm (clock steady state)")
+    ap.add_argument("--no-f64-line", action="store_true", help="skip the extra f64-sweep steps (`f64_sweep` object)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="DB windows in the CPU baseline sample")
     ap.add_argument("--no-overlap", action="store_true", help="run the text sweep after the audio sweep (one stream)")
     ap.add_argument("--text-first", action="store_true",
                     help="enqueue the text side before the audio side (round-1 order) instead of after the audio sweep")
     ap.add_argument("--check", action="store_true", help="verify the matched codes against a 1-rank run")
+    ap.add_argument("--mixed-requests", type=int, default=None,
+                    help="(testing) request slots per (owner, shard) pair of the sharded mixed-precision merge: a tiny "
+                         "value forces the overflow -> agreed re-match path")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver types it: become the launcher - one rank per GPU under
+        # torch.distributed.run (RCCL), rank 0 prints the ONE JSON line, which passes through
+        sys.exit(self_launch(a.gpus))
 
     import torch
     import torch.distributed as dist
@@ -108,9 +137,24 @@ def main():
     # QPG_BENCH_ONE_GPU=nccl: the same, but over backend nccl (RCCL) if it accepts two ranks on one device.
     one_gpu = os.environ.get("QPG_BENCH_ONE_GPU", "")
     dev = torch.device("cuda", 0 if one_gpu else local)
-    torch.cuda.set_device(dev)
-    if world > 1:
+    # QPG_BENCH_FORCE_SHARDED=1 (testing / measurement on a 1-GPU box): ONE rank takes the row-shard code path - exchange
+    # layout, the collectives over backend nccl (RCCL) with world_size 1, the merge kernels with W = 1
+    force_sharded = os.environ.get("QPG_BENCH_FORCE_SHARDED", "") == "1"
+    if os.environ.get("QPG_BENCH_LAUNCH_CHECK", "") == "1":
+        # launcher self-test (CPU, gloo): prove that every rank of `--gpus N` came up and can talk, print ONE line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": int(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+    torch.cuda.set_device(dev)
+    if world > 1 or force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
         if one_gpu == "1":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -120,7 +164,7 @@ def main():
         out = cfg3_bench(a, dev, world, rank)
         if rank == 0:
             print(json.dumps(out), flush=True)
-        if world > 1:
+        if world > 1 or force_sharded:
             dist.destroy_process_group()
         return
 
@@ -144,10 +188,14 @@ def main():
     knn.audio_precision = a.audio_precision
     if a.sharded_mixed_min_gflop is not None:
         knn.sharded_mixed_min_gflop = a.sharded_mixed_min_gflop
+    if a.mixed_requests is not None:
+        knn.mixed_requests = a.mixed_requests
+    knn.force_sharded = force_sharded
     # the mixed-precision sweep: one GPU, or row shards whose merge re-evaluates through a request / response exchange
     # (taken when the shard's sweep is long enough to pay for the two extra exchanges: CodeKNN.sharded_mixed_min_gflop)
     shard_gflop = 2e-9 * (M * 8 * (CL if strong else CL * world)) * (per * 26) * 6 * 1024
-    mixed = a.audio_precision == "mixed" and (world == 1 or shard_gflop >= knn.sharded_mixed_min_gflop)
+    sharded_run = world > 1 or force_sharded
+    mixed = a.audio_precision == "mixed" and (not sharded_run or shard_gflop >= knn.sharded_mixed_min_gflop)
 
     # clips: weak = CL per rank (every rank holds all of them: M*180*1024 f32 = 4.4 MB each); strong = ONE clip in all
     n_clips = CL if strong else CL * world
@@ -165,20 +213,35 @@ def main():
 
     my_clips = CL                       # clips whose tables this rank ends up with (and walks)
 
+    n_codes = M * 30
+    rematched = [0]
+
     def step():
         # weak, N > 1: every rank sweeps all clips' queries against its DB shard; ONE all-to-all leaves each rank with
         # the final tables of its own clips.  strong: ONE all-gather + merge, every rank holds the clip's tables.
         if enc is not None:
             ids = enc.encode(enc_x)[0]
-        T = knn.sweep_tables(te_interp, te_ctx, M * n_clips, owner_blocks=world > 1 and not strong)
+        T = knn.sweep_tables(te_interp, te_ctx, M * n_clips, owner_blocks=(world > 1 or force_sharded) and not strong)
         outs = []
         for c in range(my_clips):      # each clip is an independent chain (its own seed / window chaining)
-            oc, _, _, _ = knn.walk(T, M, window_offset=c * M, seed_code=seed_code, seed_phase=seed_phase_d, sync=False)
-            outs.append(oc)
-        res = (torch.cat(outs) if len(outs) > 1 else outs[0]).cpu()   # the step ends with the indices on the host
+            knn.walk(T, M, window_offset=c * M, seed_code=seed_code, seed_phase=seed_phase_d, sync=False)
+            outs.append(knn._last_ints)                        # codes | votes | status (2): ONE D2H per step
+        res = (torch.cat(outs) if len(outs) > 1 else outs[0]).cpu().view(my_clips, -1)   # the step ends on the host
         if enc is not None:
             ids.cpu()
-        return res
+        if int(res[:, -1].max()) != 0 and knn.audio_precision != "exact":
+            # the near-tie guard's trouble word came out with the codes (on a sharded DB every rank sees the same,
+            # MAX-reduced word): this step again on the uncapped path - unguarded codes are never used
+            rematched[0] += 1
+            prev, knn.audio_precision = knn.audio_precision, "exact"
+            knn.clear_flags()
+            try:
+                return step()
+            finally:
+                knn.audio_precision = prev
+        for c in range(my_clips):
+            knn.check_status(res[c, -2:].tolist())
+        return res[:, :n_codes].reshape(my_clips * M, 30)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -214,6 +277,31 @@ def main():
                 res = step()
             return res
 
+    # Clock / cache steady state regardless of --warmup (the driver's 20-step run was 13 % slower than the
+    # 200-step profile, the GPU having idled for ~20 s of host-side data generation before a 12 ms timed region):
+    # untimed steps until at least 1 s of back-to-back work has run AND three consecutive 10-step means agree within
+    # 2 % (bounded at 6 s).  Not part of --warmup / --steps, which keep their contract meaning.
+    prewarm = {"seconds": 0.0, "steps": 0, "settled": False}
+    if not a.no_prewarm:
+        tp0 = time.perf_counter()
+        means = []
+        while True:
+            t_ = time.perf_counter()
+            run_steps(10)
+            torch.cuda.synchronize(dev)
+            means.append((time.perf_counter() - t_) / 10)
+            prewarm["steps"] += 10
+            el = time.perf_counter() - tp0
+            ok3 = len(means) >= 3 and max(means[-3:]) <= 1.02 * min(means[-3:])
+            stop = (el >= 1.0 and ok3) or el >= 6.0
+            if world > 1:                                   # all ranks leave the loop together
+                f = torch.tensor([1 if (el >= 1.0 and ok3) else 0, 0 if el >= 6.0 else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(f, op=dist.ReduceOp.MIN)
+                stop = bool(f[0].item() == 1 or f[1].item() == 0)
+            if stop:
+                prewarm.update(seconds=round(el, 3), settled=bool(ok3),
+                               last_10step_means_ms=[round(x * 1e3, 4) for x in means[-3:]])
+                break
     run_steps(a.warmup)
     knn.kernel_events = [] if os.environ.get("QPG_BENCH_NO_EVENTS", "") != "1" else None     # (diagnostics)
     knn.kernel_events_every = int(os.environ.get("QPG_BENCH_EVENTS_EVERY", "1"))
@@ -303,6 +391,7 @@ def main():
                 # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
                 # measured for exactly this launch shape only: profiles/r02_pmc_audio.md
                 "traffic": (AUDIO_MX_TRAFFIC_BYTES if mixed else AUDIO_TRAFFIC_BYTES) if default_shape else None,
+                "traffic_source": TRAFFIC_SOURCE if default_shape else None,
                 "kernel": ("audio_cosine_mx2_kernel (one launch: LDS-shared-query blocks + split-K remainder blocks; f32 "
                            "matrix cores, error bounded a priori, f64 re-evaluation in the select)")
                 if mixed else "audio_cosine_f64_kernel",
@@ -311,7 +400,8 @@ def main():
                             "launch (alone: one_clip_at_a_time.kernel_ms)" % a.clips_in_flight}
                    if a.clips_in_flight > 1 else {}),
                 "kernel_ms": round(k_ms, 4),
-                "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_launches_timed": len(ms),
+                "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_ms_median": round(float(np.median(ms)), 4),
+                "kernel_ms_max": round(float(np.max(ms)), 4), "kernel_launches_timed": len(ms),
                 "algorithmic_gflop": round(flops / 1e9, 3),
                 "algorithmic_bytes": int(alg_bytes),
                 "hbm_gbs_algorithmic": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1),
@@ -341,16 +431,46 @@ def main():
            "realtime_factor": round(24.0 * M / 6 / (dt / a.steps), 1) if strong
            else round(value / 60.0 / world, 1)}
 
+    out["prewarm"] = prewarm
+    out["rematched_steps"] = rematched[0] + (pipe.fallbacks if pipe is not None else 0)
+    if mixed and not sharded_run and CL == 1 and pipe is None and enc is None and not a.no_f64_line:
+        # the reference-precision figure beside the mixed one, in the same record: 20 more steps with the f64 sweep
+        knn.audio_precision = "f64"
+        for _ in range(5):
+            step()
+        knn.kernel_events, knn.kernel_event_pool = [], [(torch.cuda.Event(enable_timing=True),
+                                                          torch.cuda.Event(enable_timing=True)) for _ in range(28)]
+        for e0, e1 in knn.kernel_event_pool:
+            e0.record()
+            e1.record()
+        gc.collect()
+        gc.disable()
+        fence()
+        t6 = time.perf_counter()
+        for _ in range(20):
+            c64 = step()
+        fence()
+        d6 = time.perf_counter() - t6
+        gc.enable()
+        ms6 = [e0.elapsed_time(e1) for e0, e1 in knn.kernel_events]
+        knn.kernel_events = None
+        knn.audio_precision = a.audio_precision
+        k6 = float(np.mean(ms6))
+        out["f64_sweep"] = {"ms_per_step": round(d6 / 20 * 1e3, 4), "steps": 20, "kernel": "audio_cosine_f64_kernel",
+                            "kernel_ms": round(k6, 4), "kernel_ms_min": round(float(np.min(ms6)), 4),
+                            "achieved": round(flops / (k6 * 1e-3) / 1e12, 3), "peak": F64_MFMA_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(flops / (k6 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
+                            "codes_equal_default_path": bool(torch.equal(c64, codes))}
     if serial is not None:
         serial["roofline_frac"] = round(flops / (serial["kernel_ms"] * 1e-3) / 1e12 / peak, 4)
         out["one_clip_at_a_time"] = serial
-    if mixed and world > 1:
+    if mixed and sharded_run:
         st = knn.mixed_stats()
         fl = knn._guard_stats.cpu().numpy()
         out["mixed_precision"] = {"shard_f64_dot_pairs_per_step": round(st["tier1_pairs"] / (a.steps + a.warmup), 1),
                                   "cross_shard_reevaluations_per_step": round(int(fl[3]) / (a.steps + a.warmup), 1),
                                   "flags": st["flags"], "error_bound": 2.05e-6}
-    if mixed and world == 1:
+    if mixed and not sharded_run:
         # re-evaluation activity of the timed steps (+ warm-up) and the same clip through the f64 sweep: the mixed path
         # must return the same codes (its tables differ only inside the sweep's error bound)
         st = knn.mixed_stats()
@@ -400,12 +520,13 @@ def main():
         assert ok, "rank %d: sharded result differs from the single-rank result" % rank
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_sharded:
         dist.destroy_process_group()
 
 
 # HBM bytes per audio_cosine_f64_kernel launch at the default shape (N_db=2048, Q=48), rocprofv3 PMC, separate
 # --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 correction on FETCH_SIZE: profiles/r02_pmc_audio.md
+TRAFFIC_SOURCE = "profiles/r02_pmc_audio.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch shape; not re-measured per run)"
 AUDIO_TRAFFIC_BYTES = 923_000_000
 AUDIO_MX_TRAFFIC_BYTES = 1_023_000_000    # mixed-precision sweep (one launch: mx2 blocks + split-K remainder), same file
 

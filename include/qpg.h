@@ -228,6 +228,18 @@ int qpg_percode_select_guarded_f64(qpg_ctx*, void* stream, const double* D, int6
 /* base_is_f16 != 0 (here and in qpg_percode_select_mixed_f64): `base` points at an IEEE f16 track (as swept by
  * qpg_audio_cosine_f64_h / qpg_audio_cosine_mx_h); the re-evaluation then runs on the widened, i.e. rounded, values. */
 
+/* UNCAPPED form of the guarded select (round 3): same arguments, results and arithmetic, but every list lives in `ws`
+ * ([dev] qpg_percode_select_exact_ws_bytes(Q, C, K) bytes, 16-byte aligned; sized for ALL C candidates of a row inside
+ * one band), so no population of near-ties can overflow it and stats[1] is never raised: the reference's scan
+ * (GestureKNN.py:685-689) visits every candidate with a strict `<` and has no cap either.  This is the path the host
+ * re-matches a clip on when a capped select or the mixed-precision sweep raised stats[1].  Five launches; K <= 1024. */
+int64_t qpg_percode_select_exact_ws_bytes(int Q, int64_t C, int K);
+int qpg_percode_select_exact_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int16_t* cand_code,
+                                 int64_t C, int K, double absent, int32_t idx_base, double* out_dist, int32_t* out_idx,
+                                 int16_t* out_rank, int q_block, int64_t block_stride, const float* base, int T, int F,
+                                 const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32, double eps,
+                                 int32_t* stats, int base_is_f16, void* ws, int64_t ws_bytes);
+
 /* Select for the matrix of qpg_audio_cosine_mx.  Same outputs as qpg_percode_select_guarded_f64.  Two sweep values
  * further apart than eps1 (>= 2 x QPG_AUDIO_MX_ERR) are ordered like the exact distances; inside that band
  *   tier 1: all candidates within eps1 of their code's minimum (if two or more) and the winners of codes whose minima
@@ -256,31 +268,42 @@ int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K);
  *       more — and the winners of codes whose merged minima are rank neighbours within eps1 become requests to the
  *       shard holding the candidate.  req: [dev] W blocks of req_stride bytes, block w = [i64 count][R x u64
  *       (q_local << 48 | code << 32 | global candidate)]: the send buffer of an all-to-all.  ws: [dev] scratch of
- *       qpg_merge_mixed_ws_bytes(Q, K) bytes, kept for phase 2.  stats[1] |= 4 on request / flag-list overflow.
+ *       qpg_merge_mixed_ws_bytes(Q, K, fl_cap) bytes, kept for phase 2 (fl_cap = flagged (code, shard) entries per
+ *       query).  stats[1] |= 4 on request / flag-list overflow: every written request is valid and every counted flag
+ *       entry written, the surplus is dropped and the clip must be re-matched (R = Q*K and fl_cap = K*W cannot overflow).
  *   qpg_shard_refine_f64        (every shard)  req_recv = the W request blocks received (block o from owner o); the
  *       exact f64 distance of every requested (query o*q_stride + q_local, candidate - cand_base) goes to resp block o
- *       ([R x f64], resp_stride bytes apart): the send buffer of the answering all-to-all.
+ *       ([R x f64], resp_stride bytes apart): the send buffer of the answering all-to-all.  reference_arithmetic != 0:
+ *       the distance in the reference's own arithmetic instead (sklearn normalise + einsum-order sum, as tier 2).
  *   qpg_merge_mixed_phase2_f64  (owner)  winners among the re-evaluated contenders by (exact value, candidate), stable
- *       ranks over re-evaluated and untouched minima.  stats[3] += re-evaluated entries. */
-int64_t qpg_merge_mixed_ws_bytes(int Q, int K);
+ *       ranks over re-evaluated and untouched minima.  stats[3] += re-evaluated entries.  eps2 > 0: contenders of one
+ *       code, or minima of rank-neighbour codes, closer than eps2 raise stats[1] |= 8 (dot-product responses cannot
+ *       order them like the reference; the host re-matches the clip with reference-arithmetic responses and eps2 = 0).
+ * The same three calls with eps1 = the near-tie band (1e-12), reference_arithmetic = 1 and eps2 = 0 are the cross-shard
+ * TIER 2: the uncapped sharded path (CodeKNN, audio_precision "exact"). */
+int64_t qpg_merge_mixed_ws_bytes(int Q, int K, int fl_cap);
 int qpg_merge_mixed_phase1_f64(qpg_ctx*, void* stream, const void* recv, int W, int64_t src_stride, int64_t dist_off,
                                int64_t idx_off, int Q, int K, double absent, double eps1, int R, void* req,
-                               int64_t req_stride, void* ws, int64_t ws_bytes, int32_t* stats);
+                               int64_t req_stride, void* ws, int64_t ws_bytes, int32_t* stats, int fl_cap);
 int qpg_shard_refine_f64(qpg_ctx*, void* stream, const void* req_recv, int W, int64_t req_stride, int R, int q_stride,
                          int64_t cand_base, const float* base, int base_is_f16, int T, int F, const int32_t* cand_t, int G,
                          int n_taps, int tap_stride, const float* q32, const double* qn2, const double* cn2, void* resp,
-                         int64_t resp_stride);
+                         int64_t resp_stride, int reference_arithmetic);
 int qpg_merge_mixed_phase2_f64(qpg_ctx*, void* stream, const void* recv, int W, int64_t src_stride, int64_t idx_off, int Q,
                                int K, double absent, const void* ws, int64_t ws_bytes, const void* resp_recv,
-                               int64_t resp_stride, double* out_dist, int32_t* out_idx, int16_t* out_rank, int32_t* stats);
+                               int64_t resp_stride, double* out_dist, int32_t* out_idx, int16_t* out_rank, int32_t* stats,
+                               int fl_cap, double eps2);
 
 /* Cross-shard min + index merge after the RCCL exchange (the all-reduce(min, index) `north_star`
  * names, as all-gather / all-to-all + this kernel): source w's tables start at recv + w*src_stride (+ dist_off for the
  * [Q][K] distances, + idx_off for the [Q][K] i32 global candidate indices, -1 = absent in that shard).  Winner per
- * (query, code): minimum distance, lowest index among equals.  out_rank (optional): stable ranks of the merged row. */
+ * (query, code): minimum distance, lowest index among equals.  out_rank (optional): stable ranks of the merged row.
+ * _f64 only: eps2 > 0 with stats != NULL raises stats[1] |= 8 when two shards' minima of one code, or the merged minima
+ * of rank-neighbour codes, are closer than eps2 (the shards settle near-ties inside themselves only; the host then
+ * re-matches the clip on the uncapped path, whose merge compares such pairs in the reference's own arithmetic). */
 int qpg_merge_select_f64(qpg_ctx*, void* stream, const void* recv, int W, int64_t src_stride, int64_t dist_off,
                          int64_t idx_off, int Q, int K, double absent, double* out_dist, int32_t* out_idx,
-                         int16_t* out_rank);
+                         int16_t* out_rank, double eps2, int32_t* stats);
 int qpg_merge_select_f32(qpg_ctx*, void* stream, const void* recv, int W, int64_t src_stride, int64_t dist_off,
                          int64_t idx_off, int Q, int K, float absent, float* out_dist, int32_t* out_idx,
                          int16_t* out_rank);
@@ -318,8 +341,11 @@ int qpg_l2_table_f32(qpg_ctx*, void* stream, const float* sig, int K, int Dm, fl
  *                      code), and the gate outcome for every (step, previous code, previous vote) — both
  *                      tabulated in parallel, so that the sequential part is Q dependent 2-byte lookups;
  *   out_codes [dev] i32 [M][30]; out_phase [dev] f32 [M][steps][8][16]; out_vote [dev] i32 [M][steps];
- *   out_status [dev] i32 [1]: 1 if a code absent from the DB won a rank fusion (the reference raises
- *   IndexError there, GestureKNN.py:631-632).
+ *   out_status [dev] i32 [2]: [0] = 1 if a code absent from the DB won a rank fusion (the reference raises
+ *   IndexError there, GestureKNN.py:631-632); [1] = *guard_flags (0 if NULL): the trouble word stats[1] of the
+ *   sweeps / selects that produced the tables (list overflow, norms outside the error bound's range, cross-shard
+ *   near tie), copied by the walk's last kernel so that it leaves the device in the same D2H copy as the codes —
+ *   the host must not use codes whose status[1] != 0 (CodeKNN re-matches such a clip on the uncapped exact path).
  * combined = (pos_rank + freq_rank*0.05) + rank in float64 in that order; argmin = lowest index. */
 int qpg_match_steps(qpg_ctx*, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
                     const int16_t* txt_rank, const int32_t* txt_idx, const int16_t* pos_rank,
@@ -327,7 +353,7 @@ int qpg_match_steps(qpg_ctx*, void* stream, const int16_t* aud_rank, const int32
                     const int32_t* aud_pslot, int Ga, const int32_t* txt_cidx, const int32_t* txt_pslot, int Gt,
                     const float* phase, int Tp, int mode, int M, int steps, int K, int seed_code,
                     const float* seed_phase, int32_t* gate_tables, int32_t* out_codes, float* out_phase,
-                    int32_t* out_vote, int32_t* out_status);
+                    int32_t* out_vote, int32_t* out_status, const int32_t* guard_flags);
 
 /* ------------------------------------------------------------------------------------------
  * Gesture VQ-VAE (codebook/models/{vqvae,encdec,resnet,bottleneck}.py).  Activations are channels-last

@@ -46,9 +46,11 @@ def build_parser():
     p.add_argument('--mode', choices=["shipped", "audio", "text", "wavvq", "wavvq_audio"], default="shipped")
     p.add_argument('--seed', type=int, default=seed_value)
     p.add_argument('--tie_rule', choices=["numpy", "stable"], default="numpy")
-    p.add_argument('--audio_precision', choices=["mixed", "f64"], default="mixed",
+    p.add_argument('--audio_precision', choices=["mixed", "f64", "exact"], default="mixed",
                    help="mixed: f32 matrix-core sweep with an a-priori error bound + exact re-evaluation of every "
-                        "undecided comparison (same output); f64: the f64 matrix-core sweep")
+                        "undecided comparison (same output); f64: the f64 matrix-core sweep; exact: f64 sweep + the uncapped "
+                        "near-tie guard.  A clip on which a capped guard of mixed / f64 raises its trouble word is "
+                        "re-matched on `exact` automatically: unguarded codes are never written")
     return p
 
 
@@ -82,8 +84,10 @@ def main_codebook(args, maxFrames=0):
     print('begin search...')
     mode = {"shipped": MODE_AUD_TXT, "audio": MODE_AUD, "text": MODE_TXT, "wavvq": MODE_AUD_TXT,
             "wavvq_audio": MODE_AUD}[args.mode]
-    pred_seqs, _, _ = knn.match_clip(te_i, te_c, n_test_seq, mode=mode)
+    pred_seqs, _, _ = knn.match_clip(te_i, te_c, n_test_seq, mode=mode)   # (re-matches on the uncapped path if flagged)
     t2 = time.time()
+    if knn.fallbacks:
+        print('near-tie guard: a capped re-evaluation list overflowed; the clip was re-matched on the uncapped path')
     print(pred_seqs.shape)
     np.savez_compressed(args.out_knn_filename, knn_pred=pred_seqs)               # :845
     print('load+prepare %.2fs, match %.4fs (%.0f frames/s)' % (t1 - t0, t2 - t1, 240 * n_test_seq / (t2 - t1)))

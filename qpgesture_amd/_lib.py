@@ -48,10 +48,12 @@ _SIGS = {
                                        c_double, P, I],
     "qpg_percode_select_mixed_f64": [P, I, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
                                      P, P, c_double, c_double, P, P, L, I],
-    "qpg_merge_mixed_phase1_f64": [P, I, L, L, L, I, I, c_double, c_double, I, P, L, P, L, P],
-    "qpg_shard_refine_f64": [P, I, L, I, I, L, P, I, I, I, P, I, I, I, P, P, P, P, L],
-    "qpg_merge_mixed_phase2_f64": [P, I, L, L, I, I, c_double, P, L, P, L, P, P, P, P],
-    "qpg_merge_select_f64": [P, I, L, L, L, I, I, c_double, P, P, P],
+    "qpg_percode_select_exact_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
+                                     c_double, P, I, P, L],
+    "qpg_merge_mixed_phase1_f64": [P, I, L, L, L, I, I, c_double, c_double, I, P, L, P, L, P, I],
+    "qpg_shard_refine_f64": [P, I, L, I, I, L, P, I, I, I, P, I, I, I, P, P, P, P, L, I],
+    "qpg_merge_mixed_phase2_f64": [P, I, L, L, I, I, c_double, P, L, P, L, P, P, P, P, I, c_double],
+    "qpg_merge_select_f64": [P, I, L, L, L, I, I, c_double, P, P, P, c_double, P],
     "qpg_merge_select_f32": [P, I, L, L, L, I, I, c_float, P, P, P],
     "qpg_percode_argmin_f64": [P, L, I, P, I, I, P, I, I, c_double, ctypes.c_int32, P, P],
     "qpg_percode_argmin_f32": [P, L, I, P, I, I, P, I, I, c_float, ctypes.c_int32, P, P],
@@ -78,7 +80,7 @@ _SIGS = {
     "qpg_conv1d_bwd_data_f32": [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, L],
     "qpg_conv1d_bwd_weight_f32": [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, L],
     "qpg_adam_step_f32": [P, P, P, P, L, c_float, c_float, c_float, c_float, L],
-    "qpg_match_steps": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P],
+    "qpg_match_steps": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P, P],
 }
 
 
@@ -138,7 +140,9 @@ def load():
     lib.qpg_text_percode_ws_bytes.restype = c_int64
     lib.qpg_percode_select_mixed_ws_bytes.argtypes = [c_int, c_int]
     lib.qpg_percode_select_mixed_ws_bytes.restype = c_int64
-    lib.qpg_merge_mixed_ws_bytes.argtypes = [c_int, c_int]
+    lib.qpg_merge_mixed_ws_bytes.argtypes = [c_int, c_int, c_int]
+    lib.qpg_percode_select_exact_ws_bytes.argtypes = [c_int, c_int64, c_int]
+    lib.qpg_percode_select_exact_ws_bytes.restype = c_int64
     lib.qpg_merge_mixed_ws_bytes.restype = c_int64
     lib.qpg_debug_convt_shape.argtypes = [c_int, c_int]
     lib.qpg_vq_reduce_ws_bytes.argtypes = []

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .parallel import allreduce_min_index, exchange_bytes, shard_rows
+from .parallel import allreduce_max_, allreduce_min_index, exchange_bytes, shard_rows
 import ctypes
 
 from .constant import (ABSENT_DIST, NUM_AUDIO_FEAT_FRAMES, STEP_SZ, WAVVQ_GROUP_SIZE, codebook_size, num_frames,
@@ -24,6 +24,20 @@ MODE_AUD_TXT, MODE_AUD, MODE_TXT = 0, 1, 2
 # like the exact distances; 5 % margin on top)
 AUDIO_MX_ERR = 2.05e-6
 AUDIO_MX_BAND = 2.1 * AUDIO_MX_ERR
+
+# bits of the trouble word the sweeps / selects raise (stats[1] of include/qpg.h) and the walk carries out with the codes
+FLAG_LIST_OVERFLOW, FLAG_SMALL_NORMS, FLAG_REQUEST_OVERFLOW, FLAG_CROSS_SHARD_TIE = 1, 2, 4, 8
+
+
+class GuardOverflow(RuntimeError):
+    """The capped near-tie machinery of the fast audio paths could not guarantee the reference's candidates for this
+    clip (a re-evaluation list overflowed, operand norms left the error bound's range, or shard minima tied across the
+    exchange).  `flags` holds the FLAG_* bits.  CodeKNN.match_clip / ClipPipeline.collect / the CLI catch it and
+    re-match the clip on the uncapped path (audio_precision "exact"); codes of a flagged clip are never returned."""
+
+    def __init__(self, flags):
+        super().__init__("near-tie guard raised flags 0x%x: results of the capped path are not guaranteed" % flags)
+        self.flags = int(flags)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -262,13 +276,21 @@ class CodeKNN:
         # open with f64 dot products, then the near-tie guard (qpg_percode_select_mixed_f64): same candidates and ranks
         # as "f64", the sweep at twice the matrix rate.  Taken only where the select sees every comparison that
         # follows (single-GPU DB, ranks fused, guard on; f32 or f16 base); everything else runs the f64 sweep.
+        # "exact" (round 3): the f64 sweep + the UNCAPPED guard (qpg_percode_select_exact_f64; across shards a
+        # reference-arithmetic request / response round): no list that can overflow, whatever the data.  It is the path
+        # a clip is re-matched on when the faster ones raise their trouble word (GuardOverflow), and can be selected
+        # outright.  fallbacks counts the clips that took it that way.
         self.audio_precision = "mixed"
+        self.fallbacks = 0
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
         # Row-sharded DB: the shards sweep in mixed precision too and the cross-shard merge re-evaluates what their
         # bounded tables leave open through a request / response exchange (sweep_tables; qpg_merge_mixed_*).
         # Two more (small) exchanges buy a sweep at ~1.6x the rate, so it is used where the shard's sweep is long enough
         # to pay for them: at least sharded_mixed_min_gflop per rank and step (24 s clip x 2048 windows = 31 GFLOP).
         self.sharded_mixed = True
+        # force_sharded: take the row-shard code path (exchange layout, collectives, merge kernels) even with world == 1,
+        # so that a one-GPU box can execute it over RCCL (backend nccl, world_size 1): tests / bench only
+        self.force_sharded = False
         self.sharded_mixed_min_gflop = 20.0
         self.mixed_requests = None          # request slots per (owner, shard) pair and step; None: 16384 / world
         # host_ranks (the CLI's --tie_rule numpy): rank the (Q,512) audio / text minima with the reference's own
@@ -323,13 +345,14 @@ class CodeKNN:
         fused_rank = want_rank and db.world == 1
         half = db.feature_dtype == "f16"
         local_final = fused_rank and reduce and out is None               # one GPU: this select decides everything
-        shard_part = db.world > 1 and not reduce and out is not None        # row shard: sweep_tables merges (mixed protocol)
+        shard_part = (db.world > 1 or self.force_sharded) and not reduce and out is not None   # row shard: sweep_tables merges
         # (the same number on every rank — the largest shard's — so that all ranks take the same path: the mixed merge
         # has two more collectives than the f64 one)
         gflop = 2e-9 * Q * (-(-db.N // db.world) * db.Ga) * NUM_AUDIO_FEAT_FRAMES * db.F
         mixed = (self.audio_precision == "mixed" and self.tie_eps > 0 and C > 0 and db.K <= 512 and
                  (local_final or (shard_part and self.sharded_mixed and gflop >= self.sharded_mixed_min_gflop)))
-        self._last_audio_mixed = mixed
+        exact = self.audio_precision == "exact" and self.tie_eps > 0 and C > 0
+        self._last_audio_mixed, self._last_audio_exact = mixed, exact
         # the mixed-precision sweep stores its matrix in f32: it only feeds the select's two streaming passes
         D = torch.empty((Q, max(C, 1)), dtype=torch.float32 if mixed else torch.float64, device=dev)
         ev = getattr(self, "kernel_events", None)       # bench.py: HIP events around the dominant kernel
@@ -374,6 +397,15 @@ class CodeKNN:
                       db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2, AUDIO_MX_BAND, float(self.tie_eps),
                       self._guard_stats, None if self.mixed_single_launch else ws,
                       0 if self.mixed_single_launch else ws.numel(), int(half))
+        elif exact:
+            need = int(_lib.load().qpg_percode_select_exact_ws_bytes(Q, C, db.K))
+            ws = getattr(self, "_exact_ws", None)
+            if ws is None or ws.numel() < need:
+                ws = self._exact_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+            _lib.call("qpg_percode_select_exact_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K,
+                      float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
+                      db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, float(self.tie_eps), self._guard_stats, int(half),
+                      ws, ws.numel())
         elif self.tie_eps > 0 and C > 0:
             _lib.call("qpg_percode_select_guarded_f64", dev, D, D.stride(0), Q, db.aud_cand_code, C, db.K,
                       float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
@@ -502,13 +534,30 @@ class CodeKNN:
         v = self._guard_stats.cpu().numpy()
         return {"tier1_pairs": int(v[2]), "tier2_pairs": int(v[0]), "flags": int(v[1])}
 
+    def clear_flags(self):
+        self._guard_stats[1:2].zero_()
+
     @staticmethod
-    def numpy_ranks(dist):
-        """The reference's rank expression (GestureKNN.py:553, 574) on the host: np.array(list).argsort().argsort() of a
-        float64 array (its lists mix Python floats and NumPy scalars, so the array is float64 for both modalities)."""
-        d = dist.detach().cpu().numpy().astype(np.float64)
-        r = np.stack([np.array(list(row)).argsort().argsort() for row in d]).astype(np.int16)
-        return torch.from_numpy(r).to(dist.device)
+    def numpy_ranks(dist, idx=None, integer=False):
+        """The reference's rank expression (GestureKNN.py:553, 574) on the host: np.array(list).argsort().argsort().
+        The dtype of that array is part of the tie behaviour (NumPy's sort kernels differ per dtype) and follows from
+        what the list holds: the `1e+3` placeholders are Python floats, the distances NumPy scalars of the metric's
+        dtype (np.float64 audio, np.float32 text, Python ints for the Levenshtein audio).  So a row in which EVERY code
+        has a candidate is sorted in the distances' own dtype (float32 text, int64 wavvq), and a row with an absent
+        code as float64 - reproduced here row by row (`idx` < 0 marks absent codes; `integer`: Levenshtein row)."""
+        d = dist.detach().cpu().numpy()
+        present = None if idx is None else (idx.detach().cpu().numpy() >= 0)
+        out = np.empty(d.shape, np.int16)
+        for r_, row in enumerate(d):
+            full = present is not None and bool(present[r_].all())
+            if full and integer:
+                arr = np.array([int(x) for x in row])                    # list of Python ints -> int64
+            elif full:
+                arr = np.array(list(row))                                # list of np.float32 / np.float64 scalars
+            else:
+                arr = np.array(list(row.astype(np.float64)))             # a Python float in the list: float64
+            out[r_] = arr.argsort().argsort()
+        return torch.from_numpy(out).to(dist.device)
 
     def rank_rows(self, dist):
         out = torch.empty(dist.shape, dtype=torch.int16, device=dist.device)
@@ -594,7 +643,7 @@ class CodeKNN:
             cache[M] = (_i32(qw, dev), _i32(qt, dev), _i32(np.asarray(rows_), dev))
         q_win, q_t, q_row = cache[M]
         T = dict(aud_d=None, aud_idx=None, aud_rank=None, txt_d=None, txt_idx=None, txt_rank=None)
-        sharded = db.world > 1
+        sharded = db.world > 1 or self.force_sharded
         lay = None
         if sharded:
             # per-shard tables go straight into the exchange buffer (ExchangeLayout); merged after ONE collective
@@ -677,43 +726,69 @@ class CodeKNN:
                 d = torch.empty((lay.Qb, db.K), dtype=lay.dtype[p_], device=dev)
                 ix = torch.empty((lay.Qb, db.K), dtype=torch.int32, device=dev)
                 rk = torch.empty((lay.Qb, db.K), dtype=torch.int16, device=dev)
-                if p_ == "aud" and not self.use_wavvq and getattr(self, "_last_audio_mixed", False):
+                wavlm_aud = p_ == "aud" and not self.use_wavvq
+                if wavlm_aud and getattr(self, "_last_audio_mixed", False):
                     self._merge_mixed(recv, src_stride, lay, owner_blocks, d, ix, rk)
+                elif wavlm_aud and getattr(self, "_last_audio_exact", False):
+                    self._merge_mixed(recv, src_stride, lay, owner_blocks, d, ix, rk, exact=True)
+                elif f64:
+                    # (f64 sweep + capped guard per shard: near-ties ACROSS shards / codes are detected here and
+                    # re-matched on the exact path; exact integer distances of the wavvq mode need no guard)
+                    guard = wavlm_aud and self.tie_eps > 0
+                    _lib.call("qpg_merge_select_f64", dev, recv, db.world, src_stride, lay.off[p_ + "_d"],
+                              lay.off[p_ + "_i"], lay.Qb, db.K, float(ABSENT_DIST), d, ix, rk,
+                              float(self.tie_eps) if guard else 0.0, self._guard_stats if guard else None)
                 else:
-                    _lib.call("qpg_merge_select_f64" if f64 else "qpg_merge_select_f32", dev, recv, db.world, src_stride,
+                    _lib.call("qpg_merge_select_f32", dev, recv, db.world, src_stride,
                               lay.off[p_ + "_d"], lay.off[p_ + "_i"], lay.Qb, db.K, float(ABSENT_DIST), d, ix, rk)
                 T[p_ + "_d"], T[p_ + "_idx"], T[p_ + "_rank"] = d, ix, rk
+        if sharded:
+            # every rank must take the same decision about a re-match (it is a collective path): MAX of the trouble
+            # words, on the device, stream-ordered - the walk then carries the agreed value out with the codes
+            allreduce_max_(self._guard_stats[1:2], force=self.force_sharded)
         if self.host_ranks:
             for p_ in ("aud", "txt"):
                 if T[p_ + "_d"] is not None:
-                    T[p_ + "_rank"] = self.numpy_ranks(T[p_ + "_d"])
+                    T[p_ + "_rank"] = self.numpy_ranks(T[p_ + "_d"], T[p_ + "_idx"],
+                                                       integer=(p_ == "aud" and self.use_wavvq))
         return T
 
-    def _merge_mixed(self, recv, src_stride, lay, owner_blocks, d, ix, rk):
-        """Cross-shard merge of mixed-precision audio tables: approximate merge + requests (owner), one
-        all-to-all, exact re-evaluation of the requested pairs (shards), one all-to-all back, final merge + ranks."""
+    def _merge_mixed(self, recv, src_stride, lay, owner_blocks, d, ix, rk, exact=False):
+        """Cross-shard merge of audio tables whose comparisons are not all decided by their values:
+        approximate merge + requests (owner), one all-to-all, re-evaluation of the requested pairs where the rows live
+        (shards), one all-to-all back, final merge + ranks.
+        Mixed-precision tables: band = 2.1 x the sweep's bound, responses = f64 dot-product distances; what those leave
+        within tie_eps raises FLAG_CROSS_SHARD_TIE.  exact=True (f64 tables of the uncapped select): band = tie_eps,
+        responses in the reference's own arithmetic, request and flag lists sized for the worst case - the cross-shard
+        tier 2, which cannot overflow and flags nothing."""
         db, dev = self.db, self.db.device
         W, Qb, K = db.world, lay.Qb, db.K
-        R = int(self.mixed_requests) if self.mixed_requests else max(1024, 16384 // W)
+        if exact:
+            R, fl_cap, band = Qb * K, K * W, float(self.tie_eps)
+        else:
+            R = int(self.mixed_requests) if self.mixed_requests else max(1024, 16384 // W)
+            fl_cap, band = 1024, AUDIO_MX_BAND
         req_stride, resp_stride = 8 + 8 * R, 8 * R
-        bufs = self.__dict__.get("_mm_bufs")
-        need_ws = int(_lib.load().qpg_merge_mixed_ws_bytes(Qb, K))
+        key = "_mm_bufs_exact" if exact else "_mm_bufs"
+        bufs = self.__dict__.get(key)
+        need_ws = int(_lib.load().qpg_merge_mixed_ws_bytes(Qb, K, fl_cap))
         if bufs is None or bufs[0].numel() != W * req_stride or bufs[2].numel() < need_ws:
-            bufs = self.__dict__["_mm_bufs"] = (torch.empty((W * req_stride,), dtype=torch.uint8, device=dev),
-                                                torch.empty((W * resp_stride,), dtype=torch.uint8, device=dev),
-                                                torch.empty((need_ws,), dtype=torch.uint8, device=dev))
+            bufs = self.__dict__[key] = (torch.empty((W * req_stride,), dtype=torch.uint8, device=dev),
+                                         torch.empty((W * resp_stride,), dtype=torch.uint8, device=dev),
+                                         torch.empty((need_ws,), dtype=torch.uint8, device=dev))
         req, resp, ws = bufs
         _lib.call("qpg_merge_mixed_phase1_f64", dev, recv, W, src_stride, lay.off["aud_d"], lay.off["aud_i"], Qb, K,
-                  float(ABSENT_DIST), AUDIO_MX_BAND, R, req, req_stride, ws, ws.numel(), self._guard_stats)
+                  float(ABSENT_DIST), band, R, req, req_stride, ws, ws.numel(), self._guard_stats, fl_cap)
         req_recv = exchange_bytes(req, W, True)
         # block o of req_recv comes from owner o: its queries are rows o*Qb .. of this rank's packed query set when every
         # owner has its own block (all-to-all form), rows 0 .. when all ranks own the same queries (all-gather form)
         _lib.call("qpg_shard_refine_f64", dev, req_recv, W, req_stride, R, Qb if owner_blocks else 0, db.idx_base * db.Ga,
                   db.base, int(db.feature_dtype == "f16"), db.T, db.F, db.aud_t, db.Ga, NUM_AUDIO_FEAT_FRAMES,
-                  db.tap_stride, self._last_q32, self._last_qn2, db.cn2, resp, resp_stride)
+                  db.tap_stride, self._last_q32, self._last_qn2, db.cn2, resp, resp_stride, int(exact))
         resp_recv = exchange_bytes(resp, W, True)
         _lib.call("qpg_merge_mixed_phase2_f64", dev, recv, W, src_stride, lay.off["aud_i"], Qb, K, float(ABSENT_DIST), ws,
-                  ws.numel(), resp_recv, resp_stride, d, ix, rk, self._guard_stats)
+                  ws.numel(), resp_recv, resp_stride, d, ix, rk, self._guard_stats, fl_cap,
+                  0.0 if exact else float(self.tie_eps))
 
     def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True):
         """Device-side walk of windows [window_offset, window_offset+n_windows) of the tables."""
@@ -725,14 +800,16 @@ class CodeKNN:
             sp = seed_phase.to(dev, torch.float32).contiguous()
         else:
             sp = torch.as_tensor(np.asarray(seed_phase, np.float32), device=dev).contiguous()
-        # codes | votes | status in ONE buffer: the integer results leave in a single D2H copy, no gather kernel before it
+        # codes | votes | status (2) in ONE buffer: the integer results leave in a single D2H copy, no gather kernel
+        # before it.  status[0] = an absent code won a rank fusion, status[1] = the sweeps' / selects' trouble word
+        # (copied by the walk's last kernel from _guard_stats[1]): a clip whose word is not 0 is never returned.
         n_c, n_v = M * num_frames_code, M * steps
-        ints_d = torch.empty((n_c + n_v + 1,), dtype=torch.int32, device=dev)
+        ints_d = torch.empty((n_c + n_v + 2,), dtype=torch.int32, device=dev)
         out_codes = ints_d[:n_c].view(M, num_frames_code)
         out_vote = ints_d[n_c:n_c + n_v].view(M, steps)
         status = ints_d[n_c + n_v:]                                      # always written by the walk kernels
         out_phase = torch.empty((M, steps, 8, 16), dtype=torch.float32, device=dev)
-        gate = torch.empty((3, M * steps, db.K), dtype=torch.int32, device=dev)
+        gate = torch.empty((3, max(M, 1) * steps, db.K), dtype=torch.int32, device=dev)
         q0 = window_offset * steps
 
         def sl(t):
@@ -742,17 +819,24 @@ class CodeKNN:
                   db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
                   db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode | (0x100 if self.serial_walk else 0), M, steps,
                   db.K, int(seed_code), sp,
-                  gate, out_codes, out_phase, out_vote, status)
+                  gate, out_codes, out_phase, out_vote, status, self._guard_stats[1:2])
         self._last_ints = ints_d
         if not sync:
             return out_codes, out_phase, out_vote, status
         ints = ints_d.cpu().numpy()
-        if int(ints[-1]) != 0:
+        self.check_status(ints[n_c + n_v:])
+        codes = ints[:n_c].reshape(tuple(out_codes.shape)).astype(np.int64)
+        votes = ints[n_c:n_c + n_v].reshape(tuple(out_vote.shape)).copy()
+        return codes, out_phase.cpu().numpy(), votes
+
+    @staticmethod
+    def check_status(status):
+        """status: the walk's two status ints on the host.  Raises what must never be ignored."""
+        if int(status[1]) != 0:
+            raise GuardOverflow(int(status[1]))
+        if int(status[0]) != 0:
             raise IndexError("a code that never occurs in the database won a rank fusion "
                              "(the reference raises IndexError at GestureKNN.py:631-632)")
-        codes = ints[:n_c].reshape(tuple(out_codes.shape)).astype(np.int64)
-        votes = ints[n_c:-1].reshape(tuple(out_vote.shape)).copy()
-        return codes, out_phase.cpu().numpy(), votes
 
     def capture_clip_graph(self, n_windows, mode=MODE_AUD_TXT, n_sweep_windows=None, window_offset=0):
         """Capture the whole per-clip launch sequence (pack, both sweeps, per-code argmin passes, ranks,
@@ -764,11 +848,35 @@ class CodeKNN:
     def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
                    seed_phase=None, return_tables=False):
         """All windows of one clip: two batched sweeps + rank kernels + one device-side tail walk.
-        Returns (codes int64 [M,30], phases f32 [M,8,8,16], votes [M,8]) as NumPy arrays."""
-        T = self.sweep_tables(test_interp.contiguous(), test_context, n_windows, mode)
-        if return_tables:
-            self.tables = T
-        return self.walk(T, n_windows, 0, mode, seed_code, seed_phase)
+        Returns (codes int64 [M,30], phases f32 [M,8,8,16], votes [M,8]) as NumPy arrays.
+        A clip for which the capped near-tie machinery raised its trouble word (GuardOverflow) is matched again on
+        the uncapped path before anything is returned (on a sharded DB every rank sees the same word and re-matches)."""
+        if seed_code is None:                       # drawn ONCE: a re-match starts from the same state
+            seed_code, seed_phase = self.init_code_phase()
+        test_interp = test_interp.contiguous()
+        try:
+            T = self.sweep_tables(test_interp, test_context, n_windows, mode)
+            if return_tables:
+                self.tables = T
+            return self.walk(T, n_windows, 0, mode, seed_code, seed_phase)
+        except GuardOverflow as e:
+            if self.audio_precision == "exact":
+                raise RuntimeError("the uncapped path raised flags 0x%x: this is a bug" % e.flags)
+            return self.rematch_exact(test_interp, test_context, n_windows, mode, seed_code, seed_phase, return_tables)
+
+    def rematch_exact(self, test_interp, test_context, n_windows, mode, seed_code, seed_phase, return_tables=False):
+        """The clip again with audio_precision "exact" (f64 sweep + uncapped guard); clears the trouble word."""
+        prev = self.audio_precision
+        self.clear_flags()
+        self.audio_precision = "exact"
+        self.fallbacks += 1
+        try:
+            T = self.sweep_tables(test_interp, test_context, n_windows, mode)
+            if return_tables:
+                self.tables = T
+            return self.walk(T, n_windows, 0, mode, seed_code, seed_phase)
+        finally:
+            self.audio_precision = prev
 
 
 class ClipGraph:
@@ -813,7 +921,9 @@ class ClipGraph:
 
     def run(self, test_audio, test_context, seed_code, seed_phase):
         """Copies the clip into the static buffers and replays.  Returns (codes i32 [M,30], phases, votes,
-        status) device tensors (valid until the next run)."""
+        status i32 [2]) device tensors (valid until the next run).  The caller must hand the two status ints to
+        CodeKNN.check_status() before using the codes: status[1] != 0 (GuardOverflow) means this clip has to be matched
+        with CodeKNN.match_clip / rematch_exact instead."""
         self.audio.copy_(test_audio, non_blocking=True)
         self.context.copy_(test_context, non_blocking=True)
         self.seed_phase.copy_(torch.as_tensor(seed_phase), non_blocking=True)
@@ -844,7 +954,7 @@ class ClipPipeline:
         for _ in range(depth):
             knn = CodeKNN(db, rng=rng, **knn_flags)
             self.lanes.append(dict(knn=knn, stream=torch.cuda.Stream(db.device), done=torch.cuda.Event(), ints=None,
-                                   phase=None, shape=None, busy=False))
+                                   phase=None, shape=None, busy=False, inputs=None))
         self._next = 0
 
     @property
@@ -874,6 +984,9 @@ class ClipPipeline:
             # (the device results were allocated under this lane's stream: the caching allocator hands their blocks
             # back to this lane only, whose next submit is ordered after these copies)
         ln["shape"] = (tuple(oc.shape), tuple(ov.shape), tuple(op.shape))
+        # the lane keeps the clip's inputs until collect(): the caller may drop or reuse its tensors while the lane's
+        # stream is still reading them (no record_stream needed), and a flagged clip is re-matched from them
+        ln["inputs"] = (test_interp, test_context, n_windows, mode, seed_code, seed_phase)
         ln["busy"] = True
         self._next = (t + 1) % len(self.lanes)
         return t
@@ -886,16 +999,25 @@ class ClipPipeline:
             raise RuntimeError("lane %d holds no clip" % ticket)
         ln["done"].synchronize()
         ln["busy"] = False
+        inputs, ln["inputs"] = ln["inputs"], None
         sc, sv, sp = ln["shape"]
         n_c, n_v = int(np.prod(sc)), int(np.prod(sv))
         ints = ln["ints"].numpy()
-        if int(ints[n_c + n_v]) != 0:
-            raise IndexError("a code that never occurs in the database won a rank fusion "
-                             "(the reference raises IndexError at GestureKNN.py:631-632)")
+        try:
+            CodeKNN.check_status(ints[n_c + n_v:n_c + n_v + 2])
+        except GuardOverflow:
+            # never return codes the guard could not vouch for: this clip again, now, on the uncapped path
+            ti, tc, m, mode, seed_code, seed_phase = inputs
+            with torch.cuda.stream(ln["stream"]):
+                return ln["knn"].rematch_exact(ti.contiguous(), tc, m, mode, seed_code, seed_phase)
         codes = ints[:n_c].reshape(sc).astype(np.int64)
         votes = ints[n_c:n_c + n_v].reshape(sv).copy()
         phases = ln["phase"].numpy()[:int(np.prod(sp))].reshape(sp).copy()
         return codes, phases, votes
+
+    @property
+    def fallbacks(self):
+        return sum(ln["knn"].fallbacks for ln in self.lanes)
 
     def match_clips(self, clips, mode=MODE_AUD_TXT, seeds=None):
         """clips: iterable of (test_interp, test_context, n_windows); seeds: optional list of (seed_code, seed_phase).

@@ -1289,6 +1289,227 @@ extern "C" int qpg_percode_select_f32(qpg_ctx* ctx, void* stream, const float* D
 }
 
 // ---------------------------------------------------------------------------------------------
+// UNCAPPED near-tie guard (round 3): qpg_percode_select_exact_f64.  Same contract as the guarded select above, but
+// every list lives in a global workspace sized for the worst case (every candidate of a row inside the band), so NO
+// population of near-ties can overflow it: this is the path a clip is re-matched on when a capped select (guarded:
+// 256 entries, mixed: 2048 / 256) or the mixed-precision sweep's norm check raised its flag — the reference's scan
+// (GestureKNN.py:685-689) visits every candidate with a strict `<` and has no cap either.  Launches:
+//   zero | per-code minimum + first index (percode_select_kernel) | band members -> list | reference-arithmetic
+//   re-evaluation of the members of every band with two or more (all CUs, one quad per pair) | per-query merge:
+//   winners by (reference distance, index), ranks, rank-neighbour check (at most K entries: cannot overflow either).
+// Cost on ordinary data: one more streaming pass than the guarded select (~+30 us at Q = 48); with all 53 248
+// candidates of every row in one band: 2.5 M reference-arithmetic pairs, a few ms.
+// ---------------------------------------------------------------------------------------------
+struct ExactWs {
+  double* wmin;          // [Q][K] per-code minimum of the sweep's values
+  double* list_d;        // [Q][C] reference-arithmetic distance of list entry e
+  int32_t* widx;         // [Q][K] its first-wins candidate (global index, -1 absent)
+  unsigned int* near_;   // [Q][K] band population
+  int* list_c;           // [Q][C] band members (local candidate)
+  int* cnt;              // [Q] list length
+};
+__host__ static size_t exact_ws_layout(int Q, int64_t C, int K, unsigned char* b, ExactWs* w) {
+  size_t o = 0;
+  const size_t QK = (size_t)Q * K, QC = (size_t)Q * (size_t)C;
+  if (w) w->wmin = reinterpret_cast<double*>(b + o);
+  o += QK * 8;
+  if (w) w->list_d = reinterpret_cast<double*>(b + o);
+  o += QC * 8;
+  if (w) w->widx = reinterpret_cast<int32_t*>(b + o);
+  o += QK * 4;
+  if (w) w->near_ = reinterpret_cast<unsigned int*>(b + o);
+  o += QK * 4;
+  if (w) w->list_c = reinterpret_cast<int*>(b + o);
+  o += QC * 4;
+  if (w) w->cnt = reinterpret_cast<int*>(b + o);
+  o += ((size_t)Q * 4 + 15) / 16 * 16;
+  return o;
+}
+
+__global__ void exact_zero_kernel(unsigned int* __restrict__ near_, int64_t n, int* __restrict__ cnt, int Q) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) near_[i] = 0;
+  if (i < Q) cnt[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void exact_band_kernel(const double* __restrict__ D, int64_t ldD,
+                                                         const int16_t* __restrict__ cand_code, int64_t C, int K,
+                                                         double eps, ExactWs W) {
+  const int q = blockIdx.x;
+  const double* row = D + (int64_t)q * ldD;
+  for (int64_t c = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; c < C; c += (int64_t)gridDim.y * blockDim.x) {
+    const int cd = cand_code[c];
+    if ((unsigned)cd >= (unsigned)K) continue;
+    if (row[c] <= W.wmin[(int64_t)q * K + cd] + eps) {
+      atomicAdd(&W.near_[(int64_t)q * K + cd], 1u);
+      const int pos = atomicAdd(&W.cnt[q], 1);                       // pos < C: every candidate is listed at most once
+      W.list_c[(int64_t)q * C + pos] = (int)c;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void exact_refine_kernel(GuardArgs A, const int16_t* __restrict__ cand_code, int64_t C,
+                                                           int K, ExactWs W) {
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int n = W.cnt[q];
+  for (int e0 = blockIdx.y * 64; e0 < n; e0 += gridDim.y * 64) {      // 64 quads per block
+    const int e = e0 + (tid >> 2);
+    int c = 0;
+    bool need = false;
+    if (e < n) {
+      c = W.list_c[(int64_t)q * C + e];
+      need = W.near_[(int64_t)q * K + cand_code[c]] >= 2;
+    }
+    if (__ballot(need) == 0ull) continue;                             // wave-uniform: nothing to re-evaluate here
+    const double dr = refine_pair_f64(A, q, need ? c : 0, tid & 3);   // (idle quads run along: uniform control flow)
+    if (need && (tid & 3) == 0) W.list_d[(int64_t)q * C + e] = dr;
+  }
+}
+
+__global__ __launch_bounds__(1024) void exact_merge_kernel(const int16_t* __restrict__ cand_code, int64_t C, int K,
+                                                           double absent, int32_t idx_base, double* __restrict__ out_dist,
+                                                           int32_t* __restrict__ out_idx, int16_t* __restrict__ out_rank,
+                                                           int q_block, int64_t block_stride, GuardArgs A, ExactWs W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);          // [K]
+  double* v = reinterpret_cast<double*>(smem + 8 * (size_t)K);                     // [K]
+  unsigned int* besti = reinterpret_cast<unsigned int*>(smem + 16 * (size_t)K);    // [K]
+  unsigned int* nearl = besti + K;                                                 // [K]
+  int* s_code = reinterpret_cast<int*>(nearl + K);                                 // [K]
+  int* rkc = s_code + K;                                                           // [K]
+  int* l2 = rkc + K;                                                               // [K] rank-level list (codes)
+  int* ctl = l2 + K;                                                               // [2]
+  const int q = blockIdx.x, tid = threadIdx.x;
+  if (q_block > 0) {
+    const int64_t shift = (int64_t)(q / q_block) * block_stride;
+    const int64_t rowoff = (int64_t)(q % q_block) * K - (int64_t)q * K;
+    out_dist = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(out_dist) + shift) + rowoff;
+    out_idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(out_idx) + shift) + rowoff;
+  }
+  for (int k = tid; k < K; k += blockDim.x) {
+    const unsigned int nr = W.near_[(int64_t)q * K + k];
+    const int32_t wi = W.widx[(int64_t)q * K + k];
+    nearl[k] = nr;
+    best[k] = ~0ull;
+    besti[k] = nr >= 2 ? 0xffffffffu : (unsigned int)wi;                           // -1 -> 0xffffffff (absent)
+    v[k] = wi >= 0 ? W.wmin[(int64_t)q * K + k] : absent;
+  }
+  if (tid < 2) ctl[tid] = 0;
+  __syncthreads();
+  const int n = W.cnt[q];
+  const int* lc = W.list_c + (int64_t)q * C;
+  const double* ld = W.list_d + (int64_t)q * C;
+  int mine = 0;
+  for (int e = tid; e < n; e += blockDim.x) {
+    const int cd = cand_code[lc[e]];
+    if (nearl[cd] >= 2) {
+      atomicMin(&best[cd], (unsigned long long)order_key(ld[e]));
+      ++mine;
+    }
+  }
+  if (mine) atomicAdd(&ctl[1], mine);
+  __syncthreads();
+  for (int e = tid; e < n; e += blockDim.x) {
+    const int c = lc[e], cd = cand_code[c];
+    if (nearl[cd] >= 2 && (unsigned long long)order_key(ld[e]) == best[cd])
+      atomicMin(&besti[cd], (unsigned int)(c + idx_base));
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += blockDim.x) {
+    if (nearl[k] >= 2) v[k] = key_value(best[k], 0.0);
+    out_dist[(int64_t)q * K + k] = v[k];
+    out_idx[(int64_t)q * K + k] = besti[k] != 0xffffffffu ? (int32_t)besti[k] : -1;
+  }
+  if (tid == 0 && ctl[1]) atomicAdd(&A.stats[0], ctl[1]);
+  if (!out_rank) return;
+  __syncthreads();
+  auto rank_pass = [&]() {
+    block_stable_ranks(v, K, rkc, [&](int k, int r) {
+      out_rank[(int64_t)q * K + k] = (int16_t)r;
+      s_code[r] = k;
+    });
+  };
+  rank_pass();
+  __syncthreads();
+  for (int r = tid; r + 1 < K; r += blockDim.x) {
+    const int ka = s_code[r], kb = s_code[r + 1];
+    if (besti[ka] == 0xffffffffu || besti[kb] == 0xffffffffu) continue;
+    if (v[kb] - v[ka] < A.eps) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = h ? kb : ka;
+        if (atomicMax(&nearl[k], 2u) >= 2u) continue;                 // a reference-arithmetic value already / listed once
+        l2[atomicAdd(&ctl[0], 1)] = k;                                // at most K entries
+      }
+    }
+  }
+  __syncthreads();
+  const int n2 = ctl[0];
+  if (n2 == 0) return;
+  for (int i0 = 0; i0 < n2; i0 += blockDim.x / 4) {
+    const int i = i0 + (tid >> 2);
+    if (i0 + ((tid >> 6) << 4) >= n2) continue;                       // the whole wave is past the list
+    const int k = l2[i < n2 ? i : 0];
+    const double dr = refine_pair_f64(A, q, (int64_t)(besti[k] - (unsigned int)idx_base), tid & 3);
+    if (i < n2 && (tid & 3) == 0) {
+      v[k] = dr;
+      out_dist[(int64_t)q * K + k] = dr;
+    }
+  }
+  if (tid == 0) atomicAdd(&A.stats[0], n2);
+  __syncthreads();
+  rank_pass();
+}
+
+extern "C" int64_t qpg_percode_select_exact_ws_bytes(int Q, int64_t C, int K) {
+  return (Q <= 0 || K <= 0 || C < 0) ? 0 : (int64_t)exact_ws_layout(Q, C, K, nullptr, nullptr);
+}
+
+extern "C" int qpg_percode_select_exact_f64(qpg_ctx* ctx, void* stream, const double* D, int64_t ldD, int Q,
+                                            const int16_t* cand_code, int64_t C, int K, double absent, int32_t idx_base,
+                                            double* out_dist, int32_t* out_idx, int16_t* out_rank, int q_block,
+                                            int64_t block_stride, const float* base, int T, int F, const int32_t* cand_t,
+                                            int G, int n_taps, int tap_stride, const float* q32, double eps,
+                                            int32_t* stats, int base_is_f16, void* ws, int64_t ws_bytes) {
+  const char* name = "qpg_percode_select_exact_f64";
+  QPG_REQUIRE(ctx && D && (cand_code || C == 0) && out_dist && out_idx && base && cand_t && q32 && stats && ws,
+              "%s: null pointer", name);
+  QPG_REQUIRE(Q >= 0 && C >= 0 && K > 0 && K <= 1024 && ldD >= C && C + (int64_t)idx_base < 0x7fffffffll && T > 0 &&
+                  F > 0 && G > 0 && n_taps > 0 && tap_stride > 0 && eps >= 0.0 && C % G == 0,
+              "%s: bad size (K <= 1024)", name);
+  QPG_REQUIRE(q_block >= 0 && (q_block == 0 || (!out_rank && Q % q_block == 0 && block_stride % 8 == 0)),
+              "%s: block layout needs Q %% q_block == 0 and no rank output", name);
+  QPG_REQUIRE(ws_bytes >= qpg_percode_select_exact_ws_bytes(Q, C, K) && (reinterpret_cast<uintptr_t>(ws) % 16) == 0,
+              "%s: workspace too small or misaligned (qpg_percode_select_exact_ws_bytes)", name);
+  if (Q == 0) return QPG_OK;
+  ExactWs W;
+  exact_ws_layout(Q, C, K, static_cast<unsigned char*>(ws), &W);
+  GuardArgs A;
+  A.base = base; A.half = base_is_f16; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
+  A.tap_stride = tap_stride; A.eps = eps; A.stats = stats;
+  hipStream_t st = qpg_stream(stream);
+  const int64_t QK = (int64_t)Q * K;
+  hipLaunchKernelGGL(exact_zero_kernel, dim3((unsigned)((QK + 255) / 256)), dim3(256), 0, st, W.near_, QK, W.cnt, Q);
+  QPG_LAUNCH_CHECK("exact_zero_kernel");
+  const int rc = percode_select<double, unsigned long long, false>(name, ctx, stream, D, ldD, Q, cand_code, C, K, absent,
+                                                                    idx_base, W.wmin, W.widx, nullptr, 0, 0);
+  if (rc != QPG_OK) return rc;
+  int by = (int)((C + 255) / 256);
+  const int by_cap = Q >= 256 ? 8 : (Q >= 32 ? 32 : 128);
+  if (by > by_cap) by = by_cap;
+  if (by < 1) by = 1;
+  hipLaunchKernelGGL(exact_band_kernel, dim3(Q, by), dim3(256), 0, st, D, ldD, cand_code, C, K, eps, W);
+  QPG_LAUNCH_CHECK("exact_band_kernel");
+  hipLaunchKernelGGL(exact_refine_kernel, dim3(Q, by_cap), dim3(256), 0, st, A, cand_code, C, K, W);
+  QPG_LAUNCH_CHECK("exact_refine_kernel");
+  const size_t sh = 36 * (size_t)K + 16;
+  hipLaunchKernelGGL(exact_merge_kernel, dim3(Q), dim3(1024), sh, st, cand_code, C, K, absent, idx_base, out_dist,
+                     out_idx, out_rank, q_block, block_stride, A, W);
+  QPG_LAUNCH_CHECK("exact_merge_kernel");
+  return QPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Cross-shard merge (the reduction is an associative min-with-index per (query, code)): after the
 // exchange (RCCL all-gather or all-to-all of the ranks' byte buffers) row q's W candidate (distance, index) pairs
 // sit W blocks apart; the winner is the minimum distance and, among equal distances, the lowest GLOBAL candidate
@@ -1300,10 +1521,16 @@ __global__ __launch_bounds__(1024) void merge_select_kernel(const unsigned char*
                                                            int64_t src_stride, int64_t dist_off, int64_t idx_off, int K,
                                                            T absent, T* __restrict__ out_dist,
                                                            int32_t* __restrict__ out_idx,
-                                                           int16_t* __restrict__ out_rank) {
+                                                           int16_t* __restrict__ out_rank, T eps2,
+                                                           int32_t* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* v = reinterpret_cast<T*>(smem);
+  int* cnt = reinterpret_cast<int*>(v + K);
+  int* s_code = cnt + K;
+  int* have = s_code + K;
   const int q = blockIdx.x;
+  const bool guard = stats != nullptr && eps2 > T(0);
+  int trouble = 0;
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     T bd = absent;
     int32_t bi = -1;
@@ -1317,43 +1544,68 @@ __global__ __launch_bounds__(1024) void merge_select_kernel(const unsigned char*
         bi = i;
       }
     }
+    if (guard && bi >= 0) {
+      // two shards' minima of one code closer than eps2: which one the reference's own arithmetic prefers is not
+      // decided by these values (each shard settled its near-ties inside the shard only)
+      int near = 0;
+      for (int w = 0; w < W; ++w) {
+        const unsigned char* src = recv + (int64_t)w * src_stride;
+        const int32_t i = reinterpret_cast<const int32_t*>(src + idx_off)[(int64_t)q * K + k];
+        near += i >= 0 && reinterpret_cast<const T*>(src + dist_off)[(int64_t)q * K + k] <= bd + eps2;
+      }
+      trouble |= near >= 2;
+    }
     v[k] = bd;
+    have[k] = bi >= 0;
     out_dist[(int64_t)q * K + k] = bd;
     out_idx[(int64_t)q * K + k] = bi;
   }
+  if (trouble) atomicOr(&stats[1], 8);
   if (!out_rank) return;
   __syncthreads();
-  int* cnt = reinterpret_cast<int*>(v + K);
-  block_stable_ranks(v, K, cnt, [&](int k, int r) { out_rank[(int64_t)q * K + k] = (int16_t)r; });
+  block_stable_ranks(v, K, cnt, [&](int k, int r) {
+    out_rank[(int64_t)q * K + k] = (int16_t)r;
+    s_code[r] = k;
+  });
+  if (!guard) return;
+  __syncthreads();
+  // minima of DIFFERENT codes closer than eps2 (rank neighbours): the shards' selects do not compare codes with each
+  // other when the ranks are taken after the merge, so this is the only place that sees them
+  trouble = 0;
+  for (int r = threadIdx.x; r + 1 < K; r += blockDim.x) {
+    const int ka = s_code[r], kb = s_code[r + 1];
+    trouble |= have[ka] && have[kb] && v[kb] - v[ka] < eps2;
+  }
+  if (trouble) atomicOr(&stats[1], 8);
 }
 
 template <typename T>
 static int merge_select(const char* name, qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
                         int64_t dist_off, int64_t idx_off, int Q, int K, T absent, T* out_dist, int32_t* out_idx,
-                        int16_t* out_rank) {
+                        int16_t* out_rank, T eps2, int32_t* stats) {
   QPG_REQUIRE(ctx && recv && out_dist && out_idx, "%s: null pointer", name);
-  QPG_REQUIRE(W > 0 && Q >= 0 && K > 0 && K <= 8192 && src_stride >= 0 && dist_off >= 0 && idx_off >= 0 &&
+  QPG_REQUIRE(W > 0 && Q >= 0 && K > 0 && K <= 2048 && src_stride >= 0 && dist_off >= 0 && idx_off >= 0 &&
                   dist_off % (int64_t)sizeof(T) == 0 && idx_off % 4 == 0 && src_stride % 8 == 0,
               "%s: bad size / alignment", name);
   if (Q == 0) return QPG_OK;
-  hipLaunchKernelGGL((merge_select_kernel<T>), dim3(Q), dim3(1024), (sizeof(T) + 4) * (size_t)K, qpg_stream(stream),
+  hipLaunchKernelGGL((merge_select_kernel<T>), dim3(Q), dim3(1024), (sizeof(T) + 12) * (size_t)K, qpg_stream(stream),
                      static_cast<const unsigned char*>(recv), W, src_stride, dist_off, idx_off, K, absent, out_dist,
-                     out_idx, out_rank);
+                     out_idx, out_rank, eps2, stats);
   QPG_LAUNCH_CHECK(name);
   return QPG_OK;
 }
 
 extern "C" int qpg_merge_select_f64(qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
                                     int64_t dist_off, int64_t idx_off, int Q, int K, double absent, double* out_dist,
-                                    int32_t* out_idx, int16_t* out_rank) {
+                                    int32_t* out_idx, int16_t* out_rank, double eps2, int32_t* stats) {
   return merge_select<double>("qpg_merge_select_f64", ctx, stream, recv, W, src_stride, dist_off, idx_off, Q, K, absent,
-                              out_dist, out_idx, out_rank);
+                              out_dist, out_idx, out_rank, eps2, stats);
 }
 extern "C" int qpg_merge_select_f32(qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
                                     int64_t dist_off, int64_t idx_off, int Q, int K, float absent, float* out_dist,
                                     int32_t* out_idx, int16_t* out_rank) {
   return merge_select<float>("qpg_merge_select_f32", ctx, stream, recv, W, src_stride, dist_off, idx_off, Q, K, absent,
-                             out_dist, out_idx, out_rank);
+                             out_dist, out_idx, out_rank, 0.f, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1369,7 +1621,7 @@ extern "C" int qpg_merge_select_f32(qpg_ctx* ctx, void* stream, const void* recv
 // Message layout of one (owner -> shard) request block: [i64 count][R x u64 (q_local << 48 | code << 32 | candidate)];
 // response block: [R x f64].  Both travel through the same byte exchange as the tables (parallel.exchange_bytes).
 // ---------------------------------------------------------------------------------------------------------------
-#define MM_FL 1024     // flagged (code, shard) entries per query
+// (flag-list capacity per query: `fl_cap`, a call argument - 1024 on the normal path, K*W on the uncapped one)
 
 __global__ void merge_mixed_zero_counts_kernel(unsigned char* __restrict__ req, int64_t req_stride, int W) {
   for (int w = threadIdx.x; w < W; w += blockDim.x) *reinterpret_cast<long long*>(req + (int64_t)w * req_stride) = 0;
@@ -1379,7 +1631,7 @@ __global__ __launch_bounds__(1024) void merge_mixed_phase1_kernel(
     const unsigned char* __restrict__ recv, int W, int64_t src_stride, int64_t dist_off, int64_t idx_off, int K,
     double absent, double eps1, int R, unsigned char* __restrict__ req, int64_t req_stride,
     double* __restrict__ prov_d, int32_t* __restrict__ prov_i, unsigned long long* __restrict__ fl,
-    int32_t* __restrict__ fl_cnt, int32_t* __restrict__ stats) {
+    int32_t* __restrict__ fl_cnt, int32_t* __restrict__ stats, int MM_FL) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* v = reinterpret_cast<double*>(smem);                   // [K] merged approximate minimum
   int* bi = reinterpret_cast<int*>(v + K);                       // [K] its candidate
@@ -1430,15 +1682,22 @@ __global__ __launch_bounds__(1024) void merge_mixed_phase1_kernel(
   }
   __syncthreads();
   auto emit = [&](int w, int k, int cand) {
+    // Claim the request slot first and write it before anything else can fail: a claimed slot j < R is ALWAYS a valid
+    // request (the shard evaluates min(count, R) of them), and a flag-list slot is only claimed for a written request,
+    // so fl_cnt never counts an unwritten entry (round 2 reserved both, then bailed out: phase 2 decoded stale words).
     int* cntp = reinterpret_cast<int*>(req + (int64_t)w * req_stride);
     const int j = atomicAdd(cntp, 1);
-    const int pos = atomicAdd(&n_fl, 1);
-    if (j >= R || pos >= MM_FL) {
-      atomicOr(&stats[1], 4);                                    // request / flag list overflow: entry stays approximate
+    if (j >= R) {
+      atomicOr(&stats[1], 4);                                    // request overflow: the clip is re-matched (host)
       return;
     }
     reinterpret_cast<unsigned long long*>(req + (int64_t)w * req_stride + 8)[j] =
         ((unsigned long long)q << 48) | ((unsigned long long)k << 32) | (unsigned int)cand;
+    const int pos = atomicAdd(&n_fl, 1);
+    if (pos >= MM_FL) {
+      atomicOr(&stats[1], 4);                                    // flag-list overflow: the response is ignored, re-match
+      return;
+    }
     fl[(int64_t)q * MM_FL + pos] = ((unsigned long long)k << 40) | ((unsigned long long)w << 32) | (unsigned int)j;
   };
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -1483,7 +1742,7 @@ __global__ __launch_bounds__(1024) void merge_mixed_phase2_kernel(
     const double* __restrict__ prov_d, const int32_t* __restrict__ prov_i, const unsigned long long* __restrict__ fl,
     const int32_t* __restrict__ fl_cnt, const unsigned char* __restrict__ resp_recv, int64_t resp_stride,
     double* __restrict__ out_dist, int32_t* __restrict__ out_idx, int16_t* __restrict__ out_rank,
-    int32_t* __restrict__ stats) {
+    int32_t* __restrict__ stats, int MM_FL, double eps2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* v = reinterpret_cast<double*>(smem);                                       // [K]
   unsigned long long* best = reinterpret_cast<unsigned long long*>(v + K);           // [K] key of the refined minimum
@@ -1531,26 +1790,73 @@ __global__ __launch_bounds__(1024) void merge_mixed_phase2_kernel(
     out_idx[(int64_t)q * K + k] = (int32_t)besti[k];
   }
   if (threadIdx.x == 0 && n > 0) atomicAdd(&stats[3], n);
+  // eps2 > 0 (the responses are f64 dot-product distances): contenders of one code from different shards closer than
+  // eps2 — below the resolution at which this form and the reference's own arithmetic order two distances alike — are
+  // flagged (stats[1] |= 8) and the host re-matches the clip on the path whose responses ARE reference arithmetic.
+  int trouble = 0;
+  if (eps2 > 0.0)
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+      int k;
+      double d;
+      unsigned int c;
+      entry(e, k, d, c);
+      trouble |= c != besti[k] && d <= key_value(best[k], 0.0) + eps2;
+    }
+  if (trouble) atomicOr(&stats[1], 8);
   if (!out_rank) return;
   __syncthreads();
-  block_stable_ranks(v, K, touched, [&](int k, int r) { out_rank[(int64_t)q * K + k] = (int16_t)r; });
+  int* rkc = touched;                                                               // rank counters, then reused
+  int* s_code = reinterpret_cast<int*>(best);                                       // [K] code at rank r (keys are done)
+  block_stable_ranks(v, K, rkc, [&](int k, int r) {
+    out_rank[(int64_t)q * K + k] = (int16_t)r;
+    s_code[r] = k;
+  });
+  if (eps2 <= 0.0) return;
+  __syncthreads();
+  trouble = 0;
+  for (int r = threadIdx.x; r + 1 < K; r += blockDim.x) {
+    const int ka = s_code[r], kb = s_code[r + 1];
+    trouble |= besti[ka] != 0xffffffffu && besti[kb] != 0xffffffffu && v[kb] - v[ka] < eps2;
+  }
+  if (trouble) atomicOr(&stats[1], 8);
 }
 
-extern "C" int64_t qpg_merge_mixed_ws_bytes(int Q, int K) {          // prov_d | prov_i | fl | fl_cnt
-  return (Q <= 0 || K <= 0) ? 0 : (int64_t)Q * K * 12 + (int64_t)Q * MM_FL * 8 + (int64_t)Q * 4 + 64;
+// the same in the reference's own arithmetic (refine_pair_f64: one quad per request) - the uncapped sharded path
+__global__ __launch_bounds__(256) void shard_refine_ref_kernel(GuardArgs A, const unsigned char* __restrict__ req_recv,
+                                                               int64_t req_stride, int R, int q_stride, int64_t cand_base,
+                                                               unsigned char* __restrict__ resp, int64_t resp_stride) {
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const unsigned char* blk = req_recv + (int64_t)o * req_stride;
+  int n = *reinterpret_cast<const int*>(blk);
+  n = n < R ? n : R;
+  const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(blk + 8);
+  double* out = reinterpret_cast<double*>(resp + (int64_t)o * resp_stride);
+  for (int e0 = blockIdx.y * 64; e0 < n; e0 += gridDim.y * 64) {
+    const int e = e0 + (tid >> 2);
+    const unsigned long long x = ent[e < n ? e : 0];                  // (idle quads run along: uniform control flow)
+    const int q = o * q_stride + (int)(x >> 48);
+    const int64_t c = (int64_t)(unsigned int)(x & 0xffffffffu) - cand_base;
+    const double dr = refine_pair_f64(A, q, c, tid & 3);
+    if (e < n && (tid & 3) == 0) out[e] = dr;
+  }
+}
+
+extern "C" int64_t qpg_merge_mixed_ws_bytes(int Q, int K, int fl_cap) {          // prov_d | prov_i | fl | fl_cnt
+  return (Q <= 0 || K <= 0 || fl_cap <= 0) ? 0 : (int64_t)Q * K * 12 + (int64_t)Q * fl_cap * 8 + (int64_t)Q * 4 + 64;
 }
 
 extern "C" int qpg_merge_mixed_phase1_f64(qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
                                           int64_t dist_off, int64_t idx_off, int Q, int K, double absent, double eps1,
                                           int R, void* req, int64_t req_stride, void* ws, int64_t ws_bytes,
-                                          int32_t* stats) {
+                                          int32_t* stats, int fl_cap) {
+  const int MM_FL = fl_cap;
   const char* name = "qpg_merge_mixed_phase1_f64";
   QPG_REQUIRE(ctx && recv && req && ws && stats, "%s: null pointer", name);
   QPG_REQUIRE(W > 0 && W <= 255 && Q >= 0 && Q < 65536 && K > 0 && K <= 2048 && R > 0 && src_stride % 8 == 0 &&
                   dist_off % 8 == 0 && idx_off % 4 == 0 && req_stride >= 8 + 8 * (int64_t)R && req_stride % 8 == 0 &&
-                  eps1 >= 2.0 * QPG_AUDIO_MX_ERR && ws_bytes >= qpg_merge_mixed_ws_bytes(Q, K) &&
+                  eps1 > 0.0 && fl_cap > 0 && ws_bytes >= qpg_merge_mixed_ws_bytes(Q, K, fl_cap) &&
                   (reinterpret_cast<uintptr_t>(ws) % 8) == 0 && (reinterpret_cast<uintptr_t>(req) % 8) == 0,
-              "%s: bad size / alignment (W <= 255, Q < 65536, K <= 2048, eps1 >= 2 x the sweep's bound)", name);
+              "%s: bad size / alignment (W <= 255, Q < 65536, K <= 2048, eps1 > 0)", name);
   if (Q == 0) return QPG_OK;
   unsigned char* w = static_cast<unsigned char*>(ws);
   double* prov_d = reinterpret_cast<double*>(w);
@@ -1562,7 +1868,7 @@ extern "C" int qpg_merge_mixed_phase1_f64(qpg_ctx* ctx, void* stream, const void
   QPG_LAUNCH_CHECK("merge_mixed_zero_counts_kernel");
   hipLaunchKernelGGL(merge_mixed_phase1_kernel, dim3(Q), dim3(1024), (size_t)K * 32, qpg_stream(stream),
                      static_cast<const unsigned char*>(recv), W, src_stride, dist_off, idx_off, K, absent, eps1, R,
-                     static_cast<unsigned char*>(req), req_stride, prov_d, prov_i, fl, fl_cnt, stats);
+                     static_cast<unsigned char*>(req), req_stride, prov_d, prov_i, fl, fl_cnt, stats, MM_FL);
   QPG_LAUNCH_CHECK("merge_mixed_phase1_kernel");
   return QPG_OK;
 }
@@ -1570,7 +1876,8 @@ extern "C" int qpg_merge_mixed_phase1_f64(qpg_ctx* ctx, void* stream, const void
 extern "C" int qpg_shard_refine_f64(qpg_ctx* ctx, void* stream, const void* req_recv, int W, int64_t req_stride, int R,
                                     int q_stride, int64_t cand_base, const float* base, int base_is_f16, int T, int F,
                                     const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32,
-                                    const double* qn2, const double* cn2, void* resp, int64_t resp_stride) {
+                                    const double* qn2, const double* cn2, void* resp, int64_t resp_stride,
+                                    int reference_arithmetic) {
   const char* name = "qpg_shard_refine_f64";
   QPG_REQUIRE(ctx && req_recv && base && cand_t && q32 && qn2 && cn2 && resp, "%s: null pointer", name);
   QPG_REQUIRE(W > 0 && R > 0 && req_stride >= 8 + 8 * (int64_t)R && resp_stride >= 8 * (int64_t)R && T > 0 && F > 0 &&
@@ -1579,6 +1886,13 @@ extern "C" int qpg_shard_refine_f64(qpg_ctx* ctx, void* stream, const void* req_
   GuardArgs A;
   A.base = base; A.half = base_is_f16; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
   A.tap_stride = tap_stride; A.eps = 0.0; A.stats = nullptr;
+  if (reference_arithmetic) {
+    hipLaunchKernelGGL(shard_refine_ref_kernel, dim3(W, 64), dim3(256), 0, qpg_stream(stream), A,
+                       static_cast<const unsigned char*>(req_recv), req_stride, R, q_stride, cand_base,
+                       static_cast<unsigned char*>(resp), resp_stride);
+    QPG_LAUNCH_CHECK("shard_refine_ref_kernel");
+    return QPG_OK;
+  }
   const int fast = (n_taps == 6 && F == 1024) ? 1 : 0;
   hipLaunchKernelGGL(shard_refine_kernel, dim3(W, 64), dim3(256), 0, qpg_stream(stream), A,
                      static_cast<const unsigned char*>(req_recv), req_stride, R, q_stride, cand_base, cn2, qn2,
@@ -1590,10 +1904,12 @@ extern "C" int qpg_shard_refine_f64(qpg_ctx* ctx, void* stream, const void* req_
 extern "C" int qpg_merge_mixed_phase2_f64(qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
                                           int64_t idx_off, int Q, int K, double absent, const void* ws, int64_t ws_bytes,
                                           const void* resp_recv, int64_t resp_stride, double* out_dist, int32_t* out_idx,
-                                          int16_t* out_rank, int32_t* stats) {
+                                          int16_t* out_rank, int32_t* stats, int fl_cap, double eps2) {
+  const int MM_FL = fl_cap;
   const char* name = "qpg_merge_mixed_phase2_f64";
   QPG_REQUIRE(ctx && recv && ws && resp_recv && out_dist && out_idx && stats, "%s: null pointer", name);
-  QPG_REQUIRE(W > 0 && Q >= 0 && K > 0 && K <= 2048 && ws_bytes >= qpg_merge_mixed_ws_bytes(Q, K) && resp_stride % 8 == 0,
+  QPG_REQUIRE(W > 0 && Q >= 0 && K > 0 && K <= 2048 && fl_cap > 0 && eps2 >= 0.0 &&
+                  ws_bytes >= qpg_merge_mixed_ws_bytes(Q, K, fl_cap) && resp_stride % 8 == 0,
               "%s: bad size", name);
   if (Q == 0) return QPG_OK;
   const unsigned char* w = static_cast<const unsigned char*>(ws);
@@ -1603,7 +1919,8 @@ extern "C" int qpg_merge_mixed_phase2_f64(qpg_ctx* ctx, void* stream, const void
   const int32_t* fl_cnt = reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(fl) + (size_t)Q * MM_FL * 8);
   hipLaunchKernelGGL(merge_mixed_phase2_kernel, dim3(Q), dim3(1024), (size_t)K * 24, qpg_stream(stream),
                      static_cast<const unsigned char*>(recv), W, src_stride, idx_off, K, absent, prov_d, prov_i, fl, fl_cnt,
-                     static_cast<const unsigned char*>(resp_recv), resp_stride, out_dist, out_idx, out_rank, stats);
+                     static_cast<const unsigned char*>(resp_recv), resp_stride, out_dist, out_idx, out_rank, stats, MM_FL,
+                     eps2);
   QPG_LAUNCH_CHECK("merge_mixed_phase2_kernel");
   return QPG_OK;
 }

@@ -210,7 +210,9 @@ struct TailArgs {
   int32_t* out_codes;        // [M][codes_per_window]
   float* out_phase;          // [M][steps][8][16]
   int32_t* out_vote;         // [M][steps]
-  int32_t* out_status;       // [1] 0 ok, 1 = an absent code won a rank fusion (reference would raise IndexError)
+  int32_t* out_status;       // [2] [0]: 0 ok, 1 = an absent code won a rank fusion (reference would raise IndexError);
+                             //     [1]: copy of *guard_flags (0 without it)
+  const int32_t* guard_flags;  // the sweeps' / selects' trouble word (stats[1]), or NULL: rides out with the results
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -385,7 +387,10 @@ __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
     if (lane < A.codes_per_window) A.out_codes[(int64_t)w * A.codes_per_window + lane] = wincodes[lane];
     prev_code = wincodes[last_idx];
   }
-  if (lane == 0) A.out_status[0] = bad;
+  if (lane == 0) {
+    A.out_status[0] = bad;
+    A.out_status[1] = A.guard_flags ? A.guard_flags[0] : 0;
+  }
 }
 
 
@@ -524,7 +529,15 @@ __global__ __launch_bounds__(1024) void gate_chase_kernel(TailArgs A, const uint
     A.out_codes[i] = A.code[pb + c % A.step_codes];
   }
   __syncthreads();
-  if (tid == 0) A.out_status[0] = bad_s;
+  if (tid == 0) {
+    A.out_status[0] = bad_s;
+    A.out_status[1] = A.guard_flags ? A.guard_flags[0] : 0;
+  }
+}
+
+__global__ void status_only_kernel(int32_t* out_status, const int32_t* guard_flags) {
+  out_status[0] = 0;
+  out_status[1] = guard_flags ? guard_flags[0] : 0;
 }
 
 extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
@@ -533,7 +546,7 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
                                const int32_t* aud_pslot, int Ga, const int32_t* txt_cidx, const int32_t* txt_pslot,
                                int Gt, const float* phase, int Tp, int mode, int M, int steps, int K, int seed_code,
                                const float* seed_phase, int32_t* gate_tables, int32_t* out_codes, float* out_phase,
-                               int32_t* out_vote, int32_t* out_status) {
+                               int32_t* out_vote, int32_t* out_status, const int32_t* guard_flags) {
   QPG_REQUIRE(ctx && pos_rank && freq_rank && code && phase && seed_phase && gate_tables && out_codes && out_phase &&
                   out_vote && out_status,
               "qpg_match_steps: null pointer");
@@ -549,7 +562,11 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
               "qpg_match_steps: bad size");
   const size_t lds = (size_t)2 * steps * K * sizeof(int32_t);
   QPG_REQUIRE(lds <= 96 * 1024, "qpg_match_steps: steps*K too large for the LDS gate tables");
-  if (M == 0) return QPG_OK;
+  if (M == 0) {              // an empty clip still gets a defined status word (the host reads it with the results)
+    hipLaunchKernelGGL(status_only_kernel, dim3(1), dim3(1), 0, qpg_stream(stream), out_status, guard_flags);
+    QPG_LAUNCH_CHECK("status_only_kernel");
+    return QPG_OK;
+  }
   const int Q = M * steps;
   int32_t* T0 = gate_tables;
   int32_t* T1 = gate_tables + (int64_t)Q * K;
@@ -573,6 +590,7 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   A.codes_per_window = (steps * 4 < 30) ? steps * 4 : 30;
   A.K = K; A.seed_code = seed_code; A.seed_phase = seed_phase;
   A.out_codes = out_codes; A.out_phase = out_phase; A.out_vote = out_vote; A.out_status = out_status;
+  A.guard_flags = guard_flags;
   // tabulated walk when the code that seeds the next window comes from the window's LAST step (always true for the
   // reference's grids: 8 steps x 4 codes, 30 kept) and the state fits 16 bits; the one-wave sequential walk otherwise
   const int last_idx = A.codes_per_window - 1;

@@ -124,6 +124,21 @@ def allreduce_sum_(t, average=False):
     return t
 
 
+def allreduce_max_(t, force=False):
+    """In-place MAX all-reduce of a small device tensor (the matcher's trouble word: every rank must take the same
+    re-match decision); a no-op without an initialised process group of more than one rank (`force`: also with one)."""
+    import torch.distributed as dist_
+    if not (_active() or (force and dist_.is_available() and dist_.is_initialized())):
+        return t
+    if _host_staged():
+        h = t.cpu()
+        dist_.all_reduce(h, op=dist_.ReduceOp.MAX)
+        t.copy_(h)
+    else:
+        dist_.all_reduce(t, op=dist_.ReduceOp.MAX)
+    return t
+
+
 def broadcast_(t, src=0):
     if not _active():
         return t

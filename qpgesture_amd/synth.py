@@ -77,7 +77,17 @@ def apply_variant(tr, te, code, variant):
         within ~1e-19), 22 an exact duplicate of 5 with the same codes (exact tie: first index wins).
     'texttie': repeated context rows, as real BEAT data has (every silent code frame carries the identical
         encode(['']) embedding, make_beat_dataset.py:556-565): many codes tie EXACTLY in txt_dist, often at distance 0,
-        and the reference ranks them with NumPy's unstable argsort."""
+        and the reference ranks them with NumPy's unstable argsort.
+    'nearsilent': a near-silent stretch, as a speaker DB has between utterances: DB windows 8..37 and test window 0
+        carry ONE quiet feature vector (amplitude 1e-3) in every frame, the copies differing by about one float32 ulp
+        per element (8..12 are bit-identical), 22 of the 30 windows sharing six codes.  All 30 x 26 = 780 candidates of
+        that stretch then sit within ~1e-14 of each other for a quiet query (about 130 per crowded code) - more than
+        any fixed-size near-tie list holds - and the reference's strict `<` scan (GestureKNN.py:685-689) still has an
+        answer for every one of them in its own arithmetic.
+    'speechlike': feature statistics closer to real WavLM tracks than i.i.d. N(0,1): AR(1) in time (rho = 0.95) on
+        rank-64 mixtures over the 1024 features plus a small full-rank residual, 10 % near-silent frames (amplitude
+        1e-3 around a common quiet vector), and context rows that repeat over a few code frames (words spanning
+        frames) with 20 % silence embeddings."""
     if variant is None:
         return
     if variant == "neartie":
@@ -103,6 +113,45 @@ def apply_variant(tr, te, code, variant):
             ctx[j, 10:14] = ctx[j, 10]
         tq = te["context"]
         tq[:, ::4] = sil                                               # silent query frames: distance exactly 0
+    elif variant == "nearsilent":
+        rng = _rng(778)
+        F = tr["wavlm"].shape[2]
+        quiet = (rng.standard_normal((F,)) * 1e-3).astype(np.float32)
+
+        def stretch(n):
+            x = np.broadcast_to(quiet, (n, 199, F)).astype(np.float32)
+            flip = rng.integers(-1, 2, size=x.shape)                    # -1 / 0 / +1 ulp per element
+            up = np.nextafter(x, np.float32(np.inf))
+            dn = np.nextafter(x, np.float32(-np.inf))
+            return np.where(flip > 0, up, np.where(flip < 0, dn, x)).astype(np.float32)
+        w = tr["wavlm"]
+        w[8:38] = stretch(30)
+        w[8:13] = quiet                                                 # bit-identical windows: exact ties, first wins
+        code[8:30] = 100 + rng.integers(0, 6, size=(22, code.shape[1]))  # six crowded codes; 30..37 keep their own
+        te["wavlm"][0] = stretch(1)[0]
+    elif variant == "speechlike":
+        for d, sd in ((tr, 779), (te, 780)):
+            rng = _rng(sd)
+            n, T, F = d["wavlm"].shape
+            mix = (rng.standard_normal((64, F)) / 8.0).astype(np.float32)
+            z = np.empty((n, T, 64), np.float32)
+            z[:, 0] = rng.standard_normal((n, 64))
+            innov = (rng.standard_normal((n, T, 64)) * np.sqrt(1 - 0.95 ** 2)).astype(np.float32)
+            for t in range(1, T):
+                z[:, t] = 0.95 * z[:, t - 1] + innov[:, t]
+            x = z @ mix + 0.05 * d["wavlm"]                              # low-rank, slowly varying + a little of the rest
+            quiet = (_rng(781).standard_normal((F,)) * 1e-3).astype(np.float32)
+            sil = rng.random((n, T)) < 0.10
+            x[sil] = quiet * (1.0 + 1e-3 * rng.standard_normal((int(sil.sum()), F)).astype(np.float32))
+            d["wavlm"][...] = x.astype(np.float32)
+            ctx = d["context"]
+            silence = _rng(782).standard_normal((384,)).astype(np.float32)
+            for j in range(n):
+                r = 0
+                while r < ctx.shape[1]:
+                    span = int(rng.integers(1, 5))
+                    ctx[j, r:r + span] = silence if rng.random() < 0.2 else ctx[j, r]
+                    r += span
     else:
         raise ValueError(variant)
 

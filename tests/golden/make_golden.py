@@ -200,6 +200,10 @@ FIXTURES = {
     # planted audio near-ties (ulp-perturbed duplicate windows) / exact text ties (repeated context rows)
     "shipped_neartie_n48_m2_s30": (48, 2, (30, 31, 32, 33), 0, "shipped", "neartie"),
     "shipped_texttie_n48_m2_s40": (48, 2, (40, 41, 42, 43), 0, "shipped", "texttie"),
+    # a near-silent stretch: 780 candidates within ~1e-14 of each other (more than any capped near-tie list holds)
+    "shipped_nearsilent_n48_m2_s50": (48, 2, (50, 51, 52, 53), 0, "shipped", "nearsilent"),
+    # AR(1) / rank-64 / 10 % near-silent frames / repeating context rows
+    "shipped_speechlike_n48_m2_s60": (48, 2, (60, 61, 62, 63), 0, "shipped", "speechlike"),
     # vq-wav2vec + Levenshtein audio (the mode the paper describes); wavlm_dim=8 keeps the unused WavLM small
     "wavvq_aud_txt_n40_m2_s20": (40, 2, (20, 21, 22, 23), 0, "wavvq_aud_txt"),
     "wavvq_aud_n40_m2_s20": (40, 2, (20, 21, 22, 23), 0, "wavvq_aud"),

@@ -186,3 +186,26 @@ def test_byte_exchange_protocol(tmp_path):
                 rows = slice(r * qc, (r + 1) * qc) if owner else slice(None)
                 assert np.array_equal(got["aud_d"], d[rows]) and np.array_equal(got["aud_i"], ix[rows])
                 assert np.array_equal(got["txt_d"], dt[rows]) and np.array_equal(got["txt_i"], it[rows])
+
+
+def _worker_flags(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qpgesture_amd.parallel import allreduce_max_
+    got = []
+    for flags in ([0, 0, 0], [0, 4, 0], [1, 0, 8]):             # the trouble word of each rank, three clips
+        t = torch.tensor([flags[rank]], dtype=torch.int32)
+        allreduce_max_(t)
+        got.append(int(t[0]))
+    np.save(out % rank, np.array(got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_a_rematch(tmp_path):
+    """The matcher's trouble word is MAX-reduced before the walk carries it to the host, so that every rank takes the
+    same decision about re-matching a clip (the re-match is a collective path)."""
+    out = str(tmp_path / "f%d.npy")
+    mp.spawn(_worker_flags, args=(3, _free_port(), out), nprocs=3, join=True)
+    for r in range(3):
+        assert np.load(out % r).tolist() == [0, 4, 8]

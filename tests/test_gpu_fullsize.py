@@ -106,7 +106,7 @@ def test_speaker1_class_db_8192_windows_vs_c_oracle():
     od = torch.empty((Q, K), dtype=torch.float64, device="cuda:0")
     oi = torch.empty((Q, K), dtype=torch.int32, device="cuda:0")
     _lib.call("qpg_merge_select_f64", torch.device("cuda:0"), buf, 2, buf.numel() // 2, 0, Q * K * 8, Q, K,
-              float(ABSENT_DIST), od, oi, None)
+              float(ABSENT_DIST), od, oi, None, 0.0, None)
     # (sweep_audio(reduce=False) without an exchange layout runs the f64 sweep; the unsharded tables the mixed-precision one)
     assert torch.equal(oi, T["aud_idx"]) and float((od - T["aud_d"]).abs().max()) < tol
 

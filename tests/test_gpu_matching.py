@@ -213,7 +213,7 @@ def test_clip_graph_replay_equals_eager():
     cg = knn.capture_clip_graph(M)
     for rep in range(2):                    # second run reuses the captured graph
         codes, phases, votes, status = cg.run(te_i, te_c, sc, sp)
-        assert int(status.item()) == 0
+        assert status.cpu().tolist() == [0, 0]        # [absent code won, guard trouble word]
         assert np.array_equal(codes.cpu().numpy().astype(np.int64), g["knn_pred"])
         assert np.array_equal(phases.cpu().numpy(), g["phase_out"])
         assert np.array_equal(votes.cpu().numpy(), g["vote"])

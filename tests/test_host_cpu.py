@@ -25,7 +25,8 @@ def test_bindings_cover_the_header():
                                "qpg_vq_workspace_floats", "qpg_vq_reduce_ws_bytes",
                                "qpg_conv1d_wgrad_ws_floats", "qpg_vq_code_sums_ws_bytes",
                                "qpg_text_percode_ws_bytes", "qpg_percode_select_mixed_ws_bytes",
-                               "qpg_merge_mixed_ws_bytes", "qpg_debug_convt_shape"}
+                               "qpg_merge_mixed_ws_bytes", "qpg_debug_convt_shape",
+                               "qpg_percode_select_exact_ws_bytes"}
     assert declared == bound
 
 
@@ -287,3 +288,59 @@ def test_mixed_precision_constants_agree_with_the_header():
     assert code_knn.AUDIO_MX_BAND >= 2.0 * code_knn.AUDIO_MX_ERR
     u = 2.0 ** -24
     assert code_knn.AUDIO_MX_ERR >= 32 * u / (1 - 32 * u) + 1e-13        # gamma_32 + the f64 part
+
+
+def test_numpy_ranks_follow_the_reference_s_array_dtype():
+    """the reference ranks np.array(list): float32 when every code has a (np.float32) text distance, float64 as
+    soon as one `1e+3` Python float is left in the list, int64 for the Levenshtein audio (GestureKNN.py:553, 574)."""
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal((3, 512)).astype(np.float32)
+    d[:, 100:200] = d[:, :1]                                     # exact ties: the order NumPy's sort leaves is dtype business
+    idx = np.zeros((3, 512), np.int32)
+    idx[1, 7] = -1
+    d[1, 7] = 1e3
+    got = CodeKNN.numpy_ranks(torch.from_numpy(d), torch.from_numpy(idx)).numpy()
+    for r in range(3):
+        lst = [np.float32(x) for x in d[r]]
+        if r == 1:
+            lst[7] = 1e+3                                        # the reference's placeholder: a Python float
+        arr = np.array(lst)
+        assert arr.dtype == (np.float64 if r == 1 else np.float32)
+        assert np.array_equal(got[r], arr.argsort().argsort())
+    lev = rng.integers(0, 12, size=(2, 512)).astype(np.float32)
+    got = CodeKNN.numpy_ranks(torch.from_numpy(lev), torch.zeros((2, 512), dtype=torch.int32), integer=True).numpy()
+    for r in range(2):
+        arr = np.array([int(x) for x in lev[r]])
+        assert arr.dtype == np.int64 and np.array_equal(got[r], arr.argsort().argsort())
+
+
+def test_status_word_is_never_ignored():
+    from qpgesture_amd.code_knn import CodeKNN, GuardOverflow
+    CodeKNN.check_status([0, 0])
+    with pytest.raises(GuardOverflow) as e:
+        CodeKNN.check_status([1, 5])                              # the guard's word outranks the IndexError
+    assert e.value.flags == 5
+    with pytest.raises(IndexError):
+        CodeKNN.check_status([1, 0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with WORLD_SIZE unset re-executes itself under torch.distributed.run with N ranks and
+    still prints ONE JSON line (VERDICT r2 next #3a).  QPG_BENCH_LAUNCH_CHECK=1 stops every rank after the rendezvous
+    (gloo all-reduce), before anything needs a GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QPG_BENCH_LAUNCH_CHECK="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"launch_check": True, "n_gpus": 3, "rank_sum": 6}

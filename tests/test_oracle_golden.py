@@ -114,7 +114,8 @@ def test_oracle_wavvq_vs_reference(name, use_txt):
     assert O.wavvq_feat(np.zeros((1, 398, 2), np.int64)).shape == (1, 398, 22)
 
 
-@pytest.mark.parametrize("name", ["shipped_neartie_n48_m2_s30", "shipped_texttie_n48_m2_s40"])
+@pytest.mark.parametrize("name", ["shipped_neartie_n48_m2_s30", "shipped_texttie_n48_m2_s40",
+                                  "shipped_nearsilent_n48_m2_s50", "shipped_speechlike_n48_m2_s60"])
 def test_c_scans_vs_reference_planted_ties(name):
     """The planted-tie fixtures (ulp-perturbed duplicate windows / repeated context rows, synth.apply_variant): the
     oracle's C port still reproduces the reference's minima bit for bit and its first-wins winners, including codes
@@ -132,3 +133,24 @@ def test_c_scans_vs_reference_planted_ties(name):
     assert np.array_equal(d, g["txt_dist"]) and np.array_equal(ix, np.where(gj >= 0, gj * 26 + gk // 8, -1))
     if name.startswith("shipped_neartie"):
         assert ((g["aud_dist"] > 0) & (g["aud_dist"] < 1e-15)).sum() >= 14       # the planted sub-noise gaps are there
+    if name.startswith("shipped_nearsilent"):
+        # the quiet stretch: in each of the quiet window's 8 steps 176 codes' minima lie within 1e-12 of each other
+        assert ((g["aud_dist"] < 1e-12).sum(axis=1)[:8] == 176).all()
+
+
+@pytest.mark.parametrize("name", ["shipped_nearsilent_n48_m2_s50", "shipped_speechlike_n48_m2_s60"])
+def test_oracle_pipeline_vs_reference_realistic_statistics(name):
+    """The restated pipeline on the near-silent and the speech-like fixture: knn_pred and the per-step tables are the
+    reference's (the C scans; exact ties between codes are ranked by the same NumPy call as upstream, so knn_pred is
+    compared when this host's NumPy orders them like the capturing machine's)."""
+    g = load_golden(name)
+    ntr, nte, s0, s1, s2, s3, mf = [int(v) for v in g["meta"]]
+    with tempfile.TemporaryDirectory() as td:
+        paths = synth.write_npz_set(td, ntr, nte, s0, s1, s2, s3, variant=str(g["variant"]))
+        trace = []
+        (motion, phases, votes), knn = O.load_and_match(paths, max_frames=mf, trace=trace, scan="c")
+    assert np.array_equal(np.array([t["aud_d"] for t in trace])[0], g["aud_dist"][0])
+    here = np.stack([np.array(list(r)).argsort().argsort() for r in g["aud_dist"]])
+    if np.array_equal(here, g["step_aud_score"]) and knn.tied_decisions == 0:
+        assert np.array_equal(motion, g["knn_pred"]) and np.array_equal(votes, g["vote"])
+        assert np.array_equal(np.array([t["aud_d"] for t in trace]), g["aud_dist"])

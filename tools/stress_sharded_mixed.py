@@ -46,10 +46,10 @@ for t in range(trials):
     recv = torch.cat([l.send for l in lays]); src_stride = lays[0].send.numel()
     R = 8192; req_stride, resp_stride = 8 + 8 * R, 8 * R
     req = torch.zeros((W * req_stride,), dtype=torch.uint8, device=dev)
-    ws = torch.empty((int(_lib.load().qpg_merge_mixed_ws_bytes(Q, K)),), dtype=torch.uint8, device=dev)
+    ws = torch.empty((int(_lib.load().qpg_merge_mixed_ws_bytes(Q, K, 1024)),), dtype=torch.uint8, device=dev)
     stats = torch.zeros((4,), dtype=torch.int32, device=dev)
     _lib.call("qpg_merge_mixed_phase1_f64", dev, recv, W, src_stride, lays[0].off["aud_d"], lays[0].off["aud_i"], Q, K,
-              float(ABSENT_DIST), AUDIO_MX_BAND, R, req, req_stride, ws, ws.numel(), stats)
+              float(ABSENT_DIST), AUDIO_MX_BAND, R, req, req_stride, ws, ws.numel(), stats, 1024)
     resp_recv = torch.zeros((W * resp_stride,), dtype=torch.uint8, device=dev)
     for w in range(W):
         req_recv = torch.zeros((W * req_stride,), dtype=torch.uint8, device=dev)
@@ -57,12 +57,12 @@ for t in range(trials):
         resp = torch.zeros((W * resp_stride,), dtype=torch.uint8, device=dev)
         k, db = shards[w], shards[w].db
         _lib.call("qpg_shard_refine_f64", dev, req_recv, W, req_stride, R, 0, db.idx_base * db.Ga, db.base, int(half), db.T,
-                  db.F, db.aud_t, db.Ga, 6, db.tap_stride, k._last_q32, k._last_qn2, db.cn2, resp, resp_stride)
+                  db.F, db.aud_t, db.Ga, 6, db.tap_stride, k._last_q32, k._last_qn2, db.cn2, resp, resp_stride, 0)
         resp_recv[w * resp_stride:(w + 1) * resp_stride] = resp[:resp_stride]
     d = torch.empty((Q, K), dtype=torch.float64, device=dev); ix = torch.empty((Q, K), dtype=torch.int32, device=dev)
     rk = torch.empty((Q, K), dtype=torch.int16, device=dev)
     _lib.call("qpg_merge_mixed_phase2_f64", dev, recv, W, src_stride, lays[0].off["aud_i"], Q, K, float(ABSENT_DIST), ws,
-              ws.numel(), resp_recv, resp_stride, d, ix, rk, stats)
+              ws.numel(), resp_recv, resp_stride, d, ix, rk, stats, 1024, 1e-12)
     st = stats.cpu().numpy()
     ok = (torch.equal(ix, T["aud_idx"]) and torch.equal(rk, T["aud_rank"]) and st[1] == 0
           and float((d - T["aud_d"]).abs().max()) <= AUDIO_MX_ERR)
