@@ -1089,6 +1089,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     }
     for (int k = tid; k < K; k += blockDim.x)
       if (near_[k] >= 2) {
+        rk[k] = (int)besti[k];                                 // kept for codes a TRUNCATED list has no entry of (below)
         best[k] = ~0ull;
         besti[k] = 0xffffffffu;
         s_code[k] = 0;                                         // scratch: members within eps2 of the refined minimum
@@ -1137,8 +1138,14 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       if ((unsigned long long)order_key(l_d[e]) == best[l_k[e]])
         atomicMin(&besti[l_k[e]], (unsigned int)(l_c[e] + idx_base));
     __syncthreads();
+    // A touched code with no list entry exists only after a list overflow (flagged: the host re-matches the clip):
+    // it keeps its sweep value and candidate, so that nothing below ranks a NaN or dereferences an empty slot
+    // (round 2 did, and a crowded row - 3 000 near-copies under one code - faulted in the rank-level refine).
     for (int k = tid; k < K; k += blockDim.x)
-      if (near_[k] >= 2) v[k] = key_value(best[k], 0.0);
+      if (near_[k] >= 2) {
+        if (best[k] != ~0ull) v[k] = key_value(best[k], 0.0);
+        else besti[k] = (unsigned int)rk[k];
+      }
     if (tid == 0) atomicAdd(&A.stats[2], n);
     __syncthreads();
   }

@@ -222,7 +222,10 @@ def test_sharded_mixed_merge_protocol_on_one_gpu():
     torch.cuda.synchronize()
     st = stats.cpu().numpy()
     print("requests per shard", counts, " cross-shard re-evaluations", int(st[3]), " flags", int(st[1]))
-    assert st[1] == 0 and st[3] == sum(counts)
+    # (flag 8 = FLAG_CROSS_SHARD_TIE: the planted EXACT duplicates across the shard boundary tie below 1e-12, which the
+    # dot-product responses cannot order like the reference for sure - the host would re-match this clip on the exact
+    # path, tests/test_gpu_guard_overflow.py; the tables are right here because equal values fall back to the index)
+    assert (st[1] & ~8) == 0 and (st[1] & 8) and st[3] == sum(counts)
     assert torch.equal(ix, want_idx)
     assert torch.equal(rk, want_rank)
     from qpgesture_amd.code_knn import AUDIO_MX_ERR

@@ -64,7 +64,7 @@ for t in range(trials):
     _lib.call("qpg_merge_mixed_phase2_f64", dev, recv, W, src_stride, lays[0].off["aud_i"], Q, K, float(ABSENT_DIST), ws,
               ws.numel(), resp_recv, resp_stride, d, ix, rk, stats, 1024, 1e-12)
     st = stats.cpu().numpy()
-    ok = (torch.equal(ix, T["aud_idx"]) and torch.equal(rk, T["aud_rank"]) and st[1] == 0
+    ok = (torch.equal(ix, T["aud_idx"]) and torch.equal(rk, T["aud_rank"]) and (st[1] & ~8) == 0
           and float((d - T["aud_d"]).abs().max()) <= AUDIO_MX_ERR)
     bad += not ok
     print("trial %2d W=%d N=%3d M=%d %s  cross-shard re-evaluations %d  %s" % (t, W, N, M, fd, int(st[3]),
