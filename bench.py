@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 2048 flop / 64 cycles / SIMD x 1024 SIMDs x 2.4 GHz
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2 / 16x16x4, 64 flop/clk/SIMD
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak
 
 
 def chunked_db(n_db, lo, hi, seed, F=1024):
@@ -92,6 +93,9 @@ def main():
                     help="mixed (default, the product default): f32 matrix-core sweep with an a-priori error bound + f64 / "
                          "reference-arithmetic re-evaluation of every undecided comparison; f64: the f64 matrix-core sweep; "
                          "exact: f64 sweep + the uncapped near-tie guard (the path flagged clips are re-matched on)")
+    ap.add_argument("--audio-kernel", choices=["hl", "mx"], default="hl",
+                    help="kernel of the mixed-precision sweep: hl = split-operand f16 matrix cores on the frame-major image "
+                         "(HBM-bound, the default), mx = round 2's f32-matrix-core kernel")
     ap.add_argument("--clips", type=int, default=1, help="concurrent clips per GPU in one batched sweep")
     ap.add_argument("--clips-in-flight", type=int, default=1,
                     help="lanes of independent clips in flight (code_knn.ClipPipeline; single GPU, one clip per step): the "
@@ -186,6 +190,7 @@ def main():
     knn.overlap_sweeps = not a.no_overlap
     knn.text_after_sweep = not a.text_first
     knn.audio_precision = a.audio_precision
+    knn.audio_kernel = a.audio_kernel
     if a.sharded_mixed_min_gflop is not None:
         knn.sharded_mixed_min_gflop = a.sharded_mixed_min_gflop
     if a.mixed_requests is not None:
@@ -260,6 +265,7 @@ def main():
         for ln in pipe.lanes:
             ln["knn"].overlap_sweeps = knn.overlap_sweeps
             ln["knn"].audio_precision = knn.audio_precision
+            ln["knn"].audio_kernel = knn.audio_kernel
 
         def run_steps(n):
             pending, res = [], None
@@ -386,26 +392,52 @@ def main():
     alg_bytes = db.n_local * 81 * db.F * fb + C * 8 + Q * 6 * db.F * 4 + Q * C * 8
     default_shape = world == 1 and N == 2048 and M == 6 and CL == 1 and fb == 4
     peak = F32_MFMA_PEAK_TFLOPS if mixed else F64_MFMA_PEAK_TFLOPS
-    roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4),
-                # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
-                # measured for exactly this launch shape only: profiles/r02_pmc_audio.md
-                "traffic": (AUDIO_MX_TRAFFIC_BYTES if mixed else AUDIO_TRAFFIC_BYTES) if default_shape else None,
-                "traffic_source": TRAFFIC_SOURCE if default_shape else None,
-                "kernel": ("audio_cosine_mx2_kernel (one launch: LDS-shared-query blocks + split-K remainder blocks; f32 "
-                           "matrix cores, error bounded a priori, f64 re-evaluation in the select)")
-                if mixed else "audio_cosine_f64_kernel",
-                "precision": "mixed" if mixed else "f64",
-                **({"note": "kernel_ms is measured with %d clips in flight: other clips' kernels share the CUs during the "
-                            "launch (alone: one_clip_at_a_time.kernel_ms)" % a.clips_in_flight}
-                   if a.clips_in_flight > 1 else {}),
-                "kernel_ms": round(k_ms, 4),
-                "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_ms_median": round(float(np.median(ms)), 4),
-                "kernel_ms_max": round(float(np.max(ms)), 4), "kernel_launches_timed": len(ms),
-                "algorithmic_gflop": round(flops / 1e9, 3),
-                "algorithmic_bytes": int(alg_bytes),
-                "hbm_gbs_algorithmic": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1),
-                "hbm_frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    hl = bool(mixed and getattr(knn, "_last_audio_hl", False))
+    if hl:
+        # split-operand f16 sweep: every database frame is read once from the frame-major image (27 super-rows x 3 frames
+        # x F x 4 B per window = the 81 even frames), the matrix leaves in f32; three f16 MFMAs per 32 k-steps of a
+        # 32-row x 96-column tile (27 of 32 rows live)
+        alg_bytes = db.n_local * 81 * db.F * 4 + C * 8 + Q * 6 * db.F * 4 + Q * C * 4
+        chunks = (Q + 47) // 48
+        mfma_issued = 3 * 2.0 * (db.n_local * 32) * (chunks * 96) * (3 * db.F)
+        gbs = alg_bytes / (k_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": AUDIO_HL_TRAFFIC_BYTES if default_shape else None,
+                    "traffic_source": HL_TRAFFIC_SOURCE if default_shape else None,
+                    "kernel": ("audio_cosine_hl_kernel (split-operand f16 matrix cores on a frame-major image: every "
+                               "database frame read once; h h' block sums added in f64, error bounded a priori, f64 "
+                               "re-evaluation in the select)"),
+                    "precision": "mixed", "kernel_ms": round(k_ms, 4),
+                    "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_ms_median": round(float(np.median(ms)), 4),
+                    "kernel_ms_max": round(float(np.max(ms)), 4), "kernel_launches_timed": len(ms),
+                    "algorithmic_bytes": int(alg_bytes), "algorithmic_gflop": round(flops / 1e9, 3),
+                    "mfma": {"issued_tflops_f16": round(mfma_issued / (k_ms * 1e-3) / 1e12, 1), "peak": F16_MFMA_PEAK_TFLOPS,
+                             "frac": round(mfma_issued / (k_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4),
+                             "equivalent_tflops_of_the_f32_formulation": round(achieved, 1),
+                             "f32_matrix_peak": F32_MFMA_PEAK_TFLOPS},
+                    "hbm_frac_of_6_3_tbs_achievable": round(gbs / 6300.0, 4)}
+    else:
+        roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4),
+                    # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
+                    # measured for exactly this launch shape only: profiles/r02_pmc_audio.md
+                    "traffic": (AUDIO_MX_TRAFFIC_BYTES if mixed else AUDIO_TRAFFIC_BYTES) if default_shape else None,
+                    "traffic_source": TRAFFIC_SOURCE if default_shape else None,
+                    "kernel": ("audio_cosine_mx2_kernel (one launch: LDS-shared-query blocks + split-K remainder blocks; "
+                               "f32 matrix cores, error bounded a priori, f64 re-evaluation in the select)")
+                    if mixed else "audio_cosine_f64_kernel",
+                    "precision": "mixed" if mixed else "f64",
+                    **({"note": "kernel_ms is measured with %d clips in flight: other clips' kernels share the CUs during "
+                                "the launch (alone: one_clip_at_a_time.kernel_ms)" % a.clips_in_flight}
+                       if a.clips_in_flight > 1 else {}),
+                    "kernel_ms": round(k_ms, 4),
+                    "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_ms_median": round(float(np.median(ms)), 4),
+                    "kernel_ms_max": round(float(np.max(ms)), 4), "kernel_launches_timed": len(ms),
+                    "algorithmic_gflop": round(flops / 1e9, 3),
+                    "algorithmic_bytes": int(alg_bytes),
+                    "hbm_gbs_algorithmic": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1),
+                    "hbm_frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     if strong:
         par = ("db-row-shard x%d + all-gather(min,index) + local merge, replicated walk" % world) if world > 1 \
@@ -415,7 +447,8 @@ def main():
     out = {"metric": "matched gesture frames/sec (GestureKNN)", "value": round(value, 1), "unit": "frames/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
-           "dtype": "f32 sweep + f64 re-evaluation" if mixed else "f64",
+           "dtype": ("split-f16 products / f64 block sums + f64 re-evaluation" if hl else "f32 sweep + f64 re-evaluation")
+           if mixed else "f64",
            "data": "synthetic",
            "config": {"workload": "%d x 24 s clip%s (M=%d windows, Q=%d steps, %d frames each) %s vs speaker-%s-class DB "
                                   "N_db=%d windows (%d candidates), shipped mode wavlm_feat(%s)+text(f32)+phase%s%s"
@@ -462,7 +495,8 @@ def main():
                             "unit": "TFLOP/s", "frac": round(flops / (k6 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
                             "codes_equal_default_path": bool(torch.equal(c64, codes))}
     if serial is not None:
-        serial["roofline_frac"] = round(flops / (serial["kernel_ms"] * 1e-3) / 1e12 / peak, 4)
+        serial["roofline_frac"] = (round(alg_bytes / (serial["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if hl else
+                                   round(flops / (serial["kernel_ms"] * 1e-3) / 1e12 / peak, 4))
         out["one_clip_at_a_time"] = serial
     if mixed and sharded_run:
         st = knn.mixed_stats()
@@ -527,6 +561,8 @@ def main():
 # HBM bytes per audio_cosine_f64_kernel launch at the default shape (N_db=2048, Q=48), rocprofv3 PMC, separate
 # --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 correction on FETCH_SIZE: profiles/r02_pmc_audio.md
 TRAFFIC_SOURCE = "profiles/r02_pmc_audio.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch shape; not re-measured per run)"
+HL_TRAFFIC_SOURCE = "profiles/r03_pmc_audio_hl.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch shape; not re-measured per run)"
+AUDIO_HL_TRAFFIC_BYTES = 835_000_000      # split-operand f16 sweep: FETCH_SIZE 402.8e3 KB x 1024 x 2 + WRITE_SIZE 9 984 KB x 1024
 AUDIO_TRAFFIC_BYTES = 923_000_000
 AUDIO_MX_TRAFFIC_BYTES = 1_023_000_000    # mixed-precision sweep (one launch: mx2 blocks + split-K remainder), same file
 

@@ -120,6 +120,37 @@ int qpg_audio_cosine_mx_h(qpg_ctx*, void* stream, const void* base_f16, int N, i
                           int n_taps, int tap_stride, const double* cn2, const float* q32, const double* qn2, int Q,
                           void* D, int d_is_f32, int64_t ldD, int32_t* stats);
 
+/* SPLIT-OPERAND f16 form of the mixed-precision sweep (round 3; the default audio sweep where the grid allows it):
+ * same contract and the same a-priori bound as qpg_audio_cosine_mx (|D - exact| <= QPG_AUDIO_MX_ERR for every pair,
+ * consumed by qpg_percode_select_mixed_f64), with the products on the f16 matrix cores: every value is scaled by a power
+ * of two and stored as two f16 numbers (h, l) with x = h + 2^-11 l (+ <= 2^-23 |x|), the h h' block sums of every MFMA
+ * are added in f64, the cross terms run as f32 chains, and the database is read in a frame-major image in which every
+ * frame occurs ONCE (super-rows of three frames: dot(q, cand g) = S[g][q first 3 taps] + S[g+1][q last 3 taps]) — the
+ * sweep is HBM-bound.  Derivation of the bound and layouts: qpgesture_amd/csrc/qpg_audio_hl.hip.
+ *   qpg_audio_hl_supported   1 if the candidate grid has the required shape: 6 taps, G = 26 grid positions
+ *                            `cand_step` = 3 x tap_stride frames apart, F %% 128 == 0 (the reference's WavLM grid,
+ *                            data_processing.py:264-268 / GestureKNN.py:672-690); else use qpg_audio_cosine_mx.
+ *   qpg_audio_hl_pack_db     one-off: base [dev] f32 [N][T][F] -> image [dev] (qpg_audio_hl_db_bytes(N, F) bytes, 16-byte
+ *                            aligned): [window][row tile 2][k-block][plane][lane 64][8 f16] + scale exponent.
+ *   qpg_audio_hl_pack_queries per clip: q32 [dev] f32 [Q][6 F] (qpg_audio_pack_queries) -> image [dev]
+ *                            (qpg_audio_hl_query_bytes(Q, F) bytes): chunks of 48 queries + one scale exponent per query.
+ *   qpg_audio_cosine_hl      D [dev] [Q][N*G] (f32 if d_is_f32, else f64; row stride ldD elements).  cn2 [dev] f64 [N][G],
+ *                            qn2 [dev] f64 [Q]: the UNSCALED squared norms (qpg_audio_cand_norm2 / qpg_audio_pack_queries).
+ *                            stats[1] |= 2 if a non-zero operand's scaled norm is < 1 (it is then < 2^-14 of the largest
+ *                            magnitude of its side: outside the range the representation bound covers). */
+int qpg_audio_hl_supported(int T, int F, int G, int n_taps, int tap_stride, int cand_step);
+int64_t qpg_audio_hl_db_bytes(int N, int F);
+int64_t qpg_audio_hl_query_bytes(int Q, int F);
+int qpg_audio_hl_pack_db(qpg_ctx*, void* stream, const float* base, int N, int T, int F, int G, int n_taps, int tap_stride,
+                         int cand_step, void* image, int64_t image_bytes);
+int qpg_audio_hl_pack_queries(qpg_ctx*, void* stream, const float* q32, int Q, int F, void* image, int64_t image_bytes);
+int qpg_audio_cosine_hl(qpg_ctx*, void* stream, const void* db_image, int N, int F, int G, const double* cn2,
+                        const void* q_image, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD, int32_t* stats);
+/* Hardware probe behind the bound's one measured constant: out[tile] = A[tile] (16 x 32 f16) . B[tile]^T (16 x 32 f16)
+ * + C[tile] (16 x 16 f32, NULL = 0) exactly as ONE v_mfma_f32_16x16x32_f16 computes it; the tests compare it with exact
+ * sums (kappa: error of a 32-product block sum in units of 2^-24 sum |products|). */
+int qpg_debug_mfma_f16_tile(qpg_ctx*, void* stream, const void* a, const void* b, const float* c, int tiles, float* out);
+
 /* One-off DB preparation for the text sweep: sklearn-normalise the grid rows x[j][cand_r[g]] (bit-exact,
  * as qpg_l2_normalize_rows_f32) and store them tiled for lane-per-candidate access:
  *   xt[c/64][e/4][c%64][e%4],  c = j*G + g   (a wave's 64 lanes read 64 consecutive 16-B pieces).

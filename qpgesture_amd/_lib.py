@@ -33,6 +33,10 @@ _SIGS = {
     "qpg_audio_cosine_f64_h": [P, I, I, I, P, I, I, I, P, P, P, I, P, L],
     "qpg_audio_cosine_mx": [P, I, I, I, P, I, I, I, P, P, P, I, P, I, L, P],
     "qpg_audio_cosine_mx_h": [P, I, I, I, P, I, I, I, P, P, P, I, P, I, L, P],
+    "qpg_audio_hl_pack_db": [P, I, I, I, I, I, I, I, P, L],
+    "qpg_audio_hl_pack_queries": [P, I, I, P, L],
+    "qpg_audio_cosine_hl": [P, I, I, I, P, P, P, I, P, I, L, P],
+    "qpg_debug_mfma_f16_tile": [P, P, P, I, P],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
     "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
     "qpg_text_percode_f32": [P, L, I, P, I, P, I, I, ctypes.c_int32, c_float, P, L, P, P, P, P],
@@ -141,6 +145,11 @@ def load():
     lib.qpg_percode_select_mixed_ws_bytes.argtypes = [c_int, c_int]
     lib.qpg_percode_select_mixed_ws_bytes.restype = c_int64
     lib.qpg_merge_mixed_ws_bytes.argtypes = [c_int, c_int, c_int]
+    lib.qpg_audio_hl_supported.argtypes = [c_int] * 6
+    lib.qpg_audio_hl_db_bytes.argtypes = [c_int, c_int]
+    lib.qpg_audio_hl_db_bytes.restype = c_int64
+    lib.qpg_audio_hl_query_bytes.argtypes = [c_int, c_int]
+    lib.qpg_audio_hl_query_bytes.restype = c_int64
     lib.qpg_percode_select_exact_ws_bytes.argtypes = [c_int, c_int64, c_int]
     lib.qpg_percode_select_exact_ws_bytes.restype = c_int64
     lib.qpg_merge_mixed_ws_bytes.restype = c_int64

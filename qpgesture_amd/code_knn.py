@@ -124,7 +124,7 @@ class GestureDB:
     """
 
     def __init__(self, code, wavlm_interp, context, phase_dense, signature, device="cuda:0",
-                 freq_rank=None, pos_rank=None, rank=0, world=1, wavvq=None, feature_dtype="f32"):
+                 freq_rank=None, pos_rank=None, rank=0, world=1, wavvq=None, feature_dtype="f32", hl_image=True):
         dev = torch.device(device)
         if feature_dtype not in ("f32", "f16"):
             raise ValueError("feature_dtype must be 'f32' or 'f16'")
@@ -197,6 +197,19 @@ class GestureDB:
             del src
             _lib.call("qpg_audio_cand_norm2", dev, fn2, self.n_local, self.T, self.aud_t, self.Ga,
                       NUM_AUDIO_FEAT_FRAMES, self.tap_stride, self.cn2)
+
+        # split-operand f16 image of the track for the HBM-bound sweep (qpg_audio_cosine_hl): every frame once, in MFMA
+        # fragment order; built when the grid has the reference's shape (6 taps 2 frames apart, 26 positions 6 apart)
+        self.hl_image = None
+        lib = _lib.load()
+        if (hl_image and feature_dtype == "f32" and self.n_local and len(kint) > 1 and
+                kint == [i * (kint[1] - kint[0]) for i in range(len(kint))] and
+                lib.qpg_audio_hl_supported(self.T, self.F, self.Ga, NUM_AUDIO_FEAT_FRAMES, self.tap_stride,
+                                           kint[1] - kint[0])):
+            nb = int(lib.qpg_audio_hl_db_bytes(self.n_local, self.F))
+            self.hl_image = torch.empty((nb,), dtype=torch.uint8, device=dev)
+            _lib.call("qpg_audio_hl_pack_db", dev, self.base, self.n_local, self.T, self.F, self.Ga,
+                      NUM_AUDIO_FEAT_FRAMES, self.tap_stride, kint[1] - kint[0], self.hl_image, nb)
 
         ctx = np.ascontiguousarray(context[self.lo:self.hi], np.float32)
         self.R, self.Dt = context.shape[1], context.shape[2]
@@ -281,6 +294,9 @@ class CodeKNN:
         # a clip is re-matched on when the faster ones raise their trouble word (GuardOverflow), and can be selected
         # outright.  fallbacks counts the clips that took it that way.
         self.audio_precision = "mixed"
+        # kernel of the mixed-precision sweep: "hl" = split-operand f16 matrix cores on the frame-major image (HBM-bound;
+        # needs GestureDB.hl_image), "mx" = the f32 matrix cores on the f32 / f16 base.  Same bound, same select.
+        self.audio_kernel = "hl"
         self.fallbacks = 0
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
         # Row-sharded DB: the shards sweep in mixed precision too and the cross-shard merge re-evaluates what their
@@ -364,8 +380,20 @@ class CodeKNN:
         if ev is not None:
             pool = getattr(self, "kernel_event_pool", None)      # events created ahead of the timed region
             e0, e1 = pool.pop() if pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            e0.record(torch.cuda.current_stream(dev))
-        if mixed:
+        use_hl = mixed and self.audio_kernel == "hl" and db.hl_image is not None and not half
+        self._last_audio_hl = use_hl
+        if use_hl:
+            nbq = int(_lib.load().qpg_audio_hl_query_bytes(Q, db.F))
+            qi = self.__dict__.get("_hl_qimage")
+            if qi is None or qi.numel() < nbq:
+                qi = self._hl_qimage = torch.empty((nbq,), dtype=torch.uint8, device=dev)
+            _lib.call("qpg_audio_hl_pack_queries", dev, q32, Q, db.F, qi, qi.numel())
+        if ev is not None:
+            e0.record(torch.cuda.current_stream(dev))          # (the events bracket the sweep kernel alone)
+        if use_hl:
+            _lib.call("qpg_audio_cosine_hl", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi, qn2, Q, D, 1,
+                      D.stride(0), self._guard_stats)
+        elif mixed:
             _lib.call("qpg_audio_cosine_mx_h" if half else "qpg_audio_cosine_mx", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
                       NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, 1, D.stride(0), self._guard_stats)
         else:

@@ -1,0 +1,525 @@
+// Audio (WavLM) candidate sweep, round 3: SPLIT-OPERAND f16 matrix cores, HBM-bound.
+//
+// Same contract as qpg_audio_cosine_mx (qpg_audio.hip): D[q][c] = cosine distance of query q and candidate c with an
+// A-PRIORI error bound <= QPG_AUDIO_MX_ERR, consumed by qpg_percode_select_mixed_f64, which re-evaluates every
+// comparison the bound leaves open (GestureKNN.py:666-691 is what the pair of them replaces).  What changes is where
+// the time goes: the f32 matrix cores need 200 us for the 31.4 GFLOP of a 24 s clip against 2 048 windows, the HBM
+// stream of the database 110 us.  This kernel moves the products to the f16 matrix cores (16x the f32 rate) without
+// giving up the bound, and reads every database frame from HBM exactly ONCE.
+//
+// 1. Frame-major formulation.  Candidate g of a window is the six frames 6g + {0,2,..,10} (data_processing.py:264-268):
+//    neighbouring candidates share three frames, so a candidate-major sweep touches every frame twice.  Group the frames
+//    by threes instead: SUPER-ROW i = frames 6i, 6i+2, 6i+4 (3 x 1024 features, i = 0..26), and split every query into its
+//    first / last three taps (two 3072-d columns, "lo" and "hi").  Then
+//        dot(q, cand_g) = S[g][q_lo] + S[g+1][q_hi],        S = A (27 super-rows x 3072)  .  B (3072 x 2 Q)
+//    — a plain GEMM over rows that do not overlap, plus one shifted add in the epilogue.
+// 2. Split operands.  Every value is scaled by a power of two (one exponent for the database, one per query; exact)
+//    so that the largest magnitude is in [2^14, 2^15), and stored as TWO f16 numbers: h = fl16(x), l = fl16((x - h) 2^11).
+//    x - h is exact in f32 (h is x rounded to 11 bits), so x = h + 2^-11 l + delta with |delta| <= 2^-23 |x| + 2^-36.
+//    A dot product becomes  sum h h'  +  2^-11 sum (h l' + l h')  (+ a dropped l l' term <= 2^-24 |x||y|): three
+//    v_mfma_f32_16x16x32_f16 per 32 k-steps.  f16 x f16 products are exact in f32.
+// 3. The accumulate is what limits an f16 matrix core's accuracy, so it is kept out of the bound: every h h' instruction
+//    starts from C = 0 and its 32-product block sum is added to an f64 running sum on the VALU (underneath the next
+//    MFMAs); only the cross terms, 2^-11 smaller, run as f32 chains over the whole contraction.
+//    Error budget, relative to |q||c| (Cauchy-Schwarz, as for the f32 sweep):
+//        h h' block sums      kappa 2^-24        |MFMA(A, B, 0) - exact| <= kappa 2^-24 sum |products|.  What the matrix
+//                                                core does was probed on MI355X (tools/probe_mfma_f16.py): the 32
+//                                                products are exact; each OCTET of k (one lane group's 8) is aligned to
+//                                                its largest product and CHOPPED to 25 bits before it is summed (7 terms x
+//                                                < 2^-24 of the octet's largest), the four octet sums and C meet in a wider
+//                                                adder, one round-to-nearest-even at the end: kappa <= 7 + 1 + 0.5.
+//                                                Worst seen in adversarial blocks 8.32; ASSUMED 9 (the one measured
+//                                                constant of this bound; tests/test_gpu_audio_hl.py re-measures it): 5.4e-7
+//        cross-term chains    384 instructions x 33 x 2^-23 x 2^-11 x 1 = 7.4e-7 (every add chopped: no assumption)
+//        representation       2 x 2^-23 + 2^-24 = 3.0e-7 (needs scaled norms >= 1, else stats[1] |= 2: such operands
+//                             are 2^-15 of the largest value in the database and the clip is re-matched)
+//        f64 sums, scaling    < 1e-13;   f32-stored matrix 1.2e-7
+//    total 1.70e-6 <= QPG_AUDIO_MX_ERR = 2.05e-6: the select's band is unchanged.
+// 4. Data layout.  The database image is written once (qpg_audio_hl_pack_db) in MFMA fragment order:
+//    [window][row tile 2][k-block 96][plane h|l][lane 64][8 f16] — a wave's operand load is ONE contiguous 1 KB run
+//    (rows 27..31 of a window are padding: never loaded).  680 MB at N = 2048: exactly the algorithmic bytes.  The
+//    queries of a clip are packed the same way per chunk of 48 (1.18 MB, L2-resident), shared by a block's four waves
+//    through LDS.  Two waves = one window (16-row tile x 96 columns x K = 3072 each): the shifted add of the epilogue is
+//    lane shuffles plus one row handed over through LDS; no workspace, no second pass.
+// Bound: HBM (0.70 GB per launch / 8 TB/s); MFMA time 46 us, VALU (f64 flush) 31 us at N = 2048.
+#include "qpg_common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define HL_ROWS 27            // super-rows per window (Ga + 1)
+#define HL_SUB 3              // frames per super-row
+#define HL_QC 48              // queries per chunk
+#define HL_CT 6               // column tiles per chunk (3 lo + 3 hi)
+#ifndef HL_KS
+#define HL_KS 2               // k-blocks per LDS stage
+#endif
+#define HL_PIECE 1024         // bytes of one [plane][lane][8 f16] fragment image
+
+__device__ __forceinline__ f32x4 mfma_h(h8 a, h8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// x (already scaled) -> (h, l): h = fl16(x), l = fl16((x - h) * 2^11)
+__device__ __forceinline__ void split_hl(float x, _Float16& h, _Float16& l) {
+  h = (_Float16)x;
+  const float r = x - (float)h;                    // exact
+  l = (_Float16)(r * 2048.0f);
+}
+
+// ---- scale exponent of the database: max |x| -> e with max * 2^e in [2^14, 2^15) -------------------------------
+__global__ __launch_bounds__(1024) void hl_absmax_kernel(const float* __restrict__ x, int64_t n, unsigned int* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  __shared__ float red[16];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, red[i]);
+    atomicMax(out, __float_as_uint(m));            // non-negative floats order like their bit patterns
+  }
+}
+
+__device__ __forceinline__ int hl_exponent(float amax) {      // e: amax * 2^e in [2^14, 2^15); 0 for amax == 0 / inf / nan
+  if (!(amax > 0.f) || amax > 3.0e38f) return 0;
+  int e;
+  frexpf(amax, &e);                                // amax = f * 2^e, f in [0.5, 1)
+  e = 15 - e;
+  return e > 100 ? 100 : (e < -100 ? -100 : e);    // (2^e must stay an f32 number; such data trips the norm check)
+}
+
+__global__ void hl_zero_u32_kernel(unsigned int* p) { *p = 0u; }
+
+__global__ void hl_exponent_kernel(const unsigned int* __restrict__ amax_bits, int32_t* __restrict__ meta) {
+  meta[0] = hl_exponent(__uint_as_float(amax_bits[0]));
+}
+
+// ---- database image ------------------------------------------------------------------------------------------------
+// thread <-> (window j, super-row i < 32, k8 = k / 8): reads 8 consecutive features, writes one 16-byte h piece and one
+// l piece.  image[(((j*2 + t)*KB + kb)*2 + plane)*64 + lane][8],  t = i / 16, lane = i % 16 + 16 * ((k % 32) / 8)
+__global__ __launch_bounds__(256) void hl_pack_db_kernel(const float* __restrict__ base, int N, int T, int F, int step,
+                                                         int tap_stride, const int32_t* __restrict__ meta,
+                                                         _Float16* __restrict__ image) {
+  const int KB = HL_SUB * F / 32, K8 = HL_SUB * F / 8;
+  const int64_t n = (int64_t)N * 32 * K8;
+  const float sc = ldexpf(1.0f, meta[0]);
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (int64_t)gridDim.x * blockDim.x) {
+    const int k8 = (int)(id % K8);
+    const int i = (int)((id / K8) % 32);
+    const int j = (int)(id / ((int64_t)K8 * 32));
+    const int k = k8 * 8, sub = k / F, f = k - sub * F;
+    const int t = step * i + tap_stride * sub;
+    f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (i < HL_ROWS && t < T) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(base + ((int64_t)j * T + t) * F + f);
+      v0 = p[0];
+      v1 = p[1];
+    }
+    h8 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 a0, b0, a1, b1;
+      split_hl(v0[e] * sc, a0, b0);
+      split_hl(v1[e] * sc, a1, b1);
+      hh[e] = a0; ll[e] = b0; hh[4 + e] = a1; ll[4 + e] = b1;
+    }
+    const int kb = k / 32, lane = (i & 15) + 16 * ((k & 31) >> 3);
+    const int64_t piece = (((int64_t)j * 2 + (i >> 4)) * KB + kb) * 2;
+    reinterpret_cast<h8*>(image)[(piece + 0) * 64 + lane] = hh;
+    reinterpret_cast<h8*>(image)[(piece + 1) * 64 + lane] = ll;
+  }
+}
+
+// ---- query image -----------------------------------------------------------------------------------------------------
+// one block per query slot (slots >= Q are written as zeros: chunks are always 48 wide).
+// image[((((chunk*KB + kb)*6 + ct)*2 + plane)*64 + lane][8], ct = half*3 + (q%48)/16, lane = q%16 + 16*((k%32)/8),
+// element k of half `half` = q32[q][half*3F + k].  qexp[q] = the query's scale exponent.
+__global__ __launch_bounds__(768) void hl_pack_queries_kernel(const float* __restrict__ q32, int Q, int F,
+                                                              _Float16* __restrict__ image, int32_t* __restrict__ qexp) {
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int D = 2 * HL_SUB * F, KB = HL_SUB * F / 32, K8h = HL_SUB * F / 8;      // K8h 8-element groups per half
+  __shared__ float red[12];
+  __shared__ int e_s;
+  float m = 0.f;
+  const bool live = q < Q;
+  const float* row = q32 + (int64_t)q * D;
+  if (live)
+    for (int i = tid; i < D / 4; i += blockDim.x) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(row)[i];
+      m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, red[i]);
+    e_s = hl_exponent(m);
+    if (live) qexp[q] = e_s;
+  }
+  __syncthreads();
+  const float sc = ldexpf(1.0f, e_s);
+  const int chunk = q / HL_QC, qq = q % HL_QC;
+  for (int id = tid; id < 2 * K8h; id += blockDim.x) {
+    const int half = id / K8h, k8 = id - half * K8h, k = k8 * 8;
+    f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (live) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(row + (int64_t)half * HL_SUB * F + k);
+      v0 = p[0];
+      v1 = p[1];
+    }
+    h8 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 a0, b0, a1, b1;
+      split_hl(v0[e] * sc, a0, b0);
+      split_hl(v1[e] * sc, a1, b1);
+      hh[e] = a0; ll[e] = b0; hh[4 + e] = a1; ll[4 + e] = b1;
+    }
+    const int kb = k / 32, ct = half * 3 + qq / 16, lane = (qq & 15) + 16 * ((k & 31) >> 3);
+    const int64_t piece = ((((int64_t)chunk * KB + kb) * HL_CT + ct) * 2);
+    reinterpret_cast<h8*>(image)[(piece + 0) * 64 + lane] = hh;
+    reinterpret_cast<h8*>(image)[(piece + 1) * 64 + lane] = ll;
+  }
+}
+
+// ---- the sweep ---------------------------------------------------------------------------------------------------------
+struct HlArgs {
+  const _Float16* db;      // database image
+  const _Float16* qi;      // query image (n_chunks x KB x 6 x 2 x 1 KB)
+  const int32_t* meta;     // [0] database scale exponent
+  const int32_t* qexp;     // [Q]
+  const double* cn2;       // [N][G] squared norms of the candidates (unscaled)
+  const double* qn2;       // [Q]
+  void* D;                 // [Q][ldD] f32 (d_f32) or f64
+  const float* zeros;      // the context's zero page (>= 16 bytes): what padding rows read
+  int64_t ldD;
+  int32_t* stats;
+  int N, G, Q, KB, d_f32;
+};
+
+#define HL_RING (2 * HL_KS)  // k-blocks of database fragments in flight per wave (2 KB each): two stages
+#define HL_PS (3 * HL_KS)    // pair-steps per stage
+// ablation hooks (experiments/audio_hl): -DQPG_HL_PROBE=<bits> compiles parts of the k loop out; the product build
+// defines nothing.  1: no f64 flush; 2: query fragments read from LDS once; 4: database fragments not reloaded;
+// 8: no cross-term MFMAs; 16: no query staging (loads, LDS stores, barriers) after the first stage
+#ifndef QPG_HL_PROBE
+#define QPG_HL_PROBE 0
+#endif
+
+// Block = HL_WPB database windows x 2 row tiles = 2 HL_WPB waves; wave w: window HL_WPB*blockIdx.x + (w >> 1), rows
+// 16*(w & 1) .. +15, all 96 columns of the chunk (a 16 x 96 tile of S, K = 3072).  Two waves per SIMD, <= 256 registers
+// each, the f64 sums in architectural VGPRs.  Organisations measured and dropped (experiments/audio_hl): 4 waves with
+// 32 x 96 tiles (the f64 sums land in AGPRs and the flush drowns in v_accvgpr moves: 275 us); 8 waves with 32 x 48 tiles
+// (half the LDS reads, twice the database-fragment loads: 234 us against 206).
+//
+// The k loop is ONE basic block, software-pipelined by hand (left to itself hipcc waits lgkmcnt(0) right behind every
+// pair of fragment reads, drains the HBM ring with vmcnt(0) at each __syncthreads and puts dependent MFMAs back to back:
+// 257 us):
+//   pair-step = two column tiles of one k-block: 6 MFMAs (2 h h' block sums from C = 0, 2 x 2 cross terms, the two
+//   MFMAs of one accumulator two instructions apart), the 4 fragment reads of the NEXT pair-step, and the f64 flush of
+//   the PREVIOUS pair-step's block sums (16 VALU operations), interleaved by sched_group_barrier.
+//   stage = HL_KS k-blocks; the query fragments of stage s+1 are stored to the other LDS buffer at the start of stage s,
+//   and the ONE barrier of a stage (LDS-only: s_waitcnt lgkmcnt(0) + s_barrier, the HBM ring stays in flight) sits in
+//   the last pair-step, behind the arrival of that pair-step's own fragments: behind it nobody reads this stage's
+//   buffer any more and everybody's stores of the next stage are done, so the next stage's first fragments are
+//   prefetched under the last pair-step's MFMAs - no bubble.
+#ifndef HL_WPB
+#define HL_WPB 4           // database windows per block (2 waves each)
+#endif
+#define HL_THREADS (128 * HL_WPB)
+#define HL_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+__global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 * HL_KS * HL_CT * 2 * HL_PIECE bytes
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wl = w >> 1, t = w & 1;                           // window of the block, row tile
+  const int j = blockIdx.x * HL_WPB + wl;
+  const int chunk = blockIdx.y;
+  const int KB = a.KB, n_stage = KB / HL_KS;
+  const bool win_ok = j < a.N;
+  // database fragments: plane p of k-block kb: one 16-byte load per lane, 1 KB per wave, contiguous.  Padding rows
+  // (27..31) and windows past N read the context's zero page instead (stride 0): no branch in the loop.
+  const bool row_ok = win_ok && (16 * t + (lane & 15)) < HL_ROWS;
+  const h8* dbp = row_ok ? reinterpret_cast<const h8*>(a.db) + (((int64_t)j * 2 + t) * KB * 2) * 64 + lane
+                         : reinterpret_cast<const h8*>(a.zeros);
+  const int kb_step = row_ok ? 128 : 0, pl_step = row_ok ? 64 : 0;      // h8 units per k-block / plane
+  auto load_a = [&](int kb, h8 (&dst)[2]) {
+    dst[0] = dbp[(int64_t)kb * kb_step];
+    dst[1] = dbp[(int64_t)kb * kb_step + pl_step];
+  };
+  // query image of this chunk: stage s = HL_KS*6*2 pieces of 1 KB; 16-byte units, stage_units / HL_THREADS per thread
+  constexpr int stage_units = HL_KS * HL_CT * 2 * 64;
+  const h8* qsrc = reinterpret_cast<const h8*>(a.qi) + (int64_t)chunk * KB * HL_CT * 2 * 64;
+  constexpr int QLD = stage_units / HL_THREADS;
+  h8 qreg[QLD];
+  auto load_q = [&](int s) {
+    s = s < n_stage ? s : n_stage - 1;                        // (past the end: a harmless re-read)
+#pragma unroll
+    for (int u = 0; u < QLD; ++u) qreg[u] = qsrc[(int64_t)s * stage_units + u * HL_THREADS + tid];
+  };
+  auto store_q = [&](int buf) {
+    h8* dst = reinterpret_cast<h8*>(lds) + buf * stage_units;
+#pragma unroll
+    for (int u = 0; u < QLD; ++u) dst[u * HL_THREADS + tid] = qreg[u];
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  double acc[HL_CT][4];
+  f32x4 xacc[HL_CT];
+#pragma unroll
+  for (int c = 0; c < HL_CT; ++c) {
+    xacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[c][r] = 0.0;
+  }
+  h8 ring[HL_RING][2];
+#pragma unroll
+  for (int i = 0; i < HL_RING; ++i) load_a(i, ring[i]);
+  load_q(0);
+  store_q(0);
+  load_q(1);
+  lds_barrier();
+  store_q(1);                                                   // stage 1's fragments: read after stage 0's barrier
+  load_q(2);
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // fragments of a pair-step: [column tile of the pair][plane]; pair-step ps of a stage: k2 = ps / 3, c0 = 2 * (ps % 3)
+  h8 B[2][2][2];
+  auto ld_b = [&](int buf, int ps, h8 (&d)[2][2]) {
+    const h8* qb = reinterpret_cast<const h8*>(lds) + buf * stage_units + lane;
+    const int k2 = ps / 3, c0 = 2 * (ps % 3);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) d[jj][pl] = qb[((k2 * HL_CT + c0 + jj) * 2 + pl) * 64];
+  };
+  f32x4 hp[2] = {zero4, zero4};                                 // the previous pair-step's block sums, not yet flushed
+  ld_b(0, 0, B[0]);
+
+  for (int s2 = 0; s2 < n_stage; s2 += 2) {                     // two stages per trip: ring / buffer indices are static
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const int s = s2 + ss;
+#pragma unroll
+      for (int ps = 0; ps < HL_PS; ++ps) {
+        const int k2 = ps / 3, c0 = 2 * (ps % 3);
+        const int pc0 = 2 * ((ps + 2) % 3);                     // the previous pair-step's column tiles
+        const int kb = s * HL_KS + k2;
+        h8 (&af)[2] = ring[(ss * HL_KS + k2) % HL_RING];
+        h8 (&Bc)[2][2] = B[ps & 1];
+        h8 (&Bn)[2][2] = B[(ps + 1) & 1];
+        if (ps == HL_PS - 1) {
+          // this pair-step's fragments have arrived (they are about to be used): from here on nobody reads this
+          // stage's buffer, and every wave's stores of the next stage (issued at the start of this one) are done
+          lds_barrier();
+          ld_b((ss + 1) & 1, 0, Bn);                            // next stage, pair-step 0
+        } else {
+          ld_b(ss, ps + 1, Bn);
+        }
+        const f32x4 h0 = mfma_h(af[0], Bc[0][0], zero4);        // 32 exact products each: one block sum
+        const f32x4 h1 = mfma_h(af[0], Bc[1][0], zero4);
+        if (!(QPG_HL_PROBE & 8)) {
+          xacc[c0] = mfma_h(af[0], Bc[0][1], xacc[c0]);         // cross terms: f32 chains (2^-11 smaller)
+          xacc[c0 + 1] = mfma_h(af[0], Bc[1][1], xacc[c0 + 1]);
+          xacc[c0] = mfma_h(af[1], Bc[0][0], xacc[c0]);
+          xacc[c0 + 1] = mfma_h(af[1], Bc[1][0], xacc[c0 + 1]);
+        }
+        if (!(QPG_HL_PROBE & 1)) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[pc0 + jj][r] += (double)hp[jj][r];      // f64 running sums
+        }
+        hp[0] = h0;
+        hp[1] = h1;
+        if (ps % 3 == 2 && !(QPG_HL_PROBE & 4)) {                                  // this k-block is done: refill its slot
+          const int kn = kb + HL_RING < KB ? kb + HL_RING : KB - 1;
+          load_a(kn, af);
+        }
+        if (ps == HL_PS - 1) {                                  // (behind the barrier) next-but-one stage -> this buffer
+          store_q(ss);
+          load_q(s + 3);
+        }
+        // issue order: an MFMA, then a fragment read and a share of the flush underneath it
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          HL_SGB(0x008, 1);
+          if (i < 4) HL_SGB(0x100, 1);
+          HL_SGB(0x002, 3);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)                                // the last pair-step's block sums (column tiles 4, 5)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[4 + jj][r] += (double)hp[jj][r];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // surplus prefetches must not outlive their registers
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: S = hh + 2^-11 cross; dot(q, cand g) = S[g][lo col] + S[g+1][hi col]; cosine distance; store
+  const int cg = lane & 15, rg = lane >> 4;
+  double* exch = reinterpret_cast<double*>(lds);              // [windows][3 ct][16 cols]: row 16 of the hi columns
+  double hi[3][4];
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hi[ct][r] = acc[3 + ct][r] + (double)xacc[3 + ct][r] * (1.0 / 2048.0);
+  if (t == 1 && rg == 0)
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) exch[(wl * 3 + ct) * 16 + cg] = hi[ct][0];
+  __syncthreads();
+  const int e_c = a.meta[0];
+  const int src = (lane + 16) & 63;
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    const int q = chunk * HL_QC + ct * 16 + cg;
+    const bool q_ok = q < a.Q;
+    const double qq = q_ok ? a.qn2[q] : 1.0;
+    const int e_q = q_ok ? a.qexp[q] : 0;
+    // S[row + 1][hi column]: reg r+1 of the same lane, reg 0 of the lane 16 further (next row group), or - from row
+    // group 3 of tile 0 - row 16, which the window's other wave left in LDS
+    const double nx = __shfl(hi[ct][0], src, 64);
+    const double n16 = exch[(wl * 3 + ct) * 16 + cg];
+    double hs[4];
+    hs[0] = hi[ct][1];
+    hs[1] = hi[ct][2];
+    hs[2] = hi[ct][3];
+    hs[3] = rg < 3 ? nx : (t == 0 ? n16 : 0.0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int g = 16 * t + 4 * rg + r;                        // candidate = super-rows g, g + 1
+      if (!win_ok || !q_ok || g >= a.G) continue;
+      const double lo = acc[ct][r] + (double)xacc[ct][r] * (1.0 / 2048.0);
+      const double dot = ldexp(lo + hs[r], -(e_c + e_q));
+      const int64_t c = (int64_t)j * a.G + g;
+      const double cc = a.cn2[c];
+      // validity range of the representation bound: scaled norms >= 1 (4^e * |x|^2 >= 1), zero rows excepted
+      if (a.stats && ((cc > 0.0 && ldexp(cc, 2 * e_c) < 1.0) || (qq > 0.0 && ldexp(qq, 2 * e_q) < 1.0)))
+        atomicOr(&a.stats[1], 2);
+      const double dd = cosine_from_dot(dot, qq, cc);
+      if (a.d_f32) reinterpret_cast<float*>(a.D)[(int64_t)q * a.ldD + c] = (float)dd;
+      else reinterpret_cast<double*>(a.D)[(int64_t)q * a.ldD + c] = dd;
+    }
+  }
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------------------
+extern "C" int64_t qpg_audio_hl_db_bytes(int N, int F) {            // database image + 64 bytes of metadata
+  return (N <= 0 || F <= 0) ? 0 : (int64_t)N * 2 * (HL_SUB * F / 32) * 2 * HL_PIECE + 64;
+}
+extern "C" int64_t qpg_audio_hl_query_bytes(int Q, int F) {
+  const int chunks = (Q + HL_QC - 1) / HL_QC;
+  return (Q <= 0 || F <= 0) ? 0 : (int64_t)chunks * (HL_SUB * F / 32) * HL_CT * 2 * HL_PIECE + (int64_t)chunks * HL_QC * 4;
+}
+
+static bool hl_grid_ok(int T, int F, int G, int n_taps, int tap_stride, int step) {
+  return n_taps == 2 * HL_SUB && G == HL_ROWS - 1 && step == HL_SUB * tap_stride && (F % 32) == 0 && F >= 32 &&
+         ((HL_SUB * F / 32) % (2 * HL_KS)) == 0 && T > 0;
+}
+
+extern "C" int qpg_audio_hl_supported(int T, int F, int G, int n_taps, int tap_stride, int cand_step) {
+  return hl_grid_ok(T, F, G, n_taps, tap_stride, cand_step) ? 1 : 0;
+}
+
+extern "C" int qpg_audio_hl_pack_db(qpg_ctx* ctx, void* stream, const float* base, int N, int T, int F, int G, int n_taps,
+                                    int tap_stride, int cand_step, void* image, int64_t image_bytes) {
+  const char* name = "qpg_audio_hl_pack_db";
+  QPG_REQUIRE(ctx && base && image && N > 0, "%s: bad argument", name);
+  QPG_REQUIRE(hl_grid_ok(T, F, G, n_taps, tap_stride, cand_step),
+              "%s: needs 6 taps, 26 grid positions %d frames apart (= 3 x tap_stride) and F %% 128 == 0", name,
+              HL_SUB * tap_stride);
+  QPG_REQUIRE(image_bytes >= qpg_audio_hl_db_bytes(N, F) && (reinterpret_cast<uintptr_t>(image) % 16) == 0 &&
+                  (reinterpret_cast<uintptr_t>(base) % 16) == 0,
+              "%s: image too small or misaligned (qpg_audio_hl_db_bytes)", name);
+  hipStream_t st = qpg_stream(stream);
+  unsigned char* img = static_cast<unsigned char*>(image);
+  const int64_t body = qpg_audio_hl_db_bytes(N, F) - 64;
+  int32_t* meta = reinterpret_cast<int32_t*>(img + body);
+  unsigned int* amax = reinterpret_cast<unsigned int*>(meta + 4);
+  hipLaunchKernelGGL(hl_zero_u32_kernel, dim3(1), dim3(1), 0, st, amax);
+  hipLaunchKernelGGL(hl_absmax_kernel, dim3(1024), dim3(1024), 0, st, base, (int64_t)N * T * F, amax);
+  hipLaunchKernelGGL(hl_exponent_kernel, dim3(1), dim3(1), 0, st, (const unsigned int*)amax, meta);
+  hipLaunchKernelGGL(hl_pack_db_kernel, dim3(4096), dim3(256), 0, st, base, N, T, F, cand_step, tap_stride,
+                     (const int32_t*)meta, reinterpret_cast<_Float16*>(img));
+  QPG_LAUNCH_CHECK("hl_pack_db_kernel");
+  return QPG_OK;
+}
+
+extern "C" int qpg_audio_hl_pack_queries(qpg_ctx* ctx, void* stream, const float* q32, int Q, int F, void* image,
+                                         int64_t image_bytes) {
+  const char* name = "qpg_audio_hl_pack_queries";
+  QPG_REQUIRE(ctx && q32 && image && Q > 0 && F > 0 && (F % 32) == 0, "%s: bad argument", name);
+  QPG_REQUIRE(image_bytes >= qpg_audio_hl_query_bytes(Q, F) && (reinterpret_cast<uintptr_t>(image) % 16) == 0 &&
+                  (reinterpret_cast<uintptr_t>(q32) % 16) == 0,
+              "%s: image too small or misaligned (qpg_audio_hl_query_bytes)", name);
+  const int chunks = (Q + HL_QC - 1) / HL_QC;
+  unsigned char* img = static_cast<unsigned char*>(image);
+  int32_t* qexp = reinterpret_cast<int32_t*>(img + (int64_t)chunks * (HL_SUB * F / 32) * HL_CT * 2 * HL_PIECE);
+  hipLaunchKernelGGL(hl_pack_queries_kernel, dim3(chunks * HL_QC), dim3(768), 0, qpg_stream(stream), q32, Q, F,
+                     reinterpret_cast<_Float16*>(img), qexp);
+  QPG_LAUNCH_CHECK("hl_pack_queries_kernel");
+  return QPG_OK;
+}
+
+extern "C" int qpg_audio_cosine_hl(qpg_ctx* ctx, void* stream, const void* db_image, int N, int F, int G,
+                                   const double* cn2, const void* q_image, const double* qn2, int Q, void* D,
+                                   int d_is_f32, int64_t ldD, int32_t* stats) {
+  const char* name = "qpg_audio_cosine_hl";
+  QPG_REQUIRE(ctx && db_image && cn2 && q_image && qn2 && D, "%s: null pointer", name);
+  QPG_REQUIRE(N > 0 && Q > 0 && G == HL_ROWS - 1 && (F % 32) == 0 && ((HL_SUB * F / 32) % (2 * HL_KS)) == 0 &&
+                  ldD >= (int64_t)N * G,
+              "%s: bad size", name);
+  const int chunks = (Q + HL_QC - 1) / HL_QC, KB = HL_SUB * F / 32;
+  HlArgs a;
+  const unsigned char* dbi = static_cast<const unsigned char*>(db_image);
+  const unsigned char* qi = static_cast<const unsigned char*>(q_image);
+  a.db = reinterpret_cast<const _Float16*>(dbi);
+  a.meta = reinterpret_cast<const int32_t*>(dbi + (qpg_audio_hl_db_bytes(N, F) - 64));
+  a.qi = reinterpret_cast<const _Float16*>(qi);
+  a.qexp = reinterpret_cast<const int32_t*>(qi + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
+  a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = N; a.G = G; a.Q = Q; a.KB = KB; a.d_f32 = d_is_f32;
+  const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
+  if (lds_bytes > 64 * 1024) {
+    static bool raised = false;
+    if (!raised && hipFuncSetAttribute(reinterpret_cast<const void*>(audio_cosine_hl_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+      qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
+      return QPG_EHIP;
+    }
+    raised = true;
+  }
+  hipLaunchKernelGGL(audio_cosine_hl_kernel, dim3((N + HL_WPB - 1) / HL_WPB, chunks), dim3(HL_THREADS), lds_bytes,
+                     qpg_stream(stream), a);
+  QPG_LAUNCH_CHECK("audio_cosine_hl_kernel");
+  return QPG_OK;
+}
+
+// ---- hardware probe: one v_mfma_f32_16x16x32_f16 per 16 x 16 tile of (A rows, B rows), C given -------------------------------
+// a, b: [tiles][16][32] f16; c: [tiles][16][16] f32 (may be NULL = 0); out: [tiles][16][16] f32 = A . B^T + C as the
+// matrix core computes it.  tests/test_gpu_audio_hl.py measures its error against exact sums (the kappa of the bound).
+__global__ __launch_bounds__(64) void hl_probe_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B,
+                                                      const float* __restrict__ C, float* __restrict__ out) {
+  const int tile = blockIdx.x, lane = threadIdx.x;
+  const h8 a = reinterpret_cast<const h8*>(A + (int64_t)tile * 512 + (lane & 15) * 32)[lane >> 4];
+  const h8 b = reinterpret_cast<const h8*>(B + (int64_t)tile * 512 + (lane & 15) * 32)[lane >> 4];
+  f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (C)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = C[(int64_t)tile * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)];
+  const f32x4 d = mfma_h(a, b, c);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(int64_t)tile * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = d[r];
+}
+
+extern "C" int qpg_debug_mfma_f16_tile(qpg_ctx* ctx, void* stream, const void* a, const void* b, const float* c, int tiles,
+                                       float* out) {
+  QPG_REQUIRE(ctx && a && b && out && tiles > 0, "qpg_debug_mfma_f16_tile: bad argument");
+  hipLaunchKernelGGL(hl_probe_kernel, dim3(tiles), dim3(64), 0, qpg_stream(stream), static_cast<const _Float16*>(a),
+                     static_cast<const _Float16*>(b), c, out);
+  QPG_LAUNCH_CHECK("hl_probe_kernel");
+  return QPG_OK;
+}
