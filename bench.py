@@ -501,8 +501,9 @@ def main():
     if mixed and sharded_run:
         st = knn.mixed_stats()
         fl = knn._guard_stats.cpu().numpy()
-        out["mixed_precision"] = {"shard_f64_dot_pairs_per_step": round(st["tier1_pairs"] / (a.steps + a.warmup), 1),
-                                  "cross_shard_reevaluations_per_step": round(int(fl[3]) / (a.steps + a.warmup), 1),
+        n_run = a.steps + a.warmup + prewarm["steps"]
+        out["mixed_precision"] = {"shard_f64_dot_pairs_per_step": round(st["tier1_pairs"] / n_run, 1),
+                                  "cross_shard_reevaluations_per_step": round(int(fl[3]) / n_run, 1),
                                   "flags": st["flags"], "error_bound": 2.05e-6}
     if mixed and not sharded_run:
         # re-evaluation activity of the timed steps (+ warm-up) and the same clip through the f64 sweep: the mixed path
@@ -512,7 +513,7 @@ def main():
             ls = [ln["knn"].mixed_stats() for ln in pipe.lanes]
             st = {"tier1_pairs": sum(x["tier1_pairs"] for x in ls), "tier2_pairs": sum(x["tier2_pairs"] for x in ls),
                   "flags": int(np.bitwise_or.reduce([x["flags"] for x in ls]))}
-        n_run = a.steps + a.warmup
+        n_run = a.steps + a.warmup + prewarm["steps"]
         k64 = CodeKNN(db, rng=np.random.RandomState(123456))
         k64.audio_precision = "f64"
         T64 = k64.sweep_tables(te_interp, te_ctx, M * n_clips)

@@ -121,8 +121,8 @@ int qpg_audio_cosine_mx_h(qpg_ctx*, void* stream, const void* base_f16, int N, i
                           void* D, int d_is_f32, int64_t ldD, int32_t* stats);
 
 /* SPLIT-OPERAND f16 form of the mixed-precision sweep (round 3; the default audio sweep where the grid allows it):
- * same contract and the same a-priori bound as qpg_audio_cosine_mx (|D - exact| <= QPG_AUDIO_MX_ERR for every pair,
- * consumed by qpg_percode_select_mixed_f64), with the products on the f16 matrix cores: every value is scaled by a power
+ * same contract as qpg_audio_cosine_mx with a tighter a-priori bound (|D - exact| <= QPG_AUDIO_HL_ERR for every pair,
+ * consumed by qpg_percode_select_mixed_f64 with eps1 >= 2 x that), with the products on the f16 matrix cores: every value is scaled by a power
  * of two and stored as two f16 numbers (h, l) with x = h + 2^-11 l (+ <= 2^-23 |x|), the h h' block sums of every MFMA
  * are added in f64, the cross terms run as f32 chains, and the database is read in a frame-major image in which every
  * frame occurs ONCE (super-rows of three frames: dot(q, cand g) = S[g][q first 3 taps] + S[g+1][q last 3 taps]) — the
@@ -138,7 +138,14 @@ int qpg_audio_cosine_mx_h(qpg_ctx*, void* stream, const void* base_f16, int N, i
  *                            qn2 [dev] f64 [Q]: the UNSCALED squared norms (qpg_audio_cand_norm2 / qpg_audio_pack_queries).
  *                            stats[1] |= 2 if a non-zero operand's scaled norm is < 1 (it is then < 2^-14 of the largest
  *                            magnitude of its side: outside the range the representation bound covers). */
+#define QPG_AUDIO_HL_ERR 1.3e-6 /* a-priori bound of qpg_audio_cosine_hl: |D - exact| <= this for every pair in range */
 int qpg_audio_hl_supported(int T, int F, int G, int n_taps, int tap_stride, int cand_step);
+/* qpg_audio_pack_queries + qpg_audio_hl_pack_queries in ONE launch (the pair sits on a clip's critical path): gathers the
+ * queries from qbase [dev] f32 [M][T][F] like qpg_audio_pack_queries (q32, qn2 are still written: the select's
+ * re-evaluations read them) and writes the split-f16 image.  6 taps, F %% 32 == 0, F <= 2048. */
+int qpg_audio_pack_queries_hl(qpg_ctx*, void* stream, const float* qbase, int M, int T, int F, const int32_t* q_win,
+                              const int32_t* q_t, int Q, int n_taps, int tap_stride, float* q32, double* qn2, void* image,
+                              int64_t image_bytes);
 int64_t qpg_audio_hl_db_bytes(int N, int F);
 int64_t qpg_audio_hl_query_bytes(int Q, int F);
 int qpg_audio_hl_pack_db(qpg_ctx*, void* stream, const float* base, int N, int T, int F, int G, int n_taps, int tap_stride,

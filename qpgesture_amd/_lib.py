@@ -35,6 +35,7 @@ _SIGS = {
     "qpg_audio_cosine_mx_h": [P, I, I, I, P, I, I, I, P, P, P, I, P, I, L, P],
     "qpg_audio_hl_pack_db": [P, I, I, I, I, I, I, I, P, L],
     "qpg_audio_hl_pack_queries": [P, I, I, P, L],
+    "qpg_audio_pack_queries_hl": [P, I, I, I, P, P, I, I, I, P, P, P, L],
     "qpg_audio_cosine_hl": [P, I, I, I, P, P, P, I, P, I, L, P],
     "qpg_debug_mfma_f16_tile": [P, P, P, I, P],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],

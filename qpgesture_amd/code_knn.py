@@ -24,6 +24,9 @@ MODE_AUD_TXT, MODE_AUD, MODE_TXT = 0, 1, 2
 # like the exact distances; 5 % margin on top)
 AUDIO_MX_ERR = 2.05e-6
 AUDIO_MX_BAND = 2.1 * AUDIO_MX_ERR
+# the split-operand f16 sweep (qpg_audio_cosine_hl, QPG_AUDIO_HL_ERR): a tighter bound, a narrower band
+AUDIO_HL_ERR = 1.3e-6
+AUDIO_HL_BAND = 2.1 * AUDIO_HL_ERR
 
 # bits of the trouble word the sweeps / selects raise (stats[1] of include/qpg.h) and the walk carries out with the codes
 FLAG_LIST_OVERFLOW, FLAG_SMALL_NORMS, FLAG_REQUEST_OVERFLOW, FLAG_CROSS_SHARD_TIE = 1, 2, 4, 8
@@ -355,8 +358,6 @@ class CodeKNN:
         ts = db.tap_stride if tap_stride is None else tap_stride
         q32 = torch.empty((Q, NUM_AUDIO_FEAT_FRAMES * F), dtype=torch.float32, device=dev)
         qn2 = torch.empty((Q,), dtype=torch.float64, device=dev)
-        _lib.call("qpg_audio_pack_queries", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
-                  NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2)
         C = db.n_local * db.Ga
         fused_rank = want_rank and db.world == 1
         half = db.feature_dtype == "f16"
@@ -382,12 +383,16 @@ class CodeKNN:
             e0, e1 = pool.pop() if pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         use_hl = mixed and self.audio_kernel == "hl" and db.hl_image is not None and not half
         self._last_audio_hl = use_hl
-        if use_hl:
+        if use_hl:                    # gather + norms + split-f16 image in ONE launch
             nbq = int(_lib.load().qpg_audio_hl_query_bytes(Q, db.F))
             qi = self.__dict__.get("_hl_qimage")
             if qi is None or qi.numel() < nbq:
                 qi = self._hl_qimage = torch.empty((nbq,), dtype=torch.uint8, device=dev)
-            _lib.call("qpg_audio_hl_pack_queries", dev, q32, Q, db.F, qi, qi.numel())
+            _lib.call("qpg_audio_pack_queries_hl", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
+                      NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2, qi, qi.numel())
+        else:
+            _lib.call("qpg_audio_pack_queries", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
+                      NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2)
         if ev is not None:
             e0.record(torch.cuda.current_stream(dev))          # (the events bracket the sweep kernel alone)
         if use_hl:
@@ -422,7 +427,8 @@ class CodeKNN:
                 ws = self._mix_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
             _lib.call("qpg_percode_select_mixed_f64", dev, D, 1, D.stride(0), Q, db.aud_cand_code, C, db.K,
                       float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
-                      db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2, AUDIO_MX_BAND, float(self.tie_eps),
+                      db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2,
+                      AUDIO_HL_BAND if use_hl else AUDIO_MX_BAND, float(self.tie_eps),
                       self._guard_stats, None if self.mixed_single_launch else ws,
                       0 if self.mixed_single_launch else ws.numel(), int(half))
         elif exact:
@@ -795,7 +801,7 @@ class CodeKNN:
             R, fl_cap, band = Qb * K, K * W, float(self.tie_eps)
         else:
             R = int(self.mixed_requests) if self.mixed_requests else max(1024, 16384 // W)
-            fl_cap, band = 1024, AUDIO_MX_BAND
+            fl_cap, band = 1024, (AUDIO_HL_BAND if getattr(self, "_last_audio_hl", False) else AUDIO_MX_BAND)
         req_stride, resp_stride = 8 + 8 * R, 8 * R
         key = "_mm_bufs_exact" if exact else "_mm_bufs"
         bufs = self.__dict__.get(key)

@@ -1214,9 +1214,9 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
   QPG_REQUIRE(Q >= 0 && C >= 0 && K > 0 && K <= 512 && ldD >= C && C + (int64_t)idx_base < 0x7fffffffll,
               "%s: bad size (K <= 512)", name);
   QPG_REQUIRE(T > 0 && F > 0 && (F % 4) == 0 && G > 0 && n_taps > 0 && tap_stride > 0 && C % G == 0 &&
-                  eps1 >= 2.0 * QPG_AUDIO_MX_ERR && eps2 >= 0.0 && eps2 < eps1,
-              "%s: bad geometry (F %% 4 == 0) or eps (eps1 >= 2 x the sweep's error bound %g, 0 <= eps2 < eps1)", name,
-              (double)QPG_AUDIO_MX_ERR);
+                  eps1 >= 2.0 * QPG_AUDIO_HL_ERR && eps2 >= 0.0 && eps2 < eps1,
+              "%s: bad geometry (F %% 4 == 0) or eps (eps1 >= 2 x the sweep's error bound - at least %g -, 0 <= eps2 < eps1)",
+              name, 2.0 * (double)QPG_AUDIO_HL_ERR);
   QPG_REQUIRE(q_block >= 0 && (q_block == 0 || (!out_rank && Q % q_block == 0 && block_stride % 8 == 0)),
               "%s: block layout needs Q %% q_block == 0, an 8-byte multiple stride and no rank output", name);
   if (Q == 0) return QPG_OK;

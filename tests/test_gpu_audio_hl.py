@@ -118,7 +118,7 @@ def _sweeps(N, Q, seed, F=1024, plant=True):
 
 
 def test_hl_sweep_stays_inside_the_error_bound():
-    from qpgesture_amd.code_knn import AUDIO_MX_ERR
+    from qpgesture_amd.code_knn import AUDIO_HL_ERR as AUDIO_MX_ERR
     for Q, N, F in ((48, 96, 1024), (16, 37, 1024), (5, 8, 1024), (100, 50, 1024), (768, 24, 1024), (48, 700, 1024),
                     (48, 33, 256)):
         D64, Dhl, stats = _sweeps(N, Q, seed=Q + N, F=F)
@@ -137,8 +137,7 @@ def test_hl_sweep_flags_operands_outside_its_range():
     """A window 1e-7 of the loudest value of the database: its scaled norm is < 1, the representation bound does not
     cover it -> stats[1] |= 2 (the host re-matches such a clip); everything else stays inside the bound."""
     import torch
-    from qpgesture_amd.code_knn import AUDIO_MX_ERR
-    import tests.test_gpu_audio_hl as me
+    from qpgesture_amd.code_knn import AUDIO_HL_ERR as AUDIO_MX_ERR
     orig = torch.randn
 
     def planted(*a, **k):
@@ -172,7 +171,7 @@ def _build(A, freq_rank, kernel, dev="cuda:0"):
 @pytest.mark.parametrize("name", ["shipped_n48_m2_s0", "shipped_n64_m3_s10", "shipped_neartie_n48_m2_s30",
                                   "shipped_speechlike_n48_m2_s60"])
 def test_matcher_on_the_hl_kernel_vs_reference_goldens(name):
-    from qpgesture_amd.code_knn import AUDIO_MX_ERR
+    from qpgesture_amd.code_knn import AUDIO_HL_ERR as AUDIO_MX_ERR
     g = load_golden(name)
     ntr, nte, s0, s1, s2, s3, mf = [int(v) for v in g["meta"]]
     variant = (str(g["variant"]) or None) if "variant" in g.files else None

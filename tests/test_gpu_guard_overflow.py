@@ -133,26 +133,27 @@ def _oracle_tables(A, M):
                            n_threads=min(32, os.cpu_count() or 1))
 
 
-def _match(A, prec, dev="cuda:0"):
+def _match(A, prec, dev="cuda:0", kernel="hl"):
     import torch
     from qpgesture_amd.code_knn import CodeKNN, GestureDB
     db = GestureDB(A["code"], A["tr_interp"], A["tr_ctx"], A["tr_phase"], A["sig"], device=dev)
     knn = CodeKNN(db, rng=np.random.RandomState(7))
     knn.audio_precision = prec
+    knn.audio_kernel = kernel
     te_i = torch.from_numpy(A["te_interp"]).to(dev)
     te_c = torch.from_numpy(np.ascontiguousarray(A["te_ctx"])).to(dev)
     out = knn.match_clip(te_i, te_c, 2, return_tables=True)
     return knn, out
 
 
-@pytest.mark.parametrize("prec", ["mixed", "f64"])
+@pytest.mark.parametrize("prec", ["mixed", "mixed-mx", "f64"])
 def test_three_thousand_near_copies_of_one_window_vs_c_oracle(prec):
     """>= 3 000 eps-perturbed copies of one window under one code (VERDICT r2 next #1a): every list cap is exceeded
     (tier 1: 2 048, tier 2 / guarded: 256).  After the re-match the tables are the C oracle's (reference arithmetic):
     winners, the stable rank order of the 512 minima, refined distances bit for bit; codes == the exact path's own."""
     A = _crowded(3000)
     d_ref, i_ref = _oracle_tables(A, 2)
-    knn, (codes, _, votes) = _match(A, prec)
+    knn, (codes, _, votes) = _match(A, prec.split("-")[0], kernel="mx" if prec.endswith("mx") else "hl")
     assert knn.fallbacks == 1 and knn.mixed_stats()["flags"] == 0
     T = knn.tables
     assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref)
@@ -168,12 +169,15 @@ def test_three_thousand_near_copies_of_one_window_vs_c_oracle(prec):
 
 
 def test_norms_below_the_error_bound_s_range_rematch():
-    """Operand norms scaled to ~1e-10 (|q||c| < 1e-16) void the mixed-precision sweep's a-priori bound: flag 2, re-match
-    on the f64 / exact path, tables == the C oracle's on the scaled data (cosine distance is scale-free)."""
+    """f32-matrix-core sweep (audio_kernel "mx"): operand norms scaled to ~1e-10 (|q||c| < 1e-16) void its a-priori bound
+    (f32 products may underflow): flag 2, re-match on the exact path, tables == the C oracle's on the scaled data (cosine
+    distance is scale-free).  The split-f16 sweep scales by powers of two first: the same data is inside ITS range."""
     from qpgesture_amd.code_knn import FLAG_SMALL_NORMS, GuardOverflow
     A = _crowded(8, scale=1e-11)
     d_ref, i_ref = _oracle_tables(A, 2)
-    knn, (codes, _, _) = _match(A, "mixed")
+    khl, _ = _match(A, "mixed")
+    assert khl.fallbacks == 0 and khl._last_audio_hl and np.array_equal(khl.tables["aud_idx"].cpu().numpy(), i_ref)
+    knn, (codes, _, _) = _match(A, "mixed", kernel="mx")
     assert knn.fallbacks == 1
     assert np.array_equal(knn.tables["aud_idx"].cpu().numpy(), i_ref)
     assert np.abs(knn.tables["aud_d"].cpu().numpy() - d_ref).max() < 1e-12
@@ -187,6 +191,19 @@ def test_norms_below_the_error_bound_s_range_rematch():
         knn.walk(T, 2, 0, seed_code=sc, seed_phase=sp)
     assert e.value.flags & FLAG_SMALL_NORMS
     knn.clear_flags()
+
+
+def test_split_f16_sweep_rematches_what_is_outside_its_range():
+    """Split-f16 sweep: a database window 1e-7 of the loudest value has a scaled norm < 1, where the representation bound
+    does not hold: flag 2, re-match, tables == the C oracle's."""
+    A = _crowded(8)
+    A["tr_interp"][20] *= np.float32(1e-7)
+    A["tr_interp"][33, 40:90] *= np.float32(50.0)
+    d_ref, i_ref = _oracle_tables(A, 2)
+    knn, _ = _match(A, "mixed")
+    assert knn.fallbacks == 1
+    assert np.array_equal(knn.tables["aud_idx"].cpu().numpy(), i_ref)
+    assert np.abs(knn.tables["aud_d"].cpu().numpy() - d_ref).max() < 1e-12
 
 
 def test_clips_in_flight_rematch_flagged_clips():

@@ -289,6 +289,11 @@ def test_mixed_precision_constants_agree_with_the_header():
     assert code_knn.AUDIO_MX_BAND >= 2.0 * code_knn.AUDIO_MX_ERR
     u = 2.0 ** -24
     assert code_knn.AUDIO_MX_ERR >= 32 * u / (1 - 32 * u) + 1e-13        # gamma_32 + the f64 part
+    m2 = re.search(r"#define\s+QPG_AUDIO_HL_ERR\s+([0-9.eE+-]+)", txt)
+    assert m2 and float(m2.group(1)) == code_knn.AUDIO_HL_ERR and code_knn.AUDIO_HL_BAND >= 2.0 * code_knn.AUDIO_HL_ERR
+    # the split-f16 sweep's budget (csrc/qpg_audio_hl.hip): 12 roundings per block sum + cross chains + representation
+    # + the f32-stored matrix
+    assert code_knn.AUDIO_HL_ERR >= 12 * u + 12 * 193 * u / 2048 + (2 * 2.0 ** -23 + u) + 2 * u + 1e-13
 
 
 def test_numpy_ranks_follow_the_reference_s_array_dtype():
