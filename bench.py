@@ -277,10 +277,16 @@ def main():
                 res = pipe.collect(pending.pop(0))[0]
             return torch.from_numpy(res.astype(np.int32))
     else:
+        step_times = []
+
         def run_steps(n):
             res = None
+            rec = os.environ.get("QPG_BENCH_STEP_TIMES", "") == "1"
             for _ in range(n):
+                t_ = time.perf_counter()
                 res = step()
+                if rec:
+                    step_times.append(time.perf_counter() - t_)
             return res
 
     # Clock / cache steady state regardless of --warmup (the driver's 20-step run was 13 % slower than the
@@ -308,7 +314,6 @@ def main():
                 prewarm.update(seconds=round(el, 3), settled=bool(ok3),
                                last_10step_means_ms=[round(x * 1e3, 4) for x in means[-3:]])
                 break
-    run_steps(a.warmup)
     knn.kernel_events = [] if os.environ.get("QPG_BENCH_NO_EVENTS", "") != "1" else None     # (diagnostics)
     knn.kernel_events_every = int(os.environ.get("QPG_BENCH_EVENTS_EVERY", "1"))
     # the HIP events that bracket the sweep exist before the timed region (torch creates an event at its first record)
@@ -317,16 +322,22 @@ def main():
     for e0, e1 in knn.kernel_event_pool:
         e0.record()
         e1.record()
-    if pipe is not None:
-        for ln in pipe.lanes:
-            ln["knn"].kernel_events = knn.kernel_events
-            ln["knn"].kernel_event_pool = knn.kernel_event_pool
     # Python's cyclic collector off during the timed region: a full (generation-2) collection of this process takes
     # ~40 ms, and whether one falls into the 110 ms of 200 steps depends on the allocation count so far - measured as
     # 0.73 instead of 0.54 ms per step in most runs with --steps 200 and in none with --steps 400 / 1000
     import gc
     gc.collect()
     gc.disable()
+    # the W warm-up steps come LAST, right in front of the fence: a 40 ms garbage collection (or anything else that
+    # idles the GPU) between them and the timed region costs the first timed step 0.15 ms of clock ramp - 7 us per step
+    # of a 20-step run
+    ev_keep, knn.kernel_events = knn.kernel_events, None
+    run_steps(a.warmup)
+    knn.kernel_events = ev_keep
+    if pipe is not None:
+        for ln in pipe.lanes:
+            ln["knn"].kernel_events = knn.kernel_events
+            ln["knn"].kernel_event_pool = knn.kernel_event_pool
     fence()
     prof = None
     if os.environ.get("QPG_BENCH_CPROFILE", "") == "1":       # diagnostics: where the host spends the timed region
@@ -338,6 +349,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
+    if os.environ.get("QPG_BENCH_STEP_TIMES", "") == "1" and pipe is None:
+        print("per-step ms (timed region):", ["%.3f" % (x * 1e3) for x in step_times[-a.steps:]], file=sys.stderr)
     if prof is not None:
         import pstats
         prof.disable()

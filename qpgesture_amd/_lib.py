@@ -192,20 +192,42 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+_cur_dev = None
+_dev_index = {}
+
+
 def call(name, device, *args):
     """Invoke a C-ABI entry point on torch's current stream of `device`; raise on error.
 
     HIP launches go to the CURRENT device (a stream handle of 0 means "the current device's default stream"),
     so when `device` is not the calling thread's current device the call is made under torch.cuda.device(device):
-    a GestureDB / VQVAE built on cuda:1 works whatever device the caller has selected."""
-    lib = load()
-    idx = torch.device(device).index
-    if idx is not None and idx != torch.cuda.current_device():
+    a GestureDB / VQVAE built on cuda:1 works whatever device the caller has selected.
+    (This wrapper sits in front of every launch of a clip - a dozen per 0.4 ms step - so it avoids what it can:
+    device indices are cached, tensors go in as their data_ptr() integers.)"""
+    lib = _lib if _lib is not None else load()
+    idx = _dev_index.get(device)
+    if idx is None:
+        idx = torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device()
+        _dev_index[device] = idx
+    if idx != torch.cuda.current_device():
         with torch.cuda.device(idx):
             return call(name, device, *args)
-    stream = torch.cuda.current_stream(device).cuda_stream
-    conv = [ptr(a) if isinstance(a, torch.Tensor) else (ctypes.byref(a) if isinstance(a, ctypes.Structure) else a)
-            for a in args]
-    rc = getattr(lib, name)(ctx(device), c_void_p(stream), *conv)
+    stream = torch.cuda.current_stream(idx).cuda_stream
+    conv = []
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            if not (a.is_cuda and a.is_contiguous()):
+                raise AssertionError("device-resident contiguous tensor required")
+            conv.append(a.data_ptr())
+        elif isinstance(a, ctypes.Structure):
+            conv.append(ctypes.byref(a))
+        else:
+            conv.append(a)
+    h = _ctx.get(idx)
+    if h is None:
+        h = ctx(device)
+    rc = getattr(lib, name)(h, stream, *conv)
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, last_error()))
