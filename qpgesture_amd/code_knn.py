@@ -515,39 +515,6 @@ class CodeKNN:
             return dist, idx, (rank if fused_rank else self.rank_rows(dist))
         return dist, idx
 
-    def sweep_audio_unfused(self, qbase, q_win, q_t):
-        """Same result through the stand-alone entry points (distance matrix, then qpg_percode_argmin_f64);
-        kept for the parity tests of those entry points."""
-        db, dev = self.db, self.db.device
-        Q = int(q_win.shape[0]) if isinstance(q_win, torch.Tensor) else len(q_win)
-        qbase = qbase.contiguous()
-        M, T, F = qbase.shape
-        q32 = torch.empty((Q, NUM_AUDIO_FEAT_FRAMES * F), dtype=torch.float32, device=dev)
-        qn2 = torch.empty((Q,), dtype=torch.float64, device=dev)
-        _lib.call("qpg_audio_pack_queries", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
-                  NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2)
-        D = torch.empty((Q, max(db.n_local * db.Ga, 1)), dtype=torch.float64, device=dev)
-        _lib.call("qpg_audio_cosine_f64", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
-                  NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, D.stride(0))
-        dist = torch.empty((Q, db.K), dtype=torch.float64, device=dev)
-        idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
-        _lib.call("qpg_percode_argmin_f64", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
-                  db.aud_cidx, db.Ga, db.K, float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx)
-        return dist, idx, D
-
-    def sweep_text_unfused(self, queries):
-        db, dev = self.db, self.db.device
-        Q = queries.shape[0]
-        qn = torch.empty_like(queries)
-        _lib.call("qpg_l2_normalize_rows_f32", dev, queries, Q, db.Dt, qn)
-        D = torch.empty((Q, max(db.Ct, 1)), dtype=torch.float32, device=dev)
-        _lib.call("qpg_text_cosine_f32", dev, db.ctxt, db.Ct, db.Dt, qn, Q, D, D.stride(0))
-        dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
-        idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
-        _lib.call("qpg_percode_argmin_f32", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
-                  db.txt_cidx, db.Gt, db.K, float(ABSENT_DIST), db.idx_base * db.Gt, dist, idx)
-        return dist, idx, D
-
     def _reduce_min(self, dist, idx):
         """Cross-shard min + index: all-reduce(MIN) on the distances, then
         all-reduce(MIN) on the indices of the ranks that hold that minimum.  Shards are contiguous

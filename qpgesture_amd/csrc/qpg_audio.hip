@@ -585,7 +585,15 @@ __global__ __launch_bounds__(256, QPG_MX2_OCC) void audio_cosine_mx2_kernel(
     for (int i = 0; i < PIECES / 4; ++i) {
       const float* gp = dsrc[i] + tap * F + e0;
       const unsigned la = ring_lds + (unsigned)slot * STAGE_BYTES + (w_u + 4 * i) * 1024;
+      // m0 is the LDS base of the DMA.  Naming it as a clobber makes hipcc warn that it does not preserve reserved
+      // registers across the statement - which matters only if the compiler itself keeps something in m0 around here.
+      // It does not: in this translation unit m0 occurs nowhere but in these statements (on gfx9+ ordinary LDS, global
+      // and MFMA instructions do not read m0), and tests/test_host_cpu.py::test_audio_object_uses_m0_only_in_the_dma_asm
+      // holds the built object to that.  (The builtin form hides nothing from the wait-count model: see above.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(la) : "memory", "m0");
+#pragma clang diagnostic pop
     }
   };
   auto load_a = [&](f32x4 (&a)[4], int s) {

@@ -312,24 +312,6 @@ class VQVAE:
         outs = [self.encode_fused(xc) for xc in torch.chunk(x, bs_chunks, dim=0)]
         return [outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)]
 
-    def decode_layers(self, ids):
-        """Layer-by-layer decode through the per-layer entry points (qpg_vq_gather_f32 + qpg_conv1d_f32);
-        same result as decode(), kept to test those entry points."""
-        ids = torch.as_tensor(ids).to(self.device, torch.int64).contiguous()
-        B, L = ids.shape
-        status = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        x = torch.empty((B, L, self.emb), dtype=torch.float32, device=self.device)
-        _lib.call("qpg_vq_gather_f32", self.device, self.k, ids, B * L, self.emb, self.bins, x, status)
-        T = L
-        x = self._conv(self.dec_in, x, B, T, T, in_offset=-1)
-        for res, even, odd in self.dec_up:
-            x = self._resnet(res, x, B, T, self.reverse)
-            y = torch.empty((B, 2 * T, even.cout), dtype=torch.float32, device=self.device)
-            self._conv(even, x, B, T, T, in_offset=-1, out=y, out_stride=2, out_offset=0, T_y=2 * T)
-            self._conv(odd, x, B, T, T, in_offset=0, out=y, out_stride=2, out_offset=1, T_y=2 * T)
-            x, T = y, 2 * T
-        return self._conv(self.dec_out, x, B, T, T, in_offset=-1)
-
     def decode(self, zs, start_level=0, end_level=None, bs_chunks=1):
         """VQVAE.decode (vqvae.py:152-159): zs = [LongTensor (B,L)] -> FloatTensor (B, 8L, C).
         The whole sequence is decoded in ONE convolutional pass like the reference

@@ -79,7 +79,8 @@ def test_unfused_entry_points_agree_with_fused():
     q_win, q_t = np.repeat(np.arange(M), steps), np.tile(np.arange(steps) * 24, M)
     knn.audio_precision = "f64"
     d0, i0, r0 = knn.sweep_audio(te_i, q_win, q_t, want_rank=True)
-    d1, i1, D = knn.sweep_audio_unfused(te_i, q_win, q_t)
+    from tests.helpers import sweep_audio_unfused, sweep_text_unfused
+    d1, i1, D = sweep_audio_unfused(knn, te_i, q_win, q_t)
     assert torch.equal(d0, d1) and torch.equal(i0, i1)
     assert torch.equal(r0, knn.rank_rows(d1))
     knn.audio_precision = "mixed"           # the default: same winners and ranks, values inside the sweep's bound
@@ -88,7 +89,7 @@ def test_unfused_entry_points_agree_with_fused():
     rows = [int(i / 180 * 30) for i in q_t]
     qt = te_c[torch.as_tensor(q_win, device=te_c.device), torch.as_tensor(rows, device=te_c.device)].contiguous()
     t0, j0, s0 = knn.sweep_text(qt, want_rank=True)
-    t1, j1, Dt = knn.sweep_text_unfused(qt)
+    t1, j1, Dt = sweep_text_unfused(knn, qt)
     assert torch.equal(t0, t1) and torch.equal(j0, j1) and torch.equal(s0, knn.rank_rows(t1))
     # ranks == stable argsort-argsort
     want = np.argsort(np.argsort(d1.cpu().numpy(), axis=1, kind="stable"), axis=1, kind="stable")

@@ -350,3 +350,36 @@ def test_bench_launches_its_own_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     assert json.loads(lines[0]) == {"launch_check": True, "n_gpus": 3, "rank_sum": 6}
+
+
+def test_audio_object_uses_m0_only_in_the_dma_asm():
+    """qpg_audio.hip issues its LDS-DMA from inline asm that sets m0 (so that hipcc's wait-count model does not see the
+    DMA) and names m0 as a clobber; that is safe as long as nothing the compiler generated reads or writes m0 in that
+    translation unit.  Compile it to gfx950 assembly with the product's flags and check: every m0 operand belongs to an
+    `s_mov_b32 m0` inside an ASMSTART / ASMEND block."""
+    import os
+    import subprocess
+    import tempfile
+    from qpgesture_amd import build as B
+    src = os.path.join(B.CSRC, "qpg_audio.hip")
+    if not os.path.exists(B.HIPCC):
+        pytest.skip("hipcc not available")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "a.s")
+        flags = [f for f in B.FLAGS if f not in ("-shared", "-Wall")]
+        subprocess.check_call([B.HIPCC] + flags + ["-S", "--cuda-device-only", src, "-o", out], cwd=td,
+                              stderr=subprocess.DEVNULL)
+        lines = open(out).read().splitlines()
+    inside, uses_out, movs = False, [], 0
+    for l in lines:
+        if "#ASMSTART" in l:
+            inside = True
+        elif "#ASMEND" in l:
+            inside = False
+        code = l.split(";")[0]
+        if " m0" in code or ",m0" in code:
+            if inside and "s_mov_b32 m0" in code:
+                movs += 1
+            else:
+                uses_out.append(l)
+    assert movs >= 30 and not uses_out, uses_out[:5]
