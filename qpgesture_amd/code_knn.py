@@ -425,6 +425,7 @@ class CodeKNN:
             ws = getattr(self, "_mix_ws", None)
             if ws is None or ws.numel() < need:
                 ws = self._mix_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+            self._last_mix_Q = Q
             _lib.call("qpg_percode_select_mixed_f64", dev, D, 1, D.stride(0), Q, db.aud_cand_code, C, db.K,
                       float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
                       db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2,
@@ -534,6 +535,18 @@ class CodeKNN:
         in the reference's arithmetic (tier 2), raw flag word (1 = list overflow, 2 = norms below the bound's range)."""
         v = self._guard_stats.cpu().numpy()
         return {"tier1_pairs": int(v[2]), "tier2_pairs": int(v[0]), "flags": int(v[1])}
+
+    def tier1_list_lengths(self):
+        """Entries of every query's tier-1 re-evaluation list in the last mixed-precision select (capacity 2048 each):
+        read back from the select's workspace.  Diagnostics (bench.py --data speechlike, tests): what the caps see."""
+        ws = getattr(self, "_mix_ws", None)
+        Q = getattr(self, "_last_mix_Q", 0)
+        if ws is None or not Q:
+            return np.zeros((0,), np.int64)
+        K = self.db.K
+        stride = int(_lib.load().qpg_percode_select_mixed_ws_bytes(Q, K)) // Q
+        w = ws[:Q * stride].view(Q, stride)[:, 24 * K:24 * K + 4].contiguous().view(torch.int32)
+        return w.cpu().numpy().reshape(-1).astype(np.int64)
 
     def clear_flags(self):
         self._guard_stats[1:2].zero_()

@@ -130,30 +130,38 @@ def apply_variant(tr, te, code, variant):
         code[8:30] = 100 + rng.integers(0, 6, size=(22, code.shape[1]))  # six crowded codes; 30..37 keep their own
         te["wavlm"][0] = stretch(1)[0]
     elif variant == "speechlike":
-        for d, sd in ((tr, 779), (te, 780)):
-            rng = _rng(sd)
-            n, T, F = d["wavlm"].shape
-            mix = (rng.standard_normal((64, F)) / 8.0).astype(np.float32)
-            z = np.empty((n, T, 64), np.float32)
-            z[:, 0] = rng.standard_normal((n, 64))
-            innov = (rng.standard_normal((n, T, 64)) * np.sqrt(1 - 0.95 ** 2)).astype(np.float32)
-            for t in range(1, T):
-                z[:, t] = 0.95 * z[:, t - 1] + innov[:, t]
-            x = z @ mix + 0.05 * d["wavlm"]                              # low-rank, slowly varying + a little of the rest
-            quiet = (_rng(781).standard_normal((F,)) * 1e-3).astype(np.float32)
-            sil = rng.random((n, T)) < 0.10
-            x[sil] = quiet * (1.0 + 1e-3 * rng.standard_normal((int(sil.sum()), F)).astype(np.float32))
-            d["wavlm"][...] = x.astype(np.float32)
-            ctx = d["context"]
-            silence = _rng(782).standard_normal((384,)).astype(np.float32)
-            for j in range(n):
-                r = 0
-                while r < ctx.shape[1]:
-                    span = int(rng.integers(1, 5))
-                    ctx[j, r:r + span] = silence if rng.random() < 0.2 else ctx[j, r]
-                    r += span
+        speechlike_transform(tr, 779)
+        speechlike_transform(te, 780)
     else:
         raise ValueError(variant)
+
+
+def speechlike_transform(d, seed):
+    """In place: give one split of a synthetic database (make_db) feature statistics closer to real WavLM / sentence-
+    embedding tracks (see apply_variant 'speechlike').  `seed` drives the temporal processes; the mixing matrix, the
+    quiet vector and the silence embedding are common to all splits and chunks (one speaker, one room)."""
+    rng = _rng(seed)
+    n, T, F = d["wavlm"].shape
+    mix = (_rng(783).standard_normal((64, F)) / 8.0).astype(np.float32) if seed not in (779, 780) else \
+        (rng.standard_normal((64, F)) / 8.0).astype(np.float32)
+    z = np.empty((n, T, 64), np.float32)
+    z[:, 0] = rng.standard_normal((n, 64))
+    innov = (rng.standard_normal((n, T, 64)) * np.sqrt(1 - 0.95 ** 2)).astype(np.float32)
+    for t in range(1, T):
+        z[:, t] = 0.95 * z[:, t - 1] + innov[:, t]
+    x = z @ mix + 0.05 * d["wavlm"]                              # low-rank, slowly varying + a little of the rest
+    quiet = (_rng(781).standard_normal((F,)) * 1e-3).astype(np.float32)
+    sil = rng.random((n, T)) < 0.10
+    x[sil] = quiet * (1.0 + 1e-3 * rng.standard_normal((int(sil.sum()), F)).astype(np.float32))
+    d["wavlm"][...] = x.astype(np.float32)
+    ctx = d["context"]
+    silence = _rng(782).standard_normal((384,)).astype(np.float32)
+    for j in range(n):
+        r = 0
+        while r < ctx.shape[1]:
+            span = int(rng.integers(1, 5))
+            ctx[j, r:r + span] = silence if rng.random() < 0.2 else ctx[j, r]
+            r += span
 
 
 def write_npz_set(outdir, n_train, n_test, seed_train=0, seed_test=1, seed_code=2, seed_sig=3,
