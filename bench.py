@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--encode-batch", type=int, default=0, help="pose windows VQ-VAE-encoded inside the timed step")
     ap.add_argument("--feature-dtype", choices=["f32", "f16"], default="f32")
     ap.add_argument("--workload", choices=["match", "cfg3"], default="match")
+    ap.add_argument("--cfg3-method", choices=["mfma", "valu"], default="mfma",
+                    help="cfg3: bounded matrix-core prefilter + exact refine (default) or round 2's exact VALU sweep")
     ap.add_argument("--data", choices=["gaussian", "speechlike"], default="gaussian",
                     help="feature statistics of the synthetic DB and clips: i.i.d. N(0,1) (SURVEY.md §8d, the default line) "
                          "or speech-like (AR(1) rho 0.95 on rank-64 mixtures, 10 %% near-silent frames, repeating context "

@@ -196,6 +196,30 @@ int qpg_text_percode_f16(qpg_ctx*, void* stream, const void* xh, const float* nr
                          void* ws, int64_t ws_bytes, float* out_dist, int32_t* out_idx, int16_t* out_rank,
                          int32_t* out_nn);
 
+/* BOUNDED PREFILTER + EXACT REFINE for the exact-f32 cosine family (round 3; BASELINE.json configs[2]): bit-identical
+ * tables to qpg_text_percode_f32 at a fraction of its VALU work.  Build side (host, once): sklearn-normalise the rows
+ * (qpg_l2_normalize_rows_f32), drop masked rows, sort by code (stable) into segments padded to 16 rows, R %% 32 == 0.
+ *   qpg_hl_pack_rows / qpg_hl_pack_cols   split-f16 fragment images of the sorted unit rows xs [dev] f32 [R][D] and of the
+ *       normalised queries qn [dev] f32 [Q][D] (chunks of 96); sizes: qpg_hl_rows_bytes / qpg_hl_cols_bytes.  D %% 128 == 0.
+ *   qpg_hl_gemm_distance   Dm [dev] f32 [Q][ldD >= R]: Dm[q][r] = 1 - <xs[r], qn[q]> on the f16 matrix cores (the kernel of
+ *       qpg_audio_cosine_hl with a plain epilogue; |Dm - true| <= QPG_AUDIO_HL_ERR for unit-norm operands).
+ *   qpg_percode_select_sorted_f32   per query: per-code minimum of Dm, every row within `band` of it evaluated in
+ *       sklearn's exact f32 order (0.5 * einsum_sq(qn - xs)), minimum exact distance and lowest ORIGINAL index per code.
+ *       row_code [dev] i16 [R]: code of sorted row r, | 0x4000 for padding rows; row_index [dev] i32 [R]: original index.
+ *       `band` >= 2 x (prefilter error + sklearn's own rounding against the real value): derivation in
+ *       csrc/qpg_sorted.hip (8.6e-5 at D = 512).  stats[1] |= 1 if a query's band list (8192) overflowed: run
+ *       qpg_text_percode_f32 instead.  out_nn optional: the query's global nearest neighbour (original index). */
+int64_t qpg_hl_rows_bytes(int64_t R, int D);
+int64_t qpg_hl_cols_bytes(int Q, int D);
+int qpg_hl_pack_rows(qpg_ctx*, void* stream, const float* xs, int64_t R, int D, void* image, int64_t image_bytes);
+int qpg_hl_pack_cols(qpg_ctx*, void* stream, const float* qn, int Q, int D, void* image, int64_t image_bytes);
+int qpg_hl_gemm_distance(qpg_ctx*, void* stream, const void* rows_image, int64_t R, int D, const void* cols_image, int Q,
+                         float* Dm, int64_t ldD);
+int qpg_percode_select_sorted_f32(qpg_ctx*, void* stream, const float* Dm, int64_t ldD, int Q, int64_t R,
+                                  const int16_t* row_code, const int32_t* row_index, int K, float band, const float* qn,
+                                  const float* xs, int D, float absent, float* out_dist, int32_t* out_idx, int32_t* out_nn,
+                                  int32_t* stats);
+
 /* vq-wav2vec audio sweep (the mode the paper describes; flags use_wavvq/use_feature of GestureKNN.py:557-560):
  * D[q][c] = Levenshtein distance (unit costs, python-Levenshtein distance()) between the 11-symbol strings of
  * query q and candidate c, symbol = g1*320+g2 (wavvq_distances(mode='combine'), GestureKNN.py:57-67).  Strings

@@ -38,6 +38,10 @@ _SIGS = {
     "qpg_audio_pack_queries_hl": [P, I, I, I, P, P, I, I, I, P, P, P, L],
     "qpg_audio_cosine_hl": [P, I, I, I, P, P, P, I, P, I, L, P],
     "qpg_debug_mfma_f16_tile": [P, P, P, I, P],
+    "qpg_hl_pack_rows": [P, L, I, P, L],
+    "qpg_hl_pack_cols": [P, I, I, P, L],
+    "qpg_hl_gemm_distance": [P, L, I, P, I, P, L],
+    "qpg_percode_select_sorted_f32": [P, L, I, L, P, P, I, c_float, P, P, I, c_float, P, P, P, P],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
     "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
     "qpg_text_percode_f32": [P, L, I, P, I, P, I, I, ctypes.c_int32, c_float, P, L, P, P, P, P],
@@ -151,6 +155,10 @@ def load():
     lib.qpg_audio_hl_db_bytes.restype = c_int64
     lib.qpg_audio_hl_query_bytes.argtypes = [c_int, c_int]
     lib.qpg_audio_hl_query_bytes.restype = c_int64
+    lib.qpg_hl_rows_bytes.argtypes = [c_int64, c_int]
+    lib.qpg_hl_rows_bytes.restype = c_int64
+    lib.qpg_hl_cols_bytes.argtypes = [c_int, c_int]
+    lib.qpg_hl_cols_bytes.restype = c_int64
     lib.qpg_percode_select_exact_ws_bytes.argtypes = [c_int, c_int64, c_int]
     lib.qpg_percode_select_exact_ws_bytes.restype = c_int64
     lib.qpg_merge_mixed_ws_bytes.restype = c_int64

@@ -6,6 +6,11 @@ candidate (512 of each) and the global nearest neighbour.  The arithmetic is the
 (GestureKNN.py:716 -> sklearn paired_distances(metric='cosine') on float32: normalise, einsum-order sum of squares),
 bit for bit, which rules out FMA and the matrix cores; the kernel is VALU-bound, not HBM-bound, and says so.
 
+Round 3: the tables no longer need the exact arithmetic for EVERY pair.  `CosineIndex(method="mfma")` (the default for f32
+rows) sorts the valid rows by code, runs a bounded prefilter on the f16 matrix cores (qpg_hl_gemm_distance) and evaluates
+in sklearn's exact order only the rows inside each code's band (qpg_percode_select_sorted_f32, csrc/qpg_sorted.hip):
+bit-identical tables; a query whose band list overflows (massive exact ties) falls back to the exact sweep.
+
 `CosineIndex` is the host-side mirror: build once (normalise + tile the candidates), `query()` per batch."""
 import ctypes
 import time
@@ -17,6 +22,20 @@ from . import _lib
 
 N_DB, DIM, N_Q, K_CODES = 100_000, 512, 1000, 512
 ABSENT = 1000.0
+U32 = 2.0 ** -24
+HL_GEMM_ERR = 1.3e-6          # QPG_AUDIO_HL_ERR: the split-f16 GEMM on unit-norm operands
+
+
+def prefilter_band(d):
+    """Band of the bounded prefilter for the exact-f32 cosine (derivation: csrc/qpg_sorted.hip): 2.1 x (E_pre + E_sk).
+    eps1: relative error of an f32 sklearn-normalised element (norm^2 by 4 lane chains of d/4 squares, sqrt, divide);
+    E_pre: the GEMM's bound + the two operands being off the true unit vectors by eps1 each;
+    E_sk: sklearn's own rounding against the real-number distance (normalisation errors through the difference,
+    Cauchy-Schwarz with |delta| <= 2, then the chains of d/4 squares)."""
+    eps1 = ((d / 4 + 2) / 2 + 2) * U32
+    e_pre = HL_GEMM_ERR + 2 * eps1
+    e_sk = 0.5 * (8 * eps1 + 4 * (d / 4 + 3) * U32)
+    return 2.1 * (e_pre + e_sk)
 
 
 def make_inputs(n=N_DB, d=DIM, nq=N_Q, k=K_CODES):
@@ -31,7 +50,8 @@ class CosineIndex:
     """Candidates resident in HBM, sklearn-normalised and tiled for lane-per-candidate access
     (qpg_text_pack_candidates_f32); masked rows carry code -1 and can never win."""
 
-    def __init__(self, X, code, valid=None, n_codes=K_CODES, device="cuda:0", tiles_per_chunk=1, feature_dtype="f32"):
+    def __init__(self, X, code, valid=None, n_codes=K_CODES, device="cuda:0", tiles_per_chunk=1, feature_dtype="f32",
+                 method="mfma"):
         """feature_dtype "f16": the rows are stored ROUNDED to f16 (half the bytes) with their f32 norms; the tables are
         then the reference's on the f16-rounded database (qpg_text_percode_f16)."""
         dev = torch.device(device)
@@ -57,6 +77,44 @@ class CosineIndex:
             cm = np.where(np.asarray(valid), cm, -1)
         self.cand_code = torch.from_numpy(cm.astype(np.int16)).to(dev)
         self._ws = None
+        self.fallbacks = 0
+        self.method = method if (feature_dtype == "f32" and d % 128 == 0 and n_codes < 0x4000) else "valu"
+        if self.method == "mfma":
+            self._build_sorted(xd.view(n, d), cm)
+
+    def _build_sorted(self, xd, cm):
+        """Rows for the bounded prefilter: sklearn-normalised (the exact kernel, so the refine reads what the exact sweep
+        would), masked rows dropped, sorted by code (stable: original order inside a code = first-wins), every code's
+        segment padded to 16 rows, the total to 32; + the split-f16 fragment image of those rows."""
+        dev, d, K = self.device, self.d, self.K
+        xn = torch.empty_like(xd)
+        _lib.call("qpg_l2_normalize_rows_f32", dev, xd.contiguous(), self.n, d, xn)
+        cmt = torch.from_numpy(cm).to(dev)
+        keep = torch.nonzero((cmt >= 0) & (cmt < K)).reshape(-1)
+        order = keep[torch.sort(cmt[keep], stable=True).indices]              # original indices, by (code, index)
+        codes = cmt[order]
+        cnt = torch.bincount(codes, minlength=K)
+        pad_cnt = (cnt + 15) // 16 * 16
+        start = torch.cumsum(pad_cnt, 0) - pad_cnt
+        R = int(pad_cnt.sum().item())
+        R = (R + 31) // 32 * 32
+        within = torch.arange(order.numel(), device=dev) - (torch.cumsum(cnt, 0) - cnt)[codes]
+        pos = start[codes] + within
+        row_index = torch.full((R,), -1, dtype=torch.int32, device=dev)
+        row_index[pos] = order.to(torch.int32)
+        # a padding row carries its segment's code with bit 14 set (the tail beyond the last segment: code K - 1's)
+        seg_code = torch.repeat_interleave(torch.arange(K, device=dev), pad_cnt)
+        seg_code = torch.cat((seg_code, torch.full((R - seg_code.numel(),), K - 1, device=dev, dtype=seg_code.dtype)))
+        row_code = torch.where(row_index >= 0, seg_code, seg_code | 0x4000).to(torch.int16).contiguous()
+        xs = torch.zeros((R, d), dtype=torch.float32, device=dev)
+        xs[pos] = xn[order]
+        lib = _lib.load()
+        img = torch.empty((int(lib.qpg_hl_rows_bytes(R, d)),), dtype=torch.uint8, device=dev)
+        _lib.call("qpg_hl_pack_rows", dev, xs, R, d, img, img.numel())
+        self.R, self.xs, self.row_index, self.row_code, self.rows_image = R, xs, row_index, row_code, img
+        self.band = float(prefilter_band(d))
+        self._stats = torch.zeros((4,), dtype=torch.int32, device=dev)
+        self._Dm = None
 
     def query(self, q, want_nn=True):
         """q: f32 [Q][d] device tensor.  Returns (dist f32 [Q][K], idx i32 [Q][K], nn i32 [Q])."""
@@ -64,6 +122,27 @@ class CosineIndex:
         Q = q.shape[0]
         qn = torch.empty_like(q)
         _lib.call("qpg_l2_normalize_rows_f32", dev, q, Q, self.d, qn)
+        if self.method == "mfma" and not getattr(self, "_force_valu", False):
+            lib = _lib.load()
+            nb = int(lib.qpg_hl_cols_bytes(Q, self.d))
+            if getattr(self, "_cols", None) is None or self._cols.numel() < nb:
+                self._cols = torch.empty((nb,), dtype=torch.uint8, device=dev)
+            if self._Dm is None or self._Dm.shape[0] < Q:
+                self._Dm = torch.empty((Q, self.R), dtype=torch.float32, device=dev)
+            dist = torch.empty((Q, self.K), dtype=torch.float32, device=dev)
+            idx = torch.empty((Q, self.K), dtype=torch.int32, device=dev)
+            nn = torch.empty((Q,), dtype=torch.int32, device=dev) if want_nn else None
+            _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, self._cols, self._cols.numel())
+            _lib.call("qpg_hl_gemm_distance", dev, self.rows_image, self.R, self.d, self._cols, Q, self._Dm, self.R)
+            _lib.call("qpg_percode_select_sorted_f32", dev, self._Dm, self.R, Q, self.R, self.row_code, self.row_index,
+                      self.K, self.band, qn, self.xs, self.d, ABSENT, dist, idx, nn, self._stats)
+            if not getattr(self, "check_flags", True):
+                return dist, idx, nn                   # (timing loops: the flag is read once, after the loop)
+            if int(self._stats[1].item()) == 0:
+                return dist, idx, nn
+            # a band list overflowed (massive exact ties): the exact sweep decides this batch
+            self._stats.zero_()
+            self.fallbacks += 1
         need = int(_lib.load().qpg_text_percode_ws_bytes(self.n, Q, self.K, self.tiles_per_chunk))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
@@ -89,9 +168,11 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
     lo, hi = min(rank * per, N_DB), min((rank + 1) * per, N_DB)
     import os
     f16 = getattr(a, "feature_dtype", "f32") == "f16"
+    method = getattr(a, "cfg3_method", "mfma")
     index = CosineIndex(X[lo:hi], code[lo:hi], valid[lo:hi], device=dev,
                         tiles_per_chunk=1 if f16 else int(os.environ.get("QPG_CFG3_TPC", "1")),
-                        feature_dtype="f16" if f16 else "f32")
+                        feature_dtype="f16" if f16 else "f32", method=method)
+    index.check_flags = False                      # (the timed loop reads the overflow flag once, at the end)
     qd = torch.from_numpy(q).to(dev)
     steps = min(a.steps, 50)
     for _ in range(max(a.warmup, 3)):
@@ -117,8 +198,11 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if index.method == "mfma":
+        assert int(index._stats[1].item()) == 0, "a band list overflowed during the timed loop"
     ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
     k_ms = ms[len(ms) // 2]
+    mfma = index.method == "mfma"
     n_loc = hi - lo
     alg_bytes = n_loc * DIM * (2 if f16 else 4) + n_loc * (8 if f16 else 4) + N_Q * DIM * 4 + N_Q * K_CODES * 8
     lane_ops = 3.0 * N_Q * n_loc * DIM                                                   # sub, mul, add per element pair
@@ -128,17 +212,27 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
             "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg-3: DB 100000 x 512 %s, 512 codes, Bernoulli(0.9) validity mask, 1000 queries; "
-                                   "sklearn-exact f32 cosine, per-code min + argmin + global nearest neighbour"
-                                   % ("stored f16 (rounded), widened + normalised in registers" if f16 else "f32"),
+                                   "sklearn-exact f32 cosine, per-code min + argmin + global nearest neighbour%s"
+                                   % ("stored f16 (rounded), widened + normalised in registers" if f16 else "f32",
+                                      " (bounded split-f16 matrix-core prefilter + exact-order refine of the band: "
+                                      "bit-identical tables)" if mfma else ""),
+                       "method": index.method,
                        "feature_dtype": "f16" if f16 else "f32",
                        "n_db": N_DB, "dim": DIM, "queries": N_Q, "parallelism": "db rows / %d" % world},
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": hbm_peak_gbs,
                          "unit": "GB/s", "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / hbm_peak_gbs, 4),
-                         "traffic": CFG3_TRAFFIC_BYTES if world == 1 and not f16 else None,
-                         "kernel": "text_cosine_gmin_f32_kernel (+ fill, merge)", "kernel_ms": round(k_ms, 4),
+                         "traffic": CFG3_TRAFFIC_BYTES if world == 1 and not f16 and not mfma else None,
+                         "kernel": ("audio_cosine_hl_kernel<1> (prefilter GEMM) + percode_select_sorted_kernel (+ query "
+                                    "normalise / pack)" if mfma else "text_cosine_gmin_f32_kernel (+ fill, merge)"),
+                         "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes": int(alg_bytes),
-                         "note": "the distance is sklearn's separately rounded f32 arithmetic (bit-exact indices are the "
-                                 "bar), so neither FMA nor the matrix cores are admissible: the kernel is VALU-bound",
+                         "note": ("the tables are sklearn's separately rounded f32 arithmetic (bit-exact indices are the bar); "
+                                  "the matrix cores run a PREFILTER with an a-priori bound, only the band members get the "
+                                  "exact order: the step is now bound by the prefilter's passes over the row image "
+                                  "(11 chunks of 96 queries) and the Q x R prefilter matrix it hands to the select"
+                                  if mfma else
+                                  "the distance is sklearn's separately rounded f32 arithmetic (bit-exact indices are the "
+                                  "bar), so neither FMA nor the matrix cores are admissible: the kernel is VALU-bound"),
                          "valu": {"lane_ops": lane_ops, "peak_lane_ops_per_s": valu_peak,
                                   "floor_ms": round(lane_ops / valu_peak * 1e3, 3),
                                   "frac": round(lane_ops / valu_peak / (k_ms * 1e-3), 4)}}}

@@ -285,7 +285,7 @@ struct HlArgs {
   const float* zeros;      // the context's zero page (>= 16 bytes): what padding rows read
   int64_t ldD;
   int32_t* stats;
-  int N, G, Q, KB, d_f32;
+  int N, G, Q, KB, d_f32;   // N: database windows (MODE 0) / 32-row groups (MODE 1)
 };
 
 #define HL_RING (2 * HL_KS)  // k-blocks of database fragments in flight per wave (2 KB each): two stages
@@ -319,6 +319,10 @@ struct HlArgs {
 #endif
 #define HL_THREADS (128 * HL_WPB)
 #define HL_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+// MODE 0: the audio sweep (27 live super-rows per window, shifted-add epilogue).  MODE 1: plain distance GEMM over
+// generic rows (qpg_hl_gemm_distance: groups of 32 rows, all live; D[q][row] = 1 - <row, q> for unit-norm operands;
+// the chunk's 96 columns are 96 queries).
+template <int MODE>
 __global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 * HL_KS * HL_CT * 2 * HL_PIECE bytes
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a
   const bool win_ok = j < a.N;
   // database fragments: plane p of k-block kb: one 16-byte load per lane, 1 KB per wave, contiguous.  Padding rows
   // (27..31) and windows past N read the context's zero page instead (stride 0): no branch in the loop.
-  const bool row_ok = win_ok && (16 * t + (lane & 15)) < HL_ROWS;
+  const bool row_ok = win_ok && (MODE == 1 || (16 * t + (lane & 15)) < HL_ROWS);
   const h8* dbp = row_ok ? reinterpret_cast<const h8*>(a.db) + (((int64_t)j * 2 + t) * KB * 2) * 64 + lane
                          : reinterpret_cast<const h8*>(a.zeros);
   const int kb_step = row_ok ? 128 : 0, pl_step = row_ok ? 64 : 0;      // h8 units per k-block / plane
@@ -449,8 +453,25 @@ __global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // surplus prefetches must not outlive their registers
   __builtin_amdgcn_s_barrier();
 
-  // ---- epilogue: S = hh + 2^-11 cross; dot(q, cand g) = S[g][lo col] + S[g+1][hi col]; cosine distance; store
   const int cg = lane & 15, rg = lane >> 4;
+  if (MODE == 1) {
+    // ---- generic epilogue: D[q][row] = 1 - S 2^-(e_c + e_q), four consecutive rows per lane: one 16-byte store
+    if (!win_ok) return;
+    const int e_c1 = a.meta[0];
+#pragma unroll
+    for (int ct = 0; ct < HL_CT; ++ct) {
+      const int q = chunk * (16 * HL_CT) + ct * 16 + cg;
+      if (q >= a.Q) continue;
+      const int e_q1 = a.qexp[q];
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        o[r] = (float)(1.0 - ldexp(acc[ct][r] + (double)xacc[ct][r] * (1.0 / 2048.0), -(e_c1 + e_q1)));
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (int64_t)q * a.ldD + (int64_t)j * 32 + 16 * t + 4 * rg) = o;
+    }
+    return;
+  }
+  // ---- epilogue: S = hh + 2^-11 cross; dot(q, cand g) = S[g][lo col] + S[g+1][hi col]; cosine distance; store
   double* exch = reinterpret_cast<double*>(lds);              // [windows][3 ct][16 cols]: row 16 of the hi columns
   double hi[3][4];
 #pragma unroll
@@ -594,16 +615,163 @@ extern "C" int qpg_audio_cosine_hl(qpg_ctx* ctx, void* stream, const void* db_im
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
   if (lds_bytes > 64 * 1024) {
     static bool raised = false;
-    if (!raised && hipFuncSetAttribute(reinterpret_cast<const void*>(audio_cosine_hl_kernel),
+    if (!raised && hipFuncSetAttribute(reinterpret_cast<const void*>(audio_cosine_hl_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
       qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
       return QPG_EHIP;
     }
     raised = true;
   }
-  hipLaunchKernelGGL(audio_cosine_hl_kernel, dim3((N + HL_WPB - 1) / HL_WPB, chunks), dim3(HL_THREADS), lds_bytes,
+  hipLaunchKernelGGL(audio_cosine_hl_kernel<0>, dim3((N + HL_WPB - 1) / HL_WPB, chunks), dim3(HL_THREADS), lds_bytes,
                      qpg_stream(stream), a);
   QPG_LAUNCH_CHECK("audio_cosine_hl_kernel");
+  return QPG_OK;
+}
+
+// ---- generic split-f16 distance GEMM (BASELINE.json configs[2]: the prefilter of the exact-f32 cosine family) ----------
+// rows: x [R][D] f32 (R % 32 == 0, unit-norm rows) -> image [R/32][2 row tiles][KB][plane][64 lanes][8 f16] + exponent;
+// columns: q [Q][D] f32 -> image [chunk of 96][KB][6 column tiles][plane][64][8] + one exponent per query.
+__global__ __launch_bounds__(256) void hl_pack_rows_kernel(const float* __restrict__ x, int64_t R, int D,
+                                                           const int32_t* __restrict__ meta, _Float16* __restrict__ image) {
+  const int KB = D / 32, K8 = D / 8;
+  const int64_t n = R * K8;
+  const float sc = ldexpf(1.0f, meta[0]);
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (int64_t)gridDim.x * blockDim.x) {
+    const int k8 = (int)(id % K8);
+    const int64_t row = id / K8;
+    const int i = (int)(row & 31);
+    const int64_t j = row >> 5;
+    const int k = k8 * 8;
+    const f32x4* p = reinterpret_cast<const f32x4*>(x + row * D + k);
+    const f32x4 v0 = p[0], v1 = p[1];
+    h8 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 a0, b0, a1, b1;
+      split_hl(v0[e] * sc, a0, b0);
+      split_hl(v1[e] * sc, a1, b1);
+      hh[e] = a0; ll[e] = b0; hh[4 + e] = a1; ll[4 + e] = b1;
+    }
+    const int kb = k / 32, lane = (i & 15) + 16 * ((k & 31) >> 3);
+    const int64_t piece = ((j * 2 + (i >> 4)) * KB + kb) * 2;
+    reinterpret_cast<h8*>(image)[(piece + 0) * 64 + lane] = hh;
+    reinterpret_cast<h8*>(image)[(piece + 1) * 64 + lane] = ll;
+  }
+}
+
+#define HL_GQC (16 * HL_CT)   // queries per chunk of the generic GEMM (96)
+__global__ __launch_bounds__(256) void hl_pack_cols_kernel(const float* __restrict__ q, int Q, int D,
+                                                           _Float16* __restrict__ image, int32_t* __restrict__ qexp) {
+  const int qi = blockIdx.x, tid = threadIdx.x;
+  const int KB = D / 32, K8 = D / 8;
+  __shared__ float red[4];
+  __shared__ int e_s;
+  const bool live = qi < Q;
+  const float* row = q + (int64_t)qi * D;
+  float m = 0.f;
+  if (live)
+    for (int i = tid; i < D / 4; i += blockDim.x) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(row)[i];
+      m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, red[i]);
+    e_s = hl_exponent(m);
+    if (live) qexp[qi] = e_s;
+  }
+  __syncthreads();
+  const float sc = ldexpf(1.0f, e_s);
+  const int chunk = qi / HL_GQC, qq = qi % HL_GQC;
+  for (int k8 = tid; k8 < K8; k8 += blockDim.x) {
+    const int k = k8 * 8;
+    f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (live) {
+      v0 = reinterpret_cast<const f32x4*>(row + k)[0];
+      v1 = reinterpret_cast<const f32x4*>(row + k)[1];
+    }
+    h8 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 a0, b0, a1, b1;
+      split_hl(v0[e] * sc, a0, b0);
+      split_hl(v1[e] * sc, a1, b1);
+      hh[e] = a0; ll[e] = b0; hh[4 + e] = a1; ll[4 + e] = b1;
+    }
+    const int kb = k / 32, ct = qq / 16, lane = (qq & 15) + 16 * ((k & 31) >> 3);
+    const int64_t piece = ((((int64_t)chunk * KB + kb) * HL_CT + ct) * 2);
+    reinterpret_cast<h8*>(image)[(piece + 0) * 64 + lane] = hh;
+    reinterpret_cast<h8*>(image)[(piece + 1) * 64 + lane] = ll;
+  }
+}
+
+extern "C" int64_t qpg_hl_rows_bytes(int64_t R, int D) {
+  return (R <= 0 || D <= 0) ? 0 : R * D * 4 + 64;
+}
+extern "C" int64_t qpg_hl_cols_bytes(int Q, int D) {
+  const int chunks = (Q + HL_GQC - 1) / HL_GQC;
+  return (Q <= 0 || D <= 0) ? 0 : (int64_t)chunks * (D / 32) * HL_CT * 2 * HL_PIECE + (int64_t)chunks * HL_GQC * 4;
+}
+
+extern "C" int qpg_hl_pack_rows(qpg_ctx* ctx, void* stream, const float* x, int64_t R, int D, void* image,
+                                int64_t image_bytes) {
+  const char* name = "qpg_hl_pack_rows";
+  QPG_REQUIRE(ctx && x && image && R > 0 && (R % 32) == 0 && D > 0 && (D % 128) == 0, "%s: needs R %% 32 == 0, D %% 128 == 0",
+              name);
+  QPG_REQUIRE(image_bytes >= qpg_hl_rows_bytes(R, D) && (reinterpret_cast<uintptr_t>(image) % 16) == 0 &&
+                  (reinterpret_cast<uintptr_t>(x) % 16) == 0,
+              "%s: image too small or misaligned (qpg_hl_rows_bytes)", name);
+  hipStream_t st = qpg_stream(stream);
+  unsigned char* img = static_cast<unsigned char*>(image);
+  int32_t* meta = reinterpret_cast<int32_t*>(img + (qpg_hl_rows_bytes(R, D) - 64));
+  unsigned int* amax = reinterpret_cast<unsigned int*>(meta + 4);
+  hipLaunchKernelGGL(hl_zero_u32_kernel, dim3(1), dim3(1), 0, st, amax);
+  hipLaunchKernelGGL(hl_absmax_kernel, dim3(1024), dim3(1024), 0, st, x, R * D, amax);
+  hipLaunchKernelGGL(hl_exponent_kernel, dim3(1), dim3(1), 0, st, (const unsigned int*)amax, meta);
+  hipLaunchKernelGGL(hl_pack_rows_kernel, dim3(4096), dim3(256), 0, st, x, R, D, (const int32_t*)meta,
+                     reinterpret_cast<_Float16*>(img));
+  QPG_LAUNCH_CHECK("hl_pack_rows_kernel");
+  return QPG_OK;
+}
+
+extern "C" int qpg_hl_pack_cols(qpg_ctx* ctx, void* stream, const float* q, int Q, int D, void* image, int64_t image_bytes) {
+  const char* name = "qpg_hl_pack_cols";
+  QPG_REQUIRE(ctx && q && image && Q > 0 && D > 0 && (D % 128) == 0, "%s: bad argument (D %% 128 == 0)", name);
+  QPG_REQUIRE(image_bytes >= qpg_hl_cols_bytes(Q, D) && (reinterpret_cast<uintptr_t>(image) % 16) == 0 &&
+                  (reinterpret_cast<uintptr_t>(q) % 16) == 0,
+              "%s: image too small or misaligned (qpg_hl_cols_bytes)", name);
+  const int chunks = (Q + HL_GQC - 1) / HL_GQC;
+  unsigned char* img = static_cast<unsigned char*>(image);
+  int32_t* qexp = reinterpret_cast<int32_t*>(img + (int64_t)chunks * (D / 32) * HL_CT * 2 * HL_PIECE);
+  hipLaunchKernelGGL(hl_pack_cols_kernel, dim3(chunks * HL_GQC), dim3(256), 0, qpg_stream(stream), q, Q, D,
+                     reinterpret_cast<_Float16*>(img), qexp);
+  QPG_LAUNCH_CHECK("hl_pack_cols_kernel");
+  return QPG_OK;
+}
+
+extern "C" int qpg_hl_gemm_distance(qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,
+                                    const void* cols_image, int Q, float* Dm, int64_t ldD) {
+  const char* name = "qpg_hl_gemm_distance";
+  QPG_REQUIRE(ctx && rows_image && cols_image && Dm, "%s: null pointer", name);
+  QPG_REQUIRE(R > 0 && (R % 32) == 0 && R / 32 < 0x7fffffff && Q > 0 && D > 0 && (D % 128) == 0 && ldD >= R &&
+                  (ldD % 4) == 0 && (reinterpret_cast<uintptr_t>(Dm) % 16) == 0,
+              "%s: bad size (R %% 32 == 0, D %% 128 == 0, ldD %% 4 == 0, 16-byte aligned output)", name);
+  const int chunks = (Q + HL_GQC - 1) / HL_GQC, KB = D / 32;
+  HlArgs a;
+  const unsigned char* ri = static_cast<const unsigned char*>(rows_image);
+  const unsigned char* ci = static_cast<const unsigned char*>(cols_image);
+  a.db = reinterpret_cast<const _Float16*>(ri);
+  a.meta = reinterpret_cast<const int32_t*>(ri + (qpg_hl_rows_bytes(R, D) - 64));
+  a.qi = reinterpret_cast<const _Float16*>(ci);
+  a.qexp = reinterpret_cast<const int32_t*>(ci + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
+  a.cn2 = nullptr; a.qn2 = nullptr; a.D = Dm; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = nullptr;
+  a.N = (int)(R / 32); a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1;
+  const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
+  hipLaunchKernelGGL(audio_cosine_hl_kernel<1>, dim3((a.N + HL_WPB - 1) / HL_WPB, chunks), dim3(HL_THREADS), lds_bytes,
+                     qpg_stream(stream), a);
+  QPG_LAUNCH_CHECK("audio_cosine_hl_kernel<1>");
   return QPG_OK;
 }
 

@@ -86,7 +86,7 @@ def test_cfg3_100k_by_512_per_code_min():
     # global nearest neighbour of every query
     import torch
     from qpgesture_amd.cfg3 import CosineIndex
-    index = CosineIndex(X, code, valid, n_codes=K)
+    index = CosineIndex(X, code, valid, n_codes=K, method="valu")
     qd = torch.from_numpy(q).cuda()
     fd, fi, nn = index.query(qd)
     for tpc in (64, 7, 2000, 1):                                   # work granularity must not matter
@@ -132,7 +132,7 @@ def test_cfg3_f16_storage_equals_reference_arithmetic_on_rounded_rows():
     assert valid[idx[idx >= 0]].all()
     assert np.array_equal(code[idx[idx >= 0]], np.nonzero(idx >= 0)[1])
     # against the f32-stored index: same winners almost everywhere, distances moved by the rounding of the inputs only
-    d32, i32, _ = CosineIndex(X, code, valid, n_codes=K).query(qd)
+    d32, i32, _ = CosineIndex(X, code, valid, n_codes=K, method="valu").query(qd)
     assert 1e-6 < float((d32 - fd).abs().max()) < 1e-2
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     index.query(qd)
@@ -142,3 +142,74 @@ def test_cfg3_f16_storage_equals_reference_arithmetic_on_rounded_rows():
     ev[1].record()
     torch.cuda.synchronize()
     print("cfg-3 (f16 storage): %.2f ms per 1000-query batch" % (ev[0].elapsed_time(ev[1]) / 5))
+
+
+def test_cfg3_bounded_prefilter_equals_the_exact_sweep():
+    """Round 3: CosineIndex(method="mfma") - rows sorted by code, split-f16 matrix-core prefilter with an a-priori bound
+    against sklearn's f32 value, exact-order evaluation of the band members only - returns the exact sweep's tables bit
+    for bit: distances, first-wins indices (the planted identical rows: lower index), global nearest neighbours, absent
+    codes; a slice against the C oracle; and the prefilter's error stays inside the band it is given."""
+    import torch
+    from oracle import cref
+    from qpgesture_amd import _lib
+    from qpgesture_amd.cfg3 import CosineIndex, prefilter_band
+    X, code, valid, q, rows = _inputs()
+    qd = torch.from_numpy(q).cuda()
+    ref = CosineIndex(X, code, valid, n_codes=K, method="valu")
+    rd, ri, rn = ref.query(qd)
+    index = CosineIndex(X, code, valid, n_codes=K)
+    assert index.method == "mfma" and index.R % 32 == 0
+    fd, fi, fn = index.query(qd)
+    assert index.fallbacks == 0
+    assert torch.equal(fd, rd) and torch.equal(fi, ri) and torch.equal(fn, rn)
+    sel = np.r_[0:3, 200:203, Q - 2:Q]
+    cm = np.where(valid, code, -1).astype(np.int32).reshape(N, 1)
+    od, oi = cref.text_scan(X.reshape(N, 1, D), [0], cm, [0], q[sel], K=K, n_threads=8)
+    assert np.array_equal(fi.cpu().numpy()[sel], oi) and np.array_equal(fd.cpu().numpy()[sel], od)
+    # the prefilter matrix against the exact f32 distances of the same (sorted) rows: inside half the band
+    Dm = index._Dm[:8].double().cpu().numpy()
+    rows_ok = (index.row_index >= 0).cpu().numpy()
+    xs = index.xs.double().cpu().numpy()
+    qn = torch.empty_like(qd)
+    _lib.call("qpg_l2_normalize_rows_f32", qd.device, qd, Q, D, qn)
+    exact = 1.0 - qn[:8].double().cpu().numpy() @ xs.T
+    err = np.abs(Dm - exact)[:, rows_ok].max()
+    print("prefilter: max |d~ - (1 - <x^, q^>)| = %.3g; band %.3g" % (err, prefilter_band(D)))
+    assert err <= 1.3e-6
+    # ragged batch sizes (chunks of 96) and timing
+    for nq in (1, 95, 97, 200):
+        d2, i2, n2 = index.query(qd[:nq])
+        assert torch.equal(d2, rd[:nq]) and torch.equal(i2, ri[:nq]) and torch.equal(n2, rn[:nq])
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    index.check_flags = False
+    index.query(qd)
+    ev[0].record()
+    for _ in range(5):
+        index.query(qd)
+    ev[1].record()
+    torch.cuda.synchronize()
+    assert int(index._stats[1].item()) == 0
+    print("cfg-3 (bounded prefilter + exact refine): %.2f ms per 1000-query batch" % (ev[0].elapsed_time(ev[1]) / 5))
+
+
+def test_cfg3_prefilter_falls_back_when_a_band_overflows():
+    """9 000 identical rows under one code (what repeated silence embeddings look like): every one of them is inside the
+    band of that code for every query - more than the select's list holds.  The index notices (stats flag) and answers
+    from the exact sweep: same tables, lowest index wins the 9 000-way tie."""
+    import torch
+    from qpgesture_amd.cfg3 import CosineIndex
+    rng = np.random.Generator(np.random.PCG64(11))
+    n, d, k, nq = 20_000, 512, 64, 40
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    code = rng.integers(0, k, size=n).astype(np.int32)
+    X[5_000:14_000] = X[4_999]
+    code[4_999:14_000] = 7
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    qd = torch.from_numpy(q).cuda()
+    ref = CosineIndex(X, code, None, n_codes=k, method="valu").query(qd)
+    index = CosineIndex(X, code, None, n_codes=k)
+    got = index.query(qd)
+    assert index.fallbacks == 1
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert (got[1][:, 7].cpu().numpy() != -1).all()

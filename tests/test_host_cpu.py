@@ -27,7 +27,8 @@ def test_bindings_cover_the_header():
                                "qpg_text_percode_ws_bytes", "qpg_percode_select_mixed_ws_bytes",
                                "qpg_merge_mixed_ws_bytes", "qpg_debug_convt_shape",
                                "qpg_percode_select_exact_ws_bytes", "qpg_audio_hl_supported",
-                               "qpg_audio_hl_db_bytes", "qpg_audio_hl_query_bytes"}
+                               "qpg_audio_hl_db_bytes", "qpg_audio_hl_query_bytes", "qpg_hl_rows_bytes",
+                               "qpg_hl_cols_bytes"}
     assert declared == bound
 
 
