@@ -314,6 +314,12 @@ struct HlArgs {
 //   the last pair-step, behind the arrival of that pair-step's own fragments: behind it nobody reads this stage's
 //   buffer any more and everybody's stores of the next stage are done, so the next stage's first fragments are
 //   prefetched under the last pair-step's MFMAs - no bubble.
+#ifndef HL_NT
+#define HL_NT 0
+#endif
+#ifndef HL_PD
+#define HL_PD 1            // pair-steps between a fragment read and its use (2 needs HL_PS %% 3 == 0 and 2 * HL_PS %% 3 == 0)
+#endif
 #ifndef HL_WPB
 #define HL_WPB 4           // database windows per block (2 waves each)
 #endif
@@ -337,9 +343,16 @@ __global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a
   const h8* dbp = row_ok ? reinterpret_cast<const h8*>(a.db) + (((int64_t)j * 2 + t) * KB * 2) * 64 + lane
                          : reinterpret_cast<const h8*>(a.zeros);
   const int kb_step = row_ok ? 128 : 0, pl_step = row_ok ? 64 : 0;      // h8 units per k-block / plane
+  // (HL_NT: the database image is read ONCE - a non-temporal load keeps it from evicting the query image, which every
+  // block re-reads, out of the XCD's L2)
   auto load_a = [&](int kb, h8 (&dst)[2]) {
+#if HL_NT
+    dst[0] = __builtin_nontemporal_load(dbp + (int64_t)kb * kb_step);
+    dst[1] = __builtin_nontemporal_load(dbp + (int64_t)kb * kb_step + pl_step);
+#else
     dst[0] = dbp[(int64_t)kb * kb_step];
     dst[1] = dbp[(int64_t)kb * kb_step + pl_step];
+#endif
   };
   // query image of this chunk: stage s = HL_KS*6*2 pieces of 1 KB; 16-byte units, stage_units / HL_THREADS per thread
   constexpr int stage_units = HL_KS * HL_CT * 2 * 64;
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a
   load_q(2);
   const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
   // fragments of a pair-step: [column tile of the pair][plane]; pair-step ps of a stage: k2 = ps / 3, c0 = 2 * (ps % 3)
-  h8 B[2][2][2];
+  h8 B[HL_PD + 1][2][2];                                        // ring: fragments are read HL_PD pair-steps ahead
   auto ld_b = [&](int buf, int ps, h8 (&d)[2][2]) {
     const h8* qb = reinterpret_cast<const h8*>(lds) + buf * stage_units + lane;
     const int k2 = ps / 3, c0 = 2 * (ps % 3);
@@ -390,7 +403,8 @@ __global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a
       for (int pl = 0; pl < 2; ++pl) d[jj][pl] = qb[((k2 * HL_CT + c0 + jj) * 2 + pl) * 64];
   };
   f32x4 hp[2] = {zero4, zero4};                                 // the previous pair-step's block sums, not yet flushed
-  ld_b(0, 0, B[0]);
+#pragma unroll
+  for (int i = 0; i < HL_PD; ++i) ld_b(0, i, B[i]);
 
   for (int s2 = 0; s2 < n_stage; s2 += 2) {                     // two stages per trip: ring / buffer indices are static
 #pragma unroll
@@ -402,16 +416,16 @@ __global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a
         const int pc0 = 2 * ((ps + 2) % 3);                     // the previous pair-step's column tiles
         const int kb = s * HL_KS + k2;
         h8 (&af)[2] = ring[(ss * HL_KS + k2) % HL_RING];
-        h8 (&Bc)[2][2] = B[ps & 1];
-        h8 (&Bn)[2][2] = B[(ps + 1) & 1];
-        if (ps == HL_PS - 1) {
-          // this pair-step's fragments have arrived (they are about to be used): from here on nobody reads this
-          // stage's buffer, and every wave's stores of the next stage (issued at the start of this one) are done
+        // (HL_PS is a multiple of HL_PD + 1 for the shipped shapes: the ring index is static)
+        h8 (&Bc)[2][2] = B[(ss * HL_PS + ps) % (HL_PD + 1)];
+        h8 (&Bn)[2][2] = B[(ss * HL_PS + ps + HL_PD) % (HL_PD + 1)];
+        if (ps == HL_PS - HL_PD) {
+          // the fragments of this stage's remaining pair-steps have arrived (lgkmcnt(0)): from here on nobody reads
+          // this stage's buffer, and every wave's stores of the next stage (issued at the start of this one) are done
           lds_barrier();
-          ld_b((ss + 1) & 1, 0, Bn);                            // next stage, pair-step 0
-        } else {
-          ld_b(ss, ps + 1, Bn);
         }
+        if (ps >= HL_PS - HL_PD) ld_b((ss + 1) & 1, ps + HL_PD - HL_PS, Bn);      // next stage's first pair-steps
+        else ld_b(ss, ps + HL_PD, Bn);
         const f32x4 h0 = mfma_h(af[0], Bc[0][0], zero4);        // 32 exact products each: one block sum
         const f32x4 h1 = mfma_h(af[0], Bc[1][0], zero4);
         if (!(QPG_HL_PROBE & 8)) {
