@@ -867,6 +867,9 @@ class CodeKNN:
         the uncapped path before anything is returned (on a sharded DB every rank sees the same word and re-matches)."""
         if seed_code is None:                       # drawn ONCE: a re-match starts from the same state
             seed_code, seed_phase = self.init_code_phase()
+        if n_windows == 0:                          # an empty clip (the reference's loop body never runs, :785)
+            return (np.zeros((0, num_frames_code), np.int64), np.zeros((0, self.n_steps(), 8, 16), np.float32),
+                    np.zeros((0, self.n_steps()), np.int32))
         test_interp = test_interp.contiguous()
         try:
             T = self.sweep_tables(test_interp, test_context, n_windows, mode)

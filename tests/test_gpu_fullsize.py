@@ -74,6 +74,32 @@ def test_fullsize_tables_vs_c_oracle(speechlike):
     assert np.array_equal(a, b)
 
 
+def test_empty_clip_returns_empty_arrays():
+    """n_windows = 0 used to read an uninitialised status word; the walk now always writes it and match_clip
+    answers an empty clip without launching anything."""
+    import torch
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    A = _db(16, 300)
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    te_i = torch.zeros((0, 180, 1024), device="cuda:0")
+    te_c = torch.zeros((0, 30, 384), device="cuda:0")
+    codes, phases, votes = knn.match_clip(te_i, te_c, 0)
+    assert codes.shape == (0, 30) and votes.shape[0] == 0 and phases.shape[0] == 0
+    # and the walk entry point itself: M = 0 writes a defined status
+    from qpgesture_amd import _lib
+    st = torch.full((2,), 77, dtype=torch.int32, device="cuda:0")
+    z16 = torch.zeros((1, 512), dtype=torch.int16, device="cuda:0")
+    z32 = torch.zeros((1, 512), dtype=torch.int32, device="cuda:0")
+    _lib.call("qpg_match_steps", db.device, z16, z32, z16, z32, db.pos_rank, db.freq_rank, db.code, db.code.shape[1],
+              db.aud_cidx, db.aud_pslot, db.Ga, db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, 0, 0, 8, db.K, 0,
+              torch.zeros((8, 16), device="cuda:0"), torch.zeros((3, 8, 512), dtype=torch.int32, device="cuda:0"),
+              torch.zeros((1, 30), dtype=torch.int32, device="cuda:0"), torch.zeros((1, 8, 8, 16), device="cuda:0"),
+              torch.zeros((1, 8), dtype=torch.int32, device="cuda:0"), st, None)
+    assert st.cpu().tolist() == [0, 0]
+
+
 def test_speaker1_class_db_8192_windows_vs_c_oracle():
     """BASELINE.json configs[3]'s workload on ONE GPU: N_db = 8192 windows (212 992 candidates, 6 GB resident base), one
     24 s clip.  Per-code winners of both sweeps equal the C port's, text distances bit-exact, audio <= 1e-13, ranks equal;
