@@ -196,29 +196,38 @@ int qpg_text_percode_f16(qpg_ctx*, void* stream, const void* xh, const float* nr
                          void* ws, int64_t ws_bytes, float* out_dist, int32_t* out_idx, int16_t* out_rank,
                          int32_t* out_nn);
 
-/* BOUNDED PREFILTER + EXACT REFINE for the exact-f32 cosine family (round 3; BASELINE.json configs[2]): bit-identical
- * tables to qpg_text_percode_f32 at a fraction of its VALU work.  Build side (host, once): sklearn-normalise the rows
- * (qpg_l2_normalize_rows_f32), drop masked rows, sort by code (stable) into segments padded to 16 rows, R %% 32 == 0.
+/* BOUNDED PREFILTER + EXACT REFINE for the exact-f32 cosine family (round 3; BASELINE.json configs[2] and the matcher's
+ * text side, GestureKNN.py:708-721): bit-identical tables to qpg_text_percode_f32 at a fraction of its VALU work.  Build
+ * side (host, once; qpgesture_amd/sorted_rows.py): sklearn-normalise the rows (qpg_l2_normalize_rows_f32), drop masked rows,
+ * keep per code only the FIRST of the rows the normalisation left at zero (zero_row), sort the rest by code (stable) into
+ * segments padded to 16 rows with copies of the segment's first row, R %% 32 == 0.
  *   qpg_hl_pack_rows / qpg_hl_pack_cols   split-f16 fragment images of the sorted unit rows xs [dev] f32 [R][D] and of the
  *       normalised queries qn [dev] f32 [Q][D] (chunks of 96); sizes: qpg_hl_rows_bytes / qpg_hl_cols_bytes.  D %% 128 == 0.
  *   qpg_hl_gemm_distance   Dm [dev] f32 [Q][ldD >= R]: Dm[q][r] = 1 - <xs[r], qn[q]> on the f16 matrix cores (the kernel of
- *       qpg_audio_cosine_hl with a plain epilogue; |Dm - true| <= QPG_AUDIO_HL_ERR for unit-norm operands).
- *   qpg_percode_select_sorted_f32   per query: per-code minimum of Dm, every row within `band` of it evaluated in
- *       sklearn's exact f32 order (0.5 * einsum_sq(qn - xs)), minimum exact distance and lowest ORIGINAL index per code.
- *       row_code [dev] i16 [R]: code of sorted row r, | 0x4000 for padding rows; row_index [dev] i32 [R]: original index.
+ *       qpg_audio_cosine_hl with a plain epilogue; |Dm - true| <= QPG_AUDIO_HL_ERR for unit-norm operands); tile_min
+ *       (optional) [dev] f32 [Q][ldT >= R / 16]: the minimum of every 16-row tile, what the select reads first.
+ *   qpg_percode_select_sorted_f32   per query: per-code minimum of Dm from the tile minima, every row within `band` of it
+ *       evaluated in sklearn's exact f32 order (0.5 * einsum_sq(qn - xs)), minimum exact distance and lowest ORIGINAL index
+ *       per code.  row_code [dev] i16 [R]: code of sorted row r (K <= 2048), | 0x4000 for padding rows, 0x1fff for the tail
+ *       past the last segment; row_index [dev] i32 [R]: original index; zero_row [dev] i32 [K] or NULL: original index of the
+ *       code's first all-zero row (-1: none) - it enters with the prefilter value 0.5; xs holds R + 1 rows, row R zeros;
+ *       code_tile [dev] i32 [K + 1]: first 16-row tile of every code's segment (8 blocks per query take a range of codes
+ *       each; ranks / nearest neighbours: a second small launch).  A band list is 2048 rows / 1024 opened tiles per block.
  *       `band` >= 2 x (prefilter error + sklearn's own rounding against the real value): derivation in
- *       csrc/qpg_sorted.hip (8.6e-5 at D = 512).  stats[1] |= 1 if a query's band list (8192) overflowed: run
- *       qpg_text_percode_f32 instead.  out_nn optional: the query's global nearest neighbour (original index). */
+ *       csrc/qpg_sorted.hip (8.6e-5 at D = 512).  stats[1] |= 1 if a band list overflowed: run
+ *       qpg_text_percode_f32 instead.  out_rank optional: i16 [Q][K] ranks of the table rows (qpg_rank_rows_f32's);
+ *       out_nn optional: the query's global nearest neighbour (original index). */
 int64_t qpg_hl_rows_bytes(int64_t R, int D);
 int64_t qpg_hl_cols_bytes(int Q, int D);
 int qpg_hl_pack_rows(qpg_ctx*, void* stream, const float* xs, int64_t R, int D, void* image, int64_t image_bytes);
 int qpg_hl_pack_cols(qpg_ctx*, void* stream, const float* qn, int Q, int D, void* image, int64_t image_bytes);
 int qpg_hl_gemm_distance(qpg_ctx*, void* stream, const void* rows_image, int64_t R, int D, const void* cols_image, int Q,
-                         float* Dm, int64_t ldD);
-int qpg_percode_select_sorted_f32(qpg_ctx*, void* stream, const float* Dm, int64_t ldD, int Q, int64_t R,
-                                  const int16_t* row_code, const int32_t* row_index, int K, float band, const float* qn,
-                                  const float* xs, int D, float absent, float* out_dist, int32_t* out_idx, int32_t* out_nn,
-                                  int32_t* stats);
+                         float* Dm, int64_t ldD, float* tile_min, int64_t ldT);
+int qpg_percode_select_sorted_f32(qpg_ctx*, void* stream, const float* Dm, int64_t ldD, const float* tile_min, int64_t ldT,
+                                  int Q, int64_t R, const int16_t* row_code, const int32_t* row_index,
+                                  const int32_t* zero_row, const int32_t* code_tile, int K, float band, const float* qn,
+                                  const float* xs, int D, float absent, float* out_dist, int32_t* out_idx,
+                                  int16_t* out_rank, int32_t* out_nn, int32_t* stats);
 
 /* vq-wav2vec audio sweep (the mode the paper describes; flags use_wavvq/use_feature of GestureKNN.py:557-560):
  * D[q][c] = Levenshtein distance (unit costs, python-Levenshtein distance()) between the 11-symbol strings of

@@ -40,8 +40,8 @@ _SIGS = {
     "qpg_debug_mfma_f16_tile": [P, P, P, I, P],
     "qpg_hl_pack_rows": [P, L, I, P, L],
     "qpg_hl_pack_cols": [P, I, I, P, L],
-    "qpg_hl_gemm_distance": [P, L, I, P, I, P, L],
-    "qpg_percode_select_sorted_f32": [P, L, I, L, P, P, I, c_float, P, P, I, c_float, P, P, P, P],
+    "qpg_hl_gemm_distance": [P, L, I, P, I, P, L, P, L],
+    "qpg_percode_select_sorted_f32": [P, L, P, L, I, L, P, P, P, P, I, c_float, P, P, I, c_float, P, P, P, P, P],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
     "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
     "qpg_text_percode_f32": [P, L, I, P, I, P, I, I, ctypes.c_int32, c_float, P, L, P, P, P, P],

@@ -22,20 +22,7 @@ from . import _lib
 
 N_DB, DIM, N_Q, K_CODES = 100_000, 512, 1000, 512
 ABSENT = 1000.0
-U32 = 2.0 ** -24
-HL_GEMM_ERR = 1.3e-6          # QPG_AUDIO_HL_ERR: the split-f16 GEMM on unit-norm operands
-
-
-def prefilter_band(d):
-    """Band of the bounded prefilter for the exact-f32 cosine (derivation: csrc/qpg_sorted.hip): 2.1 x (E_pre + E_sk).
-    eps1: relative error of an f32 sklearn-normalised element (norm^2 by 4 lane chains of d/4 squares, sqrt, divide);
-    E_pre: the GEMM's bound + the two operands being off the true unit vectors by eps1 each;
-    E_sk: sklearn's own rounding against the real-number distance (normalisation errors through the difference,
-    Cauchy-Schwarz with |delta| <= 2, then the chains of d/4 squares)."""
-    eps1 = ((d / 4 + 2) / 2 + 2) * U32
-    e_pre = HL_GEMM_ERR + 2 * eps1
-    e_sk = 0.5 * (8 * eps1 + 4 * (d / 4 + 3) * U32)
-    return 2.1 * (e_pre + e_sk)
+from .sorted_rows import HL_GEMM_ERR, U32, SortedRows, prefilter_band  # noqa: F401  (re-exported)
 
 
 def make_inputs(n=N_DB, d=DIM, nq=N_Q, k=K_CODES):
@@ -78,43 +65,19 @@ class CosineIndex:
         self.cand_code = torch.from_numpy(cm.astype(np.int16)).to(dev)
         self._ws = None
         self.fallbacks = 0
-        self.method = method if (feature_dtype == "f32" and d % 128 == 0 and n_codes < 0x4000) else "valu"
+        self.method = method if (feature_dtype == "f32" and d % 128 == 0 and n_codes < 0x2000) else "valu"
         if self.method == "mfma":
             self._build_sorted(xd.view(n, d), cm)
 
     def _build_sorted(self, xd, cm):
         """Rows for the bounded prefilter: sklearn-normalised (the exact kernel, so the refine reads what the exact sweep
-        would), masked rows dropped, sorted by code (stable: original order inside a code = first-wins), every code's
-        segment padded to 16 rows, the total to 32; + the split-f16 fragment image of those rows."""
-        dev, d, K = self.device, self.d, self.K
+        would), masked rows dropped, sorted by code (sorted_rows.SortedRows)."""
+        dev = self.device
         xn = torch.empty_like(xd)
-        _lib.call("qpg_l2_normalize_rows_f32", dev, xd.contiguous(), self.n, d, xn)
-        cmt = torch.from_numpy(cm).to(dev)
-        keep = torch.nonzero((cmt >= 0) & (cmt < K)).reshape(-1)
-        order = keep[torch.sort(cmt[keep], stable=True).indices]              # original indices, by (code, index)
-        codes = cmt[order]
-        cnt = torch.bincount(codes, minlength=K)
-        pad_cnt = (cnt + 15) // 16 * 16
-        start = torch.cumsum(pad_cnt, 0) - pad_cnt
-        R = int(pad_cnt.sum().item())
-        R = (R + 31) // 32 * 32
-        within = torch.arange(order.numel(), device=dev) - (torch.cumsum(cnt, 0) - cnt)[codes]
-        pos = start[codes] + within
-        row_index = torch.full((R,), -1, dtype=torch.int32, device=dev)
-        row_index[pos] = order.to(torch.int32)
-        # a padding row carries its segment's code with bit 14 set (the tail beyond the last segment: code K - 1's)
-        seg_code = torch.repeat_interleave(torch.arange(K, device=dev), pad_cnt)
-        seg_code = torch.cat((seg_code, torch.full((R - seg_code.numel(),), K - 1, device=dev, dtype=seg_code.dtype)))
-        row_code = torch.where(row_index >= 0, seg_code, seg_code | 0x4000).to(torch.int16).contiguous()
-        xs = torch.zeros((R, d), dtype=torch.float32, device=dev)
-        xs[pos] = xn[order]
-        lib = _lib.load()
-        img = torch.empty((int(lib.qpg_hl_rows_bytes(R, d)),), dtype=torch.uint8, device=dev)
-        _lib.call("qpg_hl_pack_rows", dev, xs, R, d, img, img.numel())
-        self.R, self.xs, self.row_index, self.row_code, self.rows_image = R, xs, row_index, row_code, img
-        self.band = float(prefilter_band(d))
+        _lib.call("qpg_l2_normalize_rows_f32", dev, xd.contiguous(), self.n, self.d, xn)
+        self.sorted = SortedRows(xn, torch.from_numpy(cm), self.K, dev)
+        self.R, self.band = self.sorted.R, self.sorted.band
         self._stats = torch.zeros((4,), dtype=torch.int32, device=dev)
-        self._Dm = None
 
     def query(self, q, want_nn=True):
         """q: f32 [Q][d] device tensor.  Returns (dist f32 [Q][K], idx i32 [Q][K], nn i32 [Q])."""
@@ -123,19 +86,9 @@ class CosineIndex:
         qn = torch.empty_like(q)
         _lib.call("qpg_l2_normalize_rows_f32", dev, q, Q, self.d, qn)
         if self.method == "mfma" and not getattr(self, "_force_valu", False):
-            lib = _lib.load()
-            nb = int(lib.qpg_hl_cols_bytes(Q, self.d))
-            if getattr(self, "_cols", None) is None or self._cols.numel() < nb:
-                self._cols = torch.empty((nb,), dtype=torch.uint8, device=dev)
-            if self._Dm is None or self._Dm.shape[0] < Q:
-                self._Dm = torch.empty((Q, self.R), dtype=torch.float32, device=dev)
-            dist = torch.empty((Q, self.K), dtype=torch.float32, device=dev)
-            idx = torch.empty((Q, self.K), dtype=torch.int32, device=dev)
+            self.sorted.band = self.band
             nn = torch.empty((Q,), dtype=torch.int32, device=dev) if want_nn else None
-            _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, self._cols, self._cols.numel())
-            _lib.call("qpg_hl_gemm_distance", dev, self.rows_image, self.R, self.d, self._cols, Q, self._Dm, self.R)
-            _lib.call("qpg_percode_select_sorted_f32", dev, self._Dm, self.R, Q, self.R, self.row_code, self.row_index,
-                      self.K, self.band, qn, self.xs, self.d, ABSENT, dist, idx, nn, self._stats)
+            dist, idx, nn = self.sorted.select(qn, ABSENT, self._stats, nn=nn)
             if not getattr(self, "check_flags", True):
                 return dist, idx, nn                   # (timing loops: the flag is read once, after the loop)
             if int(self._stats[1].item()) == 0:

@@ -13,6 +13,7 @@ import torch
 
 from . import _lib
 from .parallel import allreduce_max_, allreduce_min_index, exchange_bytes, shard_rows
+from .sorted_rows import SortedRows
 import ctypes
 
 from .constant import (ABSENT_DIST, NUM_AUDIO_FEAT_FRAMES, STEP_SZ, WAVVQ_GROUP_SIZE, codebook_size, num_frames,
@@ -127,7 +128,8 @@ class GestureDB:
     """
 
     def __init__(self, code, wavlm_interp, context, phase_dense, signature, device="cuda:0",
-                 freq_rank=None, pos_rank=None, rank=0, world=1, wavvq=None, feature_dtype="f32", hl_image=True):
+                 freq_rank=None, pos_rank=None, rank=0, world=1, wavvq=None, feature_dtype="f32", hl_image=True,
+                 text_prefilter=True):
         dev = torch.device(device)
         if feature_dtype not in ("f32", "f16"):
             raise ValueError("feature_dtype must be 'f32' or 'f16'")
@@ -223,6 +225,15 @@ class GestureDB:
         if self.n_local:
             _lib.call("qpg_text_pack_candidates_f32", dev, ctx_d, self.n_local, self.R, self.Dt, self.txt_r,
                       self.Gt, self.ctxt)
+        # text candidates sorted by code + their split-f16 image for the bounded prefilter (sorted_rows.SortedRows,
+        # csrc/qpg_sorted.hip): rows normalised by the kernel the exact sweep's candidates are normalised by
+        self.txt_sorted = None
+        if text_prefilter and world == 1 and self.n_local and self.Dt % 128 == 0 and self.K < 0x2000:
+            rows_f = ctx_d[:, torch.as_tensor(np.asarray(rows, np.int64), device=dev), :].reshape(self.Ct, self.Dt)
+            rows_n = torch.empty_like(rows_f)
+            _lib.call("qpg_l2_normalize_rows_f32", dev, rows_f.contiguous(), self.Ct, self.Dt, rows_n)
+            self.txt_sorted = SortedRows(rows_n, self.txt_cand_code[:self.Ct], self.K, dev)
+            del rows_f, rows_n
         del ctx_d
 
         ph = np.ascontiguousarray(np.asarray(phase_dense, np.float32)[:, :, [0, 2], :])
@@ -300,6 +311,11 @@ class CodeKNN:
         # kernel of the mixed-precision sweep: "hl" = split-operand f16 matrix cores on the frame-major image (HBM-bound;
         # needs GestureDB.hl_image), "mx" = the f32 matrix cores on the f32 / f16 base.  Same bound, same select.
         self.audio_kernel = "hl"
+        # text_kernel "mfma" (round 3, default where the DB holds the sorted image: one GPU): bounded split-f16 prefilter
+        # over the candidates sorted by code + exact sklearn-order evaluation of every code's band (bit-identical tables;
+        # an overflowing band list raises the trouble word and the clip is re-matched on the exact sweep); "valu": the
+        # exact-order sweep of every pair (qpg_text_cosine_f32).
+        self.text_kernel = "mfma"
         self.fallbacks = 0
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
         # Row-sharded DB: the shards sweep in mixed precision too and the cross-shard merge re-evaluates what their
@@ -467,6 +483,15 @@ class CodeKNN:
         else:
             qn = torch.empty_like(queries)
             _lib.call("qpg_l2_normalize_rows_f32", dev, queries, Q, db.Dt, qn)
+        self._last_text_mfma = False
+        if (self.text_kernel == "mfma" and db.txt_sorted is not None and out is None and reduce and Q > 0 and
+                not self.force_sharded and self.audio_precision != "exact"):
+            self._last_text_mfma = True
+            rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if want_rank else None
+            dist, idx, _ = db.txt_sorted.select(qn, float(ABSENT_DIST), self._guard_stats, rank=rank)
+            if want_rank:
+                return dist, idx, rank
+            return dist, idx
         D = torch.empty((Q, max(db.Ct, 1)), dtype=torch.float32, device=dev)
         _lib.call("qpg_text_cosine_f32", dev, db.ctxt, db.Ct, db.Dt, qn, Q, D, D.stride(0))
         if out is not None:

@@ -286,6 +286,8 @@ struct HlArgs {
   int64_t ldD;
   int32_t* stats;
   int N, G, Q, KB, d_f32;   // N: database windows (MODE 0) / 32-row groups (MODE 1)
+  float* tmin;             // MODE 1, optional: [Q][ldT] minimum of every 16-row tile (rows 16 i .. 16 i + 15)
+  int64_t ldT;
 };
 
 #define HL_RING (2 * HL_KS)  // k-blocks of database fragments in flight per wave (2 KB each): two stages
@@ -482,6 +484,12 @@ __global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a
       for (int r = 0; r < 4; ++r)
         o[r] = (float)(1.0 - ldexp(acc[ct][r] + (double)xacc[ct][r] * (1.0 / 2048.0), -(e_c1 + e_q1)));
       *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (int64_t)q * a.ldD + (int64_t)j * 32 + 16 * t + 4 * rg) = o;
+      if (a.tmin) {           // the tile's minimum over its 16 rows: lanes cg, cg + 16, cg + 32, cg + 48 hold 4 rows each
+        float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
+        m = fminf(m, __shfl_xor(m, 16, 64));
+        m = fminf(m, __shfl_xor(m, 32, 64));
+        if (rg == 0) a.tmin[(int64_t)q * a.ldT + (int64_t)j * 2 + t] = m;
+      }
     }
     return;
   }
@@ -625,7 +633,7 @@ extern "C" int qpg_audio_cosine_hl(qpg_ctx* ctx, void* stream, const void* db_im
   a.meta = reinterpret_cast<const int32_t*>(dbi + (qpg_audio_hl_db_bytes(N, F) - 64));
   a.qi = reinterpret_cast<const _Float16*>(qi);
   a.qexp = reinterpret_cast<const int32_t*>(qi + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
-  a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = N; a.G = G; a.Q = Q; a.KB = KB; a.d_f32 = d_is_f32;
+  a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = N; a.G = G; a.Q = Q; a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0;
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
   if (lds_bytes > 64 * 1024) {
     static bool raised = false;
@@ -766,12 +774,13 @@ extern "C" int qpg_hl_pack_cols(qpg_ctx* ctx, void* stream, const float* q, int 
 }
 
 extern "C" int qpg_hl_gemm_distance(qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,
-                                    const void* cols_image, int Q, float* Dm, int64_t ldD) {
+                                    const void* cols_image, int Q, float* Dm, int64_t ldD, float* tile_min, int64_t ldT) {
   const char* name = "qpg_hl_gemm_distance";
   QPG_REQUIRE(ctx && rows_image && cols_image && Dm, "%s: null pointer", name);
   QPG_REQUIRE(R > 0 && (R % 32) == 0 && R / 32 < 0x7fffffff && Q > 0 && D > 0 && (D % 128) == 0 && ldD >= R &&
                   (ldD % 4) == 0 && (reinterpret_cast<uintptr_t>(Dm) % 16) == 0,
               "%s: bad size (R %% 32 == 0, D %% 128 == 0, ldD %% 4 == 0, 16-byte aligned output)", name);
+  QPG_REQUIRE(!tile_min || ldT >= R / 16, "%s: tile_min needs ldT >= R / 16", name);
   const int chunks = (Q + HL_GQC - 1) / HL_GQC, KB = D / 32;
   HlArgs a;
   const unsigned char* ri = static_cast<const unsigned char*>(rows_image);
@@ -781,7 +790,7 @@ extern "C" int qpg_hl_gemm_distance(qpg_ctx* ctx, void* stream, const void* rows
   a.qi = reinterpret_cast<const _Float16*>(ci);
   a.qexp = reinterpret_cast<const int32_t*>(ci + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
   a.cn2 = nullptr; a.qn2 = nullptr; a.D = Dm; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = nullptr;
-  a.N = (int)(R / 32); a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1;
+  a.N = (int)(R / 32); a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1; a.tmin = tile_min; a.ldT = ldT;
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
   hipLaunchKernelGGL(audio_cosine_hl_kernel<1>, dim3((a.N + HL_WPB - 1) / HL_WPB, chunks), dim3(HL_THREADS), lds_bytes,
                      qpg_stream(stream), a);

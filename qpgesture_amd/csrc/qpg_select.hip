@@ -329,7 +329,7 @@ __global__ __launch_bounds__(1024) void percode_select_kernel(const T* __restric
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
   unsigned int* besti = reinterpret_cast<unsigned int*>(smem + 8 * (size_t)K);
-  T* v = reinterpret_cast<T*>(smem + 12 * (size_t)K);
+  T* v = reinterpret_cast<T*>(smem + 12 * (size_t)rank_sort_pow2(K));   // (the key tables double as the rank sort's scratch)
   constexpr int VEC = 16 / sizeof(T);                      // elements per 16-byte load
   typedef T vecT __attribute__((ext_vector_type(VEC)));
   typedef int16_t vecC __attribute__((ext_vector_type(VEC)));
@@ -404,15 +404,9 @@ __global__ __launch_bounds__(1024) void percode_select_kernel(const T* __restric
   }
   if (!out_rank) return;
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const T x = v[k];
-    int r = 0;
-    for (int o = 0; o < K; ++o) {
-      const T y = v[o];
-      r += (y < x) || (y == x && o < k);
-    }
-    out_rank[(int64_t)q * K + k] = (int16_t)r;
-  }
+  const int Kp = rank_sort_pow2(K);
+  block_sorted_ranks(v, K, best, reinterpret_cast<int*>(best + Kp),
+                     [&](int k, int r) { out_rank[(int64_t)q * K + k] = (int16_t)r; });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,7 +531,7 @@ __device__ __forceinline__ double refine_pair_f64(const GuardArgs& A, int q, int
 __global__ __launch_bounds__(1024) void percode_select_guarded_f64_kernel(
     const double* __restrict__ D, int64_t ldD, const int16_t* __restrict__ cand_code, int64_t C, int K, double absent,
     int32_t idx_base, double* __restrict__ out_dist, int32_t* __restrict__ out_idx, int16_t* __restrict__ out_rank,
-    int q_block, int64_t block_stride, GuardArgs A) {
+    int q_block, int64_t block_stride, GuardArgs A, int sort_ranks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
   unsigned int* besti = reinterpret_cast<unsigned int*>(smem + 8 * (size_t)K);
@@ -651,11 +645,15 @@ __global__ __launch_bounds__(1024) void percode_select_guarded_f64_kernel(
   if (!out_rank) return;
   int* s_code = reinterpret_cast<int*>(best);                 // the key table is no longer needed: [K] code at rank r
   int* rcnt = s_code + K;                                     // second half of the key table: rank counters
+  // (sorted when the launch left room for the sort's scratch behind the lists - K <= 1024 -, counted otherwise)
+  unsigned long long* skey = reinterpret_cast<unsigned long long*>(ctl + 4);
   auto rank_pass = [&]() {
-    block_stable_ranks(v, K, rcnt, [&](int k, int r) {
+    auto emit = [&](int k, int r) {
       out_rank[(int64_t)q * K + k] = (int16_t)r;
       s_code[r] = k;
-    });
+    };
+    if (sort_ranks) block_sorted_ranks(v, K, skey, reinterpret_cast<int*>(skey + rank_sort_pow2(K)), emit);
+    else block_stable_ranks(v, K, rcnt, emit);
   };
   rank_pass();
   __syncthreads();
@@ -713,9 +711,11 @@ extern "C" int qpg_percode_select_guarded_f64(qpg_ctx* ctx, void* stream, const 
   GuardArgs A;
   A.base = base; A.half = base_is_f16; A.q32 = q32; A.cand_t = cand_t; A.T = T; A.F = F; A.G = G; A.n_taps = n_taps;
   A.tap_stride = tap_stride; A.eps = eps; A.stats = stats;
-  const size_t sh = 24 * (size_t)K + GUARD_LIST * 16 + 16;
+  size_t sh = 24 * (size_t)K + GUARD_LIST * 16 + 16;
+  const int sort_ranks = sh + 12 * (size_t)rank_sort_pow2(K) <= 64 * 1024;          // room for the rank sort's scratch
+  if (sort_ranks) sh += 12 * (size_t)rank_sort_pow2(K);
   hipLaunchKernelGGL(percode_select_guarded_f64_kernel, dim3(Q), dim3(1024), sh, qpg_stream(stream), D, ldD, cand_code,
-                     C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block, block_stride, A);
+                     C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block, block_stride, A, sort_ranks);
   QPG_LAUNCH_CHECK("percode_select_guarded_f64_kernel");
   return QPG_OK;
 }
@@ -826,6 +826,25 @@ __global__ __launch_bounds__(256) void select_refine_kernel(GuardArgs A, int K, 
   }
 }
 
+// -DQPG_SELECT_PROF (experiments/select_prof): block 0 stamps the 100 MHz wall clock at the section boundaries of the
+// mixed select; qpg_debug_select_prof copies the stamps out.  Not in the product build.
+#ifdef QPG_SELECT_PROF
+__device__ long long qpg_select_prof_buf[6][16];      // [phase]: wall clock; [3 + phase]: shader clock (s_memtime)
+#define SEL_STAMP(i)                                                                          \
+  do {                                                                                        \
+    __syncthreads();                                                                          \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                                \
+      qpg_select_prof_buf[phase][i] = wall_clock64();                                         \
+      qpg_select_prof_buf[3 + phase][i] = clock64();                                          \
+    }                                                                                         \
+  } while (0)
+extern "C" int qpg_debug_select_prof(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(qpg_select_prof_buf), sizeof(long long) * 96) == hipSuccess ? 0 : -1;
+}
+#else
+#define SEL_STAMP(i)
+#endif
+
 template <typename DT>
 __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     const DT* __restrict__ D, int64_t ldD, const int16_t* __restrict__ cand_code, int64_t C, int K, double absent,
@@ -872,44 +891,16 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   }
   if (tid < 8) ctl[tid] = 0;
   __syncthreads();
+  SEL_STAMP(0);
   // rank of every code in the value table v (stable: value, then code); s_code[r] = code at rank r
-  // (the K x K count is VALU-bound, ~35 cycles per comparison step per wave: P = blockDim / K threads share a code)
+  // (sorted, not counted: block_sorted_ranks; its scratch aliases p_c / p_k, which are dead once list (a) is built)
+  unsigned long long* skey = reinterpret_cast<unsigned long long*>(p_c);      // [512] (K <= 512: 6 KB of p_c | p_k's 12)
+  int* scode = reinterpret_cast<int*>(skey + 512);
   auto rank_pass = [&](bool store) {
-    const int P = (int)blockDim.x >= 2 * K ? (int)blockDim.x / K : 1;
-    if (P == 1) {
-      for (int k = tid; k < K; k += blockDim.x) {
-        const double x = v[k];
-        int r = 0;
-#pragma unroll 8
-        for (int o = 0; o < K; ++o) {
-          const double y = v[o];
-          r += (y < x) || (y == x && o < k);
-        }
-        if (store && out_rank) out_rank[(int64_t)q * K + k] = (int16_t)r;
-        s_code[r] = k;
-      }
-      return;
-    }
-    for (int k = tid; k < K; k += blockDim.x) rk[k] = 0;
-    __syncthreads();
-    if (tid < P * K) {
-      const int k = tid % K, part = tid / K;
-      const int o0 = (int)((int64_t)part * K / P), o1 = (int)((int64_t)(part + 1) * K / P);
-      const double x = v[k];
-      int r = 0;
-#pragma unroll 8
-      for (int o = o0; o < o1; ++o) {
-        const double y = v[o];
-        r += (y < x) || (y == x && o < k);
-      }
-      atomicAdd(&rk[k], r);
-    }
-    __syncthreads();
-    for (int k = tid; k < K; k += blockDim.x) {
-      const int r = rk[k];
+    block_sorted_ranks(v, K, skey, scode, [&](int k, int r) {
       if (store && out_rank) out_rank[(int64_t)q * K + k] = (int16_t)r;
       s_code[r] = k;
-    }
+    });
   };
   int n = 0;
   if (phase != 2) {
@@ -924,11 +915,32 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   // - the successive minima of a code (~ln(n) of its n candidates in random order) and what lies within eps1 of them -
   // are remembered, and "pass 2" below visits that list instead of streaming the row a second time.  A list that
   // overflows (adversarially ordered or crowded rows) falls back to the second pass over the row.
-  auto pass1 = [&](int64_t c, double d, int cd) {
+  // (the table is READ first and the atomic issued only for a new minimum - a code's i-th candidate is one with
+  // probability 1/i; a stale read is never below the true running minimum, so the test below only gets more inclusive.
+  // The block's LDS pipe is what bounds this pass: 53 248 gathers into the key table.  With an f32 matrix the pass keeps
+  // 4-byte keys in `s_code` (free until the ranks) - half the LDS words per gather - and widens them afterwards.)
+  constexpr bool K32 = sizeof(DT) == 4;
+  unsigned int* best32 = reinterpret_cast<unsigned int*>(s_code);
+  if (K32) {
+    for (int k = tid; k < K; k += blockDim.x) best32[k] = 0xffffffffu;
+    __syncthreads();
+  }
+  auto pass1 = [&](int64_t c, DT dv, int cd) {
     if ((unsigned)cd >= (unsigned)K) return;
-    const unsigned long long key = (unsigned long long)order_key(d);
-    const unsigned long long old = atomicMin(&best[cd], key);
-    if (d <= key_value(old < key ? old : key, 0.0) + eps1) {
+    const double d = (double)dv;
+    double lo;
+    if constexpr (K32) {
+      const unsigned int key = order_key((float)dv);
+      unsigned int old = *reinterpret_cast<volatile unsigned int*>(&best32[cd]);
+      if (key < old) old = atomicMin(&best32[cd], key);
+      lo = (double)key_value(old < key ? old : key, 0.f);
+    } else {
+      const unsigned long long key = (unsigned long long)order_key(d);
+      unsigned long long old = *reinterpret_cast<volatile unsigned long long*>(&best[cd]);
+      if (key < old) old = atomicMin(&best[cd], key);
+      lo = key_value(old < key ? old : key, 0.0);
+    }
+    if (d <= lo + eps1) {
       const int pp = atomicAdd(&ctl[4], 1);
       if (pp < MIX_POT) {
         pot_c[pp] = (int)c;
@@ -941,10 +953,18 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     const vecD d = *reinterpret_cast<const vecD*>(row + c);
     const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
 #pragma unroll
-    for (int e = 0; e < VE; ++e) pass1(c + e, (double)d[e], cd[e]);
+    for (int e = 0; e < VE; ++e) pass1(c + e, d[e], cd[e]);
   }
-  for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass1(c, (double)row[c], cand_code[c]);
+  for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass1(c, row[c], cand_code[c]);
   __syncthreads();
+  if (K32) {
+    for (int k = tid; k < K; k += blockDim.x) {
+      const unsigned int b = best32[k];
+      best[k] = b == 0xffffffffu ? ~0ull : (unsigned long long)order_key((double)key_value(b, 0.f));
+    }
+    __syncthreads();
+  }
+  SEL_STAMP(1);
   auto pass2 = [&](int64_t c, double d, int cd) {
     if ((unsigned)cd >= (unsigned)K) return;
     const unsigned long long bk = best[cd];
@@ -971,6 +991,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass2(c, (double)row[c], cand_code[c]);
   }
   __syncthreads();
+  SEL_STAMP(2);
   // ---- list (a): every member of a band with two or more members — from the members pass 2 remembered, or, if there
   // were more than it could hold, by a third pass over the row
   if (ctl[1] && ctl[3] <= MIX_LIST) {
@@ -999,28 +1020,35 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   }
   for (int k = tid; k < K; k += blockDim.x) v[k] = besti[k] != 0xffffffffu ? key_value(best[k], 0.0) : absent;
   __syncthreads();
-  // ---- list (b): winners of codes whose minima are rank neighbours within eps1 (only needed when ranks are wanted:
-  // without them the minima of different codes are never compared here)
+  SEL_STAMP(3);
+  // ---- list (b): winners of codes whose minima lie within eps1 of ANOTHER code's (only needed when ranks are wanted:
+  // without them the minima of different codes are never compared here).  Two values that close are rank neighbours, but
+  // finding them does not need the ranks (a sort: 14 us here): every present code drops its value into a grid of cells
+  // a little wider than eps1 (hashed into 2048 LDS counters); a code with company in its own or an adjacent cell is
+  // listed.  Hash collisions and cell-mates further than eps1 apart only list a code that did not need it (it then gets an
+  // f64 value like any other listed code).
   if (out_rank) {
-    rank_pass(false);
+    unsigned int* cell = reinterpret_cast<unsigned int*>(p_c);          // [2048] (p_c / p_k are dead: list (a) is built)
+    const double inv_w = 1.0 / (eps1 * 1.000001);
+    auto slot = [](long long b) { return (unsigned int)(((unsigned long long)b * 0x9E3779B97F4A7C15ull) >> 53); };
+    for (int i = tid; i < 2048; i += blockDim.x) cell[i] = 0;
     __syncthreads();
-    for (int r = tid; r + 1 < K; r += blockDim.x) {
-      const int ka = s_code[r], kb = s_code[r + 1];
-      if (besti[ka] == 0xffffffffu || besti[kb] == 0xffffffffu) continue;
-      if (v[kb] - v[ka] < eps1) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int k = h ? kb : ka;
-          if (atomicMax(&near_[k], 2u) >= 2u) continue;                  // band-listed, or listed once already
-          const int pos = atomicAdd(&ctl[0], 1);
-          if (pos < MIX_LIST) {
-            l_c[pos] = (int)(besti[k] - (unsigned int)idx_base);
-            l_k[pos] = k;
-          }
-        }
+    for (int k = tid; k < K; k += blockDim.x)
+      if (besti[k] != 0xffffffffu) atomicAdd(&cell[slot((long long)floor(v[k] * inv_w))], 1u);
+    __syncthreads();
+    for (int k = tid; k < K; k += blockDim.x) {
+      if (besti[k] == 0xffffffffu) continue;
+      const long long b = (long long)floor(v[k] * inv_w);
+      if (cell[slot(b - 1)] + cell[slot(b)] + cell[slot(b + 1)] < 2u) continue;
+      if (atomicMax(&near_[k], 2u) >= 2u) continue;                    // band-listed already
+      const int pos = atomicAdd(&ctl[0], 1);
+      if (pos < MIX_LIST) {
+        l_c[pos] = (int)(besti[k] - (unsigned int)idx_base);
+        l_k[pos] = k;
       }
     }
     __syncthreads();
+    SEL_STAMP(4);
   }
   n = ctl[0];
   if (n > MIX_LIST) {
@@ -1028,6 +1056,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     if (tid == 0) atomicOr(&A.stats[1], 1);
   }
   }   // phase != 2
+  SEL_STAMP(5);
   if (phase == 1) {            // park: [best u64 K][v f64 K][besti u32 K][near u32 K][n, pad][l_c i32 L][l_k i32 L][l_d f64 L]
     unsigned long long* w_best = reinterpret_cast<unsigned long long*>(wq);
     double* w_v = reinterpret_cast<double*>(wq + 8 * (size_t)K);
@@ -1047,6 +1076,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       w_lk[e] = l_k[e];
     }
     if (tid == 0) w_n[0] = n;
+    SEL_STAMP(6);
     return;
   }
   if (phase == 2) {
@@ -1072,6 +1102,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     }
     __syncthreads();
   }
+  SEL_STAMP(7);
   if (n > 0) {
     // ---- tier 1: f64 dot products, one wave per listed pair (phase 2: already done by select_refine_kernel)
     const double qq = qn2[q];
@@ -1154,10 +1185,12 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     out_dist[(int64_t)q * K + k] = v[k];
     out_idx[(int64_t)q * K + k] = have ? (int32_t)besti[k] : -1;
   }
+  SEL_STAMP(8);
   if (!out_rank) return;
   if (tid == 0) ctl[2] = 0;
   __syncthreads();
   rank_pass(true);
+  SEL_STAMP(9);
   if (A.eps <= 0.0) return;
   __syncthreads();
   // ---- tier 2 (rank level): refined minima of different codes within eps2 -> reference arithmetic for their winners
@@ -1178,6 +1211,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   }
   __syncthreads();
   int n3 = ctl[2];
+  SEL_STAMP(10);
   if (n3 == 0) return;
   if (n3 > MIX_LIST2) {
     n3 = MIX_LIST2;
@@ -1194,7 +1228,9 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   }
   if (tid == 0) atomicAdd(&A.stats[0], n3);
   __syncthreads();
+  SEL_STAMP(11);
   rank_pass(true);
+  SEL_STAMP(12);
 }
 
 extern "C" int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K) {
@@ -1272,7 +1308,7 @@ static int percode_select(const char* name, qpg_ctx* ctx, void* stream, const T*
   QPG_REQUIRE(q_block >= 0 && (q_block == 0 || (!out_rank && Q % q_block == 0 && block_stride % 8 == 0)),
               "%s: block layout needs Q %% q_block == 0, an 8-byte multiple stride and no rank output", name);
   if (Q == 0) return QPG_OK;
-  const size_t sh = (size_t)K * (12 + sizeof(T));
+  const size_t sh = 12 * (size_t)rank_sort_pow2(K) + (size_t)K * sizeof(T);
   hipLaunchKernelGGL((percode_select_kernel<T, KeyT, PACKED>), dim3(Q), dim3(1024), sh, qpg_stream(stream), D, ldD,
                      cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank, q_block, block_stride);
   QPG_LAUNCH_CHECK(name);
@@ -1936,28 +1972,28 @@ extern "C" int qpg_merge_mixed_phase2_f64(qpg_ctx* ctx, void* stream, const void
 template <typename T>
 __global__ __launch_bounds__(1024) void rank_rows_kernel(const T* __restrict__ d, int K, int16_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* v = reinterpret_cast<T*>(smem);
+  unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem);
+  int* scode = reinterpret_cast<int*>(skey + rank_sort_pow2(K));
+  T* v = reinterpret_cast<T*>(scode + rank_sort_pow2(K));
   const int q = blockIdx.x;
   for (int k = threadIdx.x; k < K; k += blockDim.x) v[k] = d[(int64_t)q * K + k];
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const T x = v[k];
-    int r = 0;
-    for (int o = 0; o < K; ++o) {
-      const T y = v[o];
-      r += (y < x) || (y == x && o < k);
-    }
-    out[(int64_t)q * K + k] = (int16_t)r;
-  }
+  block_sorted_ranks(v, K, skey, scode, [&](int k, int r) { out[(int64_t)q * K + k] = (int16_t)r; });
 }
 
 template <typename T>
 static int rank_rows(const char* name, qpg_ctx* ctx, void* stream, const T* d, int Q, int K, int16_t* out) {
-  QPG_REQUIRE(ctx && d && out && Q >= 0 && K > 0 && K <= 8192, "%s: bad argument", name);
+  QPG_REQUIRE(ctx && d && out && Q >= 0 && K > 0 && K <= 4096, "%s: bad argument (K <= 4096)", name);
   if (Q == 0) return QPG_OK;
-  int threads = K >= 1024 ? 1024 : ((K + 63) / 64) * 64;
-  hipLaunchKernelGGL((rank_rows_kernel<T>), dim3(Q), dim3(threads), sizeof(T) * (size_t)K, qpg_stream(stream), d, K,
-                     out);
+  const size_t sh = 12 * (size_t)rank_sort_pow2(K) + sizeof(T) * (size_t)K;        // K <= 4096: 80 KB at most
+  if (sh > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(rank_rows_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sh) != hipSuccess) {
+    qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
+    return QPG_EHIP;
+  }
+  const int threads = rank_sort_pow2(K) >= 2048 ? 1024 : (rank_sort_pow2(K) >= 128 ? rank_sort_pow2(K) / 2 : 64);
+  hipLaunchKernelGGL((rank_rows_kernel<T>), dim3(Q), dim3(threads), sh, qpg_stream(stream), d, K, out);
   QPG_LAUNCH_CHECK(name);
   return QPG_OK;
 }

@@ -7,16 +7,25 @@
 // comparisons: a prefilter whose error against the sklearn value is bounded a priori leaves, per (query, code), a BAND of
 // candidates that can be the minimum; only those are evaluated in the exact order.
 //   prefilter  qpg_hl_gemm_distance (qpg_audio_hl.hip): d~ = 1 - <x^, q^> on the f16 matrix cores (split operands,
-//              f64 block sums), rows SORTED BY CODE (stable: original order inside a code) and padded to 16 per code;
+//              f64 block sums), rows SORTED BY CODE (stable: original order inside a code) and padded to 16 per code with
+//              copies of the segment's first row; its epilogue also leaves the minimum of every 16-row tile;
 //   bound      |d~ - d_sklearn| <= E = E_pre + E_sk:  E_pre = 1.3e-6 (the GEMM, unit-norm operands) + 2 eps1 (x^, q^ are
 //              the f32-normalised rows, off the true unit vectors by eps1 = ((D/4 + 2)/2 + 2) u each);
 //              E_sk = 0.5 [ 8 eps1 + 4 (D/4 + 3) u ]  (sklearn's own f32 rounding against the real-number value:
 //              normalisation errors through the difference, Cauchy-Schwarz with |delta| <= 2, then the 4-lane chains of
 //              D/4 squares) - 4.3e-5 at D = 512; `band` = 2.1 E is passed by the caller;
-//   select     one block per query: (1) per-code minimum of d~ over the sorted row (segmented minimum over each wave:
-//              runs of a code are contiguous), (2) rows within `band` of their code's minimum are listed, (3) the listed
-//              (query, row) pairs are evaluated in sklearn's exact order from the f32 rows, (4) per code the minimum exact
-//              distance and, among equals, the lowest ORIGINAL index (first-wins); tables and nearest neighbours.
+//   select     SORT_SPLIT blocks per query, a range of codes (= of tiles) each: (1) per-code minimum of d~ from the tile minima,
+//              (2) tiles whose minimum is within `band` of their code's minimum are opened and their rows within the band listed, (3) the listed (query, row) pairs
+//              are evaluated in sklearn's exact order from the f32 rows, (4) per code the minimum exact distance and,
+//              among equals, the lowest ORIGINAL index (first-wins); tables, nearest neighbours, optionally ranks.
+//              (Round 3's first version was one block per query streaming the whole row twice: 0.43 ms of cfg-3's 0.94,
+//              71 us of the matcher's text side; the tile minima cut the reads from 2 R to R / 16 + the opened tiles.)
+// A row sklearn's normalisation leaves at (or near) zero - an all-zero embedding: its norm is replaced by 1 - is not a unit
+// vector: its distance to a unit query is 0.5 |q^|^2, not 1 - <x^, q^>.  All such rows of a code are at the SAME exact
+// distance from a query, so only the one with the lowest original index can win: the builder keeps that one per code
+// (zero_row[K]) OUTSIDE the GEMM's rows, and the select enters it with the prefilter value 0.5 (a zero QUERY shifts every
+// value by the same -0.5: order and bands are kept, and since all rows then tie inside the band the list overflows and
+// the exact sweep answers).
 // The tables are bit-identical to qpg_text_percode_f32's.  A list that overflows raises stats[1] |= 1 (the host then
 // runs the exact VALU sweep): real text embeddings repeat (silence), and thousands of exact ties in one code are then
 // all inside the band.
@@ -30,91 +39,85 @@ __device__ __forceinline__ float okey32_value(unsigned int k) {
   return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k);
 }
 
-#define SORT_LIST 8192
+#define SORT_SPLIT 8       // sub-blocks per query: rows are sorted by code, so a range of codes is a range of tiles and
+                           // its tables need nothing from the other ranges
+#define SORT_LIST 2048     // band members a sub-block can hold (x SORT_SPLIT per query)
+#define SORT_TILES 1024    // opened tiles a sub-block can hold
+#define SORT_THREADS 256
 
-__global__ __launch_bounds__(1024, 8) void percode_select_sorted_kernel(
-    const float* __restrict__ Dm, int64_t ldD, int64_t R, const int16_t* __restrict__ row_code,
-    const int32_t* __restrict__ row_index, int K, float band, const float* __restrict__ qn, const float* __restrict__ xs,
-    int Dd, float absent, float* __restrict__ out_dist, int32_t* __restrict__ out_idx, int32_t* __restrict__ out_nn,
-    int32_t* __restrict__ stats) {
+// Block (q, s): query q, codes [s K / S, (s + 1) K / S).  The GEMM's epilogue left the minimum of every 16-row TILE (a tile
+// lies inside one code's segment: segments are padded to 16 rows with copies of their first row, so a padding row never
+// lowers a minimum), so the block reads its share of the R / 16 tile minima instead of the R distances: (1) per-code
+// minimum over the tiles (+ 0.5 for a code that holds an all-zero row), (2) tiles whose minimum lies inside the code's band
+// are opened (16 lanes per tile) and their rows within the band listed, (3) exact sklearn-order distances of the listed
+// pairs, (4) tables.
+__global__ __launch_bounds__(SORT_THREADS) void percode_select_sorted_kernel(
+    const float* __restrict__ Dm, int64_t ldD, const float* __restrict__ tmin, int64_t ldT, int64_t R,
+    const int16_t* __restrict__ row_code, const int32_t* __restrict__ row_index, const int32_t* __restrict__ zero_row,
+    const int32_t* __restrict__ code_tile, int K, float band, const float* __restrict__ qn, const float* __restrict__ xs,
+    int Dd, float absent, float* __restrict__ out_dist, int32_t* __restrict__ out_idx, int32_t* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);            // [K] approx key << 32 | row
-  unsigned long long* ebest = best + K;                                               // [K] exact key << 32 | original index
-  int* list = reinterpret_cast<int*>(ebest + K);                                      // [SORT_LIST] rows in a band
-  float* qrow = reinterpret_cast<float*>(list + SORT_LIST);                           // [Dd]
-  __shared__ int n_list;
-  __shared__ unsigned long long nn_key;
-  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int S = gridDim.y, s = blockIdx.y;
+  const int k0 = (int)((int64_t)s * K / S), k1 = (int)((int64_t)(s + 1) * K / S), KL = k1 - k0;
+  const int KLmax = ((K + S - 1) / S + 4) & ~3;          // (multiple of 4: keeps qrow 16-byte aligned)
+  unsigned long long* ebest = reinterpret_cast<unsigned long long*>(smem);            // [KL] exact key << 32 | original index
+  unsigned int* best = reinterpret_cast<unsigned int*>(ebest + KLmax);                // [KL] order key of the prefilter minimum
+  int* list = reinterpret_cast<int*>(best + KLmax);                                   // [SORT_LIST] rows in a band
+  int* tl = list + SORT_LIST;                                                         // [SORT_TILES] opened tiles
+  float* qrow = reinterpret_cast<float*>(tl + SORT_TILES);                            // [Dd]
+  __shared__ int n_list, n_tiles;
+  const int q = blockIdx.x, tid = threadIdx.x;
   const float* row = Dm + (int64_t)q * ldD;
-  for (int k = tid; k < K; k += blockDim.x) {
-    best[k] = ~0ull;
+  const float* trow = tmin + (int64_t)q * ldT;
+  const int t0 = code_tile[k0], t1 = code_tile[k1];            // this range's tiles
+  for (int k = tid; k < KL; k += blockDim.x) {
     ebest[k] = ~0ull;
+    best[k] = (zero_row && zero_row[k0 + k] >= 0) ? okey32(0.5f) : 0xffffffffu;
   }
   for (int i = tid; i < Dd / 4; i += blockDim.x)
     reinterpret_cast<f32x4*>(qrow)[i] = reinterpret_cast<const f32x4*>(qn + (int64_t)q * Dd)[i];
   if (tid == 0) {
     n_list = 0;
-    nn_key = ~0ull;
+    n_tiles = 0;
   }
   __syncthreads();
-  // (1) per-code minimum of the prefilter values.  Rows are sorted by code in segments padded to 16 rows (a padding row
-  // carries its segment's code with bit 14 set): a lane's 4 consecutive rows are ONE code, runs of a code are contiguous
-  // across lanes.  Segmented minimum over the wave (6 shuffle steps), then one LDS atomic per run: a sorted row would
-  // otherwise send all 64 lanes of an instruction to the same LDS word.
-  typedef int16_t c16x4 __attribute__((ext_vector_type(4)));
-  const int wv = tid >> 6, nwv = blockDim.x >> 6;
-  constexpr int UN = 4;                                           // 256-row pieces in flight per wave (latency: the
-  for (int64_t base0 = (int64_t)wv * 256 * UN; base0 < R; base0 += (int64_t)nwv * 256 * UN) {     // row comes from HBM)
-    f32x4 dv[UN];
-    c16x4 cv[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int64_t r0 = base0 + u * 256 + lane * 4;
-      dv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      cv[u] = (c16x4){-1, -1, -1, -1};
-      if (r0 < R) {
-        dv[u] = *reinterpret_cast<const f32x4*>(row + r0);
-        cv[u] = *reinterpret_cast<const c16x4*>(row_code + r0);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int64_t r0 = base0 + u * 256 + lane * 4;
-      int code = -1 - lane;                                       // (out of range: a run of its own)
-      unsigned long long m = ~0ull;
-      if (r0 < R) {
-        code = cv[u][0] & 0x3fff;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const unsigned long long k = ((unsigned long long)okey32(dv[u][e]) << 32) | (unsigned int)(r0 + e);
-          if (!(cv[u][e] & 0x4000) && k < m) m = k;
-        }
-      }
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long om = __shfl_down(m, off, 64);
-        const int oc = __shfl_down(code, off, 64);
-        if (lane + off < 64 && oc == code && om < m) m = om;
-      }
-      const int pc = __shfl_up(code, 1, 64);
-      if ((lane == 0 || pc != code) && m != ~0ull && (unsigned)code < (unsigned)K) atomicMin(&best[code], m);
-    }
+  // (1) per-code minimum of the prefilter values, from the tile minima
+  for (int t = t0 + tid; t < t1; t += blockDim.x) {
+    const int code = (row_code[(int64_t)t * 16] & 0x1fff) - k0;
+    if ((unsigned)code < (unsigned)KL) atomicMin(&best[code], okey32(trow[t]));
   }
   __syncthreads();
-  // (2) the band of every code   (band < 0: timing diagnostics - nothing is listed, the tables come out empty)
-  if (band >= 0.f)
-#pragma unroll 4
-  for (int64_t r0 = (int64_t)tid * 4; r0 < R; r0 += (int64_t)blockDim.x * 4) {
-    const f32x4 d = *reinterpret_cast<const f32x4*>(row + r0);
-    const c16x4 cd = *reinterpret_cast<const c16x4*>(row_code + r0);
-    const int code = cd[0] & 0x3fff;
-    if ((unsigned)code >= (unsigned)K) continue;
-    const float lim = okey32_value((unsigned int)(best[code] >> 32)) + band;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if ((cd[e] & 0x4000) || !(d[e] <= lim)) continue;
-      const int pos = atomicAdd(&n_list, 1);
-      if (pos < SORT_LIST) list[pos] = (int)(r0 + e);
+  if (band >= 0.f) {           // (band < 0: timing diagnostics - nothing is listed, the tables come out empty)
+    // (2a) tiles whose minimum is inside their code's band
+    for (int t = t0 + tid; t < t1; t += blockDim.x) {
+      const int code = (row_code[(int64_t)t * 16] & 0x1fff) - k0;
+      if ((unsigned)code >= (unsigned)KL) continue;
+      if (trow[t] <= okey32_value(best[code]) + band) {
+        const int pos = atomicAdd(&n_tiles, 1);
+        if (pos < SORT_TILES) tl[pos] = t;
+      }
+    }
+    for (int k = tid; k < KL; k += blockDim.x)
+      if (zero_row && zero_row[k0 + k] >= 0 && 0.5f <= okey32_value(best[k]) + band) {
+        const int pos = atomicAdd(&n_list, 1);
+        if (pos < SORT_LIST) list[pos] = (int)R + k0 + k;            // the code's all-zero row: xs row R is zeros
+      }
+    __syncthreads();
+    int nt = n_tiles;
+    if (nt > SORT_TILES) {
+      nt = SORT_TILES;
+      if (tid == 0 && stats) atomicOr(&stats[1], 1);
+    }
+    // (2b) their rows: 16 lanes per opened tile
+    for (int i = tid >> 4; i < nt; i += blockDim.x >> 4) {
+      const int64_t r = (int64_t)tl[i] * 16 + (tid & 15);
+      const int cd = row_code[r];
+      const float d = row[r];
+      if (cd & 0x4000) continue;
+      if (d <= okey32_value(best[(cd & 0x1fff) - k0]) + band) {
+        const int pos = atomicAdd(&n_list, 1);
+        if (pos < SORT_LIST) list[pos] = (int)r;
+      }
     }
   }
   __syncthreads();
@@ -125,20 +128,21 @@ __global__ __launch_bounds__(1024, 8) void percode_select_sorted_kernel(
   }
   // (3) exact sklearn-order distance of every listed (query, row) pair: 0.5 * einsum_sq(qn - xn), four lane chains,
   // 16-element groups visited u = 3,2,1,0, separate multiply and add, (l0 + l1) + (l2 + l3).  One thread per pair, the
-  // query row in LDS, the candidate row gathered (8 loads in flight per thread).  Measured alternatives: evaluating per
-  // CODE instead (buckets of (query, row) pairs, one block per code, the rows of a code read once for all queries) is
-  // SLOWER - 465 us against ~200: every lane then gathers BOTH operands in 16-byte pieces of 128-byte lines.
+  // query row in LDS, the candidate row gathered (16 loads in flight per thread: the gather is latency-bound).  Measured
+  // alternative: evaluating per CODE instead (buckets of (query, row) pairs, one block per code, the rows of a code read
+  // once for all queries) is SLOWER - 465 us against ~200: every lane then gathers BOTH operands in 16-byte pieces.
   for (int e = tid; e < n; e += blockDim.x) {
     const int r = list[e];
-    const f32x4* xp = reinterpret_cast<const f32x4*>(xs + (int64_t)r * Dd);
+    const bool z = r >= (int)R;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(xs + (int64_t)(z ? (int)R : r) * Dd);
     const f32x4* qp = reinterpret_cast<const f32x4*>(qrow);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int g0 = 0; g0 < Dd / 16; g0 += 2) {
-      f32x4 xv[8];
+    for (int g0 = 0; g0 < Dd / 16; g0 += 4) {
+      f32x4 xv[16];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) xv[i] = (g0 * 4 + i) < Dd / 4 ? xp[g0 * 4 + i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 16; ++i) xv[i] = (g0 * 4 + i) < Dd / 4 ? xp[g0 * 4 + i] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
+      for (int gg = 0; gg < 4; ++gg) {
         if (g0 + gg >= Dd / 16) break;
 #pragma unroll
         for (int u = 3; u >= 0; --u) {
@@ -152,19 +156,45 @@ __global__ __launch_bounds__(1024, 8) void percode_select_sorted_kernel(
       }
     }
     const float dist = f_mul(0.5f, f_add(f_add(a0, a1), f_add(a2, a3)));
-    const int cd = row_code[r] & 0x3fff;
-    atomicMin(&ebest[cd], ((unsigned long long)okey32(dist) << 32) | (unsigned int)row_index[r]);
+    const int cd = z ? r - (int)R : (row_code[r] & 0x1fff);
+    const int oi = z ? zero_row[cd] : row_index[r];
+    atomicMin(&ebest[cd - k0], ((unsigned long long)okey32(dist) << 32) | (unsigned int)oi);
   }
   __syncthreads();
-  // (4) tables + the query's global nearest neighbour
-  unsigned long long mine = ~0ull;
-  for (int k = tid; k < K; k += blockDim.x) {
+  // (4) this range's part of the tables
+  for (int k = tid; k < KL; k += blockDim.x) {
     const unsigned long long kv = ebest[k];
     const bool have = kv != ~0ull;
-    out_dist[(int64_t)q * K + k] = have ? okey32_value((unsigned int)(kv >> 32)) : absent;
-    out_idx[(int64_t)q * K + k] = have ? (int32_t)(kv & 0xffffffffu) : -1;
-    if (have && kv < mine) mine = kv;
+    out_dist[(int64_t)q * K + k0 + k] = have ? okey32_value((unsigned int)(kv >> 32)) : absent;
+    out_idx[(int64_t)q * K + k0 + k] = have ? (int32_t)(kv & 0xffffffffu) : -1;
   }
+}
+
+// (5) ranks of the finished rows (stable: value, then code - qpg_rank_rows_f32's) and the nearest neighbours: its own small
+// launch.  (Letting the LAST sub-block of a query do it needs a device-scope release fence in every block; on this part
+// that writes back the XCD's whole L2 - the freshly written distance matrix included: measured 1.55 ms instead of 0.43
+// for the cfg-3 batch.)
+__global__ __launch_bounds__(256) void sorted_finish_kernel(const float* __restrict__ dist, const int32_t* __restrict__ idx,
+                                                             int K, int16_t* __restrict__ out_rank,
+                                                             int32_t* __restrict__ out_nn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem);     // [Kp] sort scratch
+  int* scode = reinterpret_cast<int*>(skey + rank_sort_pow2(K));              // [Kp]
+  float* v = reinterpret_cast<float*>(scode + rank_sort_pow2(K));             // [K]
+  __shared__ unsigned long long nn_key;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) nn_key = ~0ull;
+  unsigned long long mine = ~0ull;
+  for (int k = tid; k < K; k += blockDim.x) {
+    const float dv = dist[(int64_t)q * K + k];
+    const int iv = idx[(int64_t)q * K + k];
+    v[k] = dv;
+    if (iv >= 0) {
+      const unsigned long long kv = ((unsigned long long)okey32(dv) << 32) | (unsigned int)iv;
+      if (kv < mine) mine = kv;
+    }
+  }
+  __syncthreads();
   if (out_nn) {
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned long long other = __shfl_xor(mine, o, 64);
@@ -174,24 +204,35 @@ __global__ __launch_bounds__(1024, 8) void percode_select_sorted_kernel(
     __syncthreads();
     if (tid == 0) out_nn[q] = nn_key != ~0ull ? (int32_t)(nn_key & 0xffffffffu) : -1;
   }
+  if (!out_rank) return;
+  block_sorted_ranks(v, K, skey, scode, [&](int k, int r) { out_rank[(int64_t)q * K + k] = (int16_t)r; });
 }
 
-extern "C" int qpg_percode_select_sorted_f32(qpg_ctx* ctx, void* stream, const float* Dm, int64_t ldD, int Q, int64_t R,
-                                             const int16_t* row_code, const int32_t* row_index, int K, float band,
-                                             const float* qn, const float* xs, int Dd, float absent, float* out_dist,
-                                             int32_t* out_idx, int32_t* out_nn, int32_t* stats) {
+extern "C" int qpg_percode_select_sorted_f32(qpg_ctx* ctx, void* stream, const float* Dm, int64_t ldD, const float* tile_min,
+                                             int64_t ldT, int Q, int64_t R, const int16_t* row_code,
+                                             const int32_t* row_index, const int32_t* zero_row, const int32_t* code_tile,
+                                             int K, float band, const float* qn, const float* xs, int Dd, float absent,
+                                             float* out_dist, int32_t* out_idx, int16_t* out_rank, int32_t* out_nn,
+                                             int32_t* stats) {
   const char* name = "qpg_percode_select_sorted_f32";
-  QPG_REQUIRE(ctx && Dm && row_code && row_index && qn && xs && out_dist && out_idx, "%s: null pointer", name);
-  QPG_REQUIRE(Q >= 0 && R > 0 && (R % 4) == 0 && R < 0x7fffffffll && ldD >= R && (ldD % 4) == 0 && K > 0 && K <= 2048 &&
-                  K <= 0x3fff && Dd > 0 && (Dd % 16) == 0 && (reinterpret_cast<uintptr_t>(Dm) % 16) == 0 &&
-                  (reinterpret_cast<uintptr_t>(xs) % 16) == 0 && (reinterpret_cast<uintptr_t>(qn) % 16) == 0 &&
-                  (reinterpret_cast<uintptr_t>(row_code) % 8) == 0,
-              "%s: bad size / alignment (R %% 4 == 0, D %% 16 == 0, K <= 2048)", name);
+  QPG_REQUIRE(ctx && Dm && tile_min && row_code && row_index && code_tile && qn && xs && out_dist && out_idx,
+              "%s: null pointer", name);
+  QPG_REQUIRE(Q >= 0 && R > 0 && (R % 16) == 0 && R < 0x7fffffffll - 0x2000 && ldD >= R && ldT >= R / 16 && K > 0 &&
+                  K <= 2048 && K <= 0x1fff && Dd > 0 && (Dd % 16) == 0 && (reinterpret_cast<uintptr_t>(xs) % 16) == 0 &&
+                  (reinterpret_cast<uintptr_t>(qn) % 16) == 0,
+              "%s: bad size / alignment (R %% 16 == 0, D %% 16 == 0, K <= 2048)", name);
   if (Q == 0) return QPG_OK;
-  const size_t sh = 16 * (size_t)K + 4 * (size_t)SORT_LIST + 4 * (size_t)Dd;
+  const int S = K >= 32 * SORT_SPLIT ? SORT_SPLIT : (K >= 32 ? K / 32 : 1);
+  const int KLmax = ((K + S - 1) / S + 4) & ~3;          // (multiple of 4: keeps qrow 16-byte aligned)
+  const size_t sh = 12 * (size_t)KLmax + 4 * (size_t)SORT_LIST + 4 * (size_t)SORT_TILES + 4 * (size_t)Dd;
   QPG_REQUIRE(sh <= 64 * 1024, "%s: K / D too large for the LDS tables", name);
-  hipLaunchKernelGGL(percode_select_sorted_kernel, dim3(Q), dim3(1024), sh, qpg_stream(stream), Dm, ldD, R, row_code,
-                     row_index, K, band, qn, xs, Dd, absent, out_dist, out_idx, out_nn, stats);
+  hipLaunchKernelGGL(percode_select_sorted_kernel, dim3(Q, S), dim3(SORT_THREADS), sh, qpg_stream(stream), Dm, ldD, tile_min,
+                     ldT, R, row_code, row_index, zero_row, code_tile, K, band, qn, xs, Dd, absent, out_dist, out_idx, stats);
   QPG_LAUNCH_CHECK("percode_select_sorted_kernel");
+  if (out_rank || out_nn) {
+    hipLaunchKernelGGL(sorted_finish_kernel, dim3(Q), dim3(256), 12 * (size_t)rank_sort_pow2(K) + 4 * (size_t)K, qpg_stream(stream),
+                       (const float*)out_dist, (const int32_t*)out_idx, K, out_rank, out_nn);
+    QPG_LAUNCH_CHECK("sorted_finish_kernel");
+  }
   return QPG_OK;
 }

@@ -1,0 +1,102 @@
+"""Rows sorted by code for the bounded matrix-core prefilter of the exact-f32 cosine family (csrc/qpg_sorted.hip).
+
+The reference's text distance (GestureKNN.py:708-721 -> sklearn paired_distances(metric='cosine') on float32) is defined by
+its arithmetic, but only the per-code minimum and its first-wins candidate are wanted: a split-f16 GEMM with an a-priori
+error bound (qpg_hl_gemm_distance) leaves a band of rows per (query, code) that can be the minimum, and only those are
+evaluated in sklearn's exact order (qpg_percode_select_sorted_f32).  Used by BASELINE configs[2] (cfg3.CosineIndex) and by
+the matcher's text side (code_knn.CodeKNN.sweep_text)."""
+import torch
+
+from . import _lib
+
+U32 = 2.0 ** -24
+HL_GEMM_ERR = 1.3e-6          # QPG_AUDIO_HL_ERR: the split-f16 GEMM on unit-norm operands
+
+
+def prefilter_band(d):
+    """Band of the bounded prefilter for the exact-f32 cosine (derivation: csrc/qpg_sorted.hip): 2.1 x (E_pre + E_sk).
+    eps1: relative error of an f32 sklearn-normalised element (norm^2 by 4 lane chains of d/4 squares, sqrt, divide);
+    E_pre: the GEMM's bound + the two operands being off the true unit vectors by eps1 each;
+    E_sk: sklearn's own rounding against the real-number distance (normalisation errors through the difference,
+    Cauchy-Schwarz with |delta| <= 2, then the chains of d/4 squares)."""
+    eps1 = ((d / 4 + 2) / 2 + 2) * U32
+    e_pre = HL_GEMM_ERR + 2 * eps1
+    e_sk = 0.5 * (8 * eps1 + 4 * (d / 4 + 3) * U32)
+    return 2.1 * (e_pre + e_sk)
+
+
+class SortedRows:
+    """xn: f32 [n][d] sklearn-normalised rows on the device; codes: int tensor [n] (outside [0, K): the row can never win).
+    Builds: the non-zero rows sorted by code (stable: original order inside a code = first-wins), every code's segment
+    padded to 16 rows with copies of its first row (a 16-row tile of the GEMM then lies inside ONE code and a padding row
+    never lowers its minimum), the total padded to 32; `row_index` i32 [R] (original index, -1 padding), `row_code` i16 [R]
+    (padding rows: bit 14 set; the tail beyond the last segment: code 0x1fff), `xs` f32 [R + 1][d] (row R: zeros), the
+    split-f16 fragment image of rows [0, R), `code_tile` i32 [K + 1] (first 16-row tile of every code) and `zero_row` i32 [K]: per code the lowest original index among the rows
+    the normalisation left at zero (all-zero embeddings: all at the same distance from any query, first one wins), -1."""
+
+    def __init__(self, xn, codes, K, device):
+        dev, d = torch.device(device), xn.shape[1]
+        cmt = codes.to(dev).to(torch.int64)
+        valid = (cmt >= 0) & (cmt < K)
+        zero = xn.double().square().sum(1) < 0.5                              # not a unit vector: sklearn left it at zero
+        zr = torch.full((K,), 0x7fffffff, dtype=torch.int64, device=dev)
+        zi = torch.nonzero(valid & zero).reshape(-1)
+        if zi.numel():
+            zr.scatter_reduce_(0, cmt[zi], zi, "amin")
+        self.zero_row = torch.where(zr == 0x7fffffff, torch.full_like(zr, -1), zr).to(torch.int32).contiguous()
+        self.n_zero_rows = int(zi.numel())
+        keep = torch.nonzero(valid & ~zero).reshape(-1)
+        order = keep[torch.sort(cmt[keep], stable=True).indices]              # original indices, by (code, index)
+        cd = cmt[order]
+        cnt = torch.bincount(cd, minlength=K)
+        pad_cnt = (cnt + 15) // 16 * 16
+        start = torch.cumsum(pad_cnt, 0) - pad_cnt
+        Rs = int(pad_cnt.sum().item())
+        R = max((Rs + 31) // 32 * 32, 32)
+        first = (torch.cumsum(cnt, 0) - cnt)                                  # position in `order` of a code's first row
+        within = torch.arange(order.numel(), device=dev) - first[cd]
+        pos = start[cd] + within
+        row_index = torch.full((R,), -1, dtype=torch.int32, device=dev)
+        row_index[pos] = order.to(torch.int32)
+        seg_code = torch.repeat_interleave(torch.arange(K, device=dev), pad_cnt)
+        seg_code = torch.cat((seg_code, torch.full((R - Rs,), 0x1fff, device=dev, dtype=seg_code.dtype)))
+        self.row_code = torch.where(row_index >= 0, seg_code, seg_code | 0x4000).to(torch.int16).contiguous()
+        self.xs = torch.zeros((R + 1, d), dtype=torch.float32, device=dev)
+        if order.numel():
+            src = order[first.clamp(max=order.numel() - 1)[seg_code[:Rs]]]    # every slot: its segment's first row ...
+            self.xs[:Rs] = xn[src]
+            self.xs[pos] = xn[order]                                          # ... real rows: themselves
+        lib = _lib.load()
+        self.image = torch.empty((int(lib.qpg_hl_rows_bytes(R, d)),), dtype=torch.uint8, device=dev)
+        _lib.call("qpg_hl_pack_rows", dev, self.xs, R, d, self.image, self.image.numel())
+        self.R, self.d, self.K, self.row_index, self.device = R, d, K, row_index, dev
+        self.code_tile = torch.cat((torch.zeros((1,), dtype=torch.int64, device=dev),
+                                    torch.cumsum(pad_cnt, 0) // 16)).to(torch.int32).contiguous()      # [K + 1] tile prefix
+        self.band = float(prefilter_band(d))
+        self._cols = None
+        self._Dm = None
+        self._tmin = None
+
+    def select(self, qn, absent, stats, dist=None, idx=None, nn=None, rank=None):
+        """qn: f32 [Q][d] sklearn-normalised queries.  Prefilter GEMM + banded exact select; per-code tables (dist f32
+        [Q][K], idx i32 [Q][K] original row indices), optionally the nearest neighbours nn i32 [Q] and the ranks of the
+        table rows (rank i16 [Q][K]).  An overflowing band list ORs 1 into stats[1] (the caller re-evaluates on the exact
+        sweep)."""
+        dev, Q = self.device, qn.shape[0]
+        lib = _lib.load()
+        nb = int(lib.qpg_hl_cols_bytes(Q, self.d))
+        if self._cols is None or self._cols.numel() < nb:
+            self._cols = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        if self._Dm is None or self._Dm.shape[0] < Q:
+            self._Dm = torch.empty((Q, self.R), dtype=torch.float32, device=dev)
+            self._tmin = torch.empty((Q, self.R // 16), dtype=torch.float32, device=dev)
+        if dist is None:
+            dist = torch.empty((Q, self.K), dtype=torch.float32, device=dev)
+            idx = torch.empty((Q, self.K), dtype=torch.int32, device=dev)
+        _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, self._cols, self._cols.numel())
+        _lib.call("qpg_hl_gemm_distance", dev, self.image, self.R, self.d, self._cols, Q, self._Dm, self.R,
+                  self._tmin, self.R // 16)
+        _lib.call("qpg_percode_select_sorted_f32", dev, self._Dm, self.R, self._tmin, self.R // 16, Q, self.R,
+                  self.row_code, self.row_index, self.zero_row, self.code_tile, self.K, self.band, qn, self.xs, self.d,
+                  absent, dist, idx, rank, nn, stats)
+        return dist, idx, nn

@@ -167,12 +167,12 @@ def test_cfg3_bounded_prefilter_equals_the_exact_sweep():
     od, oi = cref.text_scan(X.reshape(N, 1, D), [0], cm, [0], q[sel], K=K, n_threads=8)
     assert np.array_equal(fi.cpu().numpy()[sel], oi) and np.array_equal(fd.cpu().numpy()[sel], od)
     # the prefilter matrix against the exact f32 distances of the same (sorted) rows: inside half the band
-    Dm = index._Dm[:8].double().cpu().numpy()
-    rows_ok = (index.row_index >= 0).cpu().numpy()
-    xs = index.xs.double().cpu().numpy()
+    Dm = index.sorted._Dm[:8].double().cpu().numpy()
+    rows_ok = (index.sorted.row_index >= 0).cpu().numpy()
+    xs = index.sorted.xs.double().cpu().numpy()
     qn = torch.empty_like(qd)
     _lib.call("qpg_l2_normalize_rows_f32", qd.device, qd, Q, D, qn)
-    exact = 1.0 - qn[:8].double().cpu().numpy() @ xs.T
+    exact = 1.0 - qn[:8].double().cpu().numpy() @ xs[:-1].T                      # (xs row R: the zero row)
     err = np.abs(Dm - exact)[:, rows_ok].max()
     print("prefilter: max |d~ - (1 - <x^, q^>)| = %.3g; band %.3g" % (err, prefilter_band(D)))
     assert err <= 1.3e-6

@@ -22,10 +22,10 @@ for k, v in times.items():
     ts = sorted(a.elapsed_time(b) for a, b in v)
     print("%-34s min %.3f  median %.3f ms" % (k, ts[0], ts[len(ts) // 2]))
 print("R =", index.R, " band =", index.band)
-# ablation: an empty band (nothing listed: phases 1 + 2 only) and a select on one pass
+# ablation: band < 0 makes the select skip its list and refine (phase 1 only: the segmented per-code minimum)
 times.clear()
 index.band = -1.0
 for _ in range(5): index.query(qd)
 torch.cuda.synchronize()
 ts = sorted(a.elapsed_time(b) for a, b in times["qpg_percode_select_sorted_f32"])
-print("select with an empty band (phases 1+2 only): median %.3f ms" % ts[len(ts) // 2])
+print("select, phase 1 only (band < 0): median %.3f ms" % ts[len(ts) // 2])
