@@ -13,14 +13,15 @@ assert lib.qpg_debug_select_prof(buf) == 0
 names = {0: "init", 1: "pass 1 (stream)", 2: "pass 2 (pot list)", 3: "list (a) + v", 4: "rank_pass(false)", 5: "list (b)",
          6: "park", 7: "phase 2 load", 8: "tier 1/2 merge + tables", 9: "rank_pass(true)", 10: "rank-level tie scan",
          11: "tier-2 refine", 12: "rank_pass again"}
-for ph in (1, 2):
+snames = {1: "stream slice", 2: "merge minima (global atomics)", 3: "survivors -> workspace"}
+for ph in (0, 1, 2):
     st = [buf[ph * 16 + i] for i in range(16)]
     ck = [buf[(3 + ph) * 16 + i] for i in range(16)]
     prev = pck = None
-    print("phase", ph)
+    print("phase", ph, "(mixed_stream_kernel, block (0, 0))" if ph == 0 else "")
     for i in range(13):
         if st[i] == 0:
             continue
         if prev is not None:
-            print("   %-26s %6.2f us  %7d shader clocks" % (names[i], (st[i] - prev) / 100.0, ck[i] - pck))
+            print("   %-26s %6.2f us  %7d shader clocks" % ((snames if ph == 0 else names)[i], (st[i] - prev) / 100.0, ck[i] - pck))
         prev, pck = st[i], ck[i]

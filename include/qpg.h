@@ -327,10 +327,14 @@ int qpg_percode_select_mixed_f64(qpg_ctx*, void* stream, const void* D, int d_is
                                  const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32,
                                  const double* qn2, const double* cn2, double eps1, double eps2, int32_t* stats,
                                  void* ws, int64_t ws_bytes, int base_is_f16);
-/* ws: [dev] scratch of qpg_percode_select_mixed_ws_bytes(Q, K) bytes, 16-byte aligned — with it the call is three
- * launches (lists | tier-1 dot products on every CU | merge, tier 2, ranks); NULL: one launch, each query's tier-1 work
- * on its own CU (slower when the lists are long). */
+/* ws: [dev] scratch of qpg_percode_select_mixed_ws_bytes(Q, K) bytes, 16-byte aligned, ZERO-FILLED ONCE by the caller
+ * (part of it is state the launches leave all-zero for the next call; a workspace may be reused for any smaller Q) - with
+ * it the call is four launches (the row streamed by 8 blocks per query | lists | tier-1 dot products of all queries' pairs
+ * on every CU | merge, tier 2, ranks; an f64 matrix: three, the lists' launch streams the row itself); NULL: one launch,
+ * each query's work on its own CU.  qpg_percode_select_mixed_ws_stride(K): bytes per query - query q's tier-1 list
+ * length is the i32 at 16 + q x stride + 24 K (diagnostics). */
 int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K);
+int64_t qpg_percode_select_mixed_ws_stride(int K);
 
 /* Cross-shard merge when the shards swept with qpg_audio_cosine_mx (their tables are accurate to QPG_AUDIO_MX_ERR; each
  * shard's own select has settled the near-ties inside the shard).  Three steps around two more byte exchanges:

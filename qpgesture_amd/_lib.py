@@ -149,6 +149,8 @@ def load():
     lib.qpg_text_percode_ws_bytes.restype = c_int64
     lib.qpg_percode_select_mixed_ws_bytes.argtypes = [c_int, c_int]
     lib.qpg_percode_select_mixed_ws_bytes.restype = c_int64
+    lib.qpg_percode_select_mixed_ws_stride.argtypes = [c_int]
+    lib.qpg_percode_select_mixed_ws_stride.restype = c_int64
     lib.qpg_merge_mixed_ws_bytes.argtypes = [c_int, c_int, c_int]
     lib.qpg_audio_hl_supported.argtypes = [c_int] * 6
     lib.qpg_audio_hl_db_bytes.argtypes = [c_int, c_int]

@@ -440,7 +440,8 @@ class CodeKNN:
             need = int(_lib.load().qpg_percode_select_mixed_ws_bytes(Q, db.K))
             ws = getattr(self, "_mix_ws", None)
             if ws is None or ws.numel() < need:
-                ws = self._mix_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+                # (zero-filled ONCE: the select's streamed state is all-zero between launches, qpg.h)
+                ws = self._mix_ws = torch.zeros((need,), dtype=torch.uint8, device=dev)
             self._last_mix_Q = Q
             _lib.call("qpg_percode_select_mixed_f64", dev, D, 1, D.stride(0), Q, db.aud_cand_code, C, db.K,
                       float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
@@ -569,8 +570,8 @@ class CodeKNN:
         if ws is None or not Q:
             return np.zeros((0,), np.int64)
         K = self.db.K
-        stride = int(_lib.load().qpg_percode_select_mixed_ws_bytes(Q, K)) // Q
-        w = ws[:Q * stride].view(Q, stride)[:, 24 * K:24 * K + 4].contiguous().view(torch.int32)
+        stride = int(_lib.load().qpg_percode_select_mixed_ws_stride(K))
+        w = ws[16:16 + Q * stride].view(Q, stride)[:, 24 * K:24 * K + 4].contiguous().view(torch.int32)
         return w.cpu().numpy().reshape(-1).astype(np.int64)
 
     def clear_flags(self):

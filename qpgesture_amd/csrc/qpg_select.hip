@@ -799,30 +799,71 @@ __device__ __forceinline__ double pair_dot_wave_f64(const GuardArgs& A, int q, i
   return s;
 }
 
-__host__ __device__ __forceinline__ size_t mix_ws_stride(int K) {          // bytes of one query's parking space
+// Workspace of the cut launch: 16-byte header (the flat list's counter), per query [parking space | streamed state], then
+// the flat list's entries.
+//   parking space   best u64 K | v f64 K | besti u32 K | near u32 K | n, pad (16 B) | l_c i32 L | l_k i32 L | l_d f64 L
+//   streamed state  inv u32 K (NOT of the minimum's order key, merged by atomicMax: all-zero = empty) | survivors of each
+//                   slice i32 [MIX_SPLIT] (-1: its list overflowed) | pot_c i32 P | pot_d f32 P | pot_k i16 P
+//                   (P = MIX_SPLIT x MIX_SPOT: slice s owns entries [s MIX_SPOT, (s + 1) MIX_SPOT) - no global counter)
+//   tail            flat i32 [Q x L]: (query, list entry) of every tier-1 pair of the launch
+// The header and the streamed states are ALL-ZERO between launches (the kernels that consume them reset them; their
+// offsets do not depend on Q): the caller zero-fills the workspace once.
+#define MIX_SPLIT 8       // blocks per query streaming the row
+#define MIX_SPOT 3072     // potential band members a slice can hold in LDS
+#define MIX_GPOT (MIX_SPLIT * MIX_SPOT)
+__host__ __device__ __forceinline__ size_t mix_park_bytes(int K) {
   return 24 * (size_t)K + 16 + 8 * (size_t)MIX_LIST + 8 * (size_t)MIX_LIST;
 }
+__host__ __device__ __forceinline__ size_t mix_ws_stride(int K) {          // bytes of one query's space (multiple of 16)
+  return ((mix_park_bytes(K) + 4 * (size_t)K + 4 * MIX_SPLIT + 10 * (size_t)MIX_GPOT) + 15) & ~(size_t)15;
+}
+struct MixStream {        // one query's streamed state
+  unsigned int* inv;
+  int* cnt;               // [MIX_SPLIT] survivors of each slice (-1: its LDS list overflowed)
+  int* pot_c;
+  float* pot_d;
+  int16_t* pot_k;
+};
+__host__ __device__ __forceinline__ unsigned char* mix_query_base(unsigned char* ws, int q, int K) {
+  return ws + 16 + (size_t)q * mix_ws_stride(K);
+}
+__host__ __device__ __forceinline__ MixStream mix_stream_of(unsigned char* ws, int q, int K) {
+  unsigned char* b = mix_query_base(ws, q, K) + mix_park_bytes(K);
+  MixStream m;
+  m.inv = reinterpret_cast<unsigned int*>(b);
+  m.cnt = reinterpret_cast<int*>(b + 4 * (size_t)K);
+  m.pot_c = m.cnt + MIX_SPLIT;
+  m.pot_d = reinterpret_cast<float*>(m.pot_c + MIX_GPOT);
+  m.pot_k = reinterpret_cast<int16_t*>(m.pot_d + MIX_GPOT);
+  return m;
+}
+__host__ __device__ __forceinline__ int* mix_flat_count(unsigned char* ws) { return reinterpret_cast<int*>(ws); }
+__host__ __device__ __forceinline__ int* mix_flat_entries(unsigned char* ws, int Q, int K) {
+  return reinterpret_cast<int*>(mix_query_base(ws, Q, K));
+}
 
-// Tier-1 dot products of every query's list, on the whole GPU: grid (Q, RB), 4 waves per block, wave g of the
-// 4*RB of a query takes list entries g, g + 4*RB, ...
+// Tier-1 dot products of every query's list, on the whole GPU.  The lists are uneven (a few queries hold twice the average),
+// so the pairs of ALL queries are numbered in one flat list (the list kernel reserves a range per query) and wave g of the
+// launch takes entries g, g + n_waves, ...: 4096 waves, one pair each at the clip's ~3 400 pairs.  (Round 2 gave every
+// query 64 waves: the longest list set the time, 23 us; flat: DESIGN.md §4.3.)
 template <int NPER>
-__global__ __launch_bounds__(256) void select_refine_kernel(GuardArgs A, int K, const double* __restrict__ cn2,
+__global__ __launch_bounds__(256) void select_refine_kernel(GuardArgs A, int Q, int K, const double* __restrict__ cn2,
                                                             const double* __restrict__ qn2, unsigned char* __restrict__ ws,
                                                             int fast) {
-  const int q = blockIdx.x, lane = threadIdx.x & 63;
-  const int g = blockIdx.y * 4 + (threadIdx.x >> 6), ng = gridDim.y * 4;
-  unsigned char* wq = ws + (size_t)q * mix_ws_stride(K);
-  const int* w_n = reinterpret_cast<const int*>(wq + 24 * (size_t)K);
-  const int* w_lc = w_n + 4;
-  double* w_ld = reinterpret_cast<double*>(const_cast<int*>(w_lc) + 2 * MIX_LIST);
-  const int n = w_n[0];
-  if (g >= n) return;
-  const double qq = qn2[q];
-  const float* qrow = A.q32 + (int64_t)q * A.n_taps * A.F;
-  for (int e = g; e < n; e += ng) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), ng = gridDim.x * 4;
+  const int* flat = mix_flat_entries(ws, Q, K);
+  const int total = *mix_flat_count(ws);
+  for (int i = g; i < total; i += ng) {
+    const int qe = flat[i];
+    const int q = qe / MIX_LIST, e = qe - q * MIX_LIST;
+    unsigned char* wq = mix_query_base(ws, q, K);
+    const int* w_lc = reinterpret_cast<const int*>(wq + 24 * (size_t)K) + 4;
+    double* w_ld = reinterpret_cast<double*>(const_cast<int*>(w_lc) + 2 * MIX_LIST);
+    const float* qrow = A.q32 + (int64_t)q * A.n_taps * A.F;
     const int c = w_lc[e];
     const double dot = fast ? pair_dot_fast_f64<NPER>(A, qrow, c, lane) : pair_dot_wave_f64(A, q, c, lane);
-    if (lane == 0) w_ld[e] = cosine_from_dot(dot, qq, cn2[c]);
+    if (lane == 0) w_ld[e] = cosine_from_dot(dot, qn2[q], cn2[c]);
   }
 }
 
@@ -833,7 +874,7 @@ __device__ long long qpg_select_prof_buf[6][16];      // [phase]: wall clock; [3
 #define SEL_STAMP(i)                                                                          \
   do {                                                                                        \
     __syncthreads();                                                                          \
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                                                \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                             \
       qpg_select_prof_buf[phase][i] = wall_clock64();                                         \
       qpg_select_prof_buf[3 + phase][i] = clock64();                                          \
     }                                                                                         \
@@ -845,13 +886,135 @@ extern "C" int qpg_debug_select_prof(long long* out) {
 #define SEL_STAMP(i)
 #endif
 
+// The streaming pass of the select, MIX_SPLIT blocks per query (a single CU pulls ~25 GB/s: one block per query spent
+// 21 us on the row's 320 KB, with 48 of the 256 CUs busy).  Block (q, s) streams slice s of row q: per-code minimum in
+// LDS (4-byte keys), the candidates within eps1 of their code's minimum SO FAR remembered; at the end those still within
+// eps1 of the slice's FINAL minimum are appended to the query's list in the workspace (candidate, value, code) and the
+// slice's minima merged into the query's table (atomicMax of the inverted key).  The list kernel (phase 1 of
+// percode_select_mixed_f64_kernel, `pre` set) starts from that state instead of streaming.
+__global__ __launch_bounds__(1024) void mixed_stream_kernel(const float* __restrict__ D, int64_t ldD,
+                                                           const int16_t* __restrict__ cand_code, int64_t C, int K,
+                                                           double eps1, unsigned char* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned int* best32 = reinterpret_cast<unsigned int*>(smem);                         // [K]
+  int* pc = reinterpret_cast<int*>(best32 + K);                                         // [MIX_SPOT]
+  float* pd = reinterpret_cast<float*>(pc + MIX_SPOT);                                  // [MIX_SPOT]
+  int16_t* pk = reinterpret_cast<int16_t*>(pd + MIX_SPOT);                              // [MIX_SPOT]
+  __shared__ int n_pot, n_keep;
+  const int q = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+#ifdef QPG_SELECT_PROF
+  const int phase = 0;
+#endif
+  const float* row = D + (int64_t)q * ldD;
+  const int64_t chunk = (((C + MIX_SPLIT - 1) / MIX_SPLIT) + 63) & ~(int64_t)63;
+  const int64_t c0 = (int64_t)sl * chunk, c1 = c0 + chunk < C ? c0 + chunk : C;
+  for (int k = tid; k < K; k += blockDim.x) best32[k] = 0xffffffffu;
+  if (tid == 0) {
+    n_pot = 0;
+    n_keep = 0;
+  }
+  __syncthreads();
+  SEL_STAMP(0);
+  auto visit = [&](int64_t c, float dv, int cd) {
+    if ((unsigned)cd >= (unsigned)K) return;
+    const unsigned int key = order_key(dv);
+    unsigned int old = *reinterpret_cast<volatile unsigned int*>(&best32[cd]);
+    if (key < old) old = atomicMin(&best32[cd], key);
+    if ((double)dv <= (double)key_value(old < key ? old : key, 0.f) + eps1) {
+      const int pp = atomicAdd(&n_pot, 1);
+      if (pp < MIX_SPOT) {
+        pc[pp] = (int)c;
+        pd[pp] = dv;
+        pk[pp] = (int16_t)cd;
+      }
+    }
+  };
+  typedef int16_t c16x4 __attribute__((ext_vector_type(4)));
+  const bool vec_ok = (ldD % 4) == 0 && (reinterpret_cast<uintptr_t>(D) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(cand_code) % 8) == 0;
+  const int64_t cv = vec_ok ? c0 + ((c1 - c0) / 4) * 4 : c0;
+  // What bounds a slice is the number of load ROUND TRIPS (~1 us each under load), not its bytes: 256 threads x 4
+  // iterations in flight took 7 round trips and 10 us for 6 656 candidates.  1024 threads x UN = 2: the whole slice of the
+  // bench geometry is in flight at once.  A batch then goes through in two sweeps - all table reads (LDS round trips,
+  // issued back to back), then the compares.
+  constexpr int UN = 2;
+  for (int64_t b = c0 + (int64_t)tid * 4; b < cv; b += (int64_t)blockDim.x * 4 * UN) {
+    f32x4 d[UN];
+    c16x4 cd[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t c = b + (int64_t)u * blockDim.x * 4;
+      d[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      cd[u] = (c16x4){-1, -1, -1, -1};
+      if (c < cv) {
+        d[u] = *reinterpret_cast<const f32x4*>(row + c);
+        cd[u] = *reinterpret_cast<const c16x4*>(cand_code + c);
+      }
+    }
+    unsigned int key[UN][4], old[UN][4];
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int code = cd[u][e];
+        key[u][e] = order_key(d[u][e]);
+        old[u][e] = (unsigned)code < (unsigned)K ? *reinterpret_cast<volatile unsigned int*>(&best32[code]) : 0u;
+      }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int code = cd[u][e];
+        if ((unsigned)code >= (unsigned)K) continue;
+        unsigned int o = old[u][e];
+        if (key[u][e] < o) o = atomicMin(&best32[code], key[u][e]);
+        const unsigned int lo = o < key[u][e] ? o : key[u][e];
+        if ((double)d[u][e] <= (double)key_value(lo, 0.f) + eps1) {
+          const int pp = atomicAdd(&n_pot, 1);
+          if (pp < MIX_SPOT) {
+            pc[pp] = (int)(b + (int64_t)u * blockDim.x * 4 + e);
+            pd[pp] = d[u][e];
+            pk[pp] = (int16_t)code;
+          }
+        }
+      }
+  }
+  for (int64_t c = cv + tid; c < c1; c += blockDim.x) visit(c, row[c], cand_code[c]);
+  __syncthreads();
+  SEL_STAMP(1);
+  MixStream m = mix_stream_of(ws, q, K);
+  for (int k = tid; k < K; k += blockDim.x)
+    if (best32[k] != 0xffffffffu) atomicMax(&m.inv[k], ~best32[k]);
+  SEL_STAMP(2);
+  const int np = n_pot;
+  if (np > MIX_SPOT) {                        // the list kernel then streams the row itself (its own fallback)
+    if (tid == 0) m.cnt[sl] = -1;
+    return;
+  }
+  // survivors: within eps1 of the slice's final minimum (a superset of what the row's final minimum keeps), into this
+  // slice's own segment of the query's list
+  const int seg = sl * MIX_SPOT;
+  for (int e = tid; e < np; e += blockDim.x) {
+    if (!((double)pd[e] <= (double)key_value(best32[pk[e]], 0.f) + eps1)) continue;
+    const int pos = seg + atomicAdd(&n_keep, 1);
+    m.pot_c[pos] = pc[e];
+    m.pot_d[pos] = pd[e];
+    m.pot_k[pos] = pk[e];
+  }
+  __syncthreads();
+  if (tid == 0) m.cnt[sl] = n_keep;
+  SEL_STAMP(3);
+}
+
 template <typename DT>
 __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     const DT* __restrict__ D, int64_t ldD, const int16_t* __restrict__ cand_code, int64_t C, int K, double absent,
     int32_t idx_base, double* __restrict__ out_dist, int32_t* __restrict__ out_idx, int16_t* __restrict__ out_rank,
     int q_block, int64_t block_stride, GuardArgs A, double eps1, const double* __restrict__ cn2,
-    const double* __restrict__ qn2, int use_qlds, int phase, unsigned char* __restrict__ ws) {
+    const double* __restrict__ qn2, int use_qlds, int phase, unsigned char* __restrict__ ws, int pre, int Q) {
   // phase 0: everything in this launch (tier-1 dot products by this block's 16 waves: one CU per query).
+  // pre (phase 1, f32 matrix): mixed_stream_kernel has streamed the row - per-code minima and the potential band members
+  // are in the workspace; this launch starts at pass 2.
   // phase 1 / 2: the launch is cut at the tier-1 list — phase 1 parks its state in `ws`, select_refine_kernel computes
   // the listed dot products on ALL CUs (a single CU pulls ~26 GB/s; the list of a 48-query clip is ~110 MB of rows),
   // phase 2 picks the state up again.
@@ -882,7 +1045,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     out_dist = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(out_dist) + shift) + rowoff;
     out_idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(out_idx) + shift) + rowoff;
   }
-  unsigned char* wq = ws ? ws + (size_t)q * mix_ws_stride(K) : nullptr;       // this query's parking space
+  unsigned char* wq = ws ? mix_query_base(ws, q, K) : nullptr;                // this query's parking space
   for (int k = tid; k < K; k += blockDim.x) {
     best[k] = ~0ull;
     besti[k] = 0xffffffffu;
@@ -921,7 +1084,10 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   // 4-byte keys in `s_code` (free until the ranks) - half the LDS words per gather - and widens them afterwards.)
   constexpr bool K32 = sizeof(DT) == 4;
   unsigned int* best32 = reinterpret_cast<unsigned int*>(s_code);
-  if (K32) {
+  const bool streamed = K32 && pre;
+  MixStream ms = {};
+  if (streamed) ms = mix_stream_of(ws, q, K);
+  if (K32 && !streamed) {
     for (int k = tid; k < K; k += blockDim.x) best32[k] = 0xffffffffu;
     __syncthreads();
   }
@@ -948,19 +1114,35 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       }
     }
   };
+  if (!streamed) {
 #pragma unroll 4
-  for (int64_t c = (int64_t)tid * VE; c < Cv; c += (int64_t)blockDim.x * VE) {
-    const vecD d = *reinterpret_cast<const vecD*>(row + c);
-    const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
+    for (int64_t c = (int64_t)tid * VE; c < Cv; c += (int64_t)blockDim.x * VE) {
+      const vecD d = *reinterpret_cast<const vecD*>(row + c);
+      const vecC cd = *reinterpret_cast<const vecC*>(cand_code + c);
 #pragma unroll
-    for (int e = 0; e < VE; ++e) pass1(c + e, d[e], cd[e]);
+      for (int e = 0; e < VE; ++e) pass1(c + e, d[e], cd[e]);
+    }
+    for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass1(c, row[c], cand_code[c]);
+    __syncthreads();
   }
-  for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass1(c, row[c], cand_code[c]);
-  __syncthreads();
+  int g_pot = 0;                              // streamed: entries of the workspace list (or the overflow mark)
   if (K32) {
     for (int k = tid; k < K; k += blockDim.x) {
-      const unsigned int b = best32[k];
+      unsigned int b;
+      if (streamed) {
+        b = ~ms.inv[k];
+        ms.inv[k] = 0;                        // (left all-zero for the next launch)
+      } else {
+        b = best32[k];
+      }
       best[k] = b == 0xffffffffu ? ~0ull : (unsigned long long)order_key((double)key_value(b, 0.f));
+    }
+    if (streamed) {
+#pragma unroll
+      for (int sl = 0; sl < MIX_SPLIT; ++sl) {
+        const int ns = ms.cnt[sl];
+        g_pot = (ns < 0 || g_pot < 0) ? -1 : g_pot + ns;     // a slice's list overflowed: pass 2 streams the row
+      }
     }
     __syncthreads();
   }
@@ -977,7 +1159,45 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       p_k[pp] = (int16_t)cd;
     }
   };
-  if (ctl[4] <= MIX_POT) {
+  if (streamed && g_pot >= 0) {
+    // the slices' segments as one index space: thread t takes entries t, t + blockDim, ... of the concatenation; all of a
+    // thread's entries (<= 4 at the usual ~4 000 survivors) are loaded before the first is used
+    int seg_end[MIX_SPLIT];
+    {
+      int acc = 0;
+#pragma unroll
+      for (int sl = 0; sl < MIX_SPLIT; ++sl) {
+        acc += ms.cnt[sl];
+        seg_end[sl] = acc;
+      }
+    }
+    constexpr int UE = 4;
+    for (int e0 = tid; e0 < g_pot; e0 += (int)blockDim.x * UE) {
+      int pc_[UE], pk_[UE];
+      float pd_[UE];
+#pragma unroll
+      for (int u = 0; u < UE; ++u) {
+        const int e = e0 + u * (int)blockDim.x;
+        pk_[u] = -1;
+        if (e < g_pot) {
+          int sl = 0, first = 0;                              // the segment e falls into and its first index
+#pragma unroll
+          for (int i = 0; i < MIX_SPLIT - 1; ++i)
+            if (e >= seg_end[i]) {
+              sl = i + 1;
+              first = seg_end[i];
+            }
+          const int pos = sl * MIX_SPOT + e - first;
+          pc_[u] = ms.pot_c[pos];
+          pd_[u] = ms.pot_d[pos];
+          pk_[u] = ms.pot_k[pos];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UE; ++u)
+        if (pk_[u] >= 0) pass2(pc_[u], (double)pd_[u], pk_[u]);
+    }
+  } else if (!streamed && ctl[4] <= MIX_POT) {
     const int npot = ctl[4];
     for (int e = tid; e < npot; e += blockDim.x) pass2(pot_c[e], (double)row[pot_c[e]], pot_k[e]);
   } else {
@@ -991,6 +1211,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     for (int64_t c = Cv + tid; c < C; c += blockDim.x) pass2(c, (double)row[c], cand_code[c]);
   }
   __syncthreads();
+  if (streamed && tid < MIX_SPLIT) ms.cnt[tid] = 0;            // (left all-zero for the next launch)
   SEL_STAMP(2);
   // ---- list (a): every member of a band with two or more members — from the members pass 2 remembered, or, if there
   // were more than it could hold, by a third pass over the row
@@ -1024,22 +1245,40 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   // ---- list (b): winners of codes whose minima lie within eps1 of ANOTHER code's (only needed when ranks are wanted:
   // without them the minima of different codes are never compared here).  Two values that close are rank neighbours, but
   // finding them does not need the ranks (a sort: 14 us here): every present code drops its value into a grid of cells
-  // a little wider than eps1 (hashed into 2048 LDS counters); a code with company in its own or an adjacent cell is
-  // listed.  Hash collisions and cell-mates further than eps1 apart only list a code that did not need it (it then gets an
-  // f64 value like any other listed code).
+  // a little wider than eps1 (hashed into 2048 LDS counters that hold population and code sum); a code looks at its own
+  // and the two adjacent cells: a single other occupant is tested directly (|dv| < eps1: a hash collision is then harmless -
+  // without the test half of the codes were listed, 273 entries per query instead of ~70), two or more list the code
+  // without a test (it then gets an f64 value like any other listed code: never wrong, only work).
   if (out_rank) {
     unsigned int* cell = reinterpret_cast<unsigned int*>(p_c);          // [2048] (p_c / p_k are dead: list (a) is built)
     const double inv_w = 1.0 / (eps1 * 1.000001);
     auto slot = [](long long b) { return (unsigned int)(((unsigned long long)b * 0x9E3779B97F4A7C15ull) >> 53); };
     for (int i = tid; i < 2048; i += blockDim.x) cell[i] = 0;
     __syncthreads();
+    // a counter holds (population << 16) + the sum of its codes: with one occupant, the occupant
     for (int k = tid; k < K; k += blockDim.x)
-      if (besti[k] != 0xffffffffu) atomicAdd(&cell[slot((long long)floor(v[k] * inv_w))], 1u);
+      if (besti[k] != 0xffffffffu) atomicAdd(&cell[slot((long long)floor(v[k] * inv_w))], 0x10000u + (unsigned int)k);
     __syncthreads();
     for (int k = tid; k < K; k += blockDim.x) {
       if (besti[k] == 0xffffffffu) continue;
       const long long b = (long long)floor(v[k] * inv_w);
-      if (cell[slot(b - 1)] + cell[slot(b)] + cell[slot(b + 1)] < 2u) continue;
+      const unsigned int s0 = slot(b);
+      bool company = false;
+#pragma unroll
+      for (int o = -1; o <= 1; ++o) {
+        const unsigned int si = slot(b + o);
+        if (o != 0 && si == s0) continue;                               // (the own counter is looked at once)
+        unsigned int c = cell[si];
+        if (si == s0) c -= 0x10000u + (unsigned int)k;                  // without this code itself
+        const unsigned int pop = c >> 16;
+        if (pop == 1) {                                                 // one other code (of this cell, or one that
+          const int other = (int)(c & 0xffffu);                         // hashed here): the test itself
+          company |= fabs(v[other] - v[k]) < eps1;
+        } else if (pop > 1) {
+          company = true;
+        }
+      }
+      if (!company) continue;
       if (atomicMax(&near_[k], 2u) >= 2u) continue;                    // band-listed already
       const int pos = atomicAdd(&ctl[0], 1);
       if (pos < MIX_LIST) {
@@ -1075,7 +1314,13 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       w_lc[e] = l_c[e];
       w_lk[e] = l_k[e];
     }
-    if (tid == 0) w_n[0] = n;
+    if (tid == 0) {
+      w_n[0] = n;
+      ctl[5] = n ? atomicAdd(mix_flat_count(ws), n) : 0;      // this query's range of the launch's flat pair list
+    }
+    __syncthreads();
+    int* flat = mix_flat_entries(ws, Q, K) + ctl[5];
+    for (int e = tid; e < n; e += blockDim.x) flat[e] = q * MIX_LIST + e;
     SEL_STAMP(6);
     return;
   }
@@ -1089,6 +1334,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     const int* w_lk = w_lc + MIX_LIST;
     const double* w_ld = reinterpret_cast<const double*>(w_lk + MIX_LIST);
     n = w_n[0];
+    if (q == 0 && tid == 0) *mix_flat_count(ws) = 0;           // (the refine launch is done: left zero for the next one)
     for (int k = tid; k < K; k += blockDim.x) {
       best[k] = w_best[k];
       v[k] = w_v[k];
@@ -1234,7 +1480,10 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
 }
 
 extern "C" int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K) {
-  return (Q <= 0 || K <= 0) ? 0 : (int64_t)((size_t)Q * mix_ws_stride(K));
+  return (Q <= 0 || K <= 0) ? 0 : (int64_t)((size_t)Q * mix_ws_stride(K) + 16 + 4 * (size_t)Q * MIX_LIST);
+}
+extern "C" int64_t qpg_percode_select_mixed_ws_stride(int K) {       // bytes per query; query q's space starts at
+  return K <= 0 ? 0 : (int64_t)mix_ws_stride(K);                     // 16 + q x stride, its list length is the i32 at + 24 K
 }
 
 extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
@@ -1276,23 +1525,35 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
   }
   unsigned char* w = static_cast<unsigned char*>(ws);
   if (ws)
-    QPG_REQUIRE(ws_bytes >= (int64_t)((size_t)Q * mix_ws_stride(K)) && (reinterpret_cast<uintptr_t>(ws) % 16) == 0,
+    QPG_REQUIRE(ws_bytes >= qpg_percode_select_mixed_ws_bytes(Q, K) && (reinterpret_cast<uintptr_t>(ws) % 16) == 0 &&
+                    (int64_t)Q * MIX_LIST < 0x7fffffffll,
                 "%s: workspace too small or misaligned (qpg_percode_select_mixed_ws_bytes)", name);
-#define SEL_MIX_LAUNCH(DT, SH, PHASE)                                                                                  \
+#define SEL_MIX_LAUNCH(DT, SH, PHASE, PRE)                                                                                  \
   hipLaunchKernelGGL((percode_select_mixed_f64_kernel<DT>), dim3(Q), dim3(1024), SH, qpg_stream(stream),               \
                      static_cast<const DT*>(D), ldD, cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank,   \
-                     q_block, block_stride, A, eps1, cn2, qn2, use_qlds, PHASE, w)
+                     q_block, block_stride, A, eps1, cn2, qn2, use_qlds, PHASE, w, PRE, Q)
   if (!ws) {
-    if (d_is_f32) SEL_MIX_LAUNCH(float, sh, 0); else SEL_MIX_LAUNCH(double, sh, 0);
+    if (d_is_f32) SEL_MIX_LAUNCH(float, sh, 0, 0); else SEL_MIX_LAUNCH(double, sh, 0, 0);
     QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel");
     return QPG_OK;
   }
-  if (d_is_f32) SEL_MIX_LAUNCH(float, sh1, 1); else SEL_MIX_LAUNCH(double, sh1, 1);
+  if (d_is_f32) {
+    // the row is streamed by MIX_SPLIT blocks per query; the list kernel starts from their state
+    const size_t shs = 4 * (size_t)K + 10 * (size_t)MIX_SPOT;
+    hipLaunchKernelGGL(mixed_stream_kernel, dim3(Q, MIX_SPLIT), dim3(1024), shs, qpg_stream(stream),
+                       static_cast<const float*>(D), ldD, cand_code, C, K, eps1, w);
+    QPG_LAUNCH_CHECK("mixed_stream_kernel");
+    SEL_MIX_LAUNCH(float, sh2, 1, 1);
+  } else {
+    SEL_MIX_LAUNCH(double, sh1, 1, 0);
+  }
   QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (lists)");
-  const int rb = Q >= 256 ? 4 : 16;          // waves per query = 4*rb; ~100 list entries per query on dense data
-  hipLaunchKernelGGL((select_refine_kernel<4>), dim3(Q, rb), dim3(256), 0, qpg_stream(stream), A, K, cn2, qn2, w, use_qlds);
+  // ~70 list entries per query on dense data: 1024 blocks x 4 waves take one pair each at Q = 48
+  const int rblocks = Q >= 256 ? 4096 : 1024;
+  hipLaunchKernelGGL((select_refine_kernel<4>), dim3(rblocks), dim3(256), 0, qpg_stream(stream), A, Q, K, cn2, qn2, w,
+                     use_qlds);
   QPG_LAUNCH_CHECK("select_refine_kernel");
-  if (d_is_f32) SEL_MIX_LAUNCH(float, sh2, 2); else SEL_MIX_LAUNCH(double, sh2, 2);
+  if (d_is_f32) SEL_MIX_LAUNCH(float, sh2, 2, 0); else SEL_MIX_LAUNCH(double, sh2, 2, 0);
   QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (merge)");
 #undef SEL_MIX_LAUNCH
   return QPG_OK;
