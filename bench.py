@@ -201,7 +201,11 @@ def main():
                    feature_dtype=a.feature_dtype)
     knn = CodeKNN(db, rng=np.random.RandomState(123456))
     knn.overlap_sweeps = not a.no_overlap
-    knn.text_after_sweep = not a.text_first
+    if a.text_first:
+        knn.text_after_sweep, knn.audio_first = False, False
+    knn.text_lead = float(os.environ.get("QPG_BENCH_TEXT_LEAD", knn.text_lead))
+    if "QPG_BENCH_AUDIO_FIRST" in os.environ:
+        knn.audio_first = os.environ["QPG_BENCH_AUDIO_FIRST"] == "1"
     knn.audio_precision = a.audio_precision
     knn.audio_kernel = a.audio_kernel
     if a.sharded_mixed_min_gflop is not None:

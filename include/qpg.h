@@ -153,6 +153,12 @@ int qpg_audio_hl_pack_db(qpg_ctx*, void* stream, const float* base, int N, int T
 int qpg_audio_hl_pack_queries(qpg_ctx*, void* stream, const float* q32, int Q, int F, void* image, int64_t image_bytes);
 int qpg_audio_cosine_hl(qpg_ctx*, void* stream, const void* db_image, int N, int F, int G, const double* cn2,
                         const void* q_image, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD, int32_t* stats);
+/* Windows [win_begin, win_end) of the same sweep (N stays the image's window count; other columns of D are untouched): two
+ * launches over complementary ranges ARE the sweep, and the caller can record an event between them (the matcher starts
+ * its text side when the first part is done instead of at the very end). */
+int qpg_audio_cosine_hl_range(qpg_ctx*, void* stream, const void* db_image, int N, int F, int G, const double* cn2,
+                              const void* q_image, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD,
+                              int32_t* stats, int win_begin, int win_end);
 /* Hardware probe behind the bound's one measured constant: out[tile] = A[tile] (16 x 32 f16) . B[tile]^T (16 x 32 f16)
  * + C[tile] (16 x 16 f32, NULL = 0) exactly as ONE v_mfma_f32_16x16x32_f16 computes it; the tests compare it with exact
  * sums (kappa: error of a 32-product block sum in units of 2^-24 sum |products|). */
@@ -329,10 +335,10 @@ int qpg_percode_select_mixed_f64(qpg_ctx*, void* stream, const void* D, int d_is
                                  void* ws, int64_t ws_bytes, int base_is_f16);
 /* ws: [dev] scratch of qpg_percode_select_mixed_ws_bytes(Q, K) bytes, 16-byte aligned, ZERO-FILLED ONCE by the caller
  * (part of it is state the launches leave all-zero for the next call; a workspace may be reused for any smaller Q) - with
- * it the call is four launches (the row streamed by 8 blocks per query | lists | tier-1 dot products of all queries' pairs
- * on every CU | merge, tier 2, ranks; an f64 matrix: three, the lists' launch streams the row itself); NULL: one launch,
- * each query's work on its own CU.  qpg_percode_select_mixed_ws_stride(K): bytes per query - query q's tier-1 list
- * length is the i32 at 16 + q x stride + 24 K (diagnostics). */
+ * it the call is four launches (the row streamed by 8 blocks per query | lists | tier-1 dot products, 256 waves per query
+ * | merge, tier 2, ranks; an f64 matrix: three, the lists' launch streams the row itself); NULL: one launch, each query's
+ * work on its own CU.  qpg_percode_select_mixed_ws_stride(K): bytes per query - query q's tier-1 list length is the i32
+ * at q x stride + 24 K (diagnostics). */
 int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K);
 int64_t qpg_percode_select_mixed_ws_stride(int K);
 

@@ -292,7 +292,9 @@ class CodeKNN:
         self.use_phase, self.use_txt = use_phase, use_txt
         self.rng = rng if rng is not None else np.random
         self.overlap_sweeps = True          # text sweep on a second HIP stream underneath the audio sweep
-        self.text_after_sweep = True        # ... started when the audio sweep ends, i.e. underneath the audio SELECT
+        self.text_after_sweep = True        # ... started when the audio sweep ends, i.e. underneath the audio SELECT ...
+        self.text_lead = 0.0                # > 0: ... when all but this fraction of it is done (measured: no gain, below)
+        self.audio_first = None             # no ordering between the two streams; None: auto (sweep_tables)
         self.serial_walk = False            # True: force the one-wave sequential walk (tests compare the two)
         # Near-tie guard of the audio select (qpg_percode_select_guarded_f64): candidates / code minima closer than
         # tie_eps are re-evaluated in the reference's own arithmetic inside the select launch.  0 disables it.
@@ -411,9 +413,25 @@ class CodeKNN:
                       NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2)
         if ev is not None:
             e0.record(torch.cuda.current_stream(dev))          # (the events bracket the sweep kernel alone)
+        early = False
         if use_hl:
-            _lib.call("qpg_audio_cosine_hl", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi, qn2, Q, D, 1,
-                      D.stride(0), self._guard_stats)
+            # text_lead > 0 (measurements): the sweep goes out in two launches and the text side's event sits between
+            # them, so that its first launches overlap the sweep's last `text_lead`.  bench.py, ms per clip at lead 0 /
+            # 0.1 / 0.2 / 0.3 / 0.45: 0.397 / 0.408 / 0.392 / 0.408 / 0.416 - the second launch's ramp-up and the
+            # contention cost what the earlier start saves; the default stays 0.
+            n1 = db.n_local
+            if getattr(self, "_want_sweep_event", False) and self.text_lead > 0:
+                n1 = max(0, min(db.n_local, int(db.n_local * (1.0 - self.text_lead)) // 4 * 4))
+            if 0 < n1 < db.n_local:
+                _lib.call("qpg_audio_cosine_hl_range", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi, qn2, Q, D,
+                          1, D.stride(0), self._guard_stats, 0, n1)
+                self._record_sweep_event(dev)
+                early = True
+                _lib.call("qpg_audio_cosine_hl_range", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi, qn2, Q, D,
+                          1, D.stride(0), self._guard_stats, n1, db.n_local)
+            else:
+                _lib.call("qpg_audio_cosine_hl", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi, qn2, Q, D, 1,
+                          D.stride(0), self._guard_stats)
         elif mixed:
             _lib.call("qpg_audio_cosine_mx_h" if half else "qpg_audio_cosine_mx", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
                       NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, 1, D.stride(0), self._guard_stats)
@@ -424,11 +442,8 @@ class CodeKNN:
         if ev is not None:
             e1.record(torch.cuda.current_stream(dev))
             ev.append((e0, e1))
-        if getattr(self, "_want_sweep_event", False):     # sweep_tables: the text side starts when the sweep has finished
-            if self.__dict__.get("_sweep_event") is None:
-                self._sweep_event = torch.cuda.Event()                  # one event, re-recorded by every clip
-            self._sweep_done = self._sweep_event
-            self._sweep_done.record(torch.cuda.current_stream(dev))
+        if getattr(self, "_want_sweep_event", False) and not early:    # sweep_tables: the text side starts behind the sweep
+            self._record_sweep_event(dev)
         if out is not None:          # exchange layout of the sharded path: written in place, merged after the collective
             dist, idx, qb, bs = out
         else:
@@ -473,6 +488,12 @@ class CodeKNN:
         if want_rank:
             return dist, idx, (rank if fused_rank else self.rank_rows(dist))
         return dist, idx
+
+    def _record_sweep_event(self, dev):
+        if self.__dict__.get("_sweep_event") is None:
+            self._sweep_event = torch.cuda.Event()                      # one event, re-recorded by every clip
+        self._sweep_done = self._sweep_event
+        self._sweep_done.record(torch.cuda.current_stream(dev))
 
     def sweep_text(self, queries, want_rank=False, reduce=True, normalised=False, out=None):
         """queries: f32 [Q,384] on the device (already sklearn-normalised if `normalised`).
@@ -571,7 +592,7 @@ class CodeKNN:
             return np.zeros((0,), np.int64)
         K = self.db.K
         stride = int(_lib.load().qpg_percode_select_mixed_ws_stride(K))
-        w = ws[16:16 + Q * stride].view(Q, stride)[:, 24 * K:24 * K + 4].contiguous().view(torch.int32)
+        w = ws[:Q * stride].view(Q, stride)[:, 24 * K:24 * K + 4].contiguous().view(torch.int32)
         return w.cpu().numpy().reshape(-1).astype(np.int64)
 
     def clear_flags(self):
@@ -721,11 +742,20 @@ class CodeKNN:
         # (`audio_first`, kept for measurements: no faster).  Now (`text_after_sweep`): audio side first, and the text
         # sweep waits on its own stream for the END of the audio sweep, so that it fills the CUs the audio select leaves
         # idle (one block per query, ~90 us): 0.58 -> 0.555 ms per clip.
-        audio_first = getattr(self, "audio_first", False)
         # text_after_sweep: the audio side is enqueued first and the text side waits (on its own stream) for the END of
         # the audio sweep: the text sweep then fills the CUs the audio select leaves idle (one block per query) instead
         # of delaying the audio sweep by its own duration at the start of the clip.
-        after = overlap and self.text_after_sweep and not self.use_wavvq
+        # Round 3: the text side on the matrix-core prefilter is ~60 us of small launches and the audio select now runs on
+        # every CU, so behind the sweep the text side became the longer of the two chains.  audio_first (None = auto: on
+        # with the matrix-core text side): the text side is enqueued behind the audio side's launches on its own stream
+        # with NO ordering - its GEMM trickles through under the sweep and the tables are ready before the audio select
+        # is.  bench.py, alternating in one run (tools/try_orders.sh), ms per clip: behind the sweep 0.400-0.404,
+        # text first 0.384-0.408, audio_first 0.360-0.374.  (`text_lead`: see sweep_audio.)
+        mfma_text = (self.text_kernel == "mfma" and db.txt_sorted is not None and not sharded and
+                     self.audio_precision != "exact")
+        audio_first = getattr(self, "audio_first", None)
+        audio_first = mfma_text if audio_first is None else bool(audio_first)
+        after = overlap and self.text_after_sweep and not audio_first and not self.use_wavvq
         qn_early = None
         if overlap and not audio_first and not after:
             with torch.cuda.stream(side):

@@ -286,6 +286,7 @@ struct HlArgs {
   int64_t ldD;
   int32_t* stats;
   int N, G, Q, KB, d_f32;   // N: database windows (MODE 0) / 32-row groups (MODE 1)
+  int j0;                  // first window / 32-row group of this launch (N: one past the last)
   float* tmin;             // MODE 1, optional: [Q][ldT] minimum of every 16-row tile (rows 16 i .. 16 i + 15)
   int64_t ldT;
 };
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 * HL_KS * HL_CT * 2 * HL_PIECE bytes
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wl = w >> 1, t = w & 1;                           // window of the block, row tile
-  const int j = blockIdx.x * HL_WPB + wl;
+  const int j = a.j0 + blockIdx.x * HL_WPB + wl;               // (j0: first window of a partial launch)
   const int chunk = blockIdx.y;
   const int KB = a.KB, n_stage = KB / HL_KS;
   const bool win_ok = j < a.N;
@@ -620,8 +621,19 @@ extern "C" int qpg_audio_pack_queries_hl(qpg_ctx* ctx, void* stream, const float
 extern "C" int qpg_audio_cosine_hl(qpg_ctx* ctx, void* stream, const void* db_image, int N, int F, int G,
                                    const double* cn2, const void* q_image, const double* qn2, int Q, void* D,
                                    int d_is_f32, int64_t ldD, int32_t* stats) {
+  return qpg_audio_cosine_hl_range(ctx, stream, db_image, N, F, G, cn2, q_image, qn2, Q, D, d_is_f32, ldD, stats, 0, N);
+}
+
+// Windows [win_begin, win_end) of the sweep (same arguments otherwise: N is the image's window count; the columns of the
+// other windows are not touched).  Two launches over complementary ranges are the sweep; the caller can record an event
+// between them - the matcher lets its text side start when the FIRST part is done (CodeKNN.sweep_audio).
+extern "C" int qpg_audio_cosine_hl_range(qpg_ctx* ctx, void* stream, const void* db_image, int N, int F, int G,
+                                         const double* cn2, const void* q_image, const double* qn2, int Q, void* D,
+                                         int d_is_f32, int64_t ldD, int32_t* stats, int win_begin, int win_end) {
   const char* name = "qpg_audio_cosine_hl";
   QPG_REQUIRE(ctx && db_image && cn2 && q_image && qn2 && D, "%s: null pointer", name);
+  QPG_REQUIRE(win_begin >= 0 && win_begin <= win_end && win_end <= N, "%s: bad window range", name);
+  if (win_begin == win_end) return QPG_OK;
   QPG_REQUIRE(N > 0 && Q > 0 && G == HL_ROWS - 1 && (F % 32) == 0 && ((HL_SUB * F / 32) % (2 * HL_KS)) == 0 &&
                   ldD >= (int64_t)N * G,
               "%s: bad size", name);
@@ -633,7 +645,7 @@ extern "C" int qpg_audio_cosine_hl(qpg_ctx* ctx, void* stream, const void* db_im
   a.meta = reinterpret_cast<const int32_t*>(dbi + (qpg_audio_hl_db_bytes(N, F) - 64));
   a.qi = reinterpret_cast<const _Float16*>(qi);
   a.qexp = reinterpret_cast<const int32_t*>(qi + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
-  a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = N; a.G = G; a.Q = Q; a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0;
+  a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = win_end; a.j0 = win_begin; a.G = G; a.Q = Q; a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0;
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
   if (lds_bytes > 64 * 1024) {
     static bool raised = false;
@@ -644,8 +656,8 @@ extern "C" int qpg_audio_cosine_hl(qpg_ctx* ctx, void* stream, const void* db_im
     }
     raised = true;
   }
-  hipLaunchKernelGGL(audio_cosine_hl_kernel<0>, dim3((N + HL_WPB - 1) / HL_WPB, chunks), dim3(HL_THREADS), lds_bytes,
-                     qpg_stream(stream), a);
+  hipLaunchKernelGGL(audio_cosine_hl_kernel<0>, dim3((win_end - win_begin + HL_WPB - 1) / HL_WPB, chunks),
+                     dim3(HL_THREADS), lds_bytes, qpg_stream(stream), a);
   QPG_LAUNCH_CHECK("audio_cosine_hl_kernel");
   return QPG_OK;
 }
@@ -790,7 +802,7 @@ extern "C" int qpg_hl_gemm_distance(qpg_ctx* ctx, void* stream, const void* rows
   a.qi = reinterpret_cast<const _Float16*>(ci);
   a.qexp = reinterpret_cast<const int32_t*>(ci + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
   a.cn2 = nullptr; a.qn2 = nullptr; a.D = Dm; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = nullptr;
-  a.N = (int)(R / 32); a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1; a.tmin = tile_min; a.ldT = ldT;
+  a.N = (int)(R / 32); a.j0 = 0; a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1; a.tmin = tile_min; a.ldT = ldT;
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
   hipLaunchKernelGGL(audio_cosine_hl_kernel<1>, dim3((a.N + HL_WPB - 1) / HL_WPB, chunks), dim3(HL_THREADS), lds_bytes,
                      qpg_stream(stream), a);

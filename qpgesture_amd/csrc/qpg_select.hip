@@ -799,15 +799,13 @@ __device__ __forceinline__ double pair_dot_wave_f64(const GuardArgs& A, int q, i
   return s;
 }
 
-// Workspace of the cut launch: 16-byte header (the flat list's counter), per query [parking space | streamed state], then
-// the flat list's entries.
+// Workspace of the cut launch: per query [parking space | streamed state].
 //   parking space   best u64 K | v f64 K | besti u32 K | near u32 K | n, pad (16 B) | l_c i32 L | l_k i32 L | l_d f64 L
 //   streamed state  inv u32 K (NOT of the minimum's order key, merged by atomicMax: all-zero = empty) | survivors of each
 //                   slice i32 [MIX_SPLIT] (-1: its list overflowed) | pot_c i32 P | pot_d f32 P | pot_k i16 P
 //                   (P = MIX_SPLIT x MIX_SPOT: slice s owns entries [s MIX_SPOT, (s + 1) MIX_SPOT) - no global counter)
-//   tail            flat i32 [Q x L]: (query, list entry) of every tier-1 pair of the launch
-// The header and the streamed states are ALL-ZERO between launches (the kernels that consume them reset them; their
-// offsets do not depend on Q): the caller zero-fills the workspace once.
+// The streamed states are ALL-ZERO between launches (the list kernel resets what it consumes; offsets do not depend on
+// Q): the caller zero-fills the workspace once.
 #define MIX_SPLIT 8       // blocks per query streaming the row
 #define MIX_SPOT 3072     // potential band members a slice can hold in LDS
 #define MIX_GPOT (MIX_SPLIT * MIX_SPOT)
@@ -825,7 +823,7 @@ struct MixStream {        // one query's streamed state
   int16_t* pot_k;
 };
 __host__ __device__ __forceinline__ unsigned char* mix_query_base(unsigned char* ws, int q, int K) {
-  return ws + 16 + (size_t)q * mix_ws_stride(K);
+  return ws + (size_t)q * mix_ws_stride(K);
 }
 __host__ __device__ __forceinline__ MixStream mix_stream_of(unsigned char* ws, int q, int K) {
   unsigned char* b = mix_query_base(ws, q, K) + mix_park_bytes(K);
@@ -837,35 +835,7 @@ __host__ __device__ __forceinline__ MixStream mix_stream_of(unsigned char* ws, i
   m.pot_k = reinterpret_cast<int16_t*>(m.pot_d + MIX_GPOT);
   return m;
 }
-__host__ __device__ __forceinline__ int* mix_flat_count(unsigned char* ws) { return reinterpret_cast<int*>(ws); }
-__host__ __device__ __forceinline__ int* mix_flat_entries(unsigned char* ws, int Q, int K) {
-  return reinterpret_cast<int*>(mix_query_base(ws, Q, K));
-}
 
-// Tier-1 dot products of every query's list, on the whole GPU.  The lists are uneven (a few queries hold twice the average),
-// so the pairs of ALL queries are numbered in one flat list (the list kernel reserves a range per query) and wave g of the
-// launch takes entries g, g + n_waves, ...: 4096 waves, one pair each at the clip's ~3 400 pairs.  (Round 2 gave every
-// query 64 waves: the longest list set the time, 23 us; flat: DESIGN.md §4.3.)
-template <int NPER>
-__global__ __launch_bounds__(256) void select_refine_kernel(GuardArgs A, int Q, int K, const double* __restrict__ cn2,
-                                                            const double* __restrict__ qn2, unsigned char* __restrict__ ws,
-                                                            int fast) {
-  const int lane = threadIdx.x & 63;
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), ng = gridDim.x * 4;
-  const int* flat = mix_flat_entries(ws, Q, K);
-  const int total = *mix_flat_count(ws);
-  for (int i = g; i < total; i += ng) {
-    const int qe = flat[i];
-    const int q = qe / MIX_LIST, e = qe - q * MIX_LIST;
-    unsigned char* wq = mix_query_base(ws, q, K);
-    const int* w_lc = reinterpret_cast<const int*>(wq + 24 * (size_t)K) + 4;
-    double* w_ld = reinterpret_cast<double*>(const_cast<int*>(w_lc) + 2 * MIX_LIST);
-    const float* qrow = A.q32 + (int64_t)q * A.n_taps * A.F;
-    const int c = w_lc[e];
-    const double dot = fast ? pair_dot_fast_f64<NPER>(A, qrow, c, lane) : pair_dot_wave_f64(A, q, c, lane);
-    if (lane == 0) w_ld[e] = cosine_from_dot(dot, qn2[q], cn2[c]);
-  }
-}
 
 // -DQPG_SELECT_PROF (experiments/select_prof): block 0 stamps the 100 MHz wall clock at the section boundaries of the
 // mixed select; qpg_debug_select_prof copies the stamps out.  Not in the product build.
@@ -885,6 +855,33 @@ extern "C" int qpg_debug_select_prof(long long* out) {
 #else
 #define SEL_STAMP(i)
 #endif
+
+// Tier-1 dot products of every query's list, on the whole GPU: grid (Q, RB), 4 waves per block, wave g of the 4 RB of a
+// query takes list entries g, g + 4 RB, ...  RB = 64 at Q = 48: 256 waves per query, one pair each for any list up to 256
+// entries (round 2 gave a query 64 waves: the longest list, ~150 entries, took three rounds of ~12 us - a pair is 24 KB of
+// gathered rows; the 3 400 pairs of a clip move 83 MB in those 12 us, the HBM rate).  Waves beyond the list leave at once.
+// (A flat list over all queries with one global counter was tried: 4 096 waves reading ONE counter address spend 13 us
+// queueing on its L2 channel.)
+template <int NPER>
+__global__ __launch_bounds__(256) void select_refine_kernel(GuardArgs A, int K, const double* __restrict__ cn2,
+                                                            const double* __restrict__ qn2, unsigned char* __restrict__ ws,
+                                                            int fast) {
+  const int q = blockIdx.x, lane = threadIdx.x & 63;
+  const int g = blockIdx.y * 4 + (threadIdx.x >> 6), ng = gridDim.y * 4;
+  unsigned char* wq = mix_query_base(ws, q, K);
+  const int* w_n = reinterpret_cast<const int*>(wq + 24 * (size_t)K);
+  const int* w_lc = w_n + 4;
+  double* w_ld = reinterpret_cast<double*>(const_cast<int*>(w_lc) + 2 * MIX_LIST);
+  const int n = w_n[0];
+  if (g >= n) return;
+  const double qq = qn2[q];
+  const float* qrow = A.q32 + (int64_t)q * A.n_taps * A.F;
+  for (int e = g; e < n; e += ng) {
+    const int c = w_lc[e];
+    const double dot = fast ? pair_dot_fast_f64<NPER>(A, qrow, c, lane) : pair_dot_wave_f64(A, q, c, lane);
+    if (lane == 0) w_ld[e] = cosine_from_dot(dot, qq, cn2[c]);
+  }
+}
 
 // The streaming pass of the select, MIX_SPLIT blocks per query (a single CU pulls ~25 GB/s: one block per query spent
 // 21 us on the row's 320 KB, with 48 of the 256 CUs busy).  Block (q, s) streams slice s of row q: per-code minimum in
@@ -1314,13 +1311,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       w_lc[e] = l_c[e];
       w_lk[e] = l_k[e];
     }
-    if (tid == 0) {
-      w_n[0] = n;
-      ctl[5] = n ? atomicAdd(mix_flat_count(ws), n) : 0;      // this query's range of the launch's flat pair list
-    }
-    __syncthreads();
-    int* flat = mix_flat_entries(ws, Q, K) + ctl[5];
-    for (int e = tid; e < n; e += blockDim.x) flat[e] = q * MIX_LIST + e;
+    if (tid == 0) w_n[0] = n;
     SEL_STAMP(6);
     return;
   }
@@ -1334,7 +1325,6 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     const int* w_lk = w_lc + MIX_LIST;
     const double* w_ld = reinterpret_cast<const double*>(w_lk + MIX_LIST);
     n = w_n[0];
-    if (q == 0 && tid == 0) *mix_flat_count(ws) = 0;           // (the refine launch is done: left zero for the next one)
     for (int k = tid; k < K; k += blockDim.x) {
       best[k] = w_best[k];
       v[k] = w_v[k];
@@ -1480,10 +1470,10 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
 }
 
 extern "C" int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K) {
-  return (Q <= 0 || K <= 0) ? 0 : (int64_t)((size_t)Q * mix_ws_stride(K) + 16 + 4 * (size_t)Q * MIX_LIST);
+  return (Q <= 0 || K <= 0) ? 0 : (int64_t)((size_t)Q * mix_ws_stride(K));
 }
 extern "C" int64_t qpg_percode_select_mixed_ws_stride(int K) {       // bytes per query; query q's space starts at
-  return K <= 0 ? 0 : (int64_t)mix_ws_stride(K);                     // 16 + q x stride, its list length is the i32 at + 24 K
+  return K <= 0 ? 0 : (int64_t)mix_ws_stride(K);                     // q x stride, its list length is the i32 at + 24 K
 }
 
 extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
@@ -1525,8 +1515,7 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
   }
   unsigned char* w = static_cast<unsigned char*>(ws);
   if (ws)
-    QPG_REQUIRE(ws_bytes >= qpg_percode_select_mixed_ws_bytes(Q, K) && (reinterpret_cast<uintptr_t>(ws) % 16) == 0 &&
-                    (int64_t)Q * MIX_LIST < 0x7fffffffll,
+    QPG_REQUIRE(ws_bytes >= qpg_percode_select_mixed_ws_bytes(Q, K) && (reinterpret_cast<uintptr_t>(ws) % 16) == 0,
                 "%s: workspace too small or misaligned (qpg_percode_select_mixed_ws_bytes)", name);
 #define SEL_MIX_LAUNCH(DT, SH, PHASE, PRE)                                                                                  \
   hipLaunchKernelGGL((percode_select_mixed_f64_kernel<DT>), dim3(Q), dim3(1024), SH, qpg_stream(stream),               \
@@ -1548,10 +1537,8 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
     SEL_MIX_LAUNCH(double, sh1, 1, 0);
   }
   QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (lists)");
-  // ~70 list entries per query on dense data: 1024 blocks x 4 waves take one pair each at Q = 48
-  const int rblocks = Q >= 256 ? 4096 : 1024;
-  hipLaunchKernelGGL((select_refine_kernel<4>), dim3(rblocks), dim3(256), 0, qpg_stream(stream), A, Q, K, cn2, qn2, w,
-                     use_qlds);
+  const int rb = Q >= 512 ? 8 : (Q >= 128 ? 16 : 64);         // waves per query = 4 rb
+  hipLaunchKernelGGL((select_refine_kernel<4>), dim3(Q, rb), dim3(256), 0, qpg_stream(stream), A, K, cn2, qn2, w, use_qlds);
   QPG_LAUNCH_CHECK("select_refine_kernel");
   if (d_is_f32) SEL_MIX_LAUNCH(float, sh2, 2, 0); else SEL_MIX_LAUNCH(double, sh2, 2, 0);
   QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (merge)");

@@ -6,6 +6,7 @@
 // the host.  Float paths reproduce the reference's arithmetic: combined scores in float64 in the
 // reference's operation order, the 128-d phase-gate cosine in scikit-learn's float32 order.
 #include "qpg_common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
 // pose-signature distance table: out[p][c] = |sig[p] - sig[c]|_2 (f32), +inf on the diagonal
@@ -179,11 +180,23 @@ __global__ __launch_bounds__(256) void fuse_best_quad_kernel(const int16_t* __re
       mt = amin(mt, ArgMin{pos_score + (double)vt[e], c0 + e});
     }
   }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {
-    ma = amin(ma, ArgMin{__shfl_xor(ma.v, o, 64), __shfl_xor(ma.i, o, 64)});
-    mt = amin(mt, ArgMin{__shfl_xor(mt.v, o, 64), __shfl_xor(mt.i, o, 64)});
-  }
+  // argmin inside the 16-lane group: lane_xor (DPP moves, qpg_common.h) instead of __shfl_xor - a ds_bpermute_b32 costs a
+  // wave ~65 cycles and they do not overlap; the 24 of this reduction were most of a wave's time here
+  auto xchg = [](ArgMin m, auto tag) {
+    constexpr int PJ = decltype(tag)::value;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(m.v);
+    const unsigned int lo = (unsigned int)lane_xor<PJ>((int)(unsigned int)b);
+    const unsigned int hi = (unsigned int)lane_xor<PJ>((int)(unsigned int)(b >> 32));
+    return ArgMin{__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)), lane_xor<PJ>(m.i)};
+  };
+  ma = amin(ma, xchg(ma, std::integral_constant<int, 8>{}));
+  mt = amin(mt, xchg(mt, std::integral_constant<int, 8>{}));
+  ma = amin(ma, xchg(ma, std::integral_constant<int, 4>{}));
+  mt = amin(mt, xchg(mt, std::integral_constant<int, 4>{}));
+  ma = amin(ma, xchg(ma, std::integral_constant<int, 2>{}));
+  mt = amin(mt, xchg(mt, std::integral_constant<int, 2>{}));
+  ma = amin(ma, xchg(ma, std::integral_constant<int, 1>{}));
+  mt = amin(mt, xchg(mt, std::integral_constant<int, 1>{}));
   if (l16 == 0) {
     T0[task] = idx0[(int64_t)q * K + ma.i];
     T1[task] = idx1[(int64_t)q * K + mt.i];

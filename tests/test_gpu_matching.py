@@ -52,15 +52,16 @@ def test_tables_vs_reference_golden(name, prec):
                           np.argsort(g["aud_dist"], axis=1, kind="stable"))
 
 
-@pytest.mark.parametrize("order", ["text_after_sweep", "text_first", "audio_first", "one_stream"])
+@pytest.mark.parametrize("order", ["auto", "text_after_sweep", "text_first", "audio_first", "one_stream"])
 @pytest.mark.parametrize("name", GOLDENS)
 def test_knn_pred_vs_reference_golden(name, order):
     """End result of the clip: the (M,30) code indices the reference CLI wrote — bit-exact, whichever way the two
-    sides are scheduled (default: the text sweep waits for the end of the audio sweep on its own stream)."""
+    sides are scheduled (default "auto": the text side on its own stream behind the first 80 % of the audio sweep)."""
     g = load_golden(name)
     A, db, knn, te_i, te_c, M = _build(g["meta"], freq_rank=g["step_freq_score"])
-    knn.text_after_sweep = order == "text_after_sweep"
-    knn.audio_first = order == "audio_first"
+    if order != "auto":
+        knn.text_after_sweep = order == "text_after_sweep"
+        knn.audio_first = order == "audio_first"
     knn.overlap_sweeps = order != "one_stream"
     codes, phases, votes = knn.match_clip(te_i, te_c, M)
     assert codes.dtype == np.int64 and np.array_equal(codes, g["knn_pred"])

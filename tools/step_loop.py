@@ -17,8 +17,11 @@ ctx = rng.standard_normal((N, 30, 384)).astype(np.float32)
 phase = rng.standard_normal((N, 240, 4, 8)).astype(np.float32)
 db = GestureDB(synth.make_codes(N, 2), interp, ctx, phase, synth.make_signature(3), device=dev)
 knn = CodeKNN(db, rng=np.random.RandomState(123456))
-knn.audio_first = os.environ.get("QPG_AUDIO_FIRST") == "1"
-knn.text_after_sweep = os.environ.get("QPG_TEXT_AFTER", "1") == "1"
+if "QPG_AUDIO_FIRST" in os.environ:
+    knn.audio_first = os.environ["QPG_AUDIO_FIRST"] == "1"
+if "QPG_TEXT_AFTER" in os.environ:
+    knn.text_after_sweep = os.environ["QPG_TEXT_AFTER"] == "1"
+knn.text_lead = float(os.environ.get("QPG_TEXT_LEAD", knn.text_lead))
 knn.audio_kernel = os.environ.get("QPG_AUDIO_KERNEL", "hl")
 knn.tie_eps = float(os.environ.get("QPG_TIE_EPS", knn.tie_eps))
 te_i = torch.randn((M, 180, 1024), device=dev)

@@ -1,1 +1,13 @@
-for ta in 1 0; do for af in 0 1; do echo "TEXT_AFTER=$ta AUDIO_FIRST=$af"; QPG_TEXT_AFTER=$ta QPG_AUDIO_FIRST=$af python tools/step_loop.py 300 2>&1 | tail -1; done; done
+# bench.py under the three schedules of the text side, alternating (box-to-box variance is ~5 %: compare within a run)
+#   after: behind the audio sweep; --text-first: enqueued first on its own stream; QPG_BENCH_AUDIO_FIRST=1: behind the
+#   audio side's launches, no ordering
+for rep in 1 2 3; do
+  for mode in "after" "text-first" "audio-first"; do
+    fl=""; ev=""
+    [ $mode = text-first ] && fl="--text-first"
+    [ $mode = audio-first ] && ev="QPG_BENCH_AUDIO_FIRST=1"
+    [ $mode = after ] && ev="QPG_BENCH_AUDIO_FIRST=0"
+    env $ev python bench.py --no-f64-line --steps 400 $fl 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$mode', d['ms_per_step'], d['roofline']['kernel_ms'])"
+  done
+done
