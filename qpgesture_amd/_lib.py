@@ -205,6 +205,17 @@ def ptr(t):
 
 _cur_dev = None
 _dev_index = {}
+# torch's C entry points behind torch.cuda.current_device() / current_stream().cuda_stream: the Python wrappers cost ~1 and
+# ~3 us per call (lazy-init checks, a Stream object per call) and this module makes a dozen calls per 0.36 ms step
+_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+_raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _raw_stream(idx):
+    if _raw is not None:
+        return _raw(idx)
+    return torch.cuda.current_stream(idx).cuda_stream
+
 
 
 def call(name, device, *args):
@@ -222,10 +233,10 @@ def call(name, device, *args):
         if idx is None:
             idx = torch.cuda.current_device()
         _dev_index[device] = idx
-    if idx != torch.cuda.current_device():
+    if idx != _get_device():
         with torch.cuda.device(idx):
             return call(name, device, *args)
-    stream = torch.cuda.current_stream(idx).cuda_stream
+    stream = _raw_stream(idx)
     conv = []
     for a in args:
         if isinstance(a, torch.Tensor):

@@ -751,6 +751,8 @@ class CodeKNN:
         # with NO ordering - its GEMM trickles through under the sweep and the tables are ready before the audio select
         # is.  bench.py, alternating in one run (tools/try_orders.sh), ms per clip: behind the sweep 0.400-0.404,
         # text first 0.384-0.408, audio_first 0.360-0.374.  (`text_lead`: see sweep_audio.)
+        # (Enqueueing the text side even earlier - between the sweep's launch and the select's - starts its GEMM 50 us
+        # sooner and costs the sweep 25 us: 197 instead of 172.)
         mfma_text = (self.text_kernel == "mfma" and db.txt_sorted is not None and not sharded and
                      self.audio_precision != "exact")
         audio_first = getattr(self, "audio_first", None)

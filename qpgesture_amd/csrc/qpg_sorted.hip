@@ -131,6 +131,8 @@ __global__ __launch_bounds__(SORT_THREADS) void percode_select_sorted_kernel(
   // query row in LDS, the candidate row gathered (16 loads in flight per thread: the gather is latency-bound).  Measured
   // alternative: evaluating per CODE instead (buckets of (query, row) pairs, one block per code, the rows of a code read
   // once for all queries) is SLOWER - 465 us against ~200: every lane then gathers BOTH operands in 16-byte pieces.
+  // Four lanes per pair (one per chain, a lane's 96-128 floats all requested at once) is no faster either: 0.300 against
+  // 0.266 ms for the cfg-3 batch, 27 against 25 us for the matcher's text side.
   for (int e = tid; e < n; e += blockDim.x) {
     const int r = list[e];
     const bool z = r >= (int)R;

@@ -27,7 +27,8 @@ def prefilter_band(d):
 
 class SortedRows:
     """xn: f32 [n][d] sklearn-normalised rows on the device; codes: int tensor [n] (outside [0, K): the row can never win).
-    Builds: the non-zero rows sorted by code (stable: original order inside a code = first-wins), every code's segment
+    Builds: the non-zero rows - without exact duplicates of an earlier row of the same code - sorted by code (stable:
+    original order inside a code = first-wins), every code's segment
     padded to 16 rows with copies of its first row (a 16-row tile of the GEMM then lies inside ONE code and a padding row
     never lowers its minimum), the total padded to 32; `row_index` i32 [R] (original index, -1 padding), `row_code` i16 [R]
     (padding rows: bit 14 set; the tail beyond the last segment: code 0x1fff), `xs` f32 [R + 1][d] (row R: zeros), the
@@ -46,6 +47,8 @@ class SortedRows:
         self.zero_row = torch.where(zr == 0x7fffffff, torch.full_like(zr, -1), zr).to(torch.int32).contiguous()
         self.n_zero_rows = int(zi.numel())
         keep = torch.nonzero(valid & ~zero).reshape(-1)
+        keep = keep[self._first_of_duplicates(xn, cmt, keep)]
+        self.n_rows_kept = int(keep.numel())
         order = keep[torch.sort(cmt[keep], stable=True).indices]              # original indices, by (code, index)
         cd = cmt[order]
         cnt = torch.bincount(cd, minlength=K)
@@ -76,6 +79,34 @@ class SortedRows:
         self._cols = None
         self._Dm = None
         self._tmin = None
+
+    @staticmethod
+    def _first_of_duplicates(xn, codes, keep):
+        """Mask over `keep` (ascending original indices): False for a row that equals an EARLIER row of the same code.
+        Identical rows are at the identical distance from any query, so only the first can win (first-wins) - and real
+        per-frame text embeddings repeat (one sentence embedding over its frames, one embedding for silence:
+        /root/reference/process/make_beat_dataset.py:556-565), which would otherwise put thousands of exact ties into
+        every band.  Rows are grouped by (code, 64-bit hash of the row); inside a group every row is compared with the
+        group's first row, elementwise: a hash collision keeps a row, it never drops one."""
+        if keep.numel() == 0:
+            return torch.ones((0,), dtype=torch.bool, device=keep.device)
+        rows = xn[keep]
+        bits = rows.contiguous().view(torch.int32).to(torch.int64)
+        g = torch.Generator(device="cpu").manual_seed(0x5eed)
+        w = (torch.randint(1, 2 ** 31 - 1, (rows.shape[1],), generator=g, dtype=torch.int64) * 2 + 1).to(rows.device)
+        h = (bits * w).sum(1)                                                  # wraps mod 2^64
+        key_order = torch.argsort(h, stable=True)                              # (ascending index inside equal hashes)
+        key_order = key_order[torch.argsort(codes[keep][key_order], stable=True)]
+        ck, hk = codes[keep][key_order], h[key_order]
+        new_group = torch.ones_like(ck, dtype=torch.bool)
+        new_group[1:] = (ck[1:] != ck[:-1]) | (hk[1:] != hk[:-1])
+        first = torch.cummax(torch.where(new_group, torch.arange(ck.numel(), device=ck.device),
+                                         torch.zeros_like(ck)), 0).values      # position of the group's first row
+        same = (rows[key_order] == rows[key_order[first]]).all(1)
+        drop_sorted = same & ~new_group
+        mask = torch.ones((keep.numel(),), dtype=torch.bool, device=keep.device)
+        mask[key_order[drop_sorted]] = False
+        return mask
 
     def select(self, qn, absent, stats, dist=None, idx=None, nn=None, rank=None):
         """qn: f32 [Q][d] sklearn-normalised queries.  Prefilter GEMM + banded exact select; per-code tables (dist f32

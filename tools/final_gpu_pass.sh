@@ -14,6 +14,10 @@ timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_20.json 2> $O/bench
 python tools/make_profile_summary.py $O/prof $O/bench_n1 "python bench.py (N=1, 200 steps) under rocprofv3 --kernel-trace --stats" > /dev/null 2>&1
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/$O/tl -- python $R/tools/step_loop.py 30 > $R/$O/tl.log 2>&1 )
 python tools/step_timeline.py $O/tl 30 > $O/step_timeline.md 2>&1
+timeout 900 python bench.py --clips 16 > $O/bench_clips16.json 2> $O/bench_clips16.err; echo "clips16 rc=$?" >> $O/rc.txt
+timeout 900 python bench.py --scaling strong > $O/bench_strong.json 2> $O/bench_strong.err; echo "strong rc=$?" >> $O/rc.txt
+timeout 900 python bench.py --workload cfg3 > $O/bench_cfg3.json 2> $O/bench_cfg3.err; echo "cfg3 rc=$?" >> $O/rc.txt
+timeout 900 python bench.py --data speechlike > $O/bench_speechlike.json 2> $O/bench_speechlike.err; echo "speechlike rc=$?" >> $O/rc.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_$c -o a -- python $R/tools/bench_audio_hl.py > $R/$O/pmc_$c.log 2>&1 ); echo "pmc $c rc=$?" >> $O/rc.txt
   python tools/pmc_summary.py $O/pmc_$c audio > $O/pmc_$c.txt 2>&1
