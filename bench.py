@@ -535,6 +535,41 @@ def main():
                             "achieved": round(flops / (k6 * 1e-3) / 1e12, 3), "peak": F64_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(flops / (k6 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
                             "codes_equal_default_path": bool(torch.equal(c64, codes))}
+    if (mixed and not sharded_run and can_pipe and pipe is None and not a.no_f64_line and
+            os.environ.get("QPG_BENCH_NO_PIPELINED", "") != "1"):
+        # the same per-clip launches with three clips in flight (ClipPipeline: the next clips' sweeps are enqueued before a
+        # clip's indices are collected, so the host's ~50 us between a step's last GPU event and the next step's first
+        # launch and the thinly occupied tail overlap another clip's sweep); every clip's indices still reach the host
+        # inside the timed region.  A throughput figure beside the one-clip-at-a-time `value`, not a replacement for it.
+        from qpgesture_amd.code_knn import ClipPipeline
+        p3 = ClipPipeline(db, depth=3, rng=np.random.RandomState(123456))
+        for ln in p3.lanes:
+            ln["knn"].overlap_sweeps = knn.overlap_sweeps
+            ln["knn"].audio_precision = knn.audio_precision
+            ln["knn"].audio_kernel = knn.audio_kernel
+
+        def run3(n):
+            pending, res = [], None
+            for _ in range(n):
+                if len(pending) == p3.depth:
+                    res = p3.collect(pending.pop(0))[0]
+                pending.append(p3.submit(te_interp, te_ctx, M, seed_code=seed_code, seed_phase=seed_phase_d))
+            while pending:
+                res = p3.collect(pending.pop(0))[0]
+            return torch.from_numpy(res.astype(np.int32))
+        run3(30)
+        gc.collect()
+        gc.disable()
+        fence()
+        t7 = time.perf_counter()
+        c3 = run3(100)
+        fence()
+        d7 = time.perf_counter() - t7
+        gc.enable()
+        out["pipelined"] = {"clips_in_flight": 3, "steps": 100, "ms_per_step": round(d7 / 100 * 1e3, 4),
+                            "frames_per_s": round(frames_per_step * 100 / d7, 1),
+                            "codes_equal_default_path": bool(torch.equal(c3.reshape(-1), codes.reshape(-1).to(torch.int32))),
+                            "rematched_steps": p3.fallbacks}
     if serial is not None:
         serial["roofline_frac"] = (round(alg_bytes / (serial["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if hl else
                                    round(flops / (serial["kernel_ms"] * 1e-3) / 1e12 / peak, 4))
