@@ -222,7 +222,8 @@ int qpg_text_percode_f16(qpg_ctx*, void* stream, const void* xh, const float* nr
  *       `band` >= 2 x (prefilter error + sklearn's own rounding against the real value): derivation in
  *       csrc/qpg_sorted.hip (8.6e-5 at D = 512).  stats[1] |= 1 if a band list overflowed: run
  *       qpg_text_percode_f32 instead.  out_rank optional: i16 [Q][K] ranks of the table rows (qpg_rank_rows_f32's);
- *       out_nn optional: the query's global nearest neighbour (original index). */
+ *       out_nn optional: the query's global nearest neighbour (original index).  idx_base is added to every index written;
+ *       q_block / block_stride: the exchange layout of qpg_percode_select_f32 (row shards; no ranks / nn then). */
 int64_t qpg_hl_rows_bytes(int64_t R, int D);
 int64_t qpg_hl_cols_bytes(int Q, int D);
 int qpg_hl_pack_rows(qpg_ctx*, void* stream, const float* xs, int64_t R, int D, void* image, int64_t image_bytes);
@@ -233,7 +234,8 @@ int qpg_percode_select_sorted_f32(qpg_ctx*, void* stream, const float* Dm, int64
                                   int Q, int64_t R, const int16_t* row_code, const int32_t* row_index,
                                   const int32_t* zero_row, const int32_t* code_tile, int K, float band, const float* qn,
                                   const float* xs, int D, float absent, float* out_dist, int32_t* out_idx,
-                                  int16_t* out_rank, int32_t* out_nn, int32_t* stats);
+                                  int16_t* out_rank, int32_t* out_nn, int32_t* stats, int32_t idx_base, int q_block,
+                                  int64_t block_stride);
 
 /* vq-wav2vec audio sweep (the mode the paper describes; flags use_wavvq/use_feature of GestureKNN.py:557-560):
  * D[q][c] = Levenshtein distance (unit costs, python-Levenshtein distance()) between the 11-symbol strings of

@@ -228,7 +228,7 @@ class GestureDB:
         # text candidates sorted by code + their split-f16 image for the bounded prefilter (sorted_rows.SortedRows,
         # csrc/qpg_sorted.hip): rows normalised by the kernel the exact sweep's candidates are normalised by
         self.txt_sorted = None
-        if text_prefilter and world == 1 and self.n_local and self.Dt % 128 == 0 and self.K < 0x2000:
+        if text_prefilter and self.n_local and self.Dt % 128 == 0 and self.K < 0x2000:
             rows_f = ctx_d[:, torch.as_tensor(np.asarray(rows, np.int64), device=dev), :].reshape(self.Ct, self.Dt)
             rows_n = torch.empty_like(rows_f)
             _lib.call("qpg_l2_normalize_rows_f32", dev, rows_f.contiguous(), self.Ct, self.Dt, rows_n)
@@ -506,9 +506,14 @@ class CodeKNN:
             qn = torch.empty_like(queries)
             _lib.call("qpg_l2_normalize_rows_f32", dev, queries, Q, db.Dt, qn)
         self._last_text_mfma = False
-        if (self.text_kernel == "mfma" and db.txt_sorted is not None and out is None and reduce and Q > 0 and
-                not self.force_sharded and self.audio_precision != "exact"):
+        if (self.text_kernel == "mfma" and db.txt_sorted is not None and Q > 0 and self.audio_precision != "exact" and
+                ((out is None and reduce and db.world == 1) or (out is not None and not reduce))):
             self._last_text_mfma = True
+            if out is not None:           # row shard: straight into the exchange buffer, global indices, merged later
+                dist, idx, qb, bs = out
+                db.txt_sorted.select(qn, float(ABSENT_DIST), self._guard_stats, dist=dist, idx=idx,
+                                     idx_base=db.idx_base * db.Gt, q_block=qb, block_stride=bs)
+                return dist, idx
             rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if want_rank else None
             dist, idx, _ = db.txt_sorted.select(qn, float(ABSENT_DIST), self._guard_stats, rank=rank)
             if want_rank:
@@ -760,8 +765,7 @@ class CodeKNN:
         # text first 0.384-0.408, audio_first 0.360-0.374.  (`text_lead`: see sweep_audio.)
         # (Enqueueing the text side even earlier - between the sweep's launch and the select's - starts its GEMM 50 us
         # sooner and costs the sweep 25 us: 197 instead of 172.)
-        mfma_text = (self.text_kernel == "mfma" and db.txt_sorted is not None and not sharded and
-                     self.audio_precision != "exact")
+        mfma_text = self.text_kernel == "mfma" and db.txt_sorted is not None and self.audio_precision != "exact"
         audio_first = getattr(self, "audio_first", None)
         audio_first = mfma_text if audio_first is None else bool(audio_first)
         after = overlap and self.text_after_sweep and not audio_first and not self.use_wavvq

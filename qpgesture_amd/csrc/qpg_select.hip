@@ -430,6 +430,12 @@ __global__ __launch_bounds__(1024) void percode_select_kernel(const T* __restric
 template <typename T, typename F>
 __device__ __forceinline__ void block_stable_ranks(const T* v, int K, int* cnt, F&& emit) {
   const int tid = threadIdx.x;
+  if (K <= 512 && K >= 64 && (int)blockDim.x >= 256) {      // sorted (qpg_common.h) in 6 KB of static LDS: ~5 us, not 15
+    __shared__ unsigned long long rank_skey[512];
+    __shared__ int rank_scode[512];
+    block_sorted_ranks(v, K, rank_skey, rank_scode, emit);
+    return;
+  }
   const int P = (int)blockDim.x >= 2 * K ? (int)blockDim.x / K : 1;
   if (P == 1) {
     for (int k = tid; k < K; k += blockDim.x) {
@@ -1918,6 +1924,7 @@ __global__ void merge_mixed_zero_counts_kernel(unsigned char* __restrict__ req, 
   for (int w = threadIdx.x; w < W; w += blockDim.x) *reinterpret_cast<long long*>(req + (int64_t)w * req_stride) = 0;
 }
 
+#define MM_LREQ 2048      // requests a block collects in LDS before its range reservation (more: direct global atomics)
 __global__ __launch_bounds__(1024) void merge_mixed_phase1_kernel(
     const unsigned char* __restrict__ recv, int W, int64_t src_stride, int64_t dist_off, int64_t idx_off, int K,
     double absent, double eps1, int R, unsigned char* __restrict__ req, int64_t req_stride,
@@ -1972,12 +1979,19 @@ __global__ __launch_bounds__(1024) void merge_mixed_phase1_kernel(
     }
   }
   __syncthreads();
-  auto emit = [&](int w, int k, int cand) {
-    // Claim the request slot first and write it before anything else can fail: a claimed slot j < R is ALWAYS a valid
-    // request (the shard evaluates min(count, R) of them), and a flag-list slot is only claimed for a written request,
-    // so fl_cnt never counts an unwritten entry (round 2 reserved both, then bailed out: phase 2 decoded stale words).
-    int* cntp = reinterpret_cast<int*>(req + (int64_t)w * req_stride);
-    const int j = atomicAdd(cntp, 1);
+  // Requests are first collected in LDS and counted per destination shard, then the block reserves ONE range per shard
+  // (3 300 global atomicAdds per step on W counters took 50 us of this kernel at W = 1): slot j = range base + position.
+  __shared__ int cw[64], cbase[64], n_l;
+  unsigned long long* lq = reinterpret_cast<unsigned long long*>(rkc + K);        // [MM_LREQ] (k, w, cand)
+  int* lp = reinterpret_cast<int*>(lq + MM_LREQ);                                // [MM_LREQ] position inside the shard's range
+  const bool agg = W <= 64;
+  if (threadIdx.x < 64) cw[threadIdx.x] = 0;
+  if (threadIdx.x == 0) n_l = 0;
+  __syncthreads();
+  auto finish = [&](int w, int k, int cand, int j) {
+    // A claimed slot j < R is ALWAYS written (the shard evaluates min(count, R) of them), and a flag-list slot is only
+    // claimed for a written request, so fl_cnt never counts an unwritten entry (round 2 reserved both, then bailed out:
+    // phase 2 decoded stale words).
     if (j >= R) {
       atomicOr(&stats[1], 4);                                    // request overflow: the clip is re-matched (host)
       return;
@@ -1991,6 +2005,17 @@ __global__ __launch_bounds__(1024) void merge_mixed_phase1_kernel(
     }
     fl[(int64_t)q * MM_FL + pos] = ((unsigned long long)k << 40) | ((unsigned long long)w << 32) | (unsigned int)j;
   };
+  auto emit = [&](int w, int k, int cand) {
+    if (agg) {
+      const int pos = atomicAdd(&n_l, 1);
+      if (pos < MM_LREQ) {
+        lq[pos] = ((unsigned long long)k << 40) | ((unsigned long long)w << 32) | (unsigned int)cand;
+        lp[pos] = atomicAdd(&cw[w], 1);
+        return;
+      }
+    }
+    finish(w, k, cand, atomicAdd(reinterpret_cast<int*>(req + (int64_t)w * req_stride), 1));      // (direct)
+  };
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     if (bi[k] < 0) continue;
     if (cnt[k] >= 2) {
@@ -2003,6 +2028,18 @@ __global__ __launch_bounds__(1024) void merge_mixed_phase1_kernel(
     }
   }
   __syncthreads();
+  if (agg) {
+    if ((int)threadIdx.x < W && cw[threadIdx.x] > 0)
+      cbase[threadIdx.x] = atomicAdd(reinterpret_cast<int*>(req + (int64_t)threadIdx.x * req_stride), cw[threadIdx.x]);
+    __syncthreads();
+    const int nl = n_l < MM_LREQ ? n_l : MM_LREQ;
+    for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+      const unsigned long long x = lq[i];
+      const int k = (int)(x >> 40), w = (int)((x >> 32) & 0xff);
+      finish(w, k, (int)(unsigned int)(x & 0xffffffffu), cbase[w] + lp[i]);
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) fl_cnt[q] = n_fl < MM_FL ? n_fl : MM_FL;
 }
 
@@ -2014,7 +2051,10 @@ __global__ __launch_bounds__(256) void shard_refine_kernel(GuardArgs A, const un
   const int o = blockIdx.x, lane = threadIdx.x & 63;
   const int g = blockIdx.y * 4 + (threadIdx.x >> 6), ng = gridDim.y * 4;
   const unsigned char* blk = req_recv + (int64_t)o * req_stride;
-  int n = *reinterpret_cast<const int*>(blk);
+  __shared__ int n_s;                                         // (one read of the count per block: thousands of waves
+  if (threadIdx.x == 0) n_s = *reinterpret_cast<const int*>(blk);   // reading one address queue on its L2 channel)
+  __syncthreads();
+  int n = n_s;
   n = n < R ? n : R;
   const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(blk + 8);
   double* out = reinterpret_cast<double*>(resp + (int64_t)o * resp_stride);
@@ -2157,7 +2197,8 @@ extern "C" int qpg_merge_mixed_phase1_f64(qpg_ctx* ctx, void* stream, const void
   hipLaunchKernelGGL(merge_mixed_zero_counts_kernel, dim3(1), dim3(256), 0, qpg_stream(stream),
                      static_cast<unsigned char*>(req), req_stride, W);
   QPG_LAUNCH_CHECK("merge_mixed_zero_counts_kernel");
-  hipLaunchKernelGGL(merge_mixed_phase1_kernel, dim3(Q), dim3(1024), (size_t)K * 32, qpg_stream(stream),
+  hipLaunchKernelGGL(merge_mixed_phase1_kernel, dim3(Q), dim3(1024), (size_t)K * 32 + 8 + 12 * (size_t)MM_LREQ,
+                     qpg_stream(stream),
                      static_cast<const unsigned char*>(recv), W, src_stride, dist_off, idx_off, K, absent, eps1, R,
                      static_cast<unsigned char*>(req), req_stride, prov_d, prov_i, fl, fl_cnt, stats, MM_FL);
   QPG_LAUNCH_CHECK("merge_mixed_phase1_kernel");
@@ -2185,7 +2226,11 @@ extern "C" int qpg_shard_refine_f64(qpg_ctx* ctx, void* stream, const void* req_
     return QPG_OK;
   }
   const int fast = (n_taps == 6 && F == 1024) ? 1 : 0;
-  hipLaunchKernelGGL(shard_refine_kernel, dim3(W, 64), dim3(256), 0, qpg_stream(stream), A,
+  // a request is ~12 us of dependent gathers whatever the wave count: enough waves for ONE round at the usual ~3 300
+  // requests per owner and step (4 W ry >= 4096; W = 1 with 256 waves took 13 rounds, 120 us); the rest leave at once
+  int ry = 1024 / W;
+  ry = ry < 64 ? 64 : ry;
+  hipLaunchKernelGGL(shard_refine_kernel, dim3(W, ry), dim3(256), 0, qpg_stream(stream), A,
                      static_cast<const unsigned char*>(req_recv), req_stride, R, q_stride, cand_base, cn2, qn2,
                      static_cast<unsigned char*>(resp), resp_stride, fast);
   QPG_LAUNCH_CHECK("shard_refine_kernel");

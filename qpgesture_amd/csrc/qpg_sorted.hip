@@ -55,7 +55,8 @@ __global__ __launch_bounds__(SORT_THREADS) void percode_select_sorted_kernel(
     const float* __restrict__ Dm, int64_t ldD, const float* __restrict__ tmin, int64_t ldT, int64_t R,
     const int16_t* __restrict__ row_code, const int32_t* __restrict__ row_index, const int32_t* __restrict__ zero_row,
     const int32_t* __restrict__ code_tile, int K, float band, const float* __restrict__ qn, const float* __restrict__ xs,
-    int Dd, float absent, float* __restrict__ out_dist, int32_t* __restrict__ out_idx, int32_t* __restrict__ stats) {
+    int Dd, float absent, float* __restrict__ out_dist, int32_t* __restrict__ out_idx, int32_t* __restrict__ stats,
+    int32_t idx_base, int q_block, int64_t block_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int S = gridDim.y, s = blockIdx.y;
   const int k0 = (int)((int64_t)s * K / S), k1 = (int)((int64_t)(s + 1) * K / S), KL = k1 - k0;
@@ -163,12 +164,19 @@ __global__ __launch_bounds__(SORT_THREADS) void percode_select_sorted_kernel(
     atomicMin(&ebest[cd - k0], ((unsigned long long)okey32(dist) << 32) | (unsigned int)oi);
   }
   __syncthreads();
-  // (4) this range's part of the tables
+  // (4) this range's part of the tables.  Exchange layout (sharded DB): row q lives in block q / q_block of a byte buffer
+  // whose blocks are block_stride bytes apart (qpg_percode_select_f32's); indices leave as global candidate indices.
+  if (q_block > 0) {
+    const int64_t shift = (int64_t)(q / q_block) * block_stride;
+    const int64_t rowoff = (int64_t)(q % q_block) * K - (int64_t)q * K;
+    out_dist = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out_dist) + shift) + rowoff;
+    out_idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(out_idx) + shift) + rowoff;
+  }
   for (int k = tid; k < KL; k += blockDim.x) {
     const unsigned long long kv = ebest[k];
     const bool have = kv != ~0ull;
     out_dist[(int64_t)q * K + k0 + k] = have ? okey32_value((unsigned int)(kv >> 32)) : absent;
-    out_idx[(int64_t)q * K + k0 + k] = have ? (int32_t)(kv & 0xffffffffu) : -1;
+    out_idx[(int64_t)q * K + k0 + k] = have ? (int32_t)(kv & 0xffffffffu) + idx_base : -1;
   }
 }
 
@@ -215,7 +223,7 @@ extern "C" int qpg_percode_select_sorted_f32(qpg_ctx* ctx, void* stream, const f
                                              const int32_t* row_index, const int32_t* zero_row, const int32_t* code_tile,
                                              int K, float band, const float* qn, const float* xs, int Dd, float absent,
                                              float* out_dist, int32_t* out_idx, int16_t* out_rank, int32_t* out_nn,
-                                             int32_t* stats) {
+                                             int32_t* stats, int32_t idx_base, int q_block, int64_t block_stride) {
   const char* name = "qpg_percode_select_sorted_f32";
   QPG_REQUIRE(ctx && Dm && tile_min && row_code && row_index && code_tile && qn && xs && out_dist && out_idx,
               "%s: null pointer", name);
@@ -223,13 +231,17 @@ extern "C" int qpg_percode_select_sorted_f32(qpg_ctx* ctx, void* stream, const f
                   K <= 2048 && K <= 0x1fff && Dd > 0 && (Dd % 16) == 0 && (reinterpret_cast<uintptr_t>(xs) % 16) == 0 &&
                   (reinterpret_cast<uintptr_t>(qn) % 16) == 0,
               "%s: bad size / alignment (R %% 16 == 0, D %% 16 == 0, K <= 2048)", name);
+  QPG_REQUIRE(q_block >= 0 && idx_base >= 0 &&
+                  (q_block == 0 || (!out_rank && !out_nn && Q % q_block == 0 && block_stride % 8 == 0)),
+              "%s: block layout needs Q %% q_block == 0, an 8-byte multiple stride and no rank / nn output", name);
   if (Q == 0) return QPG_OK;
   const int S = K >= 32 * SORT_SPLIT ? SORT_SPLIT : (K >= 32 ? K / 32 : 1);
   const int KLmax = ((K + S - 1) / S + 4) & ~3;          // (multiple of 4: keeps qrow 16-byte aligned)
   const size_t sh = 12 * (size_t)KLmax + 4 * (size_t)SORT_LIST + 4 * (size_t)SORT_TILES + 4 * (size_t)Dd;
   QPG_REQUIRE(sh <= 64 * 1024, "%s: K / D too large for the LDS tables", name);
   hipLaunchKernelGGL(percode_select_sorted_kernel, dim3(Q, S), dim3(SORT_THREADS), sh, qpg_stream(stream), Dm, ldD, tile_min,
-                     ldT, R, row_code, row_index, zero_row, code_tile, K, band, qn, xs, Dd, absent, out_dist, out_idx, stats);
+                     ldT, R, row_code, row_index, zero_row, code_tile, K, band, qn, xs, Dd, absent, out_dist, out_idx, stats,
+                     idx_base, q_block, block_stride);
   QPG_LAUNCH_CHECK("percode_select_sorted_kernel");
   if (out_rank || out_nn) {
     hipLaunchKernelGGL(sorted_finish_kernel, dim3(Q), dim3(256), 12 * (size_t)rank_sort_pow2(K) + 4 * (size_t)K, qpg_stream(stream),

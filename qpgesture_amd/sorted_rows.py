@@ -108,11 +108,12 @@ class SortedRows:
         mask[key_order[drop_sorted]] = False
         return mask
 
-    def select(self, qn, absent, stats, dist=None, idx=None, nn=None, rank=None):
+    def select(self, qn, absent, stats, dist=None, idx=None, nn=None, rank=None, idx_base=0, q_block=0, block_stride=0):
         """qn: f32 [Q][d] sklearn-normalised queries.  Prefilter GEMM + banded exact select; per-code tables (dist f32
         [Q][K], idx i32 [Q][K] original row indices), optionally the nearest neighbours nn i32 [Q] and the ranks of the
         table rows (rank i16 [Q][K]).  An overflowing band list ORs 1 into stats[1] (the caller re-evaluates on the exact
-        sweep)."""
+        sweep).  idx_base is added to the indices; q_block / block_stride: the row shards' exchange layout (dist / idx are
+        then views of the exchange buffer; no ranks)."""
         dev, Q = self.device, qn.shape[0]
         lib = _lib.load()
         nb = int(lib.qpg_hl_cols_bytes(Q, self.d))
@@ -129,5 +130,5 @@ class SortedRows:
                   self._tmin, self.R // 16)
         _lib.call("qpg_percode_select_sorted_f32", dev, self._Dm, self.R, self._tmin, self.R // 16, Q, self.R,
                   self.row_code, self.row_index, self.zero_row, self.code_tile, self.K, self.band, qn, self.xs, self.d,
-                  absent, dist, idx, rank, nn, stats)
+                  absent, dist, idx, rank, nn, stats, int(idx_base), int(q_block), int(block_stride))
         return dist, idx, nn

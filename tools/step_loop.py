@@ -21,6 +21,12 @@ if "QPG_AUDIO_FIRST" in os.environ:
     knn.audio_first = os.environ["QPG_AUDIO_FIRST"] == "1"
 if "QPG_TEXT_AFTER" in os.environ:
     knn.text_after_sweep = os.environ["QPG_TEXT_AFTER"] == "1"
+if os.environ.get("QPG_FORCE_SHARDED") == "1":          # the row-shard code path over RCCL with world_size 1
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    knn.force_sharded = True
 knn.text_lead = float(os.environ.get("QPG_TEXT_LEAD", knn.text_lead))
 knn.audio_kernel = os.environ.get("QPG_AUDIO_KERNEL", "hl")
 knn.tie_eps = float(os.environ.get("QPG_TIE_EPS", knn.tie_eps))
@@ -34,7 +40,7 @@ g = knn.capture_clip_graph(M) if graph else None
 def step():
     if graph:
         return g.run(te_i, te_c, sc, spd)[0].cpu()
-    T = knn.sweep_tables(te_i, te_c, M)
+    T = knn.sweep_tables(te_i, te_c, M, owner_blocks=knn.force_sharded)
     return knn.walk(T, M, 0, seed_code=sc, seed_phase=spd, sync=False)[0].cpu()
 
 
