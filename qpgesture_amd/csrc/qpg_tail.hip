@@ -6,6 +6,7 @@
 // the host.  Float paths reproduce the reference's arithmetic: combined scores in float64 in the
 // reference's operation order, the 128-d phase-gate cosine in scikit-learn's float32 order.
 #include "qpg_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
@@ -197,6 +198,85 @@ __global__ __launch_bounds__(256) void fuse_best_quad_kernel(const int16_t* __re
   mt = amin(mt, xchg(mt, std::integral_constant<int, 2>{}));
   ma = amin(ma, xchg(ma, std::integral_constant<int, 1>{}));
   mt = amin(mt, xchg(mt, std::integral_constant<int, 1>{}));
+  if (l16 == 0) {
+    T0[task] = idx0[(int64_t)q * K + ma.i];
+    T1[task] = idx1[(int64_t)q * K + mt.i];
+  }
+}
+
+// The same tables again, by BRANCH AND BOUND over the ranks (round 3).  A rank row is a permutation of 0..K-1 and the
+// other two addends are non-negative, so the fused score of the code at rank r is >= r: scanning the codes of step q in
+// rank order (inv[r] = code at rank r, rebuilt in LDS per block), a 16-lane group can stop as soon as the next chunk's
+// first rank exceeds the best score so far - about 2 x sqrt(K) ranks instead of K codes (three chunks of 16 at K = 512
+// instead of 32 codes per lane; scanned four chunks at a time).  Same f64 operations per visited code, `(pos + freq * 0.05) + rank`, and the lowest code
+// index among equal scores (a later rank r == best with a zero pose / frequency part can still tie: the scan continues
+// while r <= best).  Block = the 16 previous codes p0..p0+15 of one step q (K % 16 == 0).  A row that is not a permutation
+// (never produced by the rank kernels; checked anyway) makes its block scan every code.
+__global__ __launch_bounds__(256) void fuse_best_ranked_kernel(const int16_t* __restrict__ rank0,
+                                                               const int32_t* __restrict__ idx0,
+                                                               const int16_t* __restrict__ rank1,
+                                                               const int32_t* __restrict__ idx1,
+                                                               const int16_t* __restrict__ pos_rank,
+                                                               const int16_t* __restrict__ freq_rank, int Q, int K,
+                                                               int32_t* __restrict__ T0, int32_t* __restrict__ T1) {
+  extern __shared__ __attribute__((aligned(16))) int16_t inv[];          // [2][K]
+  __shared__ int bad;
+  const int tid = threadIdx.x, l16 = tid & 15;
+  const int64_t task = (int64_t)blockIdx.x * 16 + (tid >> 4);            // (q, p): one per 16-lane group
+  const int q = (int)(((int64_t)blockIdx.x * 16) / K);
+  const int p = (int)(task - (int64_t)q * K);
+  if (tid == 0) bad = 0;
+  for (int c = tid; c < 2 * K; c += blockDim.x) inv[c] = -1;
+  __syncthreads();
+  for (int c = tid; c < K; c += blockDim.x) {
+    const int ra = rank0[(int64_t)q * K + c], rt = rank1[(int64_t)q * K + c];
+    if ((unsigned)ra < (unsigned)K) inv[ra] = (int16_t)c; else bad = 1;
+    if ((unsigned)rt < (unsigned)K) inv[K + rt] = (int16_t)c; else bad = 1;
+  }
+  __syncthreads();
+  for (int c = tid; c < 2 * K; c += blockDim.x)
+    if (inv[c] < 0) bad = 1;
+  __syncthreads();
+  const bool full = bad != 0;
+  const int16_t* pr = pos_rank + (int64_t)p * K;
+  auto xchg = [](ArgMin m, auto tag) {
+    constexpr int PJ = decltype(tag)::value;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(m.v);
+    const unsigned int lo = (unsigned int)lane_xor<PJ>((int)(unsigned int)b);
+    const unsigned int hi = (unsigned int)lane_xor<PJ>((int)(unsigned int)(b >> 32));
+    return ArgMin{__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)), lane_xor<PJ>(m.i)};
+  };
+  // (four chunks of 16 ranks per round, their gathers in flight together: a task needs ~3 chunks, and a round is one
+  // dependent gather latency either way)
+  auto scan = [&](const int16_t* iv, const int16_t* rk) {
+    ArgMin m{__builtin_inf(), 0x7fffffff};
+    for (int base = 0; base < K; base += 64) {
+      if (!full && (double)base > m.v) break;                 // (m is uniform over the group after the reduction)
+      int c[4];
+      double pv[4], fv[4], rr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = base + 16 * u + l16;
+        const bool ok = r < K;
+        c[u] = ok ? (full ? r : (int)iv[r]) : -1;
+        pv[u] = ok ? (double)pr[c[u]] : 0.0;
+        fv[u] = ok ? (double)freq_rank[c[u]] : 0.0;
+        rr[u] = ok ? (full ? (double)rk[c[u]] : (double)r) : 0.0;
+      }
+      ArgMin x{__builtin_inf(), 0x7fffffff};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c[u] >= 0) x = amin(x, ArgMin{(pv[u] + fv[u] * 0.05) + rr[u], c[u]});
+      x = amin(x, xchg(x, std::integral_constant<int, 8>{}));
+      x = amin(x, xchg(x, std::integral_constant<int, 4>{}));
+      x = amin(x, xchg(x, std::integral_constant<int, 2>{}));
+      x = amin(x, xchg(x, std::integral_constant<int, 1>{}));
+      m = amin(m, x);
+    }
+    return m;
+  };
+  const ArgMin ma = scan(inv, rank0 + (int64_t)q * K);
+  const ArgMin mt = scan(inv + K, rank1 + (int64_t)q * K);
   if (l16 == 0) {
     T0[task] = idx0[(int64_t)q * K + ma.i];
     T1[task] = idx1[(int64_t)q * K + mt.i];
@@ -585,7 +665,10 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   int32_t* T1 = gate_tables + (int64_t)Q * K;
   const bool rows16 = ((reinterpret_cast<uintptr_t>(aud_rank) | reinterpret_cast<uintptr_t>(txt_rank) |
                         reinterpret_cast<uintptr_t>(pos_rank) | reinterpret_cast<uintptr_t>(freq_rank)) & 15) == 0;
-  if (mode == 0 && (K % 128) == 0 && rows16) {
+  if (mode == 0 && (K % 16) == 0 && K <= 4096 && getenv("QPG_FUSE_BEST_QUAD") == nullptr) {
+    hipLaunchKernelGGL(fuse_best_ranked_kernel, dim3((unsigned)(((int64_t)Q * K) / 16)), dim3(256), 4 * (size_t)K,
+                       qpg_stream(stream), aud_rank, aud_idx, txt_rank, txt_idx, pos_rank, freq_rank, Q, K, T0, T1);
+  } else if (mode == 0 && (K % 128) == 0 && rows16) {
     hipLaunchKernelGGL(fuse_best_quad_kernel, dim3((unsigned)(((int64_t)Q * K + 15) / 16)), dim3(256), 0,
                        qpg_stream(stream), aud_rank, aud_idx, txt_rank, txt_idx, pos_rank, freq_rank, Q, K, T0, T1);
   } else {
