@@ -326,13 +326,16 @@ struct HlArgs {
 #ifndef HL_WPB
 #define HL_WPB 4           // database windows per block (2 waves each)
 #endif
+#ifndef HL_MINW
+#define HL_MINW 2          // waves per SIMD the register allocation must leave room for
+#endif
 #define HL_THREADS (128 * HL_WPB)
 #define HL_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 // MODE 0: the audio sweep (27 live super-rows per window, shifted-add epilogue).  MODE 1: plain distance GEMM over
 // generic rows (qpg_hl_gemm_distance: groups of 32 rows, all live; D[q][row] = 1 - <row, q> for unit-norm operands;
 // the chunk's 96 columns are 96 queries).
 template <int MODE>
-__global__ __launch_bounds__(HL_THREADS, 2) void audio_cosine_hl_kernel(HlArgs a) {
+__global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(HlArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 * HL_KS * HL_CT * 2 * HL_PIECE bytes
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wl = w >> 1, t = w & 1;                           // window of the block, row tile

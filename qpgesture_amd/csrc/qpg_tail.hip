@@ -536,6 +536,9 @@ __global__ __launch_bounds__(256) void gate_table_kernel(TailArgs A, GateGeom ge
   int pb_unused;
   const float* head = cand_block(A, k, ck, &pb_unused);
   // a = [prev[48:], head[:80]], b = [prev[80:], head[:48]]  (GestureKNN.py:636); lane l owns e = 16g + 4u + l
+  // (Reading the vectors as 16-byte pieces, 8 per lane, and transposing 4 x 4 inside the quad with DPP moves - 16 vector
+  // loads per lane instead of 128 scalar ones - measured SLOWER, 20.5 us against 17.5: the registers of the staged pieces
+  // cost more occupancy than the load instructions cost issue slots.)
   float xa[32], xb[32];
   float sa = 0.f, sb = 0.f;
 #pragma unroll
