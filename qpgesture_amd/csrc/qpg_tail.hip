@@ -6,7 +6,6 @@
 // the host.  Float paths reproduce the reference's arithmetic: combined scores in float64 in the
 // reference's operation order, the 128-d phase-gate cosine in scikit-learn's float32 order.
 #include "qpg_common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
@@ -149,62 +148,8 @@ __global__ __launch_bounds__(256) void fuse_best_kernel(const int16_t* __restric
   }
 }
 
-// The same table for the two-modality mode when K is a multiple of 128: FOUR previous codes per wave, one per 16-lane
-// group, every lane taking 8 consecutive codes per 16-byte load (K/128 loads per array) and the argmin reduction
-// staying inside the 16-lane group (4 exchange steps instead of 6).  Same f64 operations per element and the same
-// lowest-index tie rule, so the tables are identical to fuse_best_kernel's; 23.3 -> 12.9 us at Q = 48, K = 512.
-typedef short i16x8 __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(256) void fuse_best_quad_kernel(const int16_t* __restrict__ rank0,
-                                                             const int32_t* __restrict__ idx0,
-                                                             const int16_t* __restrict__ rank1,
-                                                             const int32_t* __restrict__ idx1,
-                                                             const int16_t* __restrict__ pos_rank,
-                                                             const int16_t* __restrict__ freq_rank, int Q, int K,
-                                                             int32_t* __restrict__ T0, int32_t* __restrict__ T1) {
-  const int l16 = threadIdx.x & 15;
-  const int64_t task = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);   // (q, p): one per 16-lane group
-  if (task >= (int64_t)Q * K) return;                                    // (K % 4 == 0: whole waves leave together)
-  const int q = (int)(task / K), p = (int)(task - (int64_t)q * K);
-  const int16_t* ra = rank0 + (int64_t)q * K;
-  const int16_t* rt = rank1 + (int64_t)q * K;
-  const int16_t* pr = pos_rank + (int64_t)p * K;
-  ArgMin ma{__builtin_inf(), 0x7fffffff}, mt{__builtin_inf(), 0x7fffffff};
-  for (int c0 = l16 * 8; c0 < K; c0 += 128) {
-    const i16x8 vp = *reinterpret_cast<const i16x8*>(pr + c0);
-    const i16x8 vf = *reinterpret_cast<const i16x8*>(freq_rank + c0);
-    const i16x8 va = *reinterpret_cast<const i16x8*>(ra + c0);
-    const i16x8 vt = *reinterpret_cast<const i16x8*>(rt + c0);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const double pos_score = (double)vp[e] + (double)vf[e] * 0.05;
-      ma = amin(ma, ArgMin{pos_score + (double)va[e], c0 + e});
-      mt = amin(mt, ArgMin{pos_score + (double)vt[e], c0 + e});
-    }
-  }
-  // argmin inside the 16-lane group: lane_xor (DPP moves, qpg_common.h) instead of __shfl_xor - a ds_bpermute_b32 costs a
-  // wave ~65 cycles and they do not overlap; the 24 of this reduction were most of a wave's time here
-  auto xchg = [](ArgMin m, auto tag) {
-    constexpr int PJ = decltype(tag)::value;
-    const unsigned long long b = (unsigned long long)__double_as_longlong(m.v);
-    const unsigned int lo = (unsigned int)lane_xor<PJ>((int)(unsigned int)b);
-    const unsigned int hi = (unsigned int)lane_xor<PJ>((int)(unsigned int)(b >> 32));
-    return ArgMin{__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)), lane_xor<PJ>(m.i)};
-  };
-  ma = amin(ma, xchg(ma, std::integral_constant<int, 8>{}));
-  mt = amin(mt, xchg(mt, std::integral_constant<int, 8>{}));
-  ma = amin(ma, xchg(ma, std::integral_constant<int, 4>{}));
-  mt = amin(mt, xchg(mt, std::integral_constant<int, 4>{}));
-  ma = amin(ma, xchg(ma, std::integral_constant<int, 2>{}));
-  mt = amin(mt, xchg(mt, std::integral_constant<int, 2>{}));
-  ma = amin(ma, xchg(ma, std::integral_constant<int, 1>{}));
-  mt = amin(mt, xchg(mt, std::integral_constant<int, 1>{}));
-  if (l16 == 0) {
-    T0[task] = idx0[(int64_t)q * K + ma.i];
-    T1[task] = idx1[(int64_t)q * K + mt.i];
-  }
-}
-
-// The same tables again, by BRANCH AND BOUND over the ranks (round 3).  A rank row is a permutation of 0..K-1 and the
+// The same tables for the two-modality mode, by BRANCH AND BOUND over the ranks (round 3; round 2's version gave every
+// 16-lane group one previous code and all K codes, 8 per lane per 16-byte load: 12.6 M f64 score evaluations, 15 us).  A rank row is a permutation of 0..K-1 and the
 // other two addends are non-negative, so the fused score of the code at rank r is >= r: scanning the codes of step q in
 // rank order (inv[r] = code at rank r, rebuilt in LDS per block), a 16-lane group can stop as soon as the next chunk's
 // first rank exceeds the best score so far - about 2 x sqrt(K) ranks instead of K codes (three chunks of 16 at K = 512
@@ -666,13 +611,8 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   const int Q = M * steps;
   int32_t* T0 = gate_tables;
   int32_t* T1 = gate_tables + (int64_t)Q * K;
-  const bool rows16 = ((reinterpret_cast<uintptr_t>(aud_rank) | reinterpret_cast<uintptr_t>(txt_rank) |
-                        reinterpret_cast<uintptr_t>(pos_rank) | reinterpret_cast<uintptr_t>(freq_rank)) & 15) == 0;
-  if (mode == 0 && (K % 16) == 0 && K <= 4096 && getenv("QPG_FUSE_BEST_QUAD") == nullptr) {
+  if (mode == 0 && (K % 16) == 0 && K <= 4096) {
     hipLaunchKernelGGL(fuse_best_ranked_kernel, dim3((unsigned)(((int64_t)Q * K) / 16)), dim3(256), 4 * (size_t)K,
-                       qpg_stream(stream), aud_rank, aud_idx, txt_rank, txt_idx, pos_rank, freq_rank, Q, K, T0, T1);
-  } else if (mode == 0 && (K % 128) == 0 && rows16) {
-    hipLaunchKernelGGL(fuse_best_quad_kernel, dim3((unsigned)(((int64_t)Q * K + 15) / 16)), dim3(256), 0,
                        qpg_stream(stream), aud_rank, aud_idx, txt_rank, txt_idx, pos_rank, freq_rank, Q, K, T0, T1);
   } else {
     dim3 grid((unsigned)(((int64_t)Q * K + 3) / 4), 1);
