@@ -287,6 +287,7 @@ struct HlArgs {
   int32_t* stats;
   int N, G, Q, KB, d_f32;   // N: database windows (MODE 0) / 32-row groups (MODE 1)
   int j0;                  // first window / 32-row group of this launch (N: one past the last)
+  int chunks;              // query chunks of this launch
   float* tmin;             // MODE 1, optional: [Q][ldT] minimum of every 16-row tile (rows 16 i .. 16 i + 15)
   int64_t ldT;
 };
@@ -339,8 +340,16 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 * HL_KS * HL_CT * 2 * HL_PIECE bytes
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wl = w >> 1, t = w & 1;                           // window of the block, row tile
-  const int j = a.j0 + blockIdx.x * HL_WPB + wl;               // (j0: first window of a partial launch)
-  const int chunk = blockIdx.y;
+  // Block -> (window group, query chunk), XCD-aware.  With several chunks (16 clips per sweep, W clips on a row shard,
+  // cfg-3's 1 000 queries) every chunk needs the whole database image; launched chunk-major each chunk streamed it from
+  // HBM again.  Workgroup b runs on XCD b % 8 (observed dispatch order), so linear block L takes window group
+  // (L / 8 / chunks) * 8 + L % 8 and chunk (L / 8) % chunks: an XCD works through ALL chunks of a window group back to
+  // back, and after the first of them the group's 1.3 MB of fragments come out of that XCD's L2.  One chunk: identity.
+  const int xl = (int)blockIdx.x, slot = xl >> 3;
+  const int wgrp = (slot / a.chunks) * 8 + (xl & 7);
+  const int chunk = slot % a.chunks;
+  if (a.j0 + wgrp * HL_WPB >= a.N) return;                    // (the grid is padded to whole groups of 8: nothing to do)
+  const int j = a.j0 + wgrp * HL_WPB + wl;                     // (j0: first window of a partial launch)
   const int KB = a.KB, n_stage = KB / HL_KS;
   const bool win_ok = j < a.N;
   // database fragments: plane p of k-block kb: one 16-byte load per lane, 1 KB per wave, contiguous.  Padding rows
@@ -649,6 +658,7 @@ extern "C" int qpg_audio_cosine_hl_range(qpg_ctx* ctx, void* stream, const void*
   a.qi = reinterpret_cast<const _Float16*>(qi);
   a.qexp = reinterpret_cast<const int32_t*>(qi + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
   a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = win_end; a.j0 = win_begin; a.G = G; a.Q = Q; a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0;
+  a.chunks = chunks;
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
   if (lds_bytes > 64 * 1024) {
     static bool raised = false;
@@ -659,8 +669,10 @@ extern "C" int qpg_audio_cosine_hl_range(qpg_ctx* ctx, void* stream, const void*
     }
     raised = true;
   }
-  hipLaunchKernelGGL(audio_cosine_hl_kernel<0>, dim3((win_end - win_begin + HL_WPB - 1) / HL_WPB, chunks),
-                     dim3(HL_THREADS), lds_bytes, qpg_stream(stream), a);
+  const int64_t wgroups = (win_end - win_begin + HL_WPB - 1) / HL_WPB;
+  QPG_REQUIRE(((wgroups + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
+  hipLaunchKernelGGL(audio_cosine_hl_kernel<0>, dim3((unsigned)(((wgroups + 7) / 8) * 8 * chunks)), dim3(HL_THREADS),
+                     lds_bytes, qpg_stream(stream), a);
   QPG_LAUNCH_CHECK("audio_cosine_hl_kernel");
   return QPG_OK;
 }
@@ -805,10 +817,12 @@ extern "C" int qpg_hl_gemm_distance(qpg_ctx* ctx, void* stream, const void* rows
   a.qi = reinterpret_cast<const _Float16*>(ci);
   a.qexp = reinterpret_cast<const int32_t*>(ci + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
   a.cn2 = nullptr; a.qn2 = nullptr; a.D = Dm; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = nullptr;
-  a.N = (int)(R / 32); a.j0 = 0; a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1; a.tmin = tile_min; a.ldT = ldT;
+  a.N = (int)(R / 32); a.j0 = 0; a.chunks = chunks; a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1; a.tmin = tile_min; a.ldT = ldT;
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
-  hipLaunchKernelGGL(audio_cosine_hl_kernel<1>, dim3((a.N + HL_WPB - 1) / HL_WPB, chunks), dim3(HL_THREADS), lds_bytes,
-                     qpg_stream(stream), a);
+  const int64_t rgroups = (a.N + HL_WPB - 1) / HL_WPB;
+  QPG_REQUIRE(((rgroups + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
+  hipLaunchKernelGGL(audio_cosine_hl_kernel<1>, dim3((unsigned)(((rgroups + 7) / 8) * 8 * chunks)), dim3(HL_THREADS),
+                     lds_bytes, qpg_stream(stream), a);
   QPG_LAUNCH_CHECK("audio_cosine_hl_kernel<1>");
   return QPG_OK;
 }
