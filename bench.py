@@ -639,7 +639,7 @@ def main():
 # --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 correction on FETCH_SIZE: profiles/r02_pmc_audio.md
 TRAFFIC_SOURCE = "profiles/r02_pmc_audio.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch shape; not re-measured per run)"
 HL_TRAFFIC_SOURCE = "profiles/r03_pmc_audio_hl.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch shape; not re-measured per run)"
-AUDIO_HL_TRAFFIC_BYTES = 835_000_000      # split-operand f16 sweep: FETCH_SIZE 402.8e3 KB x 1024 x 2 + WRITE_SIZE 9 984 KB x 1024
+AUDIO_HL_TRAFFIC_BYTES = 709_000_000      # split-operand f16 sweep, dense image: FETCH_SIZE 341.4e3 KB x 1024 x 2 + WRITE_SIZE 9 984 KB x 1024
 AUDIO_TRAFFIC_BYTES = 923_000_000
 AUDIO_MX_TRAFFIC_BYTES = 1_023_000_000    # mixed-precision sweep (one launch: mx2 blocks + split-K remainder), same file
 

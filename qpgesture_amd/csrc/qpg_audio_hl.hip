@@ -100,18 +100,23 @@ __global__ void hl_exponent_kernel(const unsigned int* __restrict__ amax_bits, i
 }
 
 // ---- database image ------------------------------------------------------------------------------------------------
-// thread <-> (window j, super-row i < 32, k8 = k / 8): reads 8 consecutive features, writes one 16-byte h piece and one
-// l piece.  image[(((j*2 + t)*KB + kb)*2 + plane)*64 + lane][8],  t = i / 16, lane = i % 16 + 16 * ((k % 32) / 8)
+// thread <-> (window j, super-row i < 27, k8 = k / 8): reads 8 consecutive features, writes one 16-byte h piece and one
+// l piece.  DENSE image: a window is [tile 0: KB x 2 planes x 64 units][tile 1: KB x 2 planes x 44 units] of 16 bytes;
+// tile 0 (rows 0..15): unit = lane = i + 16 * ((k % 32) / 8); tile 1 (rows 16..26, 11 live of 16): unit = 11 * ((k % 32)
+// / 8) + (i - 16).  (The first layout kept 64 units for tile 1 too and never loaded rows 27..31 - but their 16-byte slots
+// sat inside the 128-byte lines the live rows pulled in: PMC fetch 1.21 x the algorithmic bytes.)
+#define HL_T1_UNITS 44        // 16-byte units of a tile-1 fragment: 11 live rows x 4 k-groups
+#define HL_WIN_UNITS(KB) ((int64_t)(KB) * 2 * (64 + HL_T1_UNITS))
 __global__ __launch_bounds__(256) void hl_pack_db_kernel(const float* __restrict__ base, int N, int T, int F, int step,
                                                          int tap_stride, const int32_t* __restrict__ meta,
                                                          _Float16* __restrict__ image) {
   const int KB = HL_SUB * F / 32, K8 = HL_SUB * F / 8;
-  const int64_t n = (int64_t)N * 32 * K8;
+  const int64_t n = (int64_t)N * HL_ROWS * K8;
   const float sc = ldexpf(1.0f, meta[0]);
   for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (int64_t)gridDim.x * blockDim.x) {
     const int k8 = (int)(id % K8);
-    const int i = (int)((id / K8) % 32);
-    const int j = (int)(id / ((int64_t)K8 * 32));
+    const int i = (int)((id / K8) % HL_ROWS);
+    const int j = (int)(id / ((int64_t)K8 * HL_ROWS));
     const int k = k8 * 8, sub = k / F, f = k - sub * F;
     const int t = step * i + tap_stride * sub;
     f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
@@ -128,10 +133,19 @@ __global__ __launch_bounds__(256) void hl_pack_db_kernel(const float* __restrict
       split_hl(v1[e] * sc, a1, b1);
       hh[e] = a0; ll[e] = b0; hh[4 + e] = a1; ll[4 + e] = b1;
     }
-    const int kb = k / 32, lane = (i & 15) + 16 * ((k & 31) >> 3);
-    const int64_t piece = (((int64_t)j * 2 + (i >> 4)) * KB + kb) * 2;
-    reinterpret_cast<h8*>(image)[(piece + 0) * 64 + lane] = hh;
-    reinterpret_cast<h8*>(image)[(piece + 1) * 64 + lane] = ll;
+    const int kb = k / 32, kg = (k & 31) >> 3;
+    const int64_t win = (int64_t)j * HL_WIN_UNITS(KB);
+    int64_t u0;
+    int pl;
+    if (i < 16) {
+      pl = 64;
+      u0 = win + (int64_t)kb * 128 + i + 16 * kg;
+    } else {
+      pl = HL_T1_UNITS;
+      u0 = win + (int64_t)KB * 128 + (int64_t)kb * 2 * HL_T1_UNITS + 11 * kg + (i - 16);
+    }
+    reinterpret_cast<h8*>(image)[u0] = hh;
+    reinterpret_cast<h8*>(image)[u0 + pl] = ll;
   }
 }
 
@@ -355,9 +369,13 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
   // database fragments: plane p of k-block kb: one 16-byte load per lane, 1 KB per wave, contiguous.  Padding rows
   // (27..31) and windows past N read the context's zero page instead (stride 0): no branch in the loop.
   const bool row_ok = win_ok && (MODE == 1 || (16 * t + (lane & 15)) < HL_ROWS);
-  const h8* dbp = row_ok ? reinterpret_cast<const h8*>(a.db) + (((int64_t)j * 2 + t) * KB * 2) * 64 + lane
-                         : reinterpret_cast<const h8*>(a.zeros);
-  const int kb_step = row_ok ? 128 : 0, pl_step = row_ok ? 64 : 0;      // h8 units per k-block / plane
+  // MODE 0: the dense image (hl_pack_db_kernel) - tile 1 holds its 11 live rows only, 44 units per fragment
+  const bool dense1 = MODE == 0 && t == 1;
+  const int64_t unit0 = MODE == 1 ? (((int64_t)j * 2 + t) * KB * 2) * 64 + lane
+                        : (int64_t)j * HL_WIN_UNITS(KB) + (dense1 ? (int64_t)KB * 128 + 11 * (lane >> 4) + (lane & 15) : lane);
+  const h8* dbp = row_ok ? reinterpret_cast<const h8*>(a.db) + unit0 : reinterpret_cast<const h8*>(a.zeros);
+  const int pl_step = row_ok ? (dense1 ? HL_T1_UNITS : 64) : 0;         // h8 units per plane / k-block
+  const int kb_step = 2 * pl_step;
   // (HL_NT: the database image is read ONCE - a non-temporal load keeps it from evicting the query image, which every
   // block re-reads, out of the XCD's L2)
   auto load_a = [&](int kb, h8 (&dst)[2]) {
@@ -554,7 +572,7 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------------------
 extern "C" int64_t qpg_audio_hl_db_bytes(int N, int F) {            // database image + 64 bytes of metadata
-  return (N <= 0 || F <= 0) ? 0 : (int64_t)N * 2 * (HL_SUB * F / 32) * 2 * HL_PIECE + 64;
+  return (N <= 0 || F <= 0) ? 0 : (int64_t)N * HL_WIN_UNITS(HL_SUB * F / 32) * 16 + 64;
 }
 extern "C" int64_t qpg_audio_hl_query_bytes(int Q, int F) {
   const int chunks = (Q + HL_QC - 1) / HL_QC;
