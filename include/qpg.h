@@ -131,7 +131,8 @@ int qpg_audio_cosine_mx_h(qpg_ctx*, void* stream, const void* base_f16, int N, i
  *                            `cand_step` = 3 x tap_stride frames apart, F %% 128 == 0 (the reference's WavLM grid,
  *                            data_processing.py:264-268 / GestureKNN.py:672-690); else use qpg_audio_cosine_mx.
  *   qpg_audio_hl_pack_db     one-off: base [dev] f32 [N][T][F] -> image [dev] (qpg_audio_hl_db_bytes(N, F) bytes, 16-byte
- *                            aligned): [window][row tile 2][k-block][plane][lane 64][8 f16] + scale exponent.
+ *                            aligned): per window [tile 0: k-block][plane][64 units][8 f16] then [tile 1: k-block][plane]
+ *                            [44 units][8 f16] (its 11 live rows only: every byte of the image is read) + scale exponent.
  *   qpg_audio_hl_pack_queries per clip: q32 [dev] f32 [Q][6 F] (qpg_audio_pack_queries) -> image [dev]
  *                            (qpg_audio_hl_query_bytes(Q, F) bytes): chunks of 48 queries + one scale exponent per query.
  *   qpg_audio_cosine_hl      D [dev] [Q][N*G] (f32 if d_is_f32, else f64; row stride ldD elements).  cn2 [dev] f64 [N][G],
