@@ -560,13 +560,17 @@ def main():
         run3(30)
         gc.collect()
         gc.disable()
-        fence()
-        t7 = time.perf_counter()
-        c3 = run3(100)
-        fence()
-        d7 = time.perf_counter() - t7
+        d7s = []
+        for _ in range(3):              # 100 steps are 30 ms: one hiccup of the host doubles the figure - best of three
+            fence()
+            t7 = time.perf_counter()
+            c3 = run3(100)
+            fence()
+            d7s.append(time.perf_counter() - t7)
         gc.enable()
+        d7 = min(d7s)
         out["pipelined"] = {"clips_in_flight": 3, "steps": 100, "ms_per_step": round(d7 / 100 * 1e3, 4),
+                            "ms_per_step_all_three_runs": [round(x / 100 * 1e3, 4) for x in d7s],
                             "frames_per_s": round(frames_per_step * 100 / d7, 1),
                             "codes_equal_default_path": bool(torch.equal(c3.reshape(-1), codes.reshape(-1).to(torch.int32))),
                             "rematched_steps": p3.fallbacks}
