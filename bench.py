@@ -240,6 +240,8 @@ def main():
 
     n_codes = M * 30
     rematched = [0]
+    batch_walk = os.environ.get("QPG_BENCH_SERIAL_WALKS", "") != "1"          # (measurements: one walk per clip)
+    seed_phases_d = seed_phase_d.reshape(1, -1).repeat(max(my_clips, 1), 1).contiguous()
 
     def step():
         # weak, N > 1: every rank sweeps all clips' queries against its DB shard; ONE all-to-all leaves each rank with
@@ -247,11 +249,16 @@ def main():
         if enc is not None:
             ids = enc.encode(enc_x)[0]
         T = knn.sweep_tables(te_interp, te_ctx, M * n_clips, owner_blocks=(world > 1 or force_sharded) and not strong)
-        outs = []
-        for c in range(my_clips):      # each clip is an independent chain (its own seed / window chaining)
-            knn.walk(T, M, window_offset=c * M, seed_code=seed_code, seed_phase=seed_phase_d, sync=False)
-            outs.append(knn._last_ints)                        # codes | votes | status (2): ONE D2H per step
-        res = (torch.cat(outs) if len(outs) > 1 else outs[0]).cpu().view(my_clips, -1)   # the step ends on the host
+        if my_clips > 1 and batch_walk:
+            # the clips are independent chains (their own seeds / window chaining): ONE set of walk launches for all
+            knn.walk_batch(T, M, my_clips, [seed_code] * my_clips, seed_phases_d)
+            res = knn._last_ints.cpu()                         # codes | votes | status (2) per clip: ONE D2H per step
+        else:
+            outs = []
+            for c in range(my_clips):
+                knn.walk(T, M, window_offset=c * M, seed_code=seed_code, seed_phase=seed_phase_d, sync=False)
+                outs.append(knn._last_ints)
+            res = (torch.cat(outs) if len(outs) > 1 else outs[0]).cpu().view(my_clips, -1)   # the step ends on the host
         if enc is not None:
             ids.cpu()
         if int(res[:, -1].max()) != 0 and knn.audio_precision != "exact":

@@ -438,6 +438,17 @@ int qpg_match_steps(qpg_ctx*, void* stream, const int16_t* aud_rank, const int32
                     const float* phase, int Tp, int mode, int M, int steps, int K, int seed_code,
                     const float* seed_phase, int32_t* gate_tables, int32_t* out_codes, float* out_phase,
                     int32_t* out_vote, int32_t* out_status, const int32_t* guard_flags);
+/* The same for several INDEPENDENT clips (chains) of M windows each in one set of launches (BASELINE configs[4]: 16 clips
+ * per sweep): the tables hold the chains' steps back to back ([n_chains x M x steps][K]); seed_codes [dev] i32 [n_chains],
+ * seed_phase [dev] f32 [n_chains][8][16]; outputs [n_chains][...] in the single-clip shapes; chain c's status pair at
+ * out_status + c x status_stride (>= 2).  gate_tables: 3 x n_chains x M x steps x K i32.  M > 0. */
+int qpg_match_steps_batch(qpg_ctx*, void* stream, const int16_t* aud_rank, const int32_t* aud_idx, const int16_t* txt_rank,
+                          const int32_t* txt_idx, const int16_t* pos_rank, const int16_t* freq_rank, const int32_t* code,
+                          int code_ld, const int32_t* aud_cidx, const int32_t* aud_pslot, int Ga, const int32_t* txt_cidx,
+                          const int32_t* txt_pslot, int Gt, const float* phase, int Tp, int mode, int M, int steps, int K,
+                          int n_chains, const int32_t* seed_codes, const float* seed_phase, int32_t* gate_tables,
+                          int32_t* out_codes, float* out_phase, int32_t* out_vote, int32_t* out_status,
+                          int64_t status_stride, const int32_t* guard_flags);
 
 /* ------------------------------------------------------------------------------------------
  * Gesture VQ-VAE (codebook/models/{vqvae,encdec,resnet,bottleneck}.py).  Activations are channels-last

@@ -92,6 +92,7 @@ _SIGS = {
     "qpg_conv1d_bwd_weight_f32": [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, L],
     "qpg_adam_step_f32": [P, P, P, P, L, c_float, c_float, c_float, c_float, L],
     "qpg_match_steps": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P, P],
+    "qpg_match_steps_batch": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P, P, L, P],
 }
 
 

@@ -914,6 +914,43 @@ class CodeKNN:
         votes = ints[n_c:n_c + n_v].reshape(tuple(out_vote.shape)).copy()
         return codes, out_phase.cpu().numpy(), votes
 
+    def walk_batch(self, T, n_windows, n_clips, seed_codes, seed_phases, mode=MODE_AUD_TXT):
+        """Device-side walk of n_clips INDEPENDENT clips of n_windows windows each, whose steps sit back to back in the
+        tables (one batched sweep: bench.py --clips 16, BASELINE configs[4]), in one set of launches
+        (qpg_match_steps_batch).  seed_codes: ints [n_clips]; seed_phases: f32 [n_clips][8][16] (array or device tensor).
+        Returns the device tensors (codes i32 [n_clips][M][30], phases f32 [n_clips][M][steps][8][16], votes i32
+        [n_clips][M][steps]) and leaves `_last_ints` = i32 [n_clips][M*30 + M*steps + 2] (codes | votes | status per clip:
+        ONE D2H copy)."""
+        db, dev = self.db, self.db.device
+        M, steps, CL = n_windows, self.n_steps(), int(n_clips)
+        seeds = np.asarray(seed_codes, np.int64).reshape(-1)
+        if seeds.shape[0] != CL or (seeds < 0).any() or (seeds >= db.K).any():
+            raise ValueError("walk_batch: one seed code in [0, %d) per clip" % db.K)
+        sc = torch.as_tensor(seeds.astype(np.int32), device=dev)
+        if isinstance(seed_phases, torch.Tensor):
+            sp = seed_phases.to(dev, torch.float32).contiguous()
+        else:
+            sp = torch.as_tensor(np.asarray(seed_phases, np.float32), device=dev).contiguous()
+        if sp.numel() != CL * 128:
+            raise ValueError("walk_batch: seed_phases must hold [n_clips][8][16] floats")
+        n_c, n_v = M * num_frames_code, M * steps
+        status_d = torch.empty((CL, 2), dtype=torch.int32, device=dev)
+        codes_d = torch.empty((CL, M, num_frames_code), dtype=torch.int32, device=dev)
+        votes_d = torch.empty((CL, M, steps), dtype=torch.int32, device=dev)
+        out_phase = torch.empty((CL, M, steps, 8, 16), dtype=torch.float32, device=dev)
+        gate = torch.empty((3, CL * M * steps, db.K), dtype=torch.int32, device=dev)
+        a_cidx, a_pslot, a_G = self._audio_grid()
+        Qt = CL * M * steps
+
+        def sl(t):
+            return None if t is None else t[:Qt]
+        _lib.call("qpg_match_steps_batch", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]), sl(T["txt_idx"]),
+                  db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
+                  db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode, M, steps, db.K, CL, sc, sp,
+                  gate, codes_d, out_phase, votes_d, status_d, 2, self._guard_stats[1:2])
+        self._last_ints = torch.cat((codes_d.view(CL, n_c), votes_d.view(CL, n_v), status_d), dim=1)
+        return codes_d, out_phase, votes_d
+
     @staticmethod
     def check_status(status):
         """status: the walk's two status ints on the host.  Raises what must never be ignored."""

@@ -243,8 +243,11 @@ struct TailArgs {
   int Tp;
   int M, steps, step_codes, codes_per_window;
   int K;
-  int seed_code;
-  const float* seed_phase;   // [8][16]
+  int seed_code;             // seed of chain 0 when seed_codes is NULL
+  const float* seed_phase;   // [n_chains][8][16]
+  const int32_t* seed_codes; // [n_chains] (device) or NULL: several independent clips of M windows each in one launch
+  int n_chains;              // chain c owns steps [c M steps, (c + 1) M steps) of the tables and of the outputs
+  int64_t status_stride;     // ints between the chains' status pairs
   int32_t* out_codes;        // [M][codes_per_window]
   float* out_phase;          // [M][steps][8][16]
   int32_t* out_vote;         // [M][steps]
@@ -455,7 +458,7 @@ __device__ __forceinline__ const float* cand_block(const TailArgs& A, int which,
 }
 
 __global__ __launch_bounds__(256) void gate_table_kernel(TailArgs A, GateGeom geo, uint16_t* __restrict__ Gt) {
-  const int K = A.K, Q = A.M * A.steps;
+  const int K = A.K, Qc = A.M * A.steps, Q = Qc * A.n_chains;
   const int lane = threadIdx.x & 63;
   const int k = (lane >> 2) & 1, l = lane & 3;
   const int64_t task = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;          // (q, sigma)
@@ -463,13 +466,15 @@ __global__ __launch_bounds__(256) void gate_table_kernel(TailArgs A, GateGeom ge
   const bool live = task < n_task;
   const int q = live ? (int)(task / (2 * K)) : 0;
   const int sigma = live ? (int)(task - (int64_t)q * 2 * K) : 0;
-  if (q == 0 && sigma != 0) return;                     // uniform per 8-lane group; the shuffles below are group-local
+  const int chain = q / Qc;
+  const bool first = q == chain * Qc;                   // a chain's first step: the seed's state only
+  if (first && sigma != 0) return;                      // uniform per 8-lane group; the shuffles below are group-local
   const int s = q % A.steps;
   int p;
   const float* prev;                                    // 128 floats: the previous phase block
-  if (q == 0) {
-    p = A.seed_code;
-    prev = A.seed_phase;
+  if (first) {
+    p = A.seed_codes ? A.seed_codes[chain] : A.seed_code;
+    prev = A.seed_phase + (int64_t)chain * 128;
   } else {
     const int pp = sigma >> 1, kp = sigma & 1;
     const int ci = (kp ? A.T1 : A.T0)[(int64_t)(q - 1) * K + pp];
@@ -526,6 +531,16 @@ __global__ __launch_bounds__(1024) void gate_chase_kernel(TailArgs A, const uint
   __shared__ int bad_s;
   const int K = A.K, Q = A.M * A.steps, tid = threadIdx.x, nt = blockDim.x;
   const int per_w = A.steps * 2 * K;                                // u16 per window
+  // one block per chain (clip): everything below is the chain's own slice of the tables and of the outputs
+  const int chain = blockIdx.x;
+  const int64_t q0 = (int64_t)chain * Q;
+  Gt += q0 * 2 * K;
+  A.T0 += q0 * K;
+  A.T1 += q0 * K;
+  A.out_phase += q0 * 128;
+  A.out_vote += q0;
+  A.out_codes += (int64_t)chain * A.M * A.codes_per_window;
+  A.out_status += (int64_t)chain * A.status_stride;
   if (tid == 0) bad_s = 0;
   int sigma = 0;
   // two LDS buffers: the other waves stage window w+1's table while lane 0 of wave 0 chases window w
@@ -581,16 +596,19 @@ __global__ void status_only_kernel(int32_t* out_status, const int32_t* guard_fla
   out_status[1] = guard_flags ? guard_flags[0] : 0;
 }
 
-extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
-                               const int16_t* txt_rank, const int32_t* txt_idx, const int16_t* pos_rank,
-                               const int16_t* freq_rank, const int32_t* code, int code_ld, const int32_t* aud_cidx,
-                               const int32_t* aud_pslot, int Ga, const int32_t* txt_cidx, const int32_t* txt_pslot,
-                               int Gt, const float* phase, int Tp, int mode, int M, int steps, int K, int seed_code,
-                               const float* seed_phase, int32_t* gate_tables, int32_t* out_codes, float* out_phase,
-                               int32_t* out_vote, int32_t* out_status, const int32_t* guard_flags) {
+static int match_steps_impl(qpg_ctx* ctx, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
+                            const int16_t* txt_rank, const int32_t* txt_idx, const int16_t* pos_rank,
+                            const int16_t* freq_rank, const int32_t* code, int code_ld, const int32_t* aud_cidx,
+                            const int32_t* aud_pslot, int Ga, const int32_t* txt_cidx, const int32_t* txt_pslot,
+                            int Gt, const float* phase, int Tp, int mode, int M, int steps, int K, int seed_code,
+                            const float* seed_phase, int32_t* gate_tables, int32_t* out_codes, float* out_phase,
+                            int32_t* out_vote, int32_t* out_status, const int32_t* guard_flags, int n_chains,
+                            const int32_t* seed_codes, int64_t status_stride) {
   QPG_REQUIRE(ctx && pos_rank && freq_rank && code && phase && seed_phase && gate_tables && out_codes && out_phase &&
                   out_vote && out_status,
               "qpg_match_steps: null pointer");
+  QPG_REQUIRE(n_chains >= 1 && (n_chains == 1 || (seed_codes && status_stride >= 2)),
+              "qpg_match_steps_batch: n_chains >= 1, device seed codes and a status stride >= 2");
   const bool serial_walk = (mode & QPG_MODE_SERIAL_WALK) != 0;
   mode &= ~QPG_MODE_SERIAL_WALK;
   QPG_REQUIRE(mode >= 0 && mode <= 2, "qpg_match_steps: bad mode %d", mode);
@@ -608,7 +626,8 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
     QPG_LAUNCH_CHECK("status_only_kernel");
     return QPG_OK;
   }
-  const int Q = M * steps;
+  const int Qc = M * steps;                  // steps of one chain
+  const int Q = Qc * n_chains;
   int32_t* T0 = gate_tables;
   int32_t* T1 = gate_tables + (int64_t)Q * K;
   if (mode == 0 && (K % 16) == 0 && K <= 4096) {
@@ -627,7 +646,8 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   A.cidx1 = txt1 ? txt_cidx : aud_cidx; A.pslot1 = txt1 ? txt_pslot : aud_pslot; A.G1 = txt1 ? Gt : Ga;
   A.phase = phase; A.Tp = Tp; A.M = M; A.steps = steps; A.step_codes = 4;
   A.codes_per_window = (steps * 4 < 30) ? steps * 4 : 30;
-  A.K = K; A.seed_code = seed_code; A.seed_phase = seed_phase;
+  A.K = K; A.seed_code = seed_code; A.seed_phase = seed_phase; A.seed_codes = seed_codes; A.n_chains = n_chains;
+  A.status_stride = status_stride;
   A.out_codes = out_codes; A.out_phase = out_phase; A.out_vote = out_vote; A.out_status = out_status;
   A.guard_flags = guard_flags;
   // tabulated walk when the code that seeds the next window comes from the window's LAST step (always true for the
@@ -635,9 +655,10 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   const int last_idx = A.codes_per_window - 1;
   GateGeom geo{last_idx / A.step_codes, last_idx % A.step_codes};
   const size_t lds_g = (size_t)2 * steps * 2 * K * sizeof(uint16_t);     // two window tables (double buffer)
-  const bool tabulated = !serial_walk && geo.s_last == steps - 1 && 2 * K <= 65536 && Q <= QPG_CHASE_QMAX &&
+  const bool tabulated = !serial_walk && geo.s_last == steps - 1 && 2 * K <= 65536 && Qc <= QPG_CHASE_QMAX &&
                          lds_g <= 64 * 1024 && ((steps * 2 * K) % 8) == 0;
   if (!tabulated) {
+    QPG_REQUIRE(n_chains == 1, "qpg_match_steps_batch: the sequential walk takes one chain per call");
     hipLaunchKernelGGL(match_walk_kernel, dim3(1), dim3(64), lds, qpg_stream(stream), A);
     QPG_LAUNCH_CHECK("match_walk_kernel");
     return QPG_OK;
@@ -647,7 +668,37 @@ extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_ra
   hipLaunchKernelGGL(gate_table_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, qpg_stream(stream), A,
                      geo, gtab);
   QPG_LAUNCH_CHECK("gate_table_kernel");
-  hipLaunchKernelGGL(gate_chase_kernel, dim3(1), dim3(1024), lds_g, qpg_stream(stream), A, (const uint16_t*)gtab);
+  hipLaunchKernelGGL(gate_chase_kernel, dim3(n_chains), dim3(1024), lds_g, qpg_stream(stream), A, (const uint16_t*)gtab);
   QPG_LAUNCH_CHECK("gate_chase_kernel");
   return QPG_OK;
+}
+
+extern "C" int qpg_match_steps(qpg_ctx* ctx, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
+                               const int16_t* txt_rank, const int32_t* txt_idx, const int16_t* pos_rank,
+                               const int16_t* freq_rank, const int32_t* code, int code_ld, const int32_t* aud_cidx,
+                               const int32_t* aud_pslot, int Ga, const int32_t* txt_cidx, const int32_t* txt_pslot,
+                               int Gt, const float* phase, int Tp, int mode, int M, int steps, int K, int seed_code,
+                               const float* seed_phase, int32_t* gate_tables, int32_t* out_codes, float* out_phase,
+                               int32_t* out_vote, int32_t* out_status, const int32_t* guard_flags) {
+  return match_steps_impl(ctx, stream, aud_rank, aud_idx, txt_rank, txt_idx, pos_rank, freq_rank, code, code_ld, aud_cidx,
+                          aud_pslot, Ga, txt_cidx, txt_pslot, Gt, phase, Tp, mode, M, steps, K, seed_code, seed_phase,
+                          gate_tables, out_codes, out_phase, out_vote, out_status, guard_flags, 1, nullptr, 2);
+}
+
+// Several INDEPENDENT clips (chains) of M windows each in one set of launches: the tables hold the chains' steps back to
+// back ([n_chains M steps][K]); seed_codes [dev] i32 [n_chains], seed_phase [dev] f32 [n_chains][8][16]; outputs
+// [n_chains][...] in the single-clip shapes; out_status [dev] i32: chain c's pair at c x status_stride.  gate_tables:
+// 3 x n_chains x M x steps x K i32.  (bench.py --clips 16 walked its clips one after the other: 16 x 3 launches.)
+extern "C" int qpg_match_steps_batch(qpg_ctx* ctx, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
+                                     const int16_t* txt_rank, const int32_t* txt_idx, const int16_t* pos_rank,
+                                     const int16_t* freq_rank, const int32_t* code, int code_ld, const int32_t* aud_cidx,
+                                     const int32_t* aud_pslot, int Ga, const int32_t* txt_cidx, const int32_t* txt_pslot,
+                                     int Gt, const float* phase, int Tp, int mode, int M, int steps, int K,
+                                     int n_chains, const int32_t* seed_codes, const float* seed_phase,
+                                     int32_t* gate_tables, int32_t* out_codes, float* out_phase, int32_t* out_vote,
+                                     int32_t* out_status, int64_t status_stride, const int32_t* guard_flags) {
+  QPG_REQUIRE(M > 0 && seed_codes, "qpg_match_steps_batch: M > 0 and device seed codes");
+  return match_steps_impl(ctx, stream, aud_rank, aud_idx, txt_rank, txt_idx, pos_rank, freq_rank, code, code_ld, aud_cidx,
+                          aud_pslot, Ga, txt_cidx, txt_pslot, Gt, phase, Tp, mode, M, steps, K, 0, seed_phase, gate_tables,
+                          out_codes, out_phase, out_vote, out_status, guard_flags, n_chains, seed_codes, status_stride);
 }

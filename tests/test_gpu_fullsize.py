@@ -370,3 +370,38 @@ def test_graph_replays_stay_valid_after_eager_clips():
     for _ in range(20):
         out = g.run(te_i, te_c, sc, spd)
         assert torch.equal(out[0].cpu(), want) and out[3].cpu().tolist() == [0, 0]
+
+
+def test_walk_batch_equals_one_walk_per_clip():
+    """Several independent clips behind one batched sweep (BASELINE configs[4]): qpg_match_steps_batch walks them in one set
+    of launches; codes, votes, phase blocks and status words must be those of one qpg_match_steps per clip (different seed
+    codes and seed phase blocks per clip)."""
+    import torch
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    A = _db(120, 300)
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(4))
+    CL, M = 5, 3
+    g = torch.Generator(device="cpu").manual_seed(9)
+    te_i = torch.randn((CL * M, 180, 1024), generator=g).cuda()
+    te_c = torch.randn((CL * M, 30, 384), generator=g).cuda()
+    T = knn.sweep_tables(te_i, te_c, CL * M)
+    seeds, phases = [], []
+    for c in range(CL):
+        sc, sp = knn.init_code_phase()
+        seeds.append(sc)
+        phases.append(sp)
+    one = []
+    for c in range(CL):
+        oc, op, ov, st = knn.walk(T, M, window_offset=c * M, seed_code=seeds[c], seed_phase=phases[c], sync=False)
+        one.append((oc.cpu().numpy(), op.cpu().numpy(), ov.cpu().numpy(), st.cpu().numpy()))
+    bc, bp, bv = knn.walk_batch(T, M, CL, seeds, np.stack(phases))
+    ints = knn._last_ints.cpu().numpy()
+    for c in range(CL):
+        assert np.array_equal(bc[c].cpu().numpy(), one[c][0])
+        assert np.array_equal(bp[c].cpu().numpy(), one[c][1])
+        assert np.array_equal(bv[c].cpu().numpy(), one[c][2])
+        assert np.array_equal(ints[c, -2:], one[c][3])
+        assert np.array_equal(ints[c, :M * 30], one[c][0].reshape(-1))
+    assert len({tuple(o[0].reshape(-1)) for o in one}) > 1              # the clips really differ
