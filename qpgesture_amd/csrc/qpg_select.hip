@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     const DT* __restrict__ D, int64_t ldD, const int16_t* __restrict__ cand_code, int64_t C, int K, double absent,
     int32_t idx_base, double* __restrict__ out_dist, int32_t* __restrict__ out_idx, int16_t* __restrict__ out_rank,
     int q_block, int64_t block_stride, GuardArgs A, double eps1, const double* __restrict__ cn2,
-    const double* __restrict__ qn2, int use_qlds, int phase, unsigned char* __restrict__ ws, int pre, int Q) {
+    const double* __restrict__ qn2, int use_qlds, int phase, unsigned char* __restrict__ ws, int pre) {
   // phase 0: everything in this launch (tier-1 dot products by this block's 16 waves: one CU per query).
   // pre (phase 1, f32 matrix): mixed_stream_kernel has streamed the row - per-code minima and the potential band members
   // are in the workspace; this launch starts at pass 2.
@@ -1526,7 +1526,7 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
 #define SEL_MIX_LAUNCH(DT, SH, PHASE, PRE)                                                                                  \
   hipLaunchKernelGGL((percode_select_mixed_f64_kernel<DT>), dim3(Q), dim3(1024), SH, qpg_stream(stream),               \
                      static_cast<const DT*>(D), ldD, cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank,   \
-                     q_block, block_stride, A, eps1, cn2, qn2, use_qlds, PHASE, w, PRE, Q)
+                     q_block, block_stride, A, eps1, cn2, qn2, use_qlds, PHASE, w, PRE)
   if (!ws) {
     if (d_is_f32) SEL_MIX_LAUNCH(float, sh, 0, 0); else SEL_MIX_LAUNCH(double, sh, 0, 0);
     QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel");
