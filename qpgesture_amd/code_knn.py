@@ -344,10 +344,15 @@ class CodeKNN:
     def query_positions(self):
         """Matching-step positions of a window: i = 0, 4*step, ... while i < n (GestureKNN.py:528,659);
         with the float wavvq step the literal accumulation is kept."""
+        key = (self.n_db_frm, self.step_sz)
+        hit = self.__dict__.get("_qpos")
+        if hit is not None and hit[0] == key:          # (twice per clip, in front of its first launch)
+            return hit[1]
         pos, i = [], 0
         while i < self.n_db_frm:
             pos.append(i)
             i += STEP_SZ * self.step_sz
+        self.__dict__["_qpos"] = (key, pos)
         return pos
 
     # -- init (GestureKNN.py:462-473): same two draws from the (seeded) NumPy global stream ------
@@ -719,7 +724,6 @@ class CodeKNN:
         # The two sweeps are independent until the walk and lean on different pipes (f64 matrix cores vs f32
         # VALU): with both modalities on, the text side runs on a second HIP stream underneath the audio sweep.
         overlap = mode == MODE_AUD_TXT and self.overlap_sweeps
-        main = torch.cuda.current_stream(dev)
         if overlap:
             side = self.__dict__.get("_side_stream")
             if side is None:
@@ -730,7 +734,10 @@ class CodeKNN:
             if gate is None:
                 gate = self.__dict__["_side_gate"] = torch.cuda.Event()
                 self.__dict__["_side_done"] = torch.cuda.Event()
-            gate.record(main)
+            if dev.index is None or dev.index == torch.cuda.current_device():
+                gate.record()                   # (the current stream: no Stream object in front of the step's launches)
+            else:
+                gate.record(torch.cuda.current_stream(dev))
             side.wait_event(gate)
 
         def text_pack():
@@ -795,7 +802,7 @@ class CodeKNN:
         if overlap:
             done = self.__dict__["_side_done"]
             done.record(side)
-            main.wait_event(done)
+            torch.cuda.current_stream(dev).wait_event(done)
             # The text tables are allocated on `side` and consumed on `main`.  No record_stream() (measured +15 us per
             # clip for the allocator's events): a freed block can only be reused by a later `side` allocation, and every
             # use of `side` starts by waiting for `main` above, i.e. after main's consumers of the block.
