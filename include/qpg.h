@@ -493,6 +493,10 @@ int qpg_convt_pair_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, 
 /* Measurement hook (tools/bench_convt_small.py): force the short-sequence kernel's block shape - nq in {1, 2, 4}
  * channel tiles of 16, pd in {0, 4} fragment-ring depth; nq = 0 restores the launcher's own choice.  Process-wide. */
 int qpg_debug_convt_shape(int nq, int pd);
+/* T-pack of a convolution's weights on the device: w [dev] f32 [taps x Cin_pad][Cout_pad] (qpg_conv1d_f32's layout, the one
+ * the optimiser updates) -> out [dev] f32, the wt of qpg_convt_f32 (nb = 128) or one half of qpg_resblock_f32's wpack
+ * (nb = 512 for the dilated convolution): taps x Cin_pad x (Cout_pad rounded up to nb) floats. */
+int qpg_tpack_f32(qpg_ctx*, void* stream, const float* w, int taps, int Cin_pad, int Cout_pad, int nb, float* out);
 /* y[r][0..Cp) = x[r][0..C) zero-extended (rows of 135 floats are not 16-byte aligned). */
 int qpg_pad_channels_f32(qpg_ctx*, void* stream, const float* x, int64_t R, int C, int Cp, float* y);
 /* One ResConv1DBlock of width 512 in ONE launch (resnet.py:31-46):  y = x + W2 . relu(W1 (*) relu(x) + b1) + b2,

@@ -76,6 +76,7 @@ _SIGS = {
     "qpg_convt_f32": [P, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, P],
     "qpg_convt_pair_f32": [P, I, I, I, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "qpg_pad_channels_f32": [P, L, I, I, P],
+    "qpg_tpack_f32": [P, I, I, I, I, P],
     "qpg_resblock_f32": [P, I, I, I, P, P, P, P, P],
     "qpg_pose_to_euler_f64": [P, L, I, P, P, P, P, P, I, P, P],
     "qpg_vq_argmin_f32": [P, P, P, L, I, I, P, P, P],

@@ -703,3 +703,35 @@ extern "C" int qpg_pad_channels_f32(qpg_ctx* ctx, void* stream, const float* x, 
   QPG_LAUNCH_CHECK("pad_channels_kernel");
   return QPG_OK;
 }
+
+// T-pack of one convolution's weights ON THE DEVICE (what qpgesture_amd/vqvae.py::tpack builds with torch ops):
+//   out[n / nb][kb][g][n % nb][j] = w[k = 16 kb + 4 g + j][n],   w: [taps * Cin_pad][Cout_pad] (the training layout),
+// n < Cout_n = Cout_pad rounded up to nb (zeros beyond Cout_pad).  A training step changes every weight, and the
+// transposed-formulation kernels read T-packs: one launch per convolution and step instead of ~200 torch operations.
+__global__ __launch_bounds__(256) void tpack_kernel(const float* __restrict__ w, int Kd, int cout_pad, int nb, int cout_n,
+                                                    float* __restrict__ out) {
+  const int64_t n_out = (int64_t)Kd * cout_n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3);
+    const int nl = (int)((i >> 2) % nb);
+    const int64_t r = (i >> 2) / nb;
+    const int g = (int)(r & 3);
+    const int64_t r2 = r >> 2;
+    const int kb = (int)(r2 % (Kd / 16));
+    const int nbi = (int)(r2 / (Kd / 16));
+    const int k = 16 * kb + 4 * g + j, n = nbi * nb + nl;
+    out[i] = n < cout_pad ? w[(int64_t)k * cout_pad + n] : 0.f;
+  }
+}
+
+extern "C" int qpg_tpack_f32(qpg_ctx* ctx, void* stream, const float* w, int taps, int Cin_pad, int Cout_pad, int nb,
+                             float* out) {
+  QPG_REQUIRE(ctx && w && out && taps > 0 && Cin_pad > 0 && (Cin_pad % 16) == 0 && Cout_pad > 0 && nb > 0 && (nb % 4) == 0,
+              "qpg_tpack_f32: bad argument (Cin_pad %% 16 == 0)");
+  const int Kd = taps * Cin_pad, cout_n = (Cout_pad + nb - 1) / nb * nb;
+  const int64_t n = (int64_t)Kd * cout_n;
+  hipLaunchKernelGGL(tpack_kernel, dim3((unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192)), dim3(256), 0,
+                     qpg_stream(stream), w, Kd, Cout_pad, nb, cout_n, out);
+  QPG_LAUNCH_CHECK("tpack_kernel");
+  return QPG_OK;
+}

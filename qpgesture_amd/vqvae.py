@@ -188,10 +188,28 @@ class VQVAE:
         self._enc_packs = [fused(res) for _, res in self.enc_down]
         self._dec_packs = [fused(res) for res, _, _ in self.dec_up]
 
+    def _tpack_rebuild(self):
+        """The same images again, IN PLACE and on the device (qpg_tpack_f32: one launch per convolution): the buffers -
+        and with them the descriptor's pointers - stay, so a training step can refresh them every iteration (the torch
+        version above is ~200 small operations)."""
+        self._tpack_stale = False
+        if not self._tpack_on:
+            return
+        dev = self.device
+        for c in self._convs + [self.kT]:       # (kT.w is updated in place by the quantiser's refresh / EMA kernels)
+            if getattr(c, "wt", None) is not None:
+                _lib.call("qpg_tpack_f32", dev, c.w, c.taps, c.cin_pad, c.cout_pad, 128, c.wt)
+        for packs, ress in ((self._enc_packs, [res for _, res in self.enc_down]),
+                            (self._dec_packs, [res for res, _, _ in self.dec_up])):
+            for plist, res in zip(packs, ress):
+                for pack, (c3, c1) in zip(plist, res):
+                    n3 = c3.taps * c3.cin_pad * 512
+                    _lib.call("qpg_tpack_f32", dev, c3.w, c3.taps, c3.cin_pad, c3.cout_pad, 512, pack[:n3])
+                    _lib.call("qpg_tpack_f32", dev, c1.w, c1.taps, c1.cin_pad, c1.cout_pad, 128, pack[n3:])
+
     def _refresh_tpack(self):
         if getattr(self, "_tpack_stale", False):
-            self._tpack_all()
-            self._desc = self._build_descriptor()
+            self._tpack_rebuild()
 
     def parameters(self):
         """(param, grad) flat buffers — what optim.Adam(model.parameters()) iterates in the reference (train.py:71)."""
@@ -402,40 +420,65 @@ class VQVAE:
                   self.threshold, self.bins, E, self.kT.w, self.kT.cout_pad, self.kk, ws, ws.numel(), out)
         return out
 
-    def _res_fwd(self, blocks, x, B, T, reverse, tape):
+    def _res_fwd(self, blocks, x, B, T, reverse, tape, packs=None):
         for d, (c3, c1) in enumerate(blocks):
             dil = self.growth ** (self.depth - 1 - d if reverse else d)              # resnet.py:57-62
-            h = self._conv(c3, x, B, T, T, in_offset=-dil, dil=dil, relu_in=True, relu_out=True)
-            y = self._conv(c1, h, B, T, T, residual=x)
+            if packs is not None:             # one launch: the hidden activation is written for the backward pass
+                y, h = torch.empty_like(x), torch.empty_like(x)
+                _lib.call("qpg_resblock_f32", self.device, x, B, T, dil, packs[d], c3.b, c1.b, y, h)
+            else:
+                h = self._conv(c3, x, B, T, T, in_offset=-dil, dil=dil, relu_in=True, relu_out=True)
+                y = self._conv(c1, h, B, T, T, residual=x)
             tape.append(("res", c3, c1, x, h, dil, T))
             x = y
         return x
 
-    def _encoder_fwd(self, x, B, T, tape):
+    def _conv_fwd(self, c, x, B, T_in, T_out, fused, **kw):
+        """A training-forward convolution: on the transposed-formulation kernel (qpg_convt_f32, from the T-pack that
+        _tpack_rebuild refreshed) when `fused`, else qpg_conv1d_f32.  x keeps its own channel count on the tape (the
+        weight gradient reads it); the transposed kernel gets a copy padded to Cin_pad when the two differ."""
+        wt = getattr(c, "wt", None) if fused else None
+        if wt is None:
+            return self._conv(c, x, B, T_in, T_out, **kw)
+        xin = x
+        if x.shape[-1] != c.cin_pad:
+            xin = torch.empty((B, T_in, c.cin_pad), dtype=torch.float32, device=self.device)
+            _lib.call("qpg_pad_channels_f32", self.device, x, B * T_in, x.shape[-1], c.cin_pad, xin)
+        T_y = kw.get("T_y") or T_out
+        out = kw.get("out")
+        if out is None:
+            out = torch.empty((B, T_y, c.cout), dtype=torch.float32, device=self.device)
+        _lib.call("qpg_convt_f32", self.device, xin, B, T_in, c.cin_pad, wt, c.b, c.taps, c.cin_pad, c.cout, c.cout_pad,
+                  kw.get("in_stride", 1), kw.get("in_offset", 0), kw.get("dil", 1), T_out, kw.get("out_stride", 1),
+                  kw.get("out_offset", 0), T_y, kw.get("residual"), int(kw.get("relu_in", False)),
+                  int(kw.get("relu_out", False)), out)
+        return out
+
+    def _encoder_fwd(self, x, B, T, tape, fused=False):
         """Encoder.forward (encdec.py:75-90), recording what the backward pass needs."""
-        for c, res in self.enc_down:
+        for i, (c, res) in enumerate(self.enc_down):
             T_out = T // self.stride_t
-            y = self._conv(c, x, B, T, T_out, in_stride=self.stride_t, in_offset=-(self.stride_t // 2))
+            y = self._conv_fwd(c, x, B, T, T_out, fused, in_stride=self.stride_t, in_offset=-(self.stride_t // 2))
             tape.append(("down", c, x, T))
-            x, T = self._res_fwd(res, y, B, T_out, False, tape), T_out
-        z = self._conv(self.enc_out, x, B, T, T, in_offset=-1)
+            x, T = self._res_fwd(res, y, B, T_out, False, tape, self._enc_packs[i] if fused else None), T_out
+        z = self._conv_fwd(self.enc_out, x, B, T, T, fused, in_offset=-1)
         tape.append(("conv3", self.enc_out, x, T))
         return z
 
-    def decode_latent(self, zq, B, L, tape=None):
+    def decode_latent(self, zq, B, L, tape=None, fused=False):
         """Decoder.forward (encdec.py:115-136) on a channels-last quantised latent (B,L,emb) -> (B, 8L, C)."""
         tape = [] if tape is None else tape
         T = L
-        x = self._conv(self.dec_in, zq, B, T, T, in_offset=-1)
+        x = self._conv_fwd(self.dec_in, zq, B, T, T, fused, in_offset=-1)
         tape.append(("conv3", self.dec_in, zq, T))
-        for res, even, odd in self.dec_up:
-            x = self._res_fwd(res, x, B, T, self.reverse, tape)
+        for i, (res, even, odd) in enumerate(self.dec_up):
+            x = self._res_fwd(res, x, B, T, self.reverse, tape, self._dec_packs[i] if fused else None)
             y = torch.empty((B, 2 * T, even.cout), dtype=torch.float32, device=self.device)
-            self._conv(even, x, B, T, T, in_offset=-1, out=y, out_stride=2, out_offset=0, T_y=2 * T)
-            self._conv(odd, x, B, T, T, in_offset=0, out=y, out_stride=2, out_offset=1, T_y=2 * T)
+            self._conv_fwd(even, x, B, T, T, fused, in_offset=-1, out=y, out_stride=2, out_offset=0, T_y=2 * T)
+            self._conv_fwd(odd, x, B, T, T, fused, in_offset=0, out=y, out_stride=2, out_offset=1, T_y=2 * T)
             tape.append(("up", even, odd, x, T))
             x, T = y, 2 * T
-        out = self._conv(self.dec_out, x, B, T, T, in_offset=-1)
+        out = self._conv_fwd(self.dec_out, x, B, T, T, fused, in_offset=-1)
         tape.append(("conv3", self.dec_out, x, T))
         return out
 
@@ -448,7 +491,12 @@ class VQVAE:
         x = torch.as_tensor(x).to(self.device, torch.float32).contiguous()
         B, T, C = x.shape
         enc_tape, dec_tape = [], []
-        z = self._encoder_fwd(x, B, T, enc_tape)                    # (B,L,E) channels-last
+        # training forward on the transposed-formulation kernels (round 3): their T-packs are refreshed on the device
+        # from the weights the optimiser has just updated; activations are recorded as before
+        fused = bool(getattr(self, "train_fused", True) and self._tpack_on)
+        if fused:
+            self._refresh_tpack()
+        z = self._encoder_fwd(x, B, T, enc_tape, fused)             # (B,L,E) channels-last
         L, E = z.shape[1], z.shape[2]
         R = B * L
         z2 = z.view(R, E)
@@ -464,7 +512,7 @@ class VQVAE:
         ws = self._red_ws()
         _lib.call("qpg_vq_latent_stats_f32", self.device, z2, zq, dmin, R, E, ws, ws.numel(), stats)
         ema = self._update_k(z2, ids) if self.training else None
-        x_out = self.decode_latent(zq.view(B, L, E), B, L, dec_tape)
+        x_out = self.decode_latent(zq.view(B, L, E), B, L, dec_tape, fused)
         out6 = torch.empty((6,), dtype=torch.float32, device=self.device)
         _lib.call("qpg_vq_loss_f32", self.device, x_out, x, B, T, C, stats[0:1], self.commit, self.reg, self.vel,
                   self.acc, ws, ws.numel(), out6)

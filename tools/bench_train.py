@@ -8,6 +8,7 @@ from qpgesture_amd.vqvae import VQVAE
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 m = VQVAE(dict(vel=1, acc=1), 135, device=dev).load_state_dict(synth.make_vqvae_state_dict(7)).train()
+m.train_fused = os.environ.get("QPG_TRAIN_FUSED", "1") == "1"       # forward on the transposed-formulation kernels
 opt = Adam(m.parameters(), lr=3e-5, betas=(0.5, 0.999))
 x = torch.randn((B, 240, 135), device=dev)
 FWD = (1.639e9 + 1.908e9) * B           # encoder + decoder flops per window
