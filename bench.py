@@ -253,12 +253,16 @@ def main():
             # the clips are independent chains (their own seeds / window chaining): ONE set of walk launches for all
             knn.walk_batch(T, M, my_clips, [seed_code] * my_clips, seed_phases_d)
             res = knn._last_ints.cpu()                         # codes | votes | status (2) per clip: ONE D2H per step
+        elif my_clips == 1:
+            # codes | votes | status written by the walk's last kernel straight into pinned host memory: the step ends
+            # on the host with a stream synchronise, no copy launch
+            res = torch.from_numpy(knn.walk(T, M, seed_code=seed_code, seed_phase=seed_phase_d, sync="ints")).view(1, -1)
         else:
             outs = []
             for c in range(my_clips):
                 knn.walk(T, M, window_offset=c * M, seed_code=seed_code, seed_phase=seed_phase_d, sync=False)
                 outs.append(knn._last_ints)
-            res = (torch.cat(outs) if len(outs) > 1 else outs[0]).cpu().view(my_clips, -1)   # the step ends on the host
+            res = torch.cat(outs).cpu().view(my_clips, -1)                                    # the step ends on the host
         if enc is not None:
             ids.cpu()
         if int(res[:, -1].max()) != 0 and knn.audio_precision != "exact":

@@ -883,7 +883,11 @@ class CodeKNN:
                   0.0 if exact else float(self.tie_eps))
 
     def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True):
-        """Device-side walk of windows [window_offset, window_offset+n_windows) of the tables."""
+        """Device-side walk of windows [window_offset, window_offset+n_windows) of the tables.
+        sync=True: (codes, phases, votes) as NumPy arrays; sync=False: device tensors (+ the status pair), nothing waited
+        for, `_last_ints` = codes | votes | status on the device; sync="ints": the integer results only, as ONE host array
+        codes | votes | status - the walk's last kernel writes them straight into pinned host memory (zero-copy) and the
+        stream is synchronised: no D2H copy launch behind the walk (bench.py's step; ~5 us of a 0.33 ms clip)."""
         db, dev = self.db, self.db.device
         M, steps = n_windows, self.n_steps()
         if seed_code is None:
@@ -896,10 +900,21 @@ class CodeKNN:
         # before it.  status[0] = an absent code won a rank fusion, status[1] = the sweeps' / selects' trouble word
         # (copied by the walk's last kernel from _guard_stats[1]): a clip whose word is not 0 is never returned.
         n_c, n_v = M * num_frames_code, M * steps
-        ints_d = torch.empty((n_c + n_v + 2,), dtype=torch.int32, device=dev)
-        out_codes = ints_d[:n_c].view(M, num_frames_code)
-        out_vote = ints_d[n_c:n_c + n_v].view(M, steps)
-        status = ints_d[n_c + n_v:]                                      # always written by the walk kernels
+        host = sync is True or sync == "ints"
+        if host:
+            # pinned (device-visible) host memory, one buffer per clip length: safe to reuse because this call does
+            # not return before the stream has drained and the values have been copied out of it
+            pins = self.__dict__.setdefault("_pinned_ints", {})
+            pin = pins.get(M)
+            if pin is None:
+                pin = pins[M] = torch.empty((n_c + n_v + 2,), dtype=torch.int32).pin_memory()
+            base = pin.data_ptr()
+            out_codes, out_vote, status = base, base + 4 * n_c, base + 4 * (n_c + n_v)
+        else:
+            ints_d = torch.empty((n_c + n_v + 2,), dtype=torch.int32, device=dev)
+            out_codes = ints_d[:n_c].view(M, num_frames_code)
+            out_vote = ints_d[n_c:n_c + n_v].view(M, steps)
+            status = ints_d[n_c + n_v:]                                  # always written by the walk kernels
         out_phase = torch.empty((M, steps, 8, 16), dtype=torch.float32, device=dev)
         gate = torch.empty((3, max(M, 1) * steps, db.K), dtype=torch.int32, device=dev)
         q0 = window_offset * steps
@@ -912,14 +927,18 @@ class CodeKNN:
                   db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode | (0x100 if self.serial_walk else 0), M, steps,
                   db.K, int(seed_code), sp,
                   gate, out_codes, out_phase, out_vote, status, self._guard_stats[1:2])
-        self._last_ints = ints_d
-        if not sync:
+        if not host:
+            self._last_ints = ints_d
             return out_codes, out_phase, out_vote, status
-        ints = ints_d.cpu().numpy()
+        if sync == "ints":
+            torch.cuda.current_stream(dev).synchronize()
+            return pin.numpy().copy()
+        phases = out_phase.cpu().numpy()                    # (synchronises the stream: the pinned integers are complete)
+        ints = pin.numpy().copy()
         self.check_status(ints[n_c + n_v:])
-        codes = ints[:n_c].reshape(tuple(out_codes.shape)).astype(np.int64)
-        votes = ints[n_c:n_c + n_v].reshape(tuple(out_vote.shape)).copy()
-        return codes, out_phase.cpu().numpy(), votes
+        codes = ints[:n_c].reshape(M, num_frames_code).astype(np.int64)
+        votes = ints[n_c:n_c + n_v].reshape(M, steps).copy()
+        return codes, phases, votes
 
     def walk_batch(self, T, n_windows, n_clips, seed_codes, seed_phases, mode=MODE_AUD_TXT):
         """Device-side walk of n_clips INDEPENDENT clips of n_windows windows each, whose steps sit back to back in the

@@ -405,3 +405,26 @@ def test_walk_batch_equals_one_walk_per_clip():
         assert np.array_equal(ints[c, -2:], one[c][3])
         assert np.array_equal(ints[c, :M * 30], one[c][0].reshape(-1))
     assert len({tuple(o[0].reshape(-1)) for o in one}) > 1              # the clips really differ
+
+
+def test_walk_results_through_pinned_host_memory():
+    """walk(sync="ints"): codes | votes | status written by the walk's last kernel straight into pinned host memory
+    (zero-copy) == the device buffer of walk(sync=False); match_clip (sync=True) takes the same route."""
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    A = _db(90, 310)
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(2))
+    M = 4
+    g = torch.Generator(device="cpu").manual_seed(3)
+    te_i = torch.randn((M, 180, 1024), generator=g).cuda()
+    te_c = torch.randn((M, 30, 384), generator=g).cuda()
+    sc, sp = knn.init_code_phase()
+    T = knn.sweep_tables(te_i, te_c, M)
+    knn.walk(T, M, seed_code=sc, seed_phase=sp, sync=False)
+    dev_ints = knn._last_ints.cpu().numpy()
+    for _ in range(3):                                   # (the pinned buffer is reused from call to call)
+        host_ints = knn.walk(T, M, seed_code=sc, seed_phase=sp, sync="ints")
+        assert host_ints.dtype == np.int32 and np.array_equal(host_ints, dev_ints)
+    codes, phases, votes = knn.walk(T, M, seed_code=sc, seed_phase=sp, sync=True)
+    assert np.array_equal(codes.reshape(-1), dev_ints[:M * 30]) and np.array_equal(votes.reshape(-1), dev_ints[M * 30:-2])
