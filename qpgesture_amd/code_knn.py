@@ -33,6 +33,9 @@ AUDIO_HL_BAND = 2.1 * AUDIO_HL_ERR
 FLAG_LIST_OVERFLOW, FLAG_SMALL_NORMS, FLAG_REQUEST_OVERFLOW, FLAG_CROSS_SHARD_TIE = 1, 2, 4, 8
 
 
+_PIN_SENTINEL = -1234567          # never a status word (flag bits are small non-negative integers)
+
+
 class GuardOverflow(RuntimeError):
     """The capped near-tie machinery of the fast audio paths could not guarantee the reference's candidates for this
     clip (a re-evaluation list overflowed, operand norms left the error bound's range, or shard minima tied across the
@@ -910,6 +913,8 @@ class CodeKNN:
                 pin = pins[M] = torch.empty((n_c + n_v + 2,), dtype=torch.int32).pin_memory()
             base = pin.data_ptr()
             out_codes, out_vote, status = base, base + 4 * n_c, base + 4 * (n_c + n_v)
+            pin_np = pin.numpy()
+            pin_np[-1] = _PIN_SENTINEL          # overwritten by the walk's LAST store (behind a system-scope fence)
         else:
             ints_d = torch.empty((n_c + n_v + 2,), dtype=torch.int32, device=dev)
             out_codes = ints_d[:n_c].view(M, num_frames_code)
@@ -931,8 +936,16 @@ class CodeKNN:
             self._last_ints = ints_d
             return out_codes, out_phase, out_vote, status
         if sync == "ints":
-            torch.cuda.current_stream(dev).synchronize()
-            return pin.numpy().copy()
+            # the host watches the last word instead of sleeping in hipStreamSynchronize (~3.5 us sooner per clip); after
+            # ~2 ms without it (a failed launch would never write it) the stream is synchronised the ordinary way
+            for _ in range(40000):
+                if pin_np[-1] != _PIN_SENTINEL:
+                    break
+            else:
+                torch.cuda.current_stream(dev).synchronize()
+                if pin_np[-1] == _PIN_SENTINEL:
+                    raise RuntimeError("the walk did not write its status word")
+            return pin_np.copy()
         phases = out_phase.cpu().numpy()                    # (synchronises the stream: the pinned integers are complete)
         ints = pin.numpy().copy()
         self.check_status(ints[n_c + n_v:])

@@ -428,8 +428,11 @@ __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
     if (lane < A.codes_per_window) A.out_codes[(int64_t)w * A.codes_per_window + lane] = wincodes[lane];
     prev_code = wincodes[last_idx];
   }
+  __threadfence_system();          // (status pair last, behind a system-scope fence: see gate_chase_kernel)
+  __syncthreads();
   if (lane == 0) {
     A.out_status[0] = bad;
+    __threadfence_system();
     A.out_status[1] = A.guard_flags ? A.guard_flags[0] : 0;
   }
 }
@@ -584,9 +587,13 @@ __global__ __launch_bounds__(1024) void gate_chase_kernel(TailArgs A, const uint
     cand_block(A, fi, ci, &pb);
     A.out_codes[i] = A.code[pb + c % A.step_codes];
   }
+  // The status pair is written LAST and behind a system-scope fence: when the outputs live in pinned host memory (the
+  // matcher's zero-copy results) a host that sees the pair also sees the codes and votes of every thread above.
+  __threadfence_system();
   __syncthreads();
   if (tid == 0) {
     A.out_status[0] = bad_s;
+    __threadfence_system();
     A.out_status[1] = A.guard_flags ? A.guard_flags[0] : 0;
   }
 }

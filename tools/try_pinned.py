@@ -14,6 +14,7 @@ steps = knn.n_steps()
 n_c, n_v = M * num_frames_code, M * steps
 pin = torch.empty((n_c + n_v + 2,), dtype=torch.int32).pin_memory()
 base = pin.data_ptr()
+pin_np = pin.numpy()
 out_phase = torch.empty((M, steps, 8, 16), dtype=torch.float32, device=dev)
 gate = torch.empty((3, M * steps, db.K), dtype=torch.int32, device=dev)
 a_cidx, a_pslot, a_G = knn._audio_grid()
@@ -29,6 +30,18 @@ def step_pinned():
     return pin.numpy()[:n_c].copy()
 
 
+def step_spin():
+    T = knn.sweep_tables(te_i, te_c, M)
+    pin_np[-1] = -1234567                                   # the kernel's LAST store overwrites it
+    _lib.call("qpg_match_steps", dev, T["aud_rank"], T["aud_idx"], T["txt_rank"], T["txt_idx"], db.pos_rank, db.freq_rank,
+              db.code, db.code.shape[1], a_cidx, a_pslot, a_G, db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp,
+              MODE_AUD_TXT, M, steps, db.K, int(sc), spd, gate, base, out_phase, base + 4 * n_c, base + 4 * (n_c + n_v),
+              knn._guard_stats[1:2])
+    while pin_np[-1] == -1234567:
+        pass
+    return pin_np[:n_c].copy()
+
+
 def step_cpu():
     T = knn.sweep_tables(te_i, te_c, M)
     knn.walk(T, M, 0, seed_code=sc, seed_phase=spd, sync=False)
@@ -37,7 +50,8 @@ def step_cpu():
 
 a, b = step_pinned(), step_cpu()
 print("equal:", np.array_equal(a, b))
-for name, fn in (("cpu()", step_cpu), ("pinned", step_pinned), ("cpu()", step_cpu), ("pinned", step_pinned)):
+print("spin equal:", np.array_equal(step_spin(), b))
+for name, fn in (("cpu()", step_cpu), ("pinned", step_pinned), ("spin", step_spin), ("cpu()", step_cpu), ("pinned", step_pinned), ("spin", step_spin)):
     for _ in range(20):
         fn()
     torch.cuda.synchronize()
