@@ -1104,8 +1104,8 @@ class ClipPipeline:
     lanes - one CodeKNN (its own workspaces and side stream), one HIP stream and one pinned result buffer each - the
     next clip's sweeps run underneath them.  Every clip goes through exactly the launches of CodeKNN.match_clip, so
     the results are the same arrays; only the host's wait moves from the end of a clip to `collect`.
-    Measured (bench.py --clips-in-flight N, 24 s clip vs 2048 windows): 0.542 ms per clip one at a time, 0.514 with two
-    lanes, 0.459 with three.
+    Measured (bench.py `pipelined`, 24 s clip vs 2048 windows, end of round 3): 0.33-0.37 ms per clip one at a time,
+    0.25-0.30 with three lanes (round 2: 0.542 / 0.459).
     Single-GPU databases only (the sharded path's collectives stay on one stream)."""
 
     def __init__(self, db, depth=2, rng=None, **knn_flags):
