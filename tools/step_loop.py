@@ -41,7 +41,7 @@ def step():
     if graph:
         return g.run(te_i, te_c, sc, spd)[0].cpu()
     T = knn.sweep_tables(te_i, te_c, M, owner_blocks=knn.force_sharded)
-    return knn.walk(T, M, 0, seed_code=sc, seed_phase=spd, sync=False)[0].cpu()
+    return knn.walk(T, M, 0, seed_code=sc, seed_phase=spd, sync="ints")      # (codes | votes | status, pinned host memory)
 
 
 import time
