@@ -399,6 +399,7 @@ struct WgradArgs {
   const float* x;    // [B][T_in][Cin]
   const float* dy;   // [B][T_y][Cout]
   float* ws;         // [S][taps][Cin_pad][Cout_pad] then [S][Cout_pad]
+  const float* zeros;  // >= 64 B of zeros (ctx): where out-of-range loads are pointed, so that no select follows them
   int B, T_in, Cin, Cin_pad, Cout, Cout_pad, taps;
   int in_stride, in_offset, dil, T_out, out_stride, out_offset, T_y;
   int relu_in, S;
@@ -407,7 +408,7 @@ struct WgradArgs {
 
 #define WG_BK 16
 template <bool VECX, bool VECY>
-__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 4) void conv_wgrad_mfma_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float Xs[WG_BK][128];
   __shared__ __attribute__((aligned(16))) float Ys[WG_BK][128];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -432,27 +433,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  // raw prefetch registers + validity bits (x: bits 0..7, y: bits 8..15); selects / ReLU happen at the LDS commit so
-  // that the loads of the next chunk stay in flight across the MFMA block
+  // raw prefetch registers: out-of-range elements are read from the context's zero page, so the loaded values need no
+  // select and the loads of the next chunk stay in flight across the MFMA block; ReLU happens at the LDS commit
   float xv[8], yv[8];
-  unsigned okm = 0;
+  // this thread's position row, advanced by WG_BK per chunk (no division inside the loop)
+  int64_t fr = r_begin + kr;
+  int fb = (int)(fr / a.T_out);
+  int ft = (int)(fr - (int64_t)fb * a.T_out);
 
-  auto fetch = [&](int64_t r0) {
-    const int64_t r = r0 + kr;
-    const bool live = r < r_end;
-    const int b = live ? (int)(r / a.T_out) : 0;
-    const int t = live ? (int)(r - (int64_t)b * a.T_out) : 0;
-    const int t_in = t * a.in_stride + a.in_offset + tap * a.dil;
+  auto fetch = [&]() {
+    const bool live = fr < r_end;
+    const int t_in = ft * a.in_stride + a.in_offset + tap * a.dil;
     const bool x_ok = live && t_in >= 0 && t_in < a.T_in;
-    const float* xrow = a.x + ((int64_t)b * a.T_in + (x_ok ? t_in : 0)) * a.Cin + ci0 + c8;
-    const float* yrow = a.dy + ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout + co0 + c8;
-    okm = 0;
+    const float* xrow = a.x + ((int64_t)fb * a.T_in + (x_ok ? t_in : 0)) * a.Cin + ci0 + c8;
+    const float* yrow = a.dy + ((int64_t)fb * a.T_y + (int64_t)ft * a.out_stride + a.out_offset) * a.Cout + co0 + c8;
     if (VECX) {
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const bool ok = x_ok && (ci0 + c8 + 4 * v) < a.Cin;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? xrow + 4 * v : a.x);
-        okm |= ok ? (0xFu << (4 * v)) : 0u;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? xrow + 4 * v : a.zeros);
 #pragma unroll
         for (int i = 0; i < 4; ++i) xv[4 * v + i] = q[i];
       }
@@ -460,16 +459,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bool ok = x_ok && (ci0 + c8 + i) < a.Cin;
-        xv[i] = *(ok ? xrow + i : a.x);
-        okm |= ok ? (1u << i) : 0u;
+        xv[i] = *(ok ? xrow + i : a.zeros);
       }
     }
     if (VECY) {
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const bool ok = live && (co0 + c8 + 4 * v) < a.Cout;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? yrow + 4 * v : a.dy);
-        okm |= ok ? (0xF00u << (4 * v)) : 0u;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? yrow + 4 * v : a.zeros);
 #pragma unroll
         for (int i = 0; i < 4; ++i) yv[4 * v + i] = q[i];
       }
@@ -477,21 +474,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bool ok = live && (co0 + c8 + i) < a.Cout;
-        yv[i] = *(ok ? yrow + i : a.dy);
-        okm |= ok ? (0x100u << i) : 0u;
+        yv[i] = *(ok ? yrow + i : a.zeros);
       }
+    }
+    fr += WG_BK;
+    ft += WG_BK;
+    while (ft >= a.T_out) {
+      ft -= a.T_out;
+      ++fb;
     }
   };
 
-  if (r_begin < r_end) fetch(r_begin);
+  if (r_begin < r_end) fetch();
   for (int64_t r0 = r_begin; r0 < r_end; r0 += WG_BK) {
     __syncthreads();
+    if (a.relu_in) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float x = ((okm >> i) & 1u) ? xv[i] : 0.f;
-      if (a.relu_in) x = fmaxf(x, 0.f);
-      xv[i] = x;
-      yv[i] = ((okm >> (8 + i)) & 1u) ? yv[i] : 0.f;
+      for (int i = 0; i < 8; ++i) xv[i] = fmaxf(xv[i], 0.f);
     }
     *reinterpret_cast<f32x4*>(&Xs[kr][c8]) = f32x4{xv[0], xv[1], xv[2], xv[3]};
     *reinterpret_cast<f32x4*>(&Xs[kr][c8 + 4]) = f32x4{xv[4], xv[5], xv[6], xv[7]};
@@ -502,7 +501,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WgradArgs a) {
       for (int i = 0; i < 8; ++i) bsum[i] += yv[i];
     }
     __syncthreads();
-    if (r0 + WG_BK < r_end) fetch(r0 + WG_BK);
+    if (r0 + WG_BK < r_end) fetch();
     float aq[2][2], bq[2][2];
     auto lds_read = [&](int ks, int slot) {
       const int k = ks * 2 + (lane >> 5);
@@ -704,7 +703,11 @@ extern "C" int qpg_conv1d_bwd_weight_f32(qpg_ctx* ctx, void* stream, const float
   const int mblocks = (Cin_pad + 127) / 128;
   const int64_t tiles = (int64_t)taps * mblocks * (Cout_pad / 128);
   const int64_t n_w = (int64_t)taps * Cin_pad * Cout_pad;
-  int S = (int)((4 * (int64_t)ctx->n_cu + tiles - 1) / tiles);
+  // ONE round of blocks: a CU holds four blocks of this kernel (__launch_bounds__(256, 4): <= 128 VGPRs; 16 KB of LDS),
+  // so tiles * S is kept at or below 4 * n_cu.  (Rounded UP, as it was until round 3, 48 tiles x 22 splits = 1056 blocks
+  // needed a second round for the last 32 of them and the launch took two rounds' time.)
+  int S = (int)(4 * (int64_t)ctx->n_cu / tiles);
+  if (S < 1) S = 1;
   const int64_t max_by_rows = (M + 4 * WG_BK - 1) / (4 * WG_BK);     // at least 64 positions per split
   if (S > max_by_rows) S = (int)max_by_rows;
   const int64_t max_by_ws = ws_floats / (n_w + Cout_pad);
@@ -712,7 +715,7 @@ extern "C" int qpg_conv1d_bwd_weight_f32(qpg_ctx* ctx, void* stream, const float
   QPG_REQUIRE(S >= 1, "qpg_conv1d_bwd_weight_f32: workspace smaller than one partial (%lld floats needed)",
               (long long)(n_w + Cout_pad));
   WgradArgs a;
-  a.x = x; a.dy = dy; a.ws = ws;
+  a.x = x; a.dy = dy; a.ws = ws; a.zeros = ctx->zeros;
   a.B = B; a.T_in = T_in; a.Cin = Cin; a.Cin_pad = Cin_pad; a.Cout = Cout; a.Cout_pad = Cout_pad; a.taps = taps;
   a.in_stride = in_stride; a.in_offset = in_offset; a.dil = dil; a.T_out = T_out;
   a.out_stride = out_stride; a.out_offset = out_offset; a.T_y = T_y; a.relu_in = relu_in; a.S = S;

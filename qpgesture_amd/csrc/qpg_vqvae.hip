@@ -50,7 +50,7 @@ struct ConvArgs {
 // WT = backward-data: the contraction runs over the packed weights' OUTPUT-channel axis and the result is indexed
 // by their input-channel axis (B tile = W[tap]^T read in place, no transposed copy of the weights is kept).
 template <int MT, bool VEC, bool WT = false>
-__global__ __launch_bounds__(256) void conv1d_mfma_f32_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, MT == 2 ? 4 : 2) void conv1d_mfma_f32_kernel(ConvArgs a) {
   constexpr int BM = 64 * MT;
   constexpr int AR = BM * CV_BK / 256;                 // A floats per thread per slice: 4 (MT=1) or 8 (MT=2)
   __shared__ float As[1][BM][CV_BK + 1];
