@@ -18,9 +18,11 @@ timeout 900 python bench.py --clips 16 > $O/bench_clips16.json 2> $O/bench_clips
 timeout 900 python bench.py --scaling strong > $O/bench_strong.json 2> $O/bench_strong.err; echo "strong rc=$?" >> $O/rc.txt
 timeout 900 python bench.py --workload cfg3 > $O/bench_cfg3.json 2> $O/bench_cfg3.err; echo "cfg3 rc=$?" >> $O/rc.txt
 timeout 900 python bench.py --data speechlike > $O/bench_speechlike.json 2> $O/bench_speechlike.err; echo "speechlike rc=$?" >> $O/rc.txt
+timeout 300 python tools/bench_train.py 256 > $O/bench_train.log 2>&1; echo "bench_train rc=$?" >> $O/rc.txt
+timeout 300 python tools/prof_train_layers.py > $O/train_layers.md 2>&1; echo "train_layers rc=$?" >> $O/rc.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_$c -o a -- python $R/tools/bench_audio_hl.py > $R/$O/pmc_$c.log 2>&1 ); echo "pmc $c rc=$?" >> $O/rc.txt
   python tools/pmc_summary.py $O/pmc_$c audio > $O/pmc_$c.txt 2>&1
 done
 find $O -name "*.csv" -size +8M -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*memory_copy_trace.csv" -delete
-cat $O/rc.txt; tail -3 $O/pytest.log; head -c 600 $O/bench.json; echo; cat $O/step_timeline.md | tail -16; cat $O/pmc_*.txt
+cat $O/rc.txt; tail -3 $O/pytest.log; head -c 600 $O/bench.json; echo; cat $O/step_timeline.md | tail -16; cat $O/pmc_*.txt; grep forward $O/bench_train.log

@@ -1,4 +1,4 @@
-"""Per-call TFLOP/s of the training step's backward GEMMs (data / weight gradients): each C-ABI call timed alone with
+"""Per-call TFLOP/s of the training step's GEMM launches (forward, data / weight gradients): each C-ABI call timed alone with
 HIP events, grouped by shape.  python tools/prof_train_layers.py [B]"""
 import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,13 +15,25 @@ torch.cuda.synchronize()
 rec = collections.OrderedDict()
 orig = _lib.call
 def timed(name, device, *a):
-    if name not in ("qpg_conv1d_bwd_weight_f32", "qpg_conv1d_bwd_data_f32"):
+    if name not in ("qpg_conv1d_bwd_weight_f32", "qpg_conv1d_bwd_data_f32", "qpg_resblock_f32", "qpg_convt_f32", "qpg_conv1d_f32"):
         return orig(name, device, *a)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     r = orig(name, device, *a)
     e1.record(); torch.cuda.synchronize()
-    if name.endswith("weight_f32"):
+    if name == "qpg_resblock_f32":
+        Bq, T, dil = a[1], a[2], a[3]
+        key = ("resblock", 4, 512, 512, dil, T)
+        fl = 2.0 * Bq * T * 4 * 512 * 512
+    elif name == "qpg_convt_f32":
+        Bq, cx, taps, cout, dil, T_out = a[1], a[3], a[6], a[8], a[12], a[13]
+        key = ("convt", taps, cx, cout, dil, T_out)
+        fl = 2.0 * Bq * T_out * taps * cx * cout
+    elif name == "qpg_conv1d_f32":
+        Bq, cin, taps, cout, dil, T_out = a[1], a[3], a[6], a[8], a[12], a[13]
+        key = ("conv1d", taps, cin, cout, dil, T_out)
+        fl = 2.0 * Bq * T_out * taps * cin * cout
+    elif name.endswith("weight_f32"):
         Bq, T_in, cin, taps, cout, dil, T_out = a[1], a[2], a[3], a[5], a[7], a[11], a[12]
         key = ("wgrad", taps, cin, cout, dil, T_out)
         fl = 2.0 * Bq * T_out * taps * cin * cout
