@@ -41,6 +41,7 @@ struct ConvArgs {
   int tap_base, tap_step;  // weight tap used for input tap j = tap_base + j*tap_step (flips / parity subsets)
   int ksplit;          // > 1: blockIdx.z owns a contiguous range of K slices and writes raw partial sums to ws
   float* ws;           // [ksplit][M][Cout_pad]
+  int vec_out;         // Cout % 4 == 0, y / gate / res 16-byte aligned, B * T_out < 2^31: the epilogue moves 16-byte rows
 };
 
 // MT = 32-row MFMA tiles per wave along M (block tile = 64*MT positions x 128 channels); VEC = 16-B loads of
@@ -53,7 +54,7 @@ template <int MT, bool VEC, bool WT = false>
 __global__ __launch_bounds__(256, MT == 2 ? 4 : 2) void conv1d_mfma_f32_kernel(ConvArgs a) {
   constexpr int BM = 64 * MT;
   constexpr int AR = BM * CV_BK / 256;                 // A floats per thread per slice: 4 (MT=1) or 8 (MT=2)
-  __shared__ float As[1][BM][CV_BK + 1];
+  __shared__ __attribute__((aligned(16))) float As[1][BM][CV_BK + 1];
   __shared__ __attribute__((aligned(16))) float Bs[1][CV_BK][CV_BN];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -229,6 +230,60 @@ __global__ __launch_bounds__(256, MT == 2 ? 4 : 2) void conv1d_mfma_f32_kernel(C
     }
     return;
   }
+#if !defined(QPG_CONV_PROBE) || QPG_CONV_PROBE < 4
+  if (a.vec_out) {
+    // A lane of the 32x32 accumulator tile holds ONE channel of 16 positions: written out as it lies, every store /
+    // gate / residual access is 64 scattered dwords.  Each wave turns its tiles through 2 KB of the (now idle) operand
+    // tiles instead - 16 positions x 32 channels per pass, written as the accumulators lie, read back as 16-byte rows -
+    // so that a wave instruction moves whole 128-byte lines, a quarter of the memory instructions.  (Probe 4 of
+    // experiments/conv_probe: the scalar epilogue was 15 % of a k3 512 -> 512 layer at T = 120.)
+    __syncthreads();                                   // the last slice's operand reads are done
+    float* stage = w < 2 ? &As[0][0][0] + w * 512 : &Bs[0][0][0] + (w - 2) * 512;
+    const unsigned T_out = (unsigned)a.T_out;
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+          for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              stage[(8 * gg + 4 * (lane >> 5) + i) * 32 + (lane & 31)] = acc[mt][half][4 * (2 * p + gg) + i];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + (lane + 64 * j) * 4);
+            const int n = n0 + wn * 64 + half * 32 + (lane & 7) * 4;
+            const int64_t m = m0 + (wm * MT + mt) * 32 + 16 * p + (lane >> 3) + 8 * j;
+            if (m < M && n < a.Cout) {
+              const unsigned b = (unsigned)m / T_out, t = (unsigned)m - b * T_out;
+              const int64_t o = ((int64_t)b * a.T_y + (int64_t)t * a.out_stride + a.out_offset) * a.Cout + n;
+              if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+              if (a.relu_out) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+              if (a.gate) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.gate + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = g[e] > 0.f ? v[e] : 0.f;
+              }
+              if (a.res) {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+              }
+              *reinterpret_cast<f32x4*>(a.y + o) = v;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    return;
+  }
+#endif
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int n = n0 + wn * 64 + half * 32 + (lane & 31);
@@ -296,6 +351,8 @@ static int conv_launch(qpg_ctx* ctx, void* stream, ConvArgs& a, bool wt, float* 
   }
   a.ksplit = ks;
   a.ws = ws;
+  const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) % 16) == 0; };
+  a.vec_out = (a.Cout % 4) == 0 && M < ((int64_t)1 << 31) && al16(a.y) && al16(a.gate) && al16(a.res) && al16(a.bias);
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.Cout_pad / CV_BN), (unsigned)ks);
   hipStream_t st = qpg_stream(stream);
   if (wt) {
