@@ -133,6 +133,9 @@ __global__ __launch_bounds__(256, MT == 2 ? 4 : 2) void conv1d_mfma_f32_kernel(C
       }
     }
     const float* wp = WT ? w_tap + c0 : w_tap + (int64_t)c0 * a.Cout_pad;
+#if defined(QPG_CONV_PROBE) && QPG_CONV_PROBE == 5      // probe: the weight tile comes from the zero page (one hot line)
+    wp = a.zeros;
+#endif
     b0 = *reinterpret_cast<const f32x4*>(wp);
     b1 = *reinterpret_cast<const f32x4*>(wp + 4);
     if (WT && !w_ok) okm = 0x80000000u;
