@@ -420,12 +420,25 @@ class VQVAE:
                   self.threshold, self.bins, E, self.kT.w, self.kT.cout_pad, self.kk, ws, ws.numel(), out)
         return out
 
+    def _fused_block_fills_chip(self, B, T):
+        """resnet_tpath's rule (csrc/qpg_vqvae.hip): the fused block kernel where its 64-position tiles fill the chip."""
+        n_cu = self.__dict__.get("_n_cu")
+        if n_cu is None:
+            n_cu = self.__dict__["_n_cu"] = torch.cuda.get_device_properties(self.device).multi_processor_count
+        return ((B * T + 63) // 64) * 4 >= n_cu * 3
+
     def _res_fwd(self, blocks, x, B, T, reverse, tape, packs=None):
         for d, (c3, c1) in enumerate(blocks):
             dil = self.growth ** (self.depth - 1 - d if reverse else d)              # resnet.py:57-62
-            if packs is not None:             # one launch: the hidden activation is written for the backward pass
+            if packs is not None and self._fused_block_fills_chip(B, T):
+                # one launch: the hidden activation is written for the backward pass
                 y, h = torch.empty_like(x), torch.empty_like(x)
                 _lib.call("qpg_resblock_f32", self.device, x, B, T, dil, packs[d], c3.b, c1.b, y, h)
+            elif packs is not None:
+                # short level (T = 30 at B = 256: 480 waves of 16 positions for 1024 SIMDs): the two-launch form on the
+                # transposed kernels, as qpg_vq_encode_f32 does below the same threshold (0.17 against 0.27 ms per block)
+                h = self._conv_fwd(c3, x, B, T, T, True, in_offset=-dil, dil=dil, relu_in=True, relu_out=True)
+                y = self._conv_fwd(c1, h, B, T, T, True, residual=x)
             else:
                 h = self._conv(c3, x, B, T, T, in_offset=-dil, dil=dil, relu_in=True, relu_out=True)
                 y = self._conv(c1, h, B, T, T, residual=x)

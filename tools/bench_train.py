@@ -13,7 +13,7 @@ opt = Adam(m.parameters(), lr=3e-5, betas=(0.5, 0.999))
 x = torch.randn((B, 240, 135), device=dev)
 FWD = (1.639e9 + 1.908e9) * B           # encoder + decoder flops per window
 def t(fn, iters=5):
-    for _ in range(2): fn()
+    for _ in range(6): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(iters): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters
