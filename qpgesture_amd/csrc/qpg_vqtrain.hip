@@ -406,7 +406,7 @@ struct WgradArgs {
   int64_t rows_per_split;
 };
 
-#define WG_BK 16
+#define WG_BK 16     // positions per chunk (a multiple of 16; 32 - half the barriers, twice the LDS - measured equal: 0.435 vs 0.433 ms)
 template <bool VECX, bool VECY>
 __global__ __launch_bounds__(256, 4) void conv_wgrad_mfma_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float Xs[WG_BK][128];
@@ -424,7 +424,10 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_mfma_kernel(WgradArgs a) {
   if (r_end > M) r_end = M;
   const bool do_bias = blockIdx.x == 0;
 
-  const int kr = tid >> 4, c8 = (tid & 15) * 8;     // staging: thread -> (position row of the chunk, 8 channels)
+  // staging: thread -> position rows kr, kr + 16, ... of the chunk and two 4-channel groups 64 channels apart, so that
+  // eight consecutive lanes write 128 consecutive bytes of a row (ds_write_b128 without bank conflicts)
+  constexpr int RH = WG_BK / 16;
+  const int kr = tid >> 4, c4 = (tid & 15) * 4;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -435,75 +438,98 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_mfma_kernel(WgradArgs a) {
   float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // raw prefetch registers: out-of-range elements are read from the context's zero page, so the loaded values need no
   // select and the loads of the next chunk stay in flight across the MFMA block; ReLU happens at the LDS commit
-  float xv[8], yv[8];
-  // this thread's position row, advanced by WG_BK per chunk (no division inside the loop)
+  float xv[RH][8], yv[RH][8];
+  // this thread's first position row, advanced by WG_BK per chunk (no division inside the loop)
   int64_t fr = r_begin + kr;
   int fb = (int)(fr / a.T_out);
   int ft = (int)(fr - (int64_t)fb * a.T_out);
 
   auto fetch = [&]() {
-    const bool live = fr < r_end;
-    const int t_in = ft * a.in_stride + a.in_offset + tap * a.dil;
-    const bool x_ok = live && t_in >= 0 && t_in < a.T_in;
-    const float* xrow = a.x + ((int64_t)fb * a.T_in + (x_ok ? t_in : 0)) * a.Cin + ci0 + c8;
-    const float* yrow = a.dy + ((int64_t)fb * a.T_y + (int64_t)ft * a.out_stride + a.out_offset) * a.Cout + co0 + c8;
-    if (VECX) {
+    int hb = fb, ht = ft;
+#pragma unroll
+    for (int h = 0; h < RH; ++h) {
+      const bool live = fr + 16 * h < r_end;
+      const int t_in = ht * a.in_stride + a.in_offset + tap * a.dil;
+      const bool x_ok = live && t_in >= 0 && t_in < a.T_in;
+      const float* xrow = a.x + ((int64_t)hb * a.T_in + (x_ok ? t_in : 0)) * a.Cin + ci0 + c4;
+      const float* yrow = a.dy + ((int64_t)hb * a.T_y + (int64_t)ht * a.out_stride + a.out_offset) * a.Cout + co0 + c4;
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
-        const bool ok = x_ok && (ci0 + c8 + 4 * v) < a.Cin;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? xrow + 4 * v : a.zeros);
+        if (VECX) {
+          const bool ok = x_ok && (ci0 + c4 + 64 * v) < a.Cin;
+          const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? xrow + 64 * v : a.zeros);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xv[4 * v + i] = q[i];
+          for (int i = 0; i < 4; ++i) xv[h][4 * v + i] = q[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool ok = x_ok && (ci0 + c4 + 64 * v + i) < a.Cin;
+            xv[h][4 * v + i] = *(ok ? xrow + 64 * v + i : a.zeros);
+          }
+        }
+        if (VECY) {
+          const bool ok = live && (co0 + c4 + 64 * v) < a.Cout;
+          const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? yrow + 64 * v : a.zeros);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) yv[h][4 * v + i] = q[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool ok = live && (co0 + c4 + 64 * v + i) < a.Cout;
+            yv[h][4 * v + i] = *(ok ? yrow + 64 * v + i : a.zeros);
+          }
+        }
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bool ok = x_ok && (ci0 + c8 + i) < a.Cin;
-        xv[i] = *(ok ? xrow + i : a.zeros);
-      }
-    }
-    if (VECY) {
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        const bool ok = live && (co0 + c8 + 4 * v) < a.Cout;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? yrow + 4 * v : a.zeros);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) yv[4 * v + i] = q[i];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bool ok = live && (co0 + c8 + i) < a.Cout;
-        yv[i] = *(ok ? yrow + i : a.zeros);
+      ht += 16;
+      while (ht >= a.T_out) {
+        ht -= a.T_out;
+        ++hb;
       }
     }
     fr += WG_BK;
-    ft += WG_BK;
-    while (ft >= a.T_out) {
-      ft -= a.T_out;
-      ++fb;
-    }
+    fb = hb;
+    ft = ht;
   };
 
+  // ablation hooks (experiments/conv_probe): -DQPG_WGRAD_PROBE=n compiles parts of the chunk loop out; the product build
+  // defines nothing.  1: no global prefetch after the first chunk; 2: and no commit / barriers; 3: MFMAs on constant
+  // registers; 4: as 3, and the partial tile is not stored.
+#ifndef QPG_WGRAD_PROBE
+#define QPG_WGRAD_PROBE 0
+#endif
   if (r_begin < r_end) fetch();
   for (int64_t r0 = r_begin; r0 < r_end; r0 += WG_BK) {
+#if QPG_WGRAD_PROBE < 2
     __syncthreads();
-    if (a.relu_in) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) xv[i] = fmaxf(xv[i], 0.f);
-    }
-    *reinterpret_cast<f32x4*>(&Xs[kr][c8]) = f32x4{xv[0], xv[1], xv[2], xv[3]};
-    *reinterpret_cast<f32x4*>(&Xs[kr][c8 + 4]) = f32x4{xv[4], xv[5], xv[6], xv[7]};
-    *reinterpret_cast<f32x4*>(&Ys[kr][c8]) = f32x4{yv[0], yv[1], yv[2], yv[3]};
-    *reinterpret_cast<f32x4*>(&Ys[kr][c8 + 4]) = f32x4{yv[4], yv[5], yv[6], yv[7]};
-    if (do_bias) {
+    for (int h = 0; h < RH; ++h) {
+      if (a.relu_in) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bsum[i] += yv[i];
+        for (int i = 0; i < 8; ++i) xv[h][i] = fmaxf(xv[h][i], 0.f);
+      }
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        *reinterpret_cast<f32x4*>(&Xs[kr + 16 * h][c4 + 64 * v]) =
+            f32x4{xv[h][4 * v], xv[h][4 * v + 1], xv[h][4 * v + 2], xv[h][4 * v + 3]};
+        *reinterpret_cast<f32x4*>(&Ys[kr + 16 * h][c4 + 64 * v]) =
+            f32x4{yv[h][4 * v], yv[h][4 * v + 1], yv[h][4 * v + 2], yv[h][4 * v + 3]};
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bsum[i] += yv[h][i];
+      }
     }
     __syncthreads();
+#endif
+#if QPG_WGRAD_PROBE < 1
     if (r0 + WG_BK < r_end) fetch();
+#endif
     float aq[2][2], bq[2][2];
     auto lds_read = [&](int ks, int slot) {
+#if QPG_WGRAD_PROBE >= 3
+      aq[slot][0] = aq[slot][1] = bq[slot][0] = bq[slot][1] = 1.0f;
+      return;
+#endif
       const int k = ks * 2 + (lane >> 5);
       aq[slot][0] = Xs[k][wm * 64 + (lane & 31)];
       aq[slot][1] = Xs[k][wm * 64 + 32 + (lane & 31)];
@@ -532,19 +558,22 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#if QPG_WGRAD_PROBE >= 4
+        if (acc[i][j][r] != 12345.678f) continue;
+#endif
         if (ci < a.Cin_pad) wsz[(int64_t)ci * a.Cout_pad + co] = acc[i][j][r];
       }
     }
   if (do_bias) {
-    // column sums of this split's dy rows: add the 16 staging rows in row order
+    // column sums of this split's dy rows: add the 16 staging threads of a column in row order
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) Xs[kr][c8 + i] = bsum[i];
+    for (int i = 0; i < 8; ++i) Xs[kr][c4 + 64 * (i >> 2) + (i & 3)] = bsum[i];
     __syncthreads();
     if (tid < 128) {
       float sacc = 0.f;
 #pragma unroll
-      for (int k = 0; k < WG_BK; ++k) sacc += Xs[k][tid];
+      for (int k = 0; k < 16; ++k) sacc += Xs[k][tid];
       float* bws = a.ws + (int64_t)a.S * a.taps * a.Cin_pad * a.Cout_pad + (int64_t)split * a.Cout_pad;
       bws[co0 + tid] = sacc;
     }
@@ -708,7 +737,7 @@ extern "C" int qpg_conv1d_bwd_weight_f32(qpg_ctx* ctx, void* stream, const float
   // needed a second round for the last 32 of them and the launch took two rounds' time.)
   int S = (int)(4 * (int64_t)ctx->n_cu / tiles);
   if (S < 1) S = 1;
-  const int64_t max_by_rows = (M + 4 * WG_BK - 1) / (4 * WG_BK);     // at least 64 positions per split
+  const int64_t max_by_rows = (M + 4 * WG_BK - 1) / (4 * WG_BK);     // at least four chunks of positions per split
   if (S > max_by_rows) S = (int)max_by_rows;
   const int64_t max_by_ws = ws_floats / (n_w + Cout_pad);
   if (S > max_by_ws) S = (int)max_by_ws;
