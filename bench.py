@@ -324,6 +324,23 @@ def main():
     # 200-step profile, the GPU having idled for ~20 s of host-side data generation before a 12 ms timed region):
     # untimed steps until at least 1 s of back-to-back work has run AND three consecutive 10-step means agree within
     # 2 % (bounded at 6 s).  Not part of --warmup / --steps, which keep their contract meaning.
+    # Everything that idles the GPU (the event pool, a 40 ms garbage collection) happens BEFORE the pre-warm: between the
+    # pre-warm and the timed region there is nothing but the W warm-up steps.  (With the collection behind the pre-warm
+    # the first ~15 timed steps ran 5 % slow - 0.37 falling to 0.35 ms - which a 20-step run averages in.)
+    ev_list = [] if os.environ.get("QPG_BENCH_NO_EVENTS", "") != "1" else None     # (diagnostics)
+    knn.kernel_events_every = int(os.environ.get("QPG_BENCH_EVENTS_EVERY", "1"))
+    # the HIP events that bracket the sweep exist before the timed region (torch creates an event at its first record)
+    knn.kernel_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                             for _ in range(a.steps * max(1, CL if strong else 1) + 8)]
+    for e0, e1 in knn.kernel_event_pool:
+        e0.record()
+        e1.record()
+    # Python's cyclic collector off during the timed region: a full (generation-2) collection of this process takes
+    # ~40 ms, and whether one falls into the 110 ms of 200 steps depends on the allocation count so far - measured as
+    # 0.73 instead of 0.54 ms per step in most runs with --steps 200 and in none with --steps 400 / 1000
+    import gc
+    gc.collect()
+    gc.disable()
     prewarm = {"seconds": 0.0, "steps": 0, "settled": False}
     if not a.no_prewarm:
         tp0 = time.perf_counter()
@@ -345,26 +362,12 @@ def main():
                 prewarm.update(seconds=round(el, 3), settled=bool(ok3),
                                last_10step_means_ms=[round(x * 1e3, 4) for x in means[-3:]])
                 break
-    knn.kernel_events = [] if os.environ.get("QPG_BENCH_NO_EVENTS", "") != "1" else None     # (diagnostics)
-    knn.kernel_events_every = int(os.environ.get("QPG_BENCH_EVENTS_EVERY", "1"))
-    # the HIP events that bracket the sweep exist before the timed region (torch creates an event at its first record)
-    knn.kernel_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                             for _ in range(a.steps * max(1, CL if strong else 1) + 8)]
-    for e0, e1 in knn.kernel_event_pool:
-        e0.record()
-        e1.record()
-    # Python's cyclic collector off during the timed region: a full (generation-2) collection of this process takes
-    # ~40 ms, and whether one falls into the 110 ms of 200 steps depends on the allocation count so far - measured as
-    # 0.73 instead of 0.54 ms per step in most runs with --steps 200 and in none with --steps 400 / 1000
-    import gc
-    gc.collect()
-    gc.disable()
     # the W warm-up steps come LAST, right in front of the fence: a 40 ms garbage collection (or anything else that
     # idles the GPU) between them and the timed region costs the first timed step 0.15 ms of clock ramp - 7 us per step
     # of a 20-step run
-    ev_keep, knn.kernel_events = knn.kernel_events, None
+    knn.kernel_events = None
     run_steps(a.warmup)
-    knn.kernel_events = ev_keep
+    knn.kernel_events = ev_list
     if pipe is not None:
         for ln in pipe.lanes:
             ln["knn"].kernel_events = knn.kernel_events
@@ -521,15 +524,15 @@ def main():
     if mixed and not sharded_run and CL == 1 and pipe is None and enc is None and not a.no_f64_line:
         # the reference-precision figure beside the mixed one, in the same record: 20 more steps with the f64 sweep
         knn.audio_precision = "f64"
-        for _ in range(5):
-            step()
-        knn.kernel_events, knn.kernel_event_pool = [], [(torch.cuda.Event(enable_timing=True),
-                                                          torch.cuda.Event(enable_timing=True)) for _ in range(28)]
-        for e0, e1 in knn.kernel_event_pool:
+        pool6 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(28)]
+        for e0, e1 in pool6:
             e0.record()
             e1.record()
         gc.collect()
         gc.disable()
+        for _ in range(10):             # (after the collection: nothing idles the GPU between these and the timed steps)
+            step()
+        knn.kernel_events, knn.kernel_event_pool = [], pool6
         fence()
         t6 = time.perf_counter()
         for _ in range(20):
