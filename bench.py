@@ -679,15 +679,15 @@ def vqvae_bench(dev, a, world, rank):
     ids = torch.randint(0, 512, (1, 180), device=dev)
 
     def timed(fn, iters, warm):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        import gc
+        gc.collect()                     # (before the warm-up: the GPU does not idle between it and the timed iterations)
+        gc.disable()
         for _ in range(warm):
             fn()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        import gc
-        gc.collect()
-        gc.disable()
         t0 = time.perf_counter()
         for e0, e1 in ev:
             e0.record()
@@ -703,7 +703,7 @@ def vqvae_bench(dev, a, world, rank):
         per = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
         return dt / iters, per[0], per[len(per) // 2]
     te, te_min, te_med = timed(lambda: model.encode(x), 50, 8)
-    td, td_min, td_med = timed(lambda: model.decode([ids]), 50, 8)
+    td, td_min, td_med = timed(lambda: model.decode([ids]), 50, 30)
     enc_flop = 1.639e9 * Bw                                        # 1.639 GFLOP per 240-frame window
     dec_flop = 1.908e9 * 6                                         # 1.908 GFLOP per 240 output frames
     res = {"vqvae_encode_frames_per_s": round(240 * Bw * world / te, 1),
