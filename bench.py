@@ -256,7 +256,18 @@ def main():
         elif my_clips == 1:
             # codes | votes | status written by the walk's last kernel straight into pinned host memory: the step ends
             # on the host with a stream synchronise, no copy launch
-            res = torch.from_numpy(knn.walk(T, M, seed_code=seed_code, seed_phase=seed_phase_d, sync="ints")).view(1, -1)
+            # (the harness stays in NumPy here: three torch CPU operations per step were ~10 us of a 0.34 ms clip)
+            arr = knn.walk(T, M, seed_code=seed_code, seed_phase=seed_phase_d, sync="ints")
+            if arr[-1] != 0 and knn.audio_precision != "exact":
+                rematched[0] += 1
+                prev, knn.audio_precision = knn.audio_precision, "exact"
+                knn.clear_flags()
+                try:
+                    return step()
+                finally:
+                    knn.audio_precision = prev
+            knn.check_status(arr[-2:])
+            return arr[:n_codes].reshape(M, 30)
         else:
             outs = []
             for c in range(my_clips):
@@ -318,7 +329,7 @@ def main():
                 res = step()
                 if rec:
                     step_times.append(time.perf_counter() - t_)
-            return res
+            return torch.from_numpy(res) if isinstance(res, np.ndarray) else res
 
     # Clock / cache steady state regardless of --warmup (the driver's 20-step run was 13 % slower than the
     # 200-step profile, the GPU having idled for ~20 s of host-side data generation before a 12 ms timed region):
@@ -426,6 +437,7 @@ def main():
         gc.enable()
         ms1 = [e0.elapsed_time(e1) for e0, e1 in knn.kernel_events]
         knn.kernel_events = None
+        c1 = torch.from_numpy(c1) if isinstance(c1, np.ndarray) else c1
         assert torch.equal(c1.reshape(-1).to(torch.int32), codes.reshape(-1)), "clips in flight changed the result"
         serial = {"latency_ms_per_clip": round(d1 / n1 * 1e3, 4), "frames_per_s": round(frames_per_step * n1 / d1, 1),
                   "steps": n1, "kernel_ms": round(float(np.mean(ms1)), 4)}
@@ -540,6 +552,7 @@ def main():
         fence()
         d6 = time.perf_counter() - t6
         gc.enable()
+        c64 = torch.from_numpy(c64) if isinstance(c64, np.ndarray) else c64
         ms6 = [e0.elapsed_time(e1) for e0, e1 in knn.kernel_events]
         knn.kernel_events = None
         knn.audio_precision = a.audio_precision
