@@ -409,11 +409,16 @@ class CodeKNN:
             e0, e1 = pool.pop() if pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         use_hl = mixed and self.audio_kernel == "hl" and db.hl_image is not None and not half
         self._last_audio_hl = use_hl
+        sweep_launch = None
         if use_hl:                    # gather + norms + split-f16 image in ONE launch
             nbq = int(_lib.load().qpg_audio_hl_query_bytes(Q, db.F))
             qi = self.__dict__.get("_hl_qimage")
             if qi is None or qi.numel() < nbq:
                 qi = self._hl_qimage = torch.empty((nbq,), dtype=torch.uint8, device=dev)
+            if not (getattr(self, "_want_sweep_event", False) and self.text_lead > 0):
+                # the sweep's arguments are converted BEFORE the pack goes out: its launch follows the pack's at once
+                sweep_launch = _lib.prepare("qpg_audio_cosine_hl", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi,
+                                            qn2, Q, D, 1, D.stride(0), self._guard_stats)
             _lib.call("qpg_audio_pack_queries_hl", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
                       NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2, qi, qi.numel())
         else:
@@ -422,7 +427,9 @@ class CodeKNN:
         if ev is not None:
             e0.record(torch.cuda.current_stream(dev))          # (the events bracket the sweep kernel alone)
         early = False
-        if use_hl:
+        if sweep_launch is not None:
+            sweep_launch()
+        elif use_hl:
             # text_lead > 0 (measurements): the sweep goes out in two launches and the text side's event sits between
             # them, so that its first launches overlap the sweep's last `text_lead`.  bench.py, ms per clip at lead 0 /
             # 0.1 / 0.2 / 0.3 / 0.45: 0.397 / 0.408 / 0.392 / 0.408 / 0.416 - the second launch's ramp-up and the
