@@ -35,6 +35,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # (qpgesture_amd/__init__.py: before the HIP runtime initialises)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

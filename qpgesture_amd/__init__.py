@@ -1,0 +1,8 @@
+"""MI355X-native CodeKNN matcher and gesture VQ-VAE."""
+import os
+
+# Kernel arguments in device memory instead of host-coherent memory (a HIP runtime setting, read when the runtime
+# initialises, i.e. at the process's first HIP call: importing this package before touching the GPU is enough; a value
+# set by the user wins).  The command processor then starts every kernel without fetching its arguments over PCIe - a
+# clip is a chain of 14 short dependent kernels: 0.347 / 0.350 -> 0.330 / 0.323 ms per clip, alternating runs on one box.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
