@@ -413,3 +413,18 @@ def test_sorted_rows_drop_later_duplicates_of_a_code():
     y[2, 5] = 1.0
     m = SortedRows._first_of_duplicates(y, torch.zeros(4, dtype=torch.int64), torch.arange(4))
     assert m.tolist() in ([True, False, True, False], [True, True, True, False])   # (a -0.0 row may hash apart: kept)
+
+
+def test_package_asks_for_device_kernargs_unless_the_user_chose():
+    """qpgesture_amd/__init__.py: HIP_FORCE_DEV_KERNARG=1 by default (read by the HIP runtime at its initialisation), a
+    value already in the environment is left alone."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os; %s; import qpgesture_amd; print(os.environ['HIP_FORCE_DEV_KERNARG'])"
+    for prelude, want in (("os.environ.pop('HIP_FORCE_DEV_KERNARG', None)", "1"),
+                          ("os.environ['HIP_FORCE_DEV_KERNARG'] = '0'", "0")):
+        r = subprocess.run([sys.executable, "-c", code % prelude], cwd=root, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.strip().splitlines()[-1] == want
