@@ -78,6 +78,7 @@ class CosineIndex:
         self.sorted = SortedRows(xn, torch.from_numpy(cm), self.K, dev)
         self.R, self.band = self.sorted.R, self.sorted.band
         self._stats = torch.zeros((4,), dtype=torch.int32, device=dev)
+        self._scratch = {}            # column image / prefilter matrix / tile minima (one index = one stream)
 
     def query(self, q, want_nn=True):
         """q: f32 [Q][d] device tensor.  Returns (dist f32 [Q][K], idx i32 [Q][K], nn i32 [Q])."""
@@ -88,7 +89,7 @@ class CosineIndex:
         if self.method == "mfma" and not getattr(self, "_force_valu", False):
             self.sorted.band = self.band
             nn = torch.empty((Q,), dtype=torch.int32, device=dev) if want_nn else None
-            dist, idx, nn = self.sorted.select(qn, ABSENT, self._stats, nn=nn)
+            dist, idx, nn = self.sorted.select(qn, ABSENT, self._stats, nn=nn, scratch=self._scratch)
             if not getattr(self, "check_flags", True):
                 return dist, idx, nn                   # (timing loops: the flag is read once, after the loop)
             if int(self._stats[1].item()) == 0:

@@ -321,6 +321,9 @@ class CodeKNN:
         # an overflowing band list raises the trouble word and the clip is re-matched on the exact sweep); "valu": the
         # exact-order sweep of every pair (qpg_text_cosine_f32).
         self.text_kernel = "mfma"
+        # column image / prefilter matrix / tile minima of the text prefilter: per matcher (= per stream), never on the
+        # shared GestureDB.txt_sorted - the lanes of a ClipPipeline run their text sides concurrently
+        self._txt_scratch = {}
         self.fallbacks = 0
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
         # Row-sharded DB: the shards sweep in mixed precision too and the cross-shard merge re-evaluates what their
@@ -527,10 +530,11 @@ class CodeKNN:
             if out is not None:           # row shard: straight into the exchange buffer, global indices, merged later
                 dist, idx, qb, bs = out
                 db.txt_sorted.select(qn, float(ABSENT_DIST), self._guard_stats, dist=dist, idx=idx,
-                                     idx_base=db.idx_base * db.Gt, q_block=qb, block_stride=bs)
+                                     idx_base=db.idx_base * db.Gt, q_block=qb, block_stride=bs, scratch=self._txt_scratch)
                 return dist, idx
             rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if want_rank else None
-            dist, idx, _ = db.txt_sorted.select(qn, float(ABSENT_DIST), self._guard_stats, rank=rank)
+            dist, idx, _ = db.txt_sorted.select(qn, float(ABSENT_DIST), self._guard_stats, rank=rank,
+                                                scratch=self._txt_scratch)
             if want_rank:
                 return dist, idx, rank
             return dist, idx
@@ -892,17 +896,26 @@ class CodeKNN:
                   ws.numel(), resp_recv, resp_stride, d, ix, rk, self._guard_stats, fl_cap,
                   0.0 if exact else float(self.tie_eps))
 
-    def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True):
+    def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True,
+             seed_ptrs=None, out_pin=None):
         """Device-side walk of windows [window_offset, window_offset+n_windows) of the tables.
         sync=True: (codes, phases, votes) as NumPy arrays; sync=False: device tensors (+ the status pair), nothing waited
         for, `_last_ints` = codes | votes | status on the device; sync="ints": the integer results only, as ONE host array
         codes | votes | status - the walk's last kernel writes them straight into pinned host memory (zero-copy) and the
-        stream is synchronised: no D2H copy launch behind the walk (bench.py's step; ~5 us of a 0.33 ms clip)."""
+        stream is synchronised: no D2H copy launch behind the walk (bench.py's step; ~5 us of a 0.33 ms clip).
+        seed_ptrs = (address of an i32 seed code, address of its f32 [8][16] phase block), both readable by the device
+        (ClipGraph: pinned host memory the host rewrites before every replay - the seed is then DATA, not a kernel
+        argument, and one captured graph serves every clip); out_pin: a pinned int32 tensor [M*30 + M*steps + 2] the
+        integer results go to (with sync=False: nothing is waited for)."""
         db, dev = self.db, self.db.device
         M, steps = n_windows, self.n_steps()
-        if seed_code is None:
+        if seed_ptrs is not None:
+            seed_code, sp = 0, int(seed_ptrs[1])
+        elif seed_code is None:
             seed_code, seed_phase = self.init_code_phase()
-        if isinstance(seed_phase, torch.Tensor):
+        if seed_ptrs is not None:
+            pass
+        elif isinstance(seed_phase, torch.Tensor):
             sp = seed_phase.to(dev, torch.float32).contiguous()
         else:
             sp = torch.as_tensor(np.asarray(seed_phase, np.float32), device=dev).contiguous()
@@ -911,7 +924,11 @@ class CodeKNN:
         # (copied by the walk's last kernel from _guard_stats[1]): a clip whose word is not 0 is never returned.
         n_c, n_v = M * num_frames_code, M * steps
         host = sync is True or sync == "ints"
-        if host:
+        if out_pin is not None:
+            assert not host and out_pin.numel() >= n_c + n_v + 2
+            base = out_pin.data_ptr()
+            out_codes, out_vote, status = base, base + 4 * n_c, base + 4 * (n_c + n_v)
+        elif host:
             # pinned (device-visible) host memory, one buffer per clip length: safe to reuse because this call does
             # not return before the stream has drained and the values have been copied out of it
             pins = self.__dict__.setdefault("_pinned_ints", {})
@@ -934,11 +951,20 @@ class CodeKNN:
         def sl(t):
             return None if t is None else t[q0:q0 + M * steps]
         a_cidx, a_pslot, a_G = self._audio_grid()
-        _lib.call("qpg_match_steps", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]), sl(T["txt_idx"]),
-                  db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
-                  db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode | (0x100 if self.serial_walk else 0), M, steps,
-                  db.K, int(seed_code), sp,
-                  gate, out_codes, out_phase, out_vote, status, self._guard_stats[1:2])
+        if seed_ptrs is not None:
+            # one chain through the batch entry: its seed code is read from memory by the kernels
+            _lib.call("qpg_match_steps_batch", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]),
+                      sl(T["txt_idx"]), db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
+                      db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode, M, steps, db.K, 1, int(seed_ptrs[0]), sp,
+                      gate, out_codes, out_phase, out_vote, status, 2, self._guard_stats[1:2])
+        else:
+            _lib.call("qpg_match_steps", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]), sl(T["txt_idx"]),
+                      db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
+                      db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode | (0x100 if self.serial_walk else 0), M,
+                      steps, db.K, int(seed_code), sp,
+                      gate, out_codes, out_phase, out_vote, status, self._guard_stats[1:2])
+        if out_pin is not None:
+            return out_codes, out_phase, out_vote, status
         if not host:
             self._last_ints = ints_d
             return out_codes, out_phase, out_vote, status
@@ -1006,12 +1032,14 @@ class CodeKNN:
             raise IndexError("a code that never occurs in the database won a rank fusion "
                              "(the reference raises IndexError at GestureKNN.py:631-632)")
 
-    def capture_clip_graph(self, n_windows, mode=MODE_AUD_TXT, n_sweep_windows=None, window_offset=0):
+    def capture_clip_graph(self, n_windows, mode=MODE_AUD_TXT, n_sweep_windows=None, window_offset=0, audio=None,
+                           context=None):
         """Capture the whole per-clip launch sequence (pack, both sweeps, per-code argmin passes, ranks,
         rank-fusion tables, walk) into one HIP graph for a fixed clip shape.  Returns a ClipGraph whose
         run(test_audio, test_context, seed_code, seed_phase) replays it; results are device tensors.
-        n_sweep_windows > n_windows sweeps more windows than it walks (several clips per sweep: bench.py N>1)."""
-        return ClipGraph(self, n_windows, mode, n_sweep_windows or n_windows, window_offset)
+        n_sweep_windows > n_windows sweeps more windows than it walks (several clips per sweep: bench.py N>1).
+        audio / context: bind the graph to the caller's resident input tensors instead of static copies."""
+        return ClipGraph(self, n_windows, mode, n_sweep_windows or n_windows, window_offset, audio, context)
 
     def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
                    seed_phase=None, return_tables=False):
@@ -1051,57 +1079,114 @@ class CodeKNN:
 
 
 class ClipGraph:
-    """A captured clip: static input buffers + one hipGraph (torch.cuda.CUDAGraph is the HIP graph wrapper;
-    every node is one of this library's kernels or a torch indexing kernel; no memset nodes, see fill_ff_kernel).  The seed code is a kernel ARGUMENT of the walk,
-    so a graph is tied to the seed code it was captured with; the seed phase block is a buffer."""
+    """A captured clip: one hipGraph (torch.cuda.CUDAGraph is the HIP graph wrapper; every node is one of this library's
+    kernels; no memset nodes, see fill_ff_kernel) that replays the whole per-clip launch sequence - query packs, both
+    sweeps, selects, ranks, rank fusion, gate tables, walk - for a fixed clip shape.
 
-    def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset):
+    Nothing about a clip is baked into the capture (round 4): the seed code and the seed phase block live in pinned host
+    memory the kernels read (the walk takes them through qpg_match_steps_batch's seed POINTERS), the inputs are either
+    static buffers `run` copies into or the caller's own resident tensors (`bind`), and the integer results (codes |
+    votes | status) land in pinned host memory behind a system-scope fence, so a replay is: write the seed, write the
+    sentinel, hipGraphLaunch, watch the status word.  One capture serves every clip of that shape."""
+
+    def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset, audio=None, context=None):
         db, dev = knn.db, knn.db.device
-        if db.world != 1:
+        if db.world != 1 or knn.force_sharded:
             raise NotImplementedError("graph capture of the sharded path (collectives inside) is not supported")
+        if knn.host_ranks:
+            raise NotImplementedError("graph capture needs the device-side ranks (tie_rule 'stable')")
         self.knn, self.M, self.mode = knn, n_windows, mode
         Ms = n_sweep_windows
-        if knn.use_wavvq:
-            self.audio = torch.zeros((Ms, db.Tv, 2), dtype=torch.int64, device=dev)
+        if audio is not None:                     # the caller's resident tensors: no copy in front of a replay
+            self.audio, self.context = audio, context
         else:
-            self.audio = torch.zeros((Ms, db.T, db.F), dtype=torch.float32, device=dev)
-        self.context = torch.zeros((Ms, db.R, db.Dt), dtype=torch.float32, device=dev)
-        self.seed_phase = torch.zeros((8, 16), dtype=torch.float32, device=dev)
-        self.seed_code = None
+            if knn.use_wavvq:
+                self.audio = torch.zeros((Ms, db.Tv, 2), dtype=torch.int64, device=dev)
+            else:
+                self.audio = torch.zeros((Ms, db.T, db.F), dtype=torch.float32, device=dev)
+            self.context = torch.zeros((Ms, db.R, db.Dt), dtype=torch.float32, device=dev)
+        # seed block in pinned host memory: [0:128] the f32 phase block, [128] the i32 seed code
+        self._seed_pin = torch.zeros((132,), dtype=torch.float32).pin_memory()
+        self._seed_np = self._seed_pin.numpy()
+        self._seed_code_np = self._seed_np[128:129].view(np.int32)
+        steps = knn.n_steps()
+        self._n_c, self._n_v = n_windows * num_frames_code, n_windows * steps
+        self._pin = torch.empty((self._n_c + self._n_v + 2,), dtype=torch.int32).pin_memory()
+        self._pin_np = self._pin.numpy()
         self._n_sweep, self._off = Ms, window_offset
         self.graph = None
+        self.captures = 0
 
-    def _capture(self, seed_code):
+    def _capture(self):
         knn = self.knn
         dev = knn.db.device
+        ptrs = (self._seed_pin.data_ptr() + 4 * 128, self._seed_pin.data_ptr())
 
         def body():
             T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode)
-            return knn.walk(T, self.M, self._off, self.mode, seed_code, self.seed_phase, sync=False)
+            return knn.walk(T, self.M, self._off, self.mode, sync=False, seed_ptrs=ptrs, out_pin=self._pin)
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
-            for _ in range(2):                       # warm-up: caches, lazy module loads
+            for _ in range(2):                       # warm-up: caches, lazy module loads, workspaces
                 body()
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.out = body()
-        self.graph, self.seed_code = g, seed_code
+        self.graph = g
+        self.captures += 1
+
+    def _set_seed(self, seed_code, seed_phase):
+        sc = int(seed_code)
+        if not 0 <= sc < self.knn.db.K:
+            raise ValueError("seed code %d outside [0, %d)" % (sc, self.knn.db.K))
+        if isinstance(seed_phase, torch.Tensor):
+            seed_phase = seed_phase.detach().cpu().numpy()
+        self._seed_np[:128] = np.asarray(seed_phase, np.float32).reshape(128)
+        self._seed_code_np[0] = sc
+
+    def launch(self, seed_code, seed_phase):
+        """Replay on the current stream without waiting (inputs: whatever the bound / static buffers hold)."""
+        self._set_seed(seed_code, seed_phase)
+        if self.graph is None:
+            self._capture()
+        self._pin_np[-1] = _PIN_SENTINEL
+        self.graph.replay()
+
+    def wait_ints(self):
+        """Host-side wait for the replay's last store (the status word, behind a system-scope fence); returns a copy of
+        codes | votes | status (int32).  The caller hands ints[-2:] to CodeKNN.check_status()."""
+        pin_np = self._pin_np
+        for _ in range(40000):
+            if pin_np[-1] != _PIN_SENTINEL:
+                break
+        else:
+            torch.cuda.current_stream(self.knn.db.device).synchronize()
+            if pin_np[-1] == _PIN_SENTINEL:
+                raise RuntimeError("the walk did not write its status word")
+        return pin_np.copy()
+
+    def run_ints(self, seed_code, seed_phase):
+        """One replay on the bound inputs, ending with the integer results on the host (bench.py's graph step)."""
+        self.launch(seed_code, seed_phase)
+        return self.wait_ints()
 
     def run(self, test_audio, test_context, seed_code, seed_phase):
-        """Copies the clip into the static buffers and replays.  Returns (codes i32 [M,30], phases, votes,
-        status i32 [2]) device tensors (valid until the next run).  The caller must hand the two status ints to
-        CodeKNN.check_status() before using the codes: status[1] != 0 (GuardOverflow) means this clip has to be matched
-        with CodeKNN.match_clip / rematch_exact instead."""
-        self.audio.copy_(test_audio, non_blocking=True)
-        self.context.copy_(test_context, non_blocking=True)
-        self.seed_phase.copy_(torch.as_tensor(seed_phase), non_blocking=True)
-        if self.graph is None or int(seed_code) != self.seed_code:
-            self._capture(int(seed_code))
-        self.graph.replay()
-        return self.out
+        """Copies the clip into the static buffers (skipped for the tensors the graph is bound to) and replays.  Returns
+        (codes i32 [M,30], phases f32 [M,steps,8,16] (device), votes i32 [M,steps], status i32 [2]); the integer results
+        are host tensors (copies).  The caller must hand the two status ints to CodeKNN.check_status() before using the
+        codes: status[1] != 0 (GuardOverflow) means this clip has to be matched with CodeKNN.match_clip / rematch_exact
+        instead."""
+        if test_audio.data_ptr() != self.audio.data_ptr():
+            self.audio.copy_(test_audio, non_blocking=True)
+        if test_context.data_ptr() != self.context.data_ptr():
+            self.context.copy_(test_context, non_blocking=True)
+        ints = torch.from_numpy(self.run_ints(seed_code, seed_phase))
+        n_c, n_v = self._n_c, self._n_v
+        return (ints[:n_c].view(self.M, num_frames_code), self.out[1], ints[n_c:n_c + n_v].view(self.M, -1),
+                ints[n_c + n_v:])
 
 
 class ClipPipeline:

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void match_walk_kernel(TailArgs A) {
     s_cidx[64 + lane] = A.cidx1[lane];
     s_pslot[64 + lane] = A.pslot1[lane];
   }
-  int prev_code = A.seed_code;
+  int prev_code = A.seed_codes ? A.seed_codes[0] : A.seed_code;
   int bad = 0;
   const float eps10 = 10.f * 1.1920928955078125e-07f;
   const int last_idx = A.codes_per_window - 1;                 // the next window is seeded by this kept code

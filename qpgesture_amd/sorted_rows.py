@@ -76,9 +76,6 @@ class SortedRows:
         self.code_tile = torch.cat((torch.zeros((1,), dtype=torch.int64, device=dev),
                                     torch.cumsum(pad_cnt, 0) // 16)).to(torch.int32).contiguous()      # [K + 1] tile prefix
         self.band = float(prefilter_band(d))
-        self._cols = None
-        self._Dm = None
-        self._tmin = None
 
     @staticmethod
     def _first_of_duplicates(xn, codes, keep):
@@ -108,27 +105,33 @@ class SortedRows:
         mask[key_order[drop_sorted]] = False
         return mask
 
-    def select(self, qn, absent, stats, dist=None, idx=None, nn=None, rank=None, idx_base=0, q_block=0, block_stride=0):
+    def select(self, qn, absent, stats, dist=None, idx=None, nn=None, rank=None, idx_base=0, q_block=0, block_stride=0,
+               scratch=None):
         """qn: f32 [Q][d] sklearn-normalised queries.  Prefilter GEMM + banded exact select; per-code tables (dist f32
         [Q][K], idx i32 [Q][K] original row indices), optionally the nearest neighbours nn i32 [Q] and the ranks of the
         table rows (rank i16 [Q][K]).  An overflowing band list ORs 1 into stats[1] (the caller re-evaluates on the exact
         sweep).  idx_base is added to the indices; q_block / block_stride: the row shards' exchange layout (dist / idx are
-        then views of the exchange buffer; no ranks)."""
+        then views of the exchange buffer; no ranks).
+        scratch: a dict OWNED BY THE CALLER that keeps the column image, the prefilter matrix and the tile minima between
+        calls.  This object is shared (GestureDB.txt_sorted is used by every lane of a ClipPipeline, each on its own
+        stream), so it holds no per-call state itself: one caller = one stream = one scratch dict; None allocates per
+        call (stream-ordered by torch's caching allocator)."""
         dev, Q = self.device, qn.shape[0]
         lib = _lib.load()
         nb = int(lib.qpg_hl_cols_bytes(Q, self.d))
-        if self._cols is None or self._cols.numel() < nb:
-            self._cols = torch.empty((nb,), dtype=torch.uint8, device=dev)
-        if self._Dm is None or self._Dm.shape[0] < Q:
-            self._Dm = torch.empty((Q, self.R), dtype=torch.float32, device=dev)
-            self._tmin = torch.empty((Q, self.R // 16), dtype=torch.float32, device=dev)
+        sc = scratch if scratch is not None else {}
+        if sc.get("cols") is None or sc["cols"].numel() < nb:
+            sc["cols"] = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        if sc.get("Dm") is None or sc["Dm"].shape[0] < Q or sc["Dm"].shape[1] != self.R:
+            sc["Dm"] = torch.empty((Q, self.R), dtype=torch.float32, device=dev)
+            sc["tmin"] = torch.empty((Q, self.R // 16), dtype=torch.float32, device=dev)
+        cols, Dm, tmin = sc["cols"], sc["Dm"], sc["tmin"]
         if dist is None:
             dist = torch.empty((Q, self.K), dtype=torch.float32, device=dev)
             idx = torch.empty((Q, self.K), dtype=torch.int32, device=dev)
-        _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, self._cols, self._cols.numel())
-        _lib.call("qpg_hl_gemm_distance", dev, self.image, self.R, self.d, self._cols, Q, self._Dm, self.R,
-                  self._tmin, self.R // 16)
-        _lib.call("qpg_percode_select_sorted_f32", dev, self._Dm, self.R, self._tmin, self.R // 16, Q, self.R,
+        _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, cols, cols.numel())
+        _lib.call("qpg_hl_gemm_distance", dev, self.image, self.R, self.d, cols, Q, Dm, self.R, tmin, self.R // 16)
+        _lib.call("qpg_percode_select_sorted_f32", dev, Dm, self.R, tmin, self.R // 16, Q, self.R,
                   self.row_code, self.row_index, self.zero_row, self.code_tile, self.K, self.band, qn, self.xs, self.d,
                   absent, dist, idx, rank, nn, stats, int(idx_base), int(q_block), int(block_stride))
         return dist, idx, nn

@@ -204,6 +204,8 @@ FIXTURES = {
     "shipped_nearsilent_n48_m2_s50": (48, 2, (50, 51, 52, 53), 0, "shipped", "nearsilent"),
     # AR(1) / rank-64 / 10 % near-silent frames / repeating context rows
     "shipped_speechlike_n48_m2_s60": (48, 2, (60, 61, 62, 63), 0, "shipped", "speechlike"),
+    # mid-size DB from the reference itself (about 80 s of reference time): a DB larger than the tier-1 list caps see
+    "shipped_n256_m2_s70": (256, 2, (70, 71, 72, 73), 0, "shipped"),
     # vq-wav2vec + Levenshtein audio (the mode the paper describes); wavlm_dim=8 keeps the unused WavLM small
     "wavvq_aud_txt_n40_m2_s20": (40, 2, (20, 21, 22, 23), 0, "wavvq_aud_txt"),
     "wavvq_aud_n40_m2_s20": (40, 2, (20, 21, 22, 23), 0, "wavvq_aud"),

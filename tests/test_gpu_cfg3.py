@@ -167,7 +167,7 @@ def test_cfg3_bounded_prefilter_equals_the_exact_sweep():
     od, oi = cref.text_scan(X.reshape(N, 1, D), [0], cm, [0], q[sel], K=K, n_threads=8)
     assert np.array_equal(fi.cpu().numpy()[sel], oi) and np.array_equal(fd.cpu().numpy()[sel], od)
     # the prefilter matrix against the exact f32 distances of the same (sorted) rows: inside half the band
-    Dm = index.sorted._Dm[:8].double().cpu().numpy()
+    Dm = index._scratch["Dm"][:8].double().cpu().numpy()
     rows_ok = (index.sorted.row_index >= 0).cpu().numpy()
     xs = index.sorted.xs.double().cpu().numpy()
     qn = torch.empty_like(qd)

@@ -7,7 +7,7 @@ from tests.helpers import fixture_arrays, load_golden
 
 pytestmark = pytest.mark.gpu
 
-GOLDENS = ["shipped_n48_m2_s0", "shipped_n64_m3_s10"]
+GOLDENS = ["shipped_n48_m2_s0", "shipped_n64_m3_s10", "shipped_n256_m2_s70"]
 
 
 def _build(meta, dev="cuda:0", freq_rank=None):
@@ -219,6 +219,23 @@ def test_clip_graph_replay_equals_eager():
         assert np.array_equal(codes.cpu().numpy().astype(np.int64), g["knn_pred"])
         assert np.array_equal(phases.cpu().numpy(), g["phase_out"])
         assert np.array_equal(votes.cpu().numpy(), g["vote"])
+    # round 4: nothing about a clip is baked into the capture - other seed codes / phase blocks / inputs replay the SAME
+    # graph (the seed is data in pinned host memory, not a kernel argument) and equal the eager path
+    for k in range(1, 5):
+        sc2, sp2 = (sc + 37 * k) % 512, np.roll(sp, k, axis=0) * (1.0 + 0.25 * k)
+        ti2 = te_i.roll(k, 0) + 0.01 * k
+        want = knn.match_clip(ti2, te_c, M, seed_code=sc2, seed_phase=sp2)
+        codes, phases, votes, status = cg.run(ti2, te_c, sc2, sp2)
+        assert status.tolist() == [0, 0]
+        assert np.array_equal(codes.numpy().astype(np.int64), want[0])
+        assert np.array_equal(phases.cpu().numpy(), want[1]) and np.array_equal(votes.numpy(), want[2])
+    assert cg.captures == 1
+    with pytest.raises(ValueError):
+        cg.run(te_i, te_c, 512, sp)
+    # bound to the caller's resident tensors: no copy in front of a replay
+    cb = knn.capture_clip_graph(M, audio=te_i, context=te_c)
+    ints = cb.run_ints(sc, sp)
+    assert np.array_equal(ints[:M * 30].reshape(M, 30), g["knn_pred"]) and ints[-2:].tolist() == [0, 0]
 
 
 @pytest.mark.parametrize("depth", [1, 2, 3])

@@ -11,7 +11,9 @@ from oracle import cref, knn_oracle as O
 from qpgesture_amd import synth
 from tests.helpers import fixture_arrays, load_golden
 
-GOLDENS = ["shipped_n48_m2_s0", "shipped_n64_m3_s10"]
+# (shipped_n256_m2_s70, round 4: ~2 minutes of the reference itself on a DB whose per-code candidate lists are longer than
+# anything the N <= 64 fixtures exercise)
+GOLDENS = ["shipped_n48_m2_s0", "shipped_n64_m3_s10", "shipped_n256_m2_s70"]
 
 
 def test_cosine_emulation_bitexact():
@@ -56,7 +58,7 @@ def test_c_scans_vs_reference(name):
 
 
 @pytest.mark.parametrize("name,scan", [("shipped_n48_m2_s0", "numpy"), ("shipped_n48_m2_s0", "c"),
-                                       ("shipped_n64_m3_s10", "c")])
+                                       ("shipped_n64_m3_s10", "c"), ("shipped_n256_m2_s70", "c")])
 def test_oracle_pipeline_vs_reference(name, scan):
     """Whole restated pipeline (npz load -> windowing -> scans -> rank fusion -> phase gate -> chaining)
     == the reference CLI's knn_pred and every captured intermediate."""

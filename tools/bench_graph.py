@@ -19,9 +19,9 @@ spd = torch.from_numpy(sp).to(dev)
 def eager():
     T = knn.sweep_tables(te_i, te_c, M)
     return knn.walk(T, M, 0, seed_code=sc, seed_phase=spd, sync=False)[0].cpu()
-g = knn.capture_clip_graph(M)
+g = knn.capture_clip_graph(M, audio=te_i, context=te_c)
 def graph():
-    return g.run(te_i, te_c, sc, spd)[0].cpu()
+    return torch.from_numpy(g.run_ints(sc, sp)[:M * 30]).view(M, 30)
 a, b = eager(), graph()
 print("graph == eager:", torch.equal(a, b))
 def t(fn, iters=50):

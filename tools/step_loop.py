@@ -34,12 +34,12 @@ te_i = torch.randn((M, 180, 1024), device=dev)
 te_c = torch.randn((M, 30, 384), device=dev)
 sc, sp = knn.init_code_phase()
 spd = torch.from_numpy(sp).to(dev)
-g = knn.capture_clip_graph(M) if graph else None
+g = knn.capture_clip_graph(M, audio=te_i, context=te_c) if graph else None
 
 
 def step():
     if graph:
-        return g.run(te_i, te_c, sc, spd)[0].cpu()
+        return g.run_ints(sc, sp)
     T = knn.sweep_tables(te_i, te_c, M, owner_blocks=knn.force_sharded)
     return knn.walk(T, M, 0, seed_code=sc, seed_phase=spd, sync="ints")      # (codes | votes | status, pinned host memory)
 

@@ -41,12 +41,26 @@ def main(d, steps):
     if any(len(x) != per for x in segs):
         print("uneven steps:", sorted(set(len(x) for x in segs)))
     print("events per step: %d" % per)
-    print("| # | event | queue | start us | dur us |")
-    print("|---|---|---|---|---|")
-    for i in range(per):
-        st = [(x[i][0] - x[0][0]) / 1e3 for x in segs]
-        du = [(x[i][1] - x[i][0]) / 1e3 for x in segs]
-        print("| %d | %s | %s | %.1f | %.1f |" % (i, segs[-1][i][2], segs[-1][i][3], sum(st) / steps, sum(du) / steps))
+    print("| # | event | queue | start us | end us | dur us |")
+    print("|---|---|---|---|---|---|")
+    # events are matched across steps by (kernel name, occurrence within the step), not by position: under a graph replay
+    # the two branches' launch order is not the same in every step
+    acc, order = {}, []
+    for x in segs:
+        seen = {}
+        for r in x:
+            k = (r[2], seen.get(r[2], 0))
+            seen[r[2]] = k[1] + 1
+            if k not in acc:
+                acc[k] = [[], [], r[3]]
+                order.append(k)
+            acc[k][0].append((r[0] - x[0][0]) / 1e3)
+            acc[k][1].append((r[1] - r[0]) / 1e3)
+    order.sort(key=lambda k: sum(acc[k][0]) / len(acc[k][0]))
+    for i, k in enumerate(order):
+        st, du, qn = acc[k]
+        a, d = sum(st) / len(st), sum(du) / len(du)
+        print("| %d | %s | %s | %.1f | %.1f | %.1f |" % (i, k[0], qn, a, a + d, d))
     ends = [(max(r[1] for r in x) - x[0][0]) / 1e3 for x in segs]
     nxt = [(segs[k + 1][0][0] - segs[k][0][0]) / 1e3 for k in range(steps - 1)]
     print("GPU-side span of a step (first start -> last end): %.1f us;  step period: %.1f us" % (sum(ends) / steps, sum(nxt) / len(nxt)))
