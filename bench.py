@@ -23,6 +23,9 @@ Modes
                    with --encode-batch B pose windows encoded (VQ-VAE) inside the same timed step and
                    --feature-dtype f16 (WavLM base stored in f16, widened in registers, same f64 arithmetic on the
                    f16-rounded values).
+  --scaling replicated  (SURVEY.md 8e "shard Q instead of N"; the throughput axis of BASELINE.json configs[4]) the WHOLE
+                   DB on every GPU (2.2 GB of 288), clips split across the ranks, NO collective in the step.  With
+                   --scaling weak and N > 1 the same leg is measured after the row-sharded figure (`replicated` object).
   --workload cfg3  (BASELINE.json configs[2]) synthetic 100 000 codes x 512-d, 1 000 queries, per-code min + argmin.
 
 Prints ONE JSON line on rank 0.
@@ -92,7 +95,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n-db", type=int, default=None, help="DB windows (default 2048; 8192 with --scaling strong)")
     ap.add_argument("--windows", type=int, default=6)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong", "replicated"], default="weak")
+    ap.add_argument("--no-replicated", action="store_true",
+                    help="N > 1, --scaling weak: skip the extra `replicated` leg (whole DB on every GPU, one clip per rank, no "
+                         "collective) that is otherwise measured after the row-sharded figure, in the same run")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-replay leg (`graph_replay` object)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (`e2e_cli` object)")
     ap.add_argument("--sharded-mixed-min-gflop", type=float, default=None,
                     help="row shards sweep in mixed precision when their sweep is at least this long (default: "
                          "CodeKNN.sharded_mixed_min_gflop = 20; 0 = always)")
@@ -188,10 +196,12 @@ def main():
         return
 
     strong = a.scaling == "strong"
+    replicated = a.scaling == "replicated"
     N = a.n_db if a.n_db is not None else (8192 if strong else 2048)
     M, CL = a.windows, a.clips
-    per = (N + world - 1) // world
-    lo, hi = min(rank * per, N), min((rank + 1) * per, N)
+    db_world, db_rank = (1, 0) if replicated else (world, rank)       # replicated: every rank holds all N windows
+    per = (N + db_world - 1) // db_world
+    lo, hi = min(db_rank * per, N), min((db_rank + 1) * per, N)
     code = synth.make_codes(N, 2)
     sig = synth.make_signature(3)
     phase = np.random.Generator(np.random.PCG64(5)).standard_normal((N, 240, 4, 8)).astype(np.float32)
@@ -199,7 +209,7 @@ def main():
     # GestureDB slices rows [lo,hi) of what it is given: hand it full-height views without the copies
     interp_full = _ShardView(interp_shard, lo, hi, N)
     ctx_full = _ShardView(ctx_shard, lo, hi, N)
-    db = GestureDB(code, interp_full, ctx_full, phase, sig, device=dev, rank=rank, world=world,
+    db = GestureDB(code, interp_full, ctx_full, phase, sig, device=dev, rank=db_rank, world=db_world,
                    feature_dtype=a.feature_dtype)
     knn = CodeKNN(db, rng=np.random.RandomState(123456))
     knn.overlap_sweeps = not a.no_overlap
@@ -218,7 +228,7 @@ def main():
     # the mixed-precision sweep: one GPU, or row shards whose merge re-evaluates through a request / response exchange
     # (taken when the shard's sweep is long enough to pay for the two extra exchanges: CodeKNN.sharded_mixed_min_gflop)
     shard_gflop = 2e-9 * (M * 8 * (CL if strong else CL * world)) * (per * 26) * 6 * 1024
-    sharded_run = world > 1 or force_sharded
+    sharded_run = (world > 1 and not replicated) or force_sharded
     mixed = a.audio_precision == "mixed" and (not sharded_run or shard_gflop >= knn.sharded_mixed_min_gflop)
 
     # clips: weak = CL per rank (every rank holds all of them: M*180*1024 f32 = 4.4 MB each); strong = ONE clip in all
@@ -245,12 +255,20 @@ def main():
     batch_walk = os.environ.get("QPG_BENCH_SERIAL_WALKS", "") != "1"          # (measurements: one walk per clip)
     seed_phases_d = seed_phase_d.reshape(1, -1).repeat(max(my_clips, 1), 1).contiguous()
 
+    te_interp_all, te_ctx_all = te_interp, te_ctx
+    if replicated and world > 1:
+        # this rank's own clips only: the sweep sees CL clips, nothing is exchanged
+        te_interp = te_interp[rank * CL * M:(rank + 1) * CL * M].contiguous()
+        te_ctx = te_ctx[rank * CL * M:(rank + 1) * CL * M].contiguous()
+    n_sweep_clips = CL if replicated else n_clips
+
     def step():
         # weak, N > 1: every rank sweeps all clips' queries against its DB shard; ONE all-to-all leaves each rank with
         # the final tables of its own clips.  strong: ONE all-gather + merge, every rank holds the clip's tables.
+        # replicated: this rank's clips against the whole DB, no exchange.
         if enc is not None:
             ids = enc.encode(enc_x)[0]
-        T = knn.sweep_tables(te_interp, te_ctx, M * n_clips, owner_blocks=(world > 1 or force_sharded) and not strong)
+        T = knn.sweep_tables(te_interp, te_ctx, M * n_sweep_clips, owner_blocks=sharded_run and not strong)
         if my_clips > 1 and batch_walk:
             # the clips are independent chains (their own seeds / window chaining): ONE set of walk launches for all
             knn.walk_batch(T, M, my_clips, [seed_code] * my_clips, seed_phases_d)
@@ -299,7 +317,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     pipe = None
-    can_pipe = world == 1 and CL == 1 and enc is None and not a.no_overlap
+    can_pipe = world == 1 and CL == 1 and enc is None and not a.no_overlap and not force_sharded
     if a.clips_in_flight > 1:
         # throughput mode: the SAME per-clip launches, issued on `clips_in_flight` lanes; a step still ends with its
         # clip's indices on the host (collected one lane later)
@@ -445,7 +463,7 @@ def main():
                   "steps": n1, "kernel_ms": round(float(np.mean(ms1)), 4)}
 
     # ---- roofline of the dominant kernel (audio_cosine_f64_kernel), per launch on this rank --------------
-    Q = M * n_clips * 8
+    Q = M * n_sweep_clips * 8
     C = db.n_local * db.Ga
     fb = 2 if a.feature_dtype == "f16" else 4
     flops = 2.0 * Q * C * 6 * db.F                                  # 2*Q*N*26*6144
@@ -503,11 +521,22 @@ def main():
     if strong:
         par = ("db-row-shard x%d + all-gather(min,index) + local merge, replicated walk" % world) if world > 1 \
             else "single GPU, unsharded DB"
+    elif replicated:
+        par = "replicated DB x%d, clip-parallel, no collective" % world
     else:
         par = ("db-row-shard x%d + all-to-all(min,index)" % world) if world > 1 else "single GPU, unsharded DB"
+    # collectives per step: all-gather form (strong) = tables + responses; all-to-all form (weak) = tables + requests +
+    # responses + the 4-byte MAX of the merge's own trouble bits; f64 shards: the tables' exchange (+ the word in the
+    # all-to-all form); replicated / one GPU: none
+    if not sharded_run:
+        n_coll = 0
+    elif mixed or a.audio_precision == "exact":
+        n_coll = 2 if strong else 4
+    else:
+        n_coll = 1 if strong else 2
     out = {"metric": "matched gesture frames/sec (GestureKNN)", "value": round(value, 1), "unit": "frames/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-           "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+           "higher_is_better": True, "scaling": "weak" if replicated else a.scaling, "vs_baseline": None,
            "dtype": ("split-f16 products / f64 block sums + f64 re-evaluation" if hl else "f32 sweep + f64 re-evaluation")
            if mixed else "f64",
            "data": "synthetic",
@@ -520,7 +549,8 @@ def main():
                                      if a.encode_batch else ""),
                       "n_db": N, "windows_per_clip": M, "clips": n_clips, "clips_per_gpu": CL,
                       "feature_dtype": a.feature_dtype, "audio_precision": "mixed" if mixed else "f64",
-                      "encode_batch": a.encode_batch, "clips_in_flight": a.clips_in_flight, "parallelism": par},
+                      "encode_batch": a.encode_batch, "clips_in_flight": a.clips_in_flight, "parallelism": par,
+                      "collectives_per_step": n_coll},
            "roofline": roofline,
            "realtime_factor": round(24.0 * M / 6 / (dt / a.steps), 1) if strong
            else round(value / 60.0 / world, 1)}
@@ -535,7 +565,9 @@ def main():
                                  "band": 2.1 * (1.3e-6 if hl else 2.05e-6)}
     out["prewarm"] = prewarm
     out["rematched_steps"] = rematched[0] + (pipe.fallbacks if pipe is not None else 0)
-    if mixed and not sharded_run and CL == 1 and pipe is None and enc is None and not a.no_f64_line:
+    if world > 1 or force_sharded:
+        out["ranks_seen"] = ranks_seen(dev, world, rank, one_gpu == "1")
+    if mixed and not sharded_run and world == 1 and CL == 1 and pipe is None and enc is None and not a.no_f64_line:
         # the reference-precision figure beside the mixed one, in the same record: 20 more steps with the f64 sweep
         knn.audio_precision = "f64"
         pool6 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(28)]
@@ -559,12 +591,45 @@ def main():
         knn.kernel_events = None
         knn.audio_precision = a.audio_precision
         k6 = float(np.mean(ms6))
+        # the like-for-like figure (the reference's f64 cosine, GestureKNN.py:685) as top-level keys beside `value`
+        out["value_f64"] = round(frames_per_step * 20 / d6, 1)
+        out["ms_per_step_f64"] = round(d6 / 20 * 1e3, 4)
         out["f64_sweep"] = {"ms_per_step": round(d6 / 20 * 1e3, 4), "steps": 20, "kernel": "audio_cosine_f64_kernel",
                             "kernel_ms": round(k6, 4), "kernel_ms_min": round(float(np.min(ms6)), 4),
                             "achieved": round(flops / (k6 * 1e-3) / 1e12, 3), "peak": F64_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(flops / (k6 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
                             "codes_equal_default_path": bool(torch.equal(c64, codes))}
-    if (mixed and not sharded_run and can_pipe and pipe is None and not a.no_f64_line and
+    if mixed and not sharded_run and world == 1 and CL == 1 and pipe is None and enc is None and not a.no_graph:
+        # the same launches replayed as ONE hipGraph (code_knn.ClipGraph, bound to the resident clip): the seed code and
+        # phase block are data in pinned host memory, the integer results come back through pinned memory - a step is
+        # "write seed + sentinel, hipGraphLaunch, watch the status word".  One capture serves every clip of this shape.
+        cg = knn.capture_clip_graph(M, audio=te_interp, context=te_ctx)
+        for _ in range(10):
+            gi = cg.run_ints(seed_code, seed_phase)
+        gc.collect()
+        gc.disable()
+        dgs = []
+        for _ in range(3):
+            fence()
+            tg = time.perf_counter()
+            for _ in range(a.steps):
+                gi = cg.run_ints(seed_code, seed_phase)
+            fence()
+            dgs.append(time.perf_counter() - tg)
+        gc.enable()
+        # another seed through the SAME capture must equal the eager path started from that seed
+        sc2 = (seed_code + 101) % 512
+        sp2 = np.roll(seed_phase, 3, axis=0)
+        g2 = cg.run_ints(sc2, sp2)
+        e2 = knn.walk(knn.sweep_tables(te_interp, te_ctx, M), M, seed_code=sc2, seed_phase=sp2, sync="ints")
+        out["graph_replay"] = {"ms_per_step": round(min(dgs) / a.steps * 1e3, 4), "steps": a.steps,
+                               "ms_per_step_all_three_runs": [round(x / a.steps * 1e3, 4) for x in dgs],
+                               "frames_per_s": round(frames_per_step * a.steps / min(dgs), 1),
+                               "captures": cg.captures,
+                               "codes_equal_default_path": bool(np.array_equal(gi[:n_codes], codes.numpy().reshape(-1))),
+                               "status": [int(gi[-2]), int(gi[-1])],
+                               "other_seed_equals_eager": bool(np.array_equal(g2, e2))}
+    if (mixed and not sharded_run and world == 1 and can_pipe and pipe is None and not a.no_f64_line and
             os.environ.get("QPG_BENCH_NO_PIPELINED", "") != "1"):
         # the same per-clip launches with three clips in flight (ClipPipeline: the next clips' sweeps are enqueued before a
         # clip's indices are collected, so the host's ~50 us between a step's last GPU event and the next step's first
@@ -625,25 +690,33 @@ def main():
         n_run = a.steps + a.warmup + prewarm["steps"]
         k64 = CodeKNN(db, rng=np.random.RandomState(123456))
         k64.audio_precision = "f64"
-        T64 = k64.sweep_tables(te_interp, te_ctx, M * n_clips)
+        T64 = k64.sweep_tables(te_interp, te_ctx, M * n_sweep_clips)
         same = True
         for c in range(my_clips):
             w64 = k64.walk(T64, M, window_offset=c * M, seed_code=seed_code, seed_phase=seed_phase_d)[0]
             same = same and bool(np.array_equal(np.asarray(w64).reshape(-1),
                                                 codes.numpy().reshape(my_clips, -1)[c].astype(np.int64)))
-        Tm = knn.sweep_tables(te_interp, te_ctx, M * n_clips)
+        Tm = knn.sweep_tables(te_interp, te_ctx, M * n_sweep_clips)
         out["mixed_precision"] = {
             "f64_dot_pairs_per_step": round(st["tier1_pairs"] / n_run, 1),
             "reference_arithmetic_pairs_per_step": round(st["tier2_pairs"] / n_run, 2),
             "flags": st["flags"], "error_bound": 1.3e-6 if hl else 2.05e-6,
+            # the one measured constant under that bound, re-measured at load time on THIS device (selfcheck.py)
+            "mfma_selfcheck": {k_: db.hl_bound_report.get(k_) for k_ in ("kappa", "kappa2", "kappa2_assumed", "kappa2_limit",
+                                                                         "skipped")},
             "max_table_difference_vs_f64_sweep": float((Tm["aud_d"] - T64["aud_d"]).abs().max()),
             "winners_equal_f64_sweep": bool(torch.equal(Tm["aud_idx"], T64["aud_idx"])),
             "ranks_equal_f64_sweep": bool(torch.equal(Tm["aud_rank"], T64["aud_rank"])),
             "codes_equal_f64_sweep": same}
+    if world > 1 and not replicated and not strong and not a.no_replicated and not force_sharded and CL == 1:
+        out["replicated"] = replicated_leg(a, dev, world, rank, N, M, code, phase, sig, te_interp_all, te_ctx_all,
+                                           seed_code, seed_phase_d, codes if a.check else None)
     if not a.no_vqvae:
         out.update(vqvae_bench(dev, a, world, rank))
     if rank == 0 and world == 1 and CL == 1 and not a.no_cold and fb == 4:
         out["cold"] = cold_bench(dev, N, M)
+    if rank == 0 and world == 1 and CL == 1 and not a.no_e2e and not a.no_cold and fb == 4 and a.data == "gaussian":
+        out["e2e_cli"] = e2e_cli_bench(dev, N, M)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and fb == 4:
         out["cpu_baseline"] = cpu_baseline(a, code, clips[0], M, N)
         out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
@@ -657,7 +730,7 @@ def main():
         want = []
         for c in range(my_clips):
             w0 = (first + c) * M
-            T1 = k1.sweep_tables(te_interp[w0:w0 + M], te_ctx[w0:w0 + M], M)
+            T1 = k1.sweep_tables(te_interp_all[w0:w0 + M], te_ctx_all[w0:w0 + M], M)
             want.append(k1.walk(T1, M, 0, seed_code=seed_code, seed_phase=seed_phase_d)[0])
         ok = bool(np.array_equal(np.concatenate(want), codes.numpy().astype(np.int64)))
         out["check"] = ok
@@ -675,6 +748,131 @@ HL_TRAFFIC_SOURCE = "profiles/r03_pmc_audio_hl.md (rocprofv3 --pmc FETCH_SIZE / 
 AUDIO_HL_TRAFFIC_BYTES = 709_000_000      # split-operand f16 sweep, dense image: FETCH_SIZE 341.4e3 KB x 1024 x 2 + WRITE_SIZE 9 984 KB x 1024
 AUDIO_TRAFFIC_BYTES = 923_000_000
 AUDIO_MX_TRAFFIC_BYTES = 1_023_000_000    # mixed-precision sweep (one launch: mx2 blocks + split-K remainder), same file
+
+
+def ranks_seen(dev, world, rank, host_staged):
+    """Proof that N ranks on N devices took part: an all-gather of every rank's device UUID (16 bytes) over the job's
+    process group (RCCL for the driver's runs)."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    props = torch.cuda.get_device_properties(dev)
+    raw = getattr(props, "uuid", None)
+    try:
+        b = raw.bytes if raw is not None else None
+    except AttributeError:
+        b = None
+    if b is None:
+        b = hashlib.md5(("%s|%s|%d" % (props.name, getattr(props, "pci_bus_id", "?"), dev.index or 0)).encode()).digest()
+    mine = torch.tensor(list(b[:16]), dtype=torch.uint8, device="cpu" if host_staged else dev)
+    allb = torch.empty((world * 16,), dtype=torch.uint8, device=mine.device)
+    if host_staged or world == 1:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        allb = torch.cat(parts)
+    else:
+        dist.all_gather_into_tensor(allb, mine)
+    ids = [bytes(allb[i * 16:(i + 1) * 16].cpu().tolist()).hex() for i in range(world)]
+    return {"ranks": world, "distinct_devices": len(set(ids)), "device_uuids": ids, "backend": dist.get_backend()}
+
+
+def replicated_leg(a, dev, world, rank, N, M, code, phase, sig, te_interp, te_ctx, seed_code, seed_phase_d, want):
+    """The clip-parallel mode beside the row-sharded figure, in the same run: the WHOLE database on every GPU (0.68 GB
+    image + 1.5 GB base of 288 GB), rank r matches clip r, no collective in the step (BASELINE.json
+    configs[4]'s throughput axis).  Same timing contract: barrier + synchronise on both sides, MAX over ranks."""
+    import gc
+    import torch
+    import torch.distributed as dist
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    full_i, full_c = chunked_db(N, 0, N, seed=0)
+    dbr = GestureDB(code, full_i, full_c, phase, sig, device=dev, feature_dtype=a.feature_dtype)
+    del full_i, full_c
+    kr = CodeKNN(dbr, rng=np.random.RandomState(123456))
+    kr.audio_precision = a.audio_precision
+    ti = te_interp[rank * M:(rank + 1) * M].contiguous()
+    tc = te_ctx[rank * M:(rank + 1) * M].contiguous()
+
+    def one():
+        T = kr.sweep_tables(ti, tc, M)
+        arr = kr.walk(T, M, seed_code=seed_code, seed_phase=seed_phase_d, sync="ints")
+        kr.check_status(arr[-2:])
+        return arr[:M * 30]
+    for _ in range(30):
+        got = one()
+    gc.collect()
+    gc.disable()
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        got = one()
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    gc.enable()
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        dt = float(h.item())
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res = {"value": round(240 * M * world * a.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
+           "steps": a.steps, "scaling": "weak", "collectives_per_step": 0,
+           "parallelism": "replicated DB x%d, clip-parallel, no collective" % world}
+    if want is not None:
+        res["codes_equal_row_sharded"] = bool(np.array_equal(got.reshape(-1), want.numpy().reshape(-1)))
+    return res
+
+
+def e2e_cli_bench(dev, N, M):
+    """BASELINE.json configs[0] / [1] end to end: the drop-in command line (qpgesture_amd/GestureKNN.py main, the
+    reference's flags) from eight .npz files on disk to result.npz - np.load, H2D, device-side resample, DB build, match,
+    np.savez_compressed - for both --tie_rule values (`numpy`, the default: both (Q,512) tables are ranked by the
+    reference's own NumPy call on the host in the middle of the step).  The phase track is written DENSE (f32
+    (N,240,4,8), accepted by the loader): the reference's object array of 245 760 pickled torch tensors per 256 windows
+    costs ~65 ms per DB window to unpickle on either side and says nothing about this path.  PCIe- and disk-inclusive:
+    never `value`."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from qpgesture_amd import synth
+    from qpgesture_amd import GestureKNN as cli
+    td = tempfile.mkdtemp(prefix="qpg_e2e_")
+    try:
+        t0 = time.perf_counter()
+        paths = synth.write_npz_set_dense(td, N, M, chunked_db)
+        t_write = time.perf_counter() - t0
+        res = {"n_db": N, "windows": M, "npz_bytes": int(sum(os.path.getsize(v) for v in paths.values())),
+               "write_s": round(t_write, 2)}
+        ref = None
+        for rule in ("numpy", "stable"):
+            ts = []
+            for rep in range(2):
+                outp = os.path.join(td, "result_%s.npz" % rule)
+                argv = []
+                for k, v in paths.items():
+                    argv += ["--" + k, v]
+                argv += ["--out_knn_filename", outp, "--tie_rule", rule, "--device", str(dev)]
+                t1 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    cli.main(argv)
+                ts.append(time.perf_counter() - t1)
+            pred = np.load(outp)["knn_pred"]
+            assert pred.shape == (M, 30) and pred.dtype == np.int64
+            res["tie_rule_" + rule] = {"seconds": round(min(ts), 3), "seconds_first_run": round(ts[0], 3),
+                                       "frames_per_s": round(240 * M / min(ts), 1)}
+            if ref is None:
+                ref = pred
+            else:
+                res["same_codes_both_rules"] = bool(np.array_equal(ref, pred))
+        return res
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def vqvae_bench(dev, a, world, rank):

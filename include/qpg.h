@@ -366,13 +366,25 @@ int64_t qpg_percode_select_mixed_ws_stride(int K);
  * The same three calls with eps1 = the near-tie band (1e-12), reference_arithmetic = 1 and eps2 = 0 are the cross-shard
  * TIER 2: the uncapped sharded path (CodeKNN, audio_precision "exact"). */
 int64_t qpg_merge_mixed_ws_bytes(int Q, int K, int fl_cap);
+/* Round 4: request slots are DETERMINISTIC - (query q, code k) -> shard w sits at slot q * (R / Q) + its position among q's
+ * requests to w in code order, unused slots hold ~0 (R % Q == 0) - so every rank that merges the same tables builds the
+ * same request blocks and, in the all-gather form, a shard refines its own block of its own run: no request exchange.
+ * Block headers (8 bytes in front of the R slots of a request / response block): [i32 count (diagnostics) | i32 trouble
+ * bits].  The bits TRAVEL WITH THE EXCHANGES: phase 1 ORs the W table blocks' flag words (at `flag_off` inside a table
+ * block, < 0: none) into stats[1] and seeds the request headers; the shard refine ORs the received request headers into
+ * stats[1] (stats may be NULL) and seeds the response headers; phase 2 ORs those in.  resp_stride >= 8 + 8 R. */
 int qpg_merge_mixed_phase1_f64(qpg_ctx*, void* stream, const void* recv, int W, int64_t src_stride, int64_t dist_off,
                                int64_t idx_off, int Q, int K, double absent, double eps1, int R, void* req,
-                               int64_t req_stride, void* ws, int64_t ws_bytes, int32_t* stats, int fl_cap);
+                               int64_t req_stride, void* ws, int64_t ws_bytes, int32_t* stats, int fl_cap,
+                               int64_t flag_off);
 int qpg_shard_refine_f64(qpg_ctx*, void* stream, const void* req_recv, int W, int64_t req_stride, int R, int q_stride,
                          int64_t cand_base, const float* base, int base_is_f16, int T, int F, const int32_t* cand_t, int G,
                          int n_taps, int tap_stride, const float* q32, const double* qn2, const double* cn2, void* resp,
-                         int64_t resp_stride, int reference_arithmetic);
+                         int64_t resp_stride, int reference_arithmetic, int32_t* stats, int Rq);
+/* The trouble word riding in an exchanged buffer: stamp = every one of nblk blocks' i32 at `off` := stats[1] (sender,
+ * before the exchange); gather = stats[1] |= OR of the nblk received words (receiver). */
+int qpg_flags_stamp(qpg_ctx*, void* stream, void* buf, int nblk, int64_t stride, int64_t off, const int32_t* stats);
+int qpg_flags_gather(qpg_ctx*, void* stream, const void* buf, int nblk, int64_t stride, int64_t off, int32_t* stats);
 int qpg_merge_mixed_phase2_f64(qpg_ctx*, void* stream, const void* recv, int W, int64_t src_stride, int64_t idx_off, int Q,
                                int K, double absent, const void* ws, int64_t ws_bytes, const void* resp_recv,
                                int64_t resp_stride, double* out_dist, int32_t* out_idx, int16_t* out_rank, int32_t* stats,

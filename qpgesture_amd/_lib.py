@@ -61,8 +61,10 @@ _SIGS = {
                                      P, P, c_double, c_double, P, P, L, I],
     "qpg_percode_select_exact_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
                                      c_double, P, I, P, L],
-    "qpg_merge_mixed_phase1_f64": [P, I, L, L, L, I, I, c_double, c_double, I, P, L, P, L, P, I],
-    "qpg_shard_refine_f64": [P, I, L, I, I, L, P, I, I, I, P, I, I, I, P, P, P, P, L, I],
+    "qpg_merge_mixed_phase1_f64": [P, I, L, L, L, I, I, c_double, c_double, I, P, L, P, L, P, I, L],
+    "qpg_shard_refine_f64": [P, I, L, I, I, L, P, I, I, I, P, I, I, I, P, P, P, P, L, I, P, I],
+    "qpg_flags_stamp": [P, I, L, L, P],
+    "qpg_flags_gather": [P, I, L, L, P],
     "qpg_merge_mixed_phase2_f64": [P, I, L, L, I, I, c_double, P, L, P, L, P, P, P, P, I, c_double],
     "qpg_merge_select_f64": [P, I, L, L, L, I, I, c_double, P, P, P, c_double, P],
     "qpg_merge_select_f32": [P, I, L, L, L, I, I, c_float, P, P, P],

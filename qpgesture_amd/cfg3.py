@@ -67,6 +67,10 @@ class CosineIndex:
         self.fallbacks = 0
         self.method = method if (feature_dtype == "f32" and d % 128 == 0 and n_codes < 0x2000) else "valu"
         if self.method == "mfma":
+            from .selfcheck import mfma_bound_ok          # the prefilter's bound rests on a measured hardware constant
+            if not mfma_bound_ok(dev)[0]:
+                self.method = "valu"
+        if self.method == "mfma":
             self._build_sorted(xd.view(n, d), cm)
 
     def _build_sorted(self, xd, cm):

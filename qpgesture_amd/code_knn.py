@@ -91,8 +91,11 @@ def _i32(x, dev):
 class ExchangeLayout:
     """Byte layout of the (minimum, index) tables a rank contributes to the cross-shard exchange: `nblk` blocks (one
     per destination rank for the owner-partitioned all-to-all, one in all for the all-gather) of `Qb` query rows,
-    each block = [aud_d f64 | aud_i i32 | txt_d f32 | txt_i i32] (the modalities in use), every array Qb*K entries.
-    The select kernels write straight into it (no packing pass); qpg_merge_select_* reads the received copy."""
+    each block = [aud_d f64 | aud_i i32 | txt_d f32 | txt_i i32] (the modalities in use), every array Qb*K entries,
+    then one 8-byte slot whose first i32 is the sender's TROUBLE WORD (qpg_flags_stamp: the bits travel with the tables
+    instead of in their own all-reduce).
+    The select kernels write straight into it (no packing pass); qpg_merge_select_* reads the received copy.
+    A layout (and its send buffer) is built once per shape and kept by the matcher (CodeKNN._layout)."""
 
     def __init__(self, Qtot, K, nblk, parts, audio_f64, device):
         assert Qtot % nblk == 0, "query rows must split evenly over the ranks"
@@ -104,9 +107,10 @@ class ExchangeLayout:
             self.off[p + "_d"], o = o, o + n * dsz
             self.off[p + "_i"], o = o, o + n * 4
             o = (o + 7) // 8 * 8
+        self.off["flags"], o = o, o + 8
         self.block_bytes = o
         self.dtype = {p: (torch.float64 if (p == "aud" and audio_f64) else torch.float32) for p in self.parts}
-        self.send = torch.empty((nblk * self.block_bytes,), dtype=torch.uint8, device=device)
+        self.send = torch.zeros((nblk * self.block_bytes,), dtype=torch.uint8, device=device)
 
     def views(self, p):
         """(dist, idx) tensors aliasing block 0's arrays of modality p + the select kernel's layout arguments."""
@@ -210,6 +214,14 @@ class GestureDB:
         # fragment order; built when the grid has the reference's shape (6 taps 2 frames apart, 26 positions 6 apart)
         self.hl_image = None
         lib = _lib.load()
+        # the bounded (split-f16) paths rest on one measured property of the matrix core: re-measured once per process
+        # and device (selfcheck.mfma_bound_ok); a device that fails it gets the f64 sweep and the exact-order text sweep
+        self.hl_bound_ok, self.hl_bound_report = (True, {"skipped": True})
+        if (hl_image or text_prefilter) and self.n_local:
+            from .selfcheck import mfma_bound_ok
+            self.hl_bound_ok, self.hl_bound_report = mfma_bound_ok(dev)
+            if not self.hl_bound_ok:
+                hl_image = text_prefilter = False
         if (hl_image and feature_dtype == "f32" and self.n_local and len(kint) > 1 and
                 kint == [i * (kint[1] - kint[0]) for i in range(len(kint))] and
                 lib.qpg_audio_hl_supported(self.T, self.F, self.Ga, NUM_AUDIO_FEAT_FRAMES, self.tap_stride,
@@ -395,7 +407,7 @@ class CodeKNN:
         # (the same number on every rank — the largest shard's — so that all ranks take the same path: the mixed merge
         # has two more collectives than the f64 one)
         gflop = 2e-9 * Q * (-(-db.N // db.world) * db.Ga) * NUM_AUDIO_FEAT_FRAMES * db.F
-        mixed = (self.audio_precision == "mixed" and self.tie_eps > 0 and C > 0 and db.K <= 512 and
+        mixed = (self.audio_precision == "mixed" and self.tie_eps > 0 and C > 0 and db.K <= 512 and db.hl_bound_ok and
                  (local_final or (shard_part and self.sharded_mixed and gflop >= self.sharded_mixed_min_gflop)))
         exact = self.audio_precision == "exact" and self.tie_eps > 0 and C > 0
         self._last_audio_mixed, self._last_audio_exact = mixed, exact
@@ -476,12 +488,18 @@ class CodeKNN:
                 # (zero-filled ONCE: the select's streamed state is all-zero between launches, qpg.h)
                 ws = self._mix_ws = torch.zeros((need,), dtype=torch.uint8, device=dev)
             self._last_mix_Q = Q
-            _lib.call("qpg_percode_select_mixed_f64", dev, D, 1, D.stride(0), Q, db.aud_cand_code, C, db.K,
-                      float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
-                      db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2,
-                      AUDIO_HL_BAND if use_hl else AUDIO_MX_BAND, float(self.tie_eps),
-                      self._guard_stats, None if self.mixed_single_launch else ws,
-                      0 if self.mixed_single_launch else ws.numel(), int(half))
+            try:
+                _lib.call("qpg_percode_select_mixed_f64", dev, D, 1, D.stride(0), Q, db.aud_cand_code, C, db.K,
+                          float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
+                          db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2,
+                          AUDIO_HL_BAND if use_hl else AUDIO_MX_BAND, float(self.tie_eps),
+                          self._guard_stats, None if self.mixed_single_launch else ws,
+                          0 if self.mixed_single_launch else ws.numel(), int(half))
+            except Exception:
+                # a failed launch between the streaming pass and the list pass would leave streamed state behind that
+                # later clips consume silently (the kernels only restore the all-zero state when all of them ran)
+                self._mix_ws = None
+                raise
         elif exact:
             need = int(_lib.load().qpg_percode_select_exact_ws_bytes(Q, C, db.K))
             ws = getattr(self, "_exact_ws", None)
@@ -734,7 +752,11 @@ class CodeKNN:
             # per-shard tables go straight into the exchange buffer (ExchangeLayout); merged after ONE collective
             parts = [p_ for p_, on in (("aud", mode in (MODE_AUD_TXT, MODE_AUD)), ("txt", mode in (MODE_AUD_TXT, MODE_TXT)))
                      if on]
-            lay = ExchangeLayout(M * steps, db.K, db.world if owner_blocks else 1, parts, not self.use_wavvq, dev)
+            lkey = (M * steps, db.world if owner_blocks else 1, tuple(parts), not self.use_wavvq)
+            lays = self.__dict__.setdefault("_layouts", {})
+            lay = lays.get(lkey)
+            if lay is None:             # one send buffer per shape, reused by every clip (stream-ordered: the previous
+                lay = lays[lkey] = ExchangeLayout(lkey[0], db.K, lkey[1], parts, lkey[3], dev)   # clip's exchange read it)
         # The two sweeps are independent until the walk and lean on different pipes (f64 matrix cores vs f32
         # VALU): with both modalities on, the text side runs on a second HIP stream underneath the audio sweep.
         overlap = mode == MODE_AUD_TXT and self.overlap_sweeps
@@ -824,9 +846,12 @@ class CodeKNN:
             text_side()
         if sharded:
             # ONE collective for both modalities (all-to-all when every rank only needs its own clip's rows, all-gather
-            # otherwise), then one merge launch per modality: min distance, lowest global index among equals, ranks
+            # otherwise), then one merge launch per modality: min distance, lowest global index among equals, ranks.
+            # The trouble word rides in the blocks (ExchangeLayout "flags"): stamped here, ORed in by the receivers.
+            _lib.call("qpg_flags_stamp", dev, lay.send, lay.nblk, lay.block_bytes, lay.off["flags"], self._guard_stats)
             recv = exchange_bytes(lay.send, db.world, owner_blocks)
             src_stride = lay.block_bytes if owner_blocks else lay.send.numel()
+            gathered = False
             for p_ in lay.parts:
                 f64 = lay.dtype[p_] == torch.float64
                 d = torch.empty((lay.Qb, db.K), dtype=lay.dtype[p_], device=dev)
@@ -835,8 +860,10 @@ class CodeKNN:
                 wavlm_aud = p_ == "aud" and not self.use_wavvq
                 if wavlm_aud and getattr(self, "_last_audio_mixed", False):
                     self._merge_mixed(recv, src_stride, lay, owner_blocks, d, ix, rk)
+                    gathered = True
                 elif wavlm_aud and getattr(self, "_last_audio_exact", False):
                     self._merge_mixed(recv, src_stride, lay, owner_blocks, d, ix, rk, exact=True)
+                    gathered = True
                 elif f64:
                     # (f64 sweep + capped guard per shard: near-ties ACROSS shards / codes are detected here and
                     # re-matched on the exact path; exact integer distances of the wavvq mode need no guard)
@@ -848,10 +875,15 @@ class CodeKNN:
                     _lib.call("qpg_merge_select_f32", dev, recv, db.world, src_stride,
                               lay.off[p_ + "_d"], lay.off[p_ + "_i"], lay.Qb, db.K, float(ABSENT_DIST), d, ix, rk)
                 T[p_ + "_d"], T[p_ + "_idx"], T[p_ + "_rank"] = d, ix, rk
-        if sharded:
-            # every rank must take the same decision about a re-match (it is a collective path): MAX of the trouble
-            # words, on the device, stream-ordered - the walk then carries the agreed value out with the codes
-            allreduce_max_(self._guard_stats[1:2], force=self.force_sharded)
+            if not gathered:            # (the mixed merge's prologue ORs the received words in itself)
+                _lib.call("qpg_flags_gather", dev, recv, db.world, src_stride, lay.off["flags"], self._guard_stats)
+            # Every rank must take the same decision about a re-match (it is a collective path).  Bits raised BEFORE an
+            # exchange reach every rank with it.  In the all-gather form every rank then runs the same merge on the same
+            # bytes, so the bits the merge itself raises (cross-shard near-ties) are the same everywhere: no collective.
+            # In the all-to-all form each owner merges its own query block: those last bits still take a 4-byte MAX
+            # all-reduce, on the device, stream-ordered - the walk carries the agreed value out with the codes.
+            if owner_blocks:
+                allreduce_max_(self._guard_stats[1:2], force=self.force_sharded)
         if self.host_ranks:
             for p_ in ("aud", "txt"):
                 if T[p_ + "_d"] is not None:
@@ -861,8 +893,12 @@ class CodeKNN:
 
     def _merge_mixed(self, recv, src_stride, lay, owner_blocks, d, ix, rk, exact=False):
         """Cross-shard merge of audio tables whose comparisons are not all decided by their values:
-        approximate merge + requests (owner), one all-to-all, re-evaluation of the requested pairs where the rows live
-        (shards), one all-to-all back, final merge + ranks.
+        approximate merge + requests, re-evaluation of the requested pairs where the rows live, final merge + ranks.
+        Request slots are deterministic (qpg_merge_mixed_phase1_f64), so:
+          all-gather form (every rank holds every shard's tables and runs the same merge): a shard refines ITS block of
+            its OWN phase-1 run - no request exchange; ONE all-gather of the responses.  Two collectives per clip in all.
+          all-to-all form (every rank owns one query block): the owner's requests travel to the shards and the responses
+            back: two more all-to-alls.
         Mixed-precision tables: band = 2.1 x the sweep's bound, responses = f64 dot-product distances; what those leave
         within tie_eps raises FLAG_CROSS_SHARD_TIE.  exact=True (f64 tables of the uncapped select): band = tie_eps,
         responses in the reference's own arithmetic, request and flag lists sized for the worst case - the cross-shard
@@ -870,28 +906,40 @@ class CodeKNN:
         db, dev = self.db, self.db.device
         W, Qb, K = db.world, lay.Qb, db.K
         if exact:
-            R, fl_cap, band = Qb * K, K * W, float(self.tie_eps)
+            Rq, fl_cap, band = K, K * W, float(self.tie_eps)
         else:
-            R = int(self.mixed_requests) if self.mixed_requests else max(1024, 16384 // W)
+            # slots per (query, shard): ~70 / W requests per query are usual with the split-f16 band
+            Rq = int(self.mixed_requests) if self.mixed_requests else max(64, 512 // W)
             fl_cap, band = 1024, (AUDIO_HL_BAND if getattr(self, "_last_audio_hl", False) else AUDIO_MX_BAND)
-        req_stride, resp_stride = 8 + 8 * R, 8 * R
-        key = "_mm_bufs_exact" if exact else "_mm_bufs"
-        bufs = self.__dict__.get(key)
+        R = Qb * Rq
+        req_stride = resp_stride = 8 + 8 * R
+        key = ("_mm_bufs_exact" if exact else "_mm_bufs", W, R)
+        cache = self.__dict__.setdefault("_mm_cache", {})
+        bufs = cache.get(key)
         need_ws = int(_lib.load().qpg_merge_mixed_ws_bytes(Qb, K, fl_cap))
-        if bufs is None or bufs[0].numel() != W * req_stride or bufs[2].numel() < need_ws:
-            bufs = self.__dict__[key] = (torch.empty((W * req_stride,), dtype=torch.uint8, device=dev),
-                                         torch.empty((W * resp_stride,), dtype=torch.uint8, device=dev),
-                                         torch.empty((need_ws,), dtype=torch.uint8, device=dev))
+        if bufs is None or bufs[2].numel() < need_ws:
+            bufs = cache[key] = (torch.empty((W * req_stride,), dtype=torch.uint8, device=dev),
+                                 torch.empty((W * resp_stride,), dtype=torch.uint8, device=dev),
+                                 torch.empty((need_ws,), dtype=torch.uint8, device=dev))
         req, resp, ws = bufs
         _lib.call("qpg_merge_mixed_phase1_f64", dev, recv, W, src_stride, lay.off["aud_d"], lay.off["aud_i"], Qb, K,
-                  float(ABSENT_DIST), band, R, req, req_stride, ws, ws.numel(), self._guard_stats, fl_cap)
-        req_recv = exchange_bytes(req, W, True)
-        # block o of req_recv comes from owner o: its queries are rows o*Qb .. of this rank's packed query set when every
-        # owner has its own block (all-to-all form), rows 0 .. when all ranks own the same queries (all-gather form)
-        _lib.call("qpg_shard_refine_f64", dev, req_recv, W, req_stride, R, Qb if owner_blocks else 0, db.idx_base * db.Ga,
-                  db.base, int(db.feature_dtype == "f16"), db.T, db.F, db.aud_t, db.Ga, NUM_AUDIO_FEAT_FRAMES,
-                  db.tap_stride, self._last_q32, self._last_qn2, db.cn2, resp, resp_stride, int(exact))
-        resp_recv = exchange_bytes(resp, W, True)
+                  float(ABSENT_DIST), band, R, req, req_stride, ws, ws.numel(), self._guard_stats, fl_cap,
+                  lay.off["flags"])
+        half = int(db.feature_dtype == "f16")
+        if owner_blocks:
+            req_recv = exchange_bytes(req, W, True)
+            # block o of req_recv comes from owner o: its queries are rows o*Qb .. of this rank's packed query set
+            _lib.call("qpg_shard_refine_f64", dev, req_recv, W, req_stride, R, Qb, db.idx_base * db.Ga, db.base, half,
+                      db.T, db.F, db.aud_t, db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, self._last_q32, self._last_qn2,
+                      db.cn2, resp, resp_stride, int(exact), self._guard_stats, Rq)
+            resp_recv = exchange_bytes(resp, W, True)
+        else:
+            # every rank ran the same phase 1: block `rank` of MY request buffer is what owner(s) would have sent me
+            mine = req[db.rank * req_stride:(db.rank + 1) * req_stride]
+            _lib.call("qpg_shard_refine_f64", dev, mine, 1, req_stride, R, 0, db.idx_base * db.Ga, db.base, half,
+                      db.T, db.F, db.aud_t, db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, self._last_q32, self._last_qn2,
+                      db.cn2, resp, resp_stride, int(exact), self._guard_stats, Rq)
+            resp_recv = exchange_bytes(resp[:resp_stride], W, False)
         _lib.call("qpg_merge_mixed_phase2_f64", dev, recv, W, src_stride, lay.off["aud_i"], Qb, K, float(ABSENT_DIST), ws,
                   ws.numel(), resp_recv, resp_stride, d, ix, rk, self._guard_stats, fl_cap,
                   0.0 if exact else float(self.tie_eps))
@@ -1060,6 +1108,7 @@ class CodeKNN:
             return self.walk(T, n_windows, 0, mode, seed_code, seed_phase)
         except GuardOverflow as e:
             if self.audio_precision == "exact":
+                self.clear_flags()          # (the sticky word must not poison the clips after this one)
                 raise RuntimeError("the uncapped path raised flags 0x%x: this is a bug" % e.flags)
             return self.rematch_exact(test_interp, test_context, n_windows, mode, seed_code, seed_phase, return_tables)
 

@@ -1920,11 +1920,64 @@ extern "C" int qpg_merge_select_f32(qpg_ctx* ctx, void* stream, const void* recv
 // ---------------------------------------------------------------------------------------------------------------
 // (flag-list capacity per query: `fl_cap`, a call argument - 1024 on the normal path, K*W on the uncapped one)
 
-__global__ void merge_mixed_zero_counts_kernel(unsigned char* __restrict__ req, int64_t req_stride, int W) {
-  for (int w = threadIdx.x; w < W; w += blockDim.x) *reinterpret_cast<long long*>(req + (int64_t)w * req_stride) = 0;
+// Trouble bits travel WITH the exchanges (round 4; they used to take their own 4-byte all-reduce): every exchanged block
+// carries a flag word - table blocks at `flag_off`, request / response blocks in the high half of their 8-byte header -
+// holding the sender's stats[1] at send time; the consumer ORs what it received into its own stats[1].
+//   qpg_flags_stamp   (sender)   flag word of each of nblk blocks = stats[1]
+//   qpg_flags_gather  (receiver) stats[1] |= OR of the nblk received flag words
+// The mixed merge folds both into its own kernels: its prologue gathers the table blocks' words and seeds the request
+// headers, the shard refine gathers the request headers and seeds the response headers, phase 2 gathers those.
+__global__ void flags_stamp_kernel(unsigned char* __restrict__ buf, int nblk, int64_t stride, int64_t off,
+                                   const int32_t* __restrict__ stats) {
+  const int f = stats[1];
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) *reinterpret_cast<int32_t*>(buf + (int64_t)b * stride + off) = f;
+}
+__global__ void flags_gather_kernel(const unsigned char* __restrict__ buf, int nblk, int64_t stride, int64_t off,
+                                    int32_t* __restrict__ stats) {
+  int f = 0;
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) f |= *reinterpret_cast<const int32_t*>(buf + (int64_t)b * stride + off);
+  if (f) atomicOr(&stats[1], f);
+}
+extern "C" int qpg_flags_stamp(qpg_ctx* ctx, void* stream, void* buf, int nblk, int64_t stride, int64_t off,
+                               const int32_t* stats) {
+  QPG_REQUIRE(ctx && buf && stats && nblk > 0 && off >= 0 && off % 4 == 0, "qpg_flags_stamp: bad argument");
+  hipLaunchKernelGGL(flags_stamp_kernel, dim3(1), dim3(64), 0, qpg_stream(stream), static_cast<unsigned char*>(buf), nblk,
+                     stride, off, stats);
+  QPG_LAUNCH_CHECK("flags_stamp_kernel");
+  return QPG_OK;
+}
+extern "C" int qpg_flags_gather(qpg_ctx* ctx, void* stream, const void* buf, int nblk, int64_t stride, int64_t off,
+                                int32_t* stats) {
+  QPG_REQUIRE(ctx && buf && stats && nblk > 0 && off >= 0 && off % 4 == 0, "qpg_flags_gather: bad argument");
+  hipLaunchKernelGGL(flags_gather_kernel, dim3(1), dim3(64), 0, qpg_stream(stream), static_cast<const unsigned char*>(buf),
+                     nblk, stride, off, stats);
+  QPG_LAUNCH_CHECK("flags_gather_kernel");
+  return QPG_OK;
 }
 
-#define MM_LREQ 2048      // requests a block collects in LDS before its range reservation (more: direct global atomics)
+// request block header: [i32 count (diagnostics) | i32 flags]; the prologue zeroes the counts, gathers the W received table
+// blocks' flag words (flag_off >= 0) and seeds every header's flag word with this rank's trouble word so far
+__global__ void merge_mixed_prologue_kernel(unsigned char* __restrict__ req, int64_t req_stride, int W,
+                                            const unsigned char* __restrict__ recv, int64_t src_stride, int64_t flag_off,
+                                            int32_t* __restrict__ stats) {
+  __shared__ int f_s;
+  if (threadIdx.x == 0) f_s = stats[1];
+  __syncthreads();
+  if (flag_off >= 0) {
+    int f = 0;
+    for (int w = threadIdx.x; w < W; w += blockDim.x) f |= *reinterpret_cast<const int32_t*>(recv + (int64_t)w * src_stride + flag_off);
+    if (f) atomicOr(&f_s, f);
+  }
+  __syncthreads();
+  const int f = f_s;
+  if (threadIdx.x == 0 && f) atomicOr(&stats[1], f);
+  for (int w = threadIdx.x; w < W; w += blockDim.x) {
+    int32_t* h = reinterpret_cast<int32_t*>(req + (int64_t)w * req_stride);
+    h[0] = 0;
+    h[1] = f;
+  }
+}
+
 __global__ __launch_bounds__(1024) void merge_mixed_phase1_kernel(
     const unsigned char* __restrict__ recv, int W, int64_t src_stride, int64_t dist_off, int64_t idx_off, int K,
     double absent, double eps1, int R, unsigned char* __restrict__ req, int64_t req_stride,
@@ -1979,87 +2032,124 @@ __global__ __launch_bounds__(1024) void merge_mixed_phase1_kernel(
     }
   }
   __syncthreads();
-  // Requests are first collected in LDS and counted per destination shard, then the block reserves ONE range per shard
-  // (3 300 global atomicAdds per step on W counters took 50 us of this kernel at W = 1): slot j = range base + position.
-  __shared__ int cw[64], cbase[64], n_l;
-  unsigned long long* lq = reinterpret_cast<unsigned long long*>(rkc + K);        // [MM_LREQ] (k, w, cand)
-  int* lp = reinterpret_cast<int*>(lq + MM_LREQ);                                // [MM_LREQ] position inside the shard's range
-  const bool agg = W <= 64;
-  if (threadIdx.x < 64) cw[threadIdx.x] = 0;
-  if (threadIdx.x == 0) n_l = 0;
-  __syncthreads();
-  auto finish = [&](int w, int k, int cand, int j) {
-    // A claimed slot j < R is ALWAYS written (the shard evaluates min(count, R) of them), and a flag-list slot is only
-    // claimed for a written request, so fl_cnt never counts an unwritten entry (round 2 reserved both, then bailed out:
-    // phase 2 decoded stale words).
-    if (j >= R) {
-      atomicOr(&stats[1], 4);                                    // request overflow: the clip is re-matched (host)
-      return;
-    }
-    reinterpret_cast<unsigned long long*>(req + (int64_t)w * req_stride + 8)[j] =
-        ((unsigned long long)q << 48) | ((unsigned long long)k << 32) | (unsigned int)cand;
-    const int pos = atomicAdd(&n_fl, 1);
-    if (pos >= MM_FL) {
-      atomicOr(&stats[1], 4);                                    // flag-list overflow: the response is ignored, re-match
-      return;
-    }
-    fl[(int64_t)q * MM_FL + pos] = ((unsigned long long)k << 40) | ((unsigned long long)w << 32) | (unsigned int)j;
-  };
-  auto emit = [&](int w, int k, int cand) {
-    if (agg) {
-      const int pos = atomicAdd(&n_l, 1);
-      if (pos < MM_LREQ) {
-        lq[pos] = ((unsigned long long)k << 40) | ((unsigned long long)w << 32) | (unsigned int)cand;
-        lp[pos] = atomicAdd(&cw[w], 1);
-        return;
-      }
-    }
-    finish(w, k, cand, atomicAdd(reinterpret_cast<int*>(req + (int64_t)w * req_stride), 1));      // (direct)
-  };
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    if (bi[k] < 0) continue;
+  // Slots are DETERMINISTIC (round 4): the request of (query q, code k) to shard w sits at q * Rq + its position among
+  // q's requests to w in code order - Rq = R / Q slots per (query, shard), unused ones hold ~0 and the shard skips them.
+  // Every rank that runs this kernel on the same tables produces the same request blocks, so in the all-gather form of the
+  // exchange (every rank holds every shard's tables) nobody has to SEND requests: a shard takes its own block of its own
+  // run.  Positions come from block-wide prefix sums over the codes, four shards per pass in 16-bit fields (a query sends
+  // a shard at most one request per code, K <= 2048).
+  const int Rq = R / (int)gridDim.x;
+  __shared__ unsigned long long wtot[17];
+  __shared__ int carry[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
+  for (int i = threadIdx.x; i < W * Rq; i += blockDim.x)
+    reinterpret_cast<unsigned long long*>(req + (int64_t)(i / Rq) * req_stride + 8)[(int64_t)q * Rq + (i % Rq)] = ~0ull;
+  auto wants = [&](int k, int w) -> int {          // candidate this query requests from shard w for code k, or -1
+    if (k >= K || bi[k] < 0) return -1;
     if (cnt[k] >= 2) {
-      for (int w = 0; w < W; ++w) {
-        const int i = ival(w, k);
-        if (i >= 0 && dval(w, k) <= v[k] + eps1) emit(w, k, i);
-      }
-    } else if (flg[k]) {
-      emit(bs[k], k, bi[k]);
+      const int i = ival(w, k);
+      return (i >= 0 && dval(w, k) <= v[k] + eps1) ? i : -1;
     }
-  }
+    return (flg[k] && bs[k] == w) ? bi[k] : -1;
+  };
   __syncthreads();
-  if (agg) {
-    if ((int)threadIdx.x < W && cw[threadIdx.x] > 0)
-      cbase[threadIdx.x] = atomicAdd(reinterpret_cast<int*>(req + (int64_t)threadIdx.x * req_stride), cw[threadIdx.x]);
+  for (int w0 = 0; w0 < W; w0 += 4) {
+    if (threadIdx.x < 4) carry[threadIdx.x] = 0;
     __syncthreads();
-    const int nl = n_l < MM_LREQ ? n_l : MM_LREQ;
-    for (int i = threadIdx.x; i < nl; i += blockDim.x) {
-      const unsigned long long x = lq[i];
-      const int k = (int)(x >> 40), w = (int)((x >> 32) & 0xff);
-      finish(w, k, (int)(unsigned int)(x & 0xffffffffu), cbase[w] + lp[i]);
+    for (int kb = 0; kb < K; kb += blockDim.x) {
+      const int k = kb + threadIdx.x;
+      int cand[4];
+      unsigned long long mine = 0;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        cand[f] = (w0 + f < W) ? wants(k, w0 + f) : -1;
+        mine |= (unsigned long long)(cand[f] >= 0) << (16 * f);
+      }
+      unsigned long long inc = mine;               // inclusive scan inside the wave
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      if (lane == 63) wtot[wv] = inc;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < nwv; ++i) {
+          const unsigned long long t = wtot[i];
+          wtot[i] = run;
+          run += t;
+        }
+        wtot[16] = run;
+      }
+      __syncthreads();
+      const unsigned long long excl = inc - mine + wtot[wv];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        if (cand[f] < 0) continue;
+        const int w = w0 + f;
+        const int pos = carry[f] + (int)((excl >> (16 * f)) & 0xffff);
+        if (pos >= Rq) {                           // request overflow: the clip is re-matched; every shard hears of it
+          atomicOr(&stats[1], 4);
+          for (int x = 0; x < W; ++x) atomicOr(reinterpret_cast<int*>(req + (int64_t)x * req_stride) + 1, 4);
+          continue;
+        }
+        const int j = q * Rq + pos;
+        reinterpret_cast<unsigned long long*>(req + (int64_t)w * req_stride + 8)[j] =
+            ((unsigned long long)q << 48) | ((unsigned long long)k << 32) | (unsigned int)cand[f];
+        const int fp = atomicAdd(&n_fl, 1);        // (order inside the flag list is irrelevant to phase 2)
+        if (fp >= MM_FL) {
+          atomicOr(&stats[1], 4);
+          for (int x = 0; x < W; ++x) atomicOr(reinterpret_cast<int*>(req + (int64_t)x * req_stride) + 1, 4);
+          continue;
+        }
+        fl[(int64_t)q * MM_FL + fp] = ((unsigned long long)k << 40) | ((unsigned long long)w << 32) | (unsigned int)j;
+      }
+      __syncthreads();
+      if (threadIdx.x < 4) carry[threadIdx.x] += (int)((wtot[16] >> (16 * threadIdx.x)) & 0xffff);
+      __syncthreads();
+    }
+    if (threadIdx.x < 4 && w0 + (int)threadIdx.x < W) {
+      const int c = carry[threadIdx.x] < Rq ? carry[threadIdx.x] : Rq;
+      if (c) atomicAdd(reinterpret_cast<int*>(req + (int64_t)(w0 + threadIdx.x) * req_stride), c);   // (diagnostics)
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) fl_cnt[q] = n_fl < MM_FL ? n_fl : MM_FL;
 }
 
-// shards: exact distance of every requested (query, candidate); one wave per request
+// shards: exact distance of every requested (query, candidate); one wave per request.  All R slots of a block are visited
+// (deterministic slots: unused ones hold ~0).  Block (o, 0) carries the trouble bits on: what the W received request headers
+// hold is ORed into stats[1] and, with this shard's own word, into the header of response block o.
+__device__ __forceinline__ void refine_carry_flags(const unsigned char* req_recv, int64_t req_stride, int W,
+                                                   unsigned char* resp, int64_t resp_stride, int o, int32_t* stats) {
+  if (blockIdx.y != 0 || threadIdx.x != 0) return;
+  int f = stats ? stats[1] : 0;
+  for (int w = 0; w < W; ++w) f |= reinterpret_cast<const int32_t*>(req_recv + (int64_t)w * req_stride)[1];
+  if (stats && f) atomicOr(&stats[1], f);
+  int32_t* h = reinterpret_cast<int32_t*>(resp + (int64_t)o * resp_stride);
+  h[0] = 0;
+  h[1] = f;
+}
+
 __global__ __launch_bounds__(256) void shard_refine_kernel(GuardArgs A, const unsigned char* __restrict__ req_recv,
                                                            int64_t req_stride, int R, int q_stride, int64_t cand_base,
                                                            const double* __restrict__ cn2, const double* __restrict__ qn2,
-                                                           unsigned char* __restrict__ resp, int64_t resp_stride, int fast) {
+                                                           unsigned char* __restrict__ resp, int64_t resp_stride, int fast,
+                                                           int W, int32_t* __restrict__ stats, int Rq) {
   const int o = blockIdx.x, lane = threadIdx.x & 63;
   const int g = blockIdx.y * 4 + (threadIdx.x >> 6), ng = gridDim.y * 4;
   const unsigned char* blk = req_recv + (int64_t)o * req_stride;
-  __shared__ int n_s;                                         // (one read of the count per block: thousands of waves
-  if (threadIdx.x == 0) n_s = *reinterpret_cast<const int*>(blk);   // reading one address queue on its L2 channel)
-  __syncthreads();
-  int n = n_s;
-  n = n < R ? n : R;
+  refine_carry_flags(req_recv, req_stride, W, resp, resp_stride, o, stats);
   const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(blk + 8);
-  double* out = reinterpret_cast<double*>(resp + (int64_t)o * resp_stride);
-  for (int e = g; e < n; e += ng) {
+  double* out = reinterpret_cast<double*>(resp + (int64_t)o * resp_stride + 8);
+  // slots are visited POSITION-major (all queries' first slots, then their second ones, ...): a query's requests sit at the
+  // front of its Rq-slot segment, so this spreads the live slots over the waves of the first round
+  const int Qn = R / Rq;
+  for (int t = g; t < R; t += ng) {
+    const int e = (t % Qn) * Rq + t / Qn;
     const unsigned long long x = ent[e];
+    if (x == ~0ull) continue;
     const int q = o * q_stride + (int)(x >> 48);
     const int64_t c = (int64_t)(unsigned int)(x & 0xffffffffu) - cand_base;        // local candidate
     const float* qrow = A.q32 + (int64_t)q * A.n_taps * A.F;
@@ -2092,9 +2182,14 @@ __global__ __launch_bounds__(1024) void merge_mixed_phase2_kernel(
     const unsigned long long x = fl[(int64_t)q * MM_FL + e];
     k = (int)(x >> 40);
     const int w = (int)((x >> 32) & 0xff), j = (int)(x & 0xffffffffu);
-    d = reinterpret_cast<const double*>(resp_recv + (int64_t)w * resp_stride)[j];
+    d = reinterpret_cast<const double*>(resp_recv + (int64_t)w * resp_stride + 8)[j];
     cand = (unsigned int)reinterpret_cast<const int32_t*>(recv + (int64_t)w * src_stride + idx_off)[(int64_t)q * K + k];
   };
+  if (q == 0) {                                          // the response headers' trouble bits (see qpg_flags_stamp)
+    int f = 0;
+    for (int w = threadIdx.x; w < W; w += blockDim.x) f |= reinterpret_cast<const int32_t*>(resp_recv + (int64_t)w * resp_stride)[1];
+    if (f) atomicOr(&stats[1], f);
+  }
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
     int k;
     double d;
@@ -2155,20 +2250,29 @@ __global__ __launch_bounds__(1024) void merge_mixed_phase2_kernel(
 // the same in the reference's own arithmetic (refine_pair_f64: one quad per request) - the uncapped sharded path
 __global__ __launch_bounds__(256) void shard_refine_ref_kernel(GuardArgs A, const unsigned char* __restrict__ req_recv,
                                                                int64_t req_stride, int R, int q_stride, int64_t cand_base,
-                                                               unsigned char* __restrict__ resp, int64_t resp_stride) {
+                                                               unsigned char* __restrict__ resp, int64_t resp_stride,
+                                                               int W, int32_t* __restrict__ stats, int Rq) {
   const int o = blockIdx.x, tid = threadIdx.x;
   const unsigned char* blk = req_recv + (int64_t)o * req_stride;
-  int n = *reinterpret_cast<const int*>(blk);
-  n = n < R ? n : R;
+  refine_carry_flags(req_recv, req_stride, W, resp, resp_stride, o, stats);
   const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(blk + 8);
-  double* out = reinterpret_cast<double*>(resp + (int64_t)o * resp_stride);
-  for (int e0 = blockIdx.y * 64; e0 < n; e0 += gridDim.y * 64) {
-    const int e = e0 + (tid >> 2);
-    const unsigned long long x = ent[e < n ? e : 0];                  // (idle quads run along: uniform control flow)
+  double* out = reinterpret_cast<double*>(resp + (int64_t)o * resp_stride + 8);
+  const int Qn = R / Rq;
+  for (int e0 = blockIdx.y * 64; e0 < R; e0 += gridDim.y * 64) {
+    const int t = e0 + (tid >> 2);                                    // position-major slot order (see shard_refine_kernel)
+    const int e = t < R ? (t % Qn) * Rq + t / Qn : 0;
+    unsigned long long x = ent[e];
+    const bool live = t < R && x != ~0ull;
+    // (a wave whose 16 slots are all unused skips the evaluation; otherwise idle quads run along on slot data that is
+    // valid for SOME request - uniform control flow inside refine_pair_f64's quad shuffles)
+    const unsigned long long m = __ballot(live);                      // (wave-uniform: taken before any divergence)
+    if (m == 0) continue;
+    const unsigned long long xl = __shfl(x, __ffsll((long long)m) - 1, 64);   // a live lane's request
+    if (!live) x = xl;
     const int q = o * q_stride + (int)(x >> 48);
     const int64_t c = (int64_t)(unsigned int)(x & 0xffffffffu) - cand_base;
     const double dr = refine_pair_f64(A, q, c, tid & 3);
-    if (e < n && (tid & 3) == 0) out[e] = dr;
+    if (live && (tid & 3) == 0) out[e] = dr;
   }
 }
 
@@ -2179,10 +2283,12 @@ extern "C" int64_t qpg_merge_mixed_ws_bytes(int Q, int K, int fl_cap) {         
 extern "C" int qpg_merge_mixed_phase1_f64(qpg_ctx* ctx, void* stream, const void* recv, int W, int64_t src_stride,
                                           int64_t dist_off, int64_t idx_off, int Q, int K, double absent, double eps1,
                                           int R, void* req, int64_t req_stride, void* ws, int64_t ws_bytes,
-                                          int32_t* stats, int fl_cap) {
+                                          int32_t* stats, int fl_cap, int64_t flag_off) {
   const int MM_FL = fl_cap;
   const char* name = "qpg_merge_mixed_phase1_f64";
   QPG_REQUIRE(ctx && recv && req && ws && stats, "%s: null pointer", name);
+  QPG_REQUIRE(Q == 0 || (R % Q) == 0, "%s: R must be a multiple of Q (R / Q slots per query and shard)", name);
+  QPG_REQUIRE(flag_off < 0 || flag_off % 4 == 0, "%s: misaligned flag word", name);
   QPG_REQUIRE(W > 0 && W <= 255 && Q >= 0 && Q < 65536 && K > 0 && K <= 2048 && R > 0 && src_stride % 8 == 0 &&
                   dist_off % 8 == 0 && idx_off % 4 == 0 && req_stride >= 8 + 8 * (int64_t)R && req_stride % 8 == 0 &&
                   eps1 > 0.0 && fl_cap > 0 && ws_bytes >= qpg_merge_mixed_ws_bytes(Q, K, fl_cap) &&
@@ -2194,10 +2300,11 @@ extern "C" int qpg_merge_mixed_phase1_f64(qpg_ctx* ctx, void* stream, const void
   int32_t* prov_i = reinterpret_cast<int32_t*>(w + (size_t)Q * K * 8);
   unsigned long long* fl = reinterpret_cast<unsigned long long*>(w + (((size_t)Q * K * 12 + 7) / 8) * 8);
   int32_t* fl_cnt = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(fl) + (size_t)Q * MM_FL * 8);
-  hipLaunchKernelGGL(merge_mixed_zero_counts_kernel, dim3(1), dim3(256), 0, qpg_stream(stream),
-                     static_cast<unsigned char*>(req), req_stride, W);
-  QPG_LAUNCH_CHECK("merge_mixed_zero_counts_kernel");
-  hipLaunchKernelGGL(merge_mixed_phase1_kernel, dim3(Q), dim3(1024), (size_t)K * 32 + 8 + 12 * (size_t)MM_LREQ,
+  hipLaunchKernelGGL(merge_mixed_prologue_kernel, dim3(1), dim3(256), 0, qpg_stream(stream),
+                     static_cast<unsigned char*>(req), req_stride, W, static_cast<const unsigned char*>(recv), src_stride,
+                     flag_off, stats);
+  QPG_LAUNCH_CHECK("merge_mixed_prologue_kernel");
+  hipLaunchKernelGGL(merge_mixed_phase1_kernel, dim3(Q), dim3(1024), (size_t)K * 32 + 8,
                      qpg_stream(stream),
                      static_cast<const unsigned char*>(recv), W, src_stride, dist_off, idx_off, K, absent, eps1, R,
                      static_cast<unsigned char*>(req), req_stride, prov_d, prov_i, fl, fl_cnt, stats, MM_FL);
@@ -2209,10 +2316,11 @@ extern "C" int qpg_shard_refine_f64(qpg_ctx* ctx, void* stream, const void* req_
                                     int q_stride, int64_t cand_base, const float* base, int base_is_f16, int T, int F,
                                     const int32_t* cand_t, int G, int n_taps, int tap_stride, const float* q32,
                                     const double* qn2, const double* cn2, void* resp, int64_t resp_stride,
-                                    int reference_arithmetic) {
+                                    int reference_arithmetic, int32_t* stats, int Rq) {
   const char* name = "qpg_shard_refine_f64";
+  QPG_REQUIRE(Rq > 0 && (R % Rq) == 0, "%s: R must be a multiple of Rq (slots per query)", name);
   QPG_REQUIRE(ctx && req_recv && base && cand_t && q32 && qn2 && cn2 && resp, "%s: null pointer", name);
-  QPG_REQUIRE(W > 0 && R > 0 && req_stride >= 8 + 8 * (int64_t)R && resp_stride >= 8 * (int64_t)R && T > 0 && F > 0 &&
+  QPG_REQUIRE(W > 0 && R > 0 && req_stride >= 8 + 8 * (int64_t)R && resp_stride >= 8 + 8 * (int64_t)R && T > 0 && F > 0 &&
                   (F % 4) == 0 && G > 0 && n_taps > 0 && tap_stride > 0 && q_stride >= 0,
               "%s: bad size", name);
   GuardArgs A;
@@ -2221,7 +2329,7 @@ extern "C" int qpg_shard_refine_f64(qpg_ctx* ctx, void* stream, const void* req_
   if (reference_arithmetic) {
     hipLaunchKernelGGL(shard_refine_ref_kernel, dim3(W, 64), dim3(256), 0, qpg_stream(stream), A,
                        static_cast<const unsigned char*>(req_recv), req_stride, R, q_stride, cand_base,
-                       static_cast<unsigned char*>(resp), resp_stride);
+                       static_cast<unsigned char*>(resp), resp_stride, W, stats, Rq);
     QPG_LAUNCH_CHECK("shard_refine_ref_kernel");
     return QPG_OK;
   }
@@ -2232,7 +2340,7 @@ extern "C" int qpg_shard_refine_f64(qpg_ctx* ctx, void* stream, const void* req_
   ry = ry < 64 ? 64 : ry;
   hipLaunchKernelGGL(shard_refine_kernel, dim3(W, ry), dim3(256), 0, qpg_stream(stream), A,
                      static_cast<const unsigned char*>(req_recv), req_stride, R, q_stride, cand_base, cn2, qn2,
-                     static_cast<unsigned char*>(resp), resp_stride, fast);
+                     static_cast<unsigned char*>(resp), resp_stride, fast, W, stats, Rq);
   QPG_LAUNCH_CHECK("shard_refine_kernel");
   return QPG_OK;
 }

@@ -1,0 +1,109 @@
+"""Load-time check of the one MEASURED constant the mixed-precision paths rest on.
+
+The a-priori bound of the split-operand f16 sweep (QPG_AUDIO_HL_ERR = 1.3e-6, reused by the text prefilter as
+sorted_rows.HL_GEMM_ERR) assumes that a chain of two v_mfma_f32_16x16x32_f16 instructions is within
+kappa_2 * 2^-24 * sum|64 products| of the exact sum, with kappa_2 <= 13.  Nothing in the ISA documents how the matrix core
+aligns and rounds its 32 products; the constant was probed (tools/probe_mfma_f16.py, tools/probe_mfma_chain.py: worst
+9.72).  So the product re-measures it once per process and device, on blocks built against the accumulator (dominant
+products, wide dynamic range, big-then-small chains), through the same instruction (qpg_debug_mfma_f16_tile), and a
+device that does not honour the assumption is NOT given the bounded paths: CodeKNN then sweeps in f64 and the text
+side runs the exact-order sweep (both still HIP kernels; nothing falls back to the CPU).  The exact sums the measured
+values are compared with are 64-term f64 sums of exactly representable f16 x f16 products, computed on the host with
+NumPy: ~10 ms, once.
+"""
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib
+
+KAPPA2_ASSUMED = 13.0          # what QPG_AUDIO_HL_ERR budgets for a chain of two (csrc/qpg_audio_hl.hip)
+KAPPA2_LIMIT = 12.0            # the check fails ABOVE this: one unit of slack against families the probe does not build
+_cache = {}
+
+
+def _probe(dev, a16, b16, c=None):
+    tiles = a16.shape[0]
+    ad = torch.from_numpy(a16).to(dev).contiguous()
+    bd = torch.from_numpy(b16).to(dev).contiguous()
+    cd = None if c is None else torch.from_numpy(np.ascontiguousarray(c, np.float32)).to(dev)
+    out = torch.empty((tiles, 16, 16), dtype=torch.float32, device=dev)
+    _lib.call("qpg_debug_mfma_f16_tile", dev, ad, bd, cd, tiles, out)
+    return out.cpu().numpy()
+
+
+def measure_kappa(device, tiles=512, seed=20260929):
+    """Worst |chain of two MFMAs - exact| / (2^-24 sum |products|) over the adversarial families; also the single
+    instruction's kappa.  Returns {"kappa": .., "kappa2": .., "families": {...}}."""
+    dev = torch.device(device)
+    rng = np.random.default_rng(seed)
+    fam = {}
+
+    def rnd(scale=1.0):
+        return rng.standard_normal((tiles, 16, 32)) * scale
+
+    def chain(name, a1, b1, a2, b2):
+        a1, b1, a2, b2 = (np.ascontiguousarray(x.astype(np.float16)) for x in (a1, b1, a2, b2))
+        r1 = _probe(dev, a1, b1)
+        got = _probe(dev, a2, b2, r1).astype(np.float64)
+        A1, B1, A2, B2 = (x.astype(np.float64) for x in (a1, b1, a2, b2))
+        e1, e2 = np.einsum("tik,tjk->tij", A1, B1), np.einsum("tik,tjk->tij", A2, B2)
+        m1 = np.einsum("tik,tjk->tij", np.abs(A1), np.abs(B1))
+        m2 = np.einsum("tik,tjk->tij", np.abs(A2), np.abs(B2))
+        k1 = np.abs(r1.astype(np.float64) - e1) / np.maximum(2.0 ** -24 * m1, 1e-300)
+        k2 = np.abs(got - (e1 + e2)) / np.maximum(2.0 ** -24 * (m1 + m2), 1e-300)
+        fam[name] = (max(fam.get(name, (0, 0))[0], float(k1.max())), max(fam.get(name, (0, 0))[1], float(k2.max())))
+
+    def dominant():
+        a, b = np.abs(rnd()), np.abs(rnd())
+        k0 = int(rng.integers(0, 32))
+        a[:, :, k0] *= 2.0 ** int(rng.integers(8, 12))
+        b[:, :, k0] *= 2.0 ** int(rng.integers(8, 12))
+        return a, b
+
+    chain("normal", rnd(), rnd(), rnd(), rnd())
+    chain("scaled", rnd(2.0 ** 13), rnd(2.0 ** 13), rnd(2.0 ** 13), rnd(2.0 ** 13))
+    wide = lambda: rnd() * 2.0 ** rng.integers(-10, 11, size=(tiles, 16, 32))
+    chain("wide", wide(), wide(), wide(), wide())
+    for s in (2.0 ** -6, 2.0 ** -12):
+        chain("big, small", np.abs(rnd()), np.abs(rnd()), np.abs(rnd(s)), np.abs(rnd()))
+        chain("small, big", np.abs(rnd(s)), np.abs(rnd()), np.abs(rnd()), np.abs(rnd()))
+    for _ in range(3):
+        a, b = dominant()
+        chain("dominant in first", a, b, np.abs(rnd()), np.abs(rnd()))
+        a, b = dominant()
+        chain("dominant in second", np.abs(rnd()), np.abs(rnd()), a, b)
+        a1, b1 = dominant()
+        a2, b2 = dominant()
+        chain("dominant in both", a1, b1, a2, b2)
+    a, b = rnd(), rnd()
+    a[:, :, 1::2] = -a[:, :, 0::2]
+    b[:, :, 1::2] = b[:, :, 0::2]
+    chain("cancelling first", a, b, rnd(), rnd())
+    return {"kappa": max(v[0] for v in fam.values()), "kappa2": max(v[1] for v in fam.values()),
+            "families": {k: [round(v[0], 3), round(v[1], 3)] for k, v in fam.items()}}
+
+
+def mfma_bound_ok(device):
+    """(ok, report) for `device`, measured once per process: ok = the matrix core honours the kappa_2 the bounded
+    sweeps assume.  QPG_SKIP_SELFCHECK=1 skips the measurement (report["skipped"])."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    hit = _cache.get(idx)
+    if hit is not None:
+        return hit
+    if os.environ.get("QPG_SKIP_SELFCHECK", "") == "1":
+        rep = {"skipped": True, "kappa2_assumed": KAPPA2_ASSUMED}
+        _cache[idx] = (True, rep)
+        return _cache[idx]
+    rep = measure_kappa(torch.device("cuda", idx))
+    rep.update(kappa2_assumed=KAPPA2_ASSUMED, kappa2_limit=KAPPA2_LIMIT, skipped=False)
+    ok = rep["kappa2"] <= KAPPA2_LIMIT and rep["kappa"] <= KAPPA2_LIMIT
+    if not ok:
+        warnings.warn("qpgesture_amd: this device's f16 matrix core measured kappa_2 = %.2f (> %.1f): the a-priori bound "
+                      "of the split-f16 sweeps does not hold here; audio sweeps run in f64 and the text side on the "
+                      "exact-order kernel" % (rep["kappa2"], KAPPA2_LIMIT), RuntimeWarning)
+    _cache[idx] = (ok, rep)
+    return _cache[idx]

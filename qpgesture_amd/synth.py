@@ -190,6 +190,33 @@ def write_npz_set(outdir, n_train, n_test, seed_train=0, seed_test=1, seed_code=
     return p
 
 
+def write_npz_set_dense(outdir, n_train, n_test, chunked_db=None, seed_code=2, seed_sig=3):
+    """The 8 npz files of the CLI at bench size (n_train in the thousands), generated in 64-window chunks, with the phase
+    track written as a DENSE f32 (n,240,4,8) array (data_processing.densify_phase accepts it; the reference's object
+    array of pickled torch tensors takes ~0.2 s per DB window to write and to read back).  Returns the path dict."""
+    os.makedirs(outdir, exist_ok=True)
+
+    def chunks(n, seed0):
+        parts = [make_db(min(64, n - c0), seed0 * 100003 + c0 // 64) for c0 in range(0, n, 64)]
+        return {k: np.concatenate([p_[k] for p_ in parts]) for k in parts[0]}
+    tr, te = chunks(n_train, 0), chunks(n_test, 1)
+    p = {k: os.path.join(outdir, v) for k, v in dict(
+        train_database="train_240_txt_2.npz", test_data="test_240_txt_2.npz",
+        train_codebook="train_240_code.npz", codebook_signature="code.npz",
+        train_wavlm="train_240_WavLM.npz", test_wavlm="test_240_WavLM.npz",
+        train_wavvq="train_240_WavVQ.npz", test_wavvq="test_wavvq_240.npz").items()}
+    for d, path in ((tr, p["train_database"]), (te, p["test_data"])):
+        np.savez(path, mfcc=d["mfcc"], energy=d["energy"], pitch=d["pitch"], volume=d["volume"],
+                 context=d["context"], phase=np.ascontiguousarray(d["phase_dense"], np.float32))
+    np.savez(p["train_codebook"], code=make_codes(n_train, seed_code))
+    np.savez(p["codebook_signature"], signature=make_signature(seed_sig))
+    np.savez(p["train_wavlm"], wavlm=tr["wavlm"])
+    np.savez(p["test_wavlm"], wavlm=te["wavlm"])
+    np.savez(p["train_wavvq"], wavvq=tr["wavvq"])
+    np.savez(p["test_wavvq"], wavvq=te["wavvq"])
+    return p
+
+
 # ----------------------------------------------------------------------------------------------
 # gesture VQ-VAE: seeded weights with the reference's checkpoint key names (SURVEY.md §8a-14)
 # ----------------------------------------------------------------------------------------------

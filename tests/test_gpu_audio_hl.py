@@ -227,3 +227,38 @@ def test_matcher_on_the_hl_kernel_vs_reference_goldens(name):
     else:
         assert np.array_equal(np.argsort(d, axis=1, kind="stable"), np.argsort(g["aud_dist"], axis=1, kind="stable"))
     assert np.array_equal(codes, g["knn_pred"]) and np.array_equal(votes, g["vote"])
+
+
+def test_load_time_selfcheck_and_routing_when_it_fails(monkeypatch):
+    """selfcheck.mfma_bound_ok: the measured kappa_2 of this device is inside the assumption (and is what GestureDB
+    records); a device that fails the check gets no bounded path - the audio sweep runs in f64, the text side on the
+    exact-order kernel - and still returns the reference's tables and codes."""
+    import torch
+    from qpgesture_amd import selfcheck
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    selfcheck._cache.clear()
+    ok, rep = selfcheck.mfma_bound_ok("cuda:0")
+    print("selfcheck:", rep)
+    assert ok and not rep["skipped"] and 1.0 < rep["kappa2"] <= selfcheck.KAPPA2_LIMIT < selfcheck.KAPPA2_ASSUMED
+    g = load_golden("shipped_n48_m2_s0")
+    ntr, nte, s0, s1, s2, s3, mf = [int(v) for v in g["meta"]]
+    A = fixture_arrays(ntr, nte, s0, s1, s2, s3)
+
+    def run():
+        db = GestureDB(A["code"], A["tr_interp"], A["tr_ctx"], A["tr_phase"], A["sig"], device="cuda:0",
+                       freq_rank=g["step_freq_score"])
+        knn = CodeKNN(db, rng=np.random.RandomState(123456))
+        te_i = torch.from_numpy(A["te_interp"]).cuda()
+        te_c = torch.from_numpy(np.ascontiguousarray(A["te_ctx"])).cuda()
+        codes, _, _ = knn.match_clip(te_i, te_c, nte, return_tables=True)
+        return db, knn, codes
+    db, knn, codes = run()
+    assert db.hl_bound_ok and db.hl_image is not None and knn._last_audio_hl and knn._last_text_mfma
+    assert np.array_equal(codes, g["knn_pred"])
+    monkeypatch.setitem(selfcheck._cache, 0, (False, dict(rep, kappa2=14.2)))
+    db, knn, codes = run()
+    assert not db.hl_bound_ok and db.hl_image is None and db.txt_sorted is None
+    assert not knn._last_audio_mixed and not knn._last_text_mfma
+    assert np.array_equal(codes, g["knn_pred"])
+    assert np.abs(knn.tables["aud_d"].cpu().numpy() - g["aud_dist"]).max() < 1e-13
+    assert np.array_equal(knn.tables["txt_d"].cpu().numpy(), g["txt_dist"])

@@ -73,7 +73,7 @@ def test_bench_sharded_small_shards_keep_the_f64_sweep():
 
 def test_bench_self_launches_and_rematches_on_request_overflow():
     """`python bench.py --gpus 2` WITHOUT torchrun (how the driver types it) launches its own ranks and prints one line;
-    with 8 request slots per (owner, shard) pair the cross-shard request lists overflow in every step: the trouble word
+    with ONE request slot per (query, shard) the cross-shard request lists overflow in every step: the trouble word
     is MAX-reduced over the ranks, comes out with the codes, and every rank re-matches the step on the uncapped sharded
     path (cross-shard tier 2) - the codes still equal the unsharded match (--check)."""
     env = dict(os.environ, QPG_BENCH_ONE_GPU="1")
@@ -81,7 +81,7 @@ def test_bench_self_launches_and_rematches_on_request_overflow():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-db", "200",
            "--windows", "2", "--check", "--no-cpu-baseline", "--no-vqvae", "--no-prewarm", "--sharded-mixed-min-gflop", "0",
-           "--mixed-requests", "8"]
+           "--mixed-requests", "1"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -89,6 +89,41 @@ def test_bench_self_launches_and_rematches_on_request_overflow():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["check"] is True
     assert out["rematched_steps"] >= 2
+
+
+@pytest.mark.parametrize("world,scaling", [(4, "weak"), (4, "strong"), (8, "strong"), (8, "weak")])
+def test_bench_four_and_eight_ranks_on_one_gpu(world, scaling):
+    """The round-4 protocol (deterministic request slots; all-gather form = two collectives and no request exchange;
+    all-to-all form = three + the 4-byte word; trouble bits riding in the block headers) with 4 and 8 ranks sharing the
+    one GPU over gloo: codes == the unsharded match on every rank (--check), nothing re-matched; `ranks_seen` counts
+    the ranks and reports that they share one device."""
+    env = dict(os.environ, QPG_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--n-db", "264", "--windows", "2", "--check",
+           "--no-cpu-baseline", "--no-vqvae", "--no-prewarm", "--sharded-mixed-min-gflop", "0", "--scaling", scaling,
+           "--no-replicated"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["check"] is True and out["n_gpus"] == world and out["rematched_steps"] == 0
+    assert out["ranks_seen"]["ranks"] == world and out["ranks_seen"]["distinct_devices"] == 1
+    assert out["config"]["collectives_per_step"] == (2 if scaling == "strong" else 4)
+
+
+def test_bench_replicated_mode_two_ranks():
+    """--scaling replicated (shard the QUERIES, not the database): every rank holds the whole DB and matches
+    its own clip, no collective in the step; the codes equal the single-rank match (--check)."""
+    env = dict(os.environ, QPG_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--n-db", "200", "--windows", "2", "--check", "--no-cpu-baseline",
+           "--no-vqvae", "--no-prewarm", "--scaling", "replicated"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["check"] is True and out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["collectives_per_step"] == 0 and "replicated" in out["config"]["parallelism"]
 
 
 def test_sharded_path_over_rccl_with_one_rank():

@@ -255,22 +255,24 @@ def _protocol(shards, lays, Q, band, R, fl_cap, reference_arithmetic, eps2):
     W, K = len(shards), shards[0].db.K
     recv = torch.cat([l.send for l in lays])
     src_stride = lays[0].send.numel()
-    req_stride, resp_stride = 8 + 8 * R, 8 * R
+    req_stride, resp_stride = 8 + 8 * R, 8 + 8 * R
     req = torch.zeros((W * req_stride,), dtype=torch.uint8, device=dev)
     ws = torch.empty((int(_lib.load().qpg_merge_mixed_ws_bytes(Q, K, fl_cap)),), dtype=torch.uint8, device=dev)
     stats = torch.zeros((4,), dtype=torch.int32, device=dev)
     _lib.call("qpg_merge_mixed_phase1_f64", dev, recv, W, src_stride, lays[0].off["aud_d"], lays[0].off["aud_i"], Q, K,
-              float(ABSENT_DIST), band, R, req, req_stride, ws, ws.numel(), stats, fl_cap)
-    counts = [int(req[w * req_stride:w * req_stride + 8].view(torch.int64)[0]) for w in range(W)]
+              float(ABSENT_DIST), band, R, req, req_stride, ws, ws.numel(), stats, fl_cap, -1)
+    counts = [int(req[w * req_stride:w * req_stride + 4].view(torch.int32)[0]) for w in range(W)]   # header: count | flags
     resp_recv = torch.zeros((W * resp_stride,), dtype=torch.uint8, device=dev)
     for w in range(W):
-        req_recv = torch.zeros((W * req_stride,), dtype=torch.uint8, device=dev)
+        req_recv = torch.full((W * req_stride,), 255, dtype=torch.uint8, device=dev)      # (unused slots / blocks: ~0)
+        for b in range(W):
+            req_recv[b * req_stride:b * req_stride + 8] = 0                       # headers: count | flags
         req_recv[:req_stride] = req[w * req_stride:(w + 1) * req_stride]
         resp = torch.zeros((W * resp_stride,), dtype=torch.uint8, device=dev)
         k, db = shards[w], shards[w].db
         _lib.call("qpg_shard_refine_f64", dev, req_recv, W, req_stride, R, 0, db.idx_base * db.Ga, db.base, 0, db.T, db.F,
                   db.aud_t, db.Ga, 6, db.tap_stride, k._last_q32, k._last_qn2, db.cn2, resp, resp_stride,
-                  int(reference_arithmetic))
+                  int(reference_arithmetic), None, R // Q)
         resp_recv[w * resp_stride:(w + 1) * resp_stride] = resp[:resp_stride]
     d = torch.empty((Q, K), dtype=torch.float64, device=dev)
     ix = torch.empty((Q, K), dtype=torch.int32, device=dev)
@@ -364,7 +366,7 @@ def test_request_overflow_is_flagged_and_leaves_no_stale_entries():
     Q = nte * 8
     shards, lays = _shard_tables(A, W, te_i, "mixed", q_win, q_t, Q)
     K = shards[0].db.K
-    for R, fl_cap in ((8, 1024), (4096, 4), (8, 4)):
+    for R, fl_cap in ((16, 1024), (4096, 4), (16, 4)):          # (R = Q x slots per (query, shard))
         # poison the workspace the way torch.empty may: stale words must never be decoded
         d, ix, rk, st, counts, recv = _protocol(shards, lays, Q, AUDIO_MX_BAND, R, fl_cap, False, 1e-12)
         assert int(st[1]) & FLAG_REQUEST_OVERFLOW, (R, fl_cap)

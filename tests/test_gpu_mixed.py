@@ -196,23 +196,25 @@ def test_sharded_mixed_merge_protocol_on_one_gpu():
     recv = torch.cat([l.send for l in lays])                 # what the all-gather leaves on every rank
     src_stride = lays[0].send.numel()
     R = 4096
-    req_stride, resp_stride = 8 + 8 * R, 8 * R
+    req_stride, resp_stride = 8 + 8 * R, 8 + 8 * R
     owner = shards[0]
     req = torch.zeros((W * req_stride,), dtype=torch.uint8, device=dev)
     ws = torch.empty((int(_lib.load().qpg_merge_mixed_ws_bytes(Q, K, 1024)),), dtype=torch.uint8, device=dev)
     stats = torch.zeros((4,), dtype=torch.int32, device=dev)
     _lib.call("qpg_merge_mixed_phase1_f64", dev, recv, W, src_stride, lays[0].off["aud_d"], lays[0].off["aud_i"], Q, K,
-              float(ABSENT_DIST), AUDIO_MX_BAND, R, req, req_stride, ws, ws.numel(), stats, 1024)
-    counts = [int(req[w * req_stride:w * req_stride + 8].view(torch.int64)[0]) for w in range(W)]
+              float(ABSENT_DIST), AUDIO_MX_BAND, R, req, req_stride, ws, ws.numel(), stats, 1024, -1)
+    counts = [int(req[w * req_stride:w * req_stride + 4].view(torch.int32)[0]) for w in range(W)]   # header: count | flags
     assert min(counts) > 0 and max(counts) <= R              # both shards are asked (the near-ties straddle the boundary)
     resp_recv = torch.zeros((W * resp_stride,), dtype=torch.uint8, device=dev)
     for w in range(W):                                       # all-to-all by hand: owner 0's block w -> shard w's block 0
-        req_recv = torch.zeros((W * req_stride,), dtype=torch.uint8, device=dev)
+        req_recv = torch.full((W * req_stride,), 255, dtype=torch.uint8, device=dev)      # (unused slots / blocks: ~0)
+        for b in range(W):
+            req_recv[b * req_stride:b * req_stride + 8] = 0                       # headers: count | flags
         req_recv[:req_stride] = req[w * req_stride:(w + 1) * req_stride]
         resp = torch.zeros((W * resp_stride,), dtype=torch.uint8, device=dev)
         k, db = shards[w], shards[w].db
         _lib.call("qpg_shard_refine_f64", dev, req_recv, W, req_stride, R, 0, db.idx_base * db.Ga, db.base, 0, db.T, db.F,
-                  db.aud_t, db.Ga, 6, db.tap_stride, k._last_q32, k._last_qn2, db.cn2, resp, resp_stride, 0)
+                  db.aud_t, db.Ga, 6, db.tap_stride, k._last_q32, k._last_qn2, db.cn2, resp, resp_stride, 0, None, R // Q)
         resp_recv[w * resp_stride:(w + 1) * resp_stride] = resp[:resp_stride]
     d = torch.empty((Q, K), dtype=torch.float64, device=dev)
     ix = torch.empty((Q, K), dtype=torch.int32, device=dev)

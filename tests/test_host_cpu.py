@@ -224,10 +224,11 @@ def test_exchange_layout_offsets():
     from qpgesture_amd.code_knn import ExchangeLayout
     lay = ExchangeLayout(96, 512, 4, ["aud", "txt"], True, "cpu")
     n = 24 * 512
-    assert lay.Qb == 24 and lay.off == {"aud_d": 0, "aud_i": 8 * n, "txt_d": 12 * n, "txt_i": 16 * n}
-    assert lay.block_bytes == 20 * n and lay.send.numel() == 4 * 20 * n
+    # (round 4: every block ends with an 8-byte slot whose first i32 is the sender's trouble word)
+    assert lay.Qb == 24 and lay.off == {"aud_d": 0, "aud_i": 8 * n, "txt_d": 12 * n, "txt_i": 16 * n, "flags": 20 * n}
+    assert lay.block_bytes == 20 * n + 8 and lay.send.numel() == 4 * (20 * n + 8)
     d, i, qb, bs = lay.views("aud")
-    assert d.dtype.is_floating_point and d.element_size() == 8 and d.numel() == n and (qb, bs) == (24, 20 * n)
+    assert d.dtype.is_floating_point and d.element_size() == 8 and d.numel() == n and (qb, bs) == (24, 20 * n + 8)
     one = ExchangeLayout(48, 512, 1, ["aud"], False, "cpu")                 # wavvq audio: f32 distances, all-gather
     assert one.views("aud")[0].element_size() == 4 and one.views("aud")[2:] == (0, 0)
     with pytest.raises(AssertionError):
