@@ -49,6 +49,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2 / 16x16x
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak
 
 
+JSON_OUT = sys.stdout
 DATA = "gaussian"      # --data: "gaussian" (i.i.d. N(0,1): SURVEY.md §8d) or "speechlike" (synth.speechlike_transform)
 
 
@@ -147,6 +148,14 @@ def main():
         # torch.distributed.run (RCCL), rank 0 prints the ONE JSON line, which passes through
         sys.exit(self_launch(a.gpus))
 
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes its version banner to the C stdout when a
+    # communicator comes up (it surfaced BEHIND the JSON line of a forced-sharded run).  File descriptor 1 is pointed at
+    # stderr for the rest of the process and the line goes to a duplicate of the original stdout.
+    global JSON_OUT
+    sys.stdout.flush()
+    JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     global DATA
     DATA = a.data
     import torch
@@ -175,7 +184,7 @@ def main():
         t = torch.tensor([rank + 1], dtype=torch.int64)
         dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": int(t.item())}), flush=True)
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": int(t.item())}), file=JSON_OUT, flush=True)
         dist.destroy_process_group()
         return
     torch.cuda.set_device(dev)
@@ -190,7 +199,7 @@ def main():
     if a.workload == "cfg3":
         out = cfg3_bench(a, dev, world, rank)
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=JSON_OUT, flush=True)
         if world > 1 or force_sharded:
             dist.destroy_process_group()
         return
@@ -736,7 +745,7 @@ def main():
         out["check"] = ok
         assert ok, "rank %d: sharded result differs from the single-rank result" % rank
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=JSON_OUT, flush=True)
     if world > 1 or force_sharded:
         dist.destroy_process_group()
 
