@@ -23,7 +23,7 @@ def main(d, steps):
     # a step ends with its device-to-host copy of the codes (the only D2H copy of the loop)
     cuts, armed = [], False
     for i, r in enumerate(rows):       # the codes' D2H copy = the first copyBuffer after the step's gate_chase_kernel
-        if "gate_chase_kernel" in r[2]:
+        if "gate_chase" in r[2]:
             armed = True
         elif armed and "copyBuffer" in r[2]:
             cuts.append(i)
@@ -31,7 +31,7 @@ def main(d, steps):
     if len(cuts) < steps + 1:
         # no copy behind the walk: the results went straight to pinned host memory (walk(sync="ints")) - a step ends
         # with its gate_chase_kernel
-        cuts = [i for i, r in enumerate(rows) if "gate_chase_kernel" in r[2]]
+        cuts = [i for i, r in enumerate(rows) if "gate_chase" in r[2]]
     if len(cuts) < steps + 1:
         print("no step markers found (%d); events:" % len(cuts), sorted(set(r[2] for r in rows))[:40])
         return
