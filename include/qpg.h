@@ -231,7 +231,15 @@ int qpg_hl_pack_rows(qpg_ctx*, void* stream, const float* xs, int64_t R, int D, 
 int qpg_hl_pack_cols(qpg_ctx*, void* stream, const float* qn, int Q, int D, void* image, int64_t image_bytes);
 int qpg_hl_gemm_distance(qpg_ctx*, void* stream, const void* rows_image, int64_t R, int D, const void* cols_image, int Q,
                          float* Dm, int64_t ldD, float* tile_min, int64_t ldT);
-int qpg_percode_select_sorted_f32(qpg_ctx*, void* stream, const float* Dm, int64_t ldD, const float* tile_min, int64_t ldT,
+/* Round 4: the same GEMM WITHOUT its matrix - per (query, 16-row tile) the minimum and a 16-bit mask of the rows within
+ * `band` of it (tile_min f32 / tile_mask u16 [dev] [Q][ldT >= R/16]).  A tile is opened by the select only if its minimum is
+ * within the band of its code's minimum, and code minimum <= tile minimum, so the masked rows are a superset of the band's
+ * rows: qpg_percode_select_sorted_f32 with `tile_mask` never reads Dm (may be NULL).  6 bytes per (query, tile) instead of
+ * 64: cfg-3's 375 MB prefilter matrix is neither written nor read. */
+int qpg_hl_gemm_tilemin(qpg_ctx*, void* stream, const void* rows_image, int64_t R, int D, const void* cols_image, int Q,
+                        float band, float* tile_min, uint16_t* tile_mask, int64_t ldT);
+int qpg_percode_select_sorted_f32(qpg_ctx*, void* stream, const float* Dm, int64_t ldD, const float* tile_min,
+                                  const uint16_t* tile_mask /* or NULL: rows are taken from Dm */, int64_t ldT,
                                   int Q, int64_t R, const int16_t* row_code, const int32_t* row_index,
                                   const int32_t* zero_row, const int32_t* code_tile, int K, float band, const float* qn,
                                   const float* xs, int D, float absent, float* out_dist, int32_t* out_idx,

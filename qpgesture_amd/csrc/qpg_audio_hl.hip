@@ -310,6 +310,8 @@ struct HlArgs {
   int chunks;              // query chunks of this launch
   float* tmin;             // MODE 1, optional: [Q][ldT] minimum of every 16-row tile (rows 16 i .. 16 i + 15)
   int64_t ldT;
+  uint16_t* tmask;         // MODE 1, optional (with tmin): [Q][ldT] bit r = row 16 i + r lies within `band` of the tile's minimum
+  float band;              // ... the matrix itself is then not needed (D may be NULL): the select opens tiles by their masks
 };
 
 #define HL_RING (2 * HL_KS)  // k-blocks of database fragments in flight per wave (2 KB each): two stages
@@ -529,12 +531,25 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         o[r] = (float)(1.0 - ldexp(acc[ct][r] + (double)xacc[ct][r] * (1.0 / 2048.0), -(e_c1 + e_q1)));
-      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (int64_t)q * a.ldD + (int64_t)j * 32 + 16 * t + 4 * rg) = o;
+      if (a.D)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (int64_t)q * a.ldD + (int64_t)j * 32 + 16 * t + 4 * rg) = o;
       if (a.tmin) {           // the tile's minimum over its 16 rows: lanes cg, cg + 16, cg + 32, cg + 48 hold 4 rows each
         float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
         m = fminf(m, __shfl_xor(m, 16, 64));
         m = fminf(m, __shfl_xor(m, 32, 64));
         if (rg == 0) a.tmin[(int64_t)q * a.ldT + (int64_t)j * 2 + t] = m;
+        if (a.tmask) {
+          // round 4: which of the 16 rows lie within the band of the TILE's minimum - a superset of the rows within the
+          // band of the code's minimum whenever the tile is opened at all (code minimum <= tile minimum, and the f32
+          // addition is monotone).  With it the select never reads the matrix: 6 bytes per (query, tile) instead of 64.
+          const float lim = m + a.band;
+          unsigned int bits = ((o[0] <= lim) ? 1u : 0u) | ((o[1] <= lim) ? 2u : 0u) | ((o[2] <= lim) ? 4u : 0u) |
+                              ((o[3] <= lim) ? 8u : 0u);
+          bits <<= 4 * rg;
+          bits |= (unsigned int)__shfl_xor((int)bits, 16, 64);
+          bits |= (unsigned int)__shfl_xor((int)bits, 32, 64);
+          if (rg == 0) a.tmask[(int64_t)q * a.ldT + (int64_t)j * 2 + t] = (uint16_t)bits;
+        }
       }
     }
     return;
@@ -690,7 +705,7 @@ extern "C" int qpg_audio_cosine_hl_range(qpg_ctx* ctx, void* stream, const void*
   a.meta = reinterpret_cast<const int32_t*>(dbi + (qpg_audio_hl_db_bytes(N, F) - 64));
   a.qi = reinterpret_cast<const _Float16*>(qi);
   a.qexp = reinterpret_cast<const int32_t*>(qi + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
-  a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = win_end; a.j0 = win_begin; a.G = G; a.Q = Q; a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0;
+  a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = win_end; a.j0 = win_begin; a.G = G; a.Q = Q; a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0; a.tmask = nullptr; a.band = 0.f;
   a.chunks = chunks;
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
   if (lds_bytes > 64 * 1024) {
@@ -833,14 +848,15 @@ extern "C" int qpg_hl_pack_cols(qpg_ctx* ctx, void* stream, const float* q, int 
   return QPG_OK;
 }
 
-extern "C" int qpg_hl_gemm_distance(qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,
-                                    const void* cols_image, int Q, float* Dm, int64_t ldD, float* tile_min, int64_t ldT) {
-  const char* name = "qpg_hl_gemm_distance";
-  QPG_REQUIRE(ctx && rows_image && cols_image && Dm, "%s: null pointer", name);
-  QPG_REQUIRE(R > 0 && (R % 32) == 0 && R / 32 < 0x7fffffff && Q > 0 && D > 0 && (D % 128) == 0 && ldD >= R &&
-                  (ldD % 4) == 0 && (reinterpret_cast<uintptr_t>(Dm) % 16) == 0,
+static int hl_gemm_impl(const char* name, qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,
+                        const void* cols_image, int Q, float* Dm, int64_t ldD, float* tile_min, int64_t ldT,
+                        uint16_t* tile_mask, float band) {
+  QPG_REQUIRE(ctx && rows_image && cols_image && (Dm || (tile_min && tile_mask)), "%s: null pointer", name);
+  QPG_REQUIRE(R > 0 && (R % 32) == 0 && R / 32 < 0x7fffffff && Q > 0 && D > 0 && (D % 128) == 0 &&
+                  (!Dm || (ldD >= R && (ldD % 4) == 0 && (reinterpret_cast<uintptr_t>(Dm) % 16) == 0)),
               "%s: bad size (R %% 32 == 0, D %% 128 == 0, ldD %% 4 == 0, 16-byte aligned output)", name);
   QPG_REQUIRE(!tile_min || ldT >= R / 16, "%s: tile_min needs ldT >= R / 16", name);
+  QPG_REQUIRE(!tile_mask || (tile_min && band >= 0.f), "%s: tile masks need the tile minima and a band >= 0", name);
   const int chunks = (Q + HL_GQC - 1) / HL_GQC, KB = D / 32;
   HlArgs a;
   const unsigned char* ri = static_cast<const unsigned char*>(rows_image);
@@ -850,7 +866,7 @@ extern "C" int qpg_hl_gemm_distance(qpg_ctx* ctx, void* stream, const void* rows
   a.qi = reinterpret_cast<const _Float16*>(ci);
   a.qexp = reinterpret_cast<const int32_t*>(ci + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
   a.cn2 = nullptr; a.qn2 = nullptr; a.D = Dm; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = nullptr;
-  a.N = (int)(R / 32); a.j0 = 0; a.chunks = chunks; a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1; a.tmin = tile_min; a.ldT = ldT;
+  a.N = (int)(R / 32); a.j0 = 0; a.chunks = chunks; a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1; a.tmin = tile_min; a.ldT = ldT; a.tmask = tile_mask; a.band = band;
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
   const int64_t rgroups = (a.N + HL_WPB - 1) / HL_WPB;
   QPG_REQUIRE(((rgroups + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
@@ -858,6 +874,22 @@ extern "C" int qpg_hl_gemm_distance(qpg_ctx* ctx, void* stream, const void* rows
                      lds_bytes, qpg_stream(stream), a);
   QPG_LAUNCH_CHECK("audio_cosine_hl_kernel<1>");
   return QPG_OK;
+}
+
+extern "C" int qpg_hl_gemm_distance(qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,
+                                    const void* cols_image, int Q, float* Dm, int64_t ldD, float* tile_min, int64_t ldT) {
+  return hl_gemm_impl("qpg_hl_gemm_distance", ctx, stream, rows_image, R, D, cols_image, Q, Dm, ldD, tile_min, ldT, nullptr,
+                      0.f);
+}
+
+// The same GEMM WITHOUT its matrix (round 4): per (query, 16-row tile) the minimum and a 16-bit mask of the rows within
+// `band` of it - all qpg_percode_select_sorted_f32 needs (tile_mask argument).  6 bytes per (query, tile) leave the
+// kernel instead of 64: cfg-3's 375 MB prefilter matrix is never written or read.
+extern "C" int qpg_hl_gemm_tilemin(qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,
+                                   const void* cols_image, int Q, float band, float* tile_min, uint16_t* tile_mask,
+                                   int64_t ldT) {
+  return hl_gemm_impl("qpg_hl_gemm_tilemin", ctx, stream, rows_image, R, D, cols_image, Q, nullptr, 0, tile_min, ldT,
+                      tile_mask, band);
 }
 
 // ---- hardware probe: one v_mfma_f32_16x16x32_f16 per 16 x 16 tile of (A rows, B rows), C given -------------------------------

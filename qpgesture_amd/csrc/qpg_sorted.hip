@@ -52,8 +52,8 @@ __device__ __forceinline__ float okey32_value(unsigned int k) {
 // are opened (16 lanes per tile) and their rows within the band listed, (3) exact sklearn-order distances of the listed
 // pairs, (4) tables.
 __global__ __launch_bounds__(SORT_THREADS) void percode_select_sorted_kernel(
-    const float* __restrict__ Dm, int64_t ldD, const float* __restrict__ tmin, int64_t ldT, int64_t R,
-    const int16_t* __restrict__ row_code, const int32_t* __restrict__ row_index, const int32_t* __restrict__ zero_row,
+    const float* __restrict__ Dm, int64_t ldD, const float* __restrict__ tmin, const uint16_t* __restrict__ tmask,
+    int64_t ldT, int64_t R, const int16_t* __restrict__ row_code, const int32_t* __restrict__ row_index, const int32_t* __restrict__ zero_row,
     const int32_t* __restrict__ code_tile, int K, float band, const float* __restrict__ qn, const float* __restrict__ xs,
     int Dd, float absent, float* __restrict__ out_dist, int32_t* __restrict__ out_idx, int32_t* __restrict__ stats,
     int32_t idx_base, int q_block, int64_t block_stride) {
@@ -68,8 +68,9 @@ __global__ __launch_bounds__(SORT_THREADS) void percode_select_sorted_kernel(
   float* qrow = reinterpret_cast<float*>(tl + SORT_TILES);                            // [Dd]
   __shared__ int n_list, n_tiles;
   const int q = blockIdx.x, tid = threadIdx.x;
-  const float* row = Dm + (int64_t)q * ldD;
+  const float* row = Dm ? Dm + (int64_t)q * ldD : nullptr;
   const float* trow = tmin + (int64_t)q * ldT;
+  const uint16_t* mrow = tmask ? tmask + (int64_t)q * ldT : nullptr;
   const int t0 = code_tile[k0], t1 = code_tile[k1];            // this range's tiles
   for (int k = tid; k < KL; k += blockDim.x) {
     ebest[k] = ~0ull;
@@ -109,13 +110,16 @@ __global__ __launch_bounds__(SORT_THREADS) void percode_select_sorted_kernel(
       nt = SORT_TILES;
       if (tid == 0 && stats) atomicOr(&stats[1], 1);
     }
-    // (2b) their rows: 16 lanes per opened tile
+    // (2b) their rows: 16 lanes per opened tile.  With the GEMM's tile MASKS (round 4) the matrix is not read: bit r of
+    // a tile's mask = row r lies within the band of the TILE's minimum, a superset of the rows within the band of the
+    // code's minimum (code minimum <= tile minimum; the surplus only gets an exact evaluation it did not need).
     for (int i = tid >> 4; i < nt; i += blockDim.x >> 4) {
       const int64_t r = (int64_t)tl[i] * 16 + (tid & 15);
       const int cd = row_code[r];
-      const float d = row[r];
       if (cd & 0x4000) continue;
-      if (d <= okey32_value(best[(cd & 0x1fff) - k0]) + band) {
+      const bool in = mrow ? ((mrow[tl[i]] >> (tid & 15)) & 1) != 0
+                           : row[r] <= okey32_value(best[(cd & 0x1fff) - k0]) + band;
+      if (in) {
         const int pos = atomicAdd(&n_list, 1);
         if (pos < SORT_LIST) list[pos] = (int)r;
       }
@@ -219,15 +223,16 @@ __global__ __launch_bounds__(256) void sorted_finish_kernel(const float* __restr
 }
 
 extern "C" int qpg_percode_select_sorted_f32(qpg_ctx* ctx, void* stream, const float* Dm, int64_t ldD, const float* tile_min,
-                                             int64_t ldT, int Q, int64_t R, const int16_t* row_code,
+                                             const uint16_t* tile_mask, int64_t ldT, int Q, int64_t R,
+                                             const int16_t* row_code,
                                              const int32_t* row_index, const int32_t* zero_row, const int32_t* code_tile,
                                              int K, float band, const float* qn, const float* xs, int Dd, float absent,
                                              float* out_dist, int32_t* out_idx, int16_t* out_rank, int32_t* out_nn,
                                              int32_t* stats, int32_t idx_base, int q_block, int64_t block_stride) {
   const char* name = "qpg_percode_select_sorted_f32";
-  QPG_REQUIRE(ctx && Dm && tile_min && row_code && row_index && code_tile && qn && xs && out_dist && out_idx,
+  QPG_REQUIRE(ctx && (Dm || tile_mask) && tile_min && row_code && row_index && code_tile && qn && xs && out_dist && out_idx,
               "%s: null pointer", name);
-  QPG_REQUIRE(Q >= 0 && R > 0 && (R % 16) == 0 && R < 0x7fffffffll - 0x2000 && ldD >= R && ldT >= R / 16 && K > 0 &&
+  QPG_REQUIRE(Q >= 0 && R > 0 && (R % 16) == 0 && R < 0x7fffffffll - 0x2000 && (!Dm || ldD >= R) && ldT >= R / 16 && K > 0 &&
                   K <= 2048 && K <= 0x1fff && Dd > 0 && (Dd % 16) == 0 && (reinterpret_cast<uintptr_t>(xs) % 16) == 0 &&
                   (reinterpret_cast<uintptr_t>(qn) % 16) == 0,
               "%s: bad size / alignment (R %% 16 == 0, D %% 16 == 0, K <= 2048)", name);
@@ -240,7 +245,7 @@ extern "C" int qpg_percode_select_sorted_f32(qpg_ctx* ctx, void* stream, const f
   const size_t sh = 12 * (size_t)KLmax + 4 * (size_t)SORT_LIST + 4 * (size_t)SORT_TILES + 4 * (size_t)Dd;
   QPG_REQUIRE(sh <= 64 * 1024, "%s: K / D too large for the LDS tables", name);
   hipLaunchKernelGGL(percode_select_sorted_kernel, dim3(Q, S), dim3(SORT_THREADS), sh, qpg_stream(stream), Dm, ldD, tile_min,
-                     ldT, R, row_code, row_index, zero_row, code_tile, K, band, qn, xs, Dd, absent, out_dist, out_idx, stats,
+                     tile_mask, ldT, R, row_code, row_index, zero_row, code_tile, K, band, qn, xs, Dd, absent, out_dist, out_idx, stats,
                      idx_base, q_block, block_stride);
   QPG_LAUNCH_CHECK("percode_select_sorted_kernel");
   if (out_rank || out_nn) {

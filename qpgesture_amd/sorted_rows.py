@@ -76,6 +76,9 @@ class SortedRows:
         self.code_tile = torch.cat((torch.zeros((1,), dtype=torch.int64, device=dev),
                                     torch.cumsum(pad_cnt, 0) // 16)).to(torch.int32).contiguous()      # [K + 1] tile prefix
         self.band = float(prefilter_band(d))
+        # round 4: the prefilter hands the select tile minima + row masks instead of the Q x R matrix (False: the matrix,
+        # as in round 3 - tests compare the two)
+        self.use_masks = True
 
     @staticmethod
     def _first_of_duplicates(xn, codes, keep):
@@ -122,16 +125,26 @@ class SortedRows:
         sc = scratch if scratch is not None else {}
         if sc.get("cols") is None or sc["cols"].numel() < nb:
             sc["cols"] = torch.empty((nb,), dtype=torch.uint8, device=dev)
-        if sc.get("Dm") is None or sc["Dm"].shape[0] < Q or sc["Dm"].shape[1] != self.R:
-            sc["Dm"] = torch.empty((Q, self.R), dtype=torch.float32, device=dev)
-            sc["tmin"] = torch.empty((Q, self.R // 16), dtype=torch.float32, device=dev)
-        cols, Dm, tmin = sc["cols"], sc["Dm"], sc["tmin"]
+        nt = self.R // 16
+        if sc.get("tmin") is None or sc["tmin"].shape[0] < Q or sc["tmin"].shape[1] != nt:
+            sc["tmin"] = torch.empty((Q, nt), dtype=torch.float32, device=dev)
+            sc["tmask"] = torch.empty((Q, nt), dtype=torch.int16, device=dev)
+            sc["Dm"] = None
+        cols, tmin, tmask = sc["cols"], sc["tmin"], sc["tmask"]
         if dist is None:
             dist = torch.empty((Q, self.K), dtype=torch.float32, device=dev)
             idx = torch.empty((Q, self.K), dtype=torch.int32, device=dev)
         _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, cols, cols.numel())
-        _lib.call("qpg_hl_gemm_distance", dev, self.image, self.R, self.d, cols, Q, Dm, self.R, tmin, self.R // 16)
-        _lib.call("qpg_percode_select_sorted_f32", dev, Dm, self.R, tmin, self.R // 16, Q, self.R,
+        if self.use_masks:
+            # tile minima + 16-bit masks of the rows within the band of their tile's minimum: the matrix never exists
+            _lib.call("qpg_hl_gemm_tilemin", dev, self.image, self.R, self.d, cols, Q, self.band, tmin, tmask, nt)
+            Dm = None
+        else:
+            if sc.get("Dm") is None or sc["Dm"].shape[0] < Q:
+                sc["Dm"] = torch.empty((Q, self.R), dtype=torch.float32, device=dev)
+            Dm = sc["Dm"]
+            _lib.call("qpg_hl_gemm_distance", dev, self.image, self.R, self.d, cols, Q, Dm, self.R, tmin, nt)
+        _lib.call("qpg_percode_select_sorted_f32", dev, Dm, self.R, tmin, tmask if self.use_masks else None, nt, Q, self.R,
                   self.row_code, self.row_index, self.zero_row, self.code_tile, self.K, self.band, qn, self.xs, self.d,
                   absent, dist, idx, rank, nn, stats, int(idx_base), int(q_block), int(block_stride))
         return dist, idx, nn

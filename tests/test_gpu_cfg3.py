@@ -166,8 +166,23 @@ def test_cfg3_bounded_prefilter_equals_the_exact_sweep():
     cm = np.where(valid, code, -1).astype(np.int32).reshape(N, 1)
     od, oi = cref.text_scan(X.reshape(N, 1, D), [0], cm, [0], q[sel], K=K, n_threads=8)
     assert np.array_equal(fi.cpu().numpy()[sel], oi) and np.array_equal(fd.cpu().numpy()[sel], od)
+    # round 4: the product path hands the select tile minima + row masks; the same batch through the round-3 form (the
+    # Q x R prefilter matrix) must give the same tables bit for bit
+    assert index.sorted.use_masks and index._scratch.get("Dm") is None
+    index.sorted.use_masks = False
+    md, mi, mn = index.query(qd)
+    index.sorted.use_masks = True
+    assert torch.equal(fd, md) and torch.equal(fi, mi) and torch.equal(fn, mn)
     # the prefilter matrix against the exact f32 distances of the same (sorted) rows: inside half the band
     Dm = index._scratch["Dm"][:8].double().cpu().numpy()
+    # ... and the masks against it: bit r of a tile = row r within the band of the tile's minimum (f32 compare)
+    tmin = index._scratch["tmin"][:8].cpu().numpy()
+    index.query(qd)                                            # (masks of this batch)
+    tmask = index._scratch["tmask"][:8].cpu().numpy().view(np.uint16)
+    D32 = index._scratch["Dm"][:8].cpu().numpy().reshape(8, -1, 16)
+    want = (D32 <= (D32.min(axis=2, keepdims=True) + np.float32(index.band))).astype(np.uint16)
+    want = (want << np.arange(16, dtype=np.uint16)).sum(axis=2).astype(np.uint16)
+    assert np.array_equal(tmask, want) and np.array_equal(tmin, D32.min(axis=2))
     rows_ok = (index.sorted.row_index >= 0).cpu().numpy()
     xs = index.sorted.xs.double().cpu().numpy()
     qn = torch.empty_like(qd)
