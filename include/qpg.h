@@ -221,7 +221,7 @@ int qpg_text_percode_f16(qpg_ctx*, void* stream, const void* xh, const float* nr
  *       code_tile [dev] i32 [K + 1]: first 16-row tile of every code's segment (8 blocks per query take a range of codes
  *       each; ranks / nearest neighbours: a second small launch).  A band list is 2048 rows / 1024 opened tiles per block.
  *       `band` >= 2 x (prefilter error + sklearn's own rounding against the real value): derivation in
- *       csrc/qpg_sorted.hip (8.6e-5 at D = 512).  stats[1] |= 1 if a band list overflowed: run
+ *       csrc/qpg_sorted.hip (8.6e-5 at D = 512).  stats[1] |= 16 if a band list overflowed (its own bit, round 4): run
  *       qpg_text_percode_f32 instead.  out_rank optional: i16 [Q][K] ranks of the table rows (qpg_rank_rows_f32's);
  *       out_nn optional: the query's global nearest neighbour (original index).  idx_base is added to every index written;
  *       q_block / block_stride: the exchange layout of qpg_percode_select_f32 (row shards; no ranks / nn then). */

@@ -31,6 +31,9 @@ AUDIO_HL_BAND = 2.1 * AUDIO_HL_ERR
 
 # bits of the trouble word the sweeps / selects raise (stats[1] of include/qpg.h) and the walk carries out with the codes
 FLAG_LIST_OVERFLOW, FLAG_SMALL_NORMS, FLAG_REQUEST_OVERFLOW, FLAG_CROSS_SHARD_TIE = 1, 2, 4, 8
+# the text prefilter's band list overflowed (a zero-norm context query, thousands of repeated embeddings): only the TEXT side
+# has to run again, on the exact-order sweep - the audio tables of the clip stand
+FLAG_TEXT_OVERFLOW = 16
 
 
 _PIN_SENTINEL = -1234567          # never a status word (flag bits are small non-negative integers)
@@ -1110,7 +1113,27 @@ class CodeKNN:
             if self.audio_precision == "exact":
                 self.clear_flags()          # (the sticky word must not poison the clips after this one)
                 raise RuntimeError("the uncapped path raised flags 0x%x: this is a bug" % e.flags)
-            return self.rematch_exact(test_interp, test_context, n_windows, mode, seed_code, seed_phase, return_tables)
+            return self.rematch(e.flags, test_interp, test_context, n_windows, mode, seed_code, seed_phase, return_tables)
+
+    def rematch(self, flags, test_interp, test_context, n_windows, mode, seed_code, seed_phase, return_tables=False):
+        """The clip again on a path that cannot raise `flags`: only the text prefilter overflowed (FLAG_TEXT_OVERFLOW alone)
+        -> the same audio path with the text side on the exact-order sweep; anything else -> audio_precision "exact"
+        (f64 sweep + uncapped guard, which also takes the exact-order text sweep).  Clears the trouble word."""
+        if flags == FLAG_TEXT_OVERFLOW and self.text_kernel == "mfma":
+            self.clear_flags()
+            self.fallbacks += 1
+            self.text_fallbacks = getattr(self, "text_fallbacks", 0) + 1
+            self.text_kernel = "valu"
+            try:
+                T = self.sweep_tables(test_interp, test_context, n_windows, mode)
+                if return_tables:
+                    self.tables = T
+                return self.walk(T, n_windows, 0, mode, seed_code, seed_phase)
+            except GuardOverflow as e2:          # the audio side of this clip is in trouble as well
+                return self.rematch_exact(test_interp, test_context, n_windows, mode, seed_code, seed_phase, return_tables)
+            finally:
+                self.text_kernel = "mfma"
+        return self.rematch_exact(test_interp, test_context, n_windows, mode, seed_code, seed_phase, return_tables)
 
     def rematch_exact(self, test_interp, test_context, n_windows, mode, seed_code, seed_phase, return_tables=False):
         """The clip again with audio_precision "exact" (f64 sweep + uncapped guard); clears the trouble word."""
@@ -1310,11 +1333,11 @@ class ClipPipeline:
         ints = ln["ints"].numpy()
         try:
             CodeKNN.check_status(ints[n_c + n_v:n_c + n_v + 2])
-        except GuardOverflow:
-            # never return codes the guard could not vouch for: this clip again, now, on the uncapped path
+        except GuardOverflow as e:
+            # never return codes the guard could not vouch for: this clip again, now, on a path that cannot raise the word
             ti, tc, m, mode, seed_code, seed_phase = inputs
             with torch.cuda.stream(ln["stream"]):
-                return ln["knn"].rematch_exact(ti.contiguous(), tc, m, mode, seed_code, seed_phase)
+                return ln["knn"].rematch(e.flags, ti.contiguous(), tc, m, mode, seed_code, seed_phase)
         codes = ints[:n_c].reshape(sc).astype(np.int64)
         votes = ints[n_c:n_c + n_v].reshape(sv).copy()
         phases = ln["phase"].numpy()[:int(np.prod(sp))].reshape(sp).copy()

@@ -26,7 +26,7 @@
 // (zero_row[K]) OUTSIDE the GEMM's rows, and the select enters it with the prefilter value 0.5 (a zero QUERY shifts every
 // value by the same -0.5: order and bands are kept, and since all rows then tie inside the band the list overflows and
 // the exact sweep answers).
-// The tables are bit-identical to qpg_text_percode_f32's.  A list that overflows raises stats[1] |= 1 (the host then
+// The tables are bit-identical to qpg_text_percode_f32's.  A list that overflows raises stats[1] |= 16 (the host then
 // runs the exact VALU sweep): real text embeddings repeat (silence), and thousands of exact ties in one code are then
 // all inside the band.
 #include "qpg_common.h"
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(SORT_THREADS) void percode_select_sorted_kernel(
     int nt = n_tiles;
     if (nt > SORT_TILES) {
       nt = SORT_TILES;
-      if (tid == 0 && stats) atomicOr(&stats[1], 1);
+      if (tid == 0 && stats) atomicOr(&stats[1], 16);          // (16 = this prefilter's own overflow bit)
     }
     // (2b) their rows: 16 lanes per opened tile.  With the GEMM's tile MASKS (round 4) the matrix is not read: bit r of
     // a tile's mask = row r lies within the band of the TILE's minimum, a superset of the rows within the band of the
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(SORT_THREADS) void percode_select_sorted_kernel(
   int n = n_list;
   if (n > SORT_LIST) {
     n = SORT_LIST;
-    if (tid == 0 && stats) atomicOr(&stats[1], 1);
+    if (tid == 0 && stats) atomicOr(&stats[1], 16);
   }
   // (3) exact sklearn-order distance of every listed (query, row) pair: 0.5 * einsum_sq(qn - xn), four lane chains,
   // 16-element groups visited u = 3,2,1,0, separate multiply and add, (l0 + l1) + (l2 + l3).  One thread per pair, the

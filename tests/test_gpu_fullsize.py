@@ -428,3 +428,38 @@ def test_walk_results_through_pinned_host_memory():
         assert host_ints.dtype == np.int32 and np.array_equal(host_ints, dev_ints)
     codes, phases, votes = knn.walk(T, M, seed_code=sc, seed_phase=sp, sync=True)
     assert np.array_equal(codes.reshape(-1), dev_ints[:M * 30]) and np.array_equal(votes.reshape(-1), dev_ints[M * 30:-2])
+
+
+def test_clips_in_flight_on_a_full_size_db_equal_serial_clips():
+    """every lane of a ClipPipeline shares ONE GestureDB, and with the matrix-core text side the
+    prefilter's scratch (column image, tile minima / masks) used to live on the shared SortedRows - lanes on unordered
+    side streams overwrote each other's buffers.  The scratch belongs to the lane's matcher now.  Full-size DB (the text
+    sides are long enough to overlap), three lanes, DIFFERENT clips, both modalities: every clip's codes, votes and phase
+    blocks equal the same clip matched on its own."""
+    import torch
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import ClipPipeline, CodeKNN, GestureDB
+    N, M = 2048, 6
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    interp = torch.randn((N, 180, 1024), device=dev)
+    ctx = rng.standard_normal((N, 30, 384)).astype(np.float32)
+    phase = rng.standard_normal((N, 240, 4, 8)).astype(np.float32)
+    db = GestureDB(synth.make_codes(N, 2), interp, ctx, phase, synth.make_signature(3), device=dev)
+    knn = CodeKNN(db, rng=np.random.RandomState(5))
+    g = torch.Generator(device="cpu").manual_seed(17)
+    clips, seeds = [], []
+    for k in range(9):
+        m = M if k % 3 else 3
+        clips.append((torch.randn((m, 180, 1024), generator=g).to(dev), torch.randn((m, 30, 384), generator=g).to(dev), m))
+        seeds.append(knn.init_code_phase())
+    want = [knn.match_clip(ti, tc, m, seed_code=s_[0], seed_phase=s_[1]) for (ti, tc, m), s_ in zip(clips, seeds)]
+    assert knn._last_text_mfma and knn.fallbacks == 0
+    pipe = ClipPipeline(db, depth=3, rng=np.random.RandomState(1))
+    for rep in range(3):                                     # (a race shows up in some schedules only)
+        got = pipe.match_clips(clips, seeds=seeds)
+        for w, r in zip(want, got):
+            for a, b in zip(w, r):
+                assert np.array_equal(a, b)
+    assert pipe.fallbacks == 0
+    assert len({id(ln["knn"]._txt_scratch) for ln in pipe.lanes}) == 3

@@ -74,17 +74,18 @@ def test_zero_query_overflows_the_band_and_the_clip_is_rematched():
     """An all-zero text query is at 0.5 |x^|^2 from every row: all rows of a code tie inside the band.  With enough rows
     the band list overflows, the trouble word leaves with the codes, and match_clip answers from the exact path."""
     import torch
-    from qpgesture_amd.code_knn import FLAG_LIST_OVERFLOW
+    from qpgesture_amd.code_knn import FLAG_TEXT_OVERFLOW
     def mutate(A):
         A["te_ctx"][0, :, :] = 0.0
     A, db, knn, te_i, te_c = _build(n_train=700, mutate=mutate)             # 700 x 26 = 18 200 rows > the lists' 8 x 2 048
     _, _, _, fm = _text_tables(knn, te_c, 3, "mfma")
-    assert fm & FLAG_LIST_OVERFLOW
+    assert fm == FLAG_TEXT_OVERFLOW                # (its own bit: only the text side has to run again)
     knn.clear_flags()
     knn.text_kernel = "mfma"
     knn.rng = np.random.RandomState(11)
     c1, p1, v1 = knn.match_clip(te_i, te_c, 3)
-    assert knn.fallbacks == 1
+    assert knn.fallbacks == 1 and knn.text_fallbacks == 1 and knn.text_kernel == "mfma"
+    assert knn._last_audio_mixed                   # the re-match kept the mixed-precision audio path
     knn.text_kernel = "valu"
     knn.rng = np.random.RandomState(11)
     c2, p2, v2 = knn.match_clip(te_i, te_c, 3)
