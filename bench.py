@@ -712,6 +712,7 @@ def main():
             "flags": st["flags"], "error_bound": 1.3e-6 if hl else 2.05e-6,
             # the one measured constant under that bound, re-measured at load time on THIS device (selfcheck.py)
             "mfma_selfcheck": {k_: db.hl_bound_report.get(k_) for k_ in ("kappa", "kappa2", "kappa2_assumed", "kappa2_limit",
+                                                                         "kappa6", "kappa6_assumed", "subnormals_exact",
                                                                          "skipped")},
             "max_table_difference_vs_f64_sweep": float((Tm["aud_d"] - T64["aud_d"]).abs().max()),
             "winners_equal_f64_sweep": bool(torch.equal(Tm["aud_idx"], T64["aud_idx"])),

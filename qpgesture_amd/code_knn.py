@@ -25,7 +25,8 @@ MODE_AUD_TXT, MODE_AUD, MODE_TXT = 0, 1, 2
 # like the exact distances; 5 % margin on top)
 AUDIO_MX_ERR = 2.05e-6
 AUDIO_MX_BAND = 2.1 * AUDIO_MX_ERR
-# the split-operand f16 sweep (qpg_audio_cosine_hl, QPG_AUDIO_HL_ERR): a tighter bound, a narrower band
+# the split-operand f16 sweep (qpg_audio_cosine_hl, QPG_AUDIO_HL_ERR): a tighter bound, a narrower band.  (Round 4's
+# 32-row kernel runs the cross products through the h h' chains, cross terms first: the same budget, csrc/qpg_audio_hl.hip.)
 AUDIO_HL_ERR = 1.3e-6
 AUDIO_HL_BAND = 2.1 * AUDIO_HL_ERR
 

@@ -52,6 +52,7 @@
 //    lane shuffles plus one row handed over through LDS; no workspace, no second pass.
 // Bound: HBM (0.70 GB per launch / 8 TB/s); MFMA time 46 us, VALU (f64 flush) 31 us at N = 2048.
 #include "qpg_common.h"
+#include <stdlib.h>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -74,6 +75,19 @@ __device__ __forceinline__ void split_hl(float x, _Float16& h, _Float16& l) {
   h = (_Float16)x;
   const float r = x - (float)h;                    // exact
   l = (_Float16)(r * 2048.0f);
+}
+// Round 4, the AUDIO images: l = fl16(x - h) at its TRUE scale.  The cross products h l' then have their real magnitude
+// and can run through the SAME accumulator as h h' (audio_cosine_hl2_kernel); x - h is below half an ulp of h, so for
+// the large values l stays a normal f16 number with the same 11 significant bits as before, and for values more than
+// 2^13 below the largest one of their side it falls into the subnormal range: an absolute error <= 2^-25 per element,
+// i.e. <= 2^-25 sum|c_i| / (|q||c|) <= 2^-25 sqrt(6144) / 2^14 = 1.4e-10 of the product of norms (the largest element
+// alone makes the scaled norm >= 2^14).  The matrix core takes f16 subnormals as they are (checked at load time:
+// selfcheck.py).
+#define HL_AUDIO_LSHIFT 0
+__device__ __forceinline__ void split_hl_audio(float x, _Float16& h, _Float16& l) {
+  h = (_Float16)x;
+  const float r = x - (float)h;                    // exact
+  l = (_Float16)(HL_AUDIO_LSHIFT ? ldexpf(r, HL_AUDIO_LSHIFT) : r);
 }
 
 // ---- scale exponent of the database: max |x| -> e with max * 2^e in [2^14, 2^15) -------------------------------
@@ -135,8 +149,8 @@ __global__ __launch_bounds__(256) void hl_pack_db_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       _Float16 a0, b0, a1, b1;
-      split_hl(v0[e] * sc, a0, b0);
-      split_hl(v1[e] * sc, a1, b1);
+      split_hl_audio(v0[e] * sc, a0, b0);
+      split_hl_audio(v1[e] * sc, a1, b1);
       hh[e] = a0; ll[e] = b0; hh[4 + e] = a1; ll[4 + e] = b1;
     }
     const int kb = k / 32, kg = (k & 31) >> 3;
@@ -196,8 +210,8 @@ __global__ __launch_bounds__(768) void hl_pack_queries_kernel(const float* __res
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       _Float16 a0, b0, a1, b1;
-      split_hl(v0[e] * sc, a0, b0);
-      split_hl(v1[e] * sc, a1, b1);
+      split_hl_audio(v0[e] * sc, a0, b0);
+      split_hl_audio(v1[e] * sc, a1, b1);
       hh[e] = a0; ll[e] = b0; hh[4 + e] = a1; ll[4 + e] = b1;
     }
     const int kb = k / 32, ct = half * 3 + qq / 16, lane = (qq & 15) + 16 * ((k & 31) >> 3);
@@ -282,8 +296,8 @@ __global__ __launch_bounds__(768) void hl_pack_queries_fused_kernel(const float*
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       _Float16 a0, b0, a1, b1;
-      split_hl(v[u][0][e] * sc, a0, b0);
-      split_hl(v[u][1][e] * sc, a1, b1);
+      split_hl_audio(v[u][0][e] * sc, a0, b0);
+      split_hl_audio(v[u][1][e] * sc, a1, b1);
       hh[e] = a0; ll[e] = b0; hh[4 + e] = a1; ll[4 + e] = b1;
     }
     const int kb = k / 32, ct = half * 3 + qq / 16, lane = (qq & 15) + 16 * ((k & 31) >> 3);
@@ -560,7 +574,7 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hi[ct][r] = acc[3 + ct][r] + (double)xacc[3 + ct][r] * (1.0 / 2048.0);
+    for (int r = 0; r < 4; ++r) hi[ct][r] = acc[3 + ct][r] + ldexp((double)xacc[3 + ct][r], -HL_AUDIO_LSHIFT);
   if (t == 1 && rg == 0)
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) exch[(wl * 3 + ct) * 16 + cg] = hi[ct][0];
@@ -586,7 +600,7 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
     for (int r = 0; r < 4; ++r) {
       const int g = 16 * t + 4 * rg + r;                        // candidate = super-rows g, g + 1
       if (!win_ok || !q_ok || g >= a.G) continue;
-      const double lo = acc[ct][r] + (double)xacc[ct][r] * (1.0 / 2048.0);
+      const double lo = acc[ct][r] + ldexp((double)xacc[ct][r], -HL_AUDIO_LSHIFT);
       const double dot = ldexp(lo + hs[r], -(e_c + e_q));
       const int64_t c = (int64_t)j * a.G + g;
       const double cc = a.cn2[c];
@@ -596,6 +610,209 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
       const double dd = cosine_from_dot(dot, qq, cc);
       if (a.d_f32) reinterpret_cast<float*>(a.D)[(int64_t)q * a.ldD + c] = (float)dd;
       else reinterpret_cast<double*>(a.D)[(int64_t)q * a.ldD + c] = dd;
+    }
+  }
+}
+
+
+// ---- the sweep on 32-ROW wave tiles (round 4): audio_cosine_hl2_kernel ----------------------------------------------------
+// Why: in audio_cosine_hl_kernel<0> a wave owns 16 rows x 96 columns and reads the whole 12 KB of a k-block's query
+// fragments from LDS for its 18 MFMAs.  Per CU and k-block step that is 8 waves x 12 ds_read_b128 x 8 cycles = 768 LDS
+// cycles against 2 waves x 18 x 16 = 576 matrix cycles per SIMD: the LDS pipe is busier than the matrix pipes (168 k
+// LDS cycles per CU and launch = 99 us at the 1.69 GHz the kernel runs at), which is why the kernel still took 140 us
+// with the HBM stream compiled out (profiles/r03_pmc_audio_hl.md).  LDS bytes per MFMA depend on ONE thing, the rows a
+// wave owns; what kept a wave at 16 was the register file (f64 sums + chain halves + cross accumulators).
+// Here a wave owns a whole window (two row tiles, 27 live rows) x 96 columns, and the registers come from the numerics:
+//   * the l planes are stored at their true scale (split_hl_audio), so the cross products h l' + l h' carry their real
+//     magnitude and run through the SAME f32 accumulator as h h': one chain = the 6 instructions of a stage's two
+//     k-blocks for one (row tile, column tile), started from C = 0 and added to the f64 running sum when it is done -
+//     no cross accumulators, no held chain halves;
+//   * bound of such a chain: the four cross instructions come FIRST, so their block errors and the roundings of the
+//     running result are relative to a sum that is <= 2^-10 of the h h' products' (<= 17 x 2^-24 x 2^-10 in units of
+//     sum|h h' products|: 1e-9); the two h h' instructions that follow are round 3's chain of two with a tiny C in front:
+//     kappa_6 <= kappa_2 + 0.02, kappa_2 <= 13 as assumed in §4.1 (the load-time self-check measures chains of six in
+//     this order).  The budget is round 3's - chain sums 7.75e-7, representation 3.0e-7, f32 matrix 1.2e-7 - minus the
+//     cross chains' own 0.7e-7: 1.2e-6 <= QPG_AUDIO_HL_ERR = 1.3e-6, unchanged.
+// Consequences: 4 fragment reads per 12 MFMAs (half the LDS traffic), 8 windows per block (256 blocks at N = 2048: one
+// round), the shifted add of the epilogue inside one wave (no LDS exchange), the f64 flush unchanged per row.
+// Block = 8 waves = 8 windows; stage = 2 k-blocks of the chunk's query image (24 KB), double-buffered; database
+// fragments HBM -> VGPR, ring of 4 k-blocks (a stage's two slots are refilled when the stage is done: one stage = 144
+// MFMAs of lead per wave).
+#define H2_W 8
+__global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x 2 x 6 x 2 x 1 KB
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int xl = (int)blockIdx.x, slot = xl >> 3;
+  const int wgrp = (slot / a.chunks) * 8 + (xl & 7);                   // XCD-aware, as audio_cosine_hl_kernel
+  const int chunk = slot % a.chunks;
+  if (a.j0 + wgrp * H2_W >= a.N) return;
+  const int j = a.j0 + wgrp * H2_W + w;
+  const bool win_ok = j < a.N;
+  const int KB = a.KB, n_stage = KB / 2;
+  const int cg = lane & 15, rg = lane >> 4;
+  // database fragments of this window: tile 0 = 64 units per plane and k-block; tile 1 = its 11 live rows, 44 units
+  const bool ok1 = win_ok && cg < 11;
+  const h8* p0 = win_ok ? reinterpret_cast<const h8*>(a.db) + (int64_t)j * HL_WIN_UNITS(KB) + lane
+                        : reinterpret_cast<const h8*>(a.zeros);
+  const h8* p1 = ok1 ? reinterpret_cast<const h8*>(a.db) + (int64_t)j * HL_WIN_UNITS(KB) + (int64_t)KB * 128 + 11 * rg + cg
+                     : reinterpret_cast<const h8*>(a.zeros);
+  const int kb0 = win_ok ? 128 : 0, pl0 = win_ok ? 64 : 0;
+  const int kb1 = ok1 ? 2 * HL_T1_UNITS : 0, pl1 = ok1 ? HL_T1_UNITS : 0;
+  auto load_a = [&](int kb, h8 (&d)[4]) {                              // [tile 0 h, tile 0 l, tile 1 h, tile 1 l]
+    kb = kb < KB ? kb : KB - 1;
+    d[0] = p0[(int64_t)kb * kb0];
+    d[1] = p0[(int64_t)kb * kb0 + pl0];
+    d[2] = p1[(int64_t)kb * kb1];
+    d[3] = p1[(int64_t)kb * kb1 + pl1];
+  };
+  constexpr int stage_units = 2 * HL_CT * 2 * 64;
+  constexpr int QLD = stage_units / (64 * H2_W);
+  const h8* qsrc = reinterpret_cast<const h8*>(a.qi) + (int64_t)chunk * KB * HL_CT * 2 * 64;
+  h8 qreg[QLD];
+  auto load_q = [&](int s) {
+    s = s < n_stage ? s : n_stage - 1;
+#pragma unroll
+    for (int u = 0; u < QLD; ++u) qreg[u] = qsrc[(int64_t)s * stage_units + u * (64 * H2_W) + tid];
+  };
+  auto store_q = [&](int buf) {
+    h8* dst = reinterpret_cast<h8*>(lds) + buf * stage_units;
+#pragma unroll
+    for (int u = 0; u < QLD; ++u) dst[u * (64 * H2_W) + tid] = qreg[u];
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  double acc[2][HL_CT][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < HL_CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][c][r] = 0.0;
+  h8 ring[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_a(i, ring[i]);
+  load_q(0);
+  store_q(0);
+  load_q(1);
+  lds_barrier();
+  store_q(1);
+  load_q(2);
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  h8 B[2][2][2];                                                       // [step parity][k-block of the stage][plane]
+  auto ld_b = [&](int buf, int c, h8 (&d)[2][2]) {
+    const h8* qb = reinterpret_cast<const h8*>(lds) + buf * stage_units + lane;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) d[k2][pl] = qb[((k2 * HL_CT + c) * 2 + pl) * 64];
+  };
+  ld_b(0, 0, B[0]);
+  f32x4 dp[2] = {zero4, zero4};                                        // the previous step's two chains, not yet flushed
+  for (int s2 = 0; s2 < n_stage; s2 += 2) {                            // two stages per trip: ring / buffer indices static
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const int s = s2 + ss;
+      h8 (&A0)[4] = ring[ss * 2 + 0];
+      h8 (&A1)[4] = ring[ss * 2 + 1];
+#pragma unroll
+      for (int c = 0; c < HL_CT; ++c) {
+        const int st = ss * HL_CT + c;
+        h8 (&Bc)[2][2] = B[st & 1];
+        h8 (&Bn)[2][2] = B[(st + 1) & 1];
+        if (c == HL_CT - 1) {
+          lds_barrier();                       // every fragment of this stage has arrived; the next stage's are stored
+          ld_b((ss + 1) & 1, 0, Bn);
+        } else {
+          ld_b(ss, c + 1, Bn);
+        }
+        // two chains (row tile 0 / 1), interleaved.  ORDER INSIDE A CHAIN: the four cross-term instructions first (h l',
+        // l h' of both k-blocks: the running sum stays 2^-10 of the h h' scale, and so do their roundings), the two h h'
+        // instructions last - the chain then behaves like round 3's chain of two (measured: every instruction that
+        // re-rounds a FULL-SIZE running sum costs ~1.2-1.5 units of 2^-24 sum|products|, so h h' first would mean
+        // kappa_6 = 14.4 against 9.9 this way; selfcheck.py measures this order)
+        f32x4 d0 = mfma_h(A0[0], Bc[0][1], zero4);
+        f32x4 d1 = mfma_h(A0[2], Bc[0][1], zero4);
+        d0 = mfma_h(A0[1], Bc[0][0], d0);
+        d1 = mfma_h(A0[3], Bc[0][0], d1);
+        d0 = mfma_h(A1[0], Bc[1][1], d0);
+        d1 = mfma_h(A1[2], Bc[1][1], d1);
+        d0 = mfma_h(A1[1], Bc[1][0], d0);
+        d1 = mfma_h(A1[3], Bc[1][0], d1);
+        d0 = mfma_h(A0[0], Bc[0][0], d0);
+        d1 = mfma_h(A0[2], Bc[0][0], d1);
+        d0 = mfma_h(A1[0], Bc[1][0], d0);
+        d1 = mfma_h(A1[2], Bc[1][0], d1);
+        // f64 running sums: the PREVIOUS step's chains (zeros in front of the first step)
+        {
+          const int pc = (c + HL_CT - 1) % HL_CT;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[0][pc][r] += (double)dp[0][r];
+            acc[1][pc][r] += (double)dp[1][r];
+          }
+        }
+        dp[0] = d0;
+        dp[1] = d1;
+        if (c == HL_CT - 1) {
+          // the stage is done: its two ring slots take the k-blocks two stages ahead; the freed LDS buffer takes the
+          // stage after next (behind the barrier above: nobody reads this stage's buffer any more)
+          load_a(2 * (s + 2), A0);
+          load_a(2 * (s + 2) + 1, A1);
+          store_q(ss);
+          load_q(s + 3);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {         // issue order: an MFMA, then a fragment read / a share of the flush under it
+          HL_SGB(0x008, 1);
+          if (i < 4) HL_SGB(0x100, 1);
+          HL_SGB(0x002, 2);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {                                        // the last step's chains (column tile 5)
+    acc[0][HL_CT - 1][r] += (double)dp[0][r];
+    acc[1][HL_CT - 1][r] += (double)dp[1][r];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // surplus prefetches must not outlive their registers
+  if (!win_ok) return;
+  // ---- epilogue: dot(q, cand g) = S[g][lo column] + S[g + 1][hi column]; the wave holds all 27 super-rows of its window:
+  // lane (cg, rg) has rows 4 rg .. 4 rg + 3 of tile t for column cg of every column tile
+  const int e_c = a.meta[0];
+  const int src = (lane + 16) & 63;
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    const int q = chunk * HL_QC + ct * 16 + cg;
+    const bool q_ok = q < a.Q;
+    const double qq = q_ok ? a.qn2[q] : 1.0;
+    const int e_q = q_ok ? a.qexp[q] : 0;
+    // row + 1 of the hi column: register r + 1 of the same lane, register 0 of the lane 16 further (the next row group;
+    // for the last row group of tile 0 that lane is row group 0 of TILE 1), nothing behind tile 1's last group
+    const double nx0 = __shfl(acc[0][3 + ct][0], src, 64);
+    const double nx1 = __shfl(acc[1][3 + ct][0], src, 64);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      double hs[4];
+      hs[0] = acc[t][3 + ct][1];
+      hs[1] = acc[t][3 + ct][2];
+      hs[2] = acc[t][3 + ct][3];
+      hs[3] = t == 0 ? (rg < 3 ? nx0 : nx1) : (rg < 3 ? nx1 : 0.0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = 16 * t + 4 * rg + r;
+        if (!q_ok || g >= a.G) continue;
+        const double dot = ldexp(acc[t][ct][r] + hs[r], -(e_c + e_q));
+        const int64_t c = (int64_t)j * a.G + g;
+        const double cc = a.cn2[c];
+        if (a.stats && ((cc > 0.0 && ldexp(cc, 2 * e_c) < 1.0) || (qq > 0.0 && ldexp(qq, 2 * e_q) < 1.0)))
+          atomicOr(&a.stats[1], 2);
+        const double dd = cosine_from_dot(dot, qq, cc);
+        if (a.d_f32) reinterpret_cast<float*>(a.D)[(int64_t)q * a.ldD + c] = (float)dd;
+        else reinterpret_cast<double*>(a.D)[(int64_t)q * a.ldD + c] = dd;
+      }
     }
   }
 }
@@ -716,6 +933,19 @@ extern "C" int qpg_audio_cosine_hl_range(qpg_ctx* ctx, void* stream, const void*
       return QPG_EHIP;
     }
     raised = true;
+  }
+  static int use2 = -1;                        // QPG_HL2=0: round 3's 16-row organisation (measurements, tests)
+  if (use2 < 0) {
+    const char* e = getenv("QPG_HL2");
+    use2 = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (use2 && (KB % 4) == 0) {
+    const int64_t g8 = (win_end - win_begin + H2_W - 1) / H2_W;
+    QPG_REQUIRE(((g8 + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
+    hipLaunchKernelGGL(audio_cosine_hl2_kernel, dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W),
+                       2 * 2 * HL_CT * 2 * HL_PIECE, qpg_stream(stream), a);
+    QPG_LAUNCH_CHECK("audio_cosine_hl2_kernel");
+    return QPG_OK;
   }
   const int64_t wgroups = (win_end - win_begin + HL_WPB - 1) / HL_WPB;
   QPG_REQUIRE(((wgroups + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);

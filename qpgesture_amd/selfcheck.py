@@ -21,6 +21,8 @@ from . import _lib
 
 KAPPA2_ASSUMED = 13.0          # what QPG_AUDIO_HL_ERR budgets for a chain of two (csrc/qpg_audio_hl.hip)
 KAPPA2_LIMIT = 12.0            # the check fails ABOVE this: one unit of slack against families the probe does not build
+KAPPA6_ASSUMED = 13.05         # chains of six (audio_cosine_hl2_kernel: the four cross-term blocks first, then the two h h' blocks)
+KAPPA6_LIMIT = 12.0
 _cache = {}
 
 
@@ -82,7 +84,36 @@ def measure_kappa(device, tiles=512, seed=20260929):
     a[:, :, 1::2] = -a[:, :, 0::2]
     b[:, :, 1::2] = b[:, :, 0::2]
     chain("cancelling first", a, b, rnd(), rnd())
-    return {"kappa": max(v[0] for v in fam.values()), "kappa2": max(v[1] for v in fam.values()),
+    # round 4: the sweep's chains are SIX instructions through one accumulator - the four cross-term blocks (2^-11 of
+    # the h h' ones) FIRST, the two h h' blocks last: kappa_6 in units of 2^-24 x sum |the two big blocks' products|
+    k6 = 0.0
+    BIG = (4, 5)
+    for rep in range(4):
+        blocks = []
+        for i in range(6):
+            sc = 1.0 if i in BIG else 2.0 ** -11
+            if rep in (1, 3) and i == BIG[rep // 2]:
+                a_, b_ = dominant()
+            else:
+                a_, b_ = np.abs(rnd(sc)) if rep < 2 else rnd(sc), np.abs(rnd()) if rep < 2 else rnd()
+            blocks.append((np.ascontiguousarray(a_.astype(np.float16)), np.ascontiguousarray(b_.astype(np.float16))))
+        run, exact, mag = None, 0.0, 0.0
+        for i, (a16, b16) in enumerate(blocks):
+            run = _probe(dev, a16, b16, run)
+            A, B = a16.astype(np.float64), b16.astype(np.float64)
+            exact = exact + np.einsum("tik,tjk->tij", A, B)
+            if i in BIG:
+                mag = mag + np.einsum("tik,tjk->tij", np.abs(A), np.abs(B))
+        k6 = max(k6, float((np.abs(run.astype(np.float64) - exact) / (2.0 ** -24 * mag)).max()))
+    # f16 SUBNORMAL operands (the audio images' l planes hold them): the products must come out exact
+    sub = (rng.integers(1, 1024, size=(tiles, 16, 32)).astype(np.float64) * 2.0 ** -24).astype(np.float16)
+    big = rng.integers(1, 2048, size=(tiles, 16, 32)).astype(np.float16)
+    big[:, :, 1:] = 0                                       # one product per dot: exact in f32 whatever the order
+    got = _probe(dev, np.ascontiguousarray(sub), np.ascontiguousarray(big)).astype(np.float64)
+    want = np.einsum("tik,tjk->tij", sub.astype(np.float64), big.astype(np.float64))
+    sub_ok = bool(np.array_equal(got, want))
+    return {"kappa": max(v[0] for v in fam.values()), "kappa2": max(v[1] for v in fam.values()), "kappa6": k6,
+            "subnormals_exact": sub_ok,
             "families": {k: [round(v[0], 3), round(v[1], 3)] for k, v in fam.items()}}
 
 
@@ -100,10 +131,13 @@ def mfma_bound_ok(device):
         return _cache[idx]
     rep = measure_kappa(torch.device("cuda", idx))
     rep.update(kappa2_assumed=KAPPA2_ASSUMED, kappa2_limit=KAPPA2_LIMIT, skipped=False)
-    ok = rep["kappa2"] <= KAPPA2_LIMIT and rep["kappa"] <= KAPPA2_LIMIT
+    rep.update(kappa6_assumed=KAPPA6_ASSUMED, kappa6_limit=KAPPA6_LIMIT)
+    ok = (rep["kappa2"] <= KAPPA2_LIMIT and rep["kappa"] <= KAPPA2_LIMIT and rep["kappa6"] <= KAPPA6_LIMIT and
+          rep["subnormals_exact"])
     if not ok:
-        warnings.warn("qpgesture_amd: this device's f16 matrix core measured kappa_2 = %.2f (> %.1f): the a-priori bound "
-                      "of the split-f16 sweeps does not hold here; audio sweeps run in f64 and the text side on the "
-                      "exact-order kernel" % (rep["kappa2"], KAPPA2_LIMIT), RuntimeWarning)
+        warnings.warn("qpgesture_amd: this device's f16 matrix core measured kappa_2 = %.2f (limit %.1f), kappa_6 = %.2f "
+                      "(limit %.1f), f16 subnormals exact: %s - the a-priori bound of the split-f16 sweeps does not hold "
+                      "here; audio sweeps run in f64 and the text side on the exact-order kernel"
+                      % (rep["kappa2"], KAPPA2_LIMIT, rep["kappa6"], KAPPA6_LIMIT, rep["subnormals_exact"]), RuntimeWarning)
     _cache[idx] = (ok, rep)
     return _cache[idx]

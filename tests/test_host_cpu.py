@@ -294,9 +294,14 @@ def test_mixed_precision_constants_agree_with_the_header():
     assert code_knn.AUDIO_MX_ERR >= 32 * u / (1 - 32 * u) + 1e-13        # gamma_32 + the f64 part
     m2 = re.search(r"#define\s+QPG_AUDIO_HL_ERR\s+([0-9.eE+-]+)", txt)
     assert m2 and float(m2.group(1)) == code_knn.AUDIO_HL_ERR and code_knn.AUDIO_HL_BAND >= 2.0 * code_knn.AUDIO_HL_ERR
-    # the split-f16 sweep's budget (csrc/qpg_audio_hl.hip): 12 roundings per block sum + cross chains + representation
-    # + the f32-stored matrix
-    assert code_knn.AUDIO_HL_ERR >= 12 * u + 12 * 193 * u / 2048 + (2 * 2.0 ** -23 + u) + 2 * u + 1e-13
+    # the split-f16 sweep's budget (csrc/qpg_audio_hl.hip, audio_cosine_hl2_kernel): chains of six instructions through
+    # one accumulator, the four cross-term instructions first; representation; the f32-stored matrix;
+    # subnormal l planes (2^-25 sqrt(6144) / 2^14 per side); f64 sums
+    k6 = 13 + 17 * 2.0 ** -10                       # cross instructions first: round 3's chain of two + a tiny C
+    assert code_knn.AUDIO_HL_ERR >= k6 * u + (2 * 2.0 ** -23 + u) + 2 * u + 2 * 2.0 ** -25 * 6144 ** 0.5 / 2 ** 14 + 1e-13
+    # the text prefilter / cfg-3 GEMM keeps round 3's kernel and bound (chains of two, separate cross accumulators)
+    from qpgesture_amd import sorted_rows
+    assert sorted_rows.HL_GEMM_ERR >= 13 * u + 12 * 193 * u / 2048 + (2 * 2.0 ** -23 + u) + 2 * u + 1e-13
 
 
 def test_numpy_ranks_follow_the_reference_s_array_dtype():
