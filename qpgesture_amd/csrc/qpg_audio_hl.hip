@@ -638,7 +638,24 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
 // Block = 8 waves = 8 windows; stage = 2 k-blocks of the chunk's query image (24 KB), double-buffered; database
 // fragments HBM -> VGPR, ring of 4 k-blocks (a stage's two slots are refilled when the stage is done: one stage = 144
 // MFMAs of lead per wave).
+// 1 / sqrt(x) in f64 from the f32 estimate and two Newton steps (relative error < 1e-15 for x in f32's normal range): the
+// epilogue's cosine = 1 - dot * rsqrt(|q|^2) * rsqrt(|c|^2) then costs ~12 f64 operations per candidate instead of the ~90
+// of two IEEE square roots and a division - a third of what was left of the kernel behind its k loop.  (The sweep's
+// values carry the a-priori bound of 1.3e-6; this adds 3 ulp of f64.)
+__device__ __forceinline__ double fast_rsqrt_f64(double x) {
+  const float xf = (float)x;
+  double y = (double)__builtin_amdgcn_rsqf(xf);
+  const double hx = 0.5 * x;
+  y = y * (1.5 - hx * y * y);
+  y = y * (1.5 - hx * y * y);
+  return y;
+}
 #define H2_W 8
+// ablation hooks (experiments/audio_hl): -DH2_PROBE=<bits>; the product build defines nothing.  1: database fragments read
+// from one address (no HBM stream); 2: no f64 flush; 4: query fragments read from LDS once per stage pair
+#ifndef H2_PROBE
+#define H2_PROBE 0
+#endif
 __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x 2 x 6 x 2 x 1 KB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -656,8 +673,8 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
                         : reinterpret_cast<const h8*>(a.zeros);
   const h8* p1 = ok1 ? reinterpret_cast<const h8*>(a.db) + (int64_t)j * HL_WIN_UNITS(KB) + (int64_t)KB * 128 + 11 * rg + cg
                      : reinterpret_cast<const h8*>(a.zeros);
-  const int kb0 = win_ok ? 128 : 0, pl0 = win_ok ? 64 : 0;
-  const int kb1 = ok1 ? 2 * HL_T1_UNITS : 0, pl1 = ok1 ? HL_T1_UNITS : 0;
+  const int kb0 = (win_ok && !(H2_PROBE & 1)) ? 128 : 0, pl0 = win_ok ? 64 : 0;
+  const int kb1 = (ok1 && !(H2_PROBE & 1)) ? 2 * HL_T1_UNITS : 0, pl1 = ok1 ? HL_T1_UNITS : 0;
   auto load_a = [&](int kb, h8 (&d)[4]) {                              // [tile 0 h, tile 0 l, tile 1 h, tile 1 l]
     kb = kb < KB ? kb : KB - 1;
     d[0] = p0[(int64_t)kb * kb0];
@@ -722,9 +739,9 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         h8 (&Bc)[2][2] = B[st & 1];
         h8 (&Bn)[2][2] = B[(st + 1) & 1];
         if (c == HL_CT - 1) {
-          lds_barrier();                       // every fragment of this stage has arrived; the next stage's are stored
+          if (!(H2_PROBE & 8)) lds_barrier();  // every fragment of this stage has arrived; the next stage's are stored
           ld_b((ss + 1) & 1, 0, Bn);
-        } else {
+        } else if (!(H2_PROBE & 4)) {
           ld_b(ss, c + 1, Bn);
         }
         // two chains (row tile 0 / 1), interleaved.  ORDER INSIDE A CHAIN: the four cross-term instructions first (h l',
@@ -732,8 +749,8 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         // instructions last - the chain then behaves like round 3's chain of two (measured: every instruction that
         // re-rounds a FULL-SIZE running sum costs ~1.2-1.5 units of 2^-24 sum|products|, so h h' first would mean
         // kappa_6 = 14.4 against 9.9 this way; selfcheck.py measures this order)
-        f32x4 d0 = mfma_h(A0[0], Bc[0][1], zero4);
-        f32x4 d1 = mfma_h(A0[2], Bc[0][1], zero4);
+        f32x4 d0 = mfma_h(A0[0], Bc[0][1], (H2_PROBE & 2) ? dp[0] : zero4);     // (probe 2: one endless chain, no flush)
+        f32x4 d1 = mfma_h(A0[2], Bc[0][1], (H2_PROBE & 2) ? dp[1] : zero4);
         d0 = mfma_h(A0[1], Bc[0][0], d0);
         d1 = mfma_h(A0[3], Bc[0][0], d1);
         d0 = mfma_h(A1[0], Bc[1][1], d0);
@@ -745,7 +762,7 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         d0 = mfma_h(A1[0], Bc[1][0], d0);
         d1 = mfma_h(A1[2], Bc[1][0], d1);
         // f64 running sums: the PREVIOUS step's chains (zeros in front of the first step)
-        {
+        if (!(H2_PROBE & 2)) {
           const int pc = (c + HL_CT - 1) % HL_CT;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -793,6 +810,10 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
     // for the last row group of tile 0 that lane is row group 0 of TILE 1), nothing behind tile 1's last group
     const double nx0 = __shfl(acc[0][3 + ct][0], src, 64);
     const double nx1 = __shfl(acc[1][3 + ct][0], src, 64);
+    // the ordinary case - both norms in f32's normal range - takes the fast reciprocal square roots; zero / tiny / huge
+    // norms take cosine_from_dot (sklearn's degenerate-row semantics)
+    const bool q_fast = qq > 1e-30 && qq < 1e30;
+    const double iq = q_fast ? fast_rsqrt_f64(qq) : 0.0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       double hs[4];
@@ -800,16 +821,23 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
       hs[1] = acc[t][3 + ct][2];
       hs[2] = acc[t][3 + ct][3];
       hs[3] = t == 0 ? (rg < 3 ? nx0 : nx1) : (rg < 3 ? nx1 : 0.0);
+      // the four candidates of this lane are consecutive: their squared norms are one 32-byte run
+      const int g0 = 16 * t + 4 * rg;
+      double cc4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cc4[r] = (g0 + r < a.G) ? a.cn2[(int64_t)j * a.G + g0 + r] : 1.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int g = 16 * t + 4 * rg + r;
+        const int g = g0 + r;
         if (!q_ok || g >= a.G) continue;
         const double dot = ldexp(acc[t][ct][r] + hs[r], -(e_c + e_q));
         const int64_t c = (int64_t)j * a.G + g;
-        const double cc = a.cn2[c];
+        const double cc = cc4[r];
         if (a.stats && ((cc > 0.0 && ldexp(cc, 2 * e_c) < 1.0) || (qq > 0.0 && ldexp(qq, 2 * e_q) < 1.0)))
           atomicOr(&a.stats[1], 2);
-        const double dd = cosine_from_dot(dot, qq, cc);
+        double dd;
+        if (q_fast && cc > 1e-30 && cc < 1e30) dd = 1.0 - dot * (iq * fast_rsqrt_f64(cc));
+        else dd = cosine_from_dot(dot, qq, cc);
         if (a.d_f32) reinterpret_cast<float*>(a.D)[(int64_t)q * a.ldD + c] = (float)dd;
         else reinterpret_cast<double*>(a.D)[(int64_t)q * a.ldD + c] = dd;
       }
