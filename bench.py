@@ -100,7 +100,13 @@ def main():
     ap.add_argument("--no-replicated", action="store_true",
                     help="N > 1, --scaling weak: skip the extra `replicated` leg (whole DB on every GPU, one clip per rank, no "
                          "collective) that is otherwise measured after the row-sharded figure, in the same run")
-    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-replay leg (`graph_replay` object)")
+    ap.add_argument("--step-mode", choices=["auto", "graph", "eager"], default="auto",
+                    help="how the timed steps are issued: graph = ONE hipGraphLaunch per clip (code_knn.ClipGraph: the same "
+                         "kernels, seed and results through pinned memory; one capture serves every clip), eager = one "
+                         "launch per kernel from Python; auto (default) = graph for the one-GPU one-clip shape, eager "
+                         "otherwise.  In graph mode the eager figure and the HIP-event timing of the sweep kernel come from "
+                         "an eager leg of the same K steps right after the timed region (`eager` object)")
+    ap.add_argument("--no-graph", action="store_true", help="same as --step-mode eager")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (`e2e_cli` object)")
     ap.add_argument("--sharded-mixed-min-gflop", type=float, default=None,
                     help="row shards sweep in mixed precision when their sweep is at least this long (default: "
@@ -271,7 +277,7 @@ def main():
         te_ctx = te_ctx[rank * CL * M:(rank + 1) * CL * M].contiguous()
     n_sweep_clips = CL if replicated else n_clips
 
-    def step():
+    def step_eager():
         # weak, N > 1: every rank sweeps all clips' queries against its DB shard; ONE all-to-all leaves each rank with
         # the final tables of its own clips.  strong: ONE all-gather + merge, every rank holds the clip's tables.
         # replicated: this rank's clips against the whole DB, no exchange.
@@ -292,7 +298,7 @@ def main():
                 prev, knn.audio_precision = knn.audio_precision, "exact"
                 knn.clear_flags()
                 try:
-                    return step()
+                    return step_eager()
                 finally:
                     knn.audio_precision = prev
             knn.check_status(arr[-2:])
@@ -312,12 +318,40 @@ def main():
             prev, knn.audio_precision = knn.audio_precision, "exact"
             knn.clear_flags()
             try:
-                return step()
+                return step_eager()
             finally:
                 knn.audio_precision = prev
         for c in range(my_clips):
             knn.check_status(res[c, -2:].tolist())
         return res[:, :n_codes].reshape(my_clips * M, 30)
+
+    # Step mode.  graph: the whole per-clip launch sequence captured ONCE (nothing about a clip is baked in: the seed code /
+    # phase block are data in pinned host memory, the inputs are the resident tensors) and replayed with one hipGraphLaunch
+    # per clip; the integer results land in pinned host memory and the host watches the status word.  A step still ends
+    # with the clip's codes on the host, a flagged clip is still re-matched (eagerly) before anything is returned.
+    graph_mode = (a.step_mode == "graph" or (a.step_mode == "auto" and not a.no_graph)) and world == 1 and CL == 1 and \
+        enc is None and not force_sharded and a.clips_in_flight == 1
+    if a.step_mode == "graph" and not graph_mode:
+        raise SystemExit("--step-mode graph: one GPU, one clip per step, no encode leg, no clips in flight")
+    cg = None
+    if graph_mode:
+        knn_g = CodeKNN(db, rng=np.random.RandomState(123456))      # (its own workspaces / side stream: the capture's)
+        knn_g.overlap_sweeps, knn_g.audio_precision, knn_g.audio_kernel = knn.overlap_sweeps, knn.audio_precision, knn.audio_kernel
+        # (QPG_BENCH_GRAPH_TEXT_FIRST=1: the text side's nodes captured first.  A replay submits a second branch's first
+        # node ~45 us behind the first branch's, whichever comes first; measured with tools/graph_orders.sh: text first 0.2985
+        # ms per clip / GPU span 319 us, audio first 0.3048 / 307 - no order wins, the default keeps the eager order)
+        if os.environ.get("QPG_BENCH_GRAPH_TEXT_FIRST", "0") == "1":
+            knn_g.text_after_sweep, knn_g.audio_first = False, False
+        cg = knn_g.capture_clip_graph(M, audio=te_interp, context=te_ctx)
+
+    def step_graph():
+        arr = cg.run_ints(seed_code, seed_phase)
+        if arr[-1] != 0:                           # the trouble word came out with the codes: this clip again, eagerly
+            return step_eager()
+        knn.check_status(arr[-2:])
+        return arr[:n_codes].reshape(M, 30)
+
+    step = step_graph if graph_mode else step_eager
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -433,6 +467,29 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    eager_leg = None
+    if graph_mode:
+        # the eager figure and the sweep kernel's HIP-event timing: the same K steps, one launch per kernel, right behind
+        # the timed region (events cannot bracket a node of a replayed graph); the pool of events exists already
+        for _ in range(max(a.warmup, 10)):
+            step_eager()
+        knn.kernel_events = []
+        gc.collect()
+        gc.disable()
+        st0_ = knn.mixed_stats()
+        fence()
+        te0 = time.perf_counter()
+        for _ in range(a.steps):
+            ce = step_eager()
+        fence()
+        de = time.perf_counter() - te0
+        gc.enable()
+        st1_ = knn.mixed_stats()
+        eager_leg = {"ms_per_step": round(de / a.steps * 1e3, 4), "steps": a.steps,
+                     "tier1_pairs_per_step": (st1_["tier1_pairs"] - st0_["tier1_pairs"]) / a.steps,
+                     "tier2_pairs_per_step": (st1_["tier2_pairs"] - st0_["tier2_pairs"]) / a.steps,
+                     "frames_per_s": round(240 * M * n_clips * a.steps / de, 1),
+                     "codes_equal_graph_steps": bool(np.array_equal(np.asarray(ce).reshape(-1), codes.numpy().reshape(-1)))}
     ms = [e0.elapsed_time(e1) for e0, e1 in knn.kernel_events] if knn.kernel_events else [float("nan")]
     knn.kernel_events = None
     if pipe is not None:
@@ -493,9 +550,12 @@ def main():
                     "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "traffic": AUDIO_HL_TRAFFIC_BYTES if default_shape else None,
                     "traffic_source": HL_TRAFFIC_SOURCE if default_shape else None,
-                    "kernel": ("audio_cosine_hl_kernel (split-operand f16 matrix cores on a frame-major image: every "
-                               "database frame read once; h h' block sums added in f64, error bounded a priori, f64 "
-                               "re-evaluation in the select)"),
+                    "kernel": ("audio_cosine_hl2_kernel (split-operand f16 matrix cores on a frame-major image: every "
+                               "database frame read once, 32-row wave tiles; chain sums added in f64, error bounded a "
+                               "priori, f64 re-evaluation in the select)"),
+                    "kernel_ms_source": ("HIP events around the kernel on its launch stream in the %d eager steps run right "
+                                         "behind the timed region (a replayed graph's nodes cannot be bracketed)" % a.steps)
+                    if graph_mode else "HIP events around the kernel on its launch stream, every timed step",
                     "precision": "mixed", "kernel_ms": round(k_ms, 4),
                     "kernel_ms_min": round(float(np.min(ms)), 4), "kernel_ms_median": round(float(np.median(ms)), 4),
                     "kernel_ms_max": round(float(np.max(ms)), 4), "kernel_launches_timed": len(ms),
@@ -586,12 +646,12 @@ def main():
         gc.collect()
         gc.disable()
         for _ in range(10):             # (after the collection: nothing idles the GPU between these and the timed steps)
-            step()
+            step_eager()
         knn.kernel_events, knn.kernel_event_pool = [], pool6
         fence()
         t6 = time.perf_counter()
         for _ in range(20):
-            c64 = step()
+            c64 = step_eager()
         fence()
         d6 = time.perf_counter() - t6
         gc.enable()
@@ -608,35 +668,17 @@ def main():
                             "achieved": round(flops / (k6 * 1e-3) / 1e12, 3), "peak": F64_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(flops / (k6 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
                             "codes_equal_default_path": bool(torch.equal(c64, codes))}
-    if mixed and not sharded_run and world == 1 and CL == 1 and pipe is None and enc is None and not a.no_graph:
-        # the same launches replayed as ONE hipGraph (code_knn.ClipGraph, bound to the resident clip): the seed code and
-        # phase block are data in pinned host memory, the integer results come back through pinned memory - a step is
-        # "write seed + sentinel, hipGraphLaunch, watch the status word".  One capture serves every clip of this shape.
-        cg = knn.capture_clip_graph(M, audio=te_interp, context=te_ctx)
-        for _ in range(10):
-            gi = cg.run_ints(seed_code, seed_phase)
-        gc.collect()
-        gc.disable()
-        dgs = []
-        for _ in range(3):
-            fence()
-            tg = time.perf_counter()
-            for _ in range(a.steps):
-                gi = cg.run_ints(seed_code, seed_phase)
-            fence()
-            dgs.append(time.perf_counter() - tg)
-        gc.enable()
+    out["step_mode"] = "graph" if graph_mode else "eager"
+    if graph_mode:
+        out["eager"] = eager_leg
         # another seed through the SAME capture must equal the eager path started from that seed
         sc2 = (seed_code + 101) % 512
         sp2 = np.roll(seed_phase, 3, axis=0)
         g2 = cg.run_ints(sc2, sp2)
         e2 = knn.walk(knn.sweep_tables(te_interp, te_ctx, M), M, seed_code=sc2, seed_phase=sp2, sync="ints")
-        out["graph_replay"] = {"ms_per_step": round(min(dgs) / a.steps * 1e3, 4), "steps": a.steps,
-                               "ms_per_step_all_three_runs": [round(x / a.steps * 1e3, 4) for x in dgs],
-                               "frames_per_s": round(frames_per_step * a.steps / min(dgs), 1),
-                               "captures": cg.captures,
-                               "codes_equal_default_path": bool(np.array_equal(gi[:n_codes], codes.numpy().reshape(-1))),
-                               "status": [int(gi[-2]), int(gi[-1])],
+        out["graph_replay"] = {"ms_per_step": out["ms_per_step"], "steps": a.steps, "captures": cg.captures,
+                               "is_the_timed_region": True,
+                               "text_side_captured_first": bool(not knn_g.audio_first and knn_g.audio_first is not None),
                                "other_seed_equals_eager": bool(np.array_equal(g2, e2))}
     if (mixed and not sharded_run and world == 1 and can_pipe and pipe is None and not a.no_f64_line and
             os.environ.get("QPG_BENCH_NO_PIPELINED", "") != "1"):
@@ -697,6 +739,10 @@ def main():
             st = {"tier1_pairs": sum(x["tier1_pairs"] for x in ls), "tier2_pairs": sum(x["tier2_pairs"] for x in ls),
                   "flags": int(np.bitwise_or.reduce([x["flags"] for x in ls]))}
         n_run = a.steps + a.warmup + prewarm["steps"]
+        if graph_mode:                             # the timed steps ran on the capture's matcher
+            sg = knn_g.mixed_stats()
+            st = {"tier1_pairs": sg["tier1_pairs"], "tier2_pairs": sg["tier2_pairs"], "flags": sg["flags"] | st["flags"]}
+            n_run += 2                                 # (the capture's two warm-up passes)
         k64 = CodeKNN(db, rng=np.random.RandomState(123456))
         k64.audio_precision = "f64"
         T64 = k64.sweep_tables(te_interp, te_ctx, M * n_sweep_clips)
