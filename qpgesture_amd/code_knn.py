@@ -40,6 +40,27 @@ FLAG_TEXT_OVERFLOW = 16
 _PIN_SENTINEL = -1234567          # never a status word (flag bits are small non-negative integers)
 
 
+def _wait_pinned(pin_np, stream):
+    """Host side of the zero-copy results: spin on the status word (the walk's last store, behind a system-scope fence),
+    then make sure no other word still holds the sentinel - a store that the fabric delivered late is waited for, never
+    copied as it is (codes / votes / flags can not take the sentinel's value) - and return a copy.  After ~2 ms without the
+    word (a failed launch would never write it) the stream is synchronised the ordinary way."""
+    for _ in range(40000):
+        if pin_np[-1] != _PIN_SENTINEL:
+            break
+    else:
+        stream.synchronize()
+        if pin_np[-1] == _PIN_SENTINEL:
+            raise RuntimeError("the walk did not write its status word")
+    out = pin_np.copy()
+    if (out == _PIN_SENTINEL).any():
+        stream.synchronize()
+        out = pin_np.copy()
+        if (out == _PIN_SENTINEL).any():
+            raise RuntimeError("the walk left result words unwritten")
+    return out
+
+
 class GuardOverflow(RuntimeError):
     """The capped near-tie machinery of the fast audio paths could not guarantee the reference's candidates for this
     clip (a re-evaluation list overflowed, operand norms left the error bound's range, or shard minima tied across the
@@ -990,7 +1011,9 @@ class CodeKNN:
             base = pin.data_ptr()
             out_codes, out_vote, status = base, base + 4 * n_c, base + 4 * (n_c + n_v)
             pin_np = pin.numpy()
-            pin_np[-1] = _PIN_SENTINEL          # overwritten by the walk's LAST store (behind a system-scope fence)
+            # every word is a sentinel until the walk has written it; the status word is the walk's LAST store (behind a
+            # system-scope fence), the others are checked as well before the buffer is copied (_wait_pinned)
+            pin_np.fill(_PIN_SENTINEL)
         else:
             ints_d = torch.empty((n_c + n_v + 2,), dtype=torch.int32, device=dev)
             out_codes = ints_d[:n_c].view(M, num_frames_code)
@@ -1023,14 +1046,7 @@ class CodeKNN:
         if sync == "ints":
             # the host watches the last word instead of sleeping in hipStreamSynchronize (~3.5 us sooner per clip); after
             # ~2 ms without it (a failed launch would never write it) the stream is synchronised the ordinary way
-            for _ in range(40000):
-                if pin_np[-1] != _PIN_SENTINEL:
-                    break
-            else:
-                torch.cuda.current_stream(dev).synchronize()
-                if pin_np[-1] == _PIN_SENTINEL:
-                    raise RuntimeError("the walk did not write its status word")
-            return pin_np.copy()
+            return _wait_pinned(pin_np, torch.cuda.current_stream(dev))
         phases = out_phase.cpu().numpy()                    # (synchronises the stream: the pinned integers are complete)
         ints = pin.numpy().copy()
         self.check_status(ints[n_c + n_v:])
@@ -1225,21 +1241,13 @@ class ClipGraph:
         self._set_seed(seed_code, seed_phase)
         if self.graph is None:
             self._capture()
-        self._pin_np[-1] = _PIN_SENTINEL
+        self._pin_np.fill(_PIN_SENTINEL)
         self.graph.replay()
 
     def wait_ints(self):
         """Host-side wait for the replay's last store (the status word, behind a system-scope fence); returns a copy of
         codes | votes | status (int32).  The caller hands ints[-2:] to CodeKNN.check_status()."""
-        pin_np = self._pin_np
-        for _ in range(40000):
-            if pin_np[-1] != _PIN_SENTINEL:
-                break
-        else:
-            torch.cuda.current_stream(self.knn.db.device).synchronize()
-            if pin_np[-1] == _PIN_SENTINEL:
-                raise RuntimeError("the walk did not write its status word")
-        return pin_np.copy()
+        return _wait_pinned(self._pin_np, torch.cuda.current_stream(self.knn.db.device))
 
     def run_ints(self, seed_code, seed_phase):
         """One replay on the bound inputs, ending with the integer results on the host (bench.py's graph step)."""

@@ -423,9 +423,11 @@ def test_walk_results_through_pinned_host_memory():
     T = knn.sweep_tables(te_i, te_c, M)
     knn.walk(T, M, seed_code=sc, seed_phase=sp, sync=False)
     dev_ints = knn._last_ints.cpu().numpy()
-    for _ in range(3):                                   # (the pinned buffer is reused from call to call)
-        host_ints = knn.walk(T, M, seed_code=sc, seed_phase=sp, sync="ints")
-        assert host_ints.dtype == np.int32 and np.array_equal(host_ints, dev_ints)
+    for rep in range(200):                               # (the pinned buffer is reused from call to call; round 4: every
+        host_ints = knn.walk(T, M, seed_code=sc, seed_phase=sp, sync="ints")     # word is a sentinel until it is written)
+        assert host_ints.dtype == np.int32
+        assert np.array_equal(host_ints, dev_ints), (rep, np.nonzero(host_ints != dev_ints)[0], host_ints[host_ints != dev_ints],
+                                                     dev_ints[host_ints != dev_ints])
     codes, phases, votes = knn.walk(T, M, seed_code=sc, seed_phase=sp, sync=True)
     assert np.array_equal(codes.reshape(-1), dev_ints[:M * 30]) and np.array_equal(votes.reshape(-1), dev_ints[M * 30:-2])
 
