@@ -548,8 +548,7 @@ def main():
         gbs = alg_bytes / (k_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "traffic": AUDIO_HL_TRAFFIC_BYTES if default_shape else None,
-                    "traffic_source": HL_TRAFFIC_SOURCE if default_shape else None,
+                    **pmc_traffic("audio_cosine_hl2_kernel|N_db=2048 Q=48" if default_shape else None),
                     "kernel": ("audio_cosine_hl2_kernel (split-operand f16 matrix cores on a frame-major image: every "
                                "database frame read once, 32-row wave tiles; chain sums added in f64, error bounded a "
                                "priori, f64 re-evaluation in the select)"),
@@ -795,6 +794,22 @@ def main():
         print(json.dumps(out), file=JSON_OUT, flush=True)
     if world > 1 or force_sharded:
         dist.destroy_process_group()
+
+
+def pmc_traffic(key):
+    """`roofline.traffic` = HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x 2 per the
+    gfx950 correction + WRITE_SIZE, separate passes), read at run time from the committed summary profiles/pmc_traffic.json
+    (written by tools/pmc_traffic.py from the passes of tools/r04_gpu_pass.sh); null for shapes that were not measured."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if key is None or not os.path.exists(path):
+        return {"traffic": None, "traffic_source": None}
+    rec = json.load(open(path)).get(key)
+    if rec is None:
+        return {"traffic": None, "traffic_source": None}
+    return {"traffic": int(rec["hbm_bytes_per_launch"]),
+            "traffic_source": "profiles/pmc_traffic.json [%s]: FETCH_SIZE %.0f KB x 1024 x 2 + WRITE_SIZE %.0f KB x 1024, "
+                              "rocprofv3 --pmc passes of this launch shape (not re-measured per run)"
+                              % (key, rec["fetch_size_kb"], rec["write_size_kb"])}
 
 
 # HBM bytes per audio_cosine_f64_kernel launch at the default shape (N_db=2048, Q=48), rocprofv3 PMC, separate

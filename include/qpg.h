@@ -152,6 +152,13 @@ int64_t qpg_audio_hl_query_bytes(int Q, int F);
 int qpg_audio_hl_pack_db(qpg_ctx*, void* stream, const float* base, int N, int T, int F, int G, int n_taps, int tap_stride,
                          int cand_step, void* image, int64_t image_bytes);
 int qpg_audio_hl_pack_queries(qpg_ctx*, void* stream, const float* q32, int Q, int F, void* image, int64_t image_bytes);
+/* Round 4: a clip's WHOLE query side in one launch - qpg_audio_pack_queries_hl's work and the text side's query pack
+ * (qpg_text_pack_queries_f32 + qpg_hl_pack_cols, bit-identical outputs): text_ctx [dev] f32 [Mt][R][Dt], tq_win / tq_row
+ * [dev] i32 [Qt], qn_out [dev] f32 [Qt][Dt], cols_image [dev] qpg_hl_cols_bytes(Qt, Dt) bytes.  Dt %% 128 == 0. */
+int qpg_clip_pack_hl(qpg_ctx*, void* stream, const float* qbase, int M, int T, int F, const int32_t* q_win,
+                     const int32_t* q_t, int Q, int n_taps, int tap_stride, float* q32, double* qn2, void* image,
+                     int64_t image_bytes, const float* text_ctx, int Mt, int R, int Dt, const int32_t* tq_win,
+                     const int32_t* tq_row, int Qt, float* qn_out, void* cols_image, int64_t cols_bytes);
 int qpg_audio_cosine_hl(qpg_ctx*, void* stream, const void* db_image, int N, int F, int G, const double* cn2,
                         const void* q_image, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD, int32_t* stats);
 /* Windows [win_begin, win_end) of the same sweep (N stays the image's window count; other columns of D are untouched): two

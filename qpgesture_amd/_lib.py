@@ -36,6 +36,7 @@ _SIGS = {
     "qpg_audio_hl_pack_db": [P, I, I, I, I, I, I, I, P, L],
     "qpg_audio_hl_pack_queries": [P, I, I, P, L],
     "qpg_audio_pack_queries_hl": [P, I, I, I, P, P, I, I, I, P, P, P, L],
+    "qpg_clip_pack_hl": [P, I, I, I, P, P, I, I, I, P, P, P, L, P, I, I, I, P, P, I, P, P, L],
     "qpg_audio_cosine_hl": [P, I, I, I, P, P, P, I, P, I, L, P],
     "qpg_audio_cosine_hl_range": [P, I, I, I, P, P, P, I, P, I, L, P, I, I],
     "qpg_debug_mfma_f16_tile": [P, P, P, I, P],

@@ -362,6 +362,10 @@ class CodeKNN:
         # shared GestureDB.txt_sorted - the lanes of a ClipPipeline run their text sides concurrently
         self._txt_scratch = {}
         self.fallbacks = 0
+        # a clip's audio AND text query packs in one launch (qpg_clip_pack_hl; False / QPG_FUSED_PACK=0: round 3's separate
+        # launches - tests and measurements compare the two)
+        import os as _os
+        self.fused_pack = _os.environ.get("QPG_FUSED_PACK", "1") != "0"
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
         # Row-sharded DB: the shards sweep in mixed precision too and the cross-shard merge re-evaluates what their
         # bounded tables leave open through a request / response exchange (sweep_tables; qpg_merge_mixed_*).
@@ -413,7 +417,14 @@ class CodeKNN:
         return code, np.concatenate((P[:, 0], P[:, 1]), axis=1).astype(np.float32)
 
     # -- batched sweeps ------------------------------------------------------------------------
-    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None, want_rank=False, reduce=True, out=None):
+    def _hl_plan(self, sharded=False):
+        """Will sweep_audio take the split-f16 (hl) mixed-precision path for a whole-clip sweep on this DB?"""
+        db = self.db
+        return (self.audio_precision == "mixed" and self.tie_eps > 0 and db.n_local > 0 and db.K <= 512 and
+                db.hl_bound_ok and not sharded and db.world == 1 and self.audio_kernel == "hl" and
+                db.hl_image is not None and db.feature_dtype == "f32")
+
+    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None, want_rank=False, reduce=True, out=None, prepacked=None):
         """Per-code best audio candidate for every query: returns (dist f64 [Q,512], idx i32 [Q,512])
         with global candidate indices j*26+g (-1 = code absent), min-reduced across ranks; with
         want_rank also the stable ranks i16 [Q,512]."""
@@ -422,8 +433,11 @@ class CodeKNN:
         qbase = qbase.contiguous()
         M, T, F = qbase.shape
         ts = db.tap_stride if tap_stride is None else tap_stride
-        q32 = torch.empty((Q, NUM_AUDIO_FEAT_FRAMES * F), dtype=torch.float32, device=dev)
-        qn2 = torch.empty((Q,), dtype=torch.float64, device=dev)
+        if prepacked is not None:           # (sweep_tables packed the clip's whole query side in one launch)
+            q32, qn2 = prepacked[0], prepacked[1]
+        else:
+            q32 = torch.empty((Q, NUM_AUDIO_FEAT_FRAMES * F), dtype=torch.float32, device=dev)
+            qn2 = torch.empty((Q,), dtype=torch.float64, device=dev)
         C = db.n_local * db.Ga
         fused_rank = want_rank and db.world == 1
         half = db.feature_dtype == "f16"
@@ -459,9 +473,11 @@ class CodeKNN:
                 # the sweep's arguments are converted BEFORE the pack goes out: its launch follows the pack's at once
                 sweep_launch = _lib.prepare("qpg_audio_cosine_hl", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi,
                                             qn2, Q, D, 1, D.stride(0), self._guard_stats)
-            _lib.call("qpg_audio_pack_queries_hl", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
-                      NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2, qi, qi.numel())
+            if prepacked is None:
+                _lib.call("qpg_audio_pack_queries_hl", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
+                          NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2, qi, qi.numel())
         else:
+            assert prepacked is None, "the one-launch clip pack feeds the split-f16 sweep only"
             _lib.call("qpg_audio_pack_queries", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
                       NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2)
         if ev is not None:
@@ -556,7 +572,7 @@ class CodeKNN:
         self._sweep_done = self._sweep_event
         self._sweep_done.record(torch.cuda.current_stream(dev))
 
-    def sweep_text(self, queries, want_rank=False, reduce=True, normalised=False, out=None):
+    def sweep_text(self, queries, want_rank=False, reduce=True, normalised=False, out=None, cols_packed=False):
         """queries: f32 [Q,384] on the device (already sklearn-normalised if `normalised`).
         Returns (dist f32 [Q,512], idx i32 [Q,512][, rank])."""
         db, dev = self.db, self.db.device
@@ -577,7 +593,7 @@ class CodeKNN:
                 return dist, idx
             rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if want_rank else None
             dist, idx, _ = db.txt_sorted.select(qn, float(ABSENT_DIST), self._guard_stats, rank=rank,
-                                                scratch=self._txt_scratch)
+                                                scratch=self._txt_scratch, cols_packed=cols_packed)
             if want_rank:
                 return dist, idx, rank
             return dist, idx
@@ -801,6 +817,34 @@ class CodeKNN:
                 gate.record(torch.cuda.current_stream(dev))
             side.wait_event(gate)
 
+        # Round 4: the clip's WHOLE query side in one launch (qpg_clip_pack_hl: the audio gather / norms / split-f16 image
+        # AND the text queries' gather / sklearn normalisation / column image) when both sides take their matrix-core
+        # paths on an unsharded DB.  Behind the 32-row sweep, which holds every register of every CU, the text side's two
+        # tiny pack launches did not get a wave slot before the sweep was over.
+        mfma_text_ = (self.text_kernel == "mfma" and db.txt_sorted is not None and self.audio_precision != "exact")
+        packed = None
+        if (overlap and not sharded and not self.use_wavvq and mfma_text_ and self._hl_plan() and db.Dt % 128 == 0 and
+                self.fused_pack and self.text_lead <= 0):
+            Qn = M * steps
+            q32_ = torch.empty((Qn, NUM_AUDIO_FEAT_FRAMES * db.F), dtype=torch.float32, device=dev)
+            qn2_ = torch.empty((Qn,), dtype=torch.float64, device=dev)
+            nbq = int(_lib.load().qpg_audio_hl_query_bytes(Qn, db.F))
+            qi_ = self.__dict__.get("_hl_qimage")
+            if qi_ is None or qi_.numel() < nbq:
+                qi_ = self._hl_qimage = torch.empty((nbq,), dtype=torch.uint8, device=dev)
+            qn_ = torch.empty((Qn, db.Dt), dtype=torch.float32, device=dev)
+            cols_ = db.txt_sorted.cols_buffer(Qn, self._txt_scratch)
+            tc_ = test_context.contiguous()
+            ti_ = test_interp.contiguous()
+            _lib.call("qpg_clip_pack_hl", dev, ti_, ti_.shape[0], db.T, db.F, q_win, q_t, Qn,
+                      NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32_, qn2_, qi_, qi_.numel(), tc_, tc_.shape[0], tc_.shape[1],
+                      db.Dt, q_win, q_row, Qn, qn_, cols_, cols_.numel())
+            packed = (q32_, qn2_, qn_)
+            # the side stream starts BEHIND the pack
+            gate = self.__dict__["_side_gate"]
+            gate.record(torch.cuda.current_stream(dev))
+            side.wait_event(gate)
+
         def text_pack():
             # gather clip_context[int(i/n*30)] of every step + sklearn normalisation in one launch
             tc = test_context.contiguous()
@@ -809,10 +853,12 @@ class CodeKNN:
             return qn
 
         def text_side(qn=None):
-            if qn is None:
+            if packed is not None:
+                qn = packed[2]
+            elif qn is None:
                 qn = text_pack()
             r = self.sweep_text(qn, want_rank=not sharded, reduce=not sharded, normalised=True,
-                                out=lay.views("txt") if sharded else None)
+                                out=lay.views("txt") if sharded else None, cols_packed=packed is not None)
             T["txt_d"], T["txt_idx"] = r[0], r[1]
             if not sharded:
                 T["txt_rank"] = r[2]
@@ -844,15 +890,16 @@ class CodeKNN:
         if mode in (MODE_AUD_TXT, MODE_AUD):
             fn = self.sweep_audio_wavvq if self.use_wavvq else self.sweep_audio
             self._want_sweep_event, self._sweep_done = after, None
+            kw = {"prepacked": packed} if (packed is not None and not self.use_wavvq) else {}
             r = fn(test_interp, q_win, q_t, want_rank=not sharded, reduce=not sharded,
-                   out=lay.views("aud") if sharded else None)
+                   out=lay.views("aud") if sharded else None, **kw)
             self._want_sweep_event = False
             T["aud_d"], T["aud_idx"] = r[0], r[1]
             if not sharded:
                 T["aud_rank"] = r[2]
         if after:
             with torch.cuda.stream(side):
-                qn_early = text_pack()        # one small block: runs at once, next to the audio sweep
+                qn_early = None if packed is not None else text_pack()    # one small block, next to the audio sweep
             if self._sweep_done is not None:
                 side.wait_event(self._sweep_done)
             with torch.cuda.stream(side):

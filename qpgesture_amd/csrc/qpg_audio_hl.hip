@@ -61,6 +61,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define HL_SUB 3              // frames per super-row
 #define HL_QC 48              // queries per chunk
 #define HL_CT 6               // column tiles per chunk (3 lo + 3 hi)
+#define HL_GQC (16 * HL_CT)   // queries per chunk of the generic GEMM (96)
 #ifndef HL_KS
 #define HL_KS 2               // k-blocks per LDS stage
 #endif
@@ -224,13 +225,11 @@ __global__ __launch_bounds__(768) void hl_pack_queries_kernel(const float* __res
 // ---- fused query pack: gather + squared norms + scale exponent + image, ONE launch in front of the sweep -------------
 // (qpg_audio_pack_queries followed by qpg_audio_hl_pack_queries: two launches and the gap between them, 18 us on the
 // critical path of a clip; the select's re-evaluations still need q32 / qn2, so both are written)
-__global__ __launch_bounds__(768) void hl_pack_queries_fused_kernel(const float* __restrict__ qbase, int M, int T, int F,
-                                                                    const int32_t* __restrict__ q_win,
-                                                                    const int32_t* __restrict__ q_t, int Q, int tap_stride,
-                                                                    float* __restrict__ q32, double* __restrict__ qn2,
-                                                                    _Float16* __restrict__ image,
-                                                                    int32_t* __restrict__ qexp) {
-  const int q = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void hl_pack_query_block(int q, int tid, const float* __restrict__ qbase, int M, int T, int F,
+                                                    const int32_t* __restrict__ q_win, const int32_t* __restrict__ q_t,
+                                                    int Q, int tap_stride, float* __restrict__ q32,
+                                                    double* __restrict__ qn2, _Float16* __restrict__ image,
+                                                    int32_t* __restrict__ qexp) {
   const int D = 2 * HL_SUB * F, KB = HL_SUB * F / 32, K8h = HL_SUB * F / 8, n8 = 2 * K8h;
   __shared__ float redm[12];
   __shared__ double reds[12];
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(768) void hl_pack_queries_fused_kernel(const float*
   }
   __syncthreads();
   if (tid == 0) {
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
+    for (int i = 1; i < 12; ++i) {
       m = fmaxf(m, redm[i]);
       s += reds[i];
     }
@@ -304,6 +303,122 @@ __global__ __launch_bounds__(768) void hl_pack_queries_fused_kernel(const float*
     const int64_t piece = ((((int64_t)chunk * KB + kb) * HL_CT + ct) * 2);
     reinterpret_cast<h8*>(image)[(piece + 0) * 64 + lane] = hh;
     reinterpret_cast<h8*>(image)[(piece + 1) * 64 + lane] = ll;
+  }
+}
+
+
+__global__ __launch_bounds__(768) void hl_pack_queries_fused_kernel(const float* __restrict__ qbase, int M, int T, int F,
+                                                                    const int32_t* __restrict__ q_win,
+                                                                    const int32_t* __restrict__ q_t, int Q, int tap_stride,
+                                                                    float* __restrict__ q32, double* __restrict__ qn2,
+                                                                    _Float16* __restrict__ image,
+                                                                    int32_t* __restrict__ qexp) {
+  hl_pack_query_block(blockIdx.x, threadIdx.x, qbase, M, T, F, q_win, q_t, Q, tap_stride, q32, qn2, image, qexp);
+}
+
+// ---- one launch for a clip's whole query side (round 4): the audio pack above AND the text side's query pack ------------------
+// Blocks [0, n_aud) = hl_pack_query_block; blocks [n_aud, n_aud + text slots) = one text query each: gather
+// clip_context[win][row] (GestureKNN.py:549-551), sklearn's f32 normalisation (bit-exact: the four einsum lane chains of
+// qpg_core.hip's l2_normalize_rows_kernel, run by threads 0..3), the normalised row to qn (the select's exact evaluation
+// reads it) and its split-f16 column image (hl_pack_cols_kernel's).  The text side used to start with two tiny launches
+// of its own; behind a sweep that holds every register of every CU they did not get a wave slot before the sweep was over
+// (the text pack sat 100 us in the queue: profiles/r04_step_timeline_graph*.md), and the whole text chain moved behind it.
+struct ClipPackText {
+  const float* ctx;        // [Mt][R][Dt]
+  const int32_t* q_win;    // [Qt]
+  const int32_t* q_row;    // [Qt]
+  int R, Dt, Qt;
+  float* qn;               // [Qt][Dt]
+  _Float16* image;         // column image (qpg_hl_cols_bytes)
+  int32_t* qexp;
+};
+
+__global__ __launch_bounds__(768) void hl_pack_clip_kernel(const float* __restrict__ qbase, int M, int T, int F,
+                                                           const int32_t* __restrict__ q_win,
+                                                           const int32_t* __restrict__ q_t, int Q, int tap_stride,
+                                                           float* __restrict__ q32, double* __restrict__ qn2,
+                                                           _Float16* __restrict__ image, int32_t* __restrict__ qexp,
+                                                           int n_aud, ClipPackText tx) {
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < n_aud) {
+    hl_pack_query_block(blockIdx.x, tid, qbase, M, T, F, q_win, q_t, Q, tap_stride, q32, qn2, image, qexp);
+    return;
+  }
+  const int qi = (int)blockIdx.x - n_aud;
+  const int D = tx.Dt;
+  extern __shared__ __attribute__((aligned(16))) float rowbuf[];         // [D] the normalised row
+  __shared__ float n_s, red[12];
+  __shared__ int e_s;
+  const bool live = qi < tx.Qt;
+  const float* p = live ? tx.ctx + ((int64_t)tx.q_win[qi] * tx.R + tx.q_row[qi]) * D : tx.ctx;
+  if (tid < 4) {                                       // the norm, in NumPy einsum's order (lane chains l = 0..3)
+    const int l = tid;
+    float a = 0.f;
+    const int nfull = D >> 4;
+    int g = 0;
+    for (; g + 8 <= nfull; g += 8) {
+      float v[32];
+#pragma unroll
+      for (int jx = 0; jx < 32; ++jx) v[jx] = p[(g + (jx >> 2)) * 16 + (jx & 3) * 4 + l];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) {
+#pragma unroll
+        for (int u = 3; u >= 0; --u) a = f_add(f_mul(v[jx * 4 + u], v[jx * 4 + u]), a);
+      }
+    }
+    for (; g < nfull; ++g) {
+#pragma unroll
+      for (int u = 3; u >= 0; --u) {
+        const float v = p[g * 16 + u * 4 + l];
+        a = f_add(f_mul(v, v), a);
+      }
+    }
+    for (int i = nfull * 16; i < D; i += 4) {
+      const float v = (i + l < D) ? p[i + l] : 0.f;
+      a = f_add(f_mul(v, v), a);
+    }
+    const float o1 = __shfl_xor(a, 1, 64);
+    const float pair = f_add(a, o1);
+    const float o2 = __shfl_xor(pair, 2, 64);
+    float n = f_sqrt(f_add(pair, o2));
+    if (n < 10.f * 1.1920928955078125e-07f) n = 1.f;   // sklearn _handle_zeros_in_scale
+    if (l == 0) n_s = n;
+  }
+  __syncthreads();
+  const float n = n_s;
+  float m = 0.f;
+  for (int e = tid; e < D; e += 768) {
+    const float v = live ? f_div(p[e], n) : 0.f;
+    rowbuf[e] = v;
+    if (live) tx.qn[(int64_t)qi * D + e] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < 12; ++i) m = fmaxf(m, red[i]);
+    e_s = hl_exponent(m);
+    if (live) tx.qexp[qi] = e_s;
+  }
+  __syncthreads();
+  const float sc = ldexpf(1.0f, e_s);
+  const int KB = D / 32, K8 = D / 8;
+  const int chunk = qi / (16 * HL_CT), qq = qi % (16 * HL_CT);
+  for (int k8 = tid; k8 < K8; k8 += 768) {
+    const int k = k8 * 8;
+    h8 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 a0, b0;
+      split_hl(rowbuf[k + e] * sc, a0, b0);
+      hh[e] = a0;
+      ll[e] = b0;
+    }
+    const int kb = k / 32, ct = qq / 16, lane = (qq & 15) + 16 * ((k & 31) >> 3);
+    const int64_t piece = ((((int64_t)chunk * KB + kb) * HL_CT + ct) * 2);
+    reinterpret_cast<h8*>(tx.image)[(piece + 0) * 64 + lane] = hh;
+    reinterpret_cast<h8*>(tx.image)[(piece + 1) * 64 + lane] = ll;
   }
 }
 
@@ -923,6 +1038,42 @@ extern "C" int qpg_audio_pack_queries_hl(qpg_ctx* ctx, void* stream, const float
   return QPG_OK;
 }
 
+// The audio pack above and the text side's query pack in ONE launch (hl_pack_clip_kernel): text_ctx [dev] f32 [Mt][R][Dt],
+// tq_win / tq_row [dev] i32 [Qt] (window and context row of every text query), qn_out [dev] f32 [Qt][Dt] (the normalised
+// queries, bit-identical to qpg_text_pack_queries_f32's), cols_image = qpg_hl_cols_bytes(Qt, Dt) bytes (identical to
+// qpg_hl_pack_cols' image of qn_out).  Dt % 128 == 0, Dt <= 8192.
+extern "C" int qpg_clip_pack_hl(qpg_ctx* ctx, void* stream, const float* qbase, int M, int T, int F, const int32_t* q_win,
+                                const int32_t* q_t, int Q, int n_taps, int tap_stride, float* q32, double* qn2, void* image,
+                                int64_t image_bytes, const float* text_ctx, int Mt, int R, int Dt, const int32_t* tq_win,
+                                const int32_t* tq_row, int Qt, float* qn_out, void* cols_image, int64_t cols_bytes) {
+  const char* name = "qpg_clip_pack_hl";
+  QPG_REQUIRE(ctx && qbase && q_win && q_t && q32 && qn2 && image && M > 0 && T > 0 && Q > 0 && tap_stride > 0,
+              "%s: bad argument", name);
+  QPG_REQUIRE(n_taps == 2 * HL_SUB && F > 0 && (F % 32) == 0 && 2 * HL_SUB * F / 8 <= 2 * 768,
+              "%s: needs 6 taps, F %% 32 == 0, F <= 2048", name);
+  QPG_REQUIRE(image_bytes >= qpg_audio_hl_query_bytes(Q, F) && (reinterpret_cast<uintptr_t>(image) % 16) == 0 &&
+                  (reinterpret_cast<uintptr_t>(q32) % 16) == 0 && (reinterpret_cast<uintptr_t>(qbase) % 16) == 0,
+              "%s: image too small or misaligned (qpg_audio_hl_query_bytes)", name);
+  QPG_REQUIRE(text_ctx && tq_win && tq_row && qn_out && cols_image && Mt > 0 && R > 0 && Qt > 0 && Dt > 0 &&
+                  (Dt % 128) == 0 && Dt <= 8192 && cols_bytes >= qpg_hl_cols_bytes(Qt, Dt) &&
+                  (reinterpret_cast<uintptr_t>(cols_image) % 16) == 0,
+              "%s: bad text-side argument (Dt %% 128 == 0, qpg_hl_cols_bytes)", name);
+  const int chunks = (Q + HL_QC - 1) / HL_QC;
+  unsigned char* img = static_cast<unsigned char*>(image);
+  int32_t* qexp = reinterpret_cast<int32_t*>(img + (int64_t)chunks * (HL_SUB * F / 32) * HL_CT * 2 * HL_PIECE);
+  const int tchunks = (Qt + HL_GQC - 1) / HL_GQC;
+  unsigned char* cimg = static_cast<unsigned char*>(cols_image);
+  ClipPackText tx;
+  tx.ctx = text_ctx; tx.q_win = tq_win; tx.q_row = tq_row; tx.R = R; tx.Dt = Dt; tx.Qt = Qt; tx.qn = qn_out;
+  tx.image = reinterpret_cast<_Float16*>(cimg);
+  tx.qexp = reinterpret_cast<int32_t*>(cimg + (int64_t)tchunks * (Dt / 32) * HL_CT * 2 * HL_PIECE);
+  const int n_aud = chunks * HL_QC;
+  hipLaunchKernelGGL(hl_pack_clip_kernel, dim3(n_aud + tchunks * HL_GQC), dim3(768), (size_t)Dt * 4, qpg_stream(stream),
+                     qbase, M, T, F, q_win, q_t, Q, tap_stride, q32, qn2, reinterpret_cast<_Float16*>(img), qexp, n_aud, tx);
+  QPG_LAUNCH_CHECK("hl_pack_clip_kernel");
+  return QPG_OK;
+}
+
 extern "C" int qpg_audio_cosine_hl(qpg_ctx* ctx, void* stream, const void* db_image, int N, int F, int G,
                                    const double* cn2, const void* q_image, const double* qn2, int Q, void* D,
                                    int d_is_f32, int64_t ldD, int32_t* stats) {
@@ -1014,7 +1165,6 @@ __global__ __launch_bounds__(256) void hl_pack_rows_kernel(const float* __restri
   }
 }
 
-#define HL_GQC (16 * HL_CT)   // queries per chunk of the generic GEMM (96)
 __global__ __launch_bounds__(256) void hl_pack_cols_kernel(const float* __restrict__ q, int Q, int D,
                                                            _Float16* __restrict__ image, int32_t* __restrict__ qexp) {
   const int qi = blockIdx.x, tid = threadIdx.x;

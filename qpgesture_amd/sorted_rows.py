@@ -108,8 +108,15 @@ class SortedRows:
         mask[key_order[drop_sorted]] = False
         return mask
 
+    def cols_buffer(self, Q, scratch):
+        """The column-image buffer of `scratch` sized for Q queries (qpg_clip_pack_hl writes it ahead of select)."""
+        nb = int(_lib.load().qpg_hl_cols_bytes(Q, self.d))
+        if scratch.get("cols") is None or scratch["cols"].numel() < nb:
+            scratch["cols"] = torch.empty((nb,), dtype=torch.uint8, device=self.device)
+        return scratch["cols"]
+
     def select(self, qn, absent, stats, dist=None, idx=None, nn=None, rank=None, idx_base=0, q_block=0, block_stride=0,
-               scratch=None):
+               scratch=None, cols_packed=False):
         """qn: f32 [Q][d] sklearn-normalised queries.  Prefilter GEMM + banded exact select; per-code tables (dist f32
         [Q][K], idx i32 [Q][K] original row indices), optionally the nearest neighbours nn i32 [Q] and the ranks of the
         table rows (rank i16 [Q][K]).  An overflowing band list ORs 1 into stats[1] (the caller re-evaluates on the exact
@@ -134,7 +141,8 @@ class SortedRows:
         if dist is None:
             dist = torch.empty((Q, self.K), dtype=torch.float32, device=dev)
             idx = torch.empty((Q, self.K), dtype=torch.int32, device=dev)
-        _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, cols, cols.numel())
+        if not cols_packed:           # (cols_packed: qpg_clip_pack_hl wrote scratch["cols"] for exactly these queries)
+            _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, cols, cols.numel())
         if self.use_masks:
             # tile minima + 16-bit masks of the rows within the band of their tile's minimum: the matrix never exists
             _lib.call("qpg_hl_gemm_tilemin", dev, self.image, self.R, self.d, cols, Q, self.band, tmin, tmask, nt)

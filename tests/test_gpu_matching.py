@@ -270,6 +270,30 @@ def test_clips_in_flight_equal_serial_clips(depth):
     assert np.array_equal(pipe.collect(t)[0], g["knn_pred"])
 
 
+def test_one_launch_clip_pack_equals_separate_packs():
+    """qpg_clip_pack_hl (round 4: the audio query pack AND the text side's gather / sklearn normalisation / column image in
+    one launch) leaves bit-identical buffers and tables to the three separate launches of round 3."""
+    import torch
+    g = load_golden(GOLDENS[1])
+    out = {}
+    for fused in (True, False):
+        A, db, knn, te_i, te_c, M = _build(g["meta"], freq_rank=g["step_freq_score"])
+        knn.fused_pack = fused
+        T = knn.sweep_tables(te_i, te_c, M)
+        torch.cuda.synchronize()
+        Qn = M * knn.n_steps()
+        nb_c = int(__import__("qpgesture_amd")._lib.load().qpg_hl_cols_bytes(Qn, db.Dt)) - 4 * 96     # (image; the exponents follow)
+        nb_q = int(__import__("qpgesture_amd")._lib.load().qpg_audio_hl_query_bytes(Qn, db.F)) - 4 * 48
+        out[fused] = ({k: v.clone() for k, v in T.items() if v is not None}, knn._last_q32.clone(), knn._last_qn2.clone(),
+                      knn._txt_scratch["cols"][:nb_c].clone(), knn._hl_qimage[:nb_q].clone(),
+                      knn._txt_scratch["cols"][nb_c:nb_c + 4 * Qn].clone(), knn._hl_qimage[nb_q:nb_q + 4 * Qn].clone())
+        assert knn._last_audio_hl and knn._last_text_mfma
+    for k in out[True][0]:
+        assert torch.equal(out[True][0][k], out[False][0][k]), k
+    for i, (a, b) in enumerate(zip(out[True][1:], out[False][1:])):
+        assert torch.equal(a, b), i
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_tabulated_walk_equals_sequential_walk(mode):
     """qpg_match_steps' tabulated walk (gate evaluated for every reachable (step, previous code, previous vote) in
