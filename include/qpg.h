@@ -36,7 +36,13 @@ extern "C" {
 typedef struct qpg_ctx qpg_ctx;
 
 int qpg_version(void);
+/* One context per device, created by the host thread that drives that device.
+ * PERFORMANCE NOTE for direct callers: the matcher is a chain of a dozen short dependent launches per clip, and the HIP
+ * runtime hands their arguments to the command processor through device memory only when the environment variable
+ * HIP_FORCE_DEV_KERNARG=1 is set BEFORE the process's first HIP call (the Python package sets it at import; measured
+ * ~5 % of a clip, 0.347 -> 0.330 ms).  qpg_dev_kernarg() reports what this process will get: 1 = set, 0 = not set. */
 int qpg_ctx_create(int device, qpg_ctx** out);
+int qpg_dev_kernarg(void);
 int qpg_ctx_destroy(qpg_ctx* ctx);
 int qpg_last_error(char* buf, size_t n);
 

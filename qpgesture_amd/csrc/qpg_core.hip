@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "qpg_common.h"
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -12,7 +13,13 @@ void qpg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int qpg_version(void) { return 100; }
+extern "C" int qpg_version(void) { return 104; }          // 1.04: round 4's entry points (include/qpg.h)
+
+// Is HIP_FORCE_DEV_KERNARG=1 in this process's environment? (see qpg_ctx_create in include/qpg.h)
+extern "C" int qpg_dev_kernarg(void) {
+  const char* e = getenv("HIP_FORCE_DEV_KERNARG");
+  return (e && e[0] == '1') ? 1 : 0;
+}
 
 extern "C" int qpg_last_error(char* buf, size_t n) {
   if (!buf || n == 0) return QPG_EINVAL;

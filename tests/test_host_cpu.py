@@ -16,7 +16,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert len(names) >= 16 and "qpg_audio_cosine_f64" in names and "qpg_match_steps" in names
     for n in names:
         assert hasattr(lib, n), "include/qpg.h declares %s but libqpg_hip.so does not export it" % n
-    assert lib.qpg_version() >= 100
+    assert lib.qpg_version() >= 104
+    import os
+    assert lib.qpg_dev_kernarg() == (1 if os.environ.get("HIP_FORCE_DEV_KERNARG") == "1" else 0)
 
 
 def test_bindings_cover_the_header():
@@ -29,7 +31,7 @@ def test_bindings_cover_the_header():
                                "qpg_merge_mixed_ws_bytes", "qpg_debug_convt_shape",
                                "qpg_percode_select_exact_ws_bytes", "qpg_audio_hl_supported",
                                "qpg_audio_hl_db_bytes", "qpg_audio_hl_query_bytes", "qpg_hl_rows_bytes",
-                               "qpg_hl_cols_bytes"}
+                               "qpg_hl_cols_bytes", "qpg_dev_kernarg"}
     assert declared == bound
 
 
