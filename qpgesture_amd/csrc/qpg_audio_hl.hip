@@ -1256,6 +1256,195 @@ extern "C" int qpg_hl_pack_cols(qpg_ctx* ctx, void* stream, const float* q, int 
   return QPG_OK;
 }
 
+// ---- the prefilter GEMM on 32-ROW wave tiles (round 4): hl_gemm32_kernel --------------------------------------------------
+// audio_cosine_hl_kernel<1> inherits round 3's sweep organisation (16 rows x 96 columns per wave, f64 block sums).  For the
+// prefilter of the exact-f32 cosine family the band is dominated by sklearn's own rounding (8.6e-5 at D = 512), so the
+// h h' products may stay in the MFMA's f32 accumulator for the whole (short) K: a chain of KB instructions is within
+// (kappa_1 + KB) 2^-24 sum|products| of the exact sum (every instruction: its own block error + one rounding of the running
+// sum), QPG_HL_GEMM32_ERR(D) = (12 + D/32) 2^-24 + 5.2e-7 (cross terms, representation, f32 store: as §4.1) = 2.2e-6 at
+// D = 512 (sorted_rows.gemm32_err) - and without the f64 sums a wave holds TWO row tiles: 32 rows x 96 columns, 36 MFMAs
+// per 12 KB of fragment reads (half the LDS traffic per MFMA).  Block = 8 waves = 256 rows; query stages of 2 k-blocks
+// (24 KB), double-buffered.
+// What made the first versions of this kernel no faster than the 16-row one (experiments/gemm32/README.md): with K of
+// only 12-16 k-blocks a (row block, chunk) item is ~9 us of MFMAs, and the rows' fragments were requested ONE k-block
+// (0.3 us) ahead - every k-block waited for L2 / the Infinity Cache.  Now: persistent blocks over contiguous ranges of
+// items, and a ring of four k-blocks whose slots are refilled, as soon as a k-block is done, with the same k-block of the
+// NEXT stage (or of the next item's first stage): three k-blocks = 108 MFMAs per wave of lead.
+#define G32_KS 2           // k-blocks per LDS stage of the query image (24 KB)
+#define G32_RING 4         // k-blocks of row fragments in registers: two stages
+#ifndef G32_PD
+#define G32_PD 2           // steps between a column tile's fragment read and its use
+#endif
+template <int CT>
+__global__ __launch_bounds__(512, 2) void hl_gemm32_kernel(HlArgs a, int n_items) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x G32_KS x 6 x 2 x 1 KB = 48 KB
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // Work items (row block rb of 256 rows, query chunk c), id = rb * chunks + c.  XCD-AWARE order: workgroup b runs on XCD
+  // b % 8 (observed dispatch order), XCD x owns the row blocks rb % 8 == x, and the k-th item of its l-th block is entry
+  // k * (blocks per XCD) + l of the XCD's list (row block major, chunk minor) - at any time the CUs of an XCD work on
+  // ~3 row blocks x all chunks, so a row block's 256 KB of fragments are fetched from HBM once and hit that XCD's L2 for
+  // the other chunks.  (Contiguous item ranges per block - every CU on its own row block - made the 32 panels of an XCD
+  // twice its L2: 2.1 GB per cfg-3 step came out of the Infinity Cache and the GEMM sat at 0.40-0.44 ms.)
+  const int nb = (int)gridDim.x, nx = (nb % 8 == 0) ? 8 : 1;
+  const int xcd = (int)blockIdx.x % nx, lx = (int)blockIdx.x / nx, lpx = nb / nx;
+  const int n_rb = n_items / a.chunks;
+  const int nit = ((n_rb - xcd + nx - 1) / nx) * a.chunks;             // items of this XCD
+  auto vid = [&](int k) {
+    const int i = k * lpx + lx;
+    return i < nit ? ((i / a.chunks) * nx + xcd) * a.chunks + i % a.chunks : -1;
+  };
+  const int it0 = vid(0);
+  if (it0 < 0) return;
+  const int KB = a.KB, n_stage = KB / G32_KS;                          // (KB % 4 == 0: an even number of stages)
+  const int cg = lane & 15, rg = lane >> 4;
+  const int e_c1 = a.meta[0];
+  constexpr int stage_units = G32_KS * HL_CT * 2 * 64;                 // h8 units per stage
+  constexpr int QLD = stage_units / 512;
+  h8 qreg[QLD];
+  auto load_q = [&](int item, int s) {
+    const h8* qsrc = reinterpret_cast<const h8*>(a.qi) + (int64_t)(item % a.chunks) * KB * HL_CT * 2 * 64;
+#pragma unroll
+    for (int u = 0; u < QLD; ++u) qreg[u] = qsrc[(int64_t)s * stage_units + u * 512 + tid];
+  };
+  auto store_q = [&](int buf) {
+    h8* dst = reinterpret_cast<h8*>(lds) + buf * stage_units;
+#pragma unroll
+    for (int u = 0; u < QLD; ++u) dst[u * 512 + tid] = qreg[u];
+  };
+  auto lds_barrier = [&]() {                 // LDS-only: the rows' fragment loads stay in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // rows of this wave in item `item`: 32-row group j; fragments [tile][kb][plane][64 lanes]; groups past N: the zero page
+  const h8* dbp;
+  int64_t t_step;
+  int kb_step, pl_step, j;
+  bool ok;
+  auto set_rows = [&](int item) {
+    j = (item / a.chunks) * 8 + w;
+    ok = j < a.N;
+    dbp = ok ? reinterpret_cast<const h8*>(a.db) + (int64_t)j * 2 * KB * 2 * 64 + lane : reinterpret_cast<const h8*>(a.zeros);
+    t_step = ok ? (int64_t)KB * 2 * 64 : 0;
+    kb_step = ok ? 128 : 0;
+    pl_step = ok ? 64 : 0;
+  };
+  auto load_a = [&](int kb, h8 (&d)[2][2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) d[t][pl] = dbp[t * t_step + (int64_t)kb * kb_step + pl * pl_step];
+  };
+  f32x4 hh[2][CT], xx[2][CT];
+  h8 A[G32_RING][2][2];                      // [ring slot][row tile][plane]
+  h8 Bq[G32_PD + 1][2];                      // ring: a column tile's fragments are read G32_PD steps ahead
+  auto ld_b = [&](int buf, int k2, int c, h8 (&d)[2]) {
+    const h8* qb = reinterpret_cast<const h8*>(lds) + buf * stage_units + lane;
+    d[0] = qb[((k2 * HL_CT + c) * 2 + 0) * 64];
+    d[1] = qb[((k2 * HL_CT + c) * 2 + 1) * 64];
+  };
+  set_rows(it0);
+  load_q(it0, 0);
+#pragma unroll
+  for (int i = 0; i < G32_RING; ++i) load_a(i, A[i]);
+  store_q(0);
+  __syncthreads();
+  constexpr int NS = G32_KS * CT;            // steps of a stage: (k-block, column tile); 6 MFMAs each
+  static_assert((2 * NS) % (G32_PD + 1) == 0, "the fragment ring index must be static over a two-stage trip");
+#pragma unroll
+  for (int i = 0; i < G32_PD; ++i) ld_b(0, i / CT, i % CT, Bq[i]);
+  for (int kk = 0;; ++kk) {
+    const int item = vid(kk);
+    if (item < 0) break;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        hh[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        xx[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    const int j_cur = j;
+    const bool ok_cur = ok;
+    const int nitem = vid(kk + 1) >= 0 ? vid(kk + 1) : item;          // (behind the last item: harmless re-reads)
+    for (int s2 = 0; s2 < n_stage; s2 += 2) {                          // two stages per trip: ring / buffer indices static
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const int s = s2 + ss;
+        const bool last_s = s + 1 == n_stage;
+        load_q(last_s ? nitem : item, last_s ? 0 : s + 1);            // in flight underneath this stage's MFMAs
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          const int k2 = st / CT, c = st % CT;
+          h8 (&Ac)[2][2] = A[ss * G32_KS + k2];
+          h8 (&Bc)[2] = Bq[(ss * NS + st) % (G32_PD + 1)];
+          h8 (&Bn)[2] = Bq[(ss * NS + st + G32_PD) % (G32_PD + 1)];
+          if (st == NS - G32_PD) {
+            // the next stage's fragments go to the other buffer (last read one stage ago, whose barrier everybody
+            // passed), one LDS-only barrier; from here on the reads go to the next stage's buffer
+            store_q((ss + 1) & 1);
+            lds_barrier();
+          }
+          if (st >= NS - G32_PD) ld_b((ss + 1) & 1, (st + G32_PD - NS) / CT, (st + G32_PD - NS) % CT, Bn);
+          else ld_b(ss, (st + G32_PD) / CT, (st + G32_PD) % CT, Bn);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            hh[t][c] = mfma_h(Ac[t][0], Bc[0], hh[t][c]);
+            xx[t][c] = mfma_h(Ac[t][0], Bc[1], xx[t][c]);
+            xx[t][c] = mfma_h(Ac[t][1], Bc[0], xx[t][c]);
+          }
+          if (c == CT - 1) {                 // this k-block is done: its slot takes the k-block FOUR further on - of this
+            const int nk = s * G32_KS + k2 + G32_RING;          // item, or (behind its last k-block) of the next item
+            if (nk < KB) {
+              load_a(nk, Ac);
+            } else {
+              if (nk == KB) set_rows(nitem);
+              load_a(nk - KB, Ac);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {       // issue order: an MFMA, a fragment read underneath it
+            HL_SGB(0x008, 1);
+            if (i < 2) HL_SGB(0x100, 1);
+          }
+        }
+      }
+    }
+    // epilogue of the item: d = 1 - (hh + 2^-11 xx) 2^-(e_c + e_q); lane (cg, rg) holds rows 4 rg .. 4 rg + 3 of column cg
+    if (!ok_cur) continue;
+    const int chunk = item % a.chunks;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const int q = chunk * (16 * HL_CT) + c * 16 + cg;
+      if (q >= a.Q) continue;
+      const int e_q1 = a.qexp[q];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o[r] = (float)(1.0 - ldexp((double)hh[t][c][r] + (double)xx[t][c][r] * (1.0 / 2048.0), -(e_c1 + e_q1)));
+        if (a.D)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (int64_t)q * a.ldD + (int64_t)j_cur * 32 + 16 * t + 4 * rg) = o;
+        if (a.tmin) {
+          float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
+          m = fminf(m, __shfl_xor(m, 16, 64));
+          m = fminf(m, __shfl_xor(m, 32, 64));
+          if (rg == 0) a.tmin[(int64_t)q * a.ldT + (int64_t)j_cur * 2 + t] = m;
+          if (a.tmask) {
+            const float lim = m + a.band;
+            unsigned int bits = ((o[0] <= lim) ? 1u : 0u) | ((o[1] <= lim) ? 2u : 0u) | ((o[2] <= lim) ? 4u : 0u) |
+                                ((o[3] <= lim) ? 8u : 0u);
+            bits <<= 4 * rg;
+            bits |= (unsigned int)__shfl_xor((int)bits, 16, 64);
+            bits |= (unsigned int)__shfl_xor((int)bits, 32, 64);
+            if (rg == 0) a.tmask[(int64_t)q * a.ldT + (int64_t)j_cur * 2 + t] = (uint16_t)bits;
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // surplus prefetches must not outlive their registers
+}
+
 static int hl_gemm_impl(const char* name, qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,
                         const void* cols_image, int Q, float* Dm, int64_t ldD, float* tile_min, int64_t ldT,
                         uint16_t* tile_mask, float band) {
@@ -1275,6 +1464,32 @@ static int hl_gemm_impl(const char* name, qpg_ctx* ctx, void* stream, const void
   a.qexp = reinterpret_cast<const int32_t*>(ci + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
   a.cn2 = nullptr; a.qn2 = nullptr; a.D = Dm; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = nullptr;
   a.N = (int)(R / 32); a.j0 = 0; a.chunks = chunks; a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1; a.tmin = tile_min; a.ldT = ldT; a.tmask = tile_mask; a.band = band;
+  static int use32 = -1;                       // QPG_GEMM32=0: round 3's 16-row organisation (measurements, tests)
+  if (use32 < 0) {
+    const char* e = getenv("QPG_GEMM32");
+    use32 = (e && e[0] == '0') ? 0 : 1;
+  }
+  // (a clip's 48 text queries stay on the 16-row kernel: it runs UNDER the audio sweep, where the slimmer kernel gets more
+  // of the slots the sweep leaves - measured inside the step: 0.273-0.283 ms against 0.281-0.282 with this kernel)
+  if (use32 && (KB % G32_RING) == 0 && Q > 48) {
+    const size_t lds32 = 2 * (size_t)G32_KS * HL_CT * 2 * HL_PIECE;   // 48 KB
+    static bool raised32 = false;
+    if (!raised32) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(hl_gemm32_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds32) != hipSuccess) {
+        qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
+        return QPG_EHIP;
+      }
+      raised32 = true;
+    }
+    const int64_t g8 = (a.N + 7) / 8;                                 // row blocks of 8 x 32 rows
+    QPG_REQUIRE(g8 * chunks < 0x7fffffffll, "%s: too many work items", name);
+    const int n_items = (int)(g8 * chunks);
+    const int n_blocks = n_items < ctx->n_cu ? n_items : ctx->n_cu;   // one resident block per CU (96 KB of LDS)
+    hipLaunchKernelGGL(hl_gemm32_kernel<6>, dim3(n_blocks), dim3(512), lds32, qpg_stream(stream), a, n_items);
+    QPG_LAUNCH_CHECK("hl_gemm32_kernel");
+    return QPG_OK;
+  }
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
   const int64_t rgroups = (a.N + HL_WPB - 1) / HL_WPB;
   QPG_REQUIRE(((rgroups + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);

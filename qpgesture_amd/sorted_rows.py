@@ -10,7 +10,16 @@ import torch
 from . import _lib
 
 U32 = 2.0 ** -24
-HL_GEMM_ERR = 1.3e-6          # QPG_AUDIO_HL_ERR: the split-f16 GEMM on unit-norm operands
+HL_GEMM_ERR = 1.3e-6          # QPG_AUDIO_HL_ERR: the split-f16 GEMM on unit-norm operands, f64 block sums (round 3's kernel)
+
+
+def gemm32_err(d):
+    """A-priori bound of the round-4 prefilter GEMM (hl_gemm32_kernel: the h h' products stay in the MFMA's f32
+    accumulator over the whole K = d): every one of the d/32 chained instructions contributes its own block error
+    (kappa_1 <= 12 in units of 2^-24 sum|products|: measured 8.3-9.0, checked at load time by selfcheck.py) and one
+    rounding of the running sum, so the chain is within (12 + d/32) 2^-24 of the exact sum (|sum| <= 1 for unit vectors);
+    + cross-term chains 1.0e-7, split representation 3.0e-7, f32 result 1.2e-7."""
+    return (12 + d / 32) * U32 + 5.2e-7
 
 
 def prefilter_band(d):
@@ -20,7 +29,7 @@ def prefilter_band(d):
     E_sk: sklearn's own rounding against the real-number distance (normalisation errors through the difference,
     Cauchy-Schwarz with |delta| <= 2, then the chains of d/4 squares)."""
     eps1 = ((d / 4 + 2) / 2 + 2) * U32
-    e_pre = HL_GEMM_ERR + 2 * eps1
+    e_pre = max(HL_GEMM_ERR, gemm32_err(d)) + 2 * eps1
     e_sk = 0.5 * (8 * eps1 + 4 * (d / 4 + 3) * U32)
     return 2.1 * (e_pre + e_sk)
 
