@@ -771,6 +771,12 @@ __device__ __forceinline__ double fast_rsqrt_f64(double x) {
 #ifndef H2_PROBE
 #define H2_PROBE 0
 #endif
+#ifndef H2_ORDER
+#define H2_ORDER 0         // 0: the two chains of a step interleaved (product); 1: one after the other
+#endif
+#ifndef H2_SGB
+#define H2_SGB 1           // issue-order pinning of a step (1: product)
+#endif
 __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x 2 x 6 x 2 x 1 KB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -864,6 +870,7 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         // instructions last - the chain then behaves like round 3's chain of two (measured: every instruction that
         // re-rounds a FULL-SIZE running sum costs ~1.2-1.5 units of 2^-24 sum|products|, so h h' first would mean
         // kappa_6 = 14.4 against 9.9 this way; selfcheck.py measures this order)
+#if H2_ORDER == 0
         f32x4 d0 = mfma_h(A0[0], Bc[0][1], (H2_PROBE & 2) ? dp[0] : zero4);     // (probe 2: one endless chain, no flush)
         f32x4 d1 = mfma_h(A0[2], Bc[0][1], (H2_PROBE & 2) ? dp[1] : zero4);
         d0 = mfma_h(A0[1], Bc[0][0], d0);
@@ -876,6 +883,21 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         d1 = mfma_h(A0[2], Bc[0][0], d1);
         d0 = mfma_h(A1[0], Bc[1][0], d0);
         d1 = mfma_h(A1[2], Bc[1][0], d1);
+#else
+        // (experiment: the two chains one after the other - every MFMA directly behind the one it depends on)
+        f32x4 d0 = mfma_h(A0[0], Bc[0][1], zero4);
+        d0 = mfma_h(A0[1], Bc[0][0], d0);
+        d0 = mfma_h(A1[0], Bc[1][1], d0);
+        d0 = mfma_h(A1[1], Bc[1][0], d0);
+        d0 = mfma_h(A0[0], Bc[0][0], d0);
+        d0 = mfma_h(A1[0], Bc[1][0], d0);
+        f32x4 d1 = mfma_h(A0[2], Bc[0][1], zero4);
+        d1 = mfma_h(A0[3], Bc[0][0], d1);
+        d1 = mfma_h(A1[2], Bc[1][1], d1);
+        d1 = mfma_h(A1[3], Bc[1][0], d1);
+        d1 = mfma_h(A0[2], Bc[0][0], d1);
+        d1 = mfma_h(A1[2], Bc[1][0], d1);
+#endif
         // f64 running sums: the PREVIOUS step's chains (zeros in front of the first step)
         if (!(H2_PROBE & 2)) {
           const int pc = (c + HL_CT - 1) % HL_CT;
@@ -895,12 +917,43 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
           store_q(ss);
           load_q(s + 3);
         }
+#if H2_SGB == 1
 #pragma unroll
         for (int i = 0; i < 12; ++i) {         // issue order: an MFMA, then a fragment read / a share of the flush under it
           HL_SGB(0x008, 1);
           if (i < 4) HL_SGB(0x100, 1);
           HL_SGB(0x002, 2);
         }
+#elif H2_SGB == 2                              // (experiment: fillers only between the chains)
+        HL_SGB(0x008, 6);
+        HL_SGB(0x100, 2);
+        HL_SGB(0x002, 8);
+        HL_SGB(0x008, 6);
+        HL_SGB(0x100, 2);
+        HL_SGB(0x002, 8);
+#elif H2_SGB == 5                              // (experiment: one VALU per gap, the rest behind the step)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          HL_SGB(0x008, 1);
+          if (i < 4) HL_SGB(0x100, 1);
+          HL_SGB(0x002, 1);
+        }
+        HL_SGB(0x002, 4);
+#elif H2_SGB == 6                              // (experiment: reads first, two MFMAs per group)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          HL_SGB(0x008, 2);
+          if (i < 2) HL_SGB(0x100, 2);
+          HL_SGB(0x002, 3);
+        }
+#elif H2_SGB == 3                              // (experiment: one filler per MFMA gap)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          HL_SGB(0x008, 1);
+          if (i < 4) HL_SGB(0x100, 1);
+          else HL_SGB(0x002, 2);
+        }
+#endif
       }
     }
   }
