@@ -179,9 +179,19 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
                        "n_db": N_DB, "dim": DIM, "queries": N_Q, "parallelism": "db rows / %d" % world},
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": hbm_peak_gbs,
                          "unit": "GB/s", "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / hbm_peak_gbs, 4),
-                         "traffic": CFG3_TRAFFIC_BYTES if world == 1 and not f16 and not mfma else None,
-                         "kernel": ("audio_cosine_hl_kernel<1> (prefilter GEMM) + percode_select_sorted_kernel (+ query "
-                                    "normalise / pack)" if mfma else "text_cosine_gmin_f32_kernel (+ fill, merge)"),
+                         "traffic": (_pmc_step_traffic() if mfma else CFG3_TRAFFIC_BYTES) if world == 1 and not f16 else None,
+                         "traffic_source": "profiles/pmc_traffic.json [cfg3_step]: FETCH_SIZE x 2 + WRITE_SIZE summed over the "
+                                           "step's kernels (GEMM 0.40 GB, select's exact-row gathers 0.95 GB), rocprofv3 "
+                                           "--pmc passes (tools/pmc_cfg3.sh); not re-measured per run" if mfma else None,
+                         "kernel": ("hl_gemm32_kernel (prefilter GEMM, 32-row wave tiles: tile minima + row masks, no matrix) "
+                                    "+ percode_select_sorted_kernel (+ query normalise / pack)" if mfma
+                                    else "text_cosine_gmin_f32_kernel (+ fill, merge)"),
+                         # the matrix-core view of the same step: three f16 MFMAs per 16 x 16 x 32 block of the padded problem
+                         "mfma": ({"issued_tflops_f16": round(3 * 2.0 * index.R * ((N_Q + 95) // 96 * 96) * DIM / (k_ms * 1e-3) / 1e12, 1),
+                                   "peak": 2500.0,
+                                   "frac": round(3 * 2.0 * index.R * ((N_Q + 95) // 96 * 96) * DIM / (k_ms * 1e-3) / 1e12 / 2500.0, 4),
+                                   "note": "whole step (GEMM + select) against the dense f16 matrix peak; the GEMM alone "
+                                           "runs at ~0.40 of it (profiles/r04_cfg3_*.md)"} if mfma else None),
                          "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes": int(alg_bytes),
                          "note": ("the tables are sklearn's separately rounded f32 arithmetic (bit-exact indices are the bar); "
@@ -200,3 +210,14 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
 # profiles/r02_cfg3_pmc.md.  ~0.2 GB of it is the candidate array (once per XCD-local group of query blocks); the rest
 # is the 8-byte look-before-atomicMin reads of the [Q][K] table, which must bypass the per-XCD (non-coherent) L2s.
 CFG3_TRAFFIC_BYTES = 6_440_000_000
+
+
+def _pmc_step_traffic():
+    """HBM-side bytes of one cfg-3 step on the prefilter path, from the committed PMC summary (profiles/pmc_traffic.json)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    try:
+        return int(json.load(open(path))["cfg3_step|100000x512 Q=1000"]["hbm_bytes_per_step"])
+    except (OSError, KeyError, ValueError):
+        return None
