@@ -360,11 +360,11 @@ def main():
         torch.cuda.synchronize(dev)
 
     pipe = None
-    can_pipe = world == 1 and CL == 1 and enc is None and not a.no_overlap and not force_sharded
+    can_pipe = (world == 1 or strong) and CL == 1 and enc is None and not a.no_overlap and not force_sharded
     if a.clips_in_flight > 1:
         # throughput mode: the SAME per-clip launches, issued on `clips_in_flight` lanes; a step still ends with its
         # clip's indices on the host (collected one lane later)
-        assert can_pipe, "--clips-in-flight: single GPU, one clip per step, no encode leg"
+        assert can_pipe, "--clips-in-flight: one GPU (or --scaling strong: every rank matches every clip), one clip per step"
         from qpgesture_amd.code_knn import ClipPipeline
         pipe = ClipPipeline(db, depth=a.clips_in_flight, rng=np.random.RandomState(123456))
         for ln in pipe.lanes:

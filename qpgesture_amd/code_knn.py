@@ -1326,11 +1326,12 @@ class ClipPipeline:
     the results are the same arrays; only the host's wait moves from the end of a clip to `collect`.
     Measured (bench.py `pipelined`, 24 s clip vs 2048 windows, end of round 3): 0.33-0.37 ms per clip one at a time,
     0.25-0.30 with three lanes (round 2: 0.542 / 0.459).
-    Single-GPU databases only (the sharded path's collectives stay on one stream)."""
+    Row-sharded databases (round 4): every rank submits the SAME clips in the same order; a lane's collectives (the
+    all-gather form: tables + responses) are issued in that order on every rank, torch.distributed serialises them on its
+    communicator stream, and every rank walks every clip (replicated walk, as CodeKNN.match_clip on a sharded DB).  A flagged
+    clip is re-matched collectively: the trouble word every rank reads is the same."""
 
     def __init__(self, db, depth=2, rng=None, **knn_flags):
-        if db.world != 1:
-            raise NotImplementedError("clips in flight: single-GPU databases only")
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.db = db

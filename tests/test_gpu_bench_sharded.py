@@ -111,6 +111,20 @@ def test_bench_four_and_eight_ranks_on_one_gpu(world, scaling):
     assert out["config"]["collectives_per_step"] == (2 if scaling == "strong" else 4)
 
 
+def test_clips_in_flight_on_a_row_sharded_db():
+    """ClipPipeline over a row-sharded DB (round 4): two ranks, two lanes, the all-gather form of the exchange on every
+    lane's stream; the codes equal the unsharded match (--check)."""
+    env = dict(os.environ, QPG_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "6", "--warmup", "2", "--n-db", "264", "--windows", "2", "--check", "--no-cpu-baseline",
+           "--no-vqvae", "--no-prewarm", "--scaling", "strong", "--sharded-mixed-min-gflop", "0", "--clips-in-flight", "2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["check"] is True and out["config"]["clips_in_flight"] == 2 and out["rematched_steps"] == 0
+
+
 def test_bench_replicated_mode_two_ranks():
     """--scaling replicated (shard the QUERIES, not the database): every rank holds the whole DB and matches
     its own clip, no collective in the step; the codes equal the single-rank match (--check)."""
