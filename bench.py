@@ -329,6 +329,9 @@ def main():
     # phase block are data in pinned host memory, the inputs are the resident tensors) and replayed with one hipGraphLaunch
     # per clip; the integer results land in pinned host memory and the host watches the status word.  A step still ends
     # with the clip's codes on the host, a flagged clip is still re-matched (eagerly) before anything is returned.
+    # (Row shards stay eager: capturing their collectives works - tools/step_loop.py with QPG_FORCE_SHARDED=1
+    # QPG_EXPERIMENTAL_SHARDED_GRAPH=1: 0.36 ms per clip against 0.46 - but replays followed by eager collectives on the
+    # same communicator hung this ROCm / torch build, and this script needs both.)
     graph_mode = (a.step_mode == "graph" or (a.step_mode == "auto" and not a.no_graph)) and world == 1 and CL == 1 and \
         enc is None and not force_sharded and a.clips_in_flight == 1
     if a.step_mode == "graph" and not graph_mode:
@@ -342,7 +345,10 @@ def main():
         # ms per clip / GPU span 319 us, audio first 0.3048 / 307 - no order wins, the default keeps the eager order)
         if os.environ.get("QPG_BENCH_GRAPH_TEXT_FIRST", "0") == "1":
             knn_g.text_after_sweep, knn_g.audio_first = False, False
-        cg = knn_g.capture_clip_graph(M, audio=te_interp, context=te_ctx)
+        knn_g.force_sharded, knn_g.sharded_mixed_min_gflop, knn_g.mixed_requests = (
+            knn.force_sharded, knn.sharded_mixed_min_gflop, knn.mixed_requests)
+        cg = knn_g.capture_clip_graph(M, n_sweep_windows=M * n_sweep_clips, audio=te_interp, context=te_ctx,
+                                      owner_blocks=sharded_run and not strong)
 
     def step_graph():
         arr = cg.run_ints(seed_code, seed_phase)
@@ -674,7 +680,8 @@ def main():
         sc2 = (seed_code + 101) % 512
         sp2 = np.roll(seed_phase, 3, axis=0)
         g2 = cg.run_ints(sc2, sp2)
-        e2 = knn.walk(knn.sweep_tables(te_interp, te_ctx, M), M, seed_code=sc2, seed_phase=sp2, sync="ints")
+        e2 = knn.walk(knn.sweep_tables(te_interp, te_ctx, M * n_sweep_clips, owner_blocks=sharded_run and not strong), M,
+                      seed_code=sc2, seed_phase=sp2, sync="ints")
         out["graph_replay"] = {"ms_per_step": out["ms_per_step"], "steps": a.steps, "captures": cg.captures,
                                "is_the_timed_region": True,
                                "text_side_captured_first": bool(not knn_g.audio_first and knn_g.audio_first is not None),

@@ -1148,13 +1148,13 @@ class CodeKNN:
                              "(the reference raises IndexError at GestureKNN.py:631-632)")
 
     def capture_clip_graph(self, n_windows, mode=MODE_AUD_TXT, n_sweep_windows=None, window_offset=0, audio=None,
-                           context=None):
+                           context=None, owner_blocks=False):
         """Capture the whole per-clip launch sequence (pack, both sweeps, per-code argmin passes, ranks,
         rank-fusion tables, walk) into one HIP graph for a fixed clip shape.  Returns a ClipGraph whose
         run(test_audio, test_context, seed_code, seed_phase) replays it; results are device tensors.
         n_sweep_windows > n_windows sweeps more windows than it walks (several clips per sweep: bench.py N>1).
         audio / context: bind the graph to the caller's resident input tensors instead of static copies."""
-        return ClipGraph(self, n_windows, mode, n_sweep_windows or n_windows, window_offset, audio, context)
+        return ClipGraph(self, n_windows, mode, n_sweep_windows or n_windows, window_offset, audio, context, owner_blocks)
 
     def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
                    seed_phase=None, return_tables=False):
@@ -1225,10 +1225,23 @@ class ClipGraph:
     votes | status) land in pinned host memory behind a system-scope fence, so a replay is: write the seed, write the
     sentinel, hipGraphLaunch, watch the status word.  One capture serves every clip of that shape."""
 
-    def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset, audio=None, context=None):
+    def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset, audio=None, context=None, owner_blocks=False):
         db, dev = knn.db, knn.db.device
+        self.owner_blocks = owner_blocks
         if db.world != 1 or knn.force_sharded:
-            raise NotImplementedError("graph capture of the sharded path (collectives inside) is not supported")
+            # a row-sharded clip: its collectives are captured with the kernels (RCCL supports capture through
+            # torch.distributed's nccl backend; gloo is staged through the host and can not be)
+            # EXPERIMENTAL (QPG_EXPERIMENTAL_SHARDED_GRAPH=1): with one rank over RCCL a process that only replays runs
+            # (tools/step_loop.py: 0.36 ms per clip against 0.46 eager), but a process that replays AND issues eager
+            # collectives on the same communicator afterwards (bench.py's eager leg, a flagged clip's re-match) hung on
+            # this ROCm / torch build - so a sharded matcher does not hand out graphs unless asked to.
+            import os as _os
+            import torch.distributed as dist_
+            if _os.environ.get("QPG_EXPERIMENTAL_SHARDED_GRAPH", "") != "1":
+                raise NotImplementedError("graph capture of the sharded path (collectives inside) is experimental: "
+                                          "QPG_EXPERIMENTAL_SHARDED_GRAPH=1")
+            if not (dist_.is_available() and dist_.is_initialized() and dist_.get_backend() == "nccl"):
+                raise NotImplementedError("graph capture of the sharded path needs the nccl (RCCL) backend")
         if knn.host_ranks:
             raise NotImplementedError("graph capture needs the device-side ranks (tie_rule 'stable')")
         self.knn, self.M, self.mode = knn, n_windows, mode
@@ -1259,7 +1272,7 @@ class ClipGraph:
         ptrs = (self._seed_pin.data_ptr() + 4 * 128, self._seed_pin.data_ptr())
 
         def body():
-            T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode)
+            T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode, owner_blocks=self.owner_blocks)
             return knn.walk(T, self.M, self._off, self.mode, sync=False, seed_ptrs=ptrs, out_pin=self._pin)
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))

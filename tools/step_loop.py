@@ -34,7 +34,7 @@ te_i = torch.randn((M, 180, 1024), device=dev)
 te_c = torch.randn((M, 30, 384), device=dev)
 sc, sp = knn.init_code_phase()
 spd = torch.from_numpy(sp).to(dev)
-g = knn.capture_clip_graph(M, audio=te_i, context=te_c) if graph else None
+g = knn.capture_clip_graph(M, audio=te_i, context=te_c, owner_blocks=knn.force_sharded) if graph else None
 
 
 def step():
