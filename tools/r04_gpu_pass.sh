@@ -4,7 +4,9 @@
 # row-shard path on one rank over RCCL.
 set -u
 O=gpurun_out/r04; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_20.json 2> $O/bench_20.err; echo "bench20 rc=$?" > $O/rc.txt
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" > $O/rc.txt
+timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/rc.txt
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_20.json 2> $O/bench_20.err; echo "bench20 rc=$?" >> $O/rc.txt
 timeout 900 python bench.py --no-cpu-baseline --no-e2e > $O/bench_200.json 2> $O/bench_200.err; echo "bench200 rc=$?" >> $O/rc.txt
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o bench -- python $R/bench.py --steps 20 --warmup 5 > $R/$O/bench_profiled.json 2> $R/$O/prof.err ); echo "prof rc=$?" >> $O/rc.txt
 python tools/make_profile_summary.py $O/prof $O/bench_n1 "python bench.py --steps 20 --warmup 5 (N=1) under rocprofv3 --kernel-trace --stats" > /dev/null 2>&1
@@ -28,7 +30,9 @@ timeout 900 python bench.py --data speechlike --no-cpu-baseline --no-vqvae --no-
 for sc in weak strong; do
   QPG_BENCH_FORCE_SHARDED=1 timeout 600 python bench.py --steps 50 --warmup 5 --scaling $sc --n-db 2048 --no-cpu-baseline --no-vqvae --no-cold --check > $O/bench_forced_sharded_$sc.json 2> $O/bench_forced_sharded_$sc.err; echo "forced $sc rc=$?" >> $O/rc.txt
 done
+QPG_FORCE_SHARDED=1 QPG_EXPERIMENTAL_SHARDED_GRAPH=1 timeout 200 python tools/step_loop.py 200 graph > $O/forced_sharded_graph_loop.txt 2>&1
+QPG_FORCE_SHARDED=1 timeout 200 python tools/step_loop.py 200 > $O/forced_sharded_eager_loop.txt 2>&1
 ( cd /tmp && QPG_FORCE_SHARDED=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$O/tls -- python $R/tools/step_loop.py 30 > $R/$O/tls.log 2>&1 )
 python tools/step_timeline.py $O/tls 30 > $O/step_timeline_forced_sharded.md 2>&1
 find $O -name "*.csv" -size +4M -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
-cat $O/rc.txt; head -c 400 $O/bench_20.json; echo; tail -18 $O/step_timeline_graph.md; cat $O/pmc_traffic.txt; cat $O/pmc_issue_mix.txt
+tail -2 $O/pytest.log; grep "ms/step" $O/forced_sharded_*_loop.txt; cat $O/rc.txt; head -c 400 $O/bench_20.json; echo; tail -18 $O/step_timeline_graph.md; cat $O/pmc_traffic.txt; cat $O/pmc_issue_mix.txt
