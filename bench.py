@@ -103,8 +103,9 @@ def main():
     ap.add_argument("--step-mode", choices=["auto", "graph", "eager"], default="auto",
                     help="how the timed steps are issued: graph = ONE hipGraphLaunch per clip (code_knn.ClipGraph: the same "
                          "kernels, seed and results through pinned memory; one capture serves every clip), eager = one "
-                         "launch per kernel from Python; auto (default) = graph for the one-GPU one-clip shape, eager "
-                         "otherwise.  In graph mode the eager figure and the HIP-event timing of the sweep kernel come from "
+                         "launch per kernel from Python; auto (default) = graph for one clip per step and rank (row "
+                         "shards: a PROGRAM of hipGraph segments with the collectives issued eagerly between them, "
+                         "step_mode graph-segments), eager otherwise.  In graph mode the eager figure and the HIP-event timing of the sweep kernel come from "
                          "an eager leg of the same K steps right after the timed region (`eager` object)")
     ap.add_argument("--no-graph", action="store_true", help="same as --step-mode eager")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (`e2e_cli` object)")
@@ -329,13 +330,16 @@ def main():
     # phase block are data in pinned host memory, the inputs are the resident tensors) and replayed with one hipGraphLaunch
     # per clip; the integer results land in pinned host memory and the host watches the status word.  A step still ends
     # with the clip's codes on the host, a flagged clip is still re-matched (eagerly) before anything is returned.
-    # (Row shards stay eager: capturing their collectives works - tools/step_loop.py with QPG_FORCE_SHARDED=1
-    # QPG_EXPERIMENTAL_SHARDED_GRAPH=1: 0.36 ms per clip against 0.46 - but replays followed by eager collectives on the
-    # same communicator hung this ROCm / torch build, and this script needs both.)
-    graph_mode = (a.step_mode == "graph" or (a.step_mode == "auto" and not a.no_graph)) and world == 1 and CL == 1 and \
-        enc is None and not force_sharded and a.clips_in_flight == 1
+    # Row shards (N > 1, or forced on one rank): the clip is recorded in SEGMENTS - one hipGraph per run of kernels between
+    # two collectives, the collectives issued eagerly between the graph launches (parallel.SegmentRecorder); no RCCL kernel
+    # is a graph node.  (ONE graph with the collectives inside works replay-only - tools/step_loop.py with
+    # QPG_FORCE_SHARDED=1 QPG_EXPERIMENTAL_SHARDED_GRAPH=1 - but replays followed by eager collectives on the same
+    # communicator hung this ROCm / torch build, and this script needs both.)  QPG_BENCH_SHARDED_EAGER=1: shards eager.
+    shards_eager = sharded_run and os.environ.get("QPG_BENCH_SHARDED_EAGER", "") == "1" and a.step_mode != "graph"
+    graph_mode = (a.step_mode == "graph" or (a.step_mode == "auto" and not a.no_graph)) and CL == 1 and \
+        enc is None and a.clips_in_flight == 1 and not shards_eager and (world == 1 or sharded_run or replicated)
     if a.step_mode == "graph" and not graph_mode:
-        raise SystemExit("--step-mode graph: one GPU, one clip per step, no encode leg, no clips in flight")
+        raise SystemExit("--step-mode graph: one clip per step and rank, no encode leg, no clips in flight")
     cg = None
     if graph_mode:
         knn_g = CodeKNN(db, rng=np.random.RandomState(123456))      # (its own workspaces / side stream: the capture's)
@@ -673,7 +677,7 @@ def main():
                             "achieved": round(flops / (k6 * 1e-3) / 1e12, 3), "peak": F64_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(flops / (k6 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
                             "codes_equal_default_path": bool(torch.equal(c64, codes))}
-    out["step_mode"] = "graph" if graph_mode else "eager"
+    out["step_mode"] = ("graph-segments" if sharded_run else "graph") if graph_mode else "eager"
     if graph_mode:
         out["eager"] = eager_leg
         # another seed through the SAME capture must equal the eager path started from that seed
@@ -685,7 +689,8 @@ def main():
         out["graph_replay"] = {"ms_per_step": out["ms_per_step"], "steps": a.steps, "captures": cg.captures,
                                "is_the_timed_region": True,
                                "text_side_captured_first": bool(not knn_g.audio_first and knn_g.audio_first is not None),
-                               "other_seed_equals_eager": bool(np.array_equal(g2, e2))}
+                               "other_seed_equals_eager": bool(np.array_equal(g2, e2)),
+                               **({"segments": list(cg.segment_kinds)} if cg.segmented else {})}
     if (mixed and not sharded_run and world == 1 and can_pipe and pipe is None and not a.no_f64_line and
             os.environ.get("QPG_BENCH_NO_PIPELINED", "") != "1"):
         # the same per-clip launches with three clips in flight (ClipPipeline: the next clips' sweeps are enqueued before a

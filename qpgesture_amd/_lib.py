@@ -212,6 +212,7 @@ def ptr(t):
 
 _cur_dev = None
 _dev_index = {}
+n_calls = 0          # launches made through call() / prepare() (parallel.SegmentRecorder: is a captured segment empty?)
 # torch's C entry points behind torch.cuda.current_device() / current_stream().cuda_stream: the Python wrappers cost ~1 and
 # ~3 us per call (lazy-init checks, a Stream object per call) and this module makes a dozen calls per 0.36 ms step
 _get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
@@ -233,6 +234,7 @@ def call(name, device, *args):
     a GestureDB / VQVAE built on cuda:1 works whatever device the caller has selected.
     (This wrapper sits in front of every launch of a clip - a dozen per 0.4 ms step - so it avoids what it can:
     device indices are cached, tensors go in as their data_ptr() integers.)"""
+    global n_calls
     lib = _lib if _lib is not None else load()
     idx = _dev_index.get(device)
     if idx is None:
@@ -243,6 +245,7 @@ def call(name, device, *args):
     if idx != _get_device():
         with torch.cuda.device(idx):
             return call(name, device, *args)
+    n_calls += 1
     stream = _raw_stream(idx)
     conv = []
     for a in args:
@@ -287,6 +290,8 @@ def prepare(name, device, *args):
     fn = getattr(lib, name)
 
     def launch(_keep=args):          # (the tensors stay alive until the launch has been made)
+        global n_calls
+        n_calls += 1
         rc = fn(h, stream, *conv)
         if rc != 0:
             raise RuntimeError("%s failed (%d): %s" % (name, rc, last_error()))

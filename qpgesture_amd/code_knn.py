@@ -417,12 +417,16 @@ class CodeKNN:
         return code, np.concatenate((P[:, 0], P[:, 1]), axis=1).astype(np.float32)
 
     # -- batched sweeps ------------------------------------------------------------------------
-    def _hl_plan(self, sharded=False):
-        """Will sweep_audio take the split-f16 (hl) mixed-precision path for a whole-clip sweep on this DB?"""
+    def _hl_plan(self, sharded=False, Q=0):
+        """Will sweep_audio take the split-f16 (hl) mixed-precision path for a whole-clip sweep of Q queries on this DB
+        (the same conditions as sweep_audio's own; `sharded`: as a row shard inside sweep_tables)?"""
         db = self.db
-        return (self.audio_precision == "mixed" and self.tie_eps > 0 and db.n_local > 0 and db.K <= 512 and
-                db.hl_bound_ok and not sharded and db.world == 1 and self.audio_kernel == "hl" and
-                db.hl_image is not None and db.feature_dtype == "f32")
+        base = (self.audio_precision == "mixed" and self.tie_eps > 0 and db.n_local > 0 and db.K <= 512 and
+                db.hl_bound_ok and self.audio_kernel == "hl" and db.hl_image is not None and db.feature_dtype == "f32")
+        if not sharded:
+            return base and db.world == 1
+        gflop = 2e-9 * Q * (-(-db.N // db.world) * db.Ga) * NUM_AUDIO_FEAT_FRAMES * db.F
+        return base and self.sharded_mixed and gflop >= self.sharded_mixed_min_gflop
 
     def sweep_audio(self, qbase, q_win, q_t, tap_stride=None, want_rank=False, reduce=True, out=None, prepacked=None):
         """Per-code best audio candidate for every query: returns (dist f64 [Q,512], idx i32 [Q,512])
@@ -589,7 +593,8 @@ class CodeKNN:
             if out is not None:           # row shard: straight into the exchange buffer, global indices, merged later
                 dist, idx, qb, bs = out
                 db.txt_sorted.select(qn, float(ABSENT_DIST), self._guard_stats, dist=dist, idx=idx,
-                                     idx_base=db.idx_base * db.Gt, q_block=qb, block_stride=bs, scratch=self._txt_scratch)
+                                     idx_base=db.idx_base * db.Gt, q_block=qb, block_stride=bs, scratch=self._txt_scratch,
+                                     cols_packed=cols_packed)
                 return dist, idx
             rank = torch.empty((Q, db.K), dtype=torch.int16, device=dev) if want_rank else None
             dist, idx, _ = db.txt_sorted.select(qn, float(ABSENT_DIST), self._guard_stats, rank=rank,
@@ -819,11 +824,11 @@ class CodeKNN:
 
         # Round 4: the clip's WHOLE query side in one launch (qpg_clip_pack_hl: the audio gather / norms / split-f16 image
         # AND the text queries' gather / sklearn normalisation / column image) when both sides take their matrix-core
-        # paths on an unsharded DB.  Behind the 32-row sweep, which holds every register of every CU, the text side's two
+        # paths (one GPU or a row shard).  Behind the 32-row sweep, which holds every register of every CU, the text side's two
         # tiny pack launches did not get a wave slot before the sweep was over.
         mfma_text_ = (self.text_kernel == "mfma" and db.txt_sorted is not None and self.audio_precision != "exact")
         packed = None
-        if (overlap and not sharded and not self.use_wavvq and mfma_text_ and self._hl_plan() and db.Dt % 128 == 0 and
+        if (overlap and not self.use_wavvq and mfma_text_ and self._hl_plan(sharded, M * steps) and db.Dt % 128 == 0 and
                 self.fused_pack and self.text_lead <= 0):
             Qn = M * steps
             q32_ = torch.empty((Qn, NUM_AUDIO_FEAT_FRAMES * db.F), dtype=torch.float32, device=dev)
@@ -1228,20 +1233,26 @@ class ClipGraph:
     def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset, audio=None, context=None, owner_blocks=False):
         db, dev = knn.db, knn.db.device
         self.owner_blocks = owner_blocks
+        self.segmented = False
         if db.world != 1 or knn.force_sharded:
-            # a row-sharded clip: its collectives are captured with the kernels (RCCL supports capture through
-            # torch.distributed's nccl backend; gloo is staged through the host and can not be)
-            # EXPERIMENTAL (QPG_EXPERIMENTAL_SHARDED_GRAPH=1): with one rank over RCCL a process that only replays runs
-            # (tools/step_loop.py: 0.36 ms per clip against 0.46 eager), but a process that replays AND issues eager
-            # collectives on the same communicator afterwards (bench.py's eager leg, a flagged clip's re-match) hung on
-            # this ROCm / torch build - so a sharded matcher does not hand out graphs unless asked to.
+            # A row-sharded clip is recorded in SEGMENTS (parallel.SegmentRecorder): one hipGraph per run of kernels
+            # between two collectives, the collectives themselves issued eagerly between the graph launches - the host
+            # pays one hipGraphLaunch per segment instead of one Python launch per kernel (the eager sharded step is
+            # host-bound: ~0.45-0.59 ms of host time against ~0.36 ms of GPU time on one rank), and RCCL sees exactly what
+            # it sees in an uncaptured step.
+            # QPG_EXPERIMENTAL_SHARDED_GRAPH=1: ONE graph with the collectives captured inside (RCCL supports capture
+            # through torch.distributed's nccl backend).  With one rank over RCCL a process that only replays runs
+            # (tools/step_loop.py: 0.36 ms per clip), but a process that replays AND issues eager collectives on the same
+            # communicator afterwards (bench.py's eager leg, a flagged clip's re-match) hung on this ROCm / torch build.
             import os as _os
             import torch.distributed as dist_
-            if _os.environ.get("QPG_EXPERIMENTAL_SHARDED_GRAPH", "") != "1":
-                raise NotImplementedError("graph capture of the sharded path (collectives inside) is experimental: "
-                                          "QPG_EXPERIMENTAL_SHARDED_GRAPH=1")
-            if not (dist_.is_available() and dist_.is_initialized() and dist_.get_backend() == "nccl"):
-                raise NotImplementedError("graph capture of the sharded path needs the nccl (RCCL) backend")
+            if not (dist_.is_available() and dist_.is_initialized()):
+                raise NotImplementedError("graph capture of the sharded path needs an initialised process group")
+            if _os.environ.get("QPG_EXPERIMENTAL_SHARDED_GRAPH", "") == "1":
+                if dist_.get_backend() != "nccl":
+                    raise NotImplementedError("one-graph capture of the sharded path needs the nccl (RCCL) backend")
+            else:
+                self.segmented = True
         if knn.host_ranks:
             raise NotImplementedError("graph capture needs the device-side ranks (tie_rule 'stable')")
         self.knn, self.M, self.mode = knn, n_windows, mode
@@ -1281,6 +1292,31 @@ class ClipGraph:
                 body()
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
+        if self.segmented:
+            from . import parallel as _par
+            rec = _par.SegmentRecorder()
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            with torch.cuda.stream(s):
+                _par._recorder = rec
+                try:
+                    rec.begin()
+                    self.out = body()
+                    rec.end()
+                finally:
+                    _par._recorder = None
+                    if rec._g is not None:          # an exception inside a segment: close the capture before it propagates
+                        try:
+                            rec._g.capture_end()
+                        except Exception:
+                            pass
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            self._program, self.segment_kinds, self._rec = rec.program, rec.kinds, rec
+            self.graph = rec
+            self.captures += 1
+            return
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.out = body()
@@ -1302,7 +1338,11 @@ class ClipGraph:
         if self.graph is None:
             self._capture()
         self._pin_np.fill(_PIN_SENTINEL)
-        self.graph.replay()
+        if self.segmented:
+            for f in self._program:                 # hipGraphLaunch, collective, hipGraphLaunch, ...
+                f()
+        else:
+            self.graph.replay()
 
     def wait_ints(self):
         """Host-side wait for the replay's last store (the status word, behind a system-scope fence); returns a copy of

@@ -58,6 +58,35 @@ def alltoall_min_index(dist, idx, world, group=None):
     return best.contiguous(), ibest.to(torch.int32).contiguous()
 
 
+# A ClipGraph that records a row-sharded clip in SEGMENTS sets this (SegmentRecorder): every collective below then ends the
+# hipGraph being captured, runs eagerly - as torch.distributed issues it in an uncaptured step - and opens the next graph.
+_recorder = None
+
+
+def _exchange_into(out, send, world, owner_blocks, group=None):
+    """exchange_bytes on a caller-owned receive buffer (`out` may be None: allocate).  RCCL (backend nccl) moves device
+    buffers in place; gloo is staged through the host."""
+    import torch.distributed as dist_
+    gloo = dist_.get_backend(group) == "gloo"
+    host = send.is_cuda and gloo
+    s_ = send.cpu() if host else send
+    if owner_blocks:
+        r_ = torch.empty_like(s_) if (host or out is None) else out
+        dist_.all_to_all_single(r_, s_, group=group)
+    elif gloo:
+        parts = [torch.empty_like(s_) for _ in range(world)]
+        dist_.all_gather(parts, s_, group=group)
+        r_ = torch.cat(parts)
+    else:
+        r_ = out if out is not None else torch.empty((world * s_.numel(),), dtype=s_.dtype, device=s_.device)
+        dist_.all_gather_into_tensor(r_, s_, group=group)
+    if out is None:
+        return r_.to(send.device) if host else r_
+    if r_ is not out:
+        out.copy_(r_, non_blocking=False)
+    return out
+
+
 def exchange_bytes(send, world, owner_blocks, group=None):
     """The one collective of the sharded matcher.  `send` is this rank's byte buffer of per-shard (minimum, index)
     tables in exchange layout (code_knn.ExchangeLayout).  owner_blocks: the buffer is `world` equal blocks, block r
@@ -65,21 +94,67 @@ def exchange_bytes(send, world, owner_blocks, group=None):
     every rank receives every rank's whole buffer (ONE all-gather: the all-reduce(min, index) of SURVEY.md §8e with
     the reduction done locally by qpg_merge_select_*).  Returns the receive buffer: `world` source chunks, chunk w
     from rank w.  RCCL (backend nccl) moves device buffers in place; gloo is staged through the host."""
-    import torch.distributed as dist_
-    host = send.is_cuda and dist_.get_backend(group) == "gloo"
-    s_ = send.cpu() if host else send
-    if owner_blocks:
-        r_ = torch.empty_like(s_)
-        dist_.all_to_all_single(r_, s_, group=group)
-    else:
-        parts = [torch.empty_like(s_) for _ in range(world)]
-        if dist_.get_backend(group) == "gloo":
-            dist_.all_gather(parts, s_, group=group)
-            r_ = torch.cat(parts)
-        else:
-            r_ = torch.empty((world * s_.numel(),), dtype=s_.dtype, device=s_.device)
-            dist_.all_gather_into_tensor(r_, s_, group=group)
-    return r_.to(send.device) if host else r_
+    rec = _recorder
+    if rec is not None:
+        # a persistent receive buffer, allocated OUTSIDE the captures; the collective itself is replayed by calling it
+        n = send.numel() if owner_blocks else world * send.numel()
+        return rec.cut(lambda out: _exchange_into(out, send, world, owner_blocks, group),
+                       lambda: torch.empty((n,), dtype=send.dtype, device=send.device))
+    return _exchange_into(None, send, world, owner_blocks, group)
+
+
+class SegmentRecorder:
+    """A row-sharded clip as a PROGRAM: hipGraph, collective, hipGraph, collective, ..., hipGraph.
+
+    The kernels between two collectives are captured into one hipGraph each (one private memory pool for all of them:
+    they are replayed in capture order); the collectives stay what they are in an uncaptured step - torch.distributed
+    calls on persistent buffers, issued by the host between two graph launches.  A replay therefore costs the host one
+    hipGraphLaunch per segment + one torch.distributed call per collective (~25 us each) instead of one Python launch
+    per kernel, and nothing about RCCL differs from the eager path: no RCCL kernel is ever a graph node (a process that
+    replays graphs WITH captured RCCL nodes and then issues eager collectives on the same communicator hung on this
+    ROCm / torch build: DESIGN.md §5)."""
+
+    def __init__(self):
+        self.program = []           # callables, in replay order
+        self.kinds = []             # "graph" | "collective" per entry
+        self.pool = torch.cuda.graph_pool_handle()
+        self._g = None
+        self._n0 = 0
+        self._keep = []             # receive buffers
+
+    def begin(self):
+        from . import _lib
+        self._g = torch.cuda.CUDAGraph()
+        self._n0 = _lib.n_calls
+        # thread_local: the process group's watchdog thread may query its events while this thread captures
+        self._g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def end(self):
+        from . import _lib
+        g, self._g = self._g, None
+        g.capture_end()
+        if _lib.n_calls > self._n0:             # (a segment without a launch is not instantiated, nor replayed)
+            self.program.append(g.replay)
+            self.kinds.append("graph")
+
+    def cut(self, issue, alloc=None):
+        """End the open segment, run the collective `issue(out)` eagerly ONCE (every rank does: the call order on the
+        communicator is the replay's), record it, open the next segment.  Returns the collective's result."""
+        global _recorder
+        self.end()
+        out = alloc() if alloc is not None else None
+        if out is not None:
+            self._keep.append(out)
+        fn = (lambda: issue(out))
+        _recorder = None
+        try:
+            res = fn()
+        finally:
+            _recorder = self
+        self.program.append(fn)
+        self.kinds.append("collective")
+        self.begin()
+        return res
 
 
 def merge_reference(dists, idxs, absent):
@@ -130,6 +205,9 @@ def allreduce_max_(t, force=False):
     import torch.distributed as dist_
     if not (_active() or (force and dist_.is_available() and dist_.is_initialized())):
         return t
+    rec = _recorder
+    if rec is not None:
+        return rec.cut(lambda _out: allreduce_max_(t, force))
     if _host_staged():
         h = t.cpu()
         dist_.all_reduce(h, op=dist_.ReduceOp.MAX)

@@ -36,6 +36,13 @@ def test_bench_sharded_matches_unsharded(world):
     out = json.loads(line)
     assert out["n_gpus"] == world and out["check"] is True and out["scaling"] == "weak"
     assert out["config"]["clips"] == world and out["value"] > 0
+    # one clip per rank: the timed steps replay the clip's segments (hipGraph, collective, hipGraph, ...), the eager leg
+    # behind them returned the same codes, and another seed through the same capture equals the eager path
+    assert out["step_mode"] == "graph-segments" and out["eager"]["codes_equal_graph_steps"] is True
+    gr = out["graph_replay"]
+    assert gr["other_seed_equals_eager"] is True and gr["captures"] == 1
+    assert gr["segments"].count("collective") == out["config"]["collectives_per_step"] == 4
+    assert gr["segments"][0] == "graph" and gr["segments"][-1] == "graph"
     assert "roofline" in out and out["roofline"]["bound"] == "hbm"       # the shards sweep with the split-f16 kernel
     # the shards sweep in mixed precision; the merge re-evaluated something across shards and nothing overflowed
     assert out["roofline"]["precision"] == "mixed" and out["mixed_precision"]["flags"] == 0
@@ -156,6 +163,21 @@ def test_sharded_path_over_rccl_with_one_rank():
         assert r.returncode == 0, str(extra) + r.stdout[-2000:] + r.stderr[-3000:]
         out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert out["check"] is True and out["rematched_steps"] == 0, extra
+        # the timed region replayed the clip's segments; the collectives between them are the eager path's own calls
+        assert out["step_mode"] == "graph-segments", extra
+        assert out["graph_replay"]["segments"].count("collective") == out["config"]["collectives_per_step"], extra
+        assert out["graph_replay"]["other_seed_equals_eager"] and out["eager"]["codes_equal_graph_steps"], extra
+    # QPG_BENCH_SHARDED_EAGER=1: one Python launch per kernel, as before
+    env = dict(os.environ, QPG_BENCH_FORCE_SHARDED="1", QPG_BENCH_SHARDED_EAGER="1", MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--n-db", "200",
+           "--windows", "2", "--check", "--no-cpu-baseline", "--no-vqvae", "--no-prewarm", "--no-cold",
+           "--sharded-mixed-min-gflop", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["check"] is True and out["step_mode"] == "eager" and "graph_replay" not in out
 
 
 def test_merge_kernel_vs_reference():
