@@ -340,7 +340,7 @@ def main():
         enc is None and a.clips_in_flight == 1 and not shards_eager and (world == 1 or sharded_run or replicated)
     if a.step_mode == "graph" and not graph_mode:
         raise SystemExit("--step-mode graph: one clip per step and rank, no encode leg, no clips in flight")
-    cg = None
+    cg, graph_fallback = None, None
     if graph_mode:
         knn_g = CodeKNN(db, rng=np.random.RandomState(123456))      # (its own workspaces / side stream: the capture's)
         knn_g.overlap_sweeps, knn_g.audio_precision, knn_g.audio_kernel = knn.overlap_sweeps, knn.audio_precision, knn.audio_kernel
@@ -353,6 +353,22 @@ def main():
             knn.force_sharded, knn.sharded_mixed_min_gflop, knn.mixed_requests)
         cg = knn_g.capture_clip_graph(M, n_sweep_windows=M * n_sweep_clips, audio=te_interp, context=te_ctx,
                                       owner_blocks=sharded_run and not strong)
+        if sharded_run:
+            # the segments are recorded NOW, and every rank ends up in the same step mode: a capture that failed on any
+            # rank sends all of them to the eager step (MIN over the ranks of "captured")
+            ok_ = 1
+            try:
+                cg._set_seed(seed_code, seed_phase)
+                cg._capture()
+            except Exception as e_:                       # noqa: BLE001 (reported in the record)
+                ok_, graph_fallback = 0, repr(e_)[:300]
+            if world > 1:
+                f_ = torch.tensor([ok_], dtype=torch.int32, device=dev)
+                dist.all_reduce(f_, op=dist.ReduceOp.MIN)
+                ok_ = int(f_.item())
+            if not ok_:
+                graph_mode, cg = False, None
+                graph_fallback = graph_fallback or "the capture failed on another rank"
 
     def step_graph():
         arr = cg.run_ints(seed_code, seed_phase)
@@ -678,6 +694,8 @@ def main():
                             "unit": "TFLOP/s", "frac": round(flops / (k6 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
                             "codes_equal_default_path": bool(torch.equal(c64, codes))}
     out["step_mode"] = ("graph-segments" if sharded_run else "graph") if graph_mode else "eager"
+    if graph_fallback:
+        out["step_mode_fallback"] = graph_fallback
     if graph_mode:
         out["eager"] = eager_leg
         # another seed through the SAME capture must equal the eager path started from that seed
@@ -875,7 +893,27 @@ def replicated_leg(a, dev, world, rank, N, M, code, phase, sig, te_interp, te_ct
     ti = te_interp[rank * M:(rank + 1) * M].contiguous()
     tc = te_ctx[rank * M:(rank + 1) * M].contiguous()
 
+    # the same step as N = 1: one hipGraph replay per clip (--step-mode eager / --no-graph: one launch per kernel)
+    use_graph = a.step_mode != "eager" and not a.no_graph
+    sp_np = seed_phase_d.cpu().numpy()
+    cg = kr.capture_clip_graph(M, audio=ti, context=tc) if use_graph else None
+
     def one():
+        if cg is not None:
+            arr = cg.run_ints(seed_code, sp_np)
+            if arr[-1] == 0:
+                kr.check_status(arr[-2:])
+                return arr[:M * 30]
+            # the trouble word came out with the codes: this clip again on the uncapped path
+            prev, kr.audio_precision = kr.audio_precision, "exact"
+            kr.clear_flags()
+            try:
+                T = kr.sweep_tables(ti, tc, M)
+                arr = kr.walk(T, M, seed_code=seed_code, seed_phase=seed_phase_d, sync="ints")
+            finally:
+                kr.audio_precision = prev
+            kr.check_status(arr[-2:])
+            return arr[:M * 30]
         T = kr.sweep_tables(ti, tc, M)
         arr = kr.walk(T, M, seed_code=seed_code, seed_phase=seed_phase_d, sync="ints")
         kr.check_status(arr[-2:])
@@ -904,7 +942,7 @@ def replicated_leg(a, dev, world, rank, N, M, code, phase, sig, te_interp, te_ct
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     res = {"value": round(240 * M * world * a.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
-           "steps": a.steps, "scaling": "weak", "collectives_per_step": 0,
+           "steps": a.steps, "scaling": "weak", "collectives_per_step": 0, "step_mode": "graph" if cg is not None else "eager",
            "parallelism": "replicated DB x%d, clip-parallel, no collective" % world}
     if want is not None:
         res["codes_equal_row_sharded"] = bool(np.array_equal(got.reshape(-1), want.numpy().reshape(-1)))

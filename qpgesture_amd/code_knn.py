@@ -1285,7 +1285,8 @@ class ClipGraph:
         def body():
             T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode, owner_blocks=self.owner_blocks)
             return knn.walk(T, self.M, self._off, self.mode, sync=False, seed_ptrs=ptrs, out_pin=self._pin)
-        s = torch.cuda.Stream(device=dev)
+        import os as _os
+        s = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("QPG_GRAPH_PRIO", "0")))   # (measurements)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for _ in range(2):                       # warm-up: caches, lazy module loads, workspaces

@@ -43,6 +43,9 @@ def test_bench_sharded_matches_unsharded(world):
     assert gr["other_seed_equals_eager"] is True and gr["captures"] == 1
     assert gr["segments"].count("collective") == out["config"]["collectives_per_step"] == 4
     assert gr["segments"][0] == "graph" and gr["segments"][-1] == "graph"
+    # the clip-parallel leg beside it (whole DB on every rank, no collective): same codes, one graph replay per clip
+    rep = out["replicated"]
+    assert rep["codes_equal_row_sharded"] is True and rep["step_mode"] == "graph" and rep["collectives_per_step"] == 0
     assert "roofline" in out and out["roofline"]["bound"] == "hbm"       # the shards sweep with the split-f16 kernel
     # the shards sweep in mixed precision; the merge re-evaluated something across shards and nothing overflowed
     assert out["roofline"]["precision"] == "mixed" and out["mixed_precision"]["flags"] == 0

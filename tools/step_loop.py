@@ -45,6 +45,9 @@ def step():
 
 
 import time
+prio = int(os.environ.get("QPG_LOOP_PRIO", "0"))      # -1: the loop's stream is a high-priority stream (the text side's is not)
+if prio:
+    torch.cuda.set_stream(torch.cuda.Stream(dev, priority=prio))
 for _ in range(5):
     step()
 torch.cuda.synchronize()
