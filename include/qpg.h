@@ -365,6 +365,17 @@ int qpg_percode_select_mixed_f64(qpg_ctx*, void* stream, const void* D, int d_is
  * at q x stride + 24 K (diagnostics). */
 int64_t qpg_percode_select_mixed_ws_bytes(int Q, int K);
 int64_t qpg_percode_select_mixed_ws_stride(int K);
+/* The same call issued in PARTS (f32 matrix + workspace only): parts = 1 the streaming pass alone, 2 everything behind it,
+ * 3 both (= qpg_percode_select_mixed_f64).  Same arguments for both halves.  For the host's scheduling: between the two
+ * halves it records the event the text side's prefilter GEMM waits for, so that the streaming pass (on the clip's critical
+ * path, all CUs) is not shared with that GEMM and the GEMM runs beside the list pass instead (one block per query:
+ * GestureKNN.py:666-691's scan is per query, :708-721's text scan independent of it). */
+int qpg_percode_select_mixed_f64_parts(qpg_ctx*, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
+                                       const int16_t* cand_code, int64_t C, int K, double absent, int32_t idx_base,
+                                       double* out_dist, int32_t* out_idx, int16_t* out_rank, int q_block, int64_t block_stride,
+                                       const float* base, int T, int F, const int32_t* cand_t, int G, int n_taps,
+                                       int tap_stride, const float* q32, const double* qn2, const double* cn2, double eps1,
+                                       double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16, int parts);
 
 /* Cross-shard merge when the shards swept with qpg_audio_cosine_mx (their tables are accurate to QPG_AUDIO_MX_ERR; each
  * shard's own select has settled the near-ties inside the shard).  Three steps around two more byte exchanges:

@@ -366,6 +366,12 @@ class CodeKNN:
         # launches - tests and measurements compare the two)
         import os as _os
         self.fused_pack = _os.environ.get("QPG_FUSED_PACK", "1") != "0"
+        # "none" (default): no ordering between the two sides behind the pack; "stream" (measurements): the text side's GEMM
+        # waits for the end of the audio select's streaming pass.  Measured slower (tools/gate_probe.sh, one box, graph
+        # step 0.283 -> 0.307 ms): the pass does run alone (20 -> 9 us), but the GEMM then shares the chip with the tier-1
+        # dot products and the two, 82 MB and 108 MB of row gathers, take the sum of their times (54 us: ~3.6 TB/s in all) -
+        # the post-sweep path is bound by its bytes, not by how its launches are arranged.
+        self.text_gate = _os.environ.get("QPG_TEXT_GATE", "none")
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
         # Row-sharded DB: the shards sweep in mixed precision too and the cross-shard merge re-evaluates what their
         # bounded tables leave open through a request / response exchange (sweep_tables; qpg_merge_mixed_*).
@@ -533,13 +539,21 @@ class CodeKNN:
                 # (zero-filled ONCE: the select's streamed state is all-zero between launches, qpg.h)
                 ws = self._mix_ws = torch.zeros((need,), dtype=torch.uint8, device=dev)
             self._last_mix_Q = Q
+            sel_args = (D, 1, D.stride(0), Q, db.aud_cand_code, C, db.K,
+                        float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
+                        db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2,
+                        AUDIO_HL_BAND if use_hl else AUDIO_MX_BAND, float(self.tie_eps),
+                        self._guard_stats, None if self.mixed_single_launch else ws,
+                        0 if self.mixed_single_launch else ws.numel(), int(half))
             try:
-                _lib.call("qpg_percode_select_mixed_f64", dev, D, 1, D.stride(0), Q, db.aud_cand_code, C, db.K,
-                          float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, rank, qb, bs, db.base, db.T, db.F, db.aud_t,
-                          db.Ga, NUM_AUDIO_FEAT_FRAMES, db.tap_stride, q32, qn2, db.cn2,
-                          AUDIO_HL_BAND if use_hl else AUDIO_MX_BAND, float(self.tie_eps),
-                          self._guard_stats, None if self.mixed_single_launch else ws,
-                          0 if self.mixed_single_launch else ws.numel(), int(half))
+                if getattr(self, "_want_stream_event", False) and not self.mixed_single_launch:
+                    # sweep_tables gates the text side's GEMM on the END of the streaming pass: the pass (all CUs, on the
+                    # critical path) then runs alone, and the GEMM beside the list pass (one block per query)
+                    _lib.call("qpg_percode_select_mixed_f64_parts", dev, *sel_args, 1)
+                    self._record_sweep_event(dev)
+                    _lib.call("qpg_percode_select_mixed_f64_parts", dev, *sel_args, 2)
+                else:
+                    _lib.call("qpg_percode_select_mixed_f64", dev, *sel_args)
             except Exception:
                 # a failed launch between the streaming pass and the list pass would leave streamed state behind that
                 # later clips consume silently (the kernels only restore the all-zero state when all of them ran)
@@ -895,10 +909,18 @@ class CodeKNN:
         if mode in (MODE_AUD_TXT, MODE_AUD):
             fn = self.sweep_audio_wavvq if self.use_wavvq else self.sweep_audio
             self._want_sweep_event, self._sweep_done = after, None
+            # text_gate == "stream" (measurements; see __init__): the text side's GEMM, queued behind the pack, takes the
+            # freed CUs at the sweep's end and the select's streaming pass runs 20 us instead of 10 beside it; gated on the
+            # END of that pass it runs beside the tier-1 dot products instead - and the step is slower.
+            gate_stream = (overlap and audio_first and packed is not None and self.text_gate == "stream" and
+                           not self.mixed_single_launch)
+            self._want_stream_event = gate_stream
             kw = {"prepacked": packed} if (packed is not None and not self.use_wavvq) else {}
             r = fn(test_interp, q_win, q_t, want_rank=not sharded, reduce=not sharded,
                    out=lay.views("aud") if sharded else None, **kw)
-            self._want_sweep_event = False
+            self._want_sweep_event = self._want_stream_event = False
+            if gate_stream and self._sweep_done is not None:
+                side.wait_event(self._sweep_done)
             T["aud_d"], T["aud_idx"] = r[0], r[1]
             if not sharded:
                 T["aud_rank"] = r[2]

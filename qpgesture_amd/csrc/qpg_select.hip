@@ -1482,14 +1482,16 @@ extern "C" int64_t qpg_percode_select_mixed_ws_stride(int K) {       // bytes pe
   return K <= 0 ? 0 : (int64_t)mix_ws_stride(K);                     // q x stride, its list length is the i32 at + 24 K
 }
 
-extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
-                                            const int16_t* cand_code, int64_t C, int K, double absent,
-                                            int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
-                                            int q_block, int64_t block_stride, const float* base, int T, int F,
-                                            const int32_t* cand_t, int G, int n_taps, int tap_stride,
-                                            const float* q32, const double* qn2, const double* cn2, double eps1,
-                                            double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16) {
-  const char* name = "qpg_percode_select_mixed_f64";
+// parts: 1 = the streaming pass only (mixed_stream_kernel: f32 matrix + workspace), 2 = everything behind it (lists, tier-1
+// dot products, merge), 3 = both.  The split exists for the host's scheduling: the text side's GEMM is gated on the END of
+// the streaming pass (an event between the two calls), see code_knn.CodeKNN.sweep_tables.
+static int select_mixed_impl(const char* name, qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
+                             const int16_t* cand_code, int64_t C, int K, double absent,
+                             int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
+                             int q_block, int64_t block_stride, const float* base, int T, int F,
+                             const int32_t* cand_t, int G, int n_taps, int tap_stride,
+                             const float* q32, const double* qn2, const double* cn2, double eps1,
+                             double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16, int parts) {
   QPG_REQUIRE(ctx && D && (cand_code || C == 0) && out_dist && out_idx && base && cand_t && q32 && qn2 && cn2 && stats,
               "%s: null pointer", name);
   QPG_REQUIRE(Q >= 0 && C >= 0 && K > 0 && K <= 512 && ldD >= C && C + (int64_t)idx_base < 0x7fffffffll,
@@ -1528,16 +1530,21 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
                      static_cast<const DT*>(D), ldD, cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank,   \
                      q_block, block_stride, A, eps1, cn2, qn2, use_qlds, PHASE, w, PRE)
   if (!ws) {
+    QPG_REQUIRE(parts == 3, "%s: the one-launch form (no workspace) cannot be issued in parts", name);
     if (d_is_f32) SEL_MIX_LAUNCH(float, sh, 0, 0); else SEL_MIX_LAUNCH(double, sh, 0, 0);
     QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel");
     return QPG_OK;
   }
+  QPG_REQUIRE(parts == 3 || d_is_f32, "%s: only the f32 matrix has a separate streaming pass", name);
   if (d_is_f32) {
     // the row is streamed by MIX_SPLIT blocks per query; the list kernel starts from their state
-    const size_t shs = 4 * (size_t)K + 10 * (size_t)MIX_SPOT;
-    hipLaunchKernelGGL(mixed_stream_kernel, dim3(Q, MIX_SPLIT), dim3(1024), shs, qpg_stream(stream),
-                       static_cast<const float*>(D), ldD, cand_code, C, K, eps1, w);
-    QPG_LAUNCH_CHECK("mixed_stream_kernel");
+    if (parts & 1) {
+      const size_t shs = 4 * (size_t)K + 10 * (size_t)MIX_SPOT;
+      hipLaunchKernelGGL(mixed_stream_kernel, dim3(Q, MIX_SPLIT), dim3(1024), shs, qpg_stream(stream),
+                         static_cast<const float*>(D), ldD, cand_code, C, K, eps1, w);
+      QPG_LAUNCH_CHECK("mixed_stream_kernel");
+    }
+    if (!(parts & 2)) return QPG_OK;
     SEL_MIX_LAUNCH(float, sh2, 1, 1);
   } else {
     SEL_MIX_LAUNCH(double, sh1, 1, 0);
@@ -1550,6 +1557,33 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
   QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (merge)");
 #undef SEL_MIX_LAUNCH
   return QPG_OK;
+}
+
+extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
+                                            const int16_t* cand_code, int64_t C, int K, double absent,
+                                            int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
+                                            int q_block, int64_t block_stride, const float* base, int T, int F,
+                                            const int32_t* cand_t, int G, int n_taps, int tap_stride,
+                                            const float* q32, const double* qn2, const double* cn2, double eps1,
+                                            double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16) {
+  return select_mixed_impl("qpg_percode_select_mixed_f64", ctx, stream, D, d_is_f32, ldD, Q, cand_code, C, K, absent, idx_base,
+                           out_dist, out_idx, out_rank, q_block, block_stride, base, T, F, cand_t, G, n_taps, tap_stride, q32,
+                           qn2, cn2, eps1, eps2, stats, ws, ws_bytes, base_is_f16, 3);
+}
+
+extern "C" int qpg_percode_select_mixed_f64_parts(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
+                                                  const int16_t* cand_code, int64_t C, int K, double absent,
+                                                  int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
+                                                  int q_block, int64_t block_stride, const float* base, int T, int F,
+                                                  const int32_t* cand_t, int G, int n_taps, int tap_stride,
+                                                  const float* q32, const double* qn2, const double* cn2, double eps1,
+                                                  double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16,
+                                                  int parts) {
+  const char* name = "qpg_percode_select_mixed_f64_parts";
+  QPG_REQUIRE(parts >= 1 && parts <= 3, "%s: parts must be 1 (streaming pass), 2 (the rest) or 3", name);
+  return select_mixed_impl(name, ctx, stream, D, d_is_f32, ldD, Q, cand_code, C, K, absent, idx_base, out_dist, out_idx,
+                           out_rank, q_block, block_stride, base, T, F, cand_t, G, n_taps, tap_stride, q32, qn2, cn2, eps1, eps2,
+                           stats, ws, ws_bytes, base_is_f16, parts);
 }
 
 template <typename T, typename KeyT, bool PACKED>

@@ -34,14 +34,16 @@ te_i = torch.randn((M, 180, 1024), device=dev)
 te_c = torch.randn((M, 30, 384), device=dev)
 sc, sp = knn.init_code_phase()
 spd = torch.from_numpy(sp).to(dev)
-g = knn.capture_clip_graph(M, audio=te_i, context=te_c, owner_blocks=knn.force_sharded) if graph else None
+from qpgesture_amd import code_knn as _ck
+mode = getattr(_ck, os.environ.get("QPG_LOOP_MODE", "MODE_AUD_TXT"))        # MODE_AUD: audio side only (measurements)
+g = knn.capture_clip_graph(M, mode=mode, audio=te_i, context=te_c, owner_blocks=knn.force_sharded) if graph else None
 
 
 def step():
     if graph:
         return g.run_ints(sc, sp)
-    T = knn.sweep_tables(te_i, te_c, M, owner_blocks=knn.force_sharded)
-    return knn.walk(T, M, 0, seed_code=sc, seed_phase=spd, sync="ints")      # (codes | votes | status, pinned host memory)
+    T = knn.sweep_tables(te_i, te_c, M, mode=mode, owner_blocks=knn.force_sharded)
+    return knn.walk(T, M, 0, mode=mode, seed_code=sc, seed_phase=spd, sync="ints")      # (codes | votes | status, pinned host memory)
 
 
 import time
