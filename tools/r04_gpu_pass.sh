@@ -29,10 +29,14 @@ timeout 900 python bench.py --workload cfg3 > $O/bench_cfg3.json 2> $O/bench_cfg
 timeout 900 python bench.py --data speechlike --no-cpu-baseline --no-vqvae --no-e2e > $O/bench_speechlike.json 2> $O/bench_speechlike.err; echo "speechlike rc=$?" >> $O/rc.txt
 for sc in weak strong; do
   QPG_BENCH_FORCE_SHARDED=1 timeout 600 python bench.py --steps 50 --warmup 5 --scaling $sc --n-db 2048 --no-cpu-baseline --no-vqvae --no-cold --check > $O/bench_forced_sharded_$sc.json 2> $O/bench_forced_sharded_$sc.err; echo "forced $sc rc=$?" >> $O/rc.txt
+  QPG_BENCH_SHARDED_EAGER=1 QPG_BENCH_FORCE_SHARDED=1 timeout 600 python bench.py --steps 50 --warmup 5 --scaling $sc --n-db 2048 --no-cpu-baseline --no-vqvae --no-cold --check > $O/bench_forced_sharded_${sc}_eager.json 2> $O/bench_forced_sharded_${sc}_eager.err; echo "forced eager $sc rc=$?" >> $O/rc.txt
 done
 QPG_FORCE_SHARDED=1 QPG_EXPERIMENTAL_SHARDED_GRAPH=1 timeout 200 python tools/step_loop.py 200 graph > $O/forced_sharded_graph_loop.txt 2>&1
+QPG_FORCE_SHARDED=1 timeout 200 python tools/step_loop.py 200 graph > $O/forced_sharded_segments_loop.txt 2>&1
 QPG_FORCE_SHARDED=1 timeout 200 python tools/step_loop.py 200 > $O/forced_sharded_eager_loop.txt 2>&1
-( cd /tmp && QPG_FORCE_SHARDED=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$O/tls -- python $R/tools/step_loop.py 30 > $R/$O/tls.log 2>&1 )
+( cd /tmp && QPG_FORCE_SHARDED=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$O/tls -- python $R/tools/step_loop.py 30 graph > $R/$O/tls.log 2>&1 )
 python tools/step_timeline.py $O/tls 30 > $O/step_timeline_forced_sharded.md 2>&1
+( cd /tmp && QPG_FORCE_SHARDED=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$O/tlse -- python $R/tools/step_loop.py 30 > $R/$O/tlse.log 2>&1 )
+python tools/step_timeline.py $O/tlse 30 > $O/step_timeline_forced_sharded_eager.md 2>&1
 find $O -name "*.csv" -size +4M -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
 tail -2 $O/pytest.log; grep "ms/step" $O/forced_sharded_*_loop.txt; cat $O/rc.txt; head -c 400 $O/bench_20.json; echo; tail -18 $O/step_timeline_graph.md; cat $O/pmc_traffic.txt; cat $O/pmc_issue_mix.txt
