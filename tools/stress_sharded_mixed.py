@@ -44,20 +44,22 @@ for t in range(trials):
         knn.sweep_audio(ti, q_win, q_t, reduce=False, out=lay.views("aud"))
         shards.append(knn); lays.append(lay)
     recv = torch.cat([l.send for l in lays]); src_stride = lays[0].send.numel()
-    R = 8192; req_stride, resp_stride = 8 + 8 * R, 8 * R
+    Rq = 512; R = Q * Rq; req_stride = resp_stride = 8 + 8 * R      # deterministic slots: Rq = K per (query, shard) can not overflow (the product sizes them smaller and re-matches on the flag); 8-byte headers
     req = torch.zeros((W * req_stride,), dtype=torch.uint8, device=dev)
     ws = torch.empty((int(_lib.load().qpg_merge_mixed_ws_bytes(Q, K, 1024)),), dtype=torch.uint8, device=dev)
     stats = torch.zeros((4,), dtype=torch.int32, device=dev)
     _lib.call("qpg_merge_mixed_phase1_f64", dev, recv, W, src_stride, lays[0].off["aud_d"], lays[0].off["aud_i"], Q, K,
-              float(ABSENT_DIST), AUDIO_MX_BAND, R, req, req_stride, ws, ws.numel(), stats, 1024)
+              float(ABSENT_DIST), AUDIO_MX_BAND, R, req, req_stride, ws, ws.numel(), stats, 1024, -1)
     resp_recv = torch.zeros((W * resp_stride,), dtype=torch.uint8, device=dev)
     for w in range(W):
-        req_recv = torch.zeros((W * req_stride,), dtype=torch.uint8, device=dev)
+        req_recv = torch.full((W * req_stride,), 255, dtype=torch.uint8, device=dev)      # (unused slots / blocks: ~0)
+        for b in range(W):
+            req_recv[b * req_stride:b * req_stride + 8] = 0                               # headers: count | flags
         req_recv[:req_stride] = req[w * req_stride:(w + 1) * req_stride]
         resp = torch.zeros((W * resp_stride,), dtype=torch.uint8, device=dev)
         k, db = shards[w], shards[w].db
         _lib.call("qpg_shard_refine_f64", dev, req_recv, W, req_stride, R, 0, db.idx_base * db.Ga, db.base, int(half), db.T,
-                  db.F, db.aud_t, db.Ga, 6, db.tap_stride, k._last_q32, k._last_qn2, db.cn2, resp, resp_stride, 0)
+                  db.F, db.aud_t, db.Ga, 6, db.tap_stride, k._last_q32, k._last_qn2, db.cn2, resp, resp_stride, 0, None, Rq)
         resp_recv[w * resp_stride:(w + 1) * resp_stride] = resp[:resp_stride]
     d = torch.empty((Q, K), dtype=torch.float64, device=dev); ix = torch.empty((Q, K), dtype=torch.int32, device=dev)
     rk = torch.empty((Q, K), dtype=torch.int16, device=dev)

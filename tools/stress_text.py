@@ -62,11 +62,14 @@ for t in range(trials):
     a, b = out["valu"], out["mfma"]
     tables_ok = (np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]) and
                  np.array_equal(a[2], b[2]))
-    ok = np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and (tables_ok or (b[5] & 1)) and a[5] == 0
+    # (an overflowing band list raises FLAG_TEXT_OVERFLOW = 16 since round 4 - bit 1 before: the tables of that sweep are
+    # then unguarded and match_clip re-runs the text side on the exact sweep; the CODES must be equal in every case)
+    codes_ok = np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    ok = codes_ok and (tables_ok or (b[5] & (1 | 16))) and a[5] == 0
     bad += not ok
     print("trial %2d N=%4d M=%2d kind=%d kept %6d of %6d rows, %3d zero  flags=%d rematched=%d  %s"
           % (t, N, M, kind, db.txt_sorted.n_rows_kept, N * 26, db.txt_sorted.n_zero_rows, b[5], b[6],
-             "ok" if ok else "MISMATCH"), flush=True)
+             "ok" if ok else "MISMATCH (codes %s, tables %s)" % (codes_ok, tables_ok)), flush=True)
     del db
     torch.cuda.empty_cache()
 print("%d trials, %d mismatches, %.0f s" % (trials, bad, time.time() - t0))
