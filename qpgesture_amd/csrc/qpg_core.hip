@@ -13,7 +13,7 @@ void qpg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int qpg_version(void) { return 104; }          // 1.04: round 4's entry points (include/qpg.h)
+extern "C" int qpg_version(void) { return 105; }          // 1.05: round 4 (qpg_clip_pack_hl, qpg_hl_gemm_tilemin, qpg_flags_*, qpg_percode_select_mixed_f64_parts, ...: include/qpg.h)
 
 // Is HIP_FORCE_DEV_KERNARG=1 in this process's environment? (see qpg_ctx_create in include/qpg.h)
 extern "C" int qpg_dev_kernarg(void) {
