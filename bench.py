@@ -284,7 +284,7 @@ def main():
         # replicated: this rank's clips against the whole DB, no exchange.
         if enc is not None:
             ids = enc.encode(enc_x)[0]
-        T = knn.sweep_tables(te_interp, te_ctx, M * n_sweep_clips, owner_blocks=sharded_run and not strong)
+        T = knn.sweep_tables(te_interp, te_ctx, M * n_sweep_clips, owner_blocks=sharded_run and not strong, for_walk=True)
         if my_clips > 1 and batch_walk:
             # the clips are independent chains (their own seeds / window chaining): ONE set of walk launches for all
             knn.walk_batch(T, M, my_clips, [seed_code] * my_clips, seed_phases_d)
@@ -783,6 +783,9 @@ def main():
         Tm = knn.sweep_tables(te_interp, te_ctx, M * n_sweep_clips)
         out["mixed_precision"] = {
             "f64_dot_pairs_per_step": round(st["tier1_pairs"] / n_run, 1),
+            # the timed steps' select settles in f64 only what the walk can read (QPG_RANK_CUT=0: everything);
+            # the tables compared with the f64 sweep below are the fully settled ones, the CODES compared are the timed steps'
+            "walk_relevance_cut": bool(getattr(knn_g if graph_mode else knn, "_last_rank_cut", False)),
             "reference_arithmetic_pairs_per_step": round(st["tier2_pairs"] / n_run, 2),
             "flags": st["flags"], "error_bound": 1.3e-6 if hl else 2.05e-6,
             # the one measured constant under that bound, re-measured at load time on THIS device (selfcheck.py)
@@ -908,13 +911,13 @@ def replicated_leg(a, dev, world, rank, N, M, code, phase, sig, te_interp, te_ct
             prev, kr.audio_precision = kr.audio_precision, "exact"
             kr.clear_flags()
             try:
-                T = kr.sweep_tables(ti, tc, M)
+                T = kr.sweep_tables(ti, tc, M, for_walk=True)
                 arr = kr.walk(T, M, seed_code=seed_code, seed_phase=seed_phase_d, sync="ints")
             finally:
                 kr.audio_precision = prev
             kr.check_status(arr[-2:])
             return arr[:M * 30]
-        T = kr.sweep_tables(ti, tc, M)
+        T = kr.sweep_tables(ti, tc, M, for_walk=True)
         arr = kr.walk(T, M, seed_code=seed_code, seed_phase=seed_phase_d, sync="ints")
         kr.check_status(arr[-2:])
         return arr[:M * 30]

@@ -19,9 +19,10 @@ for ph in (0, 1, 2):
     ck = [buf[(3 + ph) * 16 + i] for i in range(16)]
     prev = pck = None
     print("phase", ph, "(mixed_stream_kernel, block (0, 0))" if ph == 0 else "")
-    for i in range(13):
+    names.update({13: "cut: sort", 14: "cut: lo / hi", 15: "cut: probe + Umax"})
+    for i in sorted(range(16), key=lambda j: st[j]):            # (in time order: the cut's stamps sit between 2 and 3)
         if st[i] == 0:
             continue
         if prev is not None:
-            print("   %-26s %6.2f us  %7d shader clocks" % ((snames if ph == 0 else names)[i], (st[i] - prev) / 100.0, ck[i] - pck))
+            print("   %-26s %6.2f us  %7d shader clocks" % ((snames if ph == 0 else names).get(i, str(i)), (st[i] - prev) / 100.0, ck[i] - pck))
         prev, pck = st[i], ck[i]

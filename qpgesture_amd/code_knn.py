@@ -295,6 +295,8 @@ class GestureDB:
         # code_to_freq (GestureKNN.py:481-499): 1 - count/total, 1 for unseen codes; rank of it (:544)
         cnt = np.bincount(code.reshape(-1), minlength=self.K)[:self.K]
         self.freq_dist = np.where(cnt > 0, 1 - cnt / cnt.sum(), 1.0)
+        # (the walk-relevance cut of the select reads a code's column: qpg_percode_select_mixed_f64_cut)
+        self.pos_rank_t = self.pos_rank.t().contiguous()
         if freq_rank is None:
             fd = torch.from_numpy(self.freq_dist[None].copy()).to(dev)
             self.freq_rank = torch.empty((1, self.K), dtype=torch.int16, device=dev)
@@ -366,6 +368,13 @@ class CodeKNN:
         # launches - tests and measurements compare the two)
         import os as _os
         self.fused_pack = _os.environ.get("QPG_FUSED_PACK", "1") != "0"
+        # Walk-relevance cut (round 4, last hours): when the tables go straight into the walk (match_clip without
+        # return_tables, ClipGraph, ClipPipeline, bench.py's step: sweep_tables(for_walk=True)) the select settles in f64
+        # only what the walk can read - codes whose rank is certainly above every step's winning fused score keep their
+        # sweep values (include/qpg.h: qpg_percode_select_mixed_f64_cut).  The codes the walk returns are the same; the
+        # tables sweep_tables() hands to anyone else are exact everywhere, as before.  QPG_RANK_CUT=0: off.
+        self.rank_cut = _os.environ.get("QPG_RANK_CUT", "1") != "0"
+        self.rank_cut_probe = 64
         # "none" (default): no ordering between the two sides behind the pack; "stream" (measurements): the text side's GEMM
         # waits for the end of the audio select's streaming pass.  Measured slower (tools/gate_probe.sh, one box, graph
         # step 0.283 -> 0.307 ms): the pass does run alone (20 -> 9 us), but the GEMM then shares the chip with the tier-1
@@ -434,7 +443,8 @@ class CodeKNN:
         gflop = 2e-9 * Q * (-(-db.N // db.world) * db.Ga) * NUM_AUDIO_FEAT_FRAMES * db.F
         return base and self.sharded_mixed and gflop >= self.sharded_mixed_min_gflop
 
-    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None, want_rank=False, reduce=True, out=None, prepacked=None):
+    def sweep_audio(self, qbase, q_win, q_t, tap_stride=None, want_rank=False, reduce=True, out=None, prepacked=None,
+                    cut_top_n=None):
         """Per-code best audio candidate for every query: returns (dist f64 [Q,512], idx i32 [Q,512])
         with global candidate indices j*26+g (-1 = code absent), min-reduced across ranks; with
         want_rank also the stable ranks i16 [Q,512]."""
@@ -545,8 +555,14 @@ class CodeKNN:
                         AUDIO_HL_BAND if use_hl else AUDIO_MX_BAND, float(self.tie_eps),
                         self._guard_stats, None if self.mixed_single_launch else ws,
                         0 if self.mixed_single_launch else ws.numel(), int(half))
+            use_cut = (cut_top_n in (1, 2) and local_final and rank is not None and not self.mixed_single_launch and
+                       not getattr(self, "_want_stream_event", False))
+            self._last_rank_cut = use_cut
             try:
-                if getattr(self, "_want_stream_event", False) and not self.mixed_single_launch:
+                if use_cut:
+                    _lib.call("qpg_percode_select_mixed_f64_cut", dev, *sel_args, db.pos_rank_t, db.freq_rank,
+                              int(cut_top_n), int(self.rank_cut_probe))
+                elif getattr(self, "_want_stream_event", False) and not self.mixed_single_launch:
                     # sweep_tables gates the text side's GEMM on the END of the streaming pass: the pass (all CUs, on the
                     # critical path) then runs alone, and the GEMM beside the list pass (one block per query)
                     _lib.call("qpg_percode_select_mixed_f64_parts", dev, *sel_args, 1)
@@ -777,13 +793,15 @@ class CodeKNN:
     def n_steps(self):
         return len(self.query_positions())
 
-    def sweep_tables(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, owner_blocks=False):
+    def sweep_tables(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, owner_blocks=False, for_walk=False):
         """Both batched sweeps + ranks for all Q = n_windows*steps query positions (the windows may
         belong to several clips).  test_interp: f32 [M,180,F]; test_context: f32 [M,30,384] (device).
         Returns a dict of device tensors: aud_d/aud_idx/aud_rank, txt_d/txt_idx/txt_rank.
         owner_blocks (sharded DB only): the windows are `world` equal blocks and this rank only needs the final
         tables of block `rank` — one all-to-all instead of two all-reduces; the returned tables then hold only that
-        block's Q/world rows."""
+        block's Q/world rows.
+        for_walk: the tables go straight into walk() and nowhere else - the audio select may then leave unsettled what the
+        walk can not read (CodeKNN.rank_cut; the returned tables are exact only where the walk reads them)."""
         db, dev = self.db, self.db.device
         M, steps = n_windows, self.n_steps()
         if test_interp.shape[0] < M or (mode != MODE_AUD and test_context.shape[0] < M):
@@ -916,6 +934,9 @@ class CodeKNN:
                            not self.mixed_single_launch)
             self._want_stream_event = gate_stream
             kw = {"prepacked": packed} if (packed is not None and not self.use_wavvq) else {}
+            if (for_walk and self.rank_cut and not sharded and not self.use_wavvq and not self.host_ranks and
+                    mode in (MODE_AUD_TXT, MODE_AUD)):
+                kw["cut_top_n"] = 1 if mode == MODE_AUD_TXT else 2
             r = fn(test_interp, q_win, q_t, want_rank=not sharded, reduce=not sharded,
                    out=lay.views("aud") if sharded else None, **kw)
             self._want_sweep_event = self._want_stream_event = False
@@ -1196,7 +1217,7 @@ class CodeKNN:
                     np.zeros((0, self.n_steps()), np.int32))
         test_interp = test_interp.contiguous()
         try:
-            T = self.sweep_tables(test_interp, test_context, n_windows, mode)
+            T = self.sweep_tables(test_interp, test_context, n_windows, mode, for_walk=not return_tables)
             if return_tables:
                 self.tables = T
             return self.walk(T, n_windows, 0, mode, seed_code, seed_phase)
@@ -1305,7 +1326,8 @@ class ClipGraph:
         ptrs = (self._seed_pin.data_ptr() + 4 * 128, self._seed_pin.data_ptr())
 
         def body():
-            T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode, owner_blocks=self.owner_blocks)
+            T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode, owner_blocks=self.owner_blocks,
+                                 for_walk=True)
             return knn.walk(T, self.M, self._off, self.mode, sync=False, seed_ptrs=ptrs, out_pin=self._pin)
         import os as _os
         s = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("QPG_GRAPH_PRIO", "0")))   # (measurements)
@@ -1433,7 +1455,7 @@ class ClipPipeline:
             seed_code, seed_phase = knn.init_code_phase()
         ln["stream"].wait_stream(torch.cuda.current_stream(dev))       # the caller's inputs
         with torch.cuda.stream(ln["stream"]):
-            T = knn.sweep_tables(test_interp.contiguous(), test_context, n_windows, mode)
+            T = knn.sweep_tables(test_interp.contiguous(), test_context, n_windows, mode, for_walk=True)
             oc, op, ov, st = knn.walk(T, n_windows, 0, mode, seed_code, seed_phase, sync=False)
             ints = knn._last_ints                                        # codes | votes | status, one buffer (walk)
             if ln["ints"] is None or ln["ints"].numel() < ints.numel():

@@ -477,6 +477,17 @@ struct GuardArgs {
   double eps;
   int32_t* stats;         // [2]
 };
+// Walk-relevance cut of the mixed select's tier-1 lists (round 4; pos_t == nullptr: off).  The walk reads, per step and
+// per previous code p, only the code(s) with the smallest fused score  pos_rank[p][c] + 0.05 freq_rank[c] + rank(c)
+// (GestureKNN.py:540-545, :574-576, order[0] - order[:2] without the text side, :593): a code whose rank is certainly
+// above every step's winning score can not be read, so neither its rank among near-tied neighbours nor its winner among
+// near-tied candidates has to be settled in f64.  See the list phase of percode_select_mixed_f64_kernel.
+struct RankCut {
+  const int16_t* pos_t;   // [K][K] TRANSPOSED pose ranks: pos_t[c * K + p] = rank of code c in previous code p's row
+  const int16_t* freq;    // [K] frequency ranks
+  int top_n;              // 1: the best fused score is read; 2: the best two
+  int probe;              // number of best-ranked codes the bound on the winning score is taken over (<= K)
+};
 #define GUARD_LIST 256
 typedef _Float16 g16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float guard_val(const GuardArgs& A, int64_t off) {       // base[off] as f32
@@ -1014,7 +1025,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     const DT* __restrict__ D, int64_t ldD, const int16_t* __restrict__ cand_code, int64_t C, int K, double absent,
     int32_t idx_base, double* __restrict__ out_dist, int32_t* __restrict__ out_idx, int16_t* __restrict__ out_rank,
     int q_block, int64_t block_stride, GuardArgs A, double eps1, const double* __restrict__ cn2,
-    const double* __restrict__ qn2, int use_qlds, int phase, unsigned char* __restrict__ ws, int pre) {
+    const double* __restrict__ qn2, int use_qlds, int phase, unsigned char* __restrict__ ws, int pre, RankCut RC) {
   // phase 0: everything in this launch (tier-1 dot products by this block's 16 waves: one CU per query).
   // pre (phase 1, f32 matrix): mixed_stream_kernel has streamed the row - per-code minima and the potential band members
   // are in the workspace; this launch starts at pass 2.
@@ -1216,13 +1227,137 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   __syncthreads();
   if (streamed && tid < MIX_SPLIT) ms.cnt[tid] = 0;            // (left all-zero for the next launch)
   SEL_STAMP(2);
+  for (int k = tid; k < K; k += blockDim.x) v[k] = besti[k] != 0xffffffffu ? key_value(best[k], 0.0) : absent;
+  __syncthreads();
+  // ---- walk-relevance cut (RankCut; streamed f32 path with ranks only).  With E the sweep's bound (eps1 >= 2 E), a
+  // code's true rank lies in [lo, hi] = its rank in the table of sweep values -/+ the number of codes within eps1 below /
+  // above it.  U(p) = min over the `probe` best-ranked codes c of  pos_rank[p][c] + 0.05 freq_rank[c] + hi(c)  is an upper
+  // bound on the smallest fused score of previous code p (the top_n-th smallest for top_n = 2), Umax its maximum over p.
+  // A code with lo > Umax scores above the winner(s) of EVERY previous code whatever its exact rank in [lo, hi] is, so
+  // the walk never reads its row: it is left out of both lists (its table entries keep their sweep values, its rank is
+  // its position among those) unless a code that CAN be read lies within eps1 of it (whose rank needs their order).
+  const bool cut = RC.pos_t != nullptr && streamed && out_rank != nullptr && phase == 1;
+  unsigned char* need2 = nullptr;
+  if (cut) {
+    unsigned char* cs = reinterpret_cast<unsigned char*>(pot_c);      // (the potential lists of the unstreamed path: free)
+    const int Kp = rank_sort_pow2(K);
+    unsigned long long* skey2 = reinterpret_cast<unsigned long long*>(cs);
+    int* scode2 = reinterpret_cast<int*>(skey2 + Kp);
+    int16_t* lo_ = reinterpret_cast<int16_t*>(scode2 + Kp);
+    int16_t* hi_ = lo_ + K;
+    unsigned char* need = reinterpret_cast<unsigned char*>(hi_ + K);
+    need2 = need + K;
+    double* red = reinterpret_cast<double*>(cs + 12 * (size_t)Kp + 8 * (size_t)((K + 7) / 8 * 8));   // [17]
+    const double f05 = tid < K ? (double)RC.freq[tid] * 0.05 : 0.0;   // (in flight under the sort)
+    block_sorted_ranks(v, K, skey2, scode2, [&](int k, int r) {
+      s_code[r] = k;
+      rk[k] = r;
+    });
+    __syncthreads();
+    SEL_STAMP(13);
+    for (int r = tid; r < K; r += blockDim.x) {
+      const int k = s_code[r];
+      int b = 0, a = 0;
+      if (besti[k] != 0xffffffffu) {
+        while (r - 1 - b >= 0 && v[k] - v[s_code[r - 1 - b]] <= eps1) ++b;
+        while (r + 1 + a < K && besti[s_code[r + 1 + a]] != 0xffffffffu && v[s_code[r + 1 + a]] - v[k] <= eps1) ++a;
+      }
+      lo_[k] = (int16_t)(r - b);
+      hi_[k] = (int16_t)(r + a);
+    }
+    __syncthreads();
+    SEL_STAMP(14);
+    // the probe codes' constants in LDS, then every previous code p takes its column entries of the probe codes: thread
+    // (p, half) reads 32 of the (at most 64) entries with 32 INDEPENDENT loads in flight - a loop of dependent round trips,
+    // one per probe code, cost 28 us here - and the two halves meet in LDS
+    int np = RC.probe < K ? RC.probe : K;
+    np = np < 64 ? np : 64;
+    double* pf_ = red + 17;                                            // [64] 0.05 x the probe code's frequency rank
+    double* ph_ = pf_ + 64;                                            // [64] hi of its rank
+    int* pk_ = reinterpret_cast<int*>(ph_ + 64);                       // [64] probe code (-1: absent / beyond the probe)
+    double* pm_ = reinterpret_cast<double*>(pk_ + 64);                 // [K][2] the second half's two smallest scores
+    if (tid < K) pm_[tid] = f05;                                       // (staged through pm_: free until the halves meet)
+    __syncthreads();
+    for (int r = tid; r < 64; r += blockDim.x) {
+      const int k = r < np ? s_code[r] : -1;
+      const bool ok = k >= 0 && besti[k] != 0xffffffffu;
+      pk_[r] = ok ? k : -1;
+      pf_[r] = ok ? pm_[k] : 0.0;
+      ph_[r] = ok ? (double)hi_[k] : 0.0;
+    }
+    __syncthreads();
+    double u = -1.0, m1 = __builtin_inf(), m2 = __builtin_inf();
+    const int pp = tid < K ? tid : tid - K, half = tid < K ? 0 : 1;
+    if (tid < 2 * K) {
+      const int r0 = 32 * half;
+      int kk[32];
+      int16_t pv[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) kk[i] = pk_[r0 + i];
+#pragma unroll
+      for (int i = 0; i < 32; ++i)                                      // UNCONDITIONAL (row 0 for a masked entry)
+        pv[i] = RC.pos_t[(int64_t)(kk[i] < 0 ? 0 : kk[i]) * K + pp];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        if (kk[i] < 0) continue;
+        const double sc = ((double)pv[i] + pf_[r0 + i]) + ph_[r0 + i];
+        if (sc < m1) {
+          m2 = m1;
+          m1 = sc;
+        } else if (sc < m2) {
+          m2 = sc;
+        }
+      }
+      if (half) {
+        pm_[2 * pp] = m1;
+        pm_[2 * pp + 1] = m2;
+      }
+    }
+    __syncthreads();
+    if (tid < K) {
+      const double a1 = pm_[2 * pp], a2 = pm_[2 * pp + 1];
+      if (blockDim.x >= 2 * (unsigned)K) {                              // (a block too small for two halves: none here)
+        if (a1 < m1) {
+          m2 = m1 < a2 ? m1 : a2;
+          m1 = a1;
+        } else if (a1 < m2) {
+          m2 = a1;
+        }
+      }
+      u = RC.top_n >= 2 ? m2 : m1;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double t = __shfl_xor(u, o, 64);
+      u = t > u ? t : u;
+    }
+    if (lane == 0) red[wv] = u;
+    __syncthreads();
+    if (tid == 0) {
+      double m = red[0];
+      for (int i = 1; i < nwv; ++i) m = red[i] > m ? red[i] : m;
+      red[16] = m;
+    }
+    __syncthreads();
+    const double umax = red[16];
+    SEL_STAMP(15);
+    for (int k = tid; k < K; k += blockDim.x) need[k] = (besti[k] != 0xffffffffu && (double)lo_[k] <= umax) ? 1 : 0;
+    __syncthreads();
+    for (int r = tid; r < K; r += blockDim.x) {
+      const int k = s_code[r];
+      unsigned char nd = need[k];
+      if (!nd && besti[k] != 0xffffffffu)
+        for (int rr = lo_[k]; rr <= hi_[k] && !nd; ++rr) nd = need[s_code[rr]];
+      need2[k] = nd;
+    }
+    __syncthreads();
+  }
   // ---- list (a): every member of a band with two or more members — from the members pass 2 remembered, or, if there
   // were more than it could hold, by a third pass over the row
   if (ctl[1] && ctl[3] <= MIX_LIST) {
     const int np = ctl[3];
     for (int e = tid; e < np; e += blockDim.x) {
       const int cd = p_k[e];
-      if (near_[cd] < 2) continue;
+      if (near_[cd] < 2 || (need2 && !need2[cd])) continue;
       const int pos = atomicAdd(&ctl[0], 1);
       if (pos < MIX_LIST) {
         l_c[pos] = p_c[e];
@@ -1232,7 +1367,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   } else if (ctl[1]) {
     for (int64_t c = tid; c < C; c += blockDim.x) {
       const int cd = cand_code[c];
-      if ((unsigned)cd >= (unsigned)K || near_[cd] < 2) continue;
+      if ((unsigned)cd >= (unsigned)K || near_[cd] < 2 || (need2 && !need2[cd])) continue;
       if ((double)row[c] <= key_value(best[cd], 0.0) + eps1) {
         const int pos = atomicAdd(&ctl[0], 1);
         if (pos < MIX_LIST) {
@@ -1242,7 +1377,6 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       }
     }
   }
-  for (int k = tid; k < K; k += blockDim.x) v[k] = besti[k] != 0xffffffffu ? key_value(best[k], 0.0) : absent;
   __syncthreads();
   SEL_STAMP(3);
   // ---- list (b): winners of codes whose minima lie within eps1 of ANOTHER code's (only needed when ranks are wanted:
@@ -1252,7 +1386,23 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   // and the two adjacent cells: a single other occupant is tested directly (|dv| < eps1: a hash collision is then harmless -
   // without the test half of the codes were listed, 273 entries per query instead of ~70), two or more list the code
   // without a test (it then gets an f64 value like any other listed code: never wrong, only work).
-  if (out_rank) {
+  if (out_rank && cut) {
+    // (the cut has sorted the table: a code has company iff its [lo, hi] is more than its own rank - neighbours within
+    // eps1 INCLUSIVE, a superset of the grid's test below)
+    const int16_t* lo_ = reinterpret_cast<const int16_t*>(reinterpret_cast<unsigned char*>(pot_c) + 12 * (size_t)rank_sort_pow2(K));
+    const int16_t* hi_ = lo_ + K;
+    for (int k = tid; k < K; k += blockDim.x) {
+      if (besti[k] == 0xffffffffu || lo_[k] == hi_[k] || !need2[k]) continue;
+      if (atomicMax(&near_[k], 2u) >= 2u) continue;                    // band-listed already
+      const int pos = atomicAdd(&ctl[0], 1);
+      if (pos < MIX_LIST) {
+        l_c[pos] = (int)(besti[k] - (unsigned int)idx_base);
+        l_k[pos] = k;
+      }
+    }
+    __syncthreads();
+    SEL_STAMP(4);
+  } else if (out_rank) {
     unsigned int* cell = reinterpret_cast<unsigned int*>(p_c);          // [2048] (p_c / p_k are dead: list (a) is built)
     const double inv_w = 1.0 / (eps1 * 1.000001);
     auto slot = [](long long b) { return (unsigned int)(((unsigned long long)b * 0x9E3779B97F4A7C15ull) >> 53); };
@@ -1281,7 +1431,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
           company = true;
         }
       }
-      if (!company) continue;
+      if (!company || (need2 && !need2[k])) continue;                  // (cut: the walk can not read this code's row)
       if (atomicMax(&near_[k], 2u) >= 2u) continue;                    // band-listed already
       const int pos = atomicAdd(&ctl[0], 1);
       if (pos < MIX_LIST) {
@@ -1341,6 +1491,12 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       l_c[e] = w_lc[e];
       l_k[e] = w_lk[e];
       l_d[e] = w_ld[e];
+    }
+    if (RC.pos_t) {                 // cut lists: which codes have f64 values at all (the rank-level tier 2 asks)
+      unsigned char* isref = reinterpret_cast<unsigned char*>(pot_c);
+      for (int k = tid; k < K; k += blockDim.x) isref[k] = 0;
+      __syncthreads();
+      for (int e = tid; e < n; e += blockDim.x) isref[w_lk[e]] = 1;
     }
     __syncthreads();
   }
@@ -1439,6 +1595,10 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   for (int r = tid; r + 1 < K; r += blockDim.x) {
     const int ka = s_code[r], kb = s_code[r + 1];
     if (besti[ka] == 0xffffffffu || besti[kb] == 0xffffffffu) continue;
+    // (cut lists: two sweep values that happen to coincide belong to rows the walk can not read - nothing to settle)
+    if (phase == 2 && RC.pos_t &&
+        !(reinterpret_cast<const unsigned char*>(pot_c)[ka] && reinterpret_cast<const unsigned char*>(pot_c)[kb]))
+      continue;
     if (v[kb] - v[ka] < A.eps) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -1491,7 +1651,8 @@ static int select_mixed_impl(const char* name, qpg_ctx* ctx, void* stream, const
                              int q_block, int64_t block_stride, const float* base, int T, int F,
                              const int32_t* cand_t, int G, int n_taps, int tap_stride,
                              const float* q32, const double* qn2, const double* cn2, double eps1,
-                             double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16, int parts) {
+                             double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16, int parts,
+                             const RankCut* cut = nullptr) {
   QPG_REQUIRE(ctx && D && (cand_code || C == 0) && out_dist && out_idx && base && cand_t && q32 && qn2 && cn2 && stats,
               "%s: null pointer", name);
   QPG_REQUIRE(Q >= 0 && C >= 0 && K > 0 && K <= 512 && ldD >= C && C + (int64_t)idx_base < 0x7fffffffll,
@@ -1509,6 +1670,8 @@ static int select_mixed_impl(const char* name, qpg_ctx* ctx, void* stream, const
   // fast tier-1 path (WavLM geometry: 6 taps x 1024 features): the query row is staged in LDS (+24 KB: 123 KB in all, one block per CU)
   const int use_qlds = (n_taps == 6 && F == 1024) ? 1 : 0;
   const size_t sh2 = 32 * (size_t)K + 16 * MIX_LIST + 4 * MIX_LIST2 + 32 + 6 * MIX_LIST + 4 * (size_t)K;   // merge phase
+  size_t sh2c = sh2;                                                                                       // ... + the cut's scratch
+  const RankCut RCnone = {nullptr, nullptr, 1, 0};
   const size_t sh1 = sh2 + 6 * MIX_POT;                                                                    // list phase
   const size_t sh = sh1 + (use_qlds ? (size_t)n_taps * F * 4 : 0);                                         // one launch
   if (!ctx->select_lds_raised) {
@@ -1528,7 +1691,8 @@ static int select_mixed_impl(const char* name, qpg_ctx* ctx, void* stream, const
 #define SEL_MIX_LAUNCH(DT, SH, PHASE, PRE)                                                                                  \
   hipLaunchKernelGGL((percode_select_mixed_f64_kernel<DT>), dim3(Q), dim3(1024), SH, qpg_stream(stream),               \
                      static_cast<const DT*>(D), ldD, cand_code, C, K, absent, idx_base, out_dist, out_idx, out_rank,   \
-                     q_block, block_stride, A, eps1, cn2, qn2, use_qlds, PHASE, w, PRE)
+                     q_block, block_stride, A, eps1, cn2, qn2, use_qlds, PHASE, w, PRE, RCv)
+  RankCut RCv = RCnone;
   if (!ws) {
     QPG_REQUIRE(parts == 3, "%s: the one-launch form (no workspace) cannot be issued in parts", name);
     if (d_is_f32) SEL_MIX_LAUNCH(float, sh, 0, 0); else SEL_MIX_LAUNCH(double, sh, 0, 0);
@@ -1545,7 +1709,12 @@ static int select_mixed_impl(const char* name, qpg_ctx* ctx, void* stream, const
       QPG_LAUNCH_CHECK("mixed_stream_kernel");
     }
     if (!(parts & 2)) return QPG_OK;
-    SEL_MIX_LAUNCH(float, sh2, 1, 1);
+    if (cut && cut->pos_t && out_rank) {          // walk-relevance cut: the list and merge launches get its scratch
+      RCv = *cut;
+      sh2c = sh2 + 12 * (size_t)rank_sort_pow2(K) + 8 * (size_t)((K + 7) / 8 * 8) + 17 * 8 + 64 * (8 + 8 + 4) +
+             16 * (size_t)K;
+    }
+    SEL_MIX_LAUNCH(float, sh2c, 1, 1);
   } else {
     SEL_MIX_LAUNCH(double, sh1, 1, 0);
   }
@@ -1553,7 +1722,7 @@ static int select_mixed_impl(const char* name, qpg_ctx* ctx, void* stream, const
   const int rb = Q >= 512 ? 8 : (Q >= 128 ? 16 : 64);         // waves per query = 4 rb
   hipLaunchKernelGGL((select_refine_kernel<4>), dim3(Q, rb), dim3(256), 0, qpg_stream(stream), A, K, cn2, qn2, w, use_qlds);
   QPG_LAUNCH_CHECK("select_refine_kernel");
-  if (d_is_f32) SEL_MIX_LAUNCH(float, sh2, 2, 0); else SEL_MIX_LAUNCH(double, sh2, 2, 0);
+  if (d_is_f32) SEL_MIX_LAUNCH(float, sh2c, 2, 0); else SEL_MIX_LAUNCH(double, sh2, 2, 0);
   QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel (merge)");
 #undef SEL_MIX_LAUNCH
   return QPG_OK;
@@ -1569,6 +1738,28 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
   return select_mixed_impl("qpg_percode_select_mixed_f64", ctx, stream, D, d_is_f32, ldD, Q, cand_code, C, K, absent, idx_base,
                            out_dist, out_idx, out_rank, q_block, block_stride, base, T, F, cand_t, G, n_taps, tap_stride, q32,
                            qn2, cn2, eps1, eps2, stats, ws, ws_bytes, base_is_f16, 3);
+}
+
+// The four-launch form with the walk-relevance cut (RankCut above): pos_rank_t [dev] i16 [K][K] = the TRANSPOSE of
+// qpg_match_steps' pos_rank, freq_rank [dev] i16 [K], top_n = how many of a step's best fused scores the walk reads (1 with
+// the text side, 2 without: GestureKNN.py:593, :627-657), probe = the number of best-ranked codes the bound on the winning
+// score is taken over (0: 64).  out_rank is required, an f32 matrix and a workspace too.
+extern "C" int qpg_percode_select_mixed_f64_cut(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
+                                                const int16_t* cand_code, int64_t C, int K, double absent,
+                                                int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
+                                                int q_block, int64_t block_stride, const float* base, int T, int F,
+                                                const int32_t* cand_t, int G, int n_taps, int tap_stride,
+                                                const float* q32, const double* qn2, const double* cn2, double eps1,
+                                                double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16,
+                                                const int16_t* pos_rank_t, const int16_t* freq_rank, int top_n, int probe) {
+  const char* name = "qpg_percode_select_mixed_f64_cut";
+  QPG_REQUIRE(pos_rank_t && freq_rank && out_rank && ws && d_is_f32 && q_block == 0 && (top_n == 1 || top_n == 2) &&
+                  probe >= 0,
+              "%s: needs the rank tables, out_rank, an f32 matrix, a workspace, no block layout, top_n 1 or 2", name);
+  RankCut rc = {pos_rank_t, freq_rank, top_n, probe > 0 ? probe : 64};
+  return select_mixed_impl(name, ctx, stream, D, d_is_f32, ldD, Q, cand_code, C, K, absent, idx_base, out_dist, out_idx,
+                           out_rank, q_block, block_stride, base, T, F, cand_t, G, n_taps, tap_stride, q32, qn2, cn2, eps1, eps2,
+                           stats, ws, ws_bytes, base_is_f16, 3, &rc);
 }
 
 extern "C" int qpg_percode_select_mixed_f64_parts(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,

@@ -465,3 +465,61 @@ def test_clips_in_flight_on_a_full_size_db_equal_serial_clips():
                 assert np.array_equal(a, b)
     assert pipe.fallbacks == 0
     assert len({id(ln["knn"]._txt_scratch) for ln in pipe.lanes}) == 3
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("speechlike", [False, True])
+def test_walk_relevance_cut_returns_the_same_walk(mode, speechlike):
+    """sweep_tables(for_walk=True): the audio select settles in f64 only what the walk can read (codes whose rank is
+    certainly above every step's winning fused score keep their sweep values: qpg_percode_select_mixed_f64_cut).  On a
+    full-size DB with planted near-copies: far fewer f64 re-evaluations, and for many seeds - every previous code the first
+    step can start from - codes, votes and phase blocks equal those of the exact tables; rank and candidate of every code
+    the walk can read are the exact ones, every distance stays inside the sweep's bound and no rank moved by more than
+    its tie neighbourhood allows."""
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    N, M = 1024, 6
+    d = _db(N, 31, speechlike=speechlike)
+    rs = np.random.RandomState(5)
+    for _ in range(60):                                        # near-copies: within-code and cross-code near-ties
+        j, k = rs.choice(N, 2, replace=False)
+        eps = 0.0 if rs.rand() < 0.2 else 10.0 ** rs.uniform(-7.5, -5.0)
+        d["interp"][k] = (d["interp"][j] * (1.0 + eps * rs.standard_normal(d["interp"][j].shape))).astype(np.float32)
+        if rs.rand() < 0.5:
+            d["code"][k] = d["code"][j]
+    dev = torch.device("cuda:0")
+    db = GestureDB(d["code"], d["interp"], d["ctx"], d["phase"], d["sig"], device=dev)
+    te = _db(M, 77, speechlike=speechlike)
+    te_i, te_c = torch.from_numpy(te["interp"]).to(dev), torch.from_numpy(te["ctx"]).to(dev)
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    assert knn.rank_cut
+    s0 = knn.mixed_stats()
+    T = knn.sweep_tables(te_i, te_c, M, mode=mode)
+    s1 = knn.mixed_stats()
+    Tc = knn.sweep_tables(te_i, te_c, M, mode=mode, for_walk=True)
+    s2 = knn.mixed_stats()
+    assert knn._last_rank_cut and knn._last_audio_hl and s2["flags"] == 0
+    full, cut = s1["tier1_pairs"] - s0["tier1_pairs"], s2["tier1_pairs"] - s1["tier1_pairs"]
+    print("tier-1 pairs: exact tables %d, cut %d" % (full, cut))
+    assert 0 < cut < 0.6 * full
+    # every code whose entry differs kept its sweep value (inside the bound) and its rank moved inside its neighbourhood
+    dd = (T["aud_d"] - Tc["aud_d"]).abs()
+    assert float(dd.max()) <= 1.3e-6
+    moved = (T["aud_rank"].to(torch.int32) - Tc["aud_rank"].to(torch.int32)).abs()
+    assert int(moved.max()) <= 8
+    # a code the walk can read: the best fused score of some previous code - all of those rows are exact
+    pr, fr = db.pos_rank.to(torch.float64), db.freq_rank.to(torch.float64)
+    for q in range(T["aud_rank"].shape[0]):
+        sc = pr + 0.05 * fr[None, :] + T["aud_rank"][q].to(torch.float64)[None, :]            # [prev][code]
+        top = torch.topk(sc, 2 if mode == 1 else 1, dim=1, largest=False).indices.reshape(-1).unique()
+        assert torch.equal(T["aud_rank"][q][top], Tc["aud_rank"][q][top])
+        assert torch.equal(T["aud_idx"][q][top], Tc["aud_idx"][q][top])
+        # (their DISTANCES are only equal inside the bound: the exact tables' grid test also re-evaluates codes whose
+        # nearest neighbour is up to 2 eps1 away, the cut's sorted scan only those within eps1 - the walk reads ranks and
+        # candidates, never distances)
+    for seed_code in list(range(0, 512, 7)) + [511]:
+        sp = rs.standard_normal((8, 16)).astype(np.float32)
+        a = knn.walk(T, M, mode=mode, seed_code=seed_code, seed_phase=sp)
+        b = knn.walk(Tc, M, mode=mode, seed_code=seed_code, seed_phase=sp)
+        ph = [x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x) for x in (a[1], b[1])]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(ph[0], ph[1]), seed_code

@@ -42,7 +42,7 @@ g = knn.capture_clip_graph(M, mode=mode, audio=te_i, context=te_c, owner_blocks=
 def step():
     if graph:
         return g.run_ints(sc, sp)
-    T = knn.sweep_tables(te_i, te_c, M, mode=mode, owner_blocks=knn.force_sharded)
+    T = knn.sweep_tables(te_i, te_c, M, mode=mode, owner_blocks=knn.force_sharded, for_walk=True)
     return knn.walk(T, M, 0, mode=mode, seed_code=sc, seed_phase=spd, sync="ints")      # (codes | votes | status, pinned host memory)
 
 
