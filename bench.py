@@ -482,6 +482,7 @@ def main():
     codes = run_steps(a.steps)
     fence()
     dt = time.perf_counter() - t0
+    cut_used = bool(getattr(knn_g if graph_mode else knn, "_last_rank_cut", False))     # (of the timed steps' last sweep)
     gc.enable()
     if os.environ.get("QPG_BENCH_STEP_TIMES", "") == "1" and pipe is None:
         print("per-step ms (timed region):", ["%.3f" % (x * 1e3) for x in step_times[-a.steps:]], file=sys.stderr)
@@ -785,7 +786,7 @@ def main():
             "f64_dot_pairs_per_step": round(st["tier1_pairs"] / n_run, 1),
             # the timed steps' select settles in f64 only what the walk can read (QPG_RANK_CUT=0: everything);
             # the tables compared with the f64 sweep below are the fully settled ones, the CODES compared are the timed steps'
-            "walk_relevance_cut": bool(getattr(knn_g if graph_mode else knn, "_last_rank_cut", False)),
+            "walk_relevance_cut": cut_used,
             "reference_arithmetic_pairs_per_step": round(st["tier2_pairs"] / n_run, 2),
             "flags": st["flags"], "error_bound": 1.3e-6 if hl else 2.05e-6,
             # the one measured constant under that bound, re-measured at load time on THIS device (selfcheck.py)

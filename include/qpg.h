@@ -374,14 +374,14 @@ int64_t qpg_percode_select_mixed_ws_stride(int K);
  * position among them; every entry the walk can read - and therefore every selected code index - is what
  * qpg_percode_select_mixed_f64 returns.  pos_rank_t [dev] i16 [K][K]: the TRANSPOSE of qpg_match_steps' pos_rank
  * (pos_rank_t[c * K + p]); freq_rank [dev] i16 [K]; top_n: 1 with the text side, 2 without; probe: best-ranked codes the
- * bound on the winning score is taken over (0: 64). */
+ * bound on the winning score is taken over (0: 64); parts: 3 = the whole call (1 / 2: see ..._parts below). */
 int qpg_percode_select_mixed_f64_cut(qpg_ctx*, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
                                      const int16_t* cand_code, int64_t C, int K, double absent, int32_t idx_base,
                                      double* out_dist, int32_t* out_idx, int16_t* out_rank, int q_block, int64_t block_stride,
                                      const float* base, int T, int F, const int32_t* cand_t, int G, int n_taps,
                                      int tap_stride, const float* q32, const double* qn2, const double* cn2, double eps1,
                                      double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16,
-                                     const int16_t* pos_rank_t, const int16_t* freq_rank, int top_n, int probe);
+                                     const int16_t* pos_rank_t, const int16_t* freq_rank, int top_n, int probe, int parts);
 /* The same call issued in PARTS (f32 matrix + workspace only): parts = 1 the streaming pass alone, 2 everything behind it,
  * 3 both (= qpg_percode_select_mixed_f64).  Same arguments for both halves.  For the host's scheduling: between the two
  * halves it records the event the text side's prefilter GEMM waits for, so that the streaming pass (on the clip's critical

@@ -62,7 +62,7 @@ _SIGS = {
     "qpg_percode_select_mixed_f64": [P, I, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
                                      P, P, c_double, c_double, P, P, L, I],
     "qpg_percode_select_mixed_f64_cut": [P, I, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I,
-                                         P, P, P, c_double, c_double, P, P, L, I, P, P, I, I],
+                                         P, P, P, c_double, c_double, P, P, L, I, P, P, I, I, I],
     "qpg_percode_select_mixed_f64_parts": [P, I, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I,
                                            P, P, P, c_double, c_double, P, P, L, I, I],
     "qpg_percode_select_exact_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,

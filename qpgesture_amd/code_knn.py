@@ -555,13 +555,17 @@ class CodeKNN:
                         AUDIO_HL_BAND if use_hl else AUDIO_MX_BAND, float(self.tie_eps),
                         self._guard_stats, None if self.mixed_single_launch else ws,
                         0 if self.mixed_single_launch else ws.numel(), int(half))
-            use_cut = (cut_top_n in (1, 2) and local_final and rank is not None and not self.mixed_single_launch and
-                       not getattr(self, "_want_stream_event", False))
+            use_cut = cut_top_n in (1, 2) and local_final and rank is not None and not self.mixed_single_launch
             self._last_rank_cut = use_cut
             try:
                 if use_cut:
-                    _lib.call("qpg_percode_select_mixed_f64_cut", dev, *sel_args, db.pos_rank_t, db.freq_rank,
-                              int(cut_top_n), int(self.rank_cut_probe))
+                    cut_args = sel_args + (db.pos_rank_t, db.freq_rank, int(cut_top_n), int(self.rank_cut_probe))
+                    if getattr(self, "_want_stream_event", False):
+                        _lib.call("qpg_percode_select_mixed_f64_cut", dev, *cut_args, 1)
+                        self._record_sweep_event(dev)
+                        _lib.call("qpg_percode_select_mixed_f64_cut", dev, *cut_args, 2)
+                    else:
+                        _lib.call("qpg_percode_select_mixed_f64_cut", dev, *cut_args, 3)
                 elif getattr(self, "_want_stream_event", False) and not self.mixed_single_launch:
                     # sweep_tables gates the text side's GEMM on the END of the streaming pass: the pass (all CUs, on the
                     # critical path) then runs alone, and the GEMM beside the list pass (one block per query)

@@ -1743,7 +1743,8 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
 // The four-launch form with the walk-relevance cut (RankCut above): pos_rank_t [dev] i16 [K][K] = the TRANSPOSE of
 // qpg_match_steps' pos_rank, freq_rank [dev] i16 [K], top_n = how many of a step's best fused scores the walk reads (1 with
 // the text side, 2 without: GestureKNN.py:593, :627-657), probe = the number of best-ranked codes the bound on the winning
-// score is taken over (0: 64).  out_rank is required, an f32 matrix and a workspace too.
+// score is taken over (0: 64); parts as in qpg_percode_select_mixed_f64_parts (3: the whole call).  out_rank is required,
+// an f32 matrix and a workspace too.
 extern "C" int qpg_percode_select_mixed_f64_cut(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
                                                 const int16_t* cand_code, int64_t C, int K, double absent,
                                                 int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
@@ -1751,15 +1752,16 @@ extern "C" int qpg_percode_select_mixed_f64_cut(qpg_ctx* ctx, void* stream, cons
                                                 const int32_t* cand_t, int G, int n_taps, int tap_stride,
                                                 const float* q32, const double* qn2, const double* cn2, double eps1,
                                                 double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16,
-                                                const int16_t* pos_rank_t, const int16_t* freq_rank, int top_n, int probe) {
+                                                const int16_t* pos_rank_t, const int16_t* freq_rank, int top_n, int probe,
+                                                int parts) {
   const char* name = "qpg_percode_select_mixed_f64_cut";
   QPG_REQUIRE(pos_rank_t && freq_rank && out_rank && ws && d_is_f32 && q_block == 0 && (top_n == 1 || top_n == 2) &&
-                  probe >= 0,
-              "%s: needs the rank tables, out_rank, an f32 matrix, a workspace, no block layout, top_n 1 or 2", name);
+                  probe >= 0 && parts >= 1 && parts <= 3,
+              "%s: needs the rank tables, out_rank, an f32 matrix, a workspace, no block layout, top_n 1 or 2, parts 1..3", name);
   RankCut rc = {pos_rank_t, freq_rank, top_n, probe > 0 ? probe : 64};
   return select_mixed_impl(name, ctx, stream, D, d_is_f32, ldD, Q, cand_code, C, K, absent, idx_base, out_dist, out_idx,
                            out_rank, q_block, block_stride, base, T, F, cand_t, G, n_taps, tap_stride, q32, qn2, cn2, eps1, eps2,
-                           stats, ws, ws_bytes, base_is_f16, 3, &rc);
+                           stats, ws, ws_bytes, base_is_f16, parts, &rc);
 }
 
 extern "C" int qpg_percode_select_mixed_f64_parts(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
