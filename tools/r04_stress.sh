@@ -6,5 +6,6 @@ run parity python tools/stress_parity.py 40
 run mixed python tools/stress_mixed.py 40
 run sharded_mixed python tools/stress_sharded_mixed.py 30
 run text python tools/stress_text.py 40
+run cut python tools/stress_cut.py 40
 run vqvae python tools/stress_vqvae.py 16
 cat $O/summary.txt
