@@ -470,6 +470,7 @@ class CodeKNN:
                  (local_final or (shard_part and self.sharded_mixed and gflop >= self.sharded_mixed_min_gflop)))
         exact = self.audio_precision == "exact" and self.tie_eps > 0 and C > 0
         self._last_audio_mixed, self._last_audio_exact = mixed, exact
+        self._last_rank_cut = False
         # the mixed-precision sweep stores its matrix in f32: it only feeds the select's two streaming passes
         D = torch.empty((Q, max(C, 1)), dtype=torch.float32 if mixed else torch.float64, device=dev)
         ev = getattr(self, "kernel_events", None)       # bench.py: HIP events around the dominant kernel
