@@ -1524,6 +1524,29 @@ static int hl_gemm_impl(const char* name, qpg_ctx* ctx, void* stream, const void
   }
   // (a clip's 48 text queries stay on the 16-row kernel: it runs UNDER the audio sweep, where the slimmer kernel gets more
   // of the slots the sweep leaves - measured inside the step: 0.273-0.283 ms against 0.281-0.282 with this kernel)
+  static int small32 = -1;                     // QPG_GEMM32_Q48=1 (measurements): <= 48 queries on the 32-row kernel with
+  if (small32 < 0) {                           // THREE column tiles (half a chunk's MFMAs) instead of the 16-row kernel
+    const char* e = getenv("QPG_GEMM32_Q48");
+    small32 = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (use32 && small32 && (KB % G32_RING) == 0 && Q <= 48) {
+    const size_t lds32 = 2 * (size_t)G32_KS * HL_CT * 2 * HL_PIECE;
+    static bool raised33 = false;
+    if (!raised33) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(hl_gemm32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds32) != hipSuccess) {
+        qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
+        return QPG_EHIP;
+      }
+      raised33 = true;
+    }
+    const int64_t g8 = (a.N + 7) / 8;
+    const int n_items = (int)(g8 * chunks);
+    const int n_blocks = n_items < ctx->n_cu ? n_items : ctx->n_cu;
+    hipLaunchKernelGGL(hl_gemm32_kernel<3>, dim3(n_blocks), dim3(512), lds32, qpg_stream(stream), a, n_items);
+    QPG_LAUNCH_CHECK("hl_gemm32_kernel<3>");
+    return QPG_OK;
+  }
   if (use32 && (KB % G32_RING) == 0 && Q > 48) {
     const size_t lds32 = 2 * (size_t)G32_KS * HL_CT * 2 * HL_PIECE;   // 48 KB
     static bool raised32 = false;
