@@ -24,6 +24,33 @@ def _build(meta, dev="cuda:0", freq_rank=None):
     return A, db, knn, te_i, te_c, nte
 
 
+@pytest.mark.parametrize("name", GOLDENS)
+def test_own_frequency_ranks_vs_the_reference_s(name):
+    """The table tests hand the matcher the reference's captured frequency ranks (`freq_rank=g["step_freq_score"]`); this
+    one checks the product's OWN ranking (GestureDB without freq_rank: code_to_freq on the host, qpg_rank_rows_f64 on the
+    device; GestureKNN.py:481-499, :544): it is the stable rank of 1 - count / total (value, then code index); it equals
+    the reference's captured rank wherever a frequency is unique, and inside every group of equal frequencies (NumPy's
+    default argsort leaves their order open) both hold the same set of ranks.  And the clip matched with the product's own
+    ranks returns the reference's codes."""
+    g = load_golden(name)
+    A, db, knn, te_i, te_c, M = _build(g["meta"])                       # freq_rank=None: the product's own
+    code = np.asarray(A["code"]).reshape(-1)
+    cnt = np.bincount(code, minlength=512)[:512]
+    f = np.where(cnt > 0, 1 - cnt / cnt.sum(), 1.0)
+    mine = db.freq_rank.cpu().numpy().astype(np.int64)
+    ref = np.asarray(g["step_freq_score"]).astype(np.int64)
+    assert np.array_equal(mine, np.argsort(np.argsort(f, kind="stable"), kind="stable"))
+    assert sorted(mine.tolist()) == list(range(512)) and sorted(ref.tolist()) == list(range(512))
+    for v in np.unique(f):                    # (small DBs: a handful of distinct counts, every one shared by many codes)
+        ix = np.where(f == v)[0]
+        assert sorted(mine[ix].tolist()) == sorted(ref[ix].tolist())
+        if len(ix) == 1:
+            assert mine[ix[0]] == ref[ix[0]]
+    if np.array_equal(mine, ref):                                       # (ties broken alike: the whole clip must agree)
+        codes, phases, votes = knn.match_clip(te_i, te_c, M)
+        assert np.array_equal(codes, g["knn_pred"]) and np.array_equal(votes, g["vote"])
+
+
 @pytest.mark.parametrize("prec", ["f64", "mixed"])
 @pytest.mark.parametrize("name", GOLDENS)
 def test_tables_vs_reference_golden(name, prec):
