@@ -209,3 +209,65 @@ def test_ranks_agree_on_a_rematch(tmp_path):
     mp.spawn(_worker_flags, args=(3, _free_port(), out), nprocs=3, join=True)
     for r in range(3):
         assert np.load(out % r).tolist() == [0, 4, 8]
+
+
+def _worker_segments(rank, world, port, out):
+    """parallel.SegmentRecorder.cut on CPU (the hipGraph halves stubbed out): the collectives of a recorded clip are
+    closures over PERSISTENT buffers - calling them again ("replay") exchanges whatever the send buffers hold then, into
+    the same receive buffers the first call returned."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qpgesture_amd import parallel as par
+
+    class CpuRecorder(par.SegmentRecorder):
+        def __init__(self):
+            self.program, self.kinds, self._keep, self._g = [], [], [], None
+            self.n_begin = self.n_end = 0
+
+        def begin(self):
+            self.n_begin += 1
+
+        def end(self):
+            self.n_end += 1
+
+    send_a2a = torch.arange(8, dtype=torch.uint8) + 10 * rank                 # two blocks of 4 bytes: block r -> rank r
+    send_ag = torch.arange(3, dtype=torch.uint8) + 100 * rank
+    word = torch.tensor([rank + 1], dtype=torch.int32)
+    rec = CpuRecorder()
+    par._recorder = rec
+    try:
+        rec.begin()
+        r1 = par.exchange_bytes(send_a2a, world, True)
+        r2 = par.exchange_bytes(send_ag, world, False)
+        par.allreduce_max_(word, force=True)
+        rec.end()
+    finally:
+        par._recorder = None
+    ok = rec.kinds == ["collective"] * 3 and rec.n_begin == 4 and rec.n_end == 4 and par._recorder is None
+    want1 = torch.cat([torch.arange(4, dtype=torch.uint8) + 4 * rank + 10 * w for w in range(world)])
+    want2 = torch.cat([torch.arange(3, dtype=torch.uint8) + 100 * w for w in range(world)])
+    ok = ok and torch.equal(r1, want1) and torch.equal(r2, want2) and int(word) == world
+    # "replay": new contents of the same send buffers, the recorded closures, the same receive buffers
+    send_a2a += 1
+    send_ag += 2
+    word.fill_(7 * (rank + 1))
+    p1, p2 = r1.data_ptr(), r2.data_ptr()
+    for fn in rec.program:
+        fn()
+    ok = ok and torch.equal(r1, want1 + 1) and torch.equal(r2, want2 + 2) and int(word) == 7 * world
+    ok = ok and r1.data_ptr() == p1 and r2.data_ptr() == p2
+    # and the plain calls (no recorder) still return fresh buffers with the same contents
+    f1 = par.exchange_bytes(send_a2a, world, True)
+    ok = ok and torch.equal(f1, r1) and f1.data_ptr() != r1.data_ptr()
+    res = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(res, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        np.savez(out, ok=res.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_segment_recorder_collectives_replay_on_persistent_buffers(tmp_path):
+    out = str(tmp_path / "s.npz")
+    mp.spawn(_worker_segments, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert int(np.load(out)["ok"][0]) == 1
