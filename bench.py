@@ -336,10 +336,13 @@ def main():
     # QPG_FORCE_SHARDED=1 QPG_EXPERIMENTAL_SHARDED_GRAPH=1 - but replays followed by eager collectives on the same
     # communicator hung this ROCm / torch build, and this script needs both.)  QPG_BENCH_SHARDED_EAGER=1: shards eager.
     shards_eager = sharded_run and os.environ.get("QPG_BENCH_SHARDED_EAGER", "") == "1" and a.step_mode != "graph"
-    graph_mode = (a.step_mode == "graph" or (a.step_mode == "auto" and not a.no_graph)) and CL == 1 and \
-        enc is None and a.clips_in_flight == 1 and not shards_eager and (world == 1 or sharded_run or replicated)
+    # (round 5: several clips per replay and the VQ-VAE encode leg inside the capture - BASELINE configs[4] - on one GPU or a
+    # replicated database; row shards are captured one clip per rank)
+    multi_ok = (CL == 1 and enc is None) or (not sharded_run)
+    graph_mode = (a.step_mode == "graph" or (a.step_mode == "auto" and not a.no_graph)) and multi_ok and \
+        a.clips_in_flight == 1 and not shards_eager and (world == 1 or sharded_run or replicated)
     if a.step_mode == "graph" and not graph_mode:
-        raise SystemExit("--step-mode graph: one clip per step and rank, no encode leg, no clips in flight")
+        raise SystemExit("--step-mode graph: no clips in flight; row shards: one clip per step and rank, no encode leg")
     cg, graph_fallback = None, None
     if graph_mode:
         knn_g = CodeKNN(db, rng=np.random.RandomState(123456))      # (its own workspaces / side stream: the capture's)
@@ -352,7 +355,8 @@ def main():
         knn_g.force_sharded, knn_g.sharded_mixed_min_gflop, knn_g.mixed_requests = (
             knn.force_sharded, knn.sharded_mixed_min_gflop, knn.mixed_requests)
         cg = knn_g.capture_clip_graph(M, n_sweep_windows=M * n_sweep_clips, audio=te_interp, context=te_ctx,
-                                      owner_blocks=sharded_run and not strong)
+                                      owner_blocks=sharded_run and not strong, n_clips=my_clips,
+                                      encoder=enc, encode_input=enc_x if enc is not None else None)
         if sharded_run:
             # the segments are recorded NOW, and every rank ends up in the same step mode: a capture that failed on any
             # rank sends all of them to the eager step (MIN over the ranks of "captured")
@@ -370,12 +374,17 @@ def main():
                 graph_mode, cg = False, None
                 graph_fallback = graph_fallback or "the capture failed on another rank"
 
+    graph_fallbacks = [0]
+
     def step_graph():
         arr = cg.run_ints(seed_code, seed_phase)
-        if arr[-1] != 0:                           # the trouble word came out with the codes: this clip again, eagerly
+        st_ = cg.statuses(arr)
+        if (st_[:, 1] != 0).any():                 # a trouble word came out with the codes: this step again, eagerly
+            graph_fallbacks[0] += 1                # (ClipGraph.wait_ints cleared the capture's matcher's sticky word)
             return step_eager()
-        knn.check_status(arr[-2:])
-        return arr[:n_codes].reshape(M, 30)
+        for c in range(my_clips):
+            knn.check_status(st_[c])
+        return arr[:my_clips * n_codes].reshape(my_clips * M, 30)
 
     step = step_graph if graph_mode else step_eager
 
@@ -569,16 +578,33 @@ def main():
         # split-operand f16 sweep: every database frame is read once from the frame-major image (27 super-rows x 3 frames
         # x F x 4 B per window = the 81 even frames), the matrix leaves in f32; three f16 MFMAs per 32 k-steps of a
         # 32-row x 96-column tile (27 of 32 rows live)
-        alg_bytes = db.n_local * 81 * db.F * 4 + C * 8 + Q * 6 * db.F * 4 + Q * C * 4
+        planes = int(getattr(db, "hl_planes", 2))      # 1: the f16-stored track is its own h plane (qpg_audio_cosine_hl1)
+        alg_bytes = db.n_local * 81 * db.F * (4 if planes == 2 else 2) + C * 8 + Q * 6 * db.F * 4 + Q * C * 4
         chunks = (Q + 47) // 48
-        mfma_issued = 3 * 2.0 * (db.n_local * 32) * (chunks * 96) * (3 * db.F)
+        mfma_issued = (planes + 1) * 2.0 * (db.n_local * 32) * (chunks * 96) * (3 * db.F)
         gbs = alg_bytes / (k_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    **pmc_traffic("audio_cosine_hl2_kernel|N_db=2048 Q=48" if default_shape else None),
-                    "kernel": ("audio_cosine_hl2_kernel (split-operand f16 matrix cores on a frame-major image: every "
-                               "database frame read once, 32-row wave tiles; chain sums added in f64, error bounded a "
-                               "priori, f64 re-evaluation in the select)"),
+        tfs = mfma_issued / (k_ms * 1e-3) / 1e12
+        # which roof: the launch's arithmetic intensity (issued matrix flops per algorithmic byte) against the ridge of the
+        # two peaks - one clip (Q = 48) sits below it (HBM-bound), 16 clips per sweep far above (matrix-bound)
+        ridge = F16_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        intensity = mfma_issued / alg_bytes
+        on_hbm = intensity < ridge
+        kname = "audio_cosine_hl2_kernel<%d, %d>" % (planes, 2 if planes == 2 else 3)
+        pkey = None
+        if world == 1 and N == 2048 and M == 6:
+            pkey = "%s|N_db=2048 Q=%d" % ("audio_cosine_hl2_kernel" if planes == 2 else "audio_cosine_hl1", Q)
+        roofline = {"bound": "hbm" if on_hbm else "mfma",
+                    "achieved": round(gbs, 1) if on_hbm else round(tfs, 1),
+                    "peak": HBM_PEAK_GBS if on_hbm else F16_MFMA_PEAK_TFLOPS, "unit": "GB/s" if on_hbm else "TFLOP/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4) if on_hbm else round(tfs / F16_MFMA_PEAK_TFLOPS, 4),
+                    "arithmetic_intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+                    **pmc_traffic(pkey),
+                    **rocprof_kernel_ms(pkey),
+                    "kernel": ("%s (split-operand f16 matrix cores on a frame-major image: every database frame read once, "
+                               "32-row wave tiles; %s; chain sums added in f64, error bounded a priori, f64 re-evaluation "
+                               "in the select)" % (kname, "two planes h | l of the f32 track, three products per element"
+                                                   if planes == 2 else
+                                                   "ONE plane: the f16-stored track is its own h, two products per element")),
                     "kernel_ms_source": ("HIP events around the kernel on its launch stream in the %d eager steps run right "
                                          "behind the timed region (a replayed graph's nodes cannot be bracketed)" % a.steps)
                     if graph_mode else "HIP events around the kernel on its launch stream, every timed step",
@@ -703,12 +729,25 @@ def main():
         sc2 = (seed_code + 101) % 512
         sp2 = np.roll(seed_phase, 3, axis=0)
         g2 = cg.run_ints(sc2, sp2)
-        e2 = knn.walk(knn.sweep_tables(te_interp, te_ctx, M * n_sweep_clips, owner_blocks=sharded_run and not strong), M,
-                      seed_code=sc2, seed_phase=sp2, sync="ints")
+        T2 = knn.sweep_tables(te_interp, te_ctx, M * n_sweep_clips, owner_blocks=sharded_run and not strong)
+        if my_clips == 1:
+            e2 = knn.walk(T2, M, seed_code=sc2, seed_phase=sp2, sync="ints")
+            same2 = bool(np.array_equal(g2[:e2.size], e2))
+        else:
+            knn.walk_batch(T2, M, my_clips, [sc2] * my_clips, np.tile(sp2.reshape(1, -1), (my_clips, 1)))
+            e2 = knn._last_ints.cpu().numpy()                 # [clip][codes | votes | status]
+            same2 = bool(np.array_equal(cg.codes(g2).reshape(my_clips, -1), e2[:, :n_codes]) and
+                         np.array_equal(cg.statuses(g2), e2[:, -2:]))
+        enc_same = None
+        if enc is not None:
+            enc_same = bool(np.array_equal(cg.encoded_ids(g2), enc.encode(enc_x)[0].cpu().numpy()))
         out["graph_replay"] = {"ms_per_step": out["ms_per_step"], "steps": a.steps, "captures": cg.captures,
-                               "is_the_timed_region": True,
+                               "is_the_timed_region": True, "clips_per_replay": my_clips,
+                               "fallbacks_to_eager_in_the_timed_region": graph_fallbacks[0],
+                               **({"encode_leg_in_the_capture": True, "encoded_ids_equal_eager_encode": enc_same}
+                                  if enc is not None else {}),
                                "text_side_captured_first": bool(not knn_g.audio_first and knn_g.audio_first is not None),
-                               "other_seed_equals_eager": bool(np.array_equal(g2, e2)),
+                               "other_seed_equals_eager": same2,
                                **({"segments": list(cg.segment_kinds)} if cg.segmented else {})}
     if (mixed and not sharded_run and world == 1 and can_pipe and pipe is None and not a.no_f64_line and
             os.environ.get("QPG_BENCH_NO_PIPELINED", "") != "1"):
@@ -791,7 +830,7 @@ def main():
             "flags": st["flags"], "error_bound": 1.3e-6 if hl else 2.05e-6,
             # the one measured constant under that bound, re-measured at load time on THIS device (selfcheck.py)
             "mfma_selfcheck": {k_: db.hl_bound_report.get(k_) for k_ in ("kappa", "kappa2", "kappa2_assumed", "kappa2_limit",
-                                                                         "kappa6", "kappa6_assumed", "subnormals_exact",
+                                                                         "kappa6", "kappa4", "kappa6_assumed", "subnormals_exact",
                                                                          "skipped")},
             "max_table_difference_vs_f64_sweep": float((Tm["aud_d"] - T64["aud_d"]).abs().max()),
             "winners_equal_f64_sweep": bool(torch.equal(Tm["aud_idx"], T64["aud_idx"])),
@@ -828,6 +867,21 @@ def main():
         print(json.dumps(out), file=JSON_OUT, flush=True)
     if world > 1 or force_sharded:
         dist.destroy_process_group()
+
+
+def rocprof_kernel_ms(key):
+    """The dominant kernel's average duration over ALL launches of a profiled run of this command - graph replays included,
+    which HIP events cannot bracket - from the committed rocprofv3 --kernel-trace --stats summary (profiles/
+    kernel_replay.json, written by tools/make_profile_summary.py); null for shapes that were not profiled."""
+    path = os.path.join(ROOT, "profiles", "kernel_replay.json")
+    if key is None or not os.path.exists(path):
+        return {"kernel_ms_rocprof": None}
+    rec = json.load(open(path)).get(key)
+    if rec is None:
+        return {"kernel_ms_rocprof": None}
+    return {"kernel_ms_rocprof": round(rec["avg_us"] / 1e3, 4),
+            "kernel_ms_rocprof_source": "profiles/kernel_replay.json [%s]: rocprofv3 --kernel-trace --stats of `%s`, %d "
+                                        "launches (not re-measured per run)" % (key, rec.get("command", "bench.py"), rec["calls"])}
 
 
 def pmc_traffic(key):

@@ -143,8 +143,9 @@ int qpg_audio_cosine_mx_h(qpg_ctx*, void* stream, const void* base_f16, int N, i
  *                            (qpg_audio_hl_query_bytes(Q, F) bytes): chunks of 48 queries + one scale exponent per query.
  *   qpg_audio_cosine_hl      D [dev] [Q][N*G] (f32 if d_is_f32, else f64; row stride ldD elements).  cn2 [dev] f64 [N][G],
  *                            qn2 [dev] f64 [Q]: the UNSCALED squared norms (qpg_audio_cand_norm2 / qpg_audio_pack_queries).
- *                            stats[1] |= 2 if a non-zero operand's scaled norm is < 1 (it is then < 2^-14 of the largest
- *                            magnitude of its side: outside the range the representation bound covers). */
+ *                            stats[1] |= 2 if a non-zero operand's SCALED squared norm is < 2^16 (a database row whose
+ *                            norm is below 1/64 .. 1/128 of the largest magnitude in the whole track: outside the range
+ *                            the representation bound covers - the l planes' f16 subnormals; round 5, was < 1). */
 #define QPG_AUDIO_HL_ERR 1.3e-6 /* a-priori bound of qpg_audio_cosine_hl: |D - exact| <= this for every pair in range */
 int qpg_audio_hl_supported(int T, int F, int G, int n_taps, int tap_stride, int cand_step);
 /* qpg_audio_pack_queries + qpg_audio_hl_pack_queries in ONE launch (the pair sits on a clip's critical path): gathers the
@@ -173,6 +174,20 @@ int qpg_audio_cosine_hl(qpg_ctx*, void* stream, const void* db_image, int N, int
 int qpg_audio_cosine_hl_range(qpg_ctx*, void* stream, const void* db_image, int N, int F, int G, const double* cn2,
                               const void* q_image, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD,
                               int32_t* stats, int win_begin, int win_end);
+/* The same sweep over a track stored in IEEE f16 (round 5; BASELINE.json configs[4] "fp16 features"): an f16 value is
+ * its own h plane, so the database image has ONE plane, no scale exponent and no representation error - half the bytes
+ * (N x 27 rows x 3 F f16, every byte read once) and two products per element (h h', l' h) instead of three.  Same query
+ * image (qpg_audio_pack_queries_hl / qpg_clip_pack_hl), same D, same bound QPG_AUDIO_HL_ERR on the ROUNDED track's exact
+ * distances (cn2 = its candidates' squared norms), same select.  Reference data path: data_processing.py:255-274 (the
+ * track), GestureKNN.py:666-691 (the scan).
+ *   qpg_audio_hl1_supported  qpg_audio_hl_supported's grid and 3 F / 32 a multiple of 12 (F %% 128 == 0).
+ *   qpg_audio_hl1_pack_db    one-off: base_f16 [dev] f16 [N][T][F] -> image [dev] (qpg_audio_hl1_db_bytes(N, F) bytes). */
+int qpg_audio_hl1_supported(int T, int F, int G, int n_taps, int tap_stride, int cand_step);
+int64_t qpg_audio_hl1_db_bytes(int N, int F);
+int qpg_audio_hl1_pack_db(qpg_ctx*, void* stream, const void* base_f16, int N, int T, int F, int G, int n_taps,
+                          int tap_stride, int cand_step, void* image, int64_t image_bytes);
+int qpg_audio_cosine_hl1(qpg_ctx*, void* stream, const void* db_image, int N, int F, int G, const double* cn2,
+                         const void* q_image, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD, int32_t* stats);
 /* Hardware probe behind the bound's one measured constant: out[tile] = A[tile] (16 x 32 f16) . B[tile]^T (16 x 32 f16)
  * + C[tile] (16 x 16 f32, NULL = 0) exactly as ONE v_mfma_f32_16x16x32_f16 computes it; the tests compare it with exact
  * sums (kappa: error of a 32-product block sum in units of 2^-24 sum |products|). */

@@ -39,6 +39,8 @@ _SIGS = {
     "qpg_clip_pack_hl": [P, I, I, I, P, P, I, I, I, P, P, P, L, P, I, I, I, P, P, I, P, P, L],
     "qpg_audio_cosine_hl": [P, I, I, I, P, P, P, I, P, I, L, P],
     "qpg_audio_cosine_hl_range": [P, I, I, I, P, P, P, I, P, I, L, P, I, I],
+    "qpg_audio_hl1_pack_db": [P, I, I, I, I, I, I, I, P, L],
+    "qpg_audio_cosine_hl1": [P, I, I, I, P, P, P, I, P, I, L, P],
     "qpg_debug_mfma_f16_tile": [P, P, P, I, P],
     "qpg_hl_pack_rows": [P, L, I, P, L],
     "qpg_hl_pack_cols": [P, I, I, P, L],
@@ -165,6 +167,9 @@ def load():
     lib.qpg_percode_select_mixed_ws_stride.restype = c_int64
     lib.qpg_merge_mixed_ws_bytes.argtypes = [c_int, c_int, c_int]
     lib.qpg_audio_hl_supported.argtypes = [c_int] * 6
+    lib.qpg_audio_hl1_supported.argtypes = [c_int] * 6
+    lib.qpg_audio_hl1_db_bytes.argtypes = [c_int, c_int]
+    lib.qpg_audio_hl1_db_bytes.restype = c_int64
     lib.qpg_audio_hl_db_bytes.argtypes = [c_int, c_int]
     lib.qpg_audio_hl_db_bytes.restype = c_int64
     lib.qpg_audio_hl_query_bytes.argtypes = [c_int, c_int]

@@ -40,17 +40,21 @@ FLAG_TEXT_OVERFLOW = 16
 _PIN_SENTINEL = -1234567          # never a status word (flag bits are small non-negative integers)
 
 
-def _wait_pinned(pin_np, stream):
+def _wait_pinned(pin_np, stream, watch=None):
     """Host side of the zero-copy results: spin on the status word (the walk's last store, behind a system-scope fence),
     then make sure no other word still holds the sentinel - a store that the fabric delivered late is waited for, never
     copied as it is (codes / votes / flags can not take the sentinel's value) - and return a copy.  After ~2 ms without the
-    word (a failed launch would never write it) the stream is synchronised the ordinary way."""
+    word (a failed launch would never write it) the stream is synchronised the ordinary way.
+    watch: the words to spin on (a view of pin_np: every clip's status word when one replay walks several clips - each
+    chain's block writes its own pair last); default the buffer's last word."""
+    if watch is None:
+        watch = pin_np[-1:]
     for _ in range(40000):
-        if pin_np[-1] != _PIN_SENTINEL:
+        if watch[-1] != _PIN_SENTINEL and (watch.size == 1 or not (watch == _PIN_SENTINEL).any()):
             break
     else:
         stream.synchronize()
-        if pin_np[-1] == _PIN_SENTINEL:
+        if (watch == _PIN_SENTINEL).any():
             raise RuntimeError("the walk did not write its status word")
     out = pin_np.copy()
     if (out == _PIN_SENTINEL).any():
@@ -247,14 +251,23 @@ class GestureDB:
             self.hl_bound_ok, self.hl_bound_report = mfma_bound_ok(dev)
             if not self.hl_bound_ok:
                 hl_image = text_prefilter = False
-        if (hl_image and feature_dtype == "f32" and self.n_local and len(kint) > 1 and
+        # (feature_dtype "f16", round 5: an f16 value is its own h plane - a ONE-plane image, half the bytes, two products
+        # per element instead of three: qpg_audio_cosine_hl1)
+        self.hl_planes = 2 if feature_dtype == "f32" else 1
+        supported = lib.qpg_audio_hl_supported if feature_dtype == "f32" else lib.qpg_audio_hl1_supported
+        if (hl_image and self.n_local and len(kint) > 1 and
                 kint == [i * (kint[1] - kint[0]) for i in range(len(kint))] and
-                lib.qpg_audio_hl_supported(self.T, self.F, self.Ga, NUM_AUDIO_FEAT_FRAMES, self.tap_stride,
-                                           kint[1] - kint[0])):
-            nb = int(lib.qpg_audio_hl_db_bytes(self.n_local, self.F))
-            self.hl_image = torch.empty((nb,), dtype=torch.uint8, device=dev)
-            _lib.call("qpg_audio_hl_pack_db", dev, self.base, self.n_local, self.T, self.F, self.Ga,
-                      NUM_AUDIO_FEAT_FRAMES, self.tap_stride, kint[1] - kint[0], self.hl_image, nb)
+                supported(self.T, self.F, self.Ga, NUM_AUDIO_FEAT_FRAMES, self.tap_stride, kint[1] - kint[0])):
+            if feature_dtype == "f32":
+                nb = int(lib.qpg_audio_hl_db_bytes(self.n_local, self.F))
+                self.hl_image = torch.empty((nb,), dtype=torch.uint8, device=dev)
+                _lib.call("qpg_audio_hl_pack_db", dev, self.base, self.n_local, self.T, self.F, self.Ga,
+                          NUM_AUDIO_FEAT_FRAMES, self.tap_stride, kint[1] - kint[0], self.hl_image, nb)
+            else:
+                nb = int(lib.qpg_audio_hl1_db_bytes(self.n_local, self.F))
+                self.hl_image = torch.empty((nb,), dtype=torch.uint8, device=dev)
+                _lib.call("qpg_audio_hl1_pack_db", dev, self.base, self.n_local, self.T, self.F, self.Ga,
+                          NUM_AUDIO_FEAT_FRAMES, self.tap_stride, kint[1] - kint[0], self.hl_image, nb)
 
         ctx = np.ascontiguousarray(context[self.lo:self.hi], np.float32)
         self.R, self.Dt = context.shape[1], context.shape[2]
@@ -437,7 +450,7 @@ class CodeKNN:
         (the same conditions as sweep_audio's own; `sharded`: as a row shard inside sweep_tables)?"""
         db = self.db
         base = (self.audio_precision == "mixed" and self.tie_eps > 0 and db.n_local > 0 and db.K <= 512 and
-                db.hl_bound_ok and self.audio_kernel == "hl" and db.hl_image is not None and db.feature_dtype == "f32")
+                db.hl_bound_ok and self.audio_kernel == "hl" and db.hl_image is not None)
         if not sharded:
             return base and db.world == 1
         gflop = 2e-9 * Q * (-(-db.N // db.world) * db.Ga) * NUM_AUDIO_FEAT_FRAMES * db.F
@@ -482,7 +495,8 @@ class CodeKNN:
         if ev is not None:
             pool = getattr(self, "kernel_event_pool", None)      # events created ahead of the timed region
             e0, e1 = pool.pop() if pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        use_hl = mixed and self.audio_kernel == "hl" and db.hl_image is not None and not half
+        use_hl = mixed and self.audio_kernel == "hl" and db.hl_image is not None
+        hl_fn = "qpg_audio_cosine_hl" if db.hl_planes == 2 else "qpg_audio_cosine_hl1"
         self._last_audio_hl = use_hl
         sweep_launch = None
         if use_hl:                    # gather + norms + split-f16 image in ONE launch
@@ -490,9 +504,9 @@ class CodeKNN:
             qi = self.__dict__.get("_hl_qimage")
             if qi is None or qi.numel() < nbq:
                 qi = self._hl_qimage = torch.empty((nbq,), dtype=torch.uint8, device=dev)
-            if not (getattr(self, "_want_sweep_event", False) and self.text_lead > 0):
+            if not (getattr(self, "_want_sweep_event", False) and self.text_lead > 0 and db.hl_planes == 2):
                 # the sweep's arguments are converted BEFORE the pack goes out: its launch follows the pack's at once
-                sweep_launch = _lib.prepare("qpg_audio_cosine_hl", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi,
+                sweep_launch = _lib.prepare(hl_fn, dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi,
                                             qn2, Q, D, 1, D.stride(0), self._guard_stats)
             if prepacked is None:
                 _lib.call("qpg_audio_pack_queries_hl", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
@@ -1070,7 +1084,7 @@ class CodeKNN:
                   0.0 if exact else float(self.tie_eps))
 
     def walk(self, T, n_windows, window_offset=0, mode=MODE_AUD_TXT, seed_code=None, seed_phase=None, sync=True,
-             seed_ptrs=None, out_pin=None):
+             seed_ptrs=None, out_pin=None, n_chains=1):
         """Device-side walk of windows [window_offset, window_offset+n_windows) of the tables.
         sync=True: (codes, phases, votes) as NumPy arrays; sync=False: device tensors (+ the status pair), nothing waited
         for, `_last_ints` = codes | votes | status on the device; sync="ints": the integer results only, as ONE host array
@@ -1079,9 +1093,15 @@ class CodeKNN:
         seed_ptrs = (address of an i32 seed code, address of its f32 [8][16] phase block), both readable by the device
         (ClipGraph: pinned host memory the host rewrites before every replay - the seed is then DATA, not a kernel
         argument, and one captured graph serves every clip); out_pin: a pinned int32 tensor [M*30 + M*steps + 2] the
-        integer results go to (with sync=False: nothing is waited for)."""
+        integer results go to (with sync=False: nothing is waited for).
+        n_chains > 1 (with seed_ptrs and out_pin: ClipGraph over several clips): that many INDEPENDENT clips of n_windows
+        windows whose steps sit back to back in the tables from window_offset on; seed_ptrs then address i32 [n_chains]
+        seed codes and f32 [n_chains][8][16] phase blocks, out_pin holds codes [n_chains][M*30] | votes [n_chains][M*steps]
+        | status [n_chains][2]."""
         db, dev = self.db, self.db.device
         M, steps = n_windows, self.n_steps()
+        CL = int(n_chains)
+        assert CL == 1 or (seed_ptrs is not None and out_pin is not None), "several chains: the graph path only"
         if seed_ptrs is not None:
             seed_code, sp = 0, int(seed_ptrs[1])
         elif seed_code is None:
@@ -1098,9 +1118,9 @@ class CodeKNN:
         n_c, n_v = M * num_frames_code, M * steps
         host = sync is True or sync == "ints"
         if out_pin is not None:
-            assert not host and out_pin.numel() >= n_c + n_v + 2
+            assert not host and out_pin.numel() >= CL * (n_c + n_v + 2)
             base = out_pin.data_ptr()
-            out_codes, out_vote, status = base, base + 4 * n_c, base + 4 * (n_c + n_v)
+            out_codes, out_vote, status = base, base + 4 * CL * n_c, base + 4 * CL * (n_c + n_v)
         elif host:
             # pinned (device-visible) host memory, one buffer per clip length: safe to reuse because this call does
             # not return before the stream has drained and the values have been copied out of it
@@ -1119,18 +1139,18 @@ class CodeKNN:
             out_codes = ints_d[:n_c].view(M, num_frames_code)
             out_vote = ints_d[n_c:n_c + n_v].view(M, steps)
             status = ints_d[n_c + n_v:]                                  # always written by the walk kernels
-        out_phase = torch.empty((M, steps, 8, 16), dtype=torch.float32, device=dev)
-        gate = torch.empty((3, max(M, 1) * steps, db.K), dtype=torch.int32, device=dev)
+        out_phase = torch.empty((CL * M, steps, 8, 16), dtype=torch.float32, device=dev)
+        gate = torch.empty((3, max(CL * M, 1) * steps, db.K), dtype=torch.int32, device=dev)
         q0 = window_offset * steps
 
         def sl(t):
-            return None if t is None else t[q0:q0 + M * steps]
+            return None if t is None else t[q0:q0 + CL * M * steps]
         a_cidx, a_pslot, a_G = self._audio_grid()
         if seed_ptrs is not None:
             # one chain through the batch entry: its seed code is read from memory by the kernels
             _lib.call("qpg_match_steps_batch", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]),
                       sl(T["txt_idx"]), db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
-                      db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode, M, steps, db.K, 1, int(seed_ptrs[0]), sp,
+                      db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode, M, steps, db.K, CL, int(seed_ptrs[0]), sp,
                       gate, out_codes, out_phase, out_vote, status, 2, self._guard_stats[1:2])
         else:
             _lib.call("qpg_match_steps", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]), sl(T["txt_idx"]),
@@ -1201,13 +1221,18 @@ class CodeKNN:
                              "(the reference raises IndexError at GestureKNN.py:631-632)")
 
     def capture_clip_graph(self, n_windows, mode=MODE_AUD_TXT, n_sweep_windows=None, window_offset=0, audio=None,
-                           context=None, owner_blocks=False):
+                           context=None, owner_blocks=False, n_clips=1, encoder=None, encode_input=None):
         """Capture the whole per-clip launch sequence (pack, both sweeps, per-code argmin passes, ranks,
         rank-fusion tables, walk) into one HIP graph for a fixed clip shape.  Returns a ClipGraph whose
         run(test_audio, test_context, seed_code, seed_phase) replays it; results are device tensors.
         n_sweep_windows > n_windows sweeps more windows than it walks (several clips per sweep: bench.py N>1).
-        audio / context: bind the graph to the caller's resident input tensors instead of static copies."""
-        return ClipGraph(self, n_windows, mode, n_sweep_windows or n_windows, window_offset, audio, context, owner_blocks)
+        audio / context: bind the graph to the caller's resident input tensors instead of static copies.
+        n_clips > 1 (round 5; BASELINE configs[4]): that many independent clips of n_windows windows per replay, ONE
+        batched sweep and one set of walk launches for all of them (their steps back to back in the tables).
+        encoder / encode_input: a VQVAE and a resident pose batch f32 [B][T][C] whose encode (make_beat_dataset.py:314-316)
+        runs INSIDE the capture on a branch of its own beside the match - one replay = the fused encode + match step."""
+        return ClipGraph(self, n_windows, mode, n_sweep_windows or n_windows * n_clips, window_offset, audio, context,
+                         owner_blocks, n_clips, encoder, encode_input)
 
     def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
                    seed_phase=None, return_tables=False):
@@ -1278,9 +1303,16 @@ class ClipGraph:
     votes | status) land in pinned host memory behind a system-scope fence, so a replay is: write the seed, write the
     sentinel, hipGraphLaunch, watch the status word.  One capture serves every clip of that shape."""
 
-    def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset, audio=None, context=None, owner_blocks=False):
+    def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset, audio=None, context=None, owner_blocks=False,
+                 n_clips=1, encoder=None, encode_input=None):
         db, dev = knn.db, knn.db.device
         self.owner_blocks = owner_blocks
+        self.CL = int(n_clips)
+        if self.CL < 1 or n_sweep_windows < window_offset + self.CL * n_windows:
+            raise ValueError("n_clips x n_windows windows must lie inside the swept windows")
+        self.enc, self.enc_x = encoder, encode_input
+        if (encoder is None) != (encode_input is None):
+            raise ValueError("encoder and encode_input go together")
         self.segmented = False
         if db.world != 1 or knn.force_sharded:
             # A row-sharded clip is recorded in SEGMENTS (parallel.SegmentRecorder): one hipGraph per run of kernels
@@ -1303,6 +1335,8 @@ class ClipGraph:
                 self.segmented = True
         if knn.host_ranks:
             raise NotImplementedError("graph capture needs the device-side ranks (tie_rule 'stable')")
+        if knn.serial_walk:
+            raise NotImplementedError("graph capture replays the tabulated walk (serial_walk is an eager-path switch)")
         self.knn, self.M, self.mode = knn, n_windows, mode
         Ms = n_sweep_windows
         if audio is not None:                     # the caller's resident tensors: no copy in front of a replay
@@ -1313,14 +1347,26 @@ class ClipGraph:
             else:
                 self.audio = torch.zeros((Ms, db.T, db.F), dtype=torch.float32, device=dev)
             self.context = torch.zeros((Ms, db.R, db.Dt), dtype=torch.float32, device=dev)
-        # seed block in pinned host memory: [0:128] the f32 phase block, [128] the i32 seed code
-        self._seed_pin = torch.zeros((132,), dtype=torch.float32).pin_memory()
+        # seed block in pinned host memory: [0 : 128 CL] the clips' f32 phase blocks, then their i32 seed codes
+        CL = self.CL
+        self._seed_pin = torch.zeros((128 * CL + CL + 3,), dtype=torch.float32).pin_memory()
         self._seed_np = self._seed_pin.numpy()
-        self._seed_code_np = self._seed_np[128:129].view(np.int32)
+        self._seed_code_np = self._seed_np[128 * CL:128 * CL + CL].view(np.int32)
         steps = knn.n_steps()
         self._n_c, self._n_v = n_windows * num_frames_code, n_windows * steps
-        self._pin = torch.empty((self._n_c + self._n_v + 2,), dtype=torch.int32).pin_memory()
+        # codes [CL][M*30] | votes [CL][M*steps] | status [CL][2]; then (encode leg) the code ids i32 [B][T/8]
+        self._n_ints = CL * (self._n_c + self._n_v + 2)
+        self._n_ids = 0
+        if encoder is not None:
+            if knn.db.world != 1 or knn.force_sharded:
+                raise NotImplementedError("the encode leg is captured with the one-GPU step")
+            B_, T_ = int(encode_input.shape[0]), int(encode_input.shape[1])
+            self._ids_shape = (B_, T_ // encoder.hop)
+            self._n_ids = B_ * (T_ // encoder.hop)
+        self._pin = torch.empty((self._n_ints + self._n_ids,), dtype=torch.int32).pin_memory()
         self._pin_np = self._pin.numpy()
+        self._watch = self._pin_np[self._n_ints - 2 * CL + 1:self._n_ints:2]      # every clip's status[1]
+        self._in_flight = False
         self._n_sweep, self._off = Ms, window_offset
         self.graph = None
         self.captures = 0
@@ -1328,12 +1374,30 @@ class ClipGraph:
     def _capture(self):
         knn = self.knn
         dev = knn.db.device
-        ptrs = (self._seed_pin.data_ptr() + 4 * 128, self._seed_pin.data_ptr())
+        ptrs = (self._seed_pin.data_ptr() + 4 * 128 * self.CL, self._seed_pin.data_ptr())
+        if self.enc is not None:
+            self._enc_stream = torch.cuda.Stream(dev)
+            self._enc_gate, self._enc_done = torch.cuda.Event(), torch.cuda.Event()
+            ids_pin = self._pin[self._n_ints:]
 
         def body():
+            main = torch.cuda.current_stream(dev)
+            if self.enc is not None:
+                # the encode leg: a branch of its own beside the match (independent work: DB-side pose windows), its ids
+                # narrowed to i32 and copied into the replay's pinned result block; joined in front of the walk, whose
+                # last store (the status words, behind a system-scope fence) is what the host waits for
+                self._enc_gate.record(main)
+                self._enc_stream.wait_event(self._enc_gate)
+                with torch.cuda.stream(self._enc_stream):
+                    ids = self.enc.encode_fused(self.enc_x)
+                    ids_pin.copy_(ids.reshape(-1).to(torch.int32), non_blocking=True)
+                    self._enc_done.record(self._enc_stream)
             T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode, owner_blocks=self.owner_blocks,
                                  for_walk=True)
-            return knn.walk(T, self.M, self._off, self.mode, sync=False, seed_ptrs=ptrs, out_pin=self._pin)
+            if self.enc is not None:
+                main.wait_event(self._enc_done)
+            return knn.walk(T, self.M, self._off, self.mode, sync=False, seed_ptrs=ptrs, out_pin=self._pin,
+                            n_chains=self.CL)
         import os as _os
         s = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("QPG_GRAPH_PRIO", "0")))   # (measurements)
         s.wait_stream(torch.cuda.current_stream(dev))
@@ -1374,20 +1438,34 @@ class ClipGraph:
         self.captures += 1
 
     def _set_seed(self, seed_code, seed_phase):
-        sc = int(seed_code)
-        if not 0 <= sc < self.knn.db.K:
-            raise ValueError("seed code %d outside [0, %d)" % (sc, self.knn.db.K))
+        """One (code, phase block) for every clip, or one per clip (sequence of n_clips codes, [n_clips][8][16] blocks)."""
+        CL, K = self.CL, self.knn.db.K
+        sc = np.asarray(seed_code, np.int64).reshape(-1)
+        if sc.size == 1:
+            sc = np.repeat(sc, CL)
+        if sc.size != CL or (sc < 0).any() or (sc >= K).any():
+            raise ValueError("seed codes: %d values in [0, %d) wanted" % (CL, K))
         if isinstance(seed_phase, torch.Tensor):
             seed_phase = seed_phase.detach().cpu().numpy()
-        self._seed_np[:128] = np.asarray(seed_phase, np.float32).reshape(128)
-        self._seed_code_np[0] = sc
+        sp = np.asarray(seed_phase, np.float32).reshape(-1)
+        if sp.size == 128:
+            sp = np.tile(sp, CL)
+        if sp.size != 128 * CL:
+            raise ValueError("seed phases: [n_clips][8][16] floats wanted")
+        self._seed_np[:128 * CL] = sp
+        self._seed_code_np[:] = sc.astype(np.int32)
 
     def launch(self, seed_code, seed_phase):
-        """Replay on the current stream without waiting (inputs: whatever the bound / static buffers hold)."""
+        """Replay on the current stream without waiting (inputs: whatever the bound / static buffers hold).  ONE replay in
+        flight per graph: the seed block and the pinned result block are single buffers - the previous replay
+        must have been collected with wait_ints()."""
+        if self._in_flight:
+            raise RuntimeError("ClipGraph.launch: the previous replay has not been collected (wait_ints)")
         self._set_seed(seed_code, seed_phase)
         if self.graph is None:
             self._capture()
         self._pin_np.fill(_PIN_SENTINEL)
+        self._in_flight = True
         if self.segmented:
             for f in self._program:                 # hipGraphLaunch, collective, hipGraphLaunch, ...
                 f()
@@ -1395,9 +1473,31 @@ class ClipGraph:
             self.graph.replay()
 
     def wait_ints(self):
-        """Host-side wait for the replay's last store (the status word, behind a system-scope fence); returns a copy of
-        codes | votes | status (int32).  The caller hands ints[-2:] to CodeKNN.check_status()."""
-        return _wait_pinned(self._pin_np, torch.cuda.current_stream(self.knn.db.device))
+        """Host-side wait for the replay's last store (the status words, behind a system-scope fence); returns a copy of
+        codes [n_clips][M*30] | votes [n_clips][M*steps] | status [n_clips][2] (| the encode leg's ids) as int32.  The
+        caller hands every clip's status pair to CodeKNN.check_status().  A replay that raised the trouble word leaves the
+        matcher's sticky word CLEARED (later replays of the same graph must not inherit it; the flagged clip is
+        re-matched by the caller on a path that cannot raise it)."""
+        try:
+            out = _wait_pinned(self._pin_np, torch.cuda.current_stream(self.knn.db.device), self._watch)
+        finally:
+            self._in_flight = False
+        st = out[self._n_ints - 2 * self.CL:self._n_ints].reshape(self.CL, 2)
+        if (st[:, 1] != 0).any():
+            self.knn.clear_flags()
+        return out
+
+    def statuses(self, ints):
+        """[n_clips][2] status pairs of wait_ints()' array."""
+        return ints[self._n_ints - 2 * self.CL:self._n_ints].reshape(self.CL, 2)
+
+    def codes(self, ints):
+        """[n_clips][M][30] codes of wait_ints()' array."""
+        return ints[:self.CL * self._n_c].reshape(self.CL, self.M, num_frames_code)
+
+    def encoded_ids(self, ints):
+        """The encode leg's ids [B][T/8] (int32) of wait_ints()' array."""
+        return ints[self._n_ints:self._n_ints + self._n_ids].reshape(self._ids_shape)
 
     def run_ints(self, seed_code, seed_phase):
         """One replay on the bound inputs, ending with the integer results on the host (bench.py's graph step)."""
@@ -1414,10 +1514,12 @@ class ClipGraph:
             self.audio.copy_(test_audio, non_blocking=True)
         if test_context.data_ptr() != self.context.data_ptr():
             self.context.copy_(test_context, non_blocking=True)
+        if self.CL != 1:
+            raise NotImplementedError("run() returns one clip; several clips: run_ints() + codes() / statuses()")
         ints = torch.from_numpy(self.run_ints(seed_code, seed_phase))
         n_c, n_v = self._n_c, self._n_v
         return (ints[:n_c].view(self.M, num_frames_code), self.out[1], ints[n_c:n_c + n_v].view(self.M, -1),
-                ints[n_c + n_v:])
+                ints[n_c + n_v:n_c + n_v + 2])
 
 
 class ClipPipeline:

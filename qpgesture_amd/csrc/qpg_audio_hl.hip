@@ -79,11 +79,16 @@ __device__ __forceinline__ void split_hl(float x, _Float16& h, _Float16& l) {
 }
 // Round 4, the AUDIO images: l = fl16(x - h) at its TRUE scale.  The cross products h l' then have their real magnitude
 // and can run through the SAME accumulator as h h' (audio_cosine_hl2_kernel); x - h is below half an ulp of h, so for
-// the large values l stays a normal f16 number with the same 11 significant bits as before, and for values more than
-// 2^13 below the largest one of their side it falls into the subnormal range: an absolute error <= 2^-25 per element,
-// i.e. <= 2^-25 sum|c_i| / (|q||c|) <= 2^-25 sqrt(6144) / 2^14 = 1.4e-10 of the product of norms (the largest element
-// alone makes the scaled norm >= 2^14).  The matrix core takes f16 subnormals as they are (checked at load time:
-// selfcheck.py).
+// the large values l stays a normal f16 number with the same 11 significant bits as before, and for scaled values below
+// 2^-3 it falls into the subnormal range: an ABSOLUTE error <= 2^-25 per element, i.e. a dot-product error
+// <= 2^-25 sum|y_i| <= 2^-25 sqrt(D) |y| - relative to |x||y| that is 2^-25 sqrt(6144) / |x|_scaled = 2.3e-6 / |x|_scaled.
+// It is small only for operands whose SCALED norm is large, so the sweeps' validity guard demands scaled |x|^2 >=
+// HL_NORM2_MIN = 2^16 (stats[1] |= 2 below it; round 4 asked for >= 1, under which a quiet row of a loud database could
+// take the whole budget - ADVICE r4): <= 9.1e-9 per side, 1.8e-8 of the 1e-7 the budget leaves (1.2e-6 + 1.8e-8 <=
+// QPG_AUDIO_HL_ERR).  A query always passes (its own largest element is scaled to >= 2^14); a database row fails when its
+// norm is below 2^8 / 2^14..15 = 1/64 .. 1/128 of the largest magnitude in the whole track - such a clip is re-matched on
+// the f64 path.  The matrix core takes f16 subnormals as they are (checked at load time: selfcheck.py).
+#define HL_NORM2_MIN 65536.0
 #define HL_AUDIO_LSHIFT 0
 __device__ __forceinline__ void split_hl_audio(float x, _Float16& h, _Float16& l) {
   h = (_Float16)x;
@@ -719,8 +724,8 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
       const double dot = ldexp(lo + hs[r], -(e_c + e_q));
       const int64_t c = (int64_t)j * a.G + g;
       const double cc = a.cn2[c];
-      // validity range of the representation bound: scaled norms >= 1 (4^e * |x|^2 >= 1), zero rows excepted
-      if (a.stats && ((cc > 0.0 && ldexp(cc, 2 * e_c) < 1.0) || (qq > 0.0 && ldexp(qq, 2 * e_q) < 1.0)))
+      // validity range of the representation bound: scaled |x|^2 >= HL_NORM2_MIN, zero rows excepted
+      if (a.stats && ((cc > 0.0 && ldexp(cc, 2 * e_c) < HL_NORM2_MIN) || (qq > 0.0 && ldexp(qq, 2 * e_q) < HL_NORM2_MIN)))
         atomicOr(&a.stats[1], 2);
       const double dd = cosine_from_dot(dot, qq, cc);
       if (a.d_f32) reinterpret_cast<float*>(a.D)[(int64_t)q * a.ldD + c] = (float)dd;
@@ -767,16 +772,21 @@ __device__ __forceinline__ double fast_rsqrt_f64(double x) {
 }
 #define H2_W 8
 // ablation hooks (experiments/audio_hl): -DH2_PROBE=<bits>; the product build defines nothing.  1: database fragments read
-// from one address (no HBM stream); 2: no f64 flush; 4: query fragments read from LDS once per stage pair
+// from one address (no HBM stream); 2: no f64 flush; 8: no stage barrier
 #ifndef H2_PROBE
 #define H2_PROBE 0
 #endif
-#ifndef H2_ORDER
-#define H2_ORDER 0         // 0: the two chains of a step interleaved (product); 1: one after the other
-#endif
-#ifndef H2_SGB
-#define H2_SGB 1           // issue-order pinning of a step (1: product)
-#endif
+// ONE-PLANE database image (round 5: the track stored in IEEE f16, GestureDB feature_dtype "f16").  An f16 value IS its
+// own h plane: no scaling (exponent 0), no l plane, no representation error on the database side - half the bytes (a
+// window is [tile 0: KB x 64 units][tile 1: KB x 44 units] of 16 bytes: 340 MB at N = 2048) and TWO products per element
+// instead of three (h h' and the query's l h).  A chain is the four instructions of a stage's two k-blocks, the two cross
+// blocks first; its bound is the six-instruction chain's (a sub-chain of it: selfcheck.py measures both orders).  Budget
+// relative to |q||c|: chain sums 13.05 x 2^-24 = 7.8e-7, query representation 2^-23 = 1.2e-7 (+ 1e-8 for its subnormal
+// l), f32-stored matrix 1.2e-7: 1.03e-6 <= QPG_AUDIO_HL_ERR (the select keeps ONE band for both images).
+// The 32 registers the l plane's ring held go into the ring's depth: RS = 4 stages (8 k-blocks) of fragments in flight.
+#define HL1_WIN_UNITS(KB) ((int64_t)(KB) * (64 + HL_T1_UNITS))
+// PL: planes of the database image (2: h | l, f32 track; 1: the f16 track); RS: stages of database fragments in flight
+template <int PL, int RS>
 __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x 2 x 6 x 2 x 1 KB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -788,29 +798,38 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
   const bool win_ok = j < a.N;
   const int KB = a.KB, n_stage = KB / 2;
   const int cg = lane & 15, rg = lane >> 4;
-  // database fragments of this window: tile 0 = 64 units per plane and k-block; tile 1 = its 11 live rows, 44 units
-  const bool ok1 = win_ok && cg < 11;
-  const h8* p0 = win_ok ? reinterpret_cast<const h8*>(a.db) + (int64_t)j * HL_WIN_UNITS(KB) + lane
-                        : reinterpret_cast<const h8*>(a.zeros);
-  const h8* p1 = ok1 ? reinterpret_cast<const h8*>(a.db) + (int64_t)j * HL_WIN_UNITS(KB) + (int64_t)KB * 128 + 11 * rg + cg
-                     : reinterpret_cast<const h8*>(a.zeros);
-  const int kb0 = (win_ok && !(H2_PROBE & 1)) ? 128 : 0, pl0 = win_ok ? 64 : 0;
-  const int kb1 = (ok1 && !(H2_PROBE & 1)) ? 2 * HL_T1_UNITS : 0, pl1 = ok1 ? HL_T1_UNITS : 0;
-  auto load_a = [&](int kb, h8 (&d)[4]) {                              // [tile 0 h, tile 0 l, tile 1 h, tile 1 l]
+  // database fragments of this window: tile 0 = 64 units per plane and k-block; tile 1 = its 11 live rows, 44 units.
+  // Addresses = a block-uniform base (scalar registers) + a 32-bit byte offset per lane (a block's 8 windows span
+  // < 3 MB): one address register per load and a 32-bit add per k-block (64-bit pointers per lane - which the zero-page
+  // redirect of dead lanes needed - cost two registers and a 64-bit multiply-add per load, and the one-plane kernel
+  // spilled an address INSIDE the k loop: a scratch reload's vmcnt(0) drains the whole fragment ring).  Dead lanes need no
+  // zeros: row i of an MFMA's result depends on row i of A only, rows 27..31 are never read by the epilogue, and a window
+  // past N is dropped there too - such lanes read their nearest live neighbour's bytes (same cache line, no traffic).
+  const int jb = a.j0 + wgrp * H2_W;                                   // first window of the block (uniform)
+  const uint32_t wj = (uint32_t)(win_ok ? w : a.N - 1 - jb);
+  const uint32_t win_units = (uint32_t)(PL == 2 ? HL_WIN_UNITS(KB) : HL1_WIN_UNITS(KB));
+  const unsigned char* sbase = reinterpret_cast<const unsigned char*>(a.db) + (int64_t)jb * win_units * 16;
+  const uint32_t o0 = (wj * win_units + (uint32_t)lane) * 16u;
+  const uint32_t o1 = (wj * win_units + (uint32_t)KB * (64 * PL) + 11u * rg + (cg < 11 ? cg : 10)) * 16u;
+  constexpr uint32_t st0 = (H2_PROBE & 1) ? 0u : 64u * PL * 16u, st1 = (H2_PROBE & 1) ? 0u : (uint32_t)PL * HL_T1_UNITS * 16u;
+  auto load_a = [&](int kb, h8 (&d)[2 * PL]) {                         // [tile 0 h (, l), tile 1 h (, l)]
     kb = kb < KB ? kb : KB - 1;
-    d[0] = p0[(int64_t)kb * kb0];
-    d[1] = p0[(int64_t)kb * kb0 + pl0];
-    d[2] = p1[(int64_t)kb * kb1];
-    d[3] = p1[(int64_t)kb * kb1 + pl1];
+    const uint32_t a0 = o0 + (uint32_t)kb * st0, a1 = o1 + (uint32_t)kb * st1;
+    d[0] = *reinterpret_cast<const h8*>(sbase + a0);
+    if (PL == 2) d[1] = *reinterpret_cast<const h8*>(sbase + a0 + 64 * 16);
+    d[PL] = *reinterpret_cast<const h8*>(sbase + a1);
+    if (PL == 2) d[PL + 1] = *reinterpret_cast<const h8*>(sbase + a1 + HL_T1_UNITS * 16);
   };
   constexpr int stage_units = 2 * HL_CT * 2 * 64;
   constexpr int QLD = stage_units / (64 * H2_W);
-  const h8* qsrc = reinterpret_cast<const h8*>(a.qi) + (int64_t)chunk * KB * HL_CT * 2 * 64;
+  const unsigned char* qsrc = reinterpret_cast<const unsigned char*>(a.qi) + (int64_t)chunk * KB * HL_CT * 2 * 1024;
+  const uint32_t qoff = (uint32_t)tid * 16u;
   h8 qreg[QLD];
   auto load_q = [&](int s) {
     s = s < n_stage ? s : n_stage - 1;
 #pragma unroll
-    for (int u = 0; u < QLD; ++u) qreg[u] = qsrc[(int64_t)s * stage_units + u * (64 * H2_W) + tid];
+    for (int u = 0; u < QLD; ++u)
+      qreg[u] = *reinterpret_cast<const h8*>(qsrc + (int64_t)s * (stage_units * 16) + u * (64 * H2_W * 16) + qoff);
   };
   auto store_q = [&](int buf) {
     h8* dst = reinterpret_cast<h8*>(lds) + buf * stage_units;
@@ -828,9 +847,9 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
     for (int c = 0; c < HL_CT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][c][r] = 0.0;
-  h8 ring[4][4];
+  h8 ring[2 * RS][2 * PL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) load_a(i, ring[i]);
+  for (int i = 0; i < 2 * RS; ++i) load_a(i, ring[i]);
   load_q(0);
   store_q(0);
   load_q(1);
@@ -848,12 +867,14 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
   };
   ld_b(0, 0, B[0]);
   f32x4 dp[2] = {zero4, zero4};                                        // the previous step's two chains, not yet flushed
-  for (int s2 = 0; s2 < n_stage; s2 += 2) {                            // two stages per trip: ring / buffer indices static
+  // a trip = an even number of stages that is a multiple of RS: ring slots, LDS buffers and fragment parities are static
+  constexpr int TRIP = (RS % 2 == 0) ? RS : 2 * RS;
+  for (int s0 = 0; s0 < n_stage; s0 += TRIP) {
 #pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-      const int s = s2 + ss;
-      h8 (&A0)[4] = ring[ss * 2 + 0];
-      h8 (&A1)[4] = ring[ss * 2 + 1];
+    for (int ss = 0; ss < TRIP; ++ss) {
+      const int s = s0 + ss;
+      h8 (&A0)[2 * PL] = ring[(ss % RS) * 2 + 0];
+      h8 (&A1)[2 * PL] = ring[(ss % RS) * 2 + 1];
 #pragma unroll
       for (int c = 0; c < HL_CT; ++c) {
         const int st = ss * HL_CT + c;
@@ -862,42 +883,40 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         if (c == HL_CT - 1) {
           if (!(H2_PROBE & 8)) lds_barrier();  // every fragment of this stage has arrived; the next stage's are stored
           ld_b((ss + 1) & 1, 0, Bn);
-        } else if (!(H2_PROBE & 4)) {
-          ld_b(ss, c + 1, Bn);
+          if (RS > 2) {
+            // vmcnt counts IN ORDER: the wait for a stage's query fragments (one stage after their request) also waits
+            // for every OLDER request.  With the query loads behind the ring's (below: the order of the two-stage ring,
+            // where it does not matter) a deeper ring buys nothing - the data of stage s + RS - 1 must be there at the
+            // end of stage s.  So here they go out FIRST (the data of stage s + RS - 2: two stages of lead for RS = 4),
+            // and a scheduling fence keeps hipcc from sinking them behind the ring's loads again (it did).
+            store_q(ss & 1);
+            load_q(s + 3);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          ld_b(ss & 1, c + 1, Bn);
         }
-        // two chains (row tile 0 / 1), interleaved.  ORDER INSIDE A CHAIN: the four cross-term instructions first (h l',
-        // l h' of both k-blocks: the running sum stays 2^-10 of the h h' scale, and so do their roundings), the two h h'
+        // two chains (row tile 0 / 1), interleaved.  ORDER INSIDE A CHAIN: the cross-term instructions first (h l', l h' of
+        // both k-blocks: the running sum stays 2^-10 of the h h' scale, and so do their roundings), the two h h'
         // instructions last - the chain then behaves like round 3's chain of two (measured: every instruction that
         // re-rounds a FULL-SIZE running sum costs ~1.2-1.5 units of 2^-24 sum|products|, so h h' first would mean
         // kappa_6 = 14.4 against 9.9 this way; selfcheck.py measures this order)
-#if H2_ORDER == 0
         f32x4 d0 = mfma_h(A0[0], Bc[0][1], (H2_PROBE & 2) ? dp[0] : zero4);     // (probe 2: one endless chain, no flush)
-        f32x4 d1 = mfma_h(A0[2], Bc[0][1], (H2_PROBE & 2) ? dp[1] : zero4);
-        d0 = mfma_h(A0[1], Bc[0][0], d0);
-        d1 = mfma_h(A0[3], Bc[0][0], d1);
+        f32x4 d1 = mfma_h(A0[PL], Bc[0][1], (H2_PROBE & 2) ? dp[1] : zero4);
+        if (PL == 2) {
+          d0 = mfma_h(A0[PL - 1], Bc[0][0], d0);
+          d1 = mfma_h(A0[2 * PL - 1], Bc[0][0], d1);
+        }
         d0 = mfma_h(A1[0], Bc[1][1], d0);
-        d1 = mfma_h(A1[2], Bc[1][1], d1);
-        d0 = mfma_h(A1[1], Bc[1][0], d0);
-        d1 = mfma_h(A1[3], Bc[1][0], d1);
+        d1 = mfma_h(A1[PL], Bc[1][1], d1);
+        if (PL == 2) {
+          d0 = mfma_h(A1[PL - 1], Bc[1][0], d0);
+          d1 = mfma_h(A1[2 * PL - 1], Bc[1][0], d1);
+        }
         d0 = mfma_h(A0[0], Bc[0][0], d0);
-        d1 = mfma_h(A0[2], Bc[0][0], d1);
+        d1 = mfma_h(A0[PL], Bc[0][0], d1);
         d0 = mfma_h(A1[0], Bc[1][0], d0);
-        d1 = mfma_h(A1[2], Bc[1][0], d1);
-#else
-        // (experiment: the two chains one after the other - every MFMA directly behind the one it depends on)
-        f32x4 d0 = mfma_h(A0[0], Bc[0][1], zero4);
-        d0 = mfma_h(A0[1], Bc[0][0], d0);
-        d0 = mfma_h(A1[0], Bc[1][1], d0);
-        d0 = mfma_h(A1[1], Bc[1][0], d0);
-        d0 = mfma_h(A0[0], Bc[0][0], d0);
-        d0 = mfma_h(A1[0], Bc[1][0], d0);
-        f32x4 d1 = mfma_h(A0[2], Bc[0][1], zero4);
-        d1 = mfma_h(A0[3], Bc[0][0], d1);
-        d1 = mfma_h(A1[2], Bc[1][1], d1);
-        d1 = mfma_h(A1[3], Bc[1][0], d1);
-        d1 = mfma_h(A0[2], Bc[0][0], d1);
-        d1 = mfma_h(A1[2], Bc[1][0], d1);
-#endif
+        d1 = mfma_h(A1[PL], Bc[1][0], d1);
         // f64 running sums: the PREVIOUS step's chains (zeros in front of the first step)
         if (!(H2_PROBE & 2)) {
           const int pc = (c + HL_CT - 1) % HL_CT;
@@ -910,50 +929,21 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         dp[0] = d0;
         dp[1] = d1;
         if (c == HL_CT - 1) {
-          // the stage is done: its two ring slots take the k-blocks two stages ahead; the freed LDS buffer takes the
+          // the stage is done: its two ring slots take the k-blocks RS stages ahead; the freed LDS buffer takes the
           // stage after next (behind the barrier above: nobody reads this stage's buffer any more)
-          load_a(2 * (s + 2), A0);
-          load_a(2 * (s + 2) + 1, A1);
-          store_q(ss);
-          load_q(s + 3);
+          load_a(2 * (s + RS), A0);
+          load_a(2 * (s + RS) + 1, A1);
+          if (RS <= 2) {
+            store_q(ss & 1);
+            load_q(s + 3);
+          }
         }
-#if H2_SGB == 1
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {         // issue order: an MFMA, then a fragment read / a share of the flush under it
+        for (int i = 0; i < 4 + 4 * PL; ++i) { // issue order: an MFMA, then a fragment read / a share of the flush under it
           HL_SGB(0x008, 1);
           if (i < 4) HL_SGB(0x100, 1);
-          HL_SGB(0x002, 2);
+          HL_SGB(0x002, PL == 2 ? 2 : 3);
         }
-#elif H2_SGB == 2                              // (experiment: fillers only between the chains)
-        HL_SGB(0x008, 6);
-        HL_SGB(0x100, 2);
-        HL_SGB(0x002, 8);
-        HL_SGB(0x008, 6);
-        HL_SGB(0x100, 2);
-        HL_SGB(0x002, 8);
-#elif H2_SGB == 5                              // (experiment: one VALU per gap, the rest behind the step)
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          HL_SGB(0x008, 1);
-          if (i < 4) HL_SGB(0x100, 1);
-          HL_SGB(0x002, 1);
-        }
-        HL_SGB(0x002, 4);
-#elif H2_SGB == 6                              // (experiment: reads first, two MFMAs per group)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          HL_SGB(0x008, 2);
-          if (i < 2) HL_SGB(0x100, 2);
-          HL_SGB(0x002, 3);
-        }
-#elif H2_SGB == 3                              // (experiment: one filler per MFMA gap)
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          HL_SGB(0x008, 1);
-          if (i < 4) HL_SGB(0x100, 1);
-          else HL_SGB(0x002, 2);
-        }
-#endif
       }
     }
   }
@@ -966,7 +956,7 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
   if (!win_ok) return;
   // ---- epilogue: dot(q, cand g) = S[g][lo column] + S[g + 1][hi column]; the wave holds all 27 super-rows of its window:
   // lane (cg, rg) has rows 4 rg .. 4 rg + 3 of tile t for column cg of every column tile
-  const int e_c = a.meta[0];
+  const int e_c = PL == 2 ? a.meta[0] : 0;
   const int src = (lane + 16) & 63;
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
@@ -1001,7 +991,9 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         const double dot = ldexp(acc[t][ct][r] + hs[r], -(e_c + e_q));
         const int64_t c = (int64_t)j * a.G + g;
         const double cc = cc4[r];
-        if (a.stats && ((cc > 0.0 && ldexp(cc, 2 * e_c) < 1.0) || (qq > 0.0 && ldexp(qq, 2 * e_q) < 1.0)))
+        // validity range of the representation bound (HL_NORM2_MIN above); the one-plane image holds the database exactly
+        if (a.stats && ((PL == 2 && cc > 0.0 && ldexp(cc, 2 * e_c) < HL_NORM2_MIN) ||
+                        (qq > 0.0 && ldexp(qq, 2 * e_q) < HL_NORM2_MIN)))
           atomicOr(&a.stats[1], 2);
         double dd;
         if (q_fast && cc > 1e-30 && cc < 1e30) dd = 1.0 - dot * (iq * fast_rsqrt_f64(cc));
@@ -1174,7 +1166,7 @@ extern "C" int qpg_audio_cosine_hl_range(qpg_ctx* ctx, void* stream, const void*
   if (use2 && (KB % 4) == 0) {
     const int64_t g8 = (win_end - win_begin + H2_W - 1) / H2_W;
     QPG_REQUIRE(((g8 + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
-    hipLaunchKernelGGL(audio_cosine_hl2_kernel, dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W),
+    hipLaunchKernelGGL((audio_cosine_hl2_kernel<2, 2>), dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W),
                        2 * 2 * HL_CT * 2 * HL_PIECE, qpg_stream(stream), a);
     QPG_LAUNCH_CHECK("audio_cosine_hl2_kernel");
     return QPG_OK;
@@ -1184,6 +1176,86 @@ extern "C" int qpg_audio_cosine_hl_range(qpg_ctx* ctx, void* stream, const void*
   hipLaunchKernelGGL(audio_cosine_hl_kernel<0>, dim3((unsigned)(((wgroups + 7) / 8) * 8 * chunks)), dim3(HL_THREADS),
                      lds_bytes, qpg_stream(stream), a);
   QPG_LAUNCH_CHECK("audio_cosine_hl_kernel");
+  return QPG_OK;
+}
+
+// ---- the one-plane image of an f16-stored track (round 5; BASELINE.json configs[4] "fp16 features") -------------------------
+// thread <-> (window j, super-row i < 27, k8): one 16-byte piece of the f16 base, copied to its fragment position (the
+// layout of hl_pack_db_kernel without the l planes).  No scaling: the values are the database.
+#define H1_RS 3               // stages of database fragments in flight (audio_cosine_hl2_kernel<1, H1_RS>)
+#define H1_TRIP 6             // stages per trip of its k loop: KB must be a multiple of 2 * H1_TRIP
+__global__ __launch_bounds__(256) void hl1_pack_db_kernel(const _Float16* __restrict__ base, int N, int T, int F, int step,
+                                                          int tap_stride, _Float16* __restrict__ image) {
+  const int KB = HL_SUB * F / 32, K8 = HL_SUB * F / 8;
+  const int64_t n = (int64_t)N * HL_ROWS * K8;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (int64_t)gridDim.x * blockDim.x) {
+    const int k8 = (int)(id % K8);
+    const int i = (int)((id / K8) % HL_ROWS);
+    const int j = (int)(id / ((int64_t)K8 * HL_ROWS));
+    const int k = k8 * 8, sub = k / F, f = k - sub * F;
+    const int t = step * i + tap_stride * sub;
+    h8 v = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (t < T) v = *reinterpret_cast<const h8*>(base + ((int64_t)j * T + t) * F + f);
+    const int kb = k / 32, kg = (k & 31) >> 3;
+    const int64_t win = (int64_t)j * HL1_WIN_UNITS(KB);
+    const int64_t u0 = i < 16 ? win + (int64_t)kb * 64 + i + 16 * kg
+                              : win + (int64_t)KB * 64 + (int64_t)kb * HL_T1_UNITS + 11 * kg + (i - 16);
+    reinterpret_cast<h8*>(image)[u0] = v;
+  }
+}
+
+extern "C" int64_t qpg_audio_hl1_db_bytes(int N, int F) {
+  return (N <= 0 || F <= 0) ? 0 : (int64_t)N * HL1_WIN_UNITS(HL_SUB * F / 32) * 16;
+}
+
+static bool hl1_grid_ok(int T, int F, int G, int n_taps, int tap_stride, int step) {
+  return hl_grid_ok(T, F, G, n_taps, tap_stride, step) && ((HL_SUB * F / 32) % (2 * H1_TRIP)) == 0;
+}
+
+extern "C" int qpg_audio_hl1_supported(int T, int F, int G, int n_taps, int tap_stride, int cand_step) {
+  return hl1_grid_ok(T, F, G, n_taps, tap_stride, cand_step) ? 1 : 0;
+}
+
+extern "C" int qpg_audio_hl1_pack_db(qpg_ctx* ctx, void* stream, const void* base_f16, int N, int T, int F, int G, int n_taps,
+                                     int tap_stride, int cand_step, void* image, int64_t image_bytes) {
+  const char* name = "qpg_audio_hl1_pack_db";
+  QPG_REQUIRE(ctx && base_f16 && image && N > 0, "%s: bad argument", name);
+  QPG_REQUIRE(hl1_grid_ok(T, F, G, n_taps, tap_stride, cand_step),
+              "%s: needs 6 taps, 26 grid positions %d frames apart (= 3 x tap_stride) and F %% 128 == 0", name,
+              HL_SUB * tap_stride);
+  QPG_REQUIRE(image_bytes >= qpg_audio_hl1_db_bytes(N, F) && (reinterpret_cast<uintptr_t>(image) % 16) == 0 &&
+                  (reinterpret_cast<uintptr_t>(base_f16) % 16) == 0,
+              "%s: image too small or misaligned (qpg_audio_hl1_db_bytes)", name);
+  hipLaunchKernelGGL(hl1_pack_db_kernel, dim3(4096), dim3(256), 0, qpg_stream(stream),
+                     static_cast<const _Float16*>(base_f16), N, T, F, cand_step, tap_stride, static_cast<_Float16*>(image));
+  QPG_LAUNCH_CHECK("hl1_pack_db_kernel");
+  return QPG_OK;
+}
+
+// The sweep over the one-plane image: qpg_audio_cosine_hl's contract (same query image, same D, same bound), cn2 = the
+// squared norms of the ROUNDED track's candidates.
+extern "C" int qpg_audio_cosine_hl1(qpg_ctx* ctx, void* stream, const void* db_image, int N, int F, int G, const double* cn2,
+                                    const void* q_image, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD,
+                                    int32_t* stats) {
+  const char* name = "qpg_audio_cosine_hl1";
+  QPG_REQUIRE(ctx && db_image && cn2 && q_image && qn2 && D, "%s: null pointer", name);
+  QPG_REQUIRE(N > 0 && Q > 0 && G == HL_ROWS - 1 && (F % 32) == 0 && ((HL_SUB * F / 32) % (2 * H1_TRIP)) == 0 &&
+                  ldD >= (int64_t)N * G,
+              "%s: bad size", name);
+  const int chunks = (Q + HL_QC - 1) / HL_QC, KB = HL_SUB * F / 32;
+  HlArgs a;
+  const unsigned char* qi = static_cast<const unsigned char*>(q_image);
+  a.db = static_cast<const _Float16*>(db_image);
+  a.meta = nullptr;
+  a.qi = reinterpret_cast<const _Float16*>(qi);
+  a.qexp = reinterpret_cast<const int32_t*>(qi + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
+  a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = N; a.j0 = 0; a.G = G; a.Q = Q;
+  a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0; a.tmask = nullptr; a.band = 0.f; a.chunks = chunks;
+  const int64_t g8 = ((int64_t)N + H2_W - 1) / H2_W;
+  QPG_REQUIRE(((g8 + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
+  hipLaunchKernelGGL((audio_cosine_hl2_kernel<1, H1_RS>), dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W),
+                     2 * 2 * HL_CT * 2 * HL_PIECE, qpg_stream(stream), a);
+  QPG_LAUNCH_CHECK("audio_cosine_hl2_kernel<1>");
   return QPG_OK;
 }
 

@@ -133,9 +133,17 @@ class SegmentRecorder:
         from . import _lib
         g, self._g = self._g, None
         g.capture_end()
-        if _lib.n_calls > self._n0:             # (a segment without a launch is not instantiated, nor replayed)
-            self.program.append(g.replay)
-            self.kinds.append("graph")
+        if _lib.n_calls == self._n0:
+            # No launch of this library's in the segment.  It may still hold torch-native nodes (a copy_, a zero_, an index
+            # op between two collectives), which a replay must not lose - or be empty, which torch refuses to
+            # replay.  One trial replay tells the two apart: an empty graph raises, anything else runs once more than
+            # the eager recording pass did (stream-ordered, during recording only).
+            try:
+                g.replay()
+            except Exception:                   # noqa: BLE001 (an empty capture)
+                return
+        self.program.append(g.replay)
+        self.kinds.append("graph")
 
     def cut(self, issue, alloc=None):
         """End the open segment, run the collective `issue(out)` eagerly ONCE (every rank does: the call order on the

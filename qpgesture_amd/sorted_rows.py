@@ -128,8 +128,8 @@ class SortedRows:
                scratch=None, cols_packed=False):
         """qn: f32 [Q][d] sklearn-normalised queries.  Prefilter GEMM + banded exact select; per-code tables (dist f32
         [Q][K], idx i32 [Q][K] original row indices), optionally the nearest neighbours nn i32 [Q] and the ranks of the
-        table rows (rank i16 [Q][K]).  An overflowing band list ORs 1 into stats[1] (the caller re-evaluates on the exact
-        sweep).  idx_base is added to the indices; q_block / block_stride: the row shards' exchange layout (dist / idx are
+        table rows (rank i16 [Q][K]).  An overflowing band list ORs 16 (FLAG_TEXT_OVERFLOW) into stats[1] (the caller
+        re-evaluates on the exact sweep).  idx_base is added to the indices; q_block / block_stride: the row shards' exchange layout (dist / idx are
         then views of the exchange buffer; no ranks).
         scratch: a dict OWNED BY THE CALLER that keeps the column image, the prefilter matrix and the tile minima between
         calls.  This object is shared (GestureDB.txt_sorted is used by every lane of a ClipPipeline, each on its own

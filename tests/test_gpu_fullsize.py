@@ -74,6 +74,57 @@ def test_fullsize_tables_vs_c_oracle(speechlike):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("speechlike", [False, True])
+def test_fullsize_f16_track_one_plane_sweep_vs_c_oracle(speechlike):
+    """BASELINE.json configs[4] "fp16 features" at the bench size (N_db = 2048, Q = 48): the track stored in f16 is swept
+    by the ONE-plane split-f16 kernel (qpg_audio_cosine_hl1: the f16 values are their own h plane).  Tables equal the C
+    port's on the f16-ROUNDED track (winners exact, ranks exact, distances inside the a-priori bound where nothing was
+    re-evaluated), the f64 sweep of the same rounded track agrees to 1e-13, and the matched codes equal the uncapped
+    path's."""
+    import torch
+    from oracle import cref, knn_oracle as O
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    from qpgesture_amd.data_processing import interp_wavlm
+    N, M = 2048, 6
+    A = _db(N, 120, speechlike=speechlike)
+    te = synth.make_db(M, 220)
+    if speechlike:
+        synth.speechlike_transform(te, 227)
+    te_i = interp_wavlm(te["wavlm"])
+    te_c = np.ascontiguousarray(te["context"].squeeze(2))
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0", feature_dtype="f16")
+    assert db.hl_image is not None and db.hl_planes == 1 and db.hl_image.numel() == N * 27 * 3 * 1024 * 2
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    ti, tc = torch.from_numpy(te_i).cuda(), torch.from_numpy(te_c).cuda()
+    T = knn.sweep_tables(ti, tc, M)
+    assert knn._last_audio_hl and knn._last_audio_mixed
+    rounded = A["interp"].astype(np.float16).astype(np.float32)
+    cores = os.cpu_count() or 1
+    q = np.stack([O.wavlm_feat_rows(te_i, w, [24 * s])[0] for w in range(M) for s in range(8)])
+    d_ref, i_ref = cref.audio_scan(rounded, np.arange(26) * 6, A["code"], np.arange(26), q, n_threads=cores)
+    assert np.array_equal(T["aud_idx"].cpu().numpy(), i_ref)
+    assert np.abs(T["aud_d"].cpu().numpy() - d_ref).max() < aud_tol(knn)
+    want = np.argsort(np.argsort(d_ref, axis=1, kind="stable"), axis=1, kind="stable")
+    assert np.array_equal(T["aud_rank"].cpu().numpy(), want)
+    # the sweep's own matrix against the f64 sweep of the same rounded track: inside the a-priori bound, everywhere
+    D_hl = knn._last_D_aud.double()
+    k64 = CodeKNN(db, rng=np.random.RandomState(1))
+    k64.audio_precision = "f64"
+    T64 = k64.sweep_tables(ti, tc, M)
+    err = float((D_hl - k64._last_D_aud).abs().max())
+    print("one-plane sweep: max |D - f64 sweep| = %.3g (bound 1.3e-6)" % err)
+    assert err < 1.3e-6
+    assert torch.equal(T64["aud_idx"], T["aud_idx"]) and torch.equal(T64["aud_rank"], T["aud_rank"])
+    assert np.abs(T64["aud_d"].cpu().numpy() - d_ref).max() < 1e-13
+    kx = CodeKNN(db, rng=np.random.RandomState(1))
+    kx.audio_precision = "exact"
+    sc, sp = kx.init_code_phase()
+    a = knn.match_clip(ti, tc, M, seed_code=sc, seed_phase=sp)[0]
+    b = kx.match_clip(ti, tc, M, seed_code=sc, seed_phase=sp)[0]
+    assert np.array_equal(a, b) and knn.fallbacks == 0
+
+
 def test_empty_clip_returns_empty_arrays():
     """n_windows = 0 used to read an uninitialised status word; the walk now always writes it and match_clip
     answers an empty clip without launching anything."""
@@ -303,6 +354,7 @@ def test_f16_feature_storage_vs_c_oracle_on_rounded_track():
     knn = CodeKNN(db, rng=np.random.RandomState(1))
     ti, tc = torch.from_numpy(te_i).cuda(), torch.from_numpy(te_c).cuda()
     T = knn.sweep_tables(ti, tc, clips * M)
+    assert knn._last_audio_hl and db.hl_planes == 1          # round 5: the one-plane split-f16 sweep, 16 query chunks
     rounded = A["interp"].astype(np.float16).astype(np.float32)
     q = np.stack([O.wavlm_feat_rows(te_i, w, [24 * s])[0] for w in range(clips * M) for s in range(8)])
     d_ref, i_ref = cref.audio_scan(rounded, np.arange(26) * 6, A["code"], np.arange(26), q, n_threads=os.cpu_count() or 1)
@@ -319,6 +371,52 @@ def test_f16_feature_storage_vs_c_oracle_on_rounded_track():
     T32 = CodeKNN(db32, rng=np.random.RandomState(1)).sweep_tables(ti, tc, clips * M)
     assert 1e-9 < float((T32["aud_d"] - T["aud_d"]).abs().max()) < 1e-2          # input rounding, nothing else
     assert torch.equal(T32["txt_d"], T["txt_d"])                                   # the text side is untouched
+
+
+def test_captured_16_clip_step_with_the_encode_leg_equals_encode_then_match():
+    """BASELINE.json configs[4] as ONE captured step (round 5): 16 clips x 6 windows against an f16-stored track, the
+    VQ-VAE encode of a pose batch on a branch of the same hipGraph.  A replay's codes / votes / status of every clip equal
+    the eager batched walk's from the same per-clip seeds, its ids equal VQVAE.encode's, a second replay with other
+    seeds (the seed block is data) equals ITS eager walk, and a replay that was not collected can not be overwritten."""
+    import torch
+    from qpgesture_amd import synth
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    from qpgesture_amd.data_processing import interp_wavlm
+    from qpgesture_amd.vqvae import VQVAE
+    N, clips, M = 256, 16, 6
+    A = _db(N, 730)
+    te = synth.make_db(clips * M, 731)
+    ti = torch.from_numpy(interp_wavlm(te["wavlm"])).cuda()
+    tc = torch.from_numpy(np.ascontiguousarray(te["context"].squeeze(2))).cuda()
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0", feature_dtype="f16")
+    enc = VQVAE(None, 135, device="cuda:0").load_state_dict(synth.make_vqvae_state_dict(7))
+    x = torch.randn((24, 240, 135), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(5))
+    want_ids = enc.encode(x)[0].cpu().numpy()
+    knn = CodeKNN(db, rng=np.random.RandomState(1))
+    rng = np.random.RandomState(9)
+    kg = CodeKNN(db, rng=np.random.RandomState(1))
+    cg = kg.capture_clip_graph(M, audio=ti, context=tc, n_clips=clips, encoder=enc, encode_input=x)
+    for rep in range(2):
+        seeds = rng.randint(0, 512, size=clips)
+        phases = rng.standard_normal((clips, 8, 16)).astype(np.float32)
+        T = knn.sweep_tables(ti, tc, clips * M, for_walk=True)
+        knn.walk_batch(T, M, clips, seeds, phases)
+        want = knn._last_ints.cpu().numpy()                                  # [clip][codes | votes | status]
+        ints = cg.run_ints(seeds, phases)
+        assert cg.captures == 1
+        n_c = M * 30
+        assert np.array_equal(cg.codes(ints).reshape(clips, -1), want[:, :n_c])
+        assert np.array_equal(ints[clips * n_c:clips * (n_c + M * 8)].reshape(clips, -1), want[:, n_c:n_c + M * 8])
+        assert np.array_equal(cg.statuses(ints), want[:, -2:]) and not want[:, -2:].any()
+        assert np.array_equal(cg.encoded_ids(ints), want_ids)
+    # one clip of the batch matched alone from its seed: the same codes
+    alone = CodeKNN(db, rng=np.random.RandomState(1))
+    c7, _, _ = alone.match_clip(ti[7 * M:8 * M], tc[7 * M:8 * M], M, seed_code=int(seeds[7]), seed_phase=phases[7])
+    assert np.array_equal(c7, cg.codes(ints)[7])
+    cg.launch(seeds, phases)
+    with pytest.raises(RuntimeError, match="not been collected"):
+        cg.launch(seeds, phases)
+    cg.wait_ints()
 
 
 def test_input_validation():

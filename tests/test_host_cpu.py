@@ -1,5 +1,6 @@
 """CPU tests of the host logic and of the C-ABI library surface (no compute calls without a GPU)."""
 import ctypes
+import os
 import tempfile
 
 import numpy as np
@@ -31,7 +32,7 @@ def test_bindings_cover_the_header():
                                "qpg_merge_mixed_ws_bytes", "qpg_debug_convt_shape",
                                "qpg_percode_select_exact_ws_bytes", "qpg_audio_hl_supported",
                                "qpg_audio_hl_db_bytes", "qpg_audio_hl_query_bytes", "qpg_hl_rows_bytes",
-                               "qpg_hl_cols_bytes", "qpg_dev_kernarg"}
+                               "qpg_hl_cols_bytes", "qpg_dev_kernarg", "qpg_audio_hl1_supported", "qpg_audio_hl1_db_bytes"}
     assert declared == bound
 
 
@@ -298,9 +299,19 @@ def test_mixed_precision_constants_agree_with_the_header():
     assert m2 and float(m2.group(1)) == code_knn.AUDIO_HL_ERR and code_knn.AUDIO_HL_BAND >= 2.0 * code_knn.AUDIO_HL_ERR
     # the split-f16 sweep's budget (csrc/qpg_audio_hl.hip, audio_cosine_hl2_kernel): chains of six instructions through
     # one accumulator, the four cross-term instructions first; representation; the f32-stored matrix;
-    # subnormal l planes (2^-25 sqrt(6144) / 2^14 per side); f64 sums
+    # subnormal l planes: an absolute error <= 2^-25 per element = 2^-25 sqrt(6144) / |x|_scaled of the product of norms per
+    # side, with |x|_scaled >= sqrt(HL_NORM2_MIN) - the threshold the sweeps' validity guard enforces (the
+    # guard used to ask for a scaled norm >= 1 while this line divided by 2^14); f64 sums
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qpgesture_amd", "csrc",
+                            "qpg_audio_hl.hip")).read()
+    norm2_min = float(re.search(r"#define\s+HL_NORM2_MIN\s+([0-9.eE+-]+)", src).group(1))
+    assert len(re.findall(r"< HL_NORM2_MIN", src)) >= 4          # both sweep kernels, both operands
     k6 = 13 + 17 * 2.0 ** -10                       # cross instructions first: round 3's chain of two + a tiny C
-    assert code_knn.AUDIO_HL_ERR >= k6 * u + (2 * 2.0 ** -23 + u) + 2 * u + 2 * 2.0 ** -25 * 6144 ** 0.5 / 2 ** 14 + 1e-13
+    assert code_knn.AUDIO_HL_ERR >= (k6 * u + (2 * 2.0 ** -23 + u) + 2 * u +
+                                     2 * 2.0 ** -25 * 6144 ** 0.5 / norm2_min ** 0.5 + 1e-13)
+    # the one-plane image of an f16-stored track (round 5): the database side is exact - chains of four, the query's
+    # representation and subnormals only
+    assert code_knn.AUDIO_HL_ERR >= k6 * u + 2.0 ** -23 + 2 * u + 2.0 ** -25 * 6144 ** 0.5 / norm2_min ** 0.5 + 1e-13
     # the text prefilter / cfg-3 GEMM keeps round 3's kernel and bound (chains of two, separate cross accumulators)
     from qpgesture_amd import sorted_rows
     assert sorted_rows.HL_GEMM_ERR >= 13 * u + 12 * 193 * u / 2048 + (2 * 2.0 ** -23 + u) + 2 * u + 1e-13

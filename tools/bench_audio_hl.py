@@ -35,3 +35,15 @@ mx = timed(lambda: _lib.call("qpg_audio_cosine_mx", dev, base, N, T, F, cand_t, 
 byt = N * 81 * F * 4 + N * G * 8 + Q * 6 * F * 4 + Q * N * G * 4
 print("N=%d Q=%d: pack_queries min %.1f us | hl sweep min %.1f / med %.1f us = %.2f TB/s algorithmic (%.0f MB) | mx sweep min %.1f / med %.1f us"
       % (N, Q, pq[0] * 1e3, hl[0] * 1e3, hl[1] * 1e3, byt / hl[1] / 1e9, byt / 1e6, mx[0] * 1e3, mx[1] * 1e3))
+if hasattr(lib, "qpg_audio_cosine_hl1"):          # round 5: the one-plane image of an f16-stored track
+    b16 = base.to(torch.float16)
+    _lib.call("qpg_frame_norm2_f64", dev, b16.float(), N * T, F, fn2)
+    _lib.call("qpg_audio_cand_norm2", dev, fn2, N, T, cand_t, G, 6, 2, cn2)
+    img1 = torch.empty((int(lib.qpg_audio_hl1_db_bytes(N, F)),), dtype=torch.uint8, device=dev)
+    _lib.call("qpg_audio_hl1_pack_db", dev, b16, N, T, F, G, 6, 2, 6, img1, img1.numel())
+    h1 = timed(lambda: _lib.call("qpg_audio_cosine_hl1", dev, img1, N, F, G, cn2, qi, qn2, Q, D, 1, D.stride(0), stats))
+    byt1 = N * 81 * F * 2 + N * G * 8 + Q * 6 * F * 4 + Q * N * G * 4
+    chunks = (Q + 47) // 48
+    mf = 2 * N * 2 * 6 * 96 * chunks * 16 * 16 * 32 * 2
+    print("N=%d Q=%d: hl1 (one-plane f16 track) sweep min %.1f / med %.1f us = %.2f TB/s algorithmic (%.0f MB), %.0f TFLOP/s f16 issued"
+          % (N, Q, h1[0] * 1e3, h1[1] * 1e3, byt1 / h1[1] / 1e9, byt1 / 1e6, mf / h1[1] / 1e9))

@@ -10,12 +10,16 @@ from qpgesture_amd.code_knn import CodeKNN, GestureDB
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 graph = len(sys.argv) > 2 and sys.argv[2] == "graph"
 N, M = 2048, 6
+CL = int(os.environ.get("QPG_LOOP_CLIPS", "1"))            # clips per step (one batched sweep, one set of walk launches)
+F16 = os.environ.get("QPG_LOOP_F16", "0") == "1"            # the track stored in f16 (one-plane sweep)
+ENC = int(os.environ.get("QPG_LOOP_ENC", "0"))             # pose windows VQ-VAE-encoded in the step
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 interp = torch.randn((N, 180, 1024), device=dev)
 ctx = rng.standard_normal((N, 30, 384)).astype(np.float32)
 phase = rng.standard_normal((N, 240, 4, 8)).astype(np.float32)
-db = GestureDB(synth.make_codes(N, 2), interp, ctx, phase, synth.make_signature(3), device=dev)
+db = GestureDB(synth.make_codes(N, 2), interp, ctx, phase, synth.make_signature(3), device=dev,
+               feature_dtype="f16" if F16 else "f32")
 knn = CodeKNN(db, rng=np.random.RandomState(123456))
 if "QPG_AUDIO_FIRST" in os.environ:
     knn.audio_first = os.environ["QPG_AUDIO_FIRST"] == "1"
@@ -30,19 +34,35 @@ if os.environ.get("QPG_FORCE_SHARDED") == "1":          # the row-shard code pat
 knn.text_lead = float(os.environ.get("QPG_TEXT_LEAD", knn.text_lead))
 knn.audio_kernel = os.environ.get("QPG_AUDIO_KERNEL", "hl")
 knn.tie_eps = float(os.environ.get("QPG_TIE_EPS", knn.tie_eps))
-te_i = torch.randn((M, 180, 1024), device=dev)
-te_c = torch.randn((M, 30, 384), device=dev)
+te_i = torch.randn((M * CL, 180, 1024), device=dev)
+te_c = torch.randn((M * CL, 30, 384), device=dev)
+enc = enc_x = None
+if ENC:
+    from qpgesture_amd.vqvae import VQVAE
+    enc = VQVAE(None, 135, device=dev).load_state_dict(synth.make_vqvae_state_dict(7))
+    enc_x = torch.randn((ENC, 240, 135), device=dev)
+    enc.encode(enc_x)
 sc, sp = knn.init_code_phase()
 spd = torch.from_numpy(sp).to(dev)
 from qpgesture_amd import code_knn as _ck
 mode = getattr(_ck, os.environ.get("QPG_LOOP_MODE", "MODE_AUD_TXT"))        # MODE_AUD: audio side only (measurements)
-g = knn.capture_clip_graph(M, mode=mode, audio=te_i, context=te_c, owner_blocks=knn.force_sharded) if graph else None
+g = knn.capture_clip_graph(M, mode=mode, audio=te_i, context=te_c, owner_blocks=knn.force_sharded, n_clips=CL,
+                           encoder=enc, encode_input=enc_x) if graph else None
+spb = torch.from_numpy(np.tile(sp.reshape(1, -1), (CL, 1))).to(dev)
 
 
 def step():
     if graph:
         return g.run_ints(sc, sp)
-    T = knn.sweep_tables(te_i, te_c, M, mode=mode, owner_blocks=knn.force_sharded, for_walk=True)
+    if enc is not None:
+        ids = enc.encode(enc_x)[0]
+    T = knn.sweep_tables(te_i, te_c, M * CL, mode=mode, owner_blocks=knn.force_sharded, for_walk=True)
+    if CL > 1:
+        knn.walk_batch(T, M, CL, [sc] * CL, spb, mode=mode)
+        out = knn._last_ints.cpu()
+        if enc is not None:
+            ids.cpu()
+        return out
     return knn.walk(T, M, 0, mode=mode, seed_code=sc, seed_phase=spd, sync="ints")      # (codes | votes | status, pinned host memory)
 
 
