@@ -168,12 +168,6 @@ int qpg_clip_pack_hl(qpg_ctx*, void* stream, const float* qbase, int M, int T, i
                      const int32_t* tq_row, int Qt, float* qn_out, void* cols_image, int64_t cols_bytes);
 int qpg_audio_cosine_hl(qpg_ctx*, void* stream, const void* db_image, int N, int F, int G, const double* cn2,
                         const void* q_image, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD, int32_t* stats);
-/* Windows [win_begin, win_end) of the same sweep (N stays the image's window count; other columns of D are untouched): two
- * launches over complementary ranges ARE the sweep, and the caller can record an event between them (the matcher starts
- * its text side when the first part is done instead of at the very end). */
-int qpg_audio_cosine_hl_range(qpg_ctx*, void* stream, const void* db_image, int N, int F, int G, const double* cn2,
-                              const void* q_image, const double* qn2, int Q, void* D, int d_is_f32, int64_t ldD,
-                              int32_t* stats, int win_begin, int win_end);
 /* The same sweep over a track stored in IEEE f16 (round 5; BASELINE.json configs[4] "fp16 features"): an f16 value is
  * its own h plane, so the database image has ONE plane, no scale exponent and no representation error - half the bytes
  * (N x 27 rows x 3 F f16, every byte read once) and two products per element (h h', l' h) instead of three.  Same query
@@ -285,34 +279,7 @@ int qpg_wavvq_lev_f32(qpg_ctx*, void* stream, const int32_t* sym_db, int N, int 
                       const int32_t* tap_off, int n_taps, const int32_t* sym_q, int Mq, int Tq,
                       const int32_t* q_win, const int32_t* q_t, int Q, float* D, int64_t ldD);
 
-/* Segmented min + argmin by code id, first index wins on ties (GestureKNN.py:686-689).
- * code: [dev] i32 [N][code_ld]; cand_cidx: [dev] i32 [G] column of `code` for grid position g;
- * out_dist: [dev] [Q][K] (initialised to `absent`, the reference's 1e+3); out_idx: [dev] i32 [Q][K]
- * global candidate index + idx_base, -1 where the code never occurs. */
-int qpg_percode_argmin_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int32_t* code,
-                           int code_ld, int N, const int32_t* cand_cidx, int G, int K, double absent,
-                           int32_t idx_base, double* out_dist, int32_t* out_idx);
-int qpg_percode_argmin_f32(qpg_ctx*, void* stream, const float* D, int64_t ldD, int Q, const int32_t* code,
-                           int code_ld, int N, const int32_t* cand_cidx, int G, int K, float absent,
-                           int32_t idx_base, float* out_dist, int32_t* out_idx);
-
-/* Fast path of the per-code argmin.  resolve (f64): two full-chip passes over D — per-code minimum of the
- * order-preserving 64-bit distance key -> best_key [dev] u64 [Q][K] (out), then the lowest candidate index
- * (+idx_base) among the entries equal to it -> best_idx [dev] u32 [Q][K] (0xffffffff = code absent).
- * resolve (f32): distance key and index share one u64, one pass -> packed [dev] u64 [Q][K].  finalize: keys -> out_dist
- * (`absent` where the code never occurs), out_idx (-1 absent) and, if out_rank != NULL, the stable ranks. */
-int qpg_percode_resolve_f64(qpg_ctx*, void* stream, const double* D, int64_t ldD, int Q, const int32_t* code,
-                            int code_ld, int N, const int32_t* cand_cidx, int G, int K, int32_t idx_base,
-                            uint64_t* best_key, uint32_t* best_idx);
-int qpg_percode_resolve_f32(qpg_ctx*, void* stream, const float* D, int64_t ldD, int Q, const int32_t* code,
-                            int code_ld, int N, const int32_t* cand_cidx, int G, int K, int32_t idx_base,
-                            uint64_t* packed);
-int qpg_percode_finalize_f64(qpg_ctx*, void* stream, const uint64_t* best_key, const uint32_t* best_idx, int Q,
-                             int K, double absent, double* out_dist, int32_t* out_idx, int16_t* out_rank);
-int qpg_percode_finalize_f32(qpg_ctx*, void* stream, const uint64_t* packed, int Q, int K, float absent,
-                             float* out_dist, int32_t* out_idx, int16_t* out_rank);
-
-/* One-launch form of resolve + finalize (the fast path since round 2): per query row the per-code minimum, its
+/* Segmented min + argmin by code id in one launch: per query row the per-code minimum, its
  * first-wins candidate (lowest index among equal distances == the strict `<` scan of GestureKNN.py:686-689, 717-720),
  * `absent` / -1 for codes with no candidate, and optionally the stable ranks of the 512 minima.
  * D: [dev] [Q][ldD] distances; cand_code: [dev] i16 [C] code of candidate c (values outside [0,K) are skipped);
@@ -389,25 +356,14 @@ int64_t qpg_percode_select_mixed_ws_stride(int K);
  * position among them; every entry the walk can read - and therefore every selected code index - is what
  * qpg_percode_select_mixed_f64 returns.  pos_rank_t [dev] i16 [K][K]: the TRANSPOSE of qpg_match_steps' pos_rank
  * (pos_rank_t[c * K + p]); freq_rank [dev] i16 [K]; top_n: 1 with the text side, 2 without; probe: best-ranked codes the
- * bound on the winning score is taken over (0: 64); parts: 3 = the whole call (1 / 2: see ..._parts below). */
+ * bound on the winning score is taken over (0: 64). */
 int qpg_percode_select_mixed_f64_cut(qpg_ctx*, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
                                      const int16_t* cand_code, int64_t C, int K, double absent, int32_t idx_base,
                                      double* out_dist, int32_t* out_idx, int16_t* out_rank, int q_block, int64_t block_stride,
                                      const float* base, int T, int F, const int32_t* cand_t, int G, int n_taps,
                                      int tap_stride, const float* q32, const double* qn2, const double* cn2, double eps1,
                                      double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16,
-                                     const int16_t* pos_rank_t, const int16_t* freq_rank, int top_n, int probe, int parts);
-/* The same call issued in PARTS (f32 matrix + workspace only): parts = 1 the streaming pass alone, 2 everything behind it,
- * 3 both (= qpg_percode_select_mixed_f64).  Same arguments for both halves.  For the host's scheduling: between the two
- * halves it records the event the text side's prefilter GEMM waits for, so that the streaming pass (on the clip's critical
- * path, all CUs) is not shared with that GEMM and the GEMM runs beside the list pass instead (one block per query:
- * GestureKNN.py:666-691's scan is per query, :708-721's text scan independent of it). */
-int qpg_percode_select_mixed_f64_parts(qpg_ctx*, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
-                                       const int16_t* cand_code, int64_t C, int K, double absent, int32_t idx_base,
-                                       double* out_dist, int32_t* out_idx, int16_t* out_rank, int q_block, int64_t block_stride,
-                                       const float* base, int T, int F, const int32_t* cand_t, int G, int n_taps,
-                                       int tap_stride, const float* q32, const double* qn2, const double* cn2, double eps1,
-                                       double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16, int parts);
+                                     const int16_t* pos_rank_t, const int16_t* freq_rank, int top_n, int probe);
 
 /* Cross-shard merge when the shards swept with qpg_audio_cosine_mx (their tables are accurate to QPG_AUDIO_MX_ERR; each
  * shard's own select has settled the near-ties inside the shard).  Three steps around two more byte exchanges:

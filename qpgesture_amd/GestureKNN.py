@@ -51,7 +51,27 @@ def build_parser():
                         "undecided comparison (same output); f64: the f64 matrix-core sweep; exact: f64 sweep + the uncapped "
                         "near-tie guard.  A clip on which a capped guard of mixed / f64 raises its trouble word is "
                         "re-matched on `exact` automatically: unguarded codes are never written")
+    p.add_argument('--db_cache', choices=["auto", "off", "refresh"], default="auto",
+                   help="prepared-database cache (qpgesture_amd/db_cache.py): the device-resident database this command "
+                        "builds from the five database-side files is written once, keyed by their paths, sizes and mtimes, "
+                        "and restored by later invocations without re-reading / re-packing anything.  auto: use or create; "
+                        "refresh: rebuild and overwrite; off: never touch the cache directory")
+    p.add_argument('--db_cache_dir', type=str, default=None, help="default: $QPG_DB_CACHE_DIR or ~/.cache/qpgesture_amd")
     return p
+
+
+def _tables_have_exact_ties(T):
+    """Device-side: does any row of the audio / text minima hold two EQUAL values?  Only then can NumPy's unstable
+    argsort (the reference's rank expression, GestureKNN.py:553, 574) differ from the stable ranks the device took."""
+    import torch
+    flag = None
+    for k in ("aud_d", "txt_d"):
+        if T.get(k) is None:
+            continue
+        sd = torch.sort(T[k], dim=1).values
+        f = (sd[:, 1:] == sd[:, :-1]).any()
+        flag = f if flag is None else (flag | f)
+    return flag
 
 
 def main_codebook(args, maxFrames=0):
@@ -60,21 +80,35 @@ def main_codebook(args, maxFrames=0):
     from .code_knn import MODE_AUD, MODE_AUD_TXT, MODE_TXT, CodeKNN, GestureDB
     from .data_processing import load_db_codebook
 
+    from . import db_cache
+    from .data_processing import load_test_side
+
     t0 = time.time()
-    L = load_db_codebook(args.train_database, args.train_codebook, args.test_data, args.train_wavlm,
-                         args.test_wavlm, args.train_wavvq, args.test_wavvq, device=args.device)
-    signature = np.load(args.codebook_signature)['signature']                     # :476
-    freq_rank = None
-    if args.tie_rule == "numpy":
-        cnt = np.bincount(np.asarray(L.code).reshape(-1), minlength=512)[:512]
-        freq = np.where(cnt > 0, 1 - cnt / cnt.sum(), 1.0)                       # :481-499
-        freq_rank = np.array(list(freq)).argsort().argsort()                     # :544, the reference's own call
     vq = args.mode.startswith("wavvq")
-    db = GestureDB(L.code, L.train_wavlm, L.train_context, L.train_phase, signature, device=args.device,
-                   freq_rank=freq_rank, wavvq=L.train_wavvq if vq else None)
+    db, cpath, ckey = None, None, None
+    if args.db_cache != "off":
+        files = [args.train_database, args.train_codebook, args.train_wavlm, args.codebook_signature] + \
+            ([args.train_wavvq] if vq else [])
+        ckey = db_cache.file_key(files, {"tie_rule": args.tie_rule, "wavvq": vq, "device_kind": "hip"})
+        cpath = db_cache.cache_path(ckey, args.db_cache_dir)
+        if args.db_cache == "auto":
+            db = GestureDB.load(cpath, args.device, ckey)
+    from_cache = db is not None
+    if db is None:
+        L = load_db_codebook(args.train_database, args.train_codebook, args.test_data, args.train_wavlm,
+                             args.test_wavlm, args.train_wavvq, args.test_wavvq, device=args.device)
+        signature = np.load(args.codebook_signature)['signature']                 # :476
+        freq_rank = None
+        if args.tie_rule == "numpy":
+            cnt = np.bincount(np.asarray(L.code).reshape(-1), minlength=512)[:512]
+            freq = np.where(cnt > 0, 1 - cnt / cnt.sum(), 1.0)                   # :481-499
+            freq_rank = np.array(list(freq)).argsort().argsort()                 # :544, the reference's own call
+        db = GestureDB(L.code, L.train_wavlm, L.train_context, L.train_phase, signature, device=args.device,
+                       freq_rank=freq_rank, wavvq=L.train_wavvq if vq else None)
+    else:
+        L = load_test_side(args.test_data, args.test_wavlm, args.test_wavvq, device=args.device)
     knn = CodeKNN(db, use_wavlm=not vq, use_wavvq=vq)                            # draws from np.random like :463-464
     knn.audio_precision = args.audio_precision
-    knn.host_ranks = args.tie_rule == "numpy"        # audio / text minima ranked by the reference's own NumPy call
     n_test_seq = maxFrames if maxFrames != 0 else L.test_wavvq.shape[0]          # :740
     dev = db.device
     te_i = (torch.from_numpy(np.ascontiguousarray(L.test_wavvq[:n_test_seq])).to(dev) if vq
@@ -84,13 +118,29 @@ def main_codebook(args, maxFrames=0):
     print('begin search...')
     mode = {"shipped": MODE_AUD_TXT, "audio": MODE_AUD, "text": MODE_TXT, "wavvq": MODE_AUD_TXT,
             "wavvq_audio": MODE_AUD}[args.mode]
-    pred_seqs, _, _ = knn.match_clip(te_i, te_c, n_test_seq, mode=mode)   # (re-matches on the uncapped path if flagged)
+    seed_code, seed_phase = knn.init_code_phase()                                 # (drawn once: :462-473)
+    # --tie_rule numpy: the reference ranks both (Q,512) tables with NumPy's UNSTABLE argsort, whose order differs from a
+    # stable one only among EQUAL values.  So the clip is matched with the device's stable ranks, the tables are checked for
+    # exact ties on the device, and only a clip that has one is ranked again by the reference's own NumPy call on the host
+    # (CodeKNN.host_ranks: both tables through the host in the middle of the step).  Real text tracks tie (silent frames
+    # share one embedding); continuous features do not.
+    pred_seqs, _, _ = knn.match_clip(te_i, te_c, n_test_seq, mode=mode, seed_code=seed_code, seed_phase=seed_phase,
+                                     return_tables=True)                           # (re-matches on the uncapped path if flagged)
+    if args.tie_rule == "numpy" and bool(_tables_have_exact_ties(knn.tables)):
+        knn.host_ranks = True
+        pred_seqs, _, _ = knn.match_clip(te_i, te_c, n_test_seq, mode=mode, seed_code=seed_code, seed_phase=seed_phase)
     t2 = time.time()
     if knn.fallbacks:
         print('near-tie guard: a capped re-evaluation list overflowed; the clip was re-matched on the uncapped path')
     print(pred_seqs.shape)
     np.savez_compressed(args.out_knn_filename, knn_pred=pred_seqs)               # :845
-    print('load+prepare %.2fs, match %.4fs (%.0f frames/s)' % (t1 - t0, t2 - t1, 240 * n_test_seq / (t2 - t1)))
+    print('load+prepare %.2fs%s, match %.4fs (%.0f frames/s)' % (t1 - t0, ' (prepared-database cache)' if from_cache else '',
+                                                                   t2 - t1, 240 * n_test_seq / (t2 - t1)))
+    if cpath is not None and not from_cache:
+        try:                                    # behind the result: a later invocation finds the database prepared
+            db.save(cpath, ckey)
+        except (OSError, TypeError) as e:
+            print('prepared-database cache not written: %s' % e)
     return pred_seqs
 
 

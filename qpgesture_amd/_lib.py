@@ -38,7 +38,6 @@ _SIGS = {
     "qpg_audio_pack_queries_hl": [P, I, I, I, P, P, I, I, I, P, P, P, L],
     "qpg_clip_pack_hl": [P, I, I, I, P, P, I, I, I, P, P, P, L, P, I, I, I, P, P, I, P, P, L],
     "qpg_audio_cosine_hl": [P, I, I, I, P, P, P, I, P, I, L, P],
-    "qpg_audio_cosine_hl_range": [P, I, I, I, P, P, P, I, P, I, L, P, I, I],
     "qpg_audio_hl1_pack_db": [P, I, I, I, I, I, I, I, P, L],
     "qpg_audio_cosine_hl1": [P, I, I, I, P, P, P, I, P, I, L, P],
     "qpg_debug_mfma_f16_tile": [P, P, P, I, P],
@@ -53,10 +52,6 @@ _SIGS = {
     "qpg_text_percode_f32": [P, L, I, P, I, P, I, I, ctypes.c_int32, c_float, P, L, P, P, P, P],
     "qpg_text_pack_candidates_f16": [P, I, I, I, P, I, P, P],
     "qpg_text_percode_f16": [P, P, L, I, P, I, P, I, ctypes.c_int32, c_float, P, L, P, P, P, P],
-    "qpg_percode_resolve_f32": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P],
-    "qpg_percode_resolve_f64": [P, L, I, P, I, I, P, I, I, ctypes.c_int32, P, P],
-    "qpg_percode_finalize_f64": [P, P, I, I, c_double, P, P, P],
-    "qpg_percode_finalize_f32": [P, I, I, c_float, P, P, P],
     "qpg_percode_select_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L],
     "qpg_percode_select_f32": [P, L, I, P, L, I, c_float, ctypes.c_int32, P, P, P, I, L],
     "qpg_percode_select_guarded_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
@@ -64,9 +59,7 @@ _SIGS = {
     "qpg_percode_select_mixed_f64": [P, I, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
                                      P, P, c_double, c_double, P, P, L, I],
     "qpg_percode_select_mixed_f64_cut": [P, I, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I,
-                                         P, P, P, c_double, c_double, P, P, L, I, P, P, I, I, I],
-    "qpg_percode_select_mixed_f64_parts": [P, I, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I,
-                                           P, P, P, c_double, c_double, P, P, L, I, I],
+                                         P, P, P, c_double, c_double, P, P, L, I, P, P, I, I],
     "qpg_percode_select_exact_f64": [P, L, I, P, L, I, c_double, ctypes.c_int32, P, P, P, I, L, P, I, I, P, I, I, I, P,
                                      c_double, P, I, P, L],
     "qpg_merge_mixed_phase1_f64": [P, I, L, L, L, I, I, c_double, c_double, I, P, L, P, L, P, I, L],
@@ -76,8 +69,6 @@ _SIGS = {
     "qpg_merge_mixed_phase2_f64": [P, I, L, L, I, I, c_double, P, L, P, L, P, P, P, P, I, c_double],
     "qpg_merge_select_f64": [P, I, L, L, L, I, I, c_double, P, P, P, c_double, P],
     "qpg_merge_select_f32": [P, I, L, L, L, I, I, c_float, P, P, P],
-    "qpg_percode_argmin_f64": [P, L, I, P, I, I, P, I, I, c_double, ctypes.c_int32, P, P],
-    "qpg_percode_argmin_f32": [P, L, I, P, I, I, P, I, I, c_float, ctypes.c_int32, P, P],
     "qpg_rank_rows_f64": [P, I, I, P],
     "qpg_rank_rows_f32": [P, I, I, P],
     "qpg_l2_table_f32": [P, I, I, P],

@@ -318,6 +318,32 @@ class GestureDB:
         else:
             self.freq_rank = torch.as_tensor(np.asarray(freq_rank, np.int16), device=dev).contiguous()
 
+    # -- prepared-database cache (round 5; db_cache.py): what the constructor built, written once, restored without a
+    #    single build launch - the drop-in CLI's second and later invocations (GestureKNN.py:816-845 reloads everything)
+    def save(self, path, key=""):
+        from . import db_cache
+        return db_cache.save(self, path, key)
+
+    @classmethod
+    def load(cls, path, device="cuda:0", key=None):
+        """The GestureDB saved at `path`, or None (missing / foreign / keyed differently).  The bounded paths' one
+        measured hardware property is re-measured on THIS device (selfcheck.mfma_bound_ok): a device that fails it keeps
+        the restored object but not its split-f16 images."""
+        from . import db_cache
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("GestureDB needs a HIP device (got %s); there is no CPU path" % dev)
+        _lib.load()
+        db = db_cache.load(path, dev, key)
+        if db is None:
+            return None
+        if db.hl_image is not None or db.txt_sorted is not None:
+            from .selfcheck import mfma_bound_ok
+            db.hl_bound_ok, db.hl_bound_report = mfma_bound_ok(dev)
+            if not db.hl_bound_ok:
+                db.hl_image = db.txt_sorted = None
+        return db
+
     @staticmethod
     def _cand_code(code_local, cidx, dev):
         cc = np.ascontiguousarray(code_local[:, np.asarray(cidx, np.int64)].reshape(-1))
@@ -348,7 +374,6 @@ class CodeKNN:
         self.rng = rng if rng is not None else np.random
         self.overlap_sweeps = True          # text sweep on a second HIP stream underneath the audio sweep
         self.text_after_sweep = True        # ... started when the audio sweep ends, i.e. underneath the audio SELECT ...
-        self.text_lead = 0.0                # > 0: ... when all but this fraction of it is done (measured: no gain, below)
         self.audio_first = None             # no ordering between the two streams; None: auto (sweep_tables)
         self.serial_walk = False            # True: force the one-wave sequential walk (tests compare the two)
         # Near-tie guard of the audio select (qpg_percode_select_guarded_f64): candidates / code minima closer than
@@ -388,12 +413,6 @@ class CodeKNN:
         # tables sweep_tables() hands to anyone else are exact everywhere, as before.  QPG_RANK_CUT=0: off.
         self.rank_cut = _os.environ.get("QPG_RANK_CUT", "1") != "0"
         self.rank_cut_probe = 64
-        # "none" (default): no ordering between the two sides behind the pack; "stream" (measurements): the text side's GEMM
-        # waits for the end of the audio select's streaming pass.  Measured slower (tools/gate_probe.sh, one box, graph
-        # step 0.283 -> 0.307 ms): the pass does run alone (20 -> 9 us), but the GEMM then shares the chip with the tier-1
-        # dot products and the two, 82 MB and 108 MB of row gathers, take the sum of their times (54 us: ~3.6 TB/s in all) -
-        # the post-sweep path is bound by its bytes, not by how its launches are arranged.
-        self.text_gate = _os.environ.get("QPG_TEXT_GATE", "none")
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
         # Row-sharded DB: the shards sweep in mixed precision too and the cross-shard merge re-evaluates what their
         # bounded tables leave open through a request / response exchange (sweep_tables; qpg_merge_mixed_*).
@@ -504,10 +523,9 @@ class CodeKNN:
             qi = self.__dict__.get("_hl_qimage")
             if qi is None or qi.numel() < nbq:
                 qi = self._hl_qimage = torch.empty((nbq,), dtype=torch.uint8, device=dev)
-            if not (getattr(self, "_want_sweep_event", False) and self.text_lead > 0 and db.hl_planes == 2):
-                # the sweep's arguments are converted BEFORE the pack goes out: its launch follows the pack's at once
-                sweep_launch = _lib.prepare(hl_fn, dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi,
-                                            qn2, Q, D, 1, D.stride(0), self._guard_stats)
+            # the sweep's arguments are converted BEFORE the pack goes out: its launch follows the pack's at once
+            sweep_launch = _lib.prepare(hl_fn, dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi,
+                                        qn2, Q, D, 1, D.stride(0), self._guard_stats)
             if prepacked is None:
                 _lib.call("qpg_audio_pack_queries_hl", dev, qbase, M, T, F, _i32(q_win, dev), _i32(q_t, dev), Q,
                           NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2, qi, qi.numel())
@@ -517,27 +535,8 @@ class CodeKNN:
                       NUM_AUDIO_FEAT_FRAMES, ts, q32, qn2)
         if ev is not None:
             e0.record(torch.cuda.current_stream(dev))          # (the events bracket the sweep kernel alone)
-        early = False
         if sweep_launch is not None:
             sweep_launch()
-        elif use_hl:
-            # text_lead > 0 (measurements): the sweep goes out in two launches and the text side's event sits between
-            # them, so that its first launches overlap the sweep's last `text_lead`.  bench.py, ms per clip at lead 0 /
-            # 0.1 / 0.2 / 0.3 / 0.45: 0.397 / 0.408 / 0.392 / 0.408 / 0.416 - the second launch's ramp-up and the
-            # contention cost what the earlier start saves; the default stays 0.
-            n1 = db.n_local
-            if getattr(self, "_want_sweep_event", False) and self.text_lead > 0:
-                n1 = max(0, min(db.n_local, int(db.n_local * (1.0 - self.text_lead)) // 4 * 4))
-            if 0 < n1 < db.n_local:
-                _lib.call("qpg_audio_cosine_hl_range", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi, qn2, Q, D,
-                          1, D.stride(0), self._guard_stats, 0, n1)
-                self._record_sweep_event(dev)
-                early = True
-                _lib.call("qpg_audio_cosine_hl_range", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi, qn2, Q, D,
-                          1, D.stride(0), self._guard_stats, n1, db.n_local)
-            else:
-                _lib.call("qpg_audio_cosine_hl", dev, db.hl_image, db.n_local, db.F, db.Ga, db.cn2, qi, qn2, Q, D, 1,
-                          D.stride(0), self._guard_stats)
         elif mixed:
             _lib.call("qpg_audio_cosine_mx_h" if half else "qpg_audio_cosine_mx", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
                       NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, 1, D.stride(0), self._guard_stats)
@@ -548,7 +547,10 @@ class CodeKNN:
         if ev is not None:
             e1.record(torch.cuda.current_stream(dev))
             ev.append((e0, e1))
-        if getattr(self, "_want_sweep_event", False) and not early:    # sweep_tables: the text side starts behind the sweep
+        hook = self.__dict__.get("after_sweep")          # (ClipGraph: the encode leg forks here, behind the sweep kernel)
+        if hook is not None:
+            hook()
+        if getattr(self, "_want_sweep_event", False):    # sweep_tables: the text side starts behind the sweep
             self._record_sweep_event(dev)
         if out is not None:          # exchange layout of the sharded path: written in place, merged after the collective
             dist, idx, qb, bs = out
@@ -574,19 +576,8 @@ class CodeKNN:
             self._last_rank_cut = use_cut
             try:
                 if use_cut:
-                    cut_args = sel_args + (db.pos_rank_t, db.freq_rank, int(cut_top_n), int(self.rank_cut_probe))
-                    if getattr(self, "_want_stream_event", False):
-                        _lib.call("qpg_percode_select_mixed_f64_cut", dev, *cut_args, 1)
-                        self._record_sweep_event(dev)
-                        _lib.call("qpg_percode_select_mixed_f64_cut", dev, *cut_args, 2)
-                    else:
-                        _lib.call("qpg_percode_select_mixed_f64_cut", dev, *cut_args, 3)
-                elif getattr(self, "_want_stream_event", False) and not self.mixed_single_launch:
-                    # sweep_tables gates the text side's GEMM on the END of the streaming pass: the pass (all CUs, on the
-                    # critical path) then runs alone, and the GEMM beside the list pass (one block per query)
-                    _lib.call("qpg_percode_select_mixed_f64_parts", dev, *sel_args, 1)
-                    self._record_sweep_event(dev)
-                    _lib.call("qpg_percode_select_mixed_f64_parts", dev, *sel_args, 2)
+                    _lib.call("qpg_percode_select_mixed_f64_cut", dev, *sel_args, db.pos_rank_t, db.freq_rank,
+                              int(cut_top_n), int(self.rank_cut_probe))
                 else:
                     _lib.call("qpg_percode_select_mixed_f64", dev, *sel_args)
             except Exception:
@@ -880,7 +871,7 @@ class CodeKNN:
         mfma_text_ = (self.text_kernel == "mfma" and db.txt_sorted is not None and self.audio_precision != "exact")
         packed = None
         if (overlap and not self.use_wavvq and mfma_text_ and self._hl_plan(sharded, M * steps) and db.Dt % 128 == 0 and
-                self.fused_pack and self.text_lead <= 0):
+                self.fused_pack):
             Qn = M * steps
             q32_ = torch.empty((Qn, NUM_AUDIO_FEAT_FRAMES * db.F), dtype=torch.float32, device=dev)
             qn2_ = torch.empty((Qn,), dtype=torch.float64, device=dev)
@@ -932,7 +923,7 @@ class CodeKNN:
         # with the matrix-core text side): the text side is enqueued behind the audio side's launches on its own stream
         # with NO ordering - its GEMM trickles through under the sweep and the tables are ready before the audio select
         # is.  bench.py, alternating in one run (tools/try_orders.sh), ms per clip: behind the sweep 0.400-0.404,
-        # text first 0.384-0.408, audio_first 0.360-0.374.  (`text_lead`: see sweep_audio.)
+        # text first 0.384-0.408, audio_first 0.360-0.374.
         # (Enqueueing the text side even earlier - between the sweep's launch and the select's - starts its GEMM 50 us
         # sooner and costs the sweep 25 us: 197 instead of 172.)
         mfma_text = self.text_kernel == "mfma" and db.txt_sorted is not None and self.audio_precision != "exact"
@@ -946,21 +937,13 @@ class CodeKNN:
         if mode in (MODE_AUD_TXT, MODE_AUD):
             fn = self.sweep_audio_wavvq if self.use_wavvq else self.sweep_audio
             self._want_sweep_event, self._sweep_done = after, None
-            # text_gate == "stream" (measurements; see __init__): the text side's GEMM, queued behind the pack, takes the
-            # freed CUs at the sweep's end and the select's streaming pass runs 20 us instead of 10 beside it; gated on the
-            # END of that pass it runs beside the tier-1 dot products instead - and the step is slower.
-            gate_stream = (overlap and audio_first and packed is not None and self.text_gate == "stream" and
-                           not self.mixed_single_launch)
-            self._want_stream_event = gate_stream
             kw = {"prepacked": packed} if (packed is not None and not self.use_wavvq) else {}
             if (for_walk and self.rank_cut and not sharded and not self.use_wavvq and not self.host_ranks and
                     mode in (MODE_AUD_TXT, MODE_AUD)):
                 kw["cut_top_n"] = 1 if mode == MODE_AUD_TXT else 2
             r = fn(test_interp, q_win, q_t, want_rank=not sharded, reduce=not sharded,
                    out=lay.views("aud") if sharded else None, **kw)
-            self._want_sweep_event = self._want_stream_event = False
-            if gate_stream and self._sweep_done is not None:
-                side.wait_event(self._sweep_done)
+            self._want_sweep_event = False
             T["aud_d"], T["aud_idx"] = r[0], r[1]
             if not sharded:
                 T["aud_rank"] = r[2]
@@ -1380,20 +1363,36 @@ class ClipGraph:
             self._enc_gate, self._enc_done = torch.cuda.Event(), torch.cuda.Event()
             ids_pin = self._pin[self._n_ints:]
 
+        import os as _os
+        enc_at = _os.environ.get("QPG_ENCODE_AT", "sweep_end")      # measurements: "start" = beside the whole match
+
+        def encode_leg():
+            # the encode leg: a branch of its own (independent work: DB-side pose windows, make_beat_dataset.py:314-316),
+            # its ids narrowed to i32 and copied into the replay's pinned result block; joined in front of the walk's
+            # last kernel, whose final stores (the status words, behind a system-scope fence) are what the host waits
+            # for.  It forks BEHIND the audio sweep: both are matrix-core work (forked at the start of the step the two
+            # took the sum of their times, 2.1 + 1.6 ms, and slowed each other down), whereas the selects and the walk
+            # behind the sweep are ~0.5 ms of gathers and latency-bound launches that leave the matrix pipes idle.
+            main = torch.cuda.current_stream(dev)
+            self._enc_gate.record(main)
+            self._enc_stream.wait_event(self._enc_gate)
+            with torch.cuda.stream(self._enc_stream):
+                ids = self.enc.encode_fused(self.enc_x)
+                ids_pin.copy_(ids.reshape(-1).to(torch.int32), non_blocking=True)
+                self._enc_done.record(self._enc_stream)
+
         def body():
             main = torch.cuda.current_stream(dev)
             if self.enc is not None:
-                # the encode leg: a branch of its own beside the match (independent work: DB-side pose windows), its ids
-                # narrowed to i32 and copied into the replay's pinned result block; joined in front of the walk, whose
-                # last store (the status words, behind a system-scope fence) is what the host waits for
-                self._enc_gate.record(main)
-                self._enc_stream.wait_event(self._enc_gate)
-                with torch.cuda.stream(self._enc_stream):
-                    ids = self.enc.encode_fused(self.enc_x)
-                    ids_pin.copy_(ids.reshape(-1).to(torch.int32), non_blocking=True)
-                    self._enc_done.record(self._enc_stream)
-            T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode, owner_blocks=self.owner_blocks,
-                                 for_walk=True)
+                if enc_at == "start" or self.mode == MODE_TXT or knn.use_wavvq:
+                    encode_leg()
+                else:
+                    knn.after_sweep = encode_leg
+            try:
+                T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode, owner_blocks=self.owner_blocks,
+                                     for_walk=True)
+            finally:
+                knn.after_sweep = None
             if self.enc is not None:
                 main.wait_event(self._enc_done)
             return knn.walk(T, self.M, self._off, self.mode, sync=False, seed_ptrs=ptrs, out_pin=self._pin,

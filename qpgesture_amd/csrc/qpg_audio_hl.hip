@@ -488,11 +488,11 @@ struct HlArgs {
 #endif
 #define HL_THREADS (128 * HL_WPB)
 #define HL_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-// MODE 0: the audio sweep (27 live super-rows per window, shifted-add epilogue).  MODE 1: plain distance GEMM over
-// generic rows (qpg_hl_gemm_distance: groups of 32 rows, all live; D[q][row] = 1 - <row, q> for unit-norm operands;
-// the chunk's 96 columns are 96 queries).
-template <int MODE>
-__global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(HlArgs a) {
+// The 16-row organisation of round 3's audio sweep, kept as the plain distance GEMM over generic rows of a clip's <= 48
+// text queries (qpg_hl_gemm_distance / _tilemin: groups of 32 rows; D[q][row] = 1 - <row, q> for unit-norm operands; the
+// chunk's 96 columns are 96 queries).  The audio sweep itself runs on audio_cosine_hl2_kernel (32-row wave tiles) since
+// round 4; its 16-row form left the library in round 5 (every grid it accepted, the 32-row kernel accepts).
+__global__ __launch_bounds__(HL_THREADS, HL_MINW) void hl_gemm16_kernel(HlArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 * HL_KS * HL_CT * 2 * HL_PIECE bytes
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wl = w >> 1, t = w & 1;                           // window of the block, row tile
@@ -508,15 +508,12 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
   const int j = a.j0 + wgrp * HL_WPB + wl;                     // (j0: first window of a partial launch)
   const int KB = a.KB, n_stage = KB / HL_KS;
   const bool win_ok = j < a.N;
-  // database fragments: plane p of k-block kb: one 16-byte load per lane, 1 KB per wave, contiguous.  Padding rows
-  // (27..31) and windows past N read the context's zero page instead (stride 0): no branch in the loop.
-  const bool row_ok = win_ok && (MODE == 1 || (16 * t + (lane & 15)) < HL_ROWS);
-  // MODE 0: the dense image (hl_pack_db_kernel) - tile 1 holds its 11 live rows only, 44 units per fragment
-  const bool dense1 = MODE == 0 && t == 1;
-  const int64_t unit0 = MODE == 1 ? (((int64_t)j * 2 + t) * KB * 2) * 64 + lane
-                        : (int64_t)j * HL_WIN_UNITS(KB) + (dense1 ? (int64_t)KB * 128 + 11 * (lane >> 4) + (lane & 15) : lane);
+  // row fragments: plane p of k-block kb: one 16-byte load per lane, 1 KB per wave, contiguous.  Row groups past N read
+  // the context's zero page instead (stride 0): no branch in the loop.
+  const bool row_ok = win_ok;
+  const int64_t unit0 = (((int64_t)j * 2 + t) * KB * 2) * 64 + lane;
   const h8* dbp = row_ok ? reinterpret_cast<const h8*>(a.db) + unit0 : reinterpret_cast<const h8*>(a.zeros);
-  const int pl_step = row_ok ? (dense1 ? HL_T1_UNITS : 64) : 0;         // h8 units per plane / k-block
+  const int pl_step = row_ok ? 64 : 0;                                   // h8 units per plane / k-block
   const int kb_step = 2 * pl_step;
   // (HL_NT: the database image is read ONCE - a non-temporal load keeps it from evicting the query image, which every
   // block re-reads, out of the XCD's L2)
@@ -652,91 +649,44 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void audio_cosine_hl_kernel(Hl
   __builtin_amdgcn_s_barrier();
 
   const int cg = lane & 15, rg = lane >> 4;
-  if (MODE == 1) {
-    // ---- generic epilogue: D[q][row] = 1 - S 2^-(e_c + e_q), four consecutive rows per lane: one 16-byte store
-    if (!win_ok) return;
-    const int e_c1 = a.meta[0];
+  // ---- generic epilogue: D[q][row] = 1 - S 2^-(e_c + e_q), four consecutive rows per lane: one 16-byte store
+  if (!win_ok) return;
+  const int e_c1 = a.meta[0];
 #pragma unroll
-    for (int ct = 0; ct < HL_CT; ++ct) {
-      const int q = chunk * (16 * HL_CT) + ct * 16 + cg;
-      if (q >= a.Q) continue;
-      const int e_q1 = a.qexp[q];
-      f32x4 o;
+  for (int ct = 0; ct < HL_CT; ++ct) {
+    const int q = chunk * (16 * HL_CT) + ct * 16 + cg;
+    if (q >= a.Q) continue;
+    const int e_q1 = a.qexp[q];
+    f32x4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        o[r] = (float)(1.0 - ldexp(acc[ct][r] + (double)xacc[ct][r] * (1.0 / 2048.0), -(e_c1 + e_q1)));
-      if (a.D)
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (int64_t)q * a.ldD + (int64_t)j * 32 + 16 * t + 4 * rg) = o;
-      if (a.tmin) {           // the tile's minimum over its 16 rows: lanes cg, cg + 16, cg + 32, cg + 48 hold 4 rows each
-        float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
-        m = fminf(m, __shfl_xor(m, 16, 64));
-        m = fminf(m, __shfl_xor(m, 32, 64));
-        if (rg == 0) a.tmin[(int64_t)q * a.ldT + (int64_t)j * 2 + t] = m;
-        if (a.tmask) {
-          // round 4: which of the 16 rows lie within the band of the TILE's minimum - a superset of the rows within the
-          // band of the code's minimum whenever the tile is opened at all (code minimum <= tile minimum, and the f32
-          // addition is monotone).  With it the select never reads the matrix: 6 bytes per (query, tile) instead of 64.
-          const float lim = m + a.band;
-          unsigned int bits = ((o[0] <= lim) ? 1u : 0u) | ((o[1] <= lim) ? 2u : 0u) | ((o[2] <= lim) ? 4u : 0u) |
-                              ((o[3] <= lim) ? 8u : 0u);
-          bits <<= 4 * rg;
-          bits |= (unsigned int)__shfl_xor((int)bits, 16, 64);
-          bits |= (unsigned int)__shfl_xor((int)bits, 32, 64);
-          if (rg == 0) a.tmask[(int64_t)q * a.ldT + (int64_t)j * 2 + t] = (uint16_t)bits;
-        }
+    for (int r = 0; r < 4; ++r)
+      o[r] = (float)(1.0 - ldexp(acc[ct][r] + (double)xacc[ct][r] * (1.0 / 2048.0), -(e_c1 + e_q1)));
+    if (a.D)
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (int64_t)q * a.ldD + (int64_t)j * 32 + 16 * t + 4 * rg) = o;
+    if (a.tmin) {           // the tile's minimum over its 16 rows: lanes cg, cg + 16, cg + 32, cg + 48 hold 4 rows each
+      float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
+      m = fminf(m, __shfl_xor(m, 16, 64));
+      m = fminf(m, __shfl_xor(m, 32, 64));
+      if (rg == 0) a.tmin[(int64_t)q * a.ldT + (int64_t)j * 2 + t] = m;
+      if (a.tmask) {
+        // round 4: which of the 16 rows lie within the band of the TILE's minimum - a superset of the rows within the
+        // band of the code's minimum whenever the tile is opened at all (code minimum <= tile minimum, and the f32
+        // addition is monotone).  With it the select never reads the matrix: 6 bytes per (query, tile) instead of 64.
+        const float lim = m + a.band;
+        unsigned int bits = ((o[0] <= lim) ? 1u : 0u) | ((o[1] <= lim) ? 2u : 0u) | ((o[2] <= lim) ? 4u : 0u) |
+                            ((o[3] <= lim) ? 8u : 0u);
+        bits <<= 4 * rg;
+        bits |= (unsigned int)__shfl_xor((int)bits, 16, 64);
+        bits |= (unsigned int)__shfl_xor((int)bits, 32, 64);
+        if (rg == 0) a.tmask[(int64_t)q * a.ldT + (int64_t)j * 2 + t] = (uint16_t)bits;
       }
-    }
-    return;
-  }
-  // ---- epilogue: S = hh + 2^-11 cross; dot(q, cand g) = S[g][lo col] + S[g+1][hi col]; cosine distance; store
-  double* exch = reinterpret_cast<double*>(lds);              // [windows][3 ct][16 cols]: row 16 of the hi columns
-  double hi[3][4];
-#pragma unroll
-  for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hi[ct][r] = acc[3 + ct][r] + ldexp((double)xacc[3 + ct][r], -HL_AUDIO_LSHIFT);
-  if (t == 1 && rg == 0)
-#pragma unroll
-    for (int ct = 0; ct < 3; ++ct) exch[(wl * 3 + ct) * 16 + cg] = hi[ct][0];
-  __syncthreads();
-  const int e_c = a.meta[0];
-  const int src = (lane + 16) & 63;
-#pragma unroll
-  for (int ct = 0; ct < 3; ++ct) {
-    const int q = chunk * HL_QC + ct * 16 + cg;
-    const bool q_ok = q < a.Q;
-    const double qq = q_ok ? a.qn2[q] : 1.0;
-    const int e_q = q_ok ? a.qexp[q] : 0;
-    // S[row + 1][hi column]: reg r+1 of the same lane, reg 0 of the lane 16 further (next row group), or - from row
-    // group 3 of tile 0 - row 16, which the window's other wave left in LDS
-    const double nx = __shfl(hi[ct][0], src, 64);
-    const double n16 = exch[(wl * 3 + ct) * 16 + cg];
-    double hs[4];
-    hs[0] = hi[ct][1];
-    hs[1] = hi[ct][2];
-    hs[2] = hi[ct][3];
-    hs[3] = rg < 3 ? nx : (t == 0 ? n16 : 0.0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int g = 16 * t + 4 * rg + r;                        // candidate = super-rows g, g + 1
-      if (!win_ok || !q_ok || g >= a.G) continue;
-      const double lo = acc[ct][r] + ldexp((double)xacc[ct][r], -HL_AUDIO_LSHIFT);
-      const double dot = ldexp(lo + hs[r], -(e_c + e_q));
-      const int64_t c = (int64_t)j * a.G + g;
-      const double cc = a.cn2[c];
-      // validity range of the representation bound: scaled |x|^2 >= HL_NORM2_MIN, zero rows excepted
-      if (a.stats && ((cc > 0.0 && ldexp(cc, 2 * e_c) < HL_NORM2_MIN) || (qq > 0.0 && ldexp(qq, 2 * e_q) < HL_NORM2_MIN)))
-        atomicOr(&a.stats[1], 2);
-      const double dd = cosine_from_dot(dot, qq, cc);
-      if (a.d_f32) reinterpret_cast<float*>(a.D)[(int64_t)q * a.ldD + c] = (float)dd;
-      else reinterpret_cast<double*>(a.D)[(int64_t)q * a.ldD + c] = dd;
     }
   }
 }
 
 
 // ---- the sweep on 32-ROW wave tiles (round 4): audio_cosine_hl2_kernel ----------------------------------------------------
-// Why: in audio_cosine_hl_kernel<0> a wave owns 16 rows x 96 columns and reads the whole 12 KB of a k-block's query
+// Why: in round 3's kernel (hl_gemm16_kernel's organisation) a wave owns 16 rows x 96 columns and reads the whole 12 KB of a k-block's query
 // fragments from LDS for its 18 MFMAs.  Per CU and k-block step that is 8 waves x 12 ds_read_b128 x 8 cycles = 768 LDS
 // cycles against 2 waves x 18 x 16 = 576 matrix cycles per SIMD: the LDS pipe is busier than the matrix pipes (168 k
 // LDS cycles per CU and launch = 99 us at the 1.69 GHz the kernel runs at), which is why the kernel still took 140 us
@@ -791,7 +741,7 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x 2 x 6 x 2 x 1 KB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int xl = (int)blockIdx.x, slot = xl >> 3;
-  const int wgrp = (slot / a.chunks) * 8 + (xl & 7);                   // XCD-aware, as audio_cosine_hl_kernel
+  const int wgrp = (slot / a.chunks) * 8 + (xl & 7);                   // XCD-aware, as hl_gemm16_kernel
   const int chunk = slot % a.chunks;
   if (a.j0 + wgrp * H2_W >= a.N) return;
   const int j = a.j0 + wgrp * H2_W + w;
@@ -1006,15 +956,18 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------------------
+#define HL_F_MAX (1 << 20)    // feature widths beyond this are refused by the size helpers (their products stay inside int64)
 extern "C" int64_t qpg_audio_hl_db_bytes(int N, int F) {            // database image + 64 bytes of metadata
-  return (N <= 0 || F <= 0) ? 0 : (int64_t)N * HL_WIN_UNITS(HL_SUB * F / 32) * 16 + 64;
+  return (N <= 0 || F <= 0 || F > HL_F_MAX) ? 0 : (int64_t)N * HL_WIN_UNITS((int64_t)HL_SUB * F / 32) * 16 + 64;
 }
 extern "C" int64_t qpg_audio_hl_query_bytes(int Q, int F) {
-  const int chunks = (Q + HL_QC - 1) / HL_QC;
-  return (Q <= 0 || F <= 0) ? 0 : (int64_t)chunks * (HL_SUB * F / 32) * HL_CT * 2 * HL_PIECE + (int64_t)chunks * HL_QC * 4;
+  if (Q <= 0 || F <= 0 || F > HL_F_MAX) return 0;
+  const int64_t chunks = ((int64_t)Q + HL_QC - 1) / HL_QC;
+  return chunks * ((int64_t)HL_SUB * F / 32) * HL_CT * 2 * HL_PIECE + chunks * HL_QC * 4;
 }
 
 static bool hl_grid_ok(int T, int F, int G, int n_taps, int tap_stride, int step) {
+  if (tap_stride <= 0 || tap_stride > (1 << 20) || F > HL_F_MAX) return false;
   return n_taps == 2 * HL_SUB && G == HL_ROWS - 1 && step == HL_SUB * tap_stride && (F % 32) == 0 && F >= 32 &&
          ((HL_SUB * F / 32) % (2 * HL_KS)) == 0 && T > 0;
 }
@@ -1122,19 +1075,8 @@ extern "C" int qpg_clip_pack_hl(qpg_ctx* ctx, void* stream, const float* qbase, 
 extern "C" int qpg_audio_cosine_hl(qpg_ctx* ctx, void* stream, const void* db_image, int N, int F, int G,
                                    const double* cn2, const void* q_image, const double* qn2, int Q, void* D,
                                    int d_is_f32, int64_t ldD, int32_t* stats) {
-  return qpg_audio_cosine_hl_range(ctx, stream, db_image, N, F, G, cn2, q_image, qn2, Q, D, d_is_f32, ldD, stats, 0, N);
-}
-
-// Windows [win_begin, win_end) of the sweep (same arguments otherwise: N is the image's window count; the columns of the
-// other windows are not touched).  Two launches over complementary ranges are the sweep; the caller can record an event
-// between them - the matcher lets its text side start when the FIRST part is done (CodeKNN.sweep_audio).
-extern "C" int qpg_audio_cosine_hl_range(qpg_ctx* ctx, void* stream, const void* db_image, int N, int F, int G,
-                                         const double* cn2, const void* q_image, const double* qn2, int Q, void* D,
-                                         int d_is_f32, int64_t ldD, int32_t* stats, int win_begin, int win_end) {
   const char* name = "qpg_audio_cosine_hl";
   QPG_REQUIRE(ctx && db_image && cn2 && q_image && qn2 && D, "%s: null pointer", name);
-  QPG_REQUIRE(win_begin >= 0 && win_begin <= win_end && win_end <= N, "%s: bad window range", name);
-  if (win_begin == win_end) return QPG_OK;
   QPG_REQUIRE(N > 0 && Q > 0 && G == HL_ROWS - 1 && (F % 32) == 0 && ((HL_SUB * F / 32) % (2 * HL_KS)) == 0 &&
                   ldD >= (int64_t)N * G,
               "%s: bad size", name);
@@ -1146,36 +1088,13 @@ extern "C" int qpg_audio_cosine_hl_range(qpg_ctx* ctx, void* stream, const void*
   a.meta = reinterpret_cast<const int32_t*>(dbi + (qpg_audio_hl_db_bytes(N, F) - 64));
   a.qi = reinterpret_cast<const _Float16*>(qi);
   a.qexp = reinterpret_cast<const int32_t*>(qi + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
-  a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = win_end; a.j0 = win_begin; a.G = G; a.Q = Q; a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0; a.tmask = nullptr; a.band = 0.f;
-  a.chunks = chunks;
-  const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
-  if (lds_bytes > 64 * 1024) {
-    static bool raised = false;
-    if (!raised && hipFuncSetAttribute(reinterpret_cast<const void*>(audio_cosine_hl_kernel<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
-      qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
-      return QPG_EHIP;
-    }
-    raised = true;
-  }
-  static int use2 = -1;                        // QPG_HL2=0: round 3's 16-row organisation (measurements, tests)
-  if (use2 < 0) {
-    const char* e = getenv("QPG_HL2");
-    use2 = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (use2 && (KB % 4) == 0) {
-    const int64_t g8 = (win_end - win_begin + H2_W - 1) / H2_W;
-    QPG_REQUIRE(((g8 + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
-    hipLaunchKernelGGL((audio_cosine_hl2_kernel<2, 2>), dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W),
-                       2 * 2 * HL_CT * 2 * HL_PIECE, qpg_stream(stream), a);
-    QPG_LAUNCH_CHECK("audio_cosine_hl2_kernel");
-    return QPG_OK;
-  }
-  const int64_t wgroups = (win_end - win_begin + HL_WPB - 1) / HL_WPB;
-  QPG_REQUIRE(((wgroups + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
-  hipLaunchKernelGGL(audio_cosine_hl_kernel<0>, dim3((unsigned)(((wgroups + 7) / 8) * 8 * chunks)), dim3(HL_THREADS),
-                     lds_bytes, qpg_stream(stream), a);
-  QPG_LAUNCH_CHECK("audio_cosine_hl_kernel");
+  a.cn2 = cn2; a.qn2 = qn2; a.D = D; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = stats; a.N = N; a.j0 = 0; a.G = G; a.Q = Q;
+  a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0; a.tmask = nullptr; a.band = 0.f; a.chunks = chunks;
+  const int64_t g8 = ((int64_t)N + H2_W - 1) / H2_W;
+  QPG_REQUIRE(((g8 + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
+  hipLaunchKernelGGL((audio_cosine_hl2_kernel<2, 2>), dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W),
+                     2 * 2 * HL_CT * 2 * HL_PIECE, qpg_stream(stream), a);
+  QPG_LAUNCH_CHECK("audio_cosine_hl2_kernel");
   return QPG_OK;
 }
 
@@ -1205,7 +1124,7 @@ __global__ __launch_bounds__(256) void hl1_pack_db_kernel(const _Float16* __rest
 }
 
 extern "C" int64_t qpg_audio_hl1_db_bytes(int N, int F) {
-  return (N <= 0 || F <= 0) ? 0 : (int64_t)N * HL1_WIN_UNITS(HL_SUB * F / 32) * 16;
+  return (N <= 0 || F <= 0 || F > HL_F_MAX) ? 0 : (int64_t)N * HL1_WIN_UNITS((int64_t)HL_SUB * F / 32) * 16;
 }
 
 static bool hl1_grid_ok(int T, int F, int G, int n_taps, int tap_stride, int step) {
@@ -1338,11 +1257,12 @@ __global__ __launch_bounds__(256) void hl_pack_cols_kernel(const float* __restri
 }
 
 extern "C" int64_t qpg_hl_rows_bytes(int64_t R, int D) {
-  return (R <= 0 || D <= 0) ? 0 : R * D * 4 + 64;
+  return (R <= 0 || D <= 0 || D > HL_F_MAX || R > (int64_t(1) << 40)) ? 0 : R * D * 4 + 64;
 }
 extern "C" int64_t qpg_hl_cols_bytes(int Q, int D) {
-  const int chunks = (Q + HL_GQC - 1) / HL_GQC;
-  return (Q <= 0 || D <= 0) ? 0 : (int64_t)chunks * (D / 32) * HL_CT * 2 * HL_PIECE + (int64_t)chunks * HL_GQC * 4;
+  if (Q <= 0 || D <= 0 || D > HL_F_MAX) return 0;
+  const int64_t chunks = ((int64_t)Q + HL_GQC - 1) / HL_GQC;
+  return chunks * (D / 32) * HL_CT * 2 * HL_PIECE + chunks * HL_GQC * 4;
 }
 
 extern "C" int qpg_hl_pack_rows(qpg_ctx* ctx, void* stream, const float* x, int64_t R, int D, void* image,
@@ -1382,7 +1302,7 @@ extern "C" int qpg_hl_pack_cols(qpg_ctx* ctx, void* stream, const float* q, int 
 }
 
 // ---- the prefilter GEMM on 32-ROW wave tiles (round 4): hl_gemm32_kernel --------------------------------------------------
-// audio_cosine_hl_kernel<1> inherits round 3's sweep organisation (16 rows x 96 columns per wave, f64 block sums).  For the
+// hl_gemm16_kernel inherits round 3's sweep organisation (16 rows x 96 columns per wave, f64 block sums).  For the
 // prefilter of the exact-f32 cosine family the band is dominated by sklearn's own rounding (8.6e-5 at D = 512), so the
 // h h' products may stay in the MFMA's f32 accumulator for the whole (short) K: a chain of KB instructions is within
 // (kappa_1 + KB) 2^-24 sum|products| of the exact sum (every instruction: its own block error + one rounding of the running
@@ -1589,37 +1509,10 @@ static int hl_gemm_impl(const char* name, qpg_ctx* ctx, void* stream, const void
   a.qexp = reinterpret_cast<const int32_t*>(ci + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
   a.cn2 = nullptr; a.qn2 = nullptr; a.D = Dm; a.zeros = ctx->zeros; a.ldD = ldD; a.stats = nullptr;
   a.N = (int)(R / 32); a.j0 = 0; a.chunks = chunks; a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1; a.tmin = tile_min; a.ldT = ldT; a.tmask = tile_mask; a.band = band;
-  static int use32 = -1;                       // QPG_GEMM32=0: round 3's 16-row organisation (measurements, tests)
-  if (use32 < 0) {
-    const char* e = getenv("QPG_GEMM32");
-    use32 = (e && e[0] == '0') ? 0 : 1;
-  }
   // (a clip's 48 text queries stay on the 16-row kernel: it runs UNDER the audio sweep, where the slimmer kernel gets more
-  // of the slots the sweep leaves - measured inside the step: 0.273-0.283 ms against 0.281-0.282 with this kernel)
-  static int small32 = -1;                     // QPG_GEMM32_Q48=1 (measurements): <= 48 queries on the 32-row kernel with
-  if (small32 < 0) {                           // THREE column tiles (half a chunk's MFMAs) instead of the 16-row kernel
-    const char* e = getenv("QPG_GEMM32_Q48");
-    small32 = (e && e[0] == '1') ? 1 : 0;
-  }
-  if (use32 && small32 && (KB % G32_RING) == 0 && Q <= 48) {
-    const size_t lds32 = 2 * (size_t)G32_KS * HL_CT * 2 * HL_PIECE;
-    static bool raised33 = false;
-    if (!raised33) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(hl_gemm32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds32) != hipSuccess) {
-        qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
-        return QPG_EHIP;
-      }
-      raised33 = true;
-    }
-    const int64_t g8 = (a.N + 7) / 8;
-    const int n_items = (int)(g8 * chunks);
-    const int n_blocks = n_items < ctx->n_cu ? n_items : ctx->n_cu;
-    hipLaunchKernelGGL(hl_gemm32_kernel<3>, dim3(n_blocks), dim3(512), lds32, qpg_stream(stream), a, n_items);
-    QPG_LAUNCH_CHECK("hl_gemm32_kernel<3>");
-    return QPG_OK;
-  }
-  if (use32 && (KB % G32_RING) == 0 && Q > 48) {
+  // of the slots the sweep leaves - measured inside the step: 0.273-0.283 ms against 0.281-0.282 with the 32-row kernel,
+  // also with three column tiles: experiments/gemm32/README.md)
+  if ((KB % G32_RING) == 0 && Q > 48) {
     const size_t lds32 = 2 * (size_t)G32_KS * HL_CT * 2 * HL_PIECE;   // 48 KB
     static bool raised32 = false;
     if (!raised32) {
@@ -1641,9 +1534,9 @@ static int hl_gemm_impl(const char* name, qpg_ctx* ctx, void* stream, const void
   const size_t lds_bytes = 2 * HL_KS * HL_CT * 2 * HL_PIECE;
   const int64_t rgroups = (a.N + HL_WPB - 1) / HL_WPB;
   QPG_REQUIRE(((rgroups + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
-  hipLaunchKernelGGL(audio_cosine_hl_kernel<1>, dim3((unsigned)(((rgroups + 7) / 8) * 8 * chunks)), dim3(HL_THREADS),
+  hipLaunchKernelGGL(hl_gemm16_kernel, dim3((unsigned)(((rgroups + 7) / 8) * 8 * chunks)), dim3(HL_THREADS),
                      lds_bytes, qpg_stream(stream), a);
-  QPG_LAUNCH_CHECK("audio_cosine_hl_kernel<1>");
+  QPG_LAUNCH_CHECK("hl_gemm16_kernel");
   return QPG_OK;
 }
 

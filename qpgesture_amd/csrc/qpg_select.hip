@@ -1,12 +1,12 @@
 // Per-code segmented min/argmin over a distance row, and stable ranks.
 //
-// qpg_percode_argmin_*: the `if d < best[code]` update of CodeKNN.search_audio_cands /
+// qpg_percode_select_*: the `if d < best[code]` update of CodeKNN.search_audio_cands /
 // search_text_cands (GestureKNN.py:686-689, 717-720) for a whole query row at once.  The
 // reference scans candidates in index order with a strict `<`, so the winner of a code is the
-// candidate with the minimum distance and, among equals, the lowest index.  One block per
-// query: distances are mapped to order-preserving unsigned keys and reduced with LDS atomics
-// (ds_min_u64 / ds_min_u32); a second pass resolves the lowest index among the minima.
-// HBM-bound: reads D once (Q*C*sizeof) plus the code column per candidate.
+// candidate with the minimum distance and, among equals, the lowest index.  Distances are mapped
+// to order-preserving unsigned keys and reduced with LDS atomics (ds_min_u64 / ds_min_u32).
+// (Rounds 1-2's stand-alone forms - qpg_percode_argmin_*, the resolve / finalize chain over global
+// tables - left the library in round 5: no caller but tests.)
 //
 // qpg_rank_rows_*: np.argsort(np.argsort(x)) with a stable tie rule, by counting.
 #include "qpg_common.h"
@@ -28,292 +28,10 @@ __device__ __forceinline__ float key_value(unsigned int k, float) {
   return __uint_as_float(b);
 }
 
-template <typename T, typename KeyT>
-__global__ __launch_bounds__(1024) void percode_argmin_kernel(const T* __restrict__ D, int64_t ldD,
-                                                              const int32_t* __restrict__ code, int code_ld, int N,
-                                                              const int32_t* __restrict__ cand_cidx, int G, int K,
-                                                              T absent, int32_t idx_base, T* __restrict__ out_dist,
-                                                              int32_t* __restrict__ out_idx) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  KeyT* best = reinterpret_cast<KeyT*>(smem);
-  unsigned int* besti = reinterpret_cast<unsigned int*>(smem + sizeof(KeyT) * K);
-
-  const int q = blockIdx.x;
-  const int64_t C = (int64_t)N * G;
-  const T* row = D + (int64_t)q * ldD;
-  const KeyT kmax = ~(KeyT)0;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    best[k] = kmax;
-    besti[k] = 0xffffffffu;
-  }
-  __syncthreads();
-  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) {
-    const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
-    const int cd = code[(int64_t)j * code_ld + cand_cidx[g]];
-    if ((unsigned)cd < (unsigned)K) atomicMin(&best[cd], order_key(row[c]));
-  }
-  __syncthreads();
-  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) {
-    const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
-    const int cd = code[(int64_t)j * code_ld + cand_cidx[g]];
-    if ((unsigned)cd < (unsigned)K && order_key(row[c]) == best[cd]) atomicMin(&besti[cd], (unsigned int)c);
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const bool have = besti[k] != 0xffffffffu;
-    out_dist[(int64_t)q * K + k] = have ? key_value(best[k], T(0)) : absent;
-    out_idx[(int64_t)q * K + k] = have ? (int32_t)besti[k] + idx_base : -1;
-  }
-}
-
-template <typename T, typename KeyT>
-static int percode_argmin(const char* name, qpg_ctx* ctx, void* stream, const T* D, int64_t ldD, int Q,
-                          const int32_t* code, int code_ld, int N, const int32_t* cand_cidx, int G, int K, T absent,
-                          int32_t idx_base, T* out_dist, int32_t* out_idx) {
-  QPG_REQUIRE(ctx && D && code && cand_cidx && out_dist && out_idx, "%s: null pointer", name);
-  QPG_REQUIRE(Q >= 0 && N >= 0 && G > 0 && K > 0 && K <= 4096 && code_ld > 0 && ldD >= (int64_t)N * G &&
-                  (int64_t)N * G < 0x7fffffffll,
-              "%s: bad size", name);
-  if (Q == 0) return QPG_OK;
-  size_t sh = (sizeof(KeyT) + sizeof(unsigned int)) * (size_t)K;
-  hipLaunchKernelGGL((percode_argmin_kernel<T, KeyT>), dim3(Q), dim3(1024), sh, qpg_stream(stream), D, ldD, code,
-                     code_ld, N, cand_cidx, G, K, absent, idx_base, out_dist, out_idx);
-  QPG_LAUNCH_CHECK(name);
-  return QPG_OK;
-}
-
-extern "C" int qpg_percode_argmin_f64(qpg_ctx* ctx, void* stream, const double* D, int64_t ldD, int Q,
-                                      const int32_t* code, int code_ld, int N, const int32_t* cand_cidx, int G, int K,
-                                      double absent, int32_t idx_base, double* out_dist, int32_t* out_idx) {
-  return percode_argmin<double, unsigned long long>("qpg_percode_argmin_f64", ctx, stream, D, ldD, Q, code, code_ld,
-                                                    N, cand_cidx, G, K, absent, idx_base, out_dist, out_idx);
-}
-
-extern "C" int qpg_percode_argmin_f32(qpg_ctx* ctx, void* stream, const float* D, int64_t ldD, int Q,
-                                      const int32_t* code, int code_ld, int N, const int32_t* cand_cidx, int G, int K,
-                                      float absent, int32_t idx_base, float* out_dist, int32_t* out_idx) {
-  return percode_argmin<float, unsigned int>("qpg_percode_argmin_f32", ctx, stream, D, ldD, Q, code, code_ld, N,
-                                             cand_cidx, G, K, absent, idx_base, out_dist, out_idx);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fused-table protocol (the fast path; qpg_percode_argmin_* above is the stand-alone form).
-//   text  (f32): ordered distance (32 bit) and candidate index (32 bit) share one u64, so one pass of
-//                qpg_percode_resolve_f32 over D with atomicMin gives min distance + lowest index.
-//   audio (f64): distance + index do not fit one atomic word, so qpg_percode_resolve_f64 streams the
-//                distance matrix D (L2/MALL-resident, Q*C*8 B) twice with the whole chip: pass 1 takes the
-//                per-code minimum of the ordered 64-bit keys (LDS ds_min_u64 per block, then one global
-//                atomic per touched code), pass 2 the lowest candidate index among the entries equal to
-//                that minimum (== the reference's first-wins scan).  Folding pass 1 into the sweep's
-//                epilogue was measured slower (+70 us: 2.5 M uncached table probes at the end of every block).
-//   finalize:    keys -> distances (`absent` where the code never occurs), indices, and — when the
-//                table is final, i.e. single rank — the stable ranks of the row.
-// ---------------------------------------------------------------------------------------------
-#define RS_CHUNK 4096   // candidates per block in the two resolve passes
-
-// Table initialisation as a KERNEL, not hipMemsetAsync: in round 1 captured-graph replays of the matcher came back with
-// all-0xFF tables when this was a memset node.  The pattern in isolation is clean (experiments/graph_memset: 3 x 400
-// replays), so the cause was above HIP (PyTorch capture pool); the fill kernel stays because it is harmless, and only
-// these stand-alone entry points still need a global table at all.
-__global__ __launch_bounds__(256) void fill_ff_kernel(unsigned long long* __restrict__ a, int64_t na,
-                                                      unsigned int* __restrict__ b, int64_t nb) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < na) a[i] = ~0ull;
-  if (b && i < nb) b[i] = ~0u;
-}
-
-__global__ __launch_bounds__(256) void percode_min_f64_kernel(const double* __restrict__ D, int64_t ldD,
-                                                              const int32_t* __restrict__ code, int code_ld, int N,
-                                                              const int32_t* __restrict__ cand_cidx, int G, int K,
-                                                              unsigned long long* __restrict__ best_key) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
-  const int q = blockIdx.y;
-  const int64_t C = (int64_t)N * G;
-  const double* row = D + (int64_t)q * ldD;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) best[k] = ~0ull;
-  __syncthreads();
-  const int64_t cb = (int64_t)blockIdx.x * RS_CHUNK;
-  const int64_t ce = cb + RS_CHUNK < C ? cb + RS_CHUNK : C;
-  for (int64_t c = cb + threadIdx.x; c < ce; c += blockDim.x) {
-    const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
-    const int cd = code[(int64_t)j * code_ld + cand_cidx[g]];
-    if ((unsigned)cd < (unsigned)K) atomicMin(&best[cd], order_key(row[c]));
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x)
-    if (best[k] != ~0ull) atomicMin(&best_key[(int64_t)q * K + k], best[k]);
-}
-
-__global__ __launch_bounds__(256) void percode_resolve_f64_kernel(const double* __restrict__ D, int64_t ldD,
-                                                                  const int32_t* __restrict__ code, int code_ld, int N,
-                                                                  const int32_t* __restrict__ cand_cidx, int G, int K,
-                                                                  int32_t idx_base,
-                                                                  const unsigned long long* __restrict__ best_key,
-                                                                  unsigned int* __restrict__ best_idx) {
-  const int q = blockIdx.y;
-  const int64_t C = (int64_t)N * G;
-  const double* row = D + (int64_t)q * ldD;
-  const int64_t cb = (int64_t)blockIdx.x * RS_CHUNK;
-  const int64_t ce = cb + RS_CHUNK < C ? cb + RS_CHUNK : C;
-  for (int64_t c = cb + threadIdx.x; c < ce; c += blockDim.x) {
-    const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
-    const int cd = code[(int64_t)j * code_ld + cand_cidx[g]];
-    if ((unsigned)cd < (unsigned)K && order_key(row[c]) == best_key[(int64_t)q * K + cd])
-      atomicMin(&best_idx[(int64_t)q * K + cd], (unsigned int)(c + idx_base));
-  }
-}
-
-extern "C" int qpg_percode_resolve_f64(qpg_ctx* ctx, void* stream, const double* D, int64_t ldD, int Q,
-                                       const int32_t* code, int code_ld, int N, const int32_t* cand_cidx, int G,
-                                       int K, int32_t idx_base, uint64_t* best_key, uint32_t* best_idx) {
-  QPG_REQUIRE(ctx && D && code && cand_cidx && best_key && best_idx, "qpg_percode_resolve_f64: null pointer");
-  QPG_REQUIRE(Q >= 0 && N >= 0 && G > 0 && K > 0 && K <= 4096 && code_ld > 0 && ldD >= (int64_t)N * G &&
-                  (int64_t)N * G + (int64_t)idx_base < 0x7fffffffll,
-              "qpg_percode_resolve_f64: bad size (candidate indices must stay below 2^31)");
-  if (Q == 0) return QPG_OK;
-  hipStream_t st = qpg_stream(stream);
-  {
-    const int64_t n = (int64_t)Q * K;
-    hipLaunchKernelGGL(fill_ff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<unsigned long long*>(best_key), n, best_idx, n);
-    QPG_LAUNCH_CHECK("fill_ff_kernel");
-  }
-  if (N == 0) return QPG_OK;
-  const int64_t C = (int64_t)N * G;
-  const unsigned bx = (unsigned)((C + RS_CHUNK - 1) / RS_CHUNK);
-  unsigned long long* bk = reinterpret_cast<unsigned long long*>(best_key);
-  hipLaunchKernelGGL(percode_min_f64_kernel, dim3(bx, Q), dim3(256), sizeof(unsigned long long) * (size_t)K, st, D, ldD,
-                     code, code_ld, N, cand_cidx, G, K, bk);
-  QPG_LAUNCH_CHECK("percode_min_f64_kernel");
-  hipLaunchKernelGGL(percode_resolve_f64_kernel, dim3(bx, Q), dim3(256), 0, st, D, ldD, code, code_ld, N, cand_cidx, G,
-                     K, idx_base, bk, best_idx);
-  QPG_LAUNCH_CHECK("percode_resolve_f64_kernel");
-  return QPG_OK;
-}
-
-// f32: distance key (32 bit) and candidate index (32 bit) share one u64, so a single pass suffices.
-__global__ __launch_bounds__(256) void percode_min_packed_f32_kernel(const float* __restrict__ D, int64_t ldD,
-                                                                     const int32_t* __restrict__ code, int code_ld,
-                                                                     int N, const int32_t* __restrict__ cand_cidx,
-                                                                     int G, int K, int32_t idx_base,
-                                                                     unsigned long long* __restrict__ packed) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
-  const int q = blockIdx.y;
-  const int64_t C = (int64_t)N * G;
-  const float* row = D + (int64_t)q * ldD;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) best[k] = ~0ull;
-  __syncthreads();
-  const int64_t cb = (int64_t)blockIdx.x * RS_CHUNK;
-  const int64_t ce = cb + RS_CHUNK < C ? cb + RS_CHUNK : C;
-  for (int64_t c = cb + threadIdx.x; c < ce; c += blockDim.x) {
-    const int j = (int)(c / G), g = (int)(c - (int64_t)j * G);
-    const int cd = code[(int64_t)j * code_ld + cand_cidx[g]];
-    if ((unsigned)cd < (unsigned)K)
-      atomicMin(&best[cd], ((unsigned long long)order_key(row[c]) << 32) | (unsigned int)(c + idx_base));
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x)
-    if (best[k] != ~0ull) atomicMin(&packed[(int64_t)q * K + k], best[k]);
-}
-
-extern "C" int qpg_percode_resolve_f32(qpg_ctx* ctx, void* stream, const float* D, int64_t ldD, int Q,
-                                       const int32_t* code, int code_ld, int N, const int32_t* cand_cidx, int G,
-                                       int K, int32_t idx_base, uint64_t* packed) {
-  QPG_REQUIRE(ctx && D && code && cand_cidx && packed, "qpg_percode_resolve_f32: null pointer");
-  QPG_REQUIRE(Q >= 0 && N >= 0 && G > 0 && K > 0 && K <= 4096 && code_ld > 0 && ldD >= (int64_t)N * G &&
-                  (int64_t)N * G + (int64_t)idx_base < 0x7fffffffll,
-              "qpg_percode_resolve_f32: bad size (candidate indices must stay below 2^31)");
-  if (Q == 0) return QPG_OK;
-  hipStream_t st = qpg_stream(stream);
-  {
-    const int64_t n = (int64_t)Q * K;
-    hipLaunchKernelGGL(fill_ff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<unsigned long long*>(packed), n, (unsigned int*)nullptr, (int64_t)0);
-    QPG_LAUNCH_CHECK("fill_ff_kernel");
-  }
-  if (N == 0) return QPG_OK;
-  const int64_t C = (int64_t)N * G;
-  const unsigned bx = (unsigned)((C + RS_CHUNK - 1) / RS_CHUNK);
-  hipLaunchKernelGGL(percode_min_packed_f32_kernel, dim3(bx, Q), dim3(256), sizeof(unsigned long long) * (size_t)K, st,
-                     D, ldD, code, code_ld, N, cand_cidx, G, K, idx_base, reinterpret_cast<unsigned long long*>(packed));
-  QPG_LAUNCH_CHECK("percode_min_packed_f32_kernel");
-  return QPG_OK;
-}
-
-template <typename T, typename KeyT, bool PACKED>
-__global__ __launch_bounds__(1024) void percode_finalize_kernel(const unsigned long long* __restrict__ keys,
-                                                                const unsigned int* __restrict__ idxs, int K, T absent,
-                                                                T* __restrict__ out_dist, int32_t* __restrict__ out_idx,
-                                                                int16_t* __restrict__ out_rank) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* v = reinterpret_cast<T*>(smem);
-  const int q = blockIdx.x;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const unsigned long long kv = keys[(int64_t)q * K + k];
-    T d;
-    int32_t ix;
-    if (PACKED) {
-      const bool have = kv != ~0ull;
-      d = have ? key_value((KeyT)(kv >> 32), T(0)) : absent;
-      ix = have ? (int32_t)(kv & 0xffffffffu) : -1;
-    } else {
-      const unsigned int iv = idxs[(int64_t)q * K + k];
-      const bool have = iv != 0xffffffffu;
-      d = have ? key_value((KeyT)kv, T(0)) : absent;
-      ix = have ? (int32_t)iv : -1;
-    }
-    v[k] = d;
-    out_dist[(int64_t)q * K + k] = d;
-    out_idx[(int64_t)q * K + k] = ix;
-  }
-  if (!out_rank) return;
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const T x = v[k];
-    int r = 0;
-    for (int o = 0; o < K; ++o) {
-      const T y = v[o];
-      r += (y < x) || (y == x && o < k);
-    }
-    out_rank[(int64_t)q * K + k] = (int16_t)r;
-  }
-}
-
-extern "C" int qpg_percode_finalize_f64(qpg_ctx* ctx, void* stream, const uint64_t* best_key, const uint32_t* best_idx,
-                                        int Q, int K, double absent, double* out_dist, int32_t* out_idx,
-                                        int16_t* out_rank) {
-  QPG_REQUIRE(ctx && best_key && best_idx && out_dist && out_idx && Q >= 0 && K > 0 && K <= 8192,
-              "qpg_percode_finalize_f64: bad argument");
-  if (Q == 0) return QPG_OK;
-  int threads = K >= 1024 ? 1024 : ((K + 63) / 64) * 64;
-  hipLaunchKernelGGL((percode_finalize_kernel<double, unsigned long long, false>), dim3(Q), dim3(threads),
-                     sizeof(double) * (size_t)K, qpg_stream(stream),
-                     reinterpret_cast<const unsigned long long*>(best_key), best_idx, K, absent, out_dist, out_idx,
-                     out_rank);
-  QPG_LAUNCH_CHECK("percode_finalize_kernel<f64>");
-  return QPG_OK;
-}
-
-extern "C" int qpg_percode_finalize_f32(qpg_ctx* ctx, void* stream, const uint64_t* packed, int Q, int K, float absent,
-                                        float* out_dist, int32_t* out_idx, int16_t* out_rank) {
-  QPG_REQUIRE(ctx && packed && out_dist && out_idx && Q >= 0 && K > 0 && K <= 8192,
-              "qpg_percode_finalize_f32: bad argument");
-  if (Q == 0) return QPG_OK;
-  int threads = K >= 1024 ? 1024 : ((K + 63) / 64) * 64;
-  hipLaunchKernelGGL((percode_finalize_kernel<float, unsigned int, true>), dim3(Q), dim3(threads),
-                     sizeof(float) * (size_t)K, qpg_stream(stream),
-                     reinterpret_cast<const unsigned long long*>(packed), nullptr, K, absent, out_dist, out_idx,
-                     out_rank);
-  QPG_LAUNCH_CHECK("percode_finalize_kernel<f32>");
-  return QPG_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
 // One-launch select (round 2): per query row, per-code minimum + first-wins index + distances + stable ranks in ONE
-// kernel, one 1024-thread block per query.  Replaces the chain fill_ff -> percode_min -> percode_resolve ->
-// percode_finalize (4 launches, 624 blocks doing ~320 k global 64-bit atomics per clip): the whole row (C candidates,
+// kernel, one 1024-thread block per query (round 1 ran a chain of four launches over global tables, 624 blocks doing
+// ~320 k global 64-bit atomics per clip): the whole row (C candidates,
 // L2/MALL-resident: the sweep has just written it) is streamed by one block with 16-byte loads, the minima live in
 // LDS only, and the candidates' codes come from a precomputed int16 array (no division by the grid size, no double
 // indirection).  f64: two passes over the row (minimum of the ordered keys, then lowest index among the entries
@@ -1642,16 +1360,13 @@ extern "C" int64_t qpg_percode_select_mixed_ws_stride(int K) {       // bytes pe
   return K <= 0 ? 0 : (int64_t)mix_ws_stride(K);                     // q x stride, its list length is the i32 at + 24 K
 }
 
-// parts: 1 = the streaming pass only (mixed_stream_kernel: f32 matrix + workspace), 2 = everything behind it (lists, tier-1
-// dot products, merge), 3 = both.  The split exists for the host's scheduling: the text side's GEMM is gated on the END of
-// the streaming pass (an event between the two calls), see code_knn.CodeKNN.sweep_tables.
 static int select_mixed_impl(const char* name, qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
                              const int16_t* cand_code, int64_t C, int K, double absent,
                              int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
                              int q_block, int64_t block_stride, const float* base, int T, int F,
                              const int32_t* cand_t, int G, int n_taps, int tap_stride,
                              const float* q32, const double* qn2, const double* cn2, double eps1,
-                             double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16, int parts,
+                             double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16,
                              const RankCut* cut = nullptr) {
   QPG_REQUIRE(ctx && D && (cand_code || C == 0) && out_dist && out_idx && base && cand_t && q32 && qn2 && cn2 && stats,
               "%s: null pointer", name);
@@ -1694,21 +1409,16 @@ static int select_mixed_impl(const char* name, qpg_ctx* ctx, void* stream, const
                      q_block, block_stride, A, eps1, cn2, qn2, use_qlds, PHASE, w, PRE, RCv)
   RankCut RCv = RCnone;
   if (!ws) {
-    QPG_REQUIRE(parts == 3, "%s: the one-launch form (no workspace) cannot be issued in parts", name);
     if (d_is_f32) SEL_MIX_LAUNCH(float, sh, 0, 0); else SEL_MIX_LAUNCH(double, sh, 0, 0);
     QPG_LAUNCH_CHECK("percode_select_mixed_f64_kernel");
     return QPG_OK;
   }
-  QPG_REQUIRE(parts == 3 || d_is_f32, "%s: only the f32 matrix has a separate streaming pass", name);
   if (d_is_f32) {
     // the row is streamed by MIX_SPLIT blocks per query; the list kernel starts from their state
-    if (parts & 1) {
-      const size_t shs = 4 * (size_t)K + 10 * (size_t)MIX_SPOT;
-      hipLaunchKernelGGL(mixed_stream_kernel, dim3(Q, MIX_SPLIT), dim3(1024), shs, qpg_stream(stream),
-                         static_cast<const float*>(D), ldD, cand_code, C, K, eps1, w);
-      QPG_LAUNCH_CHECK("mixed_stream_kernel");
-    }
-    if (!(parts & 2)) return QPG_OK;
+    const size_t shs = 4 * (size_t)K + 10 * (size_t)MIX_SPOT;
+    hipLaunchKernelGGL(mixed_stream_kernel, dim3(Q, MIX_SPLIT), dim3(1024), shs, qpg_stream(stream),
+                       static_cast<const float*>(D), ldD, cand_code, C, K, eps1, w);
+    QPG_LAUNCH_CHECK("mixed_stream_kernel");
     if (cut && cut->pos_t && out_rank) {          // walk-relevance cut: the list and merge launches get its scratch
       RCv = *cut;
       sh2c = sh2 + 12 * (size_t)rank_sort_pow2(K) + 8 * (size_t)((K + 7) / 8 * 8) + 17 * 8 + 64 * (8 + 8 + 4) +
@@ -1737,13 +1447,13 @@ extern "C" int qpg_percode_select_mixed_f64(qpg_ctx* ctx, void* stream, const vo
                                             double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16) {
   return select_mixed_impl("qpg_percode_select_mixed_f64", ctx, stream, D, d_is_f32, ldD, Q, cand_code, C, K, absent, idx_base,
                            out_dist, out_idx, out_rank, q_block, block_stride, base, T, F, cand_t, G, n_taps, tap_stride, q32,
-                           qn2, cn2, eps1, eps2, stats, ws, ws_bytes, base_is_f16, 3);
+                           qn2, cn2, eps1, eps2, stats, ws, ws_bytes, base_is_f16);
 }
 
 // The four-launch form with the walk-relevance cut (RankCut above): pos_rank_t [dev] i16 [K][K] = the TRANSPOSE of
 // qpg_match_steps' pos_rank, freq_rank [dev] i16 [K], top_n = how many of a step's best fused scores the walk reads (1 with
 // the text side, 2 without: GestureKNN.py:593, :627-657), probe = the number of best-ranked codes the bound on the winning
-// score is taken over (0: 64); parts as in qpg_percode_select_mixed_f64_parts (3: the whole call).  out_rank is required,
+// score is taken over (0: 64).  out_rank is required,
 // an f32 matrix and a workspace too.
 extern "C" int qpg_percode_select_mixed_f64_cut(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
                                                 const int16_t* cand_code, int64_t C, int K, double absent,
@@ -1752,31 +1462,15 @@ extern "C" int qpg_percode_select_mixed_f64_cut(qpg_ctx* ctx, void* stream, cons
                                                 const int32_t* cand_t, int G, int n_taps, int tap_stride,
                                                 const float* q32, const double* qn2, const double* cn2, double eps1,
                                                 double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16,
-                                                const int16_t* pos_rank_t, const int16_t* freq_rank, int top_n, int probe,
-                                                int parts) {
+                                                const int16_t* pos_rank_t, const int16_t* freq_rank, int top_n, int probe) {
   const char* name = "qpg_percode_select_mixed_f64_cut";
   QPG_REQUIRE(pos_rank_t && freq_rank && out_rank && ws && d_is_f32 && q_block == 0 && (top_n == 1 || top_n == 2) &&
-                  probe >= 0 && parts >= 1 && parts <= 3,
-              "%s: needs the rank tables, out_rank, an f32 matrix, a workspace, no block layout, top_n 1 or 2, parts 1..3", name);
+                  probe >= 0,
+              "%s: needs the rank tables, out_rank, an f32 matrix, a workspace, no block layout, top_n 1 or 2", name);
   RankCut rc = {pos_rank_t, freq_rank, top_n, probe > 0 ? probe : 64};
   return select_mixed_impl(name, ctx, stream, D, d_is_f32, ldD, Q, cand_code, C, K, absent, idx_base, out_dist, out_idx,
                            out_rank, q_block, block_stride, base, T, F, cand_t, G, n_taps, tap_stride, q32, qn2, cn2, eps1, eps2,
-                           stats, ws, ws_bytes, base_is_f16, parts, &rc);
-}
-
-extern "C" int qpg_percode_select_mixed_f64_parts(qpg_ctx* ctx, void* stream, const void* D, int d_is_f32, int64_t ldD, int Q,
-                                                  const int16_t* cand_code, int64_t C, int K, double absent,
-                                                  int32_t idx_base, double* out_dist, int32_t* out_idx, int16_t* out_rank,
-                                                  int q_block, int64_t block_stride, const float* base, int T, int F,
-                                                  const int32_t* cand_t, int G, int n_taps, int tap_stride,
-                                                  const float* q32, const double* qn2, const double* cn2, double eps1,
-                                                  double eps2, int32_t* stats, void* ws, int64_t ws_bytes, int base_is_f16,
-                                                  int parts) {
-  const char* name = "qpg_percode_select_mixed_f64_parts";
-  QPG_REQUIRE(parts >= 1 && parts <= 3, "%s: parts must be 1 (streaming pass), 2 (the rest) or 3", name);
-  return select_mixed_impl(name, ctx, stream, D, d_is_f32, ldD, Q, cand_code, C, K, absent, idx_base, out_dist, out_idx,
-                           out_rank, q_block, block_stride, base, T, F, cand_t, G, n_taps, tap_stride, q32, qn2, cn2, eps1, eps2,
-                           stats, ws, ws_bytes, base_is_f16, parts);
+                           stats, ws, ws_bytes, base_is_f16, &rc);
 }
 
 template <typename T, typename KeyT, bool PACKED>

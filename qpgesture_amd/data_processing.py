@@ -60,6 +60,18 @@ class LoadedDB(dict):
     __getattr__ = dict.__getitem__
 
 
+def load_test_side(test_data_path, test_wavlm, test_wavvq, device=None):
+    """The query side alone (the CLI with a prepared-database cache: db_cache.py): test interpolated WavLM, context,
+    phase, wavvq - the arrays of load_db_codebook's `test_*` keys."""
+    te = np.load(test_data_path, allow_pickle=True)
+    out = LoadedDB()
+    w = np.load(test_wavlm)["wavlm"]
+    out["test_wavlm"] = interp_wavlm(w) if device is None else interp_wavlm_device(w, device)
+    out["test_wavvq"] = np.load(test_wavvq)["wavvq"]
+    out["test_context"] = np.ascontiguousarray(te["context"].squeeze(2), np.float32)
+    return out
+
+
 def load_db_codebook(data_file, codepath, test_data_path, train_wavlm, test_wavlm, train_wavvq, test_wavvq,
                      device=None):
     """Same arguments as the reference's load_db_codebook (+ `device`: resample the WavLM tracks on that GPU

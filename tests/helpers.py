@@ -40,7 +40,8 @@ def aud_tol(knn):
 
 # ---- the stand-alone C-ABI entry points, driven by hand (test scaffolding: the product calls the fused forms) ----------
 def sweep_audio_unfused(knn, qbase, q_win, q_t):
-    """Distance matrix (qpg_audio_cosine_f64), then qpg_percode_argmin_f64: same tables as CodeKNN.sweep_audio's f64 path."""
+    """Distance matrix (qpg_audio_cosine_f64), then the unguarded qpg_percode_select_f64: same tables as CodeKNN.sweep_audio's
+    f64 path on tie-free data."""
     import torch
     from qpgesture_amd import _lib
     from qpgesture_amd.code_knn import _i32
@@ -58,8 +59,8 @@ def sweep_audio_unfused(knn, qbase, q_win, q_t):
               NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, D.stride(0))
     dist = torch.empty((Q, db.K), dtype=torch.float64, device=dev)
     idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
-    _lib.call("qpg_percode_argmin_f64", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
-              db.aud_cidx, db.Ga, db.K, float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx)
+    _lib.call("qpg_percode_select_f64", dev, D, D.stride(0), Q, db.aud_cand_code, db.n_local * db.Ga, db.K,
+              float(ABSENT_DIST), db.idx_base * db.Ga, dist, idx, None, 0, 0)
     return dist, idx, D
 
 
@@ -75,8 +76,8 @@ def sweep_text_unfused(knn, queries):
     _lib.call("qpg_text_cosine_f32", dev, db.ctxt, db.Ct, db.Dt, qn, Q, D, D.stride(0))
     dist = torch.empty((Q, db.K), dtype=torch.float32, device=dev)
     idx = torch.empty((Q, db.K), dtype=torch.int32, device=dev)
-    _lib.call("qpg_percode_argmin_f32", dev, D, D.stride(0), Q, db.code_local, db.code.shape[1], db.n_local,
-              db.txt_cidx, db.Gt, db.K, float(ABSENT_DIST), db.idx_base * db.Gt, dist, idx)
+    _lib.call("qpg_percode_select_f32", dev, D, D.stride(0), Q, db.txt_cand_code, db.Ct, db.K, float(ABSENT_DIST),
+              db.idx_base * db.Gt, dist, idx, None, 0, 0)
     return dist, idx, D
 
 

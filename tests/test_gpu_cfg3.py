@@ -1,6 +1,6 @@
 """BASELINE.json configs[2]: synthetic DB of 100 000 codes x 512-d, 1 000 query windows, code ids
 uniform in [0,512), validity mask Bernoulli(0.9) — the generic cosine per-code-min kernel pair (qpg_text_pack_candidates_f32
-/ qpg_text_cosine_f32 / qpg_percode_resolve_f32 / qpg_percode_finalize_f32, sklearn-exact f32 arithmetic) at that size.
+/ qpg_text_cosine_f32 / qpg_percode_select_f32, sklearn-exact f32 arithmetic) at that size.
 Parity: a slice of the queries bit-exact against the C oracle (the oracle needs ~0.3 s per query on one core);
 all 1 000 queries through size-independent properties (planted exact matches win their code with distance 0 and the
 lowest index, masked rows never win, the global argmin is the planted row)."""
@@ -39,7 +39,7 @@ def _run(X, code, valid, q):
     cand_r = torch.zeros((1,), dtype=torch.int32, device=dev)
     xt = torch.zeros((((n + 63) // 64) * 64 * d,), dtype=torch.float32, device=dev)
     _lib.call("qpg_text_pack_candidates_f32", dev, xd, n, 1, d, cand_r, 1, xt)
-    cm = torch.from_numpy(np.where(valid, code, -1).astype(np.int32)).to(dev).view(n, 1).contiguous()
+    cm = torch.from_numpy(np.where(valid, code, -1).astype(np.int16)).to(dev).contiguous()
     qd = torch.from_numpy(q).to(dev)
     qn = torch.empty_like(qd)
     _lib.call("qpg_l2_normalize_rows_f32", dev, qd, nq, d, qn)
@@ -48,11 +48,9 @@ def _run(X, code, valid, q):
     ev[0].record()
     _lib.call("qpg_text_cosine_f32", dev, xt, n, d, qn, nq, Dm, Dm.stride(0))
     ev[1].record()
-    packed = torch.empty((nq, K), dtype=torch.int64, device=dev)
-    _lib.call("qpg_percode_resolve_f32", dev, Dm, Dm.stride(0), nq, cm, 1, n, cand_r, 1, K, 0, packed)
     dist = torch.empty((nq, K), dtype=torch.float32, device=dev)
     idx = torch.empty((nq, K), dtype=torch.int32, device=dev)
-    _lib.call("qpg_percode_finalize_f32", dev, packed, nq, K, 1000.0, dist, idx, None)
+    _lib.call("qpg_percode_select_f32", dev, Dm, Dm.stride(0), nq, cm, n, K, 1000.0, 0, dist, idx, None, 0, 0)
     ev[2].record()
     torch.cuda.synchronize()
     return dist.cpu().numpy(), idx.cpu().numpy(), ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])

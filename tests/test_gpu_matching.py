@@ -97,7 +97,7 @@ def test_knn_pred_vs_reference_golden(name, order):
 
 
 def test_unfused_entry_points_agree_with_fused():
-    """The stand-alone C-ABI entry points (distance matrix + qpg_percode_argmin_*, qpg_rank_rows_*) give
+    """The stand-alone C-ABI entry points (distance matrix + qpg_percode_select_*, qpg_rank_rows_*) give
     the same tables as the fused fast path, and the full distance matrices match the oracle's C port."""
     import torch
     from oracle import cref, knn_oracle as O
@@ -319,26 +319,6 @@ def test_one_launch_clip_pack_equals_separate_packs():
         assert torch.equal(out[True][0][k], out[False][0][k]), k
     for i, (a, b) in enumerate(zip(out[True][1:], out[False][1:])):
         assert torch.equal(a, b), i
-
-
-def test_select_issued_in_parts_equals_the_single_call():
-    """qpg_percode_select_mixed_f64_parts (1: the streaming pass, 2: everything behind it; the host's hook for gating the
-    text side's GEMM on the end of the streaming pass, CodeKNN.text_gate = "stream") leaves the same tables as the single
-    call, and the walk the same codes."""
-    import torch
-    g = load_golden(GOLDENS[1])
-    out = {}
-    for gate in ("none", "stream"):
-        A, db, knn, te_i, te_c, M = _build(g["meta"], freq_rank=g["step_freq_score"])
-        knn.text_gate = gate
-        T = knn.sweep_tables(te_i, te_c, M)
-        codes = knn.walk(T, M, seed_code=3, seed_phase=np.zeros((8, 16), np.float32))[0]
-        torch.cuda.synchronize()
-        assert knn._last_audio_hl and knn._last_text_mfma and knn.mixed_stats()["flags"] == 0
-        out[gate] = ({k: v.clone() for k, v in T.items() if v is not None}, np.asarray(codes).copy())
-    for k in out["none"][0]:
-        assert torch.equal(out["none"][0][k], out["stream"][0][k]), k
-    assert np.array_equal(out["none"][1], out["stream"][1])
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])

@@ -31,7 +31,6 @@ if os.environ.get("QPG_FORCE_SHARDED") == "1":          # the row-shard code pat
     os.environ.setdefault("MASTER_PORT", "29541")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     knn.force_sharded = True
-knn.text_lead = float(os.environ.get("QPG_TEXT_LEAD", knn.text_lead))
 knn.audio_kernel = os.environ.get("QPG_AUDIO_KERNEL", "hl")
 knn.tie_eps = float(os.environ.get("QPG_TIE_EPS", knn.tie_eps))
 te_i = torch.randn((M * CL, 180, 1024), device=dev)
