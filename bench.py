@@ -127,6 +127,9 @@ def main():
                          "`roofline` is then the sweep kernel ALONE on the GPU (with clips in flight the kernel's "
                          "duration includes what the other clips' kernels take from it)")
     ap.add_argument("--encode-batch", type=int, default=0, help="pose windows VQ-VAE-encoded inside the timed step")
+    ap.add_argument("--encode-precision", choices=["f32", "f16x3"], default="f32",
+                    help="encode leg: f32 = the f32 matrix-core kernels (exact f32 FMA chains); f16x3 = the split-operand f16 "
+                         "kernels under their margin check, flagged windows re-encoded in f32 (VQVAE.encode_f16x3)")
     ap.add_argument("--feature-dtype", choices=["f32", "f16"], default="f32")
     ap.add_argument("--workload", choices=["match", "cfg3"], default="match")
     ap.add_argument("--cfg3-method", choices=["mfma", "valu"], default="mfma",
@@ -202,6 +205,27 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # Row shards: the exchanges go through the LIBRARY's own RCCL communicator (round 5, csrc/qpg_comm.hip: no
+    # torch.distributed call - ~25 us of host time each - in a step, and the whole sharded clip is ONE hipGraph) unless it
+    # cannot be brought up (no RCCL, gloo test runs) or QPG_LIB_COLLECTIVES=0; every rank takes the same transport.
+    lib_coll, lib_coll_why = False, None
+    if (world > 1 or force_sharded) and one_gpu != "1" and os.environ.get("QPG_LIB_COLLECTIVES", "1") != "0" and \
+            a.scaling != "replicated":
+        from qpgesture_amd import parallel as _par
+        try:
+            _par.enable_lib_collectives(dev)
+            ok_ = 1
+        except Exception as e_:                                   # noqa: BLE001 (recorded in the line)
+            ok_, lib_coll_why = 0, repr(e_)[:200]
+        if world > 1:
+            f_ = torch.tensor([ok_], dtype=torch.int32, device=dev)
+            dist.all_reduce(f_, op=dist.ReduceOp.MIN)
+            ok_ = int(f_.item())
+        lib_coll = bool(ok_)
+        if not lib_coll:
+            _par.disable_lib_collectives()
+            lib_coll_why = lib_coll_why or "another rank could not create the library's communicator"
 
     if a.workload == "cfg3":
         out = cfg3_bench(a, dev, world, rank)
@@ -282,7 +306,7 @@ def main():
         # the final tables of its own clips.  strong: ONE all-gather + merge, every rank holds the clip's tables.
         # replicated: this rank's clips against the whole DB, no exchange.
         if enc is not None:
-            ids = enc.encode(enc_x)[0]
+            ids = enc.encode_f16x3(enc_x) if a.encode_precision == "f16x3" else enc.encode(enc_x)[0]
         T = knn.sweep_tables(te_interp, te_ctx, M * n_sweep_clips, owner_blocks=sharded_run and not strong, for_walk=True)
         if my_clips > 1 and batch_walk:
             # the clips are independent chains (their own seeds / window chaining): ONE set of walk launches for all
@@ -355,7 +379,8 @@ def main():
             knn.force_sharded, knn.sharded_mixed_min_gflop, knn.mixed_requests)
         cg = knn_g.capture_clip_graph(M, n_sweep_windows=M * n_sweep_clips, audio=te_interp, context=te_ctx,
                                       owner_blocks=sharded_run and not strong, n_clips=my_clips,
-                                      encoder=enc, encode_input=enc_x if enc is not None else None)
+                                      encoder=enc, encode_input=enc_x if enc is not None else None,
+                                      encode_precision=a.encode_precision)
         if sharded_run:
             # the segments are recorded NOW, and every rank ends up in the same step mode: a capture that failed on any
             # rank sends all of them to the eager step (MIN over the ranks of "captured")
@@ -377,6 +402,8 @@ def main():
 
     def step_graph():
         arr = cg.run_ints(seed_code, seed_phase)
+        if enc is not None:
+            cg.encoded_ids(arr)                    # (f16x3: windows the margin check flagged are re-encoded in f32 HERE)
         st_ = cg.statuses(arr)
         if (st_[:, 1] != 0).any():                 # a trouble word came out with the codes: this step again, eagerly
             graph_fallbacks[0] += 1                # (ClipGraph.wait_ints cleared the capture's matcher's sticky word)
@@ -665,7 +692,7 @@ def main():
                                   % (n_clips, "s" if n_clips > 1 else "", M, M * 8, 240 * M,
                                      "in all" if strong else "per job", "1" if N >= 8192 else "10", N, N * 26,
                                      "f32-bounded/f64-exact" if mixed else "f64", ", WavLM base stored f16" if fb == 2 else "",
-                                     (", + VQ-VAE encode of %d pose windows in the step" % a.encode_batch)
+                                     (", + VQ-VAE encode of %d pose windows in the step (%s)" % (a.encode_batch, a.encode_precision))
                                      if a.encode_batch else ""),
                       "n_db": N, "windows_per_clip": M, "clips": n_clips, "clips_per_gpu": CL,
                       "feature_dtype": a.feature_dtype, "audio_precision": "mixed" if mixed else "f64",
@@ -719,7 +746,11 @@ def main():
                             "achieved": round(flops / (k6 * 1e-3) / 1e12, 3), "peak": F64_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(flops / (k6 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
                             "codes_equal_default_path": bool(torch.equal(c64, codes))}
-    out["step_mode"] = ("graph-segments" if sharded_run else "graph") if graph_mode else "eager"
+    out["step_mode"] = ("graph-segments" if (sharded_run and not lib_coll) else "graph") if graph_mode else "eager"
+    if sharded_run:
+        out["collectives"] = {"transport": "libqpg_hip.so -> RCCL on the step's stream (qpg_comm_*; captured in the clip's "
+                                           "hipGraph)" if lib_coll else "torch.distributed (%s)" % dist.get_backend(),
+                              **({"library_transport_unavailable": lib_coll_why} if lib_coll_why else {})}
     if graph_fallback:
         out["step_mode_fallback"] = graph_fallback
     if graph_mode:
@@ -743,7 +774,9 @@ def main():
         out["graph_replay"] = {"ms_per_step": out["ms_per_step"], "steps": a.steps, "captures": cg.captures,
                                "is_the_timed_region": True, "clips_per_replay": my_clips,
                                "fallbacks_to_eager_in_the_timed_region": graph_fallbacks[0],
-                               **({"encode_leg_in_the_capture": True, "encoded_ids_equal_eager_encode": enc_same}
+                               **({"encode_leg_in_the_capture": True, "encoded_ids_equal_eager_encode": enc_same,
+                                   "encode_precision": a.encode_precision,
+                                   "encode_windows_re_encoded_in_f32": cg.enc_redone}
                                   if enc is not None else {}),
                                "text_side_captured_first": bool(not knn_g.audio_first and knn_g.audio_first is not None),
                                "other_seed_equals_eager": same2,

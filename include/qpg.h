@@ -483,6 +483,33 @@ int qpg_match_steps_batch(qpg_ctx*, void* stream, const int16_t* aud_rank, const
                           int64_t status_stride, const int32_t* guard_flags);
 
 /* ------------------------------------------------------------------------------------------
+ * Library-owned collectives of the row-sharded matcher (round 5).  The reference has no
+ * collective (its would-be sites are the dormant calls of codebook/models/bottleneck.py:45,75-77); the row shards and
+ * their min + index exchange are this build's.  One RCCL communicator per (process, device), created from a 128-byte
+ * unique id the host carries to the ranks once; every call below is stream-ordered on the `stream` it is handed and makes
+ * no host round trip, so a sharded step - kernels and collectives - is capturable as ONE hipGraph.  RCCL is bound lazily
+ * (dlopen): without it only these entry points fail.
+ *   qpg_comm_unique_id        rank 0: id [host] >= 128 bytes (ncclGetUniqueId).
+ *   qpg_comm_create           every rank, collectively: the id, its rank, the world size -> *out.
+ *   qpg_comm_allgather        recv [dev] world x bytes: block w = rank w's send [dev] (bytes).
+ *   qpg_comm_alltoall         send / recv [dev] world blocks of `bytes`: block w goes to / came from rank w (out of place).
+ *   qpg_comm_allreduce_max_i32  in place MAX (the agreed trouble word of an all-to-all step).
+ *   qpg_allreduce_min_u64     in place MIN of packed (order-preserving f32 distance key << 32 | global candidate index)
+ *                             tables: the global per-code winner with first-wins ties (GestureKNN.py:686-689) in one
+ *                             collective - for tables whose values decide every comparison (text f32, Levenshtein);
+ *                             qpg_pack_min_u64 / qpg_unpack_min_u64 convert (dist f32, idx i32; -1 = absent <-> all ones). */
+typedef struct qpg_comm qpg_comm;
+int qpg_comm_unique_id(void* id, int64_t id_bytes);
+int qpg_comm_create(qpg_ctx*, const void* id, int64_t id_bytes, int rank, int world, qpg_comm** out);
+int qpg_comm_destroy(qpg_comm*);
+int qpg_comm_allgather(qpg_ctx*, void* stream, qpg_comm*, const void* send, void* recv, int64_t bytes);
+int qpg_comm_alltoall(qpg_ctx*, void* stream, qpg_comm*, const void* send, void* recv, int64_t bytes);
+int qpg_comm_allreduce_max_i32(qpg_ctx*, void* stream, qpg_comm*, int32_t* buf, int64_t count);
+int qpg_allreduce_min_u64(qpg_ctx*, void* stream, qpg_comm*, uint64_t* buf, int64_t count);
+int qpg_pack_min_u64(qpg_ctx*, void* stream, const float* dist, const int32_t* idx, int64_t n, uint64_t* packed);
+int qpg_unpack_min_u64(qpg_ctx*, void* stream, const uint64_t* packed, int64_t n, float absent, float* dist, int32_t* idx);
+
+/* ------------------------------------------------------------------------------------------
  * Gesture VQ-VAE (codebook/models/{vqvae,encdec,resnet,bottleneck}.py).  Activations are channels-last
  * [B][T][C] f32 — the layout of the pose tensors at VQVAE.encode/decode's API (vqvae.py:132-136 permutes
  * to NCT and back; here nothing is permuted).
@@ -549,6 +576,24 @@ int qpg_vq_argmin_f32(qpg_ctx*, void* stream, const float* z, const float* dot, 
  * if an id is outside [0,K) (torch's F.embedding raises IndexError). */
 int qpg_vq_gather_f32(qpg_ctx*, void* stream, const float* k, const int64_t* ids, int64_t R, int E, int K, float* out,
                       int32_t* status);
+
+/* The convolution of qpg_conv1d_f32's contract on the f16 matrix cores with SPLIT operands (round 5, csrc/qpg_conv16.hip):
+ * every value is h + l (two f16 numbers; weights pre-scaled by a power of two per layer), a product is three
+ * v_mfma_f32_16x16x32_f16 (h l', l h', h h') accumulated in f32 - 3/16 of the f32 matrix time per flop, within ~1e-6
+ * (relative to sum |products|) of the f32 FMA chains, NOT bit-identical: the host uses it under a margin check and keeps
+ * the f32 kernels as the referee (qpgesture_amd/vqvae.py encode_f16x3; encdec.py:8-51, resnet.py:31-46 are the layers).
+ *   qpg_conv16_image_bytes   bytes of the weight image of a (taps, Cin, Cout) layer (Cin counted as the activation rows'
+ *                            channel count, a multiple of 8); the i32 at byte (that - 64) is the layer's scale exponent.
+ *   qpg_conv16_pack_weights  w [dev] f32 [taps][Cin_pad_w][Cout_pad_w] (qpg_conv1d_f32's layout) -> image [dev].
+ *   qpg_conv16_f32           x [dev] f32 [B][T_in][Cx] (Cx %% 8 == 0, Cx >= Cin, Cin %% 8 == 0; 16-byte aligned), geometry
+ *                            as qpg_conv1d_f32; y [dev] f32 [B][T_y][Cout]; status [dev] i32 |= 1 if an activation's
+ *                            magnitude exceeds the f16 range (the output is then meaningless: redo on the f32 kernels). */
+int64_t qpg_conv16_image_bytes(int taps, int Cin, int Cout);
+int qpg_conv16_pack_weights(qpg_ctx*, void* stream, const float* w, int taps, int Cin, int Cin_pad_w, int Cout, int Cout_pad_w,
+                            void* image, int64_t image_bytes);
+int qpg_conv16_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, int Cx, int Cin, const void* image, int w_exp,
+                   const float* bias, int taps, int Cout, int in_stride, int in_offset, int dil, int T_out, int out_stride,
+                   int out_offset, int T_y, const float* residual, int relu_in, int relu_out, float* y, int32_t* status);
 
 /* Whole-network entry points: VQVAE.encode / VQVAE.decode (vqvae.py:152-181) as ONE call each, the layer
  * sequence of encdec.py:53-136 issued from C on the caller's stream (no host round trips between layers).

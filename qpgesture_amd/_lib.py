@@ -77,6 +77,8 @@ _SIGS = {
     "qpg_convt_f32": [P, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, P],
     "qpg_convt_pair_f32": [P, I, I, I, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "qpg_pad_channels_f32": [P, L, I, I, P],
+    "qpg_conv16_pack_weights": [P, I, I, I, I, I, P, L],
+    "qpg_conv16_f32": [P, I, I, I, I, P, I, P, I, I, I, I, I, I, I, I, I, P, I, I, P, P],
     "qpg_tpack_f32": [P, I, I, I, I, P],
     "qpg_resblock_f32": [P, I, I, I, P, P, P, P, P],
     "qpg_pose_to_euler_f64": [P, L, I, P, P, P, P, P, I, P, P],
@@ -93,6 +95,12 @@ _SIGS = {
     "qpg_conv1d_bwd_data_f32": [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, L],
     "qpg_conv1d_bwd_weight_f32": [P, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, L],
     "qpg_adam_step_f32": [P, P, P, P, L, c_float, c_float, c_float, c_float, L],
+    "qpg_comm_allgather": [P, P, P, L],
+    "qpg_comm_alltoall": [P, P, P, L],
+    "qpg_comm_allreduce_max_i32": [P, P, L],
+    "qpg_allreduce_min_u64": [P, P, L],
+    "qpg_pack_min_u64": [P, P, L, P],
+    "qpg_unpack_min_u64": [P, L, c_float, P, P],
     "qpg_match_steps": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P, P],
     "qpg_match_steps_batch": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P, P, L, P],
 }
@@ -172,6 +180,11 @@ def load():
     lib.qpg_percode_select_exact_ws_bytes.argtypes = [c_int, c_int64, c_int]
     lib.qpg_percode_select_exact_ws_bytes.restype = c_int64
     lib.qpg_merge_mixed_ws_bytes.restype = c_int64
+    lib.qpg_conv16_image_bytes.argtypes = [c_int, c_int, c_int]
+    lib.qpg_conv16_image_bytes.restype = c_int64
+    lib.qpg_comm_unique_id.argtypes = [ctypes.c_char_p, c_int64]
+    lib.qpg_comm_create.argtypes = [c_void_p, ctypes.c_char_p, c_int64, c_int, c_int, ctypes.POINTER(c_void_p)]
+    lib.qpg_comm_destroy.argtypes = [c_void_p]
     lib.qpg_debug_convt_shape.argtypes = [c_int, c_int]
     lib.qpg_vq_reduce_ws_bytes.argtypes = []
     lib.qpg_vq_reduce_ws_bytes.restype = c_int64
@@ -256,7 +269,7 @@ def call(name, device, *args):
         elif isinstance(a, ctypes.Structure):
             conv.append(ctypes.byref(a))
         else:
-            conv.append(a)
+            conv.append(a)                      # (ints, floats, None, c_void_p handles)
     h = _ctx.get(idx)
     if h is None:
         h = ctx(device)

@@ -1204,7 +1204,8 @@ class CodeKNN:
                              "(the reference raises IndexError at GestureKNN.py:631-632)")
 
     def capture_clip_graph(self, n_windows, mode=MODE_AUD_TXT, n_sweep_windows=None, window_offset=0, audio=None,
-                           context=None, owner_blocks=False, n_clips=1, encoder=None, encode_input=None):
+                           context=None, owner_blocks=False, n_clips=1, encoder=None, encode_input=None,
+                           encode_precision="f32"):
         """Capture the whole per-clip launch sequence (pack, both sweeps, per-code argmin passes, ranks,
         rank-fusion tables, walk) into one HIP graph for a fixed clip shape.  Returns a ClipGraph whose
         run(test_audio, test_context, seed_code, seed_phase) replays it; results are device tensors.
@@ -1215,7 +1216,7 @@ class CodeKNN:
         encoder / encode_input: a VQVAE and a resident pose batch f32 [B][T][C] whose encode (make_beat_dataset.py:314-316)
         runs INSIDE the capture on a branch of its own beside the match - one replay = the fused encode + match step."""
         return ClipGraph(self, n_windows, mode, n_sweep_windows or n_windows * n_clips, window_offset, audio, context,
-                         owner_blocks, n_clips, encoder, encode_input)
+                         owner_blocks, n_clips, encoder, encode_input, encode_precision)
 
     def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
                    seed_phase=None, return_tables=False):
@@ -1287,7 +1288,7 @@ class ClipGraph:
     sentinel, hipGraphLaunch, watch the status word.  One capture serves every clip of that shape."""
 
     def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset, audio=None, context=None, owner_blocks=False,
-                 n_clips=1, encoder=None, encode_input=None):
+                 n_clips=1, encoder=None, encode_input=None, encode_precision="f32"):
         db, dev = knn.db, knn.db.device
         self.owner_blocks = owner_blocks
         self.CL = int(n_clips)
@@ -1296,6 +1297,12 @@ class ClipGraph:
         self.enc, self.enc_x = encoder, encode_input
         if (encoder is None) != (encode_input is None):
             raise ValueError("encoder and encode_input go together")
+        if encode_precision not in ("f32", "f16x3"):
+            raise ValueError("encode_precision must be 'f32' or 'f16x3'")
+        # "f16x3": the split-f16 encoder under its margin check (VQVAE.encode_f16x3_device): the replay also brings back one
+        # flag per window, and encoded_ids() re-encodes flagged windows on the f32 kernels before it returns anything
+        self.enc_precision = encode_precision
+        self.enc_redone = 0
         self.segmented = False
         if db.world != 1 or knn.force_sharded:
             # A row-sharded clip is recorded in SEGMENTS (parallel.SegmentRecorder): one hipGraph per run of kernels
@@ -1311,7 +1318,12 @@ class ClipGraph:
             import torch.distributed as dist_
             if not (dist_.is_available() and dist_.is_initialized()):
                 raise NotImplementedError("graph capture of the sharded path needs an initialised process group")
-            if _os.environ.get("QPG_EXPERIMENTAL_SHARDED_GRAPH", "") == "1":
+            from . import parallel as _par0
+            if _par0._libcomm is not None:
+                # round 5: the collectives are the LIBRARY's own RCCL calls on the capturing stream (csrc/qpg_comm.hip) -
+                # the whole sharded clip is ONE hipGraph, no torch.distributed call in a replay
+                pass
+            elif _os.environ.get("QPG_EXPERIMENTAL_SHARDED_GRAPH", "") == "1":
                 if dist_.get_backend() != "nccl":
                     raise NotImplementedError("one-graph capture of the sharded path needs the nccl (RCCL) backend")
             else:
@@ -1346,7 +1358,12 @@ class ClipGraph:
             B_, T_ = int(encode_input.shape[0]), int(encode_input.shape[1])
             self._ids_shape = (B_, T_ // encoder.hop)
             self._n_ids = B_ * (T_ // encoder.hop)
-        self._pin = torch.empty((self._n_ints + self._n_ids,), dtype=torch.int32).pin_memory()
+            self._n_flags = B_ if encode_precision == "f16x3" else 0
+            if self._n_flags:
+                encoder._hl_tolerance(T_)                  # (measured now: nothing inside the capture may synchronise)
+        else:
+            self._n_flags = 0
+        self._pin = torch.empty((self._n_ints + self._n_ids + self._n_flags,), dtype=torch.int32).pin_memory()
         self._pin_np = self._pin.numpy()
         self._watch = self._pin_np[self._n_ints - 2 * CL + 1:self._n_ints:2]      # every clip's status[1]
         self._in_flight = False
@@ -1361,7 +1378,8 @@ class ClipGraph:
         if self.enc is not None:
             self._enc_stream = torch.cuda.Stream(dev)
             self._enc_gate, self._enc_done = torch.cuda.Event(), torch.cuda.Event()
-            ids_pin = self._pin[self._n_ints:]
+            ids_pin = self._pin[self._n_ints:self._n_ints + self._n_ids]
+            flags_pin = self._pin[self._n_ints + self._n_ids:]
 
         import os as _os
         enc_at = _os.environ.get("QPG_ENCODE_AT", "sweep_end")      # measurements: "start" = beside the whole match
@@ -1377,7 +1395,11 @@ class ClipGraph:
             self._enc_gate.record(main)
             self._enc_stream.wait_event(self._enc_gate)
             with torch.cuda.stream(self._enc_stream):
-                ids = self.enc.encode_fused(self.enc_x)
+                if self._n_flags:
+                    ids, flags = self.enc.encode_f16x3_device(self.enc_x)
+                    flags_pin.copy_(flags, non_blocking=True)
+                else:
+                    ids = self.enc.encode_fused(self.enc_x)
                 ids_pin.copy_(ids.reshape(-1).to(torch.int32), non_blocking=True)
                 self._enc_done.record(self._enc_stream)
 
@@ -1495,8 +1517,15 @@ class ClipGraph:
         return ints[:self.CL * self._n_c].reshape(self.CL, self.M, num_frames_code)
 
     def encoded_ids(self, ints):
-        """The encode leg's ids [B][T/8] (int32) of wait_ints()' array."""
-        return ints[self._n_ints:self._n_ints + self._n_ids].reshape(self._ids_shape)
+        """The encode leg's ids [B][T/8] (int32) of wait_ints()' array.  encode_precision "f16x3": windows the margin check
+        flagged are encoded again on the f32 kernels first (VQVAE.resolve_f16x3; counted in `enc_redone`)."""
+        ids = ints[self._n_ints:self._n_ints + self._n_ids].reshape(self._ids_shape)
+        if self._n_flags:
+            flags = ints[self._n_ints + self._n_ids:self._n_ints + self._n_ids + self._n_flags]
+            if flags.any():
+                ids, n = self.enc.resolve_f16x3(self.enc_x, ids, flags)
+                self.enc_redone += n
+        return ids
 
     def run_ints(self, seed_code, seed_phase):
         """One replay on the bound inputs, ending with the integer results on the host (bench.py's graph step)."""

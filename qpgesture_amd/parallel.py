@@ -62,6 +62,93 @@ def alltoall_min_index(dist, idx, world, group=None):
 # hipGraph being captured, runs eagerly - as torch.distributed issues it in an uncaptured step - and opens the next graph.
 _recorder = None
 
+# Library-owned collectives (round 5; csrc/qpg_comm.hip): when a LibComm is active the exchanges below are RCCL calls the
+# LIBRARY makes on the current stream - no torch.distributed call, no host round trip (~25 us each), and capturable into
+# the clip's hipGraph together with the kernels around them (one graph per sharded clip instead of segments).
+_libcomm = None
+
+
+class LibComm:
+    """An RCCL communicator owned by libqpg_hip.so (qpg_comm_create), one per process and device.  The 128-byte unique
+    id is generated on rank 0 and handed to the other ranks through the already-initialised torch.distributed process
+    group (any backend: an object broadcast, once); after that torch.distributed is not involved in the data path."""
+
+    def __init__(self, device, group=None):
+        import ctypes
+        import torch.distributed as dist_
+        from . import _lib
+        if not (dist_.is_available() and dist_.is_initialized()):
+            raise RuntimeError("LibComm: initialise torch.distributed first (it carries the unique id to the ranks)")
+        lib = _lib.load()
+        self.device = torch.device(device)
+        self.rank, self.world = dist_.get_rank(group), dist_.get_world_size(group)
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            if lib.qpg_comm_unique_id(buf, 128) != 0:
+                raise RuntimeError("qpg_comm_unique_id failed: %s" % _lib.last_error())
+        box = [bytes(buf.raw) if self.rank == 0 else None]
+        if self.world > 1:
+            dist_.broadcast_object_list(box, src=0, group=group)
+        h = ctypes.c_void_p()
+        rc = lib.qpg_comm_create(_lib.ctx(self.device), box[0], 128, self.rank, self.world, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError("qpg_comm_create failed: %s" % _lib.last_error())
+        self.handle = h
+        self.calls = 0
+
+    def close(self):
+        from . import _lib
+        if self.handle is not None:
+            torch.cuda.synchronize(self.device)
+            _lib.load().qpg_comm_destroy(self.handle)
+            self.handle = None
+
+    def exchange(self, send, out, owner_blocks):
+        from . import _lib
+        self.calls += 1
+        if owner_blocks:
+            _lib.call("qpg_comm_alltoall", self.device, self.handle, send, out, send.numel() // self.world)
+        else:
+            _lib.call("qpg_comm_allgather", self.device, self.handle, send, out, send.numel())
+        return out
+
+    def allreduce_max_i32(self, t):
+        from . import _lib
+        assert t.dtype == torch.int32 and t.is_contiguous()
+        self.calls += 1
+        _lib.call("qpg_comm_allreduce_max_i32", self.device, self.handle, t, t.numel())
+        return t
+
+    def allreduce_min_packed(self, dist, idx, absent):
+        """Global per-entry (minimum f32 distance, lowest candidate index among equals) of `dist` / `idx` in ONE MIN
+        all-reduce of packed u64 keys (qpg_allreduce_min_u64).  In place on copies; returns
+        (dist, idx)."""
+        from . import _lib
+        n = dist.numel()
+        packed = torch.empty((n,), dtype=torch.int64, device=dist.device)
+        _lib.call("qpg_pack_min_u64", self.device, dist.contiguous(), idx.contiguous(), n, packed)
+        self.calls += 1
+        _lib.call("qpg_allreduce_min_u64", self.device, self.handle, packed, n)
+        d, i = torch.empty_like(dist), torch.empty_like(idx)
+        _lib.call("qpg_unpack_min_u64", self.device, packed, n, float(absent), d, i)
+        return d, i
+
+
+def enable_lib_collectives(device, group=None):
+    """Make the library's own RCCL communicator the transport of exchange_bytes / allreduce_max_ (idempotent).  Returns the
+    LibComm, or raises - the caller decides whether torch.distributed stays the transport (bench.py records the reason)."""
+    global _libcomm
+    if _libcomm is None:
+        _libcomm = LibComm(device, group)
+    return _libcomm
+
+
+def disable_lib_collectives():
+    global _libcomm
+    if _libcomm is not None:
+        _libcomm.close()
+    _libcomm = None
+
 
 def _exchange_into(out, send, world, owner_blocks, group=None):
     """exchange_bytes on a caller-owned receive buffer (`out` may be None: allocate).  RCCL (backend nccl) moves device
@@ -94,6 +181,10 @@ def exchange_bytes(send, world, owner_blocks, group=None):
     every rank receives every rank's whole buffer (ONE all-gather: the all-reduce(min, index) of SURVEY.md §8e with
     the reduction done locally by qpg_merge_select_*).  Returns the receive buffer: `world` source chunks, chunk w
     from rank w.  RCCL (backend nccl) moves device buffers in place; gloo is staged through the host."""
+    lc = _libcomm
+    if lc is not None and send.is_cuda:
+        n = send.numel() if owner_blocks else world * send.numel()
+        return lc.exchange(send, torch.empty((n,), dtype=send.dtype, device=send.device), owner_blocks)
     rec = _recorder
     if rec is not None:
         # a persistent receive buffer, allocated OUTSIDE the captures; the collective itself is replayed by calling it
@@ -213,6 +304,8 @@ def allreduce_max_(t, force=False):
     import torch.distributed as dist_
     if not (_active() or (force and dist_.is_available() and dist_.is_initialized())):
         return t
+    if _libcomm is not None and t.is_cuda and t.dtype == torch.int32:
+        return _libcomm.allreduce_max_i32(t)
     rec = _recorder
     if rec is not None:
         return rec.cut(lambda _out: allreduce_max_(t, force))

@@ -155,9 +155,14 @@ def test_sharded_path_over_rccl_with_one_rank():
     device buffers, the three mixed-merge kernels, the trouble word's all-reduce) executed over backend nccl = RCCL with
     world_size 1, weak (all-to-all) and strong (all-gather) forms, mixed-precision and f64 shards; codes == the plain
     single-GPU match (--check)."""
-    for extra in (["--sharded-mixed-min-gflop", "0"], ["--scaling", "strong", "--sharded-mixed-min-gflop", "0"],
-                  ["--sharded-mixed-min-gflop", "1e9"], ["--audio-precision", "exact"]):
-        env = dict(os.environ, QPG_BENCH_FORCE_SHARDED="1", MASTER_PORT=str(_free_port()))
+    cases = [(e, "0") for e in (["--sharded-mixed-min-gflop", "0"], ["--scaling", "strong", "--sharded-mixed-min-gflop", "0"],
+                                ["--sharded-mixed-min-gflop", "1e9"], ["--audio-precision", "exact"])]
+    # round 5: the same forms with the LIBRARY's own RCCL communicator as the transport (qpg_comm_*: the default when it
+    # comes up) - no torch.distributed call in a step, the whole sharded clip ONE hipGraph, eager re-matches behind replays
+    cases += [(e, "1") for e in (["--sharded-mixed-min-gflop", "0"], ["--scaling", "strong", "--sharded-mixed-min-gflop", "0"],
+                                 ["--sharded-mixed-min-gflop", "1e9"])]
+    for extra, libc in cases:
+        env = dict(os.environ, QPG_BENCH_FORCE_SHARDED="1", MASTER_PORT=str(_free_port()), QPG_LIB_COLLECTIVES=libc)
         for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
             env.pop(k, None)
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--n-db", "200",
@@ -166,9 +171,13 @@ def test_sharded_path_over_rccl_with_one_rank():
         assert r.returncode == 0, str(extra) + r.stdout[-2000:] + r.stderr[-3000:]
         out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert out["check"] is True and out["rematched_steps"] == 0, extra
-        # the timed region replayed the clip's segments; the collectives between them are the eager path's own calls
-        assert out["step_mode"] == "graph-segments", extra
-        assert out["graph_replay"]["segments"].count("collective") == out["config"]["collectives_per_step"], extra
+        if libc == "1":
+            assert out["step_mode"] == "graph" and out["collectives"]["transport"].startswith("libqpg_hip.so"), (extra, out["collectives"])
+            assert "segments" not in out["graph_replay"]
+        else:
+            # the timed region replayed the clip's segments; the collectives between them are the eager path's own calls
+            assert out["step_mode"] == "graph-segments" and out["collectives"]["transport"].startswith("torch.distributed"), extra
+            assert out["graph_replay"]["segments"].count("collective") == out["config"]["collectives_per_step"], extra
         assert out["graph_replay"]["other_seed_equals_eager"] and out["eager"]["codes_equal_graph_steps"], extra
     # QPG_BENCH_SHARDED_EAGER=1: one Python launch per kernel, as before
     env = dict(os.environ, QPG_BENCH_FORCE_SHARDED="1", QPG_BENCH_SHARDED_EAGER="1", MASTER_PORT=str(_free_port()))
@@ -212,3 +221,59 @@ def test_merge_kernel_vs_reference():
         assert (oi.cpu()[:, 17] == -1).all() and (od.cpu()[:, 17] == 1e3).all()
         rk = np.argsort(np.argsort(want_d.numpy(), axis=1, kind="stable"), axis=1, kind="stable")
         assert np.array_equal(ork.cpu().numpy(), rk)
+
+
+def test_library_owned_collectives_one_rank():
+    """csrc/qpg_comm.hip through parallel.LibComm on a one-rank RCCL communicator: byte all-gather / all-to-all return the
+    send buffer, the MAX / packed-MIN all-reduces leave their operands, pack / unpack of (distance, index) keys round-trip
+    (order-preserving for negative values, -1 = absent <-> all ones), and the calls are capturable in a hipGraph."""
+    import numpy as np
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+dev = torch.device("cuda:0")
+dist.init_process_group("gloo", rank=0, world_size=1)
+from qpgesture_amd import parallel as P, _lib
+lc = P.enable_lib_collectives(dev)
+send = torch.arange(4096, dtype=torch.uint8, device=dev)
+assert torch.equal(P.exchange_bytes(send, 1, False), send) and torch.equal(P.exchange_bytes(send, 1, True), send)
+t = torch.tensor([5, -3, 7], dtype=torch.int32, device=dev)
+assert torch.equal(P.allreduce_max_(t.clone(), force=True), t)
+rng = np.random.default_rng(3)
+d = torch.from_numpy(rng.standard_normal(5000).astype(np.float32)).to(dev)
+i = torch.from_numpy(rng.integers(-1, 1 << 30, size=5000).astype(np.int32)).to(dev)
+d2, i2 = lc.allreduce_min_packed(d, i, 1000.0)
+absent = i < 0
+assert torch.equal(i2, i) and torch.equal(d2[~absent], d[~absent]) and bool((d2[absent] == 1000.0).all())
+packed = torch.empty((5000,), dtype=torch.int64, device=dev)
+_lib.call("qpg_pack_min_u64", dev, d, i, 5000, packed)
+pk = packed.cpu().numpy().view(np.uint64)
+dd, ii = d.cpu().numpy(), i.cpu().numpy()
+ok = ii >= 0
+order = np.lexsort((ii[ok], dd[ok]))
+assert np.array_equal(np.argsort(pk[ok], kind="stable"), order)       # u64 order == (distance, index) order
+assert (pk[~ok] == np.uint64(0xffffffffffffffff)).all()
+g = torch.cuda.CUDAGraph()
+out = torch.empty((4096,), dtype=torch.uint8, device=dev)
+s = torch.cuda.Stream(dev)
+with torch.cuda.stream(s):
+    lc.exchange(send, out, False)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        lc.exchange(send, out, False)
+        lc.allreduce_max_i32(t)
+out.zero_()
+for _ in range(3):
+    g.replay()
+lc.exchange(send, out, True)          # an eager collective BEHIND graph replays on the same communicator
+torch.cuda.synchronize()
+assert torch.equal(out, send)
+P.disable_lib_collectives()
+print("LIBCOMM_OK", lc.calls)
+''' % ROOT
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "LIBCOMM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -3,9 +3,10 @@
 Parent mode (no arguments): builds qpgesture_amd/libqpg_hip_asan.so (python -m qpgesture_amd.build --sanitize) and re-runs
 itself as a child with clang's ASan runtime preloaded and QPG_LIB_PATH pointing at the instrumented library.
 Child mode: every entry point of include/qpg.h is called with arguments it must REFUSE - a null context, null pointers,
-zero / negative / huge sizes - and has to come back with an error code and a message (no launch is ever made, so this
-runs without a GPU; with one, the same calls are repeated with a real context so that the checks behind `ctx &&` run too),
-and the pure size helpers are driven to the edges of their integer ranges.  Any report of either sanitizer aborts the child
+zero / negative / huge sizes - and has to come back with an error code and a message (no launch is ever made: the child
+runs with the GPUs hidden - AMD's ASan runtime also intercepts the HSA allocator of a NON-instrumented HIP runtime and
+aborts its first device allocation, which says nothing about this library), and the pure size helpers are driven to the
+edges of their integer ranges.  Any report of either sanitizer aborts the child
 (-fno-sanitize-recover, halt_on_error): the parent's exit code is the verdict."""
 import ctypes
 import os
@@ -74,6 +75,7 @@ def main():
     from qpgesture_amd import build
     lib = build.build_sanitized(verbose=False)
     env = dict(os.environ, QPG_ABI_SANITIZE_CHILD="1", QPG_LIB_PATH=lib, LD_PRELOAD=build.asan_runtime(),
+               HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0:protect_shadow_gap=0",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=900)
