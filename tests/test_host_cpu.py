@@ -32,7 +32,8 @@ def test_bindings_cover_the_header():
                                "qpg_merge_mixed_ws_bytes", "qpg_debug_convt_shape",
                                "qpg_percode_select_exact_ws_bytes", "qpg_audio_hl_supported",
                                "qpg_audio_hl_db_bytes", "qpg_audio_hl_query_bytes", "qpg_hl_rows_bytes",
-                               "qpg_hl_cols_bytes", "qpg_dev_kernarg", "qpg_audio_hl1_supported", "qpg_audio_hl1_db_bytes"}
+                               "qpg_hl_cols_bytes", "qpg_dev_kernarg", "qpg_audio_hl1_supported", "qpg_audio_hl1_db_bytes",
+                               "qpg_conv16_image_bytes", "qpg_comm_unique_id", "qpg_comm_create", "qpg_comm_destroy"}
     assert declared == bound
 
 
