@@ -260,6 +260,29 @@ int qpg_hl_gemm_distance(qpg_ctx*, void* stream, const void* rows_image, int64_t
  * 64: cfg-3's 375 MB prefilter matrix is neither written nor read. */
 int qpg_hl_gemm_tilemin(qpg_ctx*, void* stream, const void* rows_image, int64_t R, int D, const void* cols_image, int Q,
                         float band, float* tile_min, uint16_t* tile_mask, int64_t ldT);
+/* Round 5, many queries per batch (BASELINE.json configs[2]): the prefilter on the h PLANES ALONE and the exact-order
+ * evaluations BY CODE.
+ *   qpg_hl_gemm_tilemin_h   one f16 MFMA per 16 x 16 x 32 block (the cross terms h l' + l h' and l l' are dropped: at most
+ *       (2^-10 + 2^-22) |x||q| by Cauchy-Schwarz - `band` must cover it: sorted_rows.gemm_h_err), 64-row wave tiles; writes
+ *       tile minima and row masks TILE-MAJOR: tile_min f32 / tile_mask u16 [dev] [R / 16][ldQ >= Q].  R %% 64 == 0,
+ *       D %% 256 == 0.  Same images as qpg_hl_gemm_tilemin (the l planes are not read).
+ *   qpg_perm32_rows_f32     y[r][32 G + 8 k + j] = x[r][16 (2 G + (j >> 2)) + 4 (3 - (j & 3)) + k]: inside every 32-element
+ *       group (one 128-byte line) the four einsum chains of sklearn's f32 sum of squares become four 32-byte runs in visiting
+ *       order (rows once at build time, the queries per batch).  D %% 32 == 0.
+ *   qpg_percode_select_bycode_f32   the tables of qpg_percode_select_sorted_f32 (bit-identical), one block per (code, query
+ *       range): the code's minimum per query from the tile-major minima, the opened tiles' masked rows listed as (query,
+ *       row) pairs, every pair evaluated in the exact order by four lanes (one per chain) from the chain-permuted rows
+ *       xs_perm [R + 1][D] / queries qn_perm [Q][D] - a segment's rows are fetched from HBM once for all queries (the by-query
+ *       kernel gathers 2 KB per pair: 0.95 GB per 1 000 queries of cfg-3).  A block = one code, its rows staged through LDS tile by tile; a tile's pair list holds 1 024 pairs;
+ *       overflow: stats[1] |= 16.  No exchange layout (q_block): single-GPU batches and per-shard tables only. */
+int qpg_hl_gemm_tilemin_h(qpg_ctx*, void* stream, const void* rows_image, int64_t R, int D, const void* cols_image, int Q,
+                          float band, float* tile_min_t, uint16_t* tile_mask_t, int64_t ldQ);
+int qpg_perm32_rows_f32(qpg_ctx*, void* stream, const float* x, int64_t R, int D, float* y);
+int qpg_percode_select_bycode_f32(qpg_ctx*, void* stream, const float* tile_min_t, const uint16_t* tile_mask_t, int64_t ldQ,
+                                  int Q, int64_t R, const int16_t* row_code, const int32_t* row_index,
+                                  const int32_t* zero_row, const int32_t* code_tile, int K, float band,
+                                  const float* qn_perm, const float* xs_perm, int D, float absent, float* out_dist,
+                                  int32_t* out_idx, int16_t* out_rank, int32_t* out_nn, int32_t* stats, int32_t idx_base);
 int qpg_percode_select_sorted_f32(qpg_ctx*, void* stream, const float* Dm, int64_t ldD, const float* tile_min,
                                   const uint16_t* tile_mask /* or NULL: rows are taken from Dm */, int64_t ldT,
                                   int Q, int64_t R, const int16_t* row_code, const int32_t* row_index,

@@ -47,6 +47,9 @@ _SIGS = {
     "qpg_percode_select_sorted_f32": [P, L, P, P, L, I, L, P, P, P, P, I, c_float, P, P, I, c_float, P, P, P, P, P,
                                       ctypes.c_int32, I, L],
     "qpg_hl_gemm_tilemin": [P, L, I, P, I, c_float, P, P, L],
+    "qpg_hl_gemm_tilemin_h": [P, L, I, P, I, c_float, P, P, L],
+    "qpg_perm32_rows_f32": [P, L, I, P],
+    "qpg_percode_select_bycode_f32": [P, P, L, I, L, P, P, P, P, I, c_float, P, P, I, c_float, P, P, P, P, P, I],
     "qpg_text_pack_candidates_f32": [P, I, I, I, P, I, P],
     "qpg_text_cosine_f32": [P, L, I, P, I, P, L],
     "qpg_text_percode_f32": [P, L, I, P, I, P, I, I, ctypes.c_int32, c_float, P, L, P, P, P, P],

@@ -80,6 +80,7 @@ class CosineIndex:
         xn = torch.empty_like(xd)
         _lib.call("qpg_l2_normalize_rows_f32", dev, xd.contiguous(), self.n, self.d, xn)
         self.sorted = SortedRows(xn, torch.from_numpy(cm), self.K, dev)
+        self.sorted.by_code = True                # round 5: h-plane prefilter + by-code exact select for batches >= 256 queries
         self.R, self.band = self.sorted.R, self.sorted.band
         self._stats = torch.zeros((4,), dtype=torch.int32, device=dev)
         self._scratch = {}            # column image / prefilter matrix / tile minima (one index = one stream)
@@ -165,45 +166,63 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
     alg_bytes = n_loc * DIM * (2 if f16 else 4) + n_loc * (8 if f16 else 4) + N_Q * DIM * 4 + N_Q * K_CODES * 8
     lane_ops = 3.0 * N_Q * n_loc * DIM                                                   # sub, mul, add per element pair
     valu_peak = 1024 * 2.4e9 * 32                                                        # packed f32 non-FMA lane-ops/s
-    return {"metric": "per-code min cosine sweep, query-candidate pairs/sec (cfg-3)", "value": round(N_Q * N_DB * steps / dt, 1),
-            "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": max(a.warmup, 3),
-            "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg-3: DB 100000 x 512 %s, 512 codes, Bernoulli(0.9) validity mask, 1000 queries; "
-                                   "sklearn-exact f32 cosine, per-code min + argmin + global nearest neighbour%s"
-                                   % ("stored f16 (rounded), widened + normalised in registers" if f16 else "f32",
-                                      " (bounded split-f16 matrix-core prefilter + exact-order refine of the band: "
-                                      "bit-identical tables)" if mfma else ""),
-                       "method": index.method,
-                       "feature_dtype": "f16" if f16 else "f32",
-                       "n_db": N_DB, "dim": DIM, "queries": N_Q, "parallelism": "db rows / %d" % world},
-            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": hbm_peak_gbs,
-                         "unit": "GB/s", "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / hbm_peak_gbs, 4),
-                         "traffic": (_pmc_step_traffic() if mfma else CFG3_TRAFFIC_BYTES) if world == 1 and not f16 else None,
-                         "traffic_source": "profiles/pmc_traffic.json [cfg3_step]: FETCH_SIZE x 2 + WRITE_SIZE summed over the "
-                                           "step's kernels (GEMM 0.40 GB, select's exact-row gathers 0.95 GB), rocprofv3 "
-                                           "--pmc passes (tools/pmc_cfg3.sh); not re-measured per run" if mfma else None,
-                         "kernel": ("hl_gemm32_kernel (prefilter GEMM, 32-row wave tiles: tile minima + row masks, no matrix) "
-                                    "+ percode_select_sorted_kernel (+ query normalise / pack)" if mfma
-                                    else "text_cosine_gmin_f32_kernel (+ fill, merge)"),
-                         # the matrix-core view of the same step: three f16 MFMAs per 16 x 16 x 32 block of the padded problem
-                         "mfma": ({"issued_tflops_f16": round(3 * 2.0 * index.R * ((N_Q + 95) // 96 * 96) * DIM / (k_ms * 1e-3) / 1e12, 1),
-                                   "peak": 2500.0,
-                                   "frac": round(3 * 2.0 * index.R * ((N_Q + 95) // 96 * 96) * DIM / (k_ms * 1e-3) / 1e12 / 2500.0, 4),
-                                   "note": "whole step (GEMM + select) against the dense f16 matrix peak; the GEMM alone "
-                                           "runs at ~0.40 of it (profiles/r04_cfg3_*.md)"} if mfma else None),
-                         "kernel_ms": round(k_ms, 4),
-                         "algorithmic_bytes": int(alg_bytes),
-                         "note": ("the tables are sklearn's separately rounded f32 arithmetic (bit-exact indices are the bar); "
-                                  "the matrix cores run a PREFILTER with an a-priori bound, only the band members get the "
-                                  "exact order: the step is now bound by the prefilter's passes over the row image "
-                                  "(11 chunks of 96 queries) and the Q x R prefilter matrix it hands to the select"
-                                  if mfma else
-                                  "the distance is sklearn's separately rounded f32 arithmetic (bit-exact indices are the "
-                                  "bar), so neither FMA nor the matrix cores are admissible: the kernel is VALU-bound"),
-                         "valu": {"lane_ops": lane_ops, "peak_lane_ops_per_s": valu_peak,
-                                  "floor_ms": round(lane_ops / valu_peak * 1e3, 3),
-                                  "frac": round(lane_ops / valu_peak / (k_ms * 1e-3), 4)}}}
+    by_code = mfma and index.sorted.uses_by_code(N_Q)
+    rec = {"metric": "per-code min cosine sweep, query-candidate pairs/sec (cfg-3)", "value": round(N_Q * N_DB * steps / dt, 1),
+           "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": max(a.warmup, 3),
+           "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "cfg-3: DB 100000 x 512 %s, 512 codes, Bernoulli(0.9) validity mask, 1000 queries; "
+                                  "sklearn-exact f32 cosine, per-code min + argmin + global nearest neighbour%s"
+                                  % ("stored f16 (rounded), widened + normalised in registers" if f16 else "f32",
+                                     " (bounded f16 matrix-core prefilter + exact-order refine of the band: "
+                                     "bit-identical tables)" if mfma else ""),
+                      "method": index.method + ("/h-plane prefilter + by-code select" if by_code else ""),
+                      "feature_dtype": "f16" if f16 else "f32",
+                      "n_db": N_DB, "dim": DIM, "queries": N_Q, "parallelism": "db rows / %d" % world}}
+    hbm_view = {"achieved": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": hbm_peak_gbs, "unit": "GB/s",
+                "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / hbm_peak_gbs, 4), "algorithmic_bytes": int(alg_bytes)}
+    valu_view = {"lane_ops": lane_ops, "peak_lane_ops_per_s": valu_peak, "floor_ms": round(lane_ops / valu_peak * 1e3, 3),
+                 "frac": round(lane_ops / valu_peak / (k_ms * 1e-3), 4)}
+    if mfma:
+        # Q = 1000 is beyond the f16 ridge (Q ~ 300): the matrix cores bound this shape.  `achieved` = the
+        # step's ALGORITHMIC flops (2 Q N D = 102.4 GFLOP, SURVEY's figure) over the step time; `issued` = what the
+        # prefilter really issues on the padded problem (one f16 MFMA per 16 x 16 x 32 block on the by-code path, three
+        # on the by-query path)
+        per_block = 1 if by_code else 3
+        qpad = (N_Q + 95) // 96 * 96
+        alg_flop = 2.0 * N_Q * n_loc * DIM
+        issued = per_block * 2.0 * index.R * qpad * DIM
+        traffic = _pmc_step_traffic("cfg3_step_bycode|100000x512 Q=1000" if by_code else "cfg3_step|100000x512 Q=1000") \
+            if world == 1 else None
+        rec["roofline"] = {
+            "bound": "mfma", "achieved": round(alg_flop / (k_ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(alg_flop / (k_ms * 1e-3) / 1e12 / 2500.0, 4),
+            "algorithmic_gflop": round(alg_flop / 1e9, 1),
+            "issued_tflops_f16": round(issued / (k_ms * 1e-3) / 1e12, 1),
+            "issued_frac": round(issued / (k_ms * 1e-3) / 1e12 / 2500.0, 4),
+            "traffic": traffic,
+            "traffic_source": ("profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE summed over the step's kernels, rocprofv3 "
+                               "--pmc passes (tools/pmc_cfg3.sh); not re-measured per run") if traffic else None,
+            "kernel": ("hl_gemm64h_kernel (prefilter on the h planes alone: one f16 MFMA per block, 64-row wave tiles, tile "
+                       "minima + row masks tile-major) + percode_select_bycode_kernel (a code's rows through LDS once, four "
+                       "lanes per exact-order pair) (+ query normalise / pack / permute, ranks + nearest neighbours)" if by_code
+                       else "hl_gemm32_kernel (prefilter GEMM, 32-row wave tiles: tile minima + row masks, no matrix) "
+                            "+ percode_select_sorted_kernel (+ query normalise / pack)"),
+            "kernel_ms": round(k_ms, 4),
+            "hbm": hbm_view,
+            "valu": valu_view,
+            "note": "the tables are sklearn's separately rounded f32 arithmetic (bit-exact indices are the bar): the matrix "
+                    "cores run a PREFILTER with an a-priori bound, only the rows inside each (query, code) band get the exact "
+                    "order.  The whole step (GEMM + select + packs) is priced against the dense f16 matrix peak; the GEMM "
+                    "alone is ~45 % of the step (profiles/r05_cfg3_*.md)"}
+    else:
+        rec["roofline"] = dict(hbm_view, bound="valu" if not f16 else "valu", traffic=CFG3_TRAFFIC_BYTES if world == 1 and not f16 else None,
+                               traffic_source=None, kernel="text_cosine_gmin_f32_kernel (+ fill, merge)",
+                               kernel_ms=round(k_ms, 4), valu=valu_view,
+                               note="the distance is sklearn's separately rounded f32 arithmetic (bit-exact indices are the "
+                                    "bar), so neither FMA nor the matrix cores are admissible: the kernel is VALU-bound")
+        rec["roofline"]["bound"] = "hbm"          # (the contract's vocabulary; the binding unit is the VALU: see `valu`)
+    return rec
 
 
 # Fabric-side bytes per step from rocprofv3 PMC (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate passes):
@@ -212,12 +231,12 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
 CFG3_TRAFFIC_BYTES = 6_440_000_000
 
 
-def _pmc_step_traffic():
+def _pmc_step_traffic(key="cfg3_step|100000x512 Q=1000"):
     """HBM-side bytes of one cfg-3 step on the prefilter path, from the committed PMC summary (profiles/pmc_traffic.json)."""
     import json
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     try:
-        return int(json.load(open(path))["cfg3_step|100000x512 Q=1000"]["hbm_bytes_per_step"])
+        return int(json.load(open(path))[key]["hbm_bytes_per_step"])
     except (OSError, KeyError, ValueError):
         return None

@@ -721,6 +721,15 @@ __device__ __forceinline__ double fast_rsqrt_f64(double x) {
   return y;
 }
 #define H2_W 8
+#ifndef H2_QFIRST
+#define H2_QFIRST 1      // the query loads go out in front of the ring's loads for every ring depth (see the k loop)
+#endif
+#ifndef H2_PIN
+#define H2_PIN 1         // two-plane kernel: where the ring's refill is issued - 0: hipcc's choice; 1: behind the stage's last
+#endif                   // MFMA; 2: two loads behind the last use of each register pair
+#ifndef H2_PRO
+#define H2_PRO 1         // prologue in the k loop's request order
+#endif
 // ablation hooks (experiments/audio_hl): -DH2_PROBE=<bits>; the product build defines nothing.  1: database fragments read
 // from one address (no HBM stream); 2: no f64 flush; 8: no stage barrier
 #ifndef H2_PROBE
@@ -798,14 +807,23 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][c][r] = 0.0;
   h8 ring[2 * RS][2 * PL];
+  // Prologue in the k loop's OWN request order - the third stage's query loads in front of the ring's last stage: hipcc's
+  // wait for a register is the tightest over every path into the loop, and with the query loads youngest here the loop
+  // head waited vmcnt(3) for them - which drains the whole ring once per trip (round 5: 137 -> see DESIGN 4.1a).
 #pragma unroll
-  for (int i = 0; i < 2 * RS; ++i) load_a(i, ring[i]);
+  for (int i = 0; i < (H2_PRO ? 2 * (RS - 1) : 2 * RS); ++i) load_a(i, ring[i]);
   load_q(0);
   store_q(0);
   load_q(1);
   lds_barrier();
   store_q(1);
   load_q(2);
+  if (H2_PRO) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 2 * (RS - 1); i < 2 * RS; ++i) load_a(i, ring[i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
   h8 B[2][2][2];                                                       // [step parity][k-block of the stage][plane]
   auto ld_b = [&](int buf, int c, h8 (&d)[2][2]) {
@@ -833,7 +851,7 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         if (c == HL_CT - 1) {
           if (!(H2_PROBE & 8)) lds_barrier();  // every fragment of this stage has arrived; the next stage's are stored
           ld_b((ss + 1) & 1, 0, Bn);
-          if (RS > 2) {
+          if (H2_QFIRST || RS > 2) {
             // vmcnt counts IN ORDER: the wait for a stage's query fragments (one stage after their request) also waits
             // for every OLDER request.  With the query loads behind the ring's (below: the order of the two-stage ring,
             // where it does not matter) a deeper ring buys nothing - the data of stage s + RS - 1 must be there at the
@@ -883,7 +901,7 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
           // stage after next (behind the barrier above: nobody reads this stage's buffer any more)
           load_a(2 * (s + RS), A0);
           load_a(2 * (s + RS) + 1, A1);
-          if (RS <= 2) {
+          if (!H2_QFIRST && RS <= 2) {
             store_q(ss & 1);
             load_q(s + 3);
           }
@@ -893,7 +911,11 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
           HL_SGB(0x008, 1);
           if (i < 4) HL_SGB(0x100, 1);
           HL_SGB(0x002, PL == 2 ? 2 : 3);
+          if (H2_PIN == 2 && PL == 2 && c == HL_CT - 1 && (i == 3 || i == 7 || i == 9 || i == 11)) HL_SGB(0x020, 2);
         }
+        // the ring's refill goes out HERE, behind the stage's last MFMAs (their registers are free then) - named, or hipcc
+        // issues it somewhere in the middle of the next stage and the ring loses a third of its lead
+        if (c == HL_CT - 1 && H2_PIN == 1 && PL == 2) HL_SGB(0x020, 4 * PL);
       }
     }
   }
@@ -1488,6 +1510,240 @@ __global__ __launch_bounds__(512, 2) void hl_gemm32_kernel(HlArgs a, int n_items
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // surplus prefetches must not outlive their registers
+}
+
+// ---- the prefilter GEMM on the h PLANES ALONE, 64-row wave tiles (round 5): hl_gemm64h_kernel ------------------------------
+// For the exact-f32 cosine family the prefilter only has to be BOUNDED: dropping both cross terms (h l' + l h') and l l'
+// costs at most (2 x 2^-11 + 2^-22) |x||q| (h = fl16(x): relative error <= 2^-11 per element in the scaled normal range,
+// Cauchy-Schwarz over the row) = 9.8e-4 for unit vectors - the band widens from 8.8e-5 to 2.1e-3, which on BASELINE
+// configs[2]'s rows (nearest-neighbour gaps ~1.6e-2 per code) lists ~12 % more pairs for the exact-order evaluation, and
+// the GEMM issues ONE v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block instead of three and reads half the row image.
+// With the cross-term accumulators gone a wave holds FOUR row tiles x six column tiles (64 x 96, 96 accumulator
+// registers): one 1 KB query fragment from LDS feeds four MFMAs (gemm32: 2 KB per six), every accumulator is revisited
+// six steps later (no dependent MFMAs back to back).  Block = 8 waves = 512 rows; query stages of FOUR k-blocks of the h
+// plane (24 KB), double-buffered; the ring of row fragments is one stage deep (four k-blocks x four tiles), a k-block's
+// slot refilled with the same k-block of the next stage as soon as its last column tile is done.  Items, XCD-aware order
+// and the persistent blocks are hl_gemm32_kernel's.  Output: tile minima and row masks only, TILE-MAJOR
+// ([tile][a.ldT], a.ldT >= Q: the 16 queries of a column tile are one 64-byte store; the by-code select reads a tile's
+// queries contiguously).  Needs KB % 8 == 0 and an even number of 32-row groups.
+#define G64_KS 4
+#define G64_PD 2
+template <int CT>
+__global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_items) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x G64_KS x CT x 1 KB = 48 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);              // (scalar: the rows' base addresses stay in SGPRs)
+  const int nb = (int)gridDim.x, nx = (nb % 8 == 0) ? 8 : 1;
+  const int xcd = (int)blockIdx.x % nx, lx = (int)blockIdx.x / nx, lpx = nb / nx;
+  const int n_rb = n_items / a.chunks;
+  const int nit = ((n_rb - xcd + nx - 1) / nx) * a.chunks;             // items of this XCD
+  auto vid = [&](int k) {
+    const int i = k * lpx + lx;
+    return i < nit ? ((i / a.chunks) * nx + xcd) * a.chunks + i % a.chunks : -1;
+  };
+  const int it0 = vid(0);
+  if (it0 < 0) return;
+  const int KB = a.KB, n_stage = KB / G64_KS;                          // (KB % 8 == 0: an even number of stages)
+  const int cg = lane & 15, rg = lane >> 4;
+  const int e_c1 = a.meta[0];
+  constexpr int stage_units = G64_KS * CT * 64;                        // h8 units per stage (h plane only)
+  constexpr int QLD = stage_units / 512;
+  static_assert(stage_units % 512 == 0, "a stage is a whole number of 16-byte units per thread");
+  h8 qreg[QLD];
+  uint32_t qoff[QLD];                                                  // (v / 64) * 2 KB + (v % 64) * 16 B: the h piece's unit
+#pragma unroll
+  for (int u = 0; u < QLD; ++u) {
+    const uint32_t v = (uint32_t)(u * 512 + tid);
+    qoff[u] = (v >> 6) * 2048u + (v & 63u) * 16u;
+  }
+  auto load_q = [&](int item, int s) {                                 // the h pieces of the stage's (k-block, column tile)s
+    const unsigned char* qsrc = reinterpret_cast<const unsigned char*>(a.qi) +
+                                ((int64_t)(item % a.chunks) * KB + (int64_t)s * G64_KS) * CT * 2048;
+#pragma unroll
+    for (int u = 0; u < QLD; ++u) qreg[u] = *reinterpret_cast<const h8*>(qsrc + qoff[u]);
+  };
+  auto store_q = [&](int buf) {
+    h8* dst = reinterpret_cast<h8*>(lds) + buf * stage_units;
+#pragma unroll
+    for (int u = 0; u < QLD; ++u) dst[u * 512 + tid] = qreg[u];
+  };
+  auto lds_barrier = [&]() {                 // LDS-only: the rows' fragment loads stay in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // rows of this wave in an item: 64-row group jj = two 32-row groups = four 16-row tiles, [tile][kb][plane][64 lanes];
+  // a group past the image reads the zero page (all strides 0).  Everything here is wave-uniform: addresses = a byte
+  // base in scalar registers + one 32-bit byte offset per lane.
+  typedef const __attribute__((address_space(1))) unsigned char* gbytes_t;   // (global: survives the register pins below)
+  typedef const __attribute__((address_space(1))) h8* gh8_t;
+  struct Rows {
+    gbytes_t base;
+    uint32_t t_step, kb_step;                 // bytes
+    int jj;
+    bool ok;
+  };
+  auto rows_of = [&](int item) {
+    Rows r;
+#ifdef G64_DUP                                  /* experiment: waves w and w + 4 read the SAME rows (L1 hits: is the kernel L2-bound?) */
+    r.jj = (item / a.chunks) * 8 + (w & 3);
+#else
+    r.jj = (item / a.chunks) * 8 + w;
+#endif
+    r.ok = 2 * r.jj < a.N;
+    r.base = r.ok ? (gbytes_t)(reinterpret_cast<const unsigned char*>(a.db) + (int64_t)r.jj * 4 * KB * 2048)
+                  : (gbytes_t)reinterpret_cast<const unsigned char*>(a.zeros);
+    r.t_step = r.ok ? (uint32_t)KB * 2048u : 0u;
+    r.kb_step = r.ok ? 2048u : 0u;
+    // (pinned in scalar registers HERE: left alone, hipcc sinks this arithmetic - a division and selects, i.e. branches -
+    // into the stage's basic block, next to the refill loads)
+    asm volatile("" : "+s"(r.base), "+s"(r.t_step), "+s"(r.kb_step));
+    return r;
+  };
+  const uint32_t loff = (uint32_t)lane * 16u;
+  auto load_a = [&](gbytes_t base, uint32_t t_step, uint32_t off, h8 (&d)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) d[t] = *(gh8_t)(base + ((uint32_t)t * t_step + off + loff));
+  };
+  f32x4 hh[4][CT];
+  h8 A[G64_KS][4];                           // [ring slot = k-block of the stage][row tile]
+  h8 Bq[G64_PD + 1];                         // ring: a column tile's fragment is read G64_PD steps ahead
+  auto ld_b = [&](int buf, int k2, int c, h8& d) {
+    d = (reinterpret_cast<const h8*>(lds) + buf * stage_units + lane)[(k2 * CT + c) * 64];
+  };
+  Rows cur = rows_of(it0);
+  load_q(it0, 0);
+#pragma unroll
+  for (int i = 0; i < G64_KS; ++i) load_a(cur.base, cur.t_step, (uint32_t)i * cur.kb_step, A[i]);
+  store_q(0);
+  __syncthreads();
+  constexpr int NS = G64_KS * CT;            // steps of a stage: (k-block, column tile); 4 MFMAs each
+  static_assert((2 * NS) % (G64_PD + 1) == 0 && NS % (G64_PD + 1) == 0, "the fragment ring index must be static");
+#pragma unroll
+  for (int i = 0; i < G64_PD; ++i) ld_b(0, i / CT, i % CT, Bq[i]);
+  for (int kk = 0;; ++kk) {
+    const int item = vid(kk);
+    if (item < 0) break;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) hh[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nitem = vid(kk + 1) >= 0 ? vid(kk + 1) : item;          // (behind the last item: harmless re-reads)
+    const Rows nxt = rows_of(nitem);
+    for (int s2 = 0; s2 < n_stage; s2 += 2) {                          // two stages per trip: buffer indices static
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const int s = s2 + ss;
+        const bool last_s = s + 1 == n_stage;
+        load_q(last_s ? nitem : item, last_s ? 0 : s + 1);            // in flight underneath this stage's MFMAs
+        // the stage's k-blocks are refilled with the same k-blocks of the next stage - of this item, or (behind its last
+        // stage) of the next item's first stage: scalars chosen HERE, so that the stage stays ONE basic block
+        gbytes_t rf_base = cur.base + (uint32_t)(s + 1) * G64_KS * cur.kb_step;
+        uint32_t rf_t = cur.t_step, rf_k = cur.kb_step;
+        if (last_s) {
+          rf_base = nxt.base;
+          rf_t = nxt.t_step;
+          rf_k = nxt.kb_step;
+        }
+        asm volatile("" : "+s"(rf_base), "+s"(rf_t), "+s"(rf_k));
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          const int k2 = st / CT, c = st % CT;
+          h8 (&Ac)[4] = A[k2];
+          h8& Bc = Bq[(ss * NS + st) % (G64_PD + 1)];
+          h8& Bn = Bq[(ss * NS + st + G64_PD) % (G64_PD + 1)];
+          if (st == NS - G64_PD) {
+            store_q((ss + 1) & 1);
+            lds_barrier();
+          }
+          if (st >= NS - G64_PD) ld_b((ss + 1) & 1, (st + G64_PD - NS) / CT, (st + G64_PD - NS) % CT, Bn);
+          else ld_b(ss, (st + G64_PD) / CT, (st + G64_PD) % CT, Bn);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) hh[t][c] = mfma_h(Ac[t], Bc, hh[t][c]);
+          if (c == CT - 1) load_a(rf_base, rf_t, (uint32_t)k2 * rf_k, Ac);      // this k-block is done: its slot is refilled
+          // issue order (every class named, or hipcc sinks the loads to their uses and waits vmcnt(0) there): the
+          // stage's query loads first; per step an MFMA, the fragment read underneath it, three MFMAs; the refill's
+          // four loads behind the step that frees their registers; the LDS stores of the next stage at its barrier
+          if (st == 0) HL_SGB(0x020, QLD);
+          if (st == NS - G64_PD) HL_SGB(0x200, QLD);
+          HL_SGB(0x008, 1);
+          HL_SGB(0x100, 1);
+          HL_SGB(0x008, 3);
+          if (c == CT - 1) HL_SGB(0x020, 4);
+        }
+      }
+    }
+    // epilogue of the item: d = 1 - hh 2^-(e_c + e_q); lane (cg, rg) holds rows 4 rg .. 4 rg + 3 of column cg
+    const Rows done = cur;
+    cur = nxt;
+    if (!done.ok) continue;
+    const int chunk = item % a.chunks;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const int q = chunk * (16 * CT) + c * 16 + cg;
+      if (q >= a.Q) continue;
+      const float sc = ldexpf(1.0f, -(e_c1 + a.qexp[q]));            // (a power of two: the product below is exact)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = 1.0f - hh[t][c][r] * sc;
+        float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
+        m = fminf(m, __shfl_xor(m, 16, 64));
+        m = fminf(m, __shfl_xor(m, 32, 64));
+        const float lim = m + a.band;
+        unsigned int bits = ((o[0] <= lim) ? 1u : 0u) | ((o[1] <= lim) ? 2u : 0u) | ((o[2] <= lim) ? 4u : 0u) |
+                            ((o[3] <= lim) ? 8u : 0u);
+        bits <<= 4 * rg;
+        bits |= (unsigned int)__shfl_xor((int)bits, 16, 64);
+        bits |= (unsigned int)__shfl_xor((int)bits, 32, 64);
+        if (rg == 0) {
+          const int64_t o_i = ((int64_t)done.jj * 4 + t) * a.ldT + q;
+          a.tmin[o_i] = m;
+          a.tmask[o_i] = (uint16_t)bits;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // surplus prefetches must not outlive their registers
+}
+
+// The h-plane prefilter (hl_gemm64h_kernel): tile minima + row masks, TILE-MAJOR: tile_min / tile_mask [R / 16][ldQ],
+// ldQ >= Q.  `band` must cover QPG_HL_GEMM_H_ERR (sorted_rows.gemm_h_err).  Needs D % 256 == 0 and R % 64 == 0.
+extern "C" int qpg_hl_gemm_tilemin_h(qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,
+                                     const void* cols_image, int Q, float band, float* tile_min, uint16_t* tile_mask,
+                                     int64_t ldQ) {
+  const char* name = "qpg_hl_gemm_tilemin_h";
+  QPG_REQUIRE(ctx && rows_image && cols_image && tile_min && tile_mask, "%s: null pointer", name);
+  QPG_REQUIRE(R > 0 && (R % 64) == 0 && R / 32 < 0x7fffffff && Q > 0 && D > 0 && (D % 256) == 0 && ldQ >= Q && band >= 0.f,
+              "%s: bad size (R %% 64 == 0, D %% 256 == 0, ldQ >= Q, band >= 0)", name);
+  const int chunks = (Q + HL_GQC - 1) / HL_GQC, KB = D / 32;
+  HlArgs a;
+  const unsigned char* ri = static_cast<const unsigned char*>(rows_image);
+  const unsigned char* ci = static_cast<const unsigned char*>(cols_image);
+  a.db = reinterpret_cast<const _Float16*>(ri);
+  a.meta = reinterpret_cast<const int32_t*>(ri + (qpg_hl_rows_bytes(R, D) - 64));
+  a.qi = reinterpret_cast<const _Float16*>(ci);
+  a.qexp = reinterpret_cast<const int32_t*>(ci + (int64_t)chunks * KB * HL_CT * 2 * HL_PIECE);
+  a.cn2 = nullptr; a.qn2 = nullptr; a.D = nullptr; a.zeros = ctx->zeros; a.ldD = 0; a.stats = nullptr;
+  a.N = (int)(R / 32); a.j0 = 0; a.chunks = chunks; a.G = 0; a.Q = Q; a.KB = KB; a.d_f32 = 1; a.tmin = tile_min; a.ldT = ldQ;
+  a.tmask = tile_mask; a.band = band;
+  const size_t lds64 = 2 * (size_t)G64_KS * HL_CT * HL_PIECE;         // 48 KB
+  static bool raised64 = false;
+  if (!raised64) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hl_gemm64h_kernel<HL_CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds64) != hipSuccess) {
+      qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
+      return QPG_EHIP;
+    }
+    raised64 = true;
+  }
+  const int64_t g8 = (R / 64 + 7) / 8;                                 // row blocks of 8 x 64 rows
+  QPG_REQUIRE(g8 * chunks < 0x7fffffffll, "%s: too many work items", name);
+  const int n_items = (int)(g8 * chunks);
+  const int n_blocks = n_items < ctx->n_cu ? n_items : ctx->n_cu;
+  hipLaunchKernelGGL(hl_gemm64h_kernel<HL_CT>, dim3(n_blocks), dim3(512), lds64, qpg_stream(stream), a, n_items);
+  QPG_LAUNCH_CHECK("hl_gemm64h_kernel");
+  return QPG_OK;
 }
 
 static int hl_gemm_impl(const char* name, qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,

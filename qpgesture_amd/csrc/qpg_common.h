@@ -10,7 +10,7 @@
 struct qpg_ctx {
   int device;
   int n_cu;
-  float* zeros;   // 256 B of device zeros: out-of-range tile loads are redirected here instead of being selected to 0
+  float* zeros;   // 4 KB of device zeros: out-of-range tile loads are redirected here instead of being selected to 0
   bool select_lds_raised;   // percode_select_mixed_f64_kernel's dynamic-LDS limit has been raised on this device
 };
 

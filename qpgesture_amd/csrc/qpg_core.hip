@@ -47,8 +47,8 @@ extern "C" int qpg_ctx_create(int device, qpg_ctx** out) {
   c->select_lds_raised = false;
   int prev = 0;
   (void)hipGetDevice(&prev);
-  const bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&c->zeros), 256) == hipSuccess &&
-                  hipMemset(c->zeros, 0, 256) == hipSuccess;
+  const bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&c->zeros), 4096) == hipSuccess &&
+                  hipMemset(c->zeros, 0, 4096) == hipSuccess;
   (void)hipSetDevice(prev);
   if (!ok) {
     qpg_set_error("qpg_ctx_create: could not allocate the context's zero page on device %d", device);

@@ -255,3 +255,294 @@ extern "C" int qpg_percode_select_sorted_f32(qpg_ctx* ctx, void* stream, const f
   }
   return QPG_OK;
 }
+
+// ---- round 5: the exact-order evaluations BY CODE (many queries per batch: BASELINE.json configs[2]) ------------------------
+// percode_select_sorted_kernel gathers one 2 KB candidate row per listed (query, row) pair: 512 K pairs = 0.95 GB per
+// 1 000 queries although every one of the 100 K rows is wanted by ~5 queries (profiles/r04_cfg3_pmc.md).  Here a block
+// owns ONE CODE (its rows are one contiguous segment of the sorted rows) and a range of queries:
+//   (1) per query the code's minimum over its tiles, from the TILE-MAJOR minima the h-plane GEMM wrote (a tile's queries
+//       are one coalesced run);  (2) opened tiles' masked rows listed as (query, row) pairs;  (3) every pair evaluated in
+//       sklearn's exact order by FOUR lanes, one per einsum chain: both operands are stored CHAIN-PERMUTED (perm32_kernel:
+//       inside every 32-element group = 128-byte line, chain k's eight elements in visiting order at 8 k .. 8 k + 7), so that
+//       lane k reads the 32 bytes it visits next and the four lanes of a pair read whole lines of the row and of the query; the rows of the
+//       segment are fetched from HBM once and hit L1 / L2 for the segment's other pairs, the queries (2 MB) live in L2;
+//       a_k = d^2 + a_k in the reference's order (groups ascending, u = 3, 2, 1, 0), (a_0 + a_1) + (a_2 + a_3) by two
+//       lane exchanges;  (4) minimum by (exact distance, ORIGINAL index) per query in LDS, one table entry per query.
+// Tables bit-identical to percode_select_sorted_kernel's and to the exact sweep's (tests/test_gpu_cfg3.py).  A pair list
+// that overflows raises stats[1] |= 16 like the by-query kernel's.  (Round 3's by-code attempt - 465 us - gathered BOTH
+// operands in 16-byte pieces per lane from a query-major matrix; this one reads 64-byte runs and nothing query-major.)
+// y[32 G + 8 k + j] = x[16 (2 G + (j >> 2)) + 4 (3 - (j & 3)) + k]: inside every 32-element group (one 128-byte line) chain
+// k's eight elements sit in visiting order - 16-element groups ascending, u = 3, 2, 1, 0 inside each (NumPy einsum's order)
+__global__ __launch_bounds__(256) void perm32_kernel(const float* __restrict__ x, int64_t n32, float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(x) + i * 8;
+    f32x4 u[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) u[v] = p[v];                        // u[4 h + uu]: group 2 G + h, vector uu
+    f32x4* o = reinterpret_cast<f32x4*>(y) + i * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[2 * k] = (f32x4){u[3][k], u[2][k], u[1][k], u[0][k]};
+      o[2 * k + 1] = (f32x4){u[7][k], u[6][k], u[5][k], u[4][k]};
+    }
+  }
+}
+
+extern "C" int qpg_perm32_rows_f32(qpg_ctx* ctx, void* stream, const float* x, int64_t R, int D, float* y) {
+  QPG_REQUIRE(ctx && x && y && x != y && R >= 0 && D > 0 && (D % 32) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0 &&
+                  (reinterpret_cast<uintptr_t>(y) % 16) == 0,
+              "qpg_perm32_rows_f32: bad argument (D %% 32 == 0, 16-byte aligned, out of place)");
+  const int64_t n32 = R * (D / 32);
+  if (n32 == 0) return QPG_OK;
+  const int64_t nb = (n32 + 255) / 256;
+  hipLaunchKernelGGL(perm32_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, qpg_stream(stream), x, n32, y);
+  QPG_LAUNCH_CHECK("perm32_kernel");
+  return QPG_OK;
+}
+
+// Block = ONE CODE, all queries of the launch (<= BYC_QMAX), 512 threads.  The code's rows are staged through LDS tile by
+// tile (16 rows = 32 KB, coalesced loads into registers one tile ahead); per tile the queries whose band the
+// tile's minimum lies in are listed from the tile-major minima / masks (~100 pairs of cfg-3's 1 000 queries) and evaluated
+// by four lanes each: the row from LDS, the query (L2-resident) gathered in whole 128-byte lines, both chain-permuted.
+// History of this kernel (cfg-3 batch, 1 000 queries): rows AND queries gathered per pair from memory, one block per
+// (code, query range): 181 us with 64-byte runs (16-element permutation), 165 us with whole lines - four dependent
+// batches of HBM-latency loads per pair whatever the block shape; rows through LDS: see DESIGN.md 4.4.
+#define BYC_THREADS 512
+#define BYC_QMAX 2048      // queries per launch of the kernel (the host wrapper loops over larger batches)
+#define BYC_LIST 1024      // (query, row) pairs of ONE tile a block can hold
+
+template <int PT>              // 16-byte units of a tile per thread: 16 (D / 4) / BYC_THREADS
+__global__ __launch_bounds__(BYC_THREADS) void percode_select_bycode_kernel(
+    const float* __restrict__ tmin_t, const uint16_t* __restrict__ tmask_t, int64_t ldQ, int Q, int64_t R,
+    const int16_t* __restrict__ row_code, const int32_t* __restrict__ row_index, const int32_t* __restrict__ zero_row,
+    const int32_t* __restrict__ code_tile, int K, float band, const float* __restrict__ qp, const float* __restrict__ xsp,
+    int Dd, float absent, float* __restrict__ out_dist, int32_t* __restrict__ out_idx, int32_t* __restrict__ stats,
+    int32_t idx_base) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int rowb = Dd * 4;                                             // bytes of a row
+  float* rows0 = reinterpret_cast<float*>(smem);                       // [17][Dd]: the tile's 16 rows + a zero row
+  unsigned long long* ebest = reinterpret_cast<unsigned long long*>(smem + (size_t)17 * rowb);       // [Q]
+  float* cmin = reinterpret_cast<float*>(ebest + Q);                   // [Q]
+  int* list_q = reinterpret_cast<int*>(cmin + Q);                      // [BYC_LIST]
+  int* list_r = list_q + BYC_LIST;                                     // [BYC_LIST] row inside the tile (16: the zero row)
+  __shared__ int n_list[2];                                            // tile t counts in n_list[t & 1]
+  const int code = blockIdx.x, tid = threadIdx.x;
+  const int t0 = code_tile[code], t1 = code_tile[code + 1], nt = t1 - t0;
+  const int zr = zero_row ? zero_row[code] : -1;
+  const int nv = Dd / 4;                                               // 16-byte units of a row
+  // (0) the code's minimum per query (tile-major minima: coalesced; eight independent loads per trip)
+  for (int q = tid; q < Q; q += BYC_THREADS) {
+    const float* tp = tmin_t + (int64_t)t0 * ldQ + q;
+    float m = zr >= 0 ? 0.5f : __builtin_inff();
+    for (int t = 0; t < nt; t += 8) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = t + i < nt ? tp[(int64_t)(t + i) * ldQ] : __builtin_inff();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m = fminf(m, v[i]);
+    }
+    cmin[q] = m;
+    ebest[q] = ~0ull;
+  }
+  for (int i = tid; i < nv; i += BYC_THREADS)                          // the zero row
+    reinterpret_cast<f32x4*>(rows0 + 16 * Dd)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (tid == 0) n_list[0] = n_list[1] = 0;
+  f32x4 stage[PT];
+  float nmin[BYC_QMAX / BYC_THREADS];                                  // the next tile's minima / masks of this thread's queries
+  unsigned int nmask[BYC_QMAX / BYC_THREADS];
+  auto fetch = [&](int t) {                                            // tile t0 + t -> registers (coalesced)
+    const f32x4* src = reinterpret_cast<const f32x4*>(xsp + (int64_t)(t0 + t) * 16 * Dd);
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+      const int i = u * BYC_THREADS + tid;
+      stage[u] = i < 16 * nv ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t to = (int64_t)(t0 + t) * ldQ;
+#pragma unroll
+    for (int u = 0; u < BYC_QMAX / BYC_THREADS; ++u) {
+      const int q = u * BYC_THREADS + tid;
+      nmin[u] = q < Q ? tmin_t[to + q] : __builtin_inff();
+      nmask[u] = q < Q ? tmask_t[to + q] : 0u;
+    }
+  };
+  auto commit = [&]() {
+    f32x4* dst = reinterpret_cast<f32x4*>(rows0);
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+      const int i = u * BYC_THREADS + tid;
+      if (i < 16 * nv) dst[i] = stage[u];
+    }
+  };
+  if (nt > 0 && band >= 0.f) {
+    fetch(0);
+    commit();
+  }
+  __syncthreads();
+  const int k4 = tid & 3;
+  const int G32 = Dd / 32;
+  for (int t = 0; t < nt && band >= 0.f; ++t) {
+    float vmin[BYC_QMAX / BYC_THREADS];
+    unsigned int vmask[BYC_QMAX / BYC_THREADS];
+#pragma unroll
+    for (int u = 0; u < BYC_QMAX / BYC_THREADS; ++u) {
+      vmin[u] = nmin[u];
+      vmask[u] = nmask[u];
+    }
+    if (t + 1 < nt) fetch(t + 1);                                      // rows, minima, masks: in flight underneath this tile
+    // (1) this tile's pairs: queries whose band the tile's minimum lies in, their masked rows (padding rows never);
+    // the code's all-zero row enters with the first tile
+#pragma unroll
+    for (int u = 0; u < BYC_QMAX / BYC_THREADS; ++u) {
+      const int q = u * BYC_THREADS + tid;
+      if (q >= Q) break;
+      const float lim = cmin[q] + band;
+      if (vmin[u] <= lim) {
+        unsigned int bits = vmask[u];
+        while (bits) {
+          const int r = __builtin_ctz(bits);
+          bits &= bits - 1;
+          if (row_code[(int64_t)(t0 + t) * 16 + r] & 0x4000) continue;
+          const int pos = atomicAdd(&n_list[t & 1], 1);
+          if (pos < BYC_LIST) {
+            list_q[pos] = q;
+            list_r[pos] = r;
+          }
+        }
+      }
+      if (t == 0 && zr >= 0 && 0.5f <= lim) {
+        const int pos = atomicAdd(&n_list[t & 1], 1);
+        if (pos < BYC_LIST) {
+          list_q[pos] = q;
+          list_r[pos] = 16;
+        }
+      }
+    }
+    __syncthreads();
+    int n = n_list[t & 1];
+    if (tid == 0) n_list[(t + 1) & 1] = 0;                             // (nobody touches it before the next barrier)
+    if (n > BYC_LIST) {
+      n = BYC_LIST;
+      if (tid == 0 && stats) atomicOr(&stats[1], 16);
+    }
+    // (2) four lanes per pair, lane k = einsum chain k: 0.5 * ((a0 + a1) + (a2 + a3)), a_k = d * d + a_k over the chain's
+    // elements in the reference's order - which the chain-permuted rows store consecutively (32 bytes per 128-byte line)
+    const float* rb = rows0;
+    for (int e0 = 0; e0 < n; e0 += BYC_THREADS / 4) {
+      const int e = e0 + (tid >> 2);
+      const bool on = e < n;
+      const int q = on ? list_q[e] : 0, r = on ? list_r[e] : 16;
+      const f32x4* xp = reinterpret_cast<const f32x4*>(rb + (size_t)r * Dd) + 2 * k4;
+      const f32x4* qv = reinterpret_cast<const f32x4*>(qp + (int64_t)q * Dd) + 2 * k4;
+      float a = 0.f;
+      for (int g0 = 0; g0 < G32; g0 += 8) {
+        f32x4 qq[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool in = g0 + i < G32;
+          qq[2 * i] = in ? qv[(g0 + i) * 8] : (f32x4){0.f, 0.f, 0.f, 0.f};
+          qq[2 * i + 1] = in ? qv[(g0 + i) * 8 + 1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (g0 + (i >> 1) >= G32) break;
+          const f32x4 xv = xp[(g0 + (i >> 1)) * 8 + (i & 1)];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = f_sub(qq[i][j], xv[j]);
+            a = f_add(f_mul(d, d), a);
+          }
+        }
+      }
+      const float s01 = f_add(a, __shfl_xor(a, 1, 64));            // lane 0: a0 + a1, lane 2: a2 + a3
+      const float s = f_add(s01, __shfl_xor(s01, 2, 64));          // lane 0: (a0 + a1) + (a2 + a3)
+      if (on && k4 == 0) {
+        const float dist = f_mul(0.5f, s);
+        const int oi = r == 16 ? zr : row_index[(int64_t)(t0 + t) * 16 + r];
+        atomicMin(&ebest[q], ((unsigned long long)okey32(dist) << 32) | (unsigned int)oi);
+      }
+    }
+    __syncthreads();                                                   // every quad is done with this tile's rows
+    if (t + 1 < nt) commit();                                          // (visible behind the next tile's listing barrier)
+  }
+  if (nt == 0 && zr >= 0 && band >= 0.f) {
+    // a code whose only rows are all-zero embeddings: every query is at 0.5 |q^|^2 from it - exact value by lane 0 alone
+    for (int q = tid; q < Q; q += BYC_THREADS) {
+      const float* qr = qp + (int64_t)q * Dd;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int G = 0; G < G32; ++G)
+        for (int j = 0; j < 8; ++j) {
+          const float d0 = qr[G * 32 + j], d1 = qr[G * 32 + 8 + j], d2 = qr[G * 32 + 16 + j], d3 = qr[G * 32 + 24 + j];
+          a0 = f_add(f_mul(d0, d0), a0);
+          a1 = f_add(f_mul(d1, d1), a1);
+          a2 = f_add(f_mul(d2, d2), a2);
+          a3 = f_add(f_mul(d3, d3), a3);
+        }
+      const float dist = f_mul(0.5f, f_add(f_add(a0, a1), f_add(a2, a3)));
+      ebest[q] = ((unsigned long long)okey32(dist) << 32) | (unsigned int)zr;
+    }
+    __syncthreads();
+  }
+  // (3) this code's column of the tables
+  for (int q = tid; q < Q; q += BYC_THREADS) {
+    const unsigned long long kv = ebest[q];
+    const bool have = kv != ~0ull;
+    out_dist[(int64_t)q * K + code] = have ? okey32_value((unsigned int)(kv >> 32)) : absent;
+    out_idx[(int64_t)q * K + code] = have ? (int32_t)(kv & 0xffffffffu) + idx_base : -1;
+  }
+}
+
+extern "C" int qpg_percode_select_bycode_f32(qpg_ctx* ctx, void* stream, const float* tile_min_t, const uint16_t* tile_mask_t,
+                                             int64_t ldQ, int Q, int64_t R, const int16_t* row_code,
+                                             const int32_t* row_index, const int32_t* zero_row, const int32_t* code_tile,
+                                             int K, float band, const float* qn_perm, const float* xs_perm, int Dd,
+                                             float absent, float* out_dist, int32_t* out_idx, int16_t* out_rank,
+                                             int32_t* out_nn, int32_t* stats, int32_t idx_base) {
+  const char* name = "qpg_percode_select_bycode_f32";
+  QPG_REQUIRE(ctx && tile_min_t && tile_mask_t && row_code && row_index && code_tile && qn_perm && xs_perm && out_dist && out_idx,
+              "%s: null pointer", name);
+  QPG_REQUIRE(Q >= 0 && ldQ >= Q && R > 0 && (R % 16) == 0 && R < 0x7fffffffll - 0x2000 && K > 0 && K <= 0x1fff && Dd > 0 &&
+                  (Dd % 128) == 0 && Dd <= 1024 && (reinterpret_cast<uintptr_t>(xs_perm) % 16) == 0 &&
+                  (reinterpret_cast<uintptr_t>(qn_perm) % 16) == 0 && idx_base >= 0,
+              "%s: bad size / alignment (R %% 16 == 0, D %% 128 == 0, D <= 1024)", name);
+  if (Q == 0) return QPG_OK;
+  static bool raised = false;
+  if (!raised) {
+    bool ok = true;
+#define BYC_RAISE(PT_) ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(percode_select_bycode_kernel<PT_>), \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess
+    BYC_RAISE(1); BYC_RAISE(2); BYC_RAISE(3); BYC_RAISE(4); BYC_RAISE(5); BYC_RAISE(6); BYC_RAISE(7); BYC_RAISE(8);
+#undef BYC_RAISE
+    if (!ok) {
+      qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
+      return QPG_EHIP;
+    }
+    raised = true;
+  }
+  for (int qa = 0; qa < Q; qa += BYC_QMAX) {                            // (tables of [Q][K]: a query range is a row range)
+    const int qn = Q - qa < BYC_QMAX ? Q - qa : BYC_QMAX;
+    const size_t sh = (size_t)17 * Dd * 4 + 12 * (size_t)qn + 8 * (size_t)BYC_LIST;
+    QPG_REQUIRE(sh <= 96 * 1024, "%s: LDS tables too large", name);
+#define BYC_GO(PT_) hipLaunchKernelGGL(percode_select_bycode_kernel<PT_>, dim3(K), dim3(BYC_THREADS), sh, qpg_stream(stream), \
+                                       tile_min_t + qa, tile_mask_t + qa, ldQ, qn, R, row_code, row_index, zero_row, code_tile, K, \
+                                       band, qn_perm + (int64_t)qa * Dd, xs_perm, Dd, absent, out_dist + (int64_t)qa * K,           \
+                                       out_idx + (int64_t)qa * K, stats, idx_base)
+    switch (Dd / 128) {                                                 // 16 (D / 4) / 512 units per thread
+      case 1: BYC_GO(1); break;
+      case 2: BYC_GO(2); break;
+      case 3: BYC_GO(3); break;
+      case 4: BYC_GO(4); break;
+      case 5: BYC_GO(5); break;
+      case 6: BYC_GO(6); break;
+      case 7: BYC_GO(7); break;
+      default: BYC_GO(8); break;
+    }
+#undef BYC_GO
+    QPG_LAUNCH_CHECK("percode_select_bycode_kernel");
+  }
+  if (out_rank || out_nn) {
+    hipLaunchKernelGGL(sorted_finish_kernel, dim3(Q), dim3(256), 12 * (size_t)rank_sort_pow2(K) + 4 * (size_t)K, qpg_stream(stream),
+                       (const float*)out_dist, (const int32_t*)out_idx, K, out_rank, out_nn);
+    QPG_LAUNCH_CHECK("sorted_finish_kernel");
+  }
+  return QPG_OK;
+}

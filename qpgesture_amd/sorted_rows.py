@@ -22,6 +22,23 @@ def gemm32_err(d):
     return (12 + d / 32) * U32 + 5.2e-7
 
 
+def gemm_h_err(d):
+    """A-priori bound of the round-5 prefilter GEMM on the h planes alone (hl_gemm64h_kernel): h = fl16(x 2^e) is within
+    2^-11 |x| of x in the scaled normal range (below it: 2^-25 absolute against scaled norms >= 2^14 - 4e-11), so the dropped
+    terms h l' + l h' + l l' are at most (2 x 2^-11 + 2^-22) sum |x_i||q_i| <= (2^-10 + 2^-22) |x||q| (Cauchy-Schwarz) =
+    9.8e-4 for unit vectors; + the chain of d/32 instructions in the f32 accumulator, (12 + d/32) 2^-24 as in gemm32_err;
+    + the f32 epilogue 1.2e-7."""
+    return 2.0 ** -10 + 2.0 ** -22 + (12 + d / 32) * U32 + 1.2e-7 + 1e-9
+
+
+def prefilter_band_h(d):
+    """Band of the by-code select behind the h-plane prefilter: 2.1 x (gemm_h_err + 2 eps1 + E_sk) - 2.1e-3 at d = 512
+    (prefilter_band: 8.8e-5; on BASELINE configs[2]'s rows ~12 % more pairs are listed)."""
+    eps1 = ((d / 4 + 2) / 2 + 2) * U32
+    e_sk = 0.5 * (8 * eps1 + 4 * (d / 4 + 3) * U32)
+    return 2.1 * (gemm_h_err(d) + 2 * eps1 + e_sk)
+
+
 def prefilter_band(d):
     """Band of the bounded prefilter for the exact-f32 cosine (derivation: csrc/qpg_sorted.hip): 2.1 x (E_pre + E_sk).
     eps1: relative error of an f32 sklearn-normalised element (norm^2 by 4 lane chains of d/4 squares, sqrt, divide);
@@ -39,7 +56,7 @@ class SortedRows:
     Builds: the non-zero rows - without exact duplicates of an earlier row of the same code - sorted by code (stable:
     original order inside a code = first-wins), every code's segment
     padded to 16 rows with copies of its first row (a 16-row tile of the GEMM then lies inside ONE code and a padding row
-    never lowers its minimum), the total padded to 32; `row_index` i32 [R] (original index, -1 padding), `row_code` i16 [R]
+    never lowers its minimum), the total padded to 64; `row_index` i32 [R] (original index, -1 padding), `row_code` i16 [R]
     (padding rows: bit 14 set; the tail beyond the last segment: code 0x1fff), `xs` f32 [R + 1][d] (row R: zeros), the
     split-f16 fragment image of rows [0, R), `code_tile` i32 [K + 1] (first 16-row tile of every code) and `zero_row` i32 [K]: per code the lowest original index among the rows
     the normalisation left at zero (all-zero embeddings: all at the same distance from any query, first one wins), -1."""
@@ -64,7 +81,7 @@ class SortedRows:
         pad_cnt = (cnt + 15) // 16 * 16
         start = torch.cumsum(pad_cnt, 0) - pad_cnt
         Rs = int(pad_cnt.sum().item())
-        R = max((Rs + 31) // 32 * 32, 32)
+        R = max((Rs + 63) // 64 * 64, 64)                                     # (64: hl_gemm64h_kernel's wave tiles)
         first = (torch.cumsum(cnt, 0) - cnt)                                  # position in `order` of a code's first row
         within = torch.arange(order.numel(), device=dev) - first[cd]
         pos = start[cd] + within
@@ -88,6 +105,40 @@ class SortedRows:
         # round 4: the prefilter hands the select tile minima + row masks instead of the Q x R matrix (False: the matrix,
         # as in round 3 - tests compare the two)
         self.use_masks = True
+        # round 5: batches of >= by_code_min_q queries take the h-plane prefilter + the by-code select (cfg3.CosineIndex
+        # turns it on: every row is wanted by several queries there; a clip's 48 text queries stay on the by-query select)
+        self.by_code = False
+        self.by_code_min_q = 256
+        self.band_h = float(prefilter_band_h(d))
+        self._xs_perm = None
+
+    def xs_perm(self):
+        """The rows chain-permuted for the four-lane exact evaluation (qpg_perm32_rows_f32), built on first use."""
+        if self._xs_perm is None:
+            self._xs_perm = torch.empty_like(self.xs)
+            _lib.call("qpg_perm32_rows_f32", self.device, self.xs, self.R + 1, self.d, self._xs_perm)
+        return self._xs_perm
+
+    def uses_by_code(self, Q, q_block=0):
+        return bool(self.by_code and Q >= self.by_code_min_q and self.d % 256 == 0 and q_block == 0 and self.use_masks)
+
+    def _select_by_code(self, qn, absent, stats, dist, idx, nn, rank, idx_base, sc, cols_packed):
+        dev, Q = self.device, qn.shape[0]
+        nt, ldq = self.R // 16, (Q + 15) // 16 * 16
+        if sc.get("tmin_t") is None or sc["tmin_t"].shape != (nt, ldq):
+            sc["tmin_t"] = torch.empty((nt, ldq), dtype=torch.float32, device=dev)
+            sc["tmask_t"] = torch.empty((nt, ldq), dtype=torch.int16, device=dev)
+        if sc.get("qperm") is None or sc["qperm"].shape != qn.shape:
+            sc["qperm"] = torch.empty_like(qn)
+        if not cols_packed:
+            _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, sc["cols"], sc["cols"].numel())
+        _lib.call("qpg_perm32_rows_f32", dev, qn, Q, self.d, sc["qperm"])
+        _lib.call("qpg_hl_gemm_tilemin_h", dev, self.image, self.R, self.d, sc["cols"], Q, self.band_h, sc["tmin_t"],
+                  sc["tmask_t"], ldq)
+        _lib.call("qpg_percode_select_bycode_f32", dev, sc["tmin_t"], sc["tmask_t"], ldq, Q, self.R, self.row_code,
+                  self.row_index, self.zero_row, self.code_tile, self.K, self.band_h, sc["qperm"], self.xs_perm(), self.d,
+                  absent, dist, idx, rank, nn, stats, int(idx_base))
+        return dist, idx, nn
 
     @staticmethod
     def _first_of_duplicates(xn, codes, keep):
@@ -142,6 +193,11 @@ class SortedRows:
         if sc.get("cols") is None or sc["cols"].numel() < nb:
             sc["cols"] = torch.empty((nb,), dtype=torch.uint8, device=dev)
         nt = self.R // 16
+        if self.uses_by_code(Q, q_block):
+            if dist is None:
+                dist = torch.empty((Q, self.K), dtype=torch.float32, device=dev)
+                idx = torch.empty((Q, self.K), dtype=torch.int32, device=dev)
+            return self._select_by_code(qn, absent, stats, dist, idx, nn, rank, idx_base, sc, cols_packed)
         if sc.get("tmin") is None or sc["tmin"].shape[0] < Q or sc["tmin"].shape[1] != nt:
             sc["tmin"] = torch.empty((Q, nt), dtype=torch.float32, device=dev)
             sc["tmask"] = torch.empty((Q, nt), dtype=torch.int16, device=dev)

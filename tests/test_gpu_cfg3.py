@@ -157,6 +157,7 @@ def test_cfg3_bounded_prefilter_equals_the_exact_sweep():
     rd, ri, rn = ref.query(qd)
     index = CosineIndex(X, code, valid, n_codes=K)
     assert index.method == "mfma" and index.R % 32 == 0
+    index.sorted.by_code = False       # (this test: the by-query select of rounds 3 / 4; round 5's by-code path: next test)
     fd, fi, fn = index.query(qd)
     assert index.fallbacks == 0
     assert torch.equal(fd, rd) and torch.equal(fi, ri) and torch.equal(fn, rn)
@@ -238,3 +239,100 @@ def test_cfg3_prefilter_falls_back_when_a_band_overflows():
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
     assert (got[1][:, 7].cpu().numpy() != -1).all()
+
+
+def test_cfg3_h_plane_prefilter_and_by_code_select_equal_the_exact_sweep():
+    """Round 5: batches of >= 256 queries take the prefilter on the h planes alone (one f16 MFMA per block, a-priori bound
+    sorted_rows.gemm_h_err) and the exact-order evaluations BY CODE (four lanes per pair on chain-permuted rows): the exact
+    sweep's tables bit for bit - all 1 000 queries, batch sizes around the chunk / threshold edges, a slice against the C
+    oracle; the tile minima stay inside the bound; the permutation is the one the kernel's comment states; all-zero rows,
+    exact duplicates and an overflowing pair list (fallback) on a small index."""
+    import torch
+    from oracle import cref
+    from qpgesture_amd import _lib
+    from qpgesture_amd.cfg3 import CosineIndex
+    from qpgesture_amd.sorted_rows import gemm_h_err, prefilter_band_h
+    X, code, valid, q, rows = _inputs()
+    qd = torch.from_numpy(q).cuda()
+    ref = CosineIndex(X, code, valid, n_codes=K, method="valu")
+    rd, ri, rn = ref.query(qd)
+    index = CosineIndex(X, code, valid, n_codes=K)
+    assert index.method == "mfma" and index.sorted.by_code and index.R % 64 == 0 and index.sorted.uses_by_code(Q)
+    fd, fi, fn = index.query(qd)
+    assert index.fallbacks == 0 and "tmin_t" in index._scratch
+    assert torch.equal(fd, rd) and torch.equal(fi, ri) and torch.equal(fn, rn)
+    sel = np.r_[0:3, 200:203, Q - 2:Q]
+    cm = np.where(valid, code, -1).astype(np.int32).reshape(N, 1)
+    od, oi = cref.text_scan(X.reshape(N, 1, D), [0], cm, [0], q[sel], K=K, n_threads=8)
+    assert np.array_equal(fi.cpu().numpy()[sel], oi) and np.array_equal(fd.cpu().numpy()[sel], od)
+    # the permutation: position 32 G + 8 k + j holds element 16 (2 G + (j >> 2)) + 4 (3 - (j & 3)) + k
+    xs, xp = index.sorted.xs[:64].cpu().numpy(), index.sorted.xs_perm()[:64].cpu().numpy()
+    want = xs.reshape(64, D // 32, 2, 4, 4)[:, :, :, ::-1, :].transpose(0, 1, 4, 2, 3).reshape(64, D)
+    assert np.array_equal(xp, want)
+    # tile minima of the h-plane GEMM against the exact 1 - <x^, q^> of the same (sorted) rows: inside its bound
+    qn = torch.empty_like(qd)
+    _lib.call("qpg_l2_normalize_rows_f32", qd.device, qd, Q, D, qn)
+    xsd = index.sorted.xs[:-1].double()
+    exact = (1.0 - qn[:8].double() @ xsd.T).cpu().numpy().reshape(8, -1, 16)
+    tmin_t = index._scratch["tmin_t"][:, :8].double().cpu().numpy().T                 # [8][tiles]
+    live = (index.sorted.row_code.cpu().numpy().reshape(-1, 16)[:, 0] & 0x1fff) != 0x1fff
+    err = np.abs(tmin_t - exact.min(axis=2))[:, live].max()
+    print("h-plane prefilter: max |tile min - exact tile min| = %.3g; bound %.3g; band %.3g" % (err, gemm_h_err(D), prefilter_band_h(D)))
+    assert err <= gemm_h_err(D)
+    # batch sizes: below the threshold (by-query path), at it, ragged chunks of 96
+    for nq in (95, 256, 257, 300, 999):
+        d2, i2, n2 = index.query(qd[:nq])
+        assert torch.equal(d2, rd[:nq]) and torch.equal(i2, ri[:nq]) and torch.equal(n2, rn[:nq]), nq
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    index.check_flags = False
+    index.query(qd)
+    ev[0].record()
+    for _ in range(5):
+        index.query(qd)
+    ev[1].record()
+    torch.cuda.synchronize()
+    assert int(index._stats[1].item()) == 0
+    print("cfg-3 (h-plane prefilter + by-code select): %.3f ms per 1000-query batch" % (ev[0].elapsed_time(ev[1]) / 5))
+    # a small index with all-zero rows, exact duplicates and masked rows
+    rng = np.random.Generator(np.random.PCG64(21))
+    n, k, nq = 6_000, 40, 300
+    Xs = rng.standard_normal((n, D), dtype=np.float32)
+    cs = rng.integers(0, k, size=n).astype(np.int32)
+    Xs[100:130] = 0.0                                       # all-zero embeddings (several codes)
+    Xs[2_000:2_050] = Xs[1_999]                             # exact duplicates of one row under one code
+    cs[1_999:2_050] = 5
+    vs = rng.random(n) < 0.8
+    qs = rng.standard_normal((nq, D), dtype=np.float32)
+    qs[7] = 3.0 * Xs[1_999]
+    qsd = torch.from_numpy(qs).cuda()
+    want3 = CosineIndex(Xs, cs, vs, n_codes=k, method="valu").query(qsd)
+    small = CosineIndex(Xs, cs, vs, n_codes=k)
+    assert small.sorted.uses_by_code(nq) and small.sorted.n_zero_rows > 0
+    got3 = small.query(qsd)
+    assert small.fallbacks == 0
+    for a, b in zip(got3, want3):
+        assert torch.equal(a, b)
+    # 9 000 NEAR-copies under one code.  One query next to them: 9 000 exact evaluations, no overflow (the by-code lists
+    # are per 16-row tile).  A hundred such queries: 1 600 pairs in every one of those tiles - the list overflows, the
+    # exact sweep answers.
+    n2, k2 = 20_000, 64
+    X2 = rng.standard_normal((n2, D), dtype=np.float32)
+    c2 = rng.integers(0, k2, size=n2).astype(np.int32)
+    X2[5_000:14_000] = X2[4_999] * (1.0 + 1e-7 * rng.standard_normal((9_000, D))).astype(np.float32)
+    c2[4_999:14_000] = 7
+    q2 = rng.standard_normal((nq, D), dtype=np.float32)
+    q2[3] = 1.5 * X2[4_999]
+    q2d = torch.from_numpy(q2).cuda()
+    want4 = CosineIndex(X2, c2, None, n_codes=k2, method="valu").query(q2d)
+    idx2 = CosineIndex(X2, c2, None, n_codes=k2)
+    got4 = idx2.query(q2d)
+    assert idx2.fallbacks == 0
+    for a, b in zip(got4, want4):
+        assert torch.equal(a, b)
+    q2[100:200] = X2[4_999][None, :] * rng.uniform(0.5, 2.0, size=(100, 1)).astype(np.float32)
+    q2d = torch.from_numpy(q2).cuda()
+    want5 = CosineIndex(X2, c2, None, n_codes=k2, method="valu").query(q2d)
+    got5 = idx2.query(q2d)
+    assert idx2.fallbacks == 1
+    for a, b in zip(got5, want5):
+        assert torch.equal(a, b)

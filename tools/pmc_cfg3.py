@@ -8,8 +8,8 @@ import json
 import os
 import sys
 
-STEP = ("hl_gemm32_kernel", "percode_select_sorted_kernel", "sorted_finish_kernel", "hl_pack_cols_kernel",
-        "l2_normalize_rows_kernel<false>")
+STEP = ("hl_gemm32_kernel", "percode_select_sorted_kernel", "hl_gemm64h_kernel", "percode_select_bycode_kernel", "perm32_kernel",
+        "sorted_finish_kernel", "hl_pack_cols_kernel", "l2_normalize_rows_kernel<false>")
 
 
 def per_kernel(d, name):
@@ -30,5 +30,6 @@ rec = {"per_kernel_kb": {k: {"fetch": round(fe.get(k, 0.0), 1), "write": round(w
        "hbm_bytes_per_step": int(sum(fe.values()) * 1024 * 2 + sum(wr.values()) * 1024),
        "recipe": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --workload cfg3; "
                  "per-dispatch means per kernel; bytes = FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024"}
-json.dump({"cfg3_step|100000x512 Q=1000": rec}, open(out, "w"), indent=1, sort_keys=True)
+key = "cfg3_step_bycode|100000x512 Q=1000" if fe.get("hl_gemm64h_kernel") else "cfg3_step|100000x512 Q=1000"
+json.dump({key: rec}, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(rec))

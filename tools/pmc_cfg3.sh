@@ -9,4 +9,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_cfg3.py $O $O/pmc_traffic_cfg3.json
 find $O -name "*.csv" -delete
-cat $O/FETCH_SIZE.txt | grep -i "gemm32\|sorted\|finish\|normalize\|pack_cols"; cat $O/pmc_traffic_cfg3.json
+cat $O/FETCH_SIZE.txt | grep -i "gemm\|sorted\|bycode\|perm32\|finish\|normalize\|pack_cols"; cat $O/pmc_traffic_cfg3.json

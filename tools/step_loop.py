@@ -46,7 +46,8 @@ spd = torch.from_numpy(sp).to(dev)
 from qpgesture_amd import code_knn as _ck
 mode = getattr(_ck, os.environ.get("QPG_LOOP_MODE", "MODE_AUD_TXT"))        # MODE_AUD: audio side only (measurements)
 g = knn.capture_clip_graph(M, mode=mode, audio=te_i, context=te_c, owner_blocks=knn.force_sharded, n_clips=CL,
-                           encoder=enc, encode_input=enc_x) if graph else None
+                           encoder=enc, encode_input=enc_x,
+                           encode_precision=os.environ.get("QPG_LOOP_ENC_PREC", "f32")) if graph else None
 spb = torch.from_numpy(np.tile(sp.reshape(1, -1), (CL, 1))).to(dev)
 
 
