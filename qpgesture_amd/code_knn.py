@@ -1376,22 +1376,34 @@ class ClipGraph:
         dev = knn.db.device
         ptrs = (self._seed_pin.data_ptr() + 4 * 128 * self.CL, self._seed_pin.data_ptr())
         if self.enc is not None:
-            self._enc_stream = torch.cuda.Stream(dev)
+            self._enc_stream = torch.cuda.Stream(dev, priority=int(__import__("os").environ.get("QPG_ENC_PRIO", "0")))
             self._enc_gate, self._enc_done = torch.cuda.Event(), torch.cuda.Event()
             ids_pin = self._pin[self._n_ints:self._n_ints + self._n_ids]
             flags_pin = self._pin[self._n_ints + self._n_ids:]
 
         import os as _os
-        enc_at = _os.environ.get("QPG_ENCODE_AT", "sweep_end")      # measurements: "start" = beside the whole match
+        # where the encode leg forks ("start": beside the whole match, the default; "sweep_end": behind the audio sweep;
+        # "serial": no branch).  Measured with 16 clips + 96 windows per replay (tools/r05_pass_e.sh, round 5's kernels):
+        # start 3.80 / 3.19 ms (f32 / f16x3 encode), sweep_end 3.94 / 3.44, serial 4.27 / 3.60; stream priorities on either
+        # branch only slow the step down.
+        enc_at = _os.environ.get("QPG_ENCODE_AT", "start")
 
         def encode_leg():
             # the encode leg: a branch of its own (independent work: DB-side pose windows, make_beat_dataset.py:314-316),
             # its ids narrowed to i32 and copied into the replay's pinned result block; joined in front of the walk's
             # last kernel, whose final stores (the status words, behind a system-scope fence) are what the host waits
-            # for.  It forks BEHIND the audio sweep: both are matrix-core work (forked at the start of the step the two
-            # took the sum of their times, 2.1 + 1.6 ms, and slowed each other down), whereas the selects and the walk
-            # behind the sweep are ~0.5 ms of gathers and latency-bound launches that leave the matrix pipes idle.
+            # for.  (Forked behind the audio sweep - the first arrangement - its convolutions delay the selects' blocks on
+            # the other queue by up to 0.6 ms: profiles/r05_step_timeline_c16_*.md.)
             main = torch.cuda.current_stream(dev)
+            if enc_at == "serial":                 # (measurements) no branch: the encode between the sweep and the selects
+                if self._n_flags:
+                    ids, flags = self.enc.encode_f16x3_device(self.enc_x)
+                    flags_pin.copy_(flags, non_blocking=True)
+                else:
+                    ids = self.enc.encode_fused(self.enc_x)
+                ids_pin.copy_(ids.reshape(-1).to(torch.int32), non_blocking=True)
+                self._enc_done.record(main)
+                return
             self._enc_gate.record(main)
             self._enc_stream.wait_event(self._enc_gate)
             with torch.cuda.stream(self._enc_stream):

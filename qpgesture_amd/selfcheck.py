@@ -21,6 +21,8 @@ from . import _lib
 
 KAPPA2_ASSUMED = 13.0          # what QPG_AUDIO_HL_ERR budgets for a chain of two (csrc/qpg_audio_hl.hip)
 KAPPA2_LIMIT = 12.0            # the check fails ABOVE this: one unit of slack against families the probe does not build
+KAPPA16_ASSUMED = 40.0         # a chain of <= 16 full-size blocks in one accumulator (the prefilter GEMMs): sorted_rows.gemm32_err
+KAPPA16_LIMIT = 36.0
 KAPPA6_ASSUMED = 13.05         # chains of six (audio_cosine_hl2_kernel: the four cross-term blocks first, then the two h h' blocks)
 KAPPA6_LIMIT = 12.0
 _cache = {}
@@ -109,6 +111,27 @@ def measure_kappa(device, tiles=512, seed=20260929):
             worst = max(worst, float((np.abs(run.astype(np.float64) - exact) / (2.0 ** -24 * mag)).max()))
         return worst
     k6 = cross_first(4)
+
+    # round 5: the prefilter GEMMs (hl_gemm32_kernel, hl_gemm64h_kernel) keep the h h' products of the WHOLE
+    # contraction in one accumulator - a chain of d / 32 FULL-SIZE blocks (16 at d = 512): kappa_16 in units of 2^-24 x
+    # sum |all products|, which sorted_rows.gemm32_err / gemm_h_err budget as KAPPA16_ASSUMED
+    def full_chain(n):
+        worst = 0.0
+        for rep in range(3):
+            run, exact, mag = None, 0.0, 0.0
+            for i in range(n):
+                if rep == 2 and i in (0, n - 1):
+                    a_, b_ = dominant()
+                else:
+                    a_, b_ = (np.abs(rnd()), np.abs(rnd())) if rep == 0 else (rnd(), rnd())
+                a16, b16 = np.ascontiguousarray(a_.astype(np.float16)), np.ascontiguousarray(b_.astype(np.float16))
+                run = _probe(dev, a16, b16, run)
+                A, B = a16.astype(np.float64), b16.astype(np.float64)
+                exact = exact + np.einsum("tik,tjk->tij", A, B)
+                mag = mag + np.einsum("tik,tjk->tij", np.abs(A), np.abs(B))
+            worst = max(worst, float((np.abs(run.astype(np.float64) - exact) / (2.0 ** -24 * mag)).max()))
+        return worst
+    k16 = full_chain(16)
     # round 5: the one-plane (f16 track) sweep's chains are FOUR instructions - the two l' h blocks, then the two h h' blocks
     k4 = cross_first(2)
     # f16 SUBNORMAL operands (the audio images' l planes hold them): the products must come out exact
@@ -119,7 +142,7 @@ def measure_kappa(device, tiles=512, seed=20260929):
     want = np.einsum("tik,tjk->tij", sub.astype(np.float64), big.astype(np.float64))
     sub_ok = bool(np.array_equal(got, want))
     return {"kappa": max(v[0] for v in fam.values()), "kappa2": max(v[1] for v in fam.values()), "kappa6": k6,
-            "kappa4": k4,
+            "kappa4": k4, "kappa16": k16,
             "subnormals_exact": sub_ok,
             "families": {k: [round(v[0], 3), round(v[1], 3)] for k, v in fam.items()}}
 
@@ -138,9 +161,9 @@ def mfma_bound_ok(device):
         return _cache[idx]
     rep = measure_kappa(torch.device("cuda", idx))
     rep.update(kappa2_assumed=KAPPA2_ASSUMED, kappa2_limit=KAPPA2_LIMIT, skipped=False)
-    rep.update(kappa6_assumed=KAPPA6_ASSUMED, kappa6_limit=KAPPA6_LIMIT)
+    rep.update(kappa6_assumed=KAPPA6_ASSUMED, kappa6_limit=KAPPA6_LIMIT, kappa16_assumed=KAPPA16_ASSUMED)
     ok = (rep["kappa2"] <= KAPPA2_LIMIT and rep["kappa"] <= KAPPA2_LIMIT and rep["kappa6"] <= KAPPA6_LIMIT and
-          rep["kappa4"] <= KAPPA6_LIMIT and rep["subnormals_exact"])
+          rep["kappa4"] <= KAPPA6_LIMIT and rep["kappa16"] <= KAPPA16_LIMIT and rep["subnormals_exact"])
     if not ok:
         warnings.warn("qpgesture_amd: this device's f16 matrix core measured kappa_2 = %.2f (limit %.1f), kappa_6 / kappa_4 = %.2f "
                       "(limit %.1f), f16 subnormals exact: %s - the a-priori bound of the split-f16 sweeps does not hold "

@@ -15,20 +15,24 @@ HL_GEMM_ERR = 1.3e-6          # QPG_AUDIO_HL_ERR: the split-f16 GEMM on unit-nor
 
 def gemm32_err(d):
     """A-priori bound of the round-4 prefilter GEMM (hl_gemm32_kernel: the h h' products stay in the MFMA's f32
-    accumulator over the whole K = d): every one of the d/32 chained instructions contributes its own block error
-    (kappa_1 <= 12 in units of 2^-24 sum|products|: measured 8.3-9.0, checked at load time by selfcheck.py) and one
-    rounding of the running sum, so the chain is within (12 + d/32) 2^-24 of the exact sum (|sum| <= 1 for unit vectors);
+    accumulator over the whole K = d): a chain of d/32 full-size instructions is within kappa_chain 2^-24 of the exact sum
+    relative to sum |products| (<= 1 for unit vectors).  kappa_chain: 40 for chains of up to 16 (selfcheck.KAPPA16_ASSUMED;
+    measured at load time - 21-25 on MI355X - and the prefilter is not used when the measurement exceeds its limit;
+    until round 5 this read 12 + d/32, a model the 16-instruction chain was never measured against: ADVICE r4), beyond
+    that 40 + 2 per further instruction (every instruction: at most ~1.5 units for re-rounding the running sum);
     + cross-term chains 1.0e-7, split representation 3.0e-7, f32 result 1.2e-7."""
-    return (12 + d / 32) * U32 + 5.2e-7
+    n = d / 32
+    kappa = 40.0 + 2.0 * max(0.0, n - 16)
+    return kappa * U32 + 5.2e-7
 
 
 def gemm_h_err(d):
     """A-priori bound of the round-5 prefilter GEMM on the h planes alone (hl_gemm64h_kernel): h = fl16(x 2^e) is within
     2^-11 |x| of x in the scaled normal range (below it: 2^-25 absolute against scaled norms >= 2^14 - 4e-11), so the dropped
     terms h l' + l h' + l l' are at most (2 x 2^-11 + 2^-22) sum |x_i||q_i| <= (2^-10 + 2^-22) |x||q| (Cauchy-Schwarz) =
-    9.8e-4 for unit vectors; + the chain of d/32 instructions in the f32 accumulator, (12 + d/32) 2^-24 as in gemm32_err;
+    9.8e-4 for unit vectors; + the chain of d/32 instructions in the f32 accumulator (gemm32_err's kappa_chain 2^-24);
     + the f32 epilogue 1.2e-7."""
-    return 2.0 ** -10 + 2.0 ** -22 + (12 + d / 32) * U32 + 1.2e-7 + 1e-9
+    return 2.0 ** -10 + 2.0 ** -22 + (gemm32_err(d) - 5.2e-7) + 1.2e-7 + 1e-9
 
 
 def prefilter_band_h(d):

@@ -37,6 +37,13 @@ done
 python tools/pmc_traffic.py $O audio_cosine_hl2_kernel "N_db=2048 Q=48" $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
 timeout 900 python bench.py --scaling strong --no-cpu-baseline --no-vqvae > $O/bench_strong.json 2> $O/bench_strong.err; echo "strong rc=$?" >> $O/rc.txt
 timeout 900 python bench.py --workload cfg3 > $O/bench_cfg3.json 2> $O/bench_cfg3.err; echo "cfg3 rc=$?" >> $O/rc.txt
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_cfg3 -o cfg3 -- python $R/bench.py --workload cfg3 > $R/$O/bench_cfg3_profiled.json 2> $R/$O/prof_cfg3.err )
+python tools/make_profile_summary.py $O/prof_cfg3 $O/cfg3 "python bench.py --workload cfg3 under rocprofv3 --kernel-trace --stats" > /dev/null 2>&1
+python tools/bench_cfg3_parts2.py > $O/cfg3_parts.log 2>&1
+bash tools/pmc_cfg3.sh > $O/pmc_cfg3.log 2>&1; cp gpurun_out/cfg3pmc/pmc_traffic_cfg3.json gpurun_out/cfg3pmc/FETCH_SIZE.txt gpurun_out/cfg3pmc/WRITE_SIZE.txt $O/ 2>/dev/null
+python tools/bench_decode.py > $O/decode.log 2>&1
+python tools/bench_vqvae.py > $O/vqvae.log 2>&1
+timeout 300 python tools/bench_train.py 256 > $O/bench_train.log 2>&1
 timeout 900 python bench.py --data speechlike --no-cpu-baseline --no-vqvae --no-e2e > $O/bench_speechlike.json 2> $O/bench_speechlike.err; echo "speechlike rc=$?" >> $O/rc.txt
 for sc in weak strong; do
   for lc in 1 0; do
