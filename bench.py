@@ -862,7 +862,8 @@ def main():
             "flags": st["flags"], "error_bound": 1.3e-6 if hl else 2.05e-6,
             # the one measured constant under that bound, re-measured at load time on THIS device (selfcheck.py)
             "mfma_selfcheck": {k_: db.hl_bound_report.get(k_) for k_ in ("kappa", "kappa2", "kappa2_assumed", "kappa2_limit",
-                                                                         "kappa6", "kappa4", "kappa6_assumed", "subnormals_exact",
+                                                                         "kappa6", "kappa4", "kappa6_assumed", "kappa16", "kappa16_assumed",
+                                                                         "subnormals_exact",
                                                                          "skipped")},
             "max_table_difference_vs_f64_sweep": float((Tm["aud_d"] - T64["aud_d"]).abs().max()),
             "winners_equal_f64_sweep": bool(torch.equal(Tm["aud_idx"], T64["aud_idx"])),
@@ -904,7 +905,7 @@ def main():
 def rocprof_kernel_ms(key):
     """The dominant kernel's average duration over ALL launches of a profiled run of this command - graph replays included,
     which HIP events cannot bracket - from the committed rocprofv3 --kernel-trace --stats summary (profiles/
-    kernel_replay.json, written by tools/make_profile_summary.py); null for shapes that were not profiled."""
+    kernel_replay.json, written by tools/kernel_replay.py from the pass of tools/r05_gpu_pass.sh); null for shapes that were not profiled."""
     path = os.path.join(ROOT, "profiles", "kernel_replay.json")
     if key is None or not os.path.exists(path):
         return {"kernel_ms_rocprof": None}

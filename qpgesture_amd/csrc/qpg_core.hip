@@ -13,7 +13,7 @@ void qpg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int qpg_version(void) { return 105; }          // 1.05: round 4 (qpg_clip_pack_hl, qpg_hl_gemm_tilemin, qpg_flags_*, qpg_percode_select_mixed_f64_parts, ...: include/qpg.h)
+extern "C" int qpg_version(void) { return 106; }          // 1.06: round 5 (qpg_audio_cosine_hl1, qpg_comm_*, qpg_conv16_*, qpg_hl_gemm_tilemin_h, qpg_percode_select_bycode_f32, ...: include/qpg.h)
 
 // Is HIP_FORCE_DEV_KERNARG=1 in this process's environment? (see qpg_ctx_create in include/qpg.h)
 extern "C" int qpg_dev_kernarg(void) {
