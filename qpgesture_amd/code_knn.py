@@ -286,6 +286,9 @@ class GestureDB:
             rows_n = torch.empty_like(rows_f)
             _lib.call("qpg_l2_normalize_rows_f32", dev, rows_f.contiguous(), self.Ct, self.Dt, rows_n)
             self.txt_sorted = SortedRows(rows_n, self.txt_cand_code[:self.Ct], self.K, dev)
+            # batches of >= 256 text queries (six clips or more per sweep) take the h-plane prefilter + the by-code select
+            # (round 5: every row is then wanted by several queries); a single clip's 48 queries stay on the by-query path
+            self.txt_sorted.by_code = True
             del rows_f, rows_n
         del ctx_d
 

@@ -1525,10 +1525,13 @@ __global__ __launch_bounds__(512, 2) void hl_gemm32_kernel(HlArgs a, int n_items
 // slot refilled with the same k-block of the next stage as soon as its last column tile is done.  Items, XCD-aware order
 // and the persistent blocks are hl_gemm32_kernel's.  Output: tile minima and row masks only, TILE-MAJOR
 // ([tile][a.ldT], a.ldT >= Q: the 16 queries of a column tile are one 64-byte store; the by-code select reads a tile's
-// queries contiguously).  Needs KB % 8 == 0 and an even number of 32-row groups.
+// queries contiguously).  Needs KB % 4 == 0 (D % 128 == 0) and an even number of 32-row groups.
 #define G64_KS 4
 #define G64_PD 2
-template <int CT>
+// PAIR: two stages per trip of the k loop, LDS buffer indices static (an even number of stages: D % 256 == 0, configs[2]);
+// !PAIR: one stage per trip, the buffer index carried in a register (any D % 128 == 0; hipcc's over-tight wait at the loop
+// head - see DESIGN.md 4.4 - is then paid per stage instead of per two)
+template <int CT, bool PAIR>
 __global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_items) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x G64_KS x CT x 1 KB = 48 KB
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1543,7 +1546,7 @@ __global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_item
   };
   const int it0 = vid(0);
   if (it0 < 0) return;
-  const int KB = a.KB, n_stage = KB / G64_KS;                          // (KB % 8 == 0: an even number of stages)
+  const int KB = a.KB, n_stage = KB / G64_KS;                          // (KB % 4 == 0; the LDS buffer of a stage: s & 1, dynamic)
   const int cg = lane & 15, rg = lane >> 4;
   const int e_c1 = a.meta[0];
   constexpr int stage_units = G64_KS * CT * 64;                        // h8 units per stage (h plane only)
@@ -1620,6 +1623,7 @@ __global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_item
   static_assert((2 * NS) % (G64_PD + 1) == 0 && NS % (G64_PD + 1) == 0, "the fragment ring index must be static");
 #pragma unroll
   for (int i = 0; i < G64_PD; ++i) ld_b(0, i / CT, i % CT, Bq[i]);
+  int sbuf = 0;                                                        // LDS buffer of the next stage to run
   for (int kk = 0;; ++kk) {
     const int item = vid(kk);
     if (item < 0) break;
@@ -1629,10 +1633,12 @@ __global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_item
       for (int c = 0; c < CT; ++c) hh[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nitem = vid(kk + 1) >= 0 ? vid(kk + 1) : item;          // (behind the last item: harmless re-reads)
     const Rows nxt = rows_of(nitem);
-    for (int s2 = 0; s2 < n_stage; s2 += 2) {                          // two stages per trip: buffer indices static
+    for (int s2 = 0; s2 < n_stage; s2 += PAIR ? 2 : 1) {               // ring slots and the fragment ring's indices are static
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const int s = s2 + ss;
+      for (int sp = 0; sp < (PAIR ? 2 : 1); ++sp) {
+        const int s = s2 + sp;
+        const int ss = PAIR ? sp : sbuf;                               // this stage's LDS buffer
+        if (!PAIR) sbuf ^= 1;
         const bool last_s = s + 1 == n_stage;
         load_q(last_s ? nitem : item, last_s ? 0 : s + 1);            // in flight underneath this stage's MFMAs
         // the stage's k-blocks are refilled with the same k-blocks of the next stage - of this item, or (behind its last
@@ -1649,13 +1655,13 @@ __global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_item
         for (int st = 0; st < NS; ++st) {
           const int k2 = st / CT, c = st % CT;
           h8 (&Ac)[4] = A[k2];
-          h8& Bc = Bq[(ss * NS + st) % (G64_PD + 1)];
-          h8& Bn = Bq[(ss * NS + st + G64_PD) % (G64_PD + 1)];
+          h8& Bc = Bq[st % (G64_PD + 1)];                              // (NS % (G64_PD + 1) == 0)
+          h8& Bn = Bq[(st + G64_PD) % (G64_PD + 1)];
           if (st == NS - G64_PD) {
-            store_q((ss + 1) & 1);
+            store_q(ss ^ 1);
             lds_barrier();
           }
-          if (st >= NS - G64_PD) ld_b((ss + 1) & 1, (st + G64_PD - NS) / CT, (st + G64_PD - NS) % CT, Bn);
+          if (st >= NS - G64_PD) ld_b(ss ^ 1, (st + G64_PD - NS) / CT, (st + G64_PD - NS) % CT, Bn);
           else ld_b(ss, (st + G64_PD) / CT, (st + G64_PD) % CT, Bn);
 #pragma unroll
           for (int t = 0; t < 4; ++t) hh[t][c] = mfma_h(Ac[t], Bc, hh[t][c]);
@@ -1714,8 +1720,8 @@ extern "C" int qpg_hl_gemm_tilemin_h(qpg_ctx* ctx, void* stream, const void* row
                                      int64_t ldQ) {
   const char* name = "qpg_hl_gemm_tilemin_h";
   QPG_REQUIRE(ctx && rows_image && cols_image && tile_min && tile_mask, "%s: null pointer", name);
-  QPG_REQUIRE(R > 0 && (R % 64) == 0 && R / 32 < 0x7fffffff && Q > 0 && D > 0 && (D % 256) == 0 && ldQ >= Q && band >= 0.f,
-              "%s: bad size (R %% 64 == 0, D %% 256 == 0, ldQ >= Q, band >= 0)", name);
+  QPG_REQUIRE(R > 0 && (R % 64) == 0 && R / 32 < 0x7fffffff && Q > 0 && D > 0 && (D % 128) == 0 && ldQ >= Q && band >= 0.f,
+              "%s: bad size (R %% 64 == 0, D %% 128 == 0, ldQ >= Q, band >= 0)", name);
   const int chunks = (Q + HL_GQC - 1) / HL_GQC, KB = D / 32;
   HlArgs a;
   const unsigned char* ri = static_cast<const unsigned char*>(rows_image);
@@ -1730,7 +1736,9 @@ extern "C" int qpg_hl_gemm_tilemin_h(qpg_ctx* ctx, void* stream, const void* row
   const size_t lds64 = 2 * (size_t)G64_KS * HL_CT * HL_PIECE;         // 48 KB
   static bool raised64 = false;
   if (!raised64) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hl_gemm64h_kernel<HL_CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hl_gemm64h_kernel<HL_CT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds64) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(hl_gemm64h_kernel<HL_CT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds64) != hipSuccess) {
       qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
       return QPG_EHIP;
@@ -1741,7 +1749,8 @@ extern "C" int qpg_hl_gemm_tilemin_h(qpg_ctx* ctx, void* stream, const void* row
   QPG_REQUIRE(g8 * chunks < 0x7fffffffll, "%s: too many work items", name);
   const int n_items = (int)(g8 * chunks);
   const int n_blocks = n_items < ctx->n_cu ? n_items : ctx->n_cu;
-  hipLaunchKernelGGL(hl_gemm64h_kernel<HL_CT>, dim3(n_blocks), dim3(512), lds64, qpg_stream(stream), a, n_items);
+  if ((KB / G64_KS) % 2 == 0) hipLaunchKernelGGL((hl_gemm64h_kernel<HL_CT, true>), dim3(n_blocks), dim3(512), lds64, qpg_stream(stream), a, n_items);
+  else hipLaunchKernelGGL((hl_gemm64h_kernel<HL_CT, false>), dim3(n_blocks), dim3(512), lds64, qpg_stream(stream), a, n_items);
   QPG_LAUNCH_CHECK("hl_gemm64h_kernel");
   return QPG_OK;
 }

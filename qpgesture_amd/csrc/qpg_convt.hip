@@ -563,7 +563,8 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
 // depth); nq = 0 restores the launcher's own choice.  Not thread-safe, not for production callers.
 static int g_force_nq = 0, g_force_pd = 0;
 extern "C" int qpg_debug_convt_shape(int nq, int pd) {
-  QPG_REQUIRE((nq == 0 || nq == 1 || nq == 2 || nq == 4) && (pd == 0 || pd == 4), "qpg_debug_convt_shape: nq in {0,1,2,4}, pd in {0,4}");
+  QPG_REQUIRE((nq == 0 || nq == 1 || nq == 2 || nq == 4 || nq == 8) && (pd == 0 || pd == 4),
+              "qpg_debug_convt_shape: nq in {0,1,2,4} (8: the 64 x 128 kernel whatever the size), pd in {0,4}");
   g_force_nq = nq;
   g_force_pd = pd;
   return QPG_OK;
@@ -585,7 +586,7 @@ static int convt_launch(qpg_ctx* ctx, void* stream, ConvTArgs a, int Cout_pad, i
   const bool relu_in = a.relu_in != 0;
   const int64_t M = (int64_t)a.B * a.T_out;
   // short sequences: 16-position x 64-channel blocks whose waves split the contraction (see convt_small_f32_kernel)
-  if (((M + CT_ROWS - 1) / CT_ROWS) * (Cout_pad / 128) * 2 * nz < 3 * (int64_t)ctx->n_cu) {
+  if (g_force_nq != 8 && ((M + CT_ROWS - 1) / CT_ROWS) * (Cout_pad / 128) * 2 * nz < 3 * (int64_t)ctx->n_cu) {
     // Channels per block: 64, 32 or 16 (NQ = 4, 2, 1 tiles).  A block's time is the time ONE CU needs to pull its
     // operands (NQ weight tiles + 1 activation tile of 16 x K floats; two blocks on one CU take twice as long, so a
     // launch takes ceil(blocks / CUs) block times): pick the NQ with the smallest product.  tools/bench_convt_small.py
@@ -602,7 +603,7 @@ static int convt_launch(qpg_ctx* ctx, void* stream, ConvTArgs a, int Cout_pad, i
     }
     const int per = (a.nstage * 4 + CTS_NW - 1) / CTS_NW;          // 16-k blocks per wave
     int pd = (a.nstage * 4) % CTS_NW == 0 && per % 4 == 0 ? 4 : 0;   // ring of 4 (a ring of 6 measured ~6% slower)
-    if (g_force_nq) {                                               // tools/bench_convt_small.py (qpg_debug_convt_shape)
+    if (g_force_nq && g_force_nq != 8) {                            // tools/bench_convt_small.py (qpg_debug_convt_shape)
       if (g_force_pd == 0 || (g_force_pd == 4 && (a.nstage * 4) % CTS_NW == 0 && per % 4 == 0)) {
         nq = g_force_nq;
         pd = g_force_pd;

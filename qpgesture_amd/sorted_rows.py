@@ -124,7 +124,7 @@ class SortedRows:
         return self._xs_perm
 
     def uses_by_code(self, Q, q_block=0):
-        return bool(self.by_code and Q >= self.by_code_min_q and self.d % 256 == 0 and q_block == 0 and self.use_masks)
+        return bool(self.by_code and Q >= self.by_code_min_q and self.d % 128 == 0 and q_block == 0 and self.use_masks)
 
     def _select_by_code(self, qn, absent, stats, dist, idx, nn, rank, idx_base, sc, cols_packed):
         dev, Q = self.device, qn.shape[0]

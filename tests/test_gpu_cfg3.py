@@ -312,6 +312,17 @@ def test_cfg3_h_plane_prefilter_and_by_code_select_equal_the_exact_sweep():
     assert small.fallbacks == 0
     for a, b in zip(got3, want3):
         assert torch.equal(a, b)
+    # D = 384 (the matcher's text width: three stages of four k-blocks - the one-stage-per-trip form of the GEMM)
+    X3 = rng.standard_normal((30_000, 384), dtype=np.float32)
+    c3 = rng.integers(0, 128, size=30_000).astype(np.int32)
+    q3 = torch.from_numpy(rng.standard_normal((400, 384), dtype=np.float32)).cuda()
+    want6 = CosineIndex(X3, c3, None, n_codes=128, method="valu").query(q3)
+    i384 = CosineIndex(X3, c3, None, n_codes=128)
+    assert i384.sorted.uses_by_code(400)
+    got6 = i384.query(q3)
+    assert i384.fallbacks == 0
+    for a, b in zip(got6, want6):
+        assert torch.equal(a, b)
     # 9 000 NEAR-copies under one code.  One query next to them: 9 000 exact evaluations, no overflow (the by-code lists
     # are per 16-row tile).  A hundred such queries: 1 600 pairs in every one of those tiles - the list overflows, the
     # exact sweep answers.
