@@ -18,6 +18,8 @@ t0 = time.time()
 for t in range(trials):
     N = int(rs.choice([rs.randint(20, 200), rs.randint(300, 900), rs.randint(900, 2100)]))
     M = int(rs.randint(1, 7)) * int(rs.randint(1, 4))
+    if t % 3 == 2:                                                         # round 5: >= 256 queries take the h-plane prefilter + by-code select
+        M = int(rs.randint(32, 61))
     tr = synth.make_db(N, int(rs.randint(0, 10000)))
     ctx = np.ascontiguousarray(tr["context"].squeeze(2))                   # (N, 30, 384)
     code = synth.make_codes(N, int(rs.randint(0, 10000)))
@@ -67,8 +69,9 @@ for t in range(trials):
     codes_ok = np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     ok = codes_ok and (tables_ok or (b[5] & (1 | 16))) and a[5] == 0
     bad += not ok
-    print("trial %2d N=%4d M=%2d kind=%d kept %6d of %6d rows, %3d zero  flags=%d rematched=%d  %s"
-          % (t, N, M, kind, db.txt_sorted.n_rows_kept, N * 26, db.txt_sorted.n_zero_rows, b[5], b[6],
+    print("trial %2d N=%4d M=%2d%s kind=%d kept %6d of %6d rows, %3d zero  flags=%d rematched=%d  %s"
+          % (t, N, M, " (by code)" if db.txt_sorted.uses_by_code(8 * M) else "", kind, db.txt_sorted.n_rows_kept, N * 26,
+             db.txt_sorted.n_zero_rows, b[5], b[6],
              "ok" if ok else "MISMATCH (codes %s, tables %s)" % (codes_ok, tables_ok)), flush=True)
     del db
     torch.cuda.empty_cache()
