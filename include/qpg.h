@@ -575,6 +575,10 @@ int qpg_convt_pair_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, 
 /* Measurement hook (tools/bench_convt_small.py): force the short-sequence kernel's block shape - nq in {1, 2, 4}
  * channel tiles of 16, pd in {0, 4} fragment-ring depth; nq = 0 restores the launcher's own choice.  Process-wide. */
 int qpg_debug_convt_shape(int nq, int pd);
+/* Measurement hook (tools/bench_decode.py, round 5): deep_ring = a wave's whole share of 8 / 12 k-blocks requested up front
+ * (k3 / up-convolution layers), xcd_map = a channel group's blocks all on one XCD.  Both measured (slower / no
+ * difference: csrc/qpg_convt.hip) and OFF by default.  Process-wide. */
+int qpg_debug_convt_opts(int deep_ring, int xcd_map);
 /* T-pack of a convolution's weights on the device: w [dev] f32 [taps x Cin_pad][Cout_pad] (qpg_conv1d_f32's layout, the one
  * the optimiser updates) -> out [dev] f32, the wt of qpg_convt_f32 (nb = 128) or one half of qpg_resblock_f32's wpack
  * (nb = 512 for the dilated convolution): taps x Cin_pad x (Cout_pad rounded up to nb) floats. */

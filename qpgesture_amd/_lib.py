@@ -189,6 +189,7 @@ def load():
     lib.qpg_comm_create.argtypes = [c_void_p, ctypes.c_char_p, c_int64, c_int, c_int, ctypes.POINTER(c_void_p)]
     lib.qpg_comm_destroy.argtypes = [c_void_p]
     lib.qpg_debug_convt_shape.argtypes = [c_int, c_int]
+    lib.qpg_debug_convt_opts.argtypes = [c_int, c_int]
     lib.qpg_vq_reduce_ws_bytes.argtypes = []
     lib.qpg_vq_reduce_ws_bytes.restype = c_int64
     for name, sig in _SIGS.items():

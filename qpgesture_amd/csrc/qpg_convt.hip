@@ -298,6 +298,10 @@ struct ConvTArgs {
   const float* wt1;
   const float* bias1;
   int in_offset1, out_offset1;
+  int xcd_map;         // convt_small_f32_kernel: 1-D grid, block -> (position tile, channel group, parity) with a channel
+                       // group's blocks all on ONE XCD (workgroup L runs on XCD L % 8): an XCD's L2 then holds 1/8 of a
+                       // layer's weights instead of all of them
+  int P, C, nz;        // (xcd_map) position tiles, channel groups, parities
 };
 
 template <bool RELU_IN>
@@ -443,17 +447,25 @@ __global__ __launch_bounds__(256, 2) void convt_f32_kernel(ConvTArgs a) {
 template <bool RELU_IN, int PD, int NQ>
 __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs a) {
   // (uniform per block) which of the two parity halves this block computes
-  const float* const wt_sel = blockIdx.z ? a.wt1 : a.wt;
-  const float* const bias_sel = blockIdx.z ? a.bias1 : a.bias;
-  const int in_offset = blockIdx.z ? a.in_offset1 : a.in_offset;
-  const int out_offset = blockIdx.z ? a.out_offset1 : a.out_offset;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd_map) {
+    const int L = (int)blockIdx.x, xcd = L & 7, i = L >> 3, pz = a.P * a.nz;
+    by = (i / pz) * 8 + xcd;
+    const int rem = i % pz;
+    bz = rem / a.P;
+    bx = rem % a.P;
+  }
+  const float* const wt_sel = bz ? a.wt1 : a.wt;
+  const float* const bias_sel = bz ? a.bias1 : a.bias;
+  const int in_offset = bz ? a.in_offset1 : a.in_offset;
+  const int out_offset = bz ? a.out_offset1 : a.out_offset;
   __shared__ __attribute__((aligned(16))) float part[CTS_NW][NQ][64][4];    // [wave][tile][lane][r]
   const int tid = threadIdx.x, lane = tid & 63, ml = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t M = (int64_t)a.B * a.T_out;
-  const int64_t m = (int64_t)blockIdx.x * 16 + ml;
+  const int64_t m = (int64_t)bx * 16 + ml;
   constexpr int NGRP = 8 / NQ;                                         // channel groups per 128-channel T-pack block
-  const int nb = blockIdx.y / NGRP, cg0 = (blockIdx.y % NGRP) * (16 * NQ);
+  const int nb = by / NGRP, cg0 = (by % NGRP) * (16 * NQ);
   if (nb * 128 + cg0 >= a.Cout) return;                                // padding-only chunk (135-channel output layer)
   const bool live = m < M;
   const int b = live ? (int)(m / a.T_out) : 0;
@@ -559,6 +571,19 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
   }
 }
 
+// Measurement hook (tools/bench_decode.py): deep = every k-block of a wave's share requested up front when the share is 8 or 12
+// k-blocks (a k3 / k2-pair layer: one round trip to the weights instead of three / two), xcd = the XCD-aware block mapping.
+// Round 5, a 24 s clip's decode on one box, alternating: neither 0.281-0.289 ms; deep ring 0.325-0.332 (SLOWER: these
+// layers are bound by the rate at which ~190-720 blocks pull their tiles out of L2, not by round trips - more requests
+// in flight only lengthen every queue, and 176 VGPRs halve the waves per SIMD); XCD map 0.285-0.290 (no difference: a
+// layer's 1-4 MB of weights fit every XCD's L2 anyway).  Both stay OFF.
+static int g_deep_ring = 0, g_xcd_map = 0;
+extern "C" int qpg_debug_convt_opts(int deep_ring, int xcd_map) {
+  g_deep_ring = deep_ring != 0;
+  g_xcd_map = xcd_map != 0;
+  return QPG_OK;
+}
+
 // Measurement hook: force the short-sequence kernel's block shape (nq in {1, 2, 4} channel tiles, pd in {0, 4} ring
 // depth); nq = 0 restores the launcher's own choice.  Not thread-safe, not for production callers.
 static int g_force_nq = 0, g_force_pd = 0;
@@ -603,15 +628,20 @@ static int convt_launch(qpg_ctx* ctx, void* stream, ConvTArgs a, int Cout_pad, i
     }
     const int per = (a.nstage * 4 + CTS_NW - 1) / CTS_NW;          // 16-k blocks per wave
     int pd = (a.nstage * 4) % CTS_NW == 0 && per % 4 == 0 ? 4 : 0;   // ring of 4 (a ring of 6 measured ~6% slower)
+    if (g_deep_ring && pd == 4 && ((per == 12 && nq <= 2) || per == 8)) pd = per;      // the whole share in flight
     if (g_force_nq && g_force_nq != 8) {                            // tools/bench_convt_small.py (qpg_debug_convt_shape)
       if (g_force_pd == 0 || (g_force_pd == 4 && (a.nstage * 4) % CTS_NW == 0 && per % 4 == 0)) {
         nq = g_force_nq;
         pd = g_force_pd;
       }
     }
-    const dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / (16 * nq)), (unsigned)nz);
+    dim3 sgrid((unsigned)((M + 15) / 16), (unsigned)(Cout_pad / (16 * nq)), (unsigned)nz);
+    a.P = (int)sgrid.x; a.C = (int)sgrid.y; a.nz = nz;
+    a.xcd_map = (g_xcd_map && a.C % 8 == 0 && (int64_t)a.P * a.C * nz < 0x7fffffffll) ? 1 : 0;
+    if (a.xcd_map) sgrid = dim3((unsigned)(a.P * a.C * nz));
 #define CTS_LAUNCH(R, P, Q_) hipLaunchKernelGGL((convt_small_f32_kernel<R, P, Q_>), sgrid, dim3(64 * CTS_NW), 0, qpg_stream(stream), a)
-#define CTS_LAUNCH_P(R, Q_) do { if (pd == 4) CTS_LAUNCH(R, 4, Q_); else CTS_LAUNCH(R, 0, Q_); } while (0)
+#define CTS_LAUNCH_P(R, Q_) do { if (pd == 12 && Q_ <= 2) CTS_LAUNCH(R, (Q_ <= 2 ? 12 : 4), Q_); else if (pd == 8) CTS_LAUNCH(R, 8, Q_); \
+                                 else if (pd == 4) CTS_LAUNCH(R, 4, Q_); else CTS_LAUNCH(R, 0, Q_); } while (0)
     if (relu_in) {
       if (nq == 1) CTS_LAUNCH_P(true, 1); else if (nq == 2) CTS_LAUNCH_P(true, 2); else CTS_LAUNCH_P(true, 4);
     } else {
@@ -661,6 +691,7 @@ extern "C" int qpg_convt_f32(qpg_ctx* ctx, void* stream, const float* x, int B, 
   a.T_y = T_y; a.Cout = Cout; a.relu_in = relu_in; a.relu_out = relu_out; a.nstage = taps * Cin_pad / 64;
   a.zeros = ctx->zeros;
   a.wt1 = wt; a.bias1 = bias; a.in_offset1 = in_offset; a.out_offset1 = out_offset;
+  a.xcd_map = 0; a.P = a.C = 0; a.nz = 1;
   return convt_launch(ctx, stream, a, Cout_pad, 1);
 }
 
@@ -682,6 +713,7 @@ extern "C" int qpg_convt_pair_f32(qpg_ctx* ctx, void* stream, const float* x, in
   a.T_y = T_y; a.Cout = Cout; a.relu_in = 0; a.relu_out = 0; a.nstage = taps * Cin_pad / 64;
   a.zeros = ctx->zeros;
   a.wt1 = wt1; a.bias1 = bias1; a.in_offset1 = in_offset1; a.out_offset1 = out_offset1;
+  a.xcd_map = 0; a.P = a.C = 0; a.nz = 2;
   return convt_launch(ctx, stream, a, Cout_pad, 2);
 }
 

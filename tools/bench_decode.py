@@ -26,6 +26,15 @@ def t(fn, n=50):
     return ms[0], ms[len(ms) // 2]
 
 
+from qpgesture_amd import _lib
+lib = _lib.load()
+ref = m.decode([ids]).clone()
+for deep, xcd in ((0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (1, 1)):
+    lib.qpg_debug_convt_opts(deep, xcd)
+    out = m.decode([ids])
+    print("deep_ring=%d xcd_map=%d: decode 24 s clip min %.3f median %.3f ms; max |out - first| = %.3g"
+          % ((deep, xcd) + t(lambda: m.decode([ids])) + (float((out - ref).abs().max()),)))
+lib.qpg_debug_convt_opts(0, 0)
 print("decode 24 s clip: min %.3f median %.3f ms" % t(lambda: m.decode([ids])))
 print("encode 1 window:  min %.3f median %.3f ms" % t(lambda: m.encode(x1)))
 for L in (30, 60, 720):
