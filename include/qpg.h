@@ -278,6 +278,9 @@ int qpg_hl_gemm_tilemin(qpg_ctx*, void* stream, const void* rows_image, int64_t 
 int qpg_hl_gemm_tilemin_h(qpg_ctx*, void* stream, const void* rows_image, int64_t R, int D, const void* cols_image, int Q,
                           float band, float* tile_min_t, uint16_t* tile_mask_t, int64_t ldQ);
 int qpg_perm32_rows_f32(qpg_ctx*, void* stream, const float* x, int64_t R, int D, float* y);
+/* Measurement hook: waves per block of qpg_hl_gemm_tilemin_h's kernel - 4 (two blocks per CU: one block's epilogue under the
+ * other's MFMAs; the default) or 8 (one block per CU).  Process-wide. */
+int qpg_debug_gemm64_waves(int nw);
 int qpg_percode_select_bycode_f32(qpg_ctx*, void* stream, const float* tile_min_t, const uint16_t* tile_mask_t, int64_t ldQ,
                                   int Q, int64_t R, const int16_t* row_code, const int32_t* row_index,
                                   const int32_t* zero_row, const int32_t* code_tile, int K, float band,

@@ -1531,8 +1531,11 @@ __global__ __launch_bounds__(512, 2) void hl_gemm32_kernel(HlArgs a, int n_items
 // PAIR: two stages per trip of the k loop, LDS buffer indices static (an even number of stages: D % 256 == 0, configs[2]);
 // !PAIR: one stage per trip, the buffer index carried in a register (any D % 128 == 0; hipcc's over-tight wait at the loop
 // head - see DESIGN.md 4.4 - is then paid per stage instead of per two)
-template <int CT, bool PAIR>
-__global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_items) {
+// NW: waves per block (= 64-row groups per item).  8: one block per CU; 4: TWO blocks per CU, so that the two waves of a SIMD
+// belong to different blocks and one's epilogue (~2 800 issue cycles per item against 6 144 cycles of MFMAs) runs under the
+// other's MFMAs - with eight waves per block both waves of a SIMD reach their epilogues together.
+template <int CT, bool PAIR, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_items) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x G64_KS x CT x 1 KB = 48 KB
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);              // (scalar: the rows' base addresses stay in SGPRs)
@@ -1550,13 +1553,14 @@ __global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_item
   const int cg = lane & 15, rg = lane >> 4;
   const int e_c1 = a.meta[0];
   constexpr int stage_units = G64_KS * CT * 64;                        // h8 units per stage (h plane only)
-  constexpr int QLD = stage_units / 512;
-  static_assert(stage_units % 512 == 0, "a stage is a whole number of 16-byte units per thread");
+  constexpr int NT = 64 * NW;
+  constexpr int QLD = stage_units / NT;
+  static_assert(stage_units % NT == 0, "a stage is a whole number of 16-byte units per thread");
   h8 qreg[QLD];
   uint32_t qoff[QLD];                                                  // (v / 64) * 2 KB + (v % 64) * 16 B: the h piece's unit
 #pragma unroll
   for (int u = 0; u < QLD; ++u) {
-    const uint32_t v = (uint32_t)(u * 512 + tid);
+    const uint32_t v = (uint32_t)(u * NT + tid);
     qoff[u] = (v >> 6) * 2048u + (v & 63u) * 16u;
   }
   auto load_q = [&](int item, int s) {                                 // the h pieces of the stage's (k-block, column tile)s
@@ -1568,7 +1572,7 @@ __global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_item
   auto store_q = [&](int buf) {
     h8* dst = reinterpret_cast<h8*>(lds) + buf * stage_units;
 #pragma unroll
-    for (int u = 0; u < QLD; ++u) dst[u * 512 + tid] = qreg[u];
+    for (int u = 0; u < QLD; ++u) dst[u * NT + tid] = qreg[u];
   };
   auto lds_barrier = [&]() {                 // LDS-only: the rows' fragment loads stay in flight across it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1588,9 +1592,9 @@ __global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_item
   auto rows_of = [&](int item) {
     Rows r;
 #ifdef G64_DUP                                  /* experiment: waves w and w + 4 read the SAME rows (L1 hits: is the kernel L2-bound?) */
-    r.jj = (item / a.chunks) * 8 + (w & 3);
+    r.jj = (item / a.chunks) * NW + (w & 3);
 #else
-    r.jj = (item / a.chunks) * 8 + w;
+    r.jj = (item / a.chunks) * NW + w;
 #endif
     r.ok = 2 * r.jj < a.N;
     r.base = r.ok ? (gbytes_t)(reinterpret_cast<const unsigned char*>(a.db) + (int64_t)r.jj * 4 * KB * 2048)
@@ -1715,6 +1719,14 @@ __global__ __launch_bounds__(512, 2) void hl_gemm64h_kernel(HlArgs a, int n_item
 
 // The h-plane prefilter (hl_gemm64h_kernel): tile minima + row masks, TILE-MAJOR: tile_min / tile_mask [R / 16][ldQ],
 // ldQ >= Q.  `band` must cover QPG_HL_GEMM_H_ERR (sorted_rows.gemm_h_err).  Needs D % 256 == 0 and R % 64 == 0.
+// Measurement hook: waves per block of hl_gemm64h_kernel (8: one block per CU; 4: two).  Process-wide.
+static int g_gemm64_nw = 4;
+extern "C" int qpg_debug_gemm64_waves(int nw) {
+  QPG_REQUIRE(nw == 4 || nw == 8, "qpg_debug_gemm64_waves: 4 or 8");
+  g_gemm64_nw = nw;
+  return QPG_OK;
+}
+
 extern "C" int qpg_hl_gemm_tilemin_h(qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,
                                      const void* cols_image, int Q, float band, float* tile_min, uint16_t* tile_mask,
                                      int64_t ldQ) {
@@ -1736,21 +1748,28 @@ extern "C" int qpg_hl_gemm_tilemin_h(qpg_ctx* ctx, void* stream, const void* row
   const size_t lds64 = 2 * (size_t)G64_KS * HL_CT * HL_PIECE;         // 48 KB
   static bool raised64 = false;
   if (!raised64) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hl_gemm64h_kernel<HL_CT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds64) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(hl_gemm64h_kernel<HL_CT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds64) != hipSuccess) {
+    bool ok = true;
+#define G64_RAISE(P_, W_) ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(hl_gemm64h_kernel<HL_CT, P_, W_>), \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64) == hipSuccess
+    G64_RAISE(true, 8); G64_RAISE(false, 8); G64_RAISE(true, 4); G64_RAISE(false, 4);
+#undef G64_RAISE
+    if (!ok) {
       qpg_set_error("%s: cannot raise the dynamic LDS limit", name);
       return QPG_EHIP;
     }
     raised64 = true;
   }
-  const int64_t g8 = (R / 64 + 7) / 8;                                 // row blocks of 8 x 64 rows
+  const int nw = g_gemm64_nw;                                          // waves per block: 4 (two blocks per CU) or 8
+  const int64_t g8 = (R / 64 + nw - 1) / nw;                           // row blocks of nw x 64 rows
   QPG_REQUIRE(g8 * chunks < 0x7fffffffll, "%s: too many work items", name);
   const int n_items = (int)(g8 * chunks);
-  const int n_blocks = n_items < ctx->n_cu ? n_items : ctx->n_cu;
-  if ((KB / G64_KS) % 2 == 0) hipLaunchKernelGGL((hl_gemm64h_kernel<HL_CT, true>), dim3(n_blocks), dim3(512), lds64, qpg_stream(stream), a, n_items);
-  else hipLaunchKernelGGL((hl_gemm64h_kernel<HL_CT, false>), dim3(n_blocks), dim3(512), lds64, qpg_stream(stream), a, n_items);
+  const int slots = ctx->n_cu * (8 / nw);
+  const int n_blocks = n_items < slots ? n_items : slots;
+  const bool pair = (KB / G64_KS) % 2 == 0;
+#define G64_GO(P_, W_) hipLaunchKernelGGL((hl_gemm64h_kernel<HL_CT, P_, W_>), dim3(n_blocks), dim3(64 * W_), lds64, qpg_stream(stream), a, n_items)
+  if (nw == 8) { if (pair) G64_GO(true, 8); else G64_GO(false, 8); }
+  else { if (pair) G64_GO(true, 4); else G64_GO(false, 4); }
+#undef G64_GO
   QPG_LAUNCH_CHECK("hl_gemm64h_kernel");
   return QPG_OK;
 }

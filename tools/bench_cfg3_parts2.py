@@ -24,6 +24,18 @@ steps = [
  ("gemm64h", lambda: _lib.call("qpg_hl_gemm_tilemin_h", dev, sr.image, sr.R, d, sc["cols"], Q, sr.band_h, sc["tmin_t"], sc["tmask_t"], ldq)),
  ("select+finish", lambda: _lib.call("qpg_percode_select_bycode_f32", dev, sc["tmin_t"], sc["tmask_t"], ldq, Q, sr.R, sr.row_code, sr.row_index, sr.zero_row, sr.code_tile, sr.K, sr.band_h, sc["qperm"], sr.xs_perm(), d, ABSENT, dist, idx, None, nn, ix._stats, 0)),
 ]
+lib = _lib.load()
+for nw in (8, 4, 8, 4):
+    lib.qpg_debug_gemm64_waves(nw)
+    fn = steps[3][1]
+    for _ in range(3): fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    print("gemm64h, %d waves per block: min %.1f med %.1f us" % (nw, ts[0] * 1e3, ts[10] * 1e3))
+lib.qpg_debug_gemm64_waves(4)
 for name, fn in steps:
     for _ in range(3): fn()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
