@@ -139,7 +139,30 @@ def enable_lib_collectives(device, group=None):
     LibComm, or raises - the caller decides whether torch.distributed stays the transport (bench.py records the reason)."""
     global _libcomm
     if _libcomm is None:
-        _libcomm = LibComm(device, group)
+        # The bring-up (ncclCommInitRank: a rendezvous of all ranks) runs in a helper thread with a deadline: a rank whose
+        # rendezvous never completes reports a failure instead of hanging the job, and the caller's agreement step (bench.py:
+        # a MIN all-reduce of the ranks' verdicts over torch.distributed) then puts EVERY rank on the torch.distributed
+        # transport.  W > 1 over xGMI has never been run here (no multi-GPU box behind gpurun): this is the seat belt.
+        import os
+        import threading
+        box = {}
+
+        def bring_up():
+            try:
+                torch.cuda.set_device(torch.device(device))      # (the current device is per thread: the id's broadcast
+                box["comm"] = LibComm(device, group)             # over an nccl group stages through it)
+            except Exception as e:                 # noqa: BLE001 (re-raised on the caller's thread)
+                box["err"] = e
+
+        deadline = float(os.environ.get("QPG_LIB_COLLECTIVES_TIMEOUT_S", "120"))
+        th = threading.Thread(target=bring_up, name="qpg-libcomm-init", daemon=True)
+        th.start()
+        th.join(deadline)
+        if th.is_alive():
+            raise TimeoutError("LibComm: the RCCL rendezvous did not complete within %.0f s" % deadline)
+        if "err" in box:
+            raise box["err"]
+        _libcomm = box["comm"]
     return _libcomm
 
 
