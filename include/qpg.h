@@ -507,6 +507,10 @@ int qpg_match_steps_batch(qpg_ctx*, void* stream, const int16_t* aud_rank, const
                           int n_chains, const int32_t* seed_codes, const float* seed_phase, int32_t* gate_tables,
                           int32_t* out_codes, float* out_phase, int32_t* out_vote, int32_t* out_status,
                           int64_t status_stride, const int32_t* guard_flags);
+/* Measurement / test hook: from how many chains per launch qpg_match_steps_batch deduplicates the gate table by the previous
+ * step's winner (one evaluation per DISTINCT winner instead of one per (previous code, vote) state; same table, bit for
+ * bit).  Default 4; 0: never.  Process-wide. */
+int qpg_debug_gate_dedup(int from_chains);
 
 /* ------------------------------------------------------------------------------------------
  * Library-owned collectives of the row-sharded matcher (round 5).  The reference has no

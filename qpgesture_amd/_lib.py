@@ -191,6 +191,7 @@ def load():
     lib.qpg_debug_convt_shape.argtypes = [c_int, c_int]
     lib.qpg_debug_convt_opts.argtypes = [c_int, c_int]
     lib.qpg_debug_gemm64_waves.argtypes = [c_int]
+    lib.qpg_debug_gate_dedup.argtypes = [c_int]
     lib.qpg_vq_reduce_ws_bytes.argtypes = []
     lib.qpg_vq_reduce_ws_bytes.restype = c_int64
     for name, sig in _SIGS.items():

@@ -460,31 +460,11 @@ __device__ __forceinline__ const float* cand_block(const TailArgs& A, int which,
   return A.phase + ((int64_t)j * A.Tp + ps) * 16;
 }
 
-__global__ __launch_bounds__(256) void gate_table_kernel(TailArgs A, GateGeom geo, uint16_t* __restrict__ Gt) {
-  const int K = A.K, Qc = A.M * A.steps, Q = Qc * A.n_chains;
-  const int lane = threadIdx.x & 63;
+// One gate evaluation by 8 lanes (k = which candidate of the pair, l = einsum lane): the state's previous phase block
+// `prev` (128 floats) and previous code p -> (p << 1) | vote.  Every lane of the group returns the same value.
+__device__ __forceinline__ unsigned int gate_eval(const TailArgs& A, int q, int p, const float* prev, int lane) {
+  const int K = A.K;
   const int k = (lane >> 2) & 1, l = lane & 3;
-  const int64_t task = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;          // (q, sigma)
-  const int64_t n_task = (int64_t)Q * 2 * K;
-  const bool live = task < n_task;
-  const int q = live ? (int)(task / (2 * K)) : 0;
-  const int sigma = live ? (int)(task - (int64_t)q * 2 * K) : 0;
-  const int chain = q / Qc;
-  const bool first = q == chain * Qc;                   // a chain's first step: the seed's state only
-  if (first && sigma != 0) return;                      // uniform per 8-lane group; the shuffles below are group-local
-  const int s = q % A.steps;
-  int p;
-  const float* prev;                                    // 128 floats: the previous phase block
-  if (first) {
-    p = A.seed_codes ? A.seed_codes[chain] : A.seed_code;
-    prev = A.seed_phase + (int64_t)chain * 128;
-  } else {
-    const int pp = sigma >> 1, kp = sigma & 1;
-    const int ci = (kp ? A.T1 : A.T0)[(int64_t)(q - 1) * K + pp];
-    int pb;
-    prev = cand_block(A, kp, ci, &pb) + 384;            // rows [ps+24, ps+32): the winner's last 8 frames
-    p = A.code[pb + (s == 0 ? geo.off_last : A.step_codes - 1)];
-  }
   const int ck = (k ? A.T1 : A.T0)[(int64_t)q * K + p];
   int pb_unused;
   const float* head = cand_block(A, k, ck, &pb_unused);
@@ -524,7 +504,108 @@ __global__ __launch_bounds__(256) void gate_table_kernel(TailArgs A, GateGeom ge
   const float other = __shfl_xor(score, 4, 64);
   const float s0 = k ? other : score, s1 = k ? score : other;
   const int fi = (s1 < s0) ? 1 : 0;                     // list.index(min): first on ties
-  if (live && (lane & 7) == 0) Gt[task] = (uint16_t)((p << 1) | fi);
+  return (unsigned int)((p << 1) | fi);
+}
+
+// previous phase block and previous code of the state "candidate ci of table kp won step q - 1" (s: step inside the window)
+__device__ __forceinline__ const float* gate_prev(const TailArgs& A, const GateGeom& geo, int s, int kp, int ci, int* p) {
+  int pb;
+  const float* prev = cand_block(A, kp, ci, &pb) + 384;   // rows [ps+24, ps+32): the winner's last 8 frames
+  *p = A.code[pb + (s == 0 ? geo.off_last : A.step_codes - 1)];
+  return prev;
+}
+
+__global__ __launch_bounds__(256) void gate_table_kernel(TailArgs A, GateGeom geo, uint16_t* __restrict__ Gt) {
+  const int K = A.K, Qc = A.M * A.steps, Q = Qc * A.n_chains;
+  const int lane = threadIdx.x & 63;
+  const int64_t task = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;          // (q, sigma)
+  const int64_t n_task = (int64_t)Q * 2 * K;
+  const bool live = task < n_task;
+  const int q = live ? (int)(task / (2 * K)) : 0;
+  const int sigma = live ? (int)(task - (int64_t)q * 2 * K) : 0;
+  const int chain = q / Qc;
+  const bool first = q == chain * Qc;                   // a chain's first step: the seed's state only
+  if (first && sigma != 0) return;                      // uniform per 8-lane group; the shuffles below are group-local
+  const int s = q % A.steps;
+  int p;
+  const float* prev;                                    // 128 floats: the previous phase block
+  if (first) {
+    p = A.seed_codes ? A.seed_codes[chain] : A.seed_code;
+    prev = A.seed_phase + (int64_t)chain * 128;
+  } else {
+    const int pp = sigma >> 1, kp = sigma & 1;
+    const int ci = (kp ? A.T1 : A.T0)[(int64_t)(q - 1) * K + pp];
+    prev = gate_prev(A, geo, s, kp, ci, &p);
+  }
+  const unsigned int g = gate_eval(A, q, p, prev, lane);
+  if (live && (lane & 7) == 0) Gt[task] = (uint16_t)g;
+}
+
+// The same table for MANY chains per launch (round 5; 16 clips: 24 576 blocks of the kernel above fill the chip and the
+// table takes 190-200 us).  A state's gate depends on (previous code pp, vote kp) only through the candidate that won step
+// q - 1, ci = T_kp[q - 1][pp] - and the 2 K states of a step share a few dozen to a few hundred distinct winners.  Block =
+// one step q: the states' winners go into an LDS hash table (key = (candidate, table)), every DISTINCT key is evaluated
+// once (8 lanes each, the code above), every state copies its key's result.  Same table, bit for bit
+// (tests/test_gpu_matching.py runs the walk on both).  For one chain the launch is 48 blocks and its three dependent
+// phases cost more than the evaluations they save (round 4 measured a deduplicated gate at 20-21 us against 17): the
+// launcher takes this kernel from four chains on.
+#define GD_SLOTS 2048
+#define GD_THREADS 512
+__global__ __launch_bounds__(GD_THREADS) void gate_table_dedup_kernel(TailArgs A, GateGeom geo, uint16_t* __restrict__ Gt) {
+  __shared__ int key[GD_SLOTS];                 // ((candidate << 1) | table) + 1; 0: empty
+  __shared__ unsigned short val[GD_SLOTS];
+  __shared__ unsigned short ulist[GD_SLOTS];    // slots of the distinct keys
+  __shared__ int n_u;
+  const int K = A.K, Qc = A.M * A.steps, tid = threadIdx.x, lane = tid & 63;
+  const int q = blockIdx.x, chain = q / Qc, s = q % A.steps;
+  uint16_t* out = Gt + (int64_t)q * 2 * K;
+  if (q == chain * Qc) {                        // a chain's first step: the seed's state only
+    if (tid < 8) {
+      const int p = A.seed_codes ? A.seed_codes[chain] : A.seed_code;
+      const unsigned int g = gate_eval(A, q, p, A.seed_phase + (int64_t)chain * 128, lane);
+      if (tid == 0) out[0] = (uint16_t)g;
+    }
+    return;
+  }
+  for (int i = tid; i < GD_SLOTS; i += GD_THREADS) key[i] = 0;
+  if (tid == 0) n_u = 0;
+  __syncthreads();
+  constexpr int PER = 2 * 512 / GD_THREADS;     // states per thread at K = 512 (the launcher's bound)
+  int slot[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int sigma = u * GD_THREADS + tid;
+    slot[u] = -1;
+    if (sigma < 2 * K) {
+      const int pp = sigma >> 1, kp = sigma & 1;
+      const int ci = (kp ? A.T1 : A.T0)[(int64_t)(q - 1) * K + pp];
+      const int kv = (((ci < 0 ? 0 : ci) << 1) | kp) + 1;          // (an absent winner reads candidate 0, as cand_block does)
+      unsigned int h = ((unsigned int)kv * 2654435761u) >> 21;     // 11 bits
+      for (;;) {
+        const int old = atomicCAS(&key[h], 0, kv);
+        if (old == 0) {
+          ulist[atomicAdd(&n_u, 1)] = (unsigned short)h;
+          break;
+        }
+        if (old == kv) break;
+        h = (h + 1) & (GD_SLOTS - 1);
+      }
+      slot[u] = (int)h;
+    }
+  }
+  __syncthreads();
+  const int nu = n_u;
+  for (int u = tid >> 3; u < nu; u += GD_THREADS >> 3) {           // (uniform per 8-lane group)
+    const int h = ulist[u], kv = key[h] - 1;
+    int p;
+    const float* prev = gate_prev(A, geo, s, kv & 1, kv >> 1, &p);
+    const unsigned int g = gate_eval(A, q, p, prev, lane);
+    if ((lane & 7) == 0) val[h] = (unsigned short)g;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+    if (slot[u] >= 0) out[u * GD_THREADS + tid] = val[slot[u]];
 }
 
 #define QPG_CHASE_QMAX 2048
@@ -603,6 +684,15 @@ __global__ void status_only_kernel(int32_t* out_status, const int32_t* guard_fla
   out_status[1] = guard_flags ? guard_flags[0] : 0;
 }
 
+// From how many chains per launch the gate table is deduplicated by the previous winner (gate_table_dedup_kernel); 0 =
+// never.  Measurement / test hook, process-wide.
+static int g_gate_dedup_chains = 4;
+extern "C" int qpg_debug_gate_dedup(int from_chains) {
+  QPG_REQUIRE(from_chains >= 0, "qpg_debug_gate_dedup: from_chains >= 0");
+  g_gate_dedup_chains = from_chains;
+  return QPG_OK;
+}
+
 static int match_steps_impl(qpg_ctx* ctx, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
                             const int16_t* txt_rank, const int32_t* txt_idx, const int16_t* pos_rank,
                             const int16_t* freq_rank, const int32_t* code, int code_ld, const int32_t* aud_cidx,
@@ -672,9 +762,15 @@ static int match_steps_impl(qpg_ctx* ctx, void* stream, const int16_t* aud_rank,
   }
   uint16_t* gtab = reinterpret_cast<uint16_t*>(gate_tables + (int64_t)2 * Q * K);     // third [Q][K] i32 region
   const int64_t lanes = (int64_t)Q * 2 * K * 8;
-  hipLaunchKernelGGL(gate_table_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, qpg_stream(stream), A,
-                     geo, gtab);
-  QPG_LAUNCH_CHECK("gate_table_kernel");
+  const int dedup_from = g_gate_dedup_chains;                          // (qpg_debug_gate_dedup; 0: never)
+  if (dedup_from > 0 && n_chains >= dedup_from && K <= 512) {
+    hipLaunchKernelGGL(gate_table_dedup_kernel, dim3((unsigned)Q), dim3(GD_THREADS), 0, qpg_stream(stream), A, geo, gtab);
+    QPG_LAUNCH_CHECK("gate_table_dedup_kernel");
+  } else {
+    hipLaunchKernelGGL(gate_table_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, qpg_stream(stream), A,
+                       geo, gtab);
+    QPG_LAUNCH_CHECK("gate_table_kernel");
+  }
   hipLaunchKernelGGL(gate_chase_kernel, dim3(n_chains), dim3(1024), lds_g, qpg_stream(stream), A, (const uint16_t*)gtab);
   QPG_LAUNCH_CHECK("gate_chase_kernel");
   return QPG_OK;

@@ -494,14 +494,23 @@ def test_walk_batch_equals_one_walk_per_clip():
     for c in range(CL):
         oc, op, ov, st = knn.walk(T, M, window_offset=c * M, seed_code=seeds[c], seed_phase=phases[c], sync=False)
         one.append((oc.cpu().numpy(), op.cpu().numpy(), ov.cpu().numpy(), st.cpu().numpy()))
-    bc, bp, bv = knn.walk_batch(T, M, CL, seeds, np.stack(phases))
-    ints = knn._last_ints.cpu().numpy()
-    for c in range(CL):
-        assert np.array_equal(bc[c].cpu().numpy(), one[c][0])
-        assert np.array_equal(bp[c].cpu().numpy(), one[c][1])
-        assert np.array_equal(bv[c].cpu().numpy(), one[c][2])
-        assert np.array_equal(ints[c, -2:], one[c][3])
-        assert np.array_equal(ints[c, :M * 30], one[c][0].reshape(-1))
+    from qpgesture_amd import _lib
+    lib = _lib.load()
+    try:
+        # round 5: from four chains per launch the gate table is deduplicated by the previous winner
+        # (gate_table_dedup_kernel); 0 = the plain kernel for the batch as well - both must equal the one-clip walks
+        for dedup_from in (4, 0, 2):
+            assert lib.qpg_debug_gate_dedup(dedup_from) == 0
+            bc, bp, bv = knn.walk_batch(T, M, CL, seeds, np.stack(phases))
+            ints = knn._last_ints.cpu().numpy()
+            for c in range(CL):
+                assert np.array_equal(bc[c].cpu().numpy(), one[c][0]), dedup_from
+                assert np.array_equal(bp[c].cpu().numpy(), one[c][1]), dedup_from
+                assert np.array_equal(bv[c].cpu().numpy(), one[c][2]), dedup_from
+                assert np.array_equal(ints[c, -2:], one[c][3])
+                assert np.array_equal(ints[c, :M * 30], one[c][0].reshape(-1))
+    finally:
+        lib.qpg_debug_gate_dedup(4)
     assert len({tuple(o[0].reshape(-1)) for o in one}) > 1              # the clips really differ
 
 

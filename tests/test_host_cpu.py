@@ -29,7 +29,7 @@ def test_bindings_cover_the_header():
                                "qpg_conv1d_wgrad_ws_floats", "qpg_vq_code_sums_ws_bytes",
                                "qpg_text_percode_ws_bytes", "qpg_percode_select_mixed_ws_bytes",
                                "qpg_percode_select_mixed_ws_stride",
-                               "qpg_merge_mixed_ws_bytes", "qpg_debug_convt_shape", "qpg_debug_convt_opts", "qpg_debug_gemm64_waves",
+                               "qpg_merge_mixed_ws_bytes", "qpg_debug_convt_shape", "qpg_debug_convt_opts", "qpg_debug_gemm64_waves", "qpg_debug_gate_dedup",
                                "qpg_percode_select_exact_ws_bytes", "qpg_audio_hl_supported",
                                "qpg_audio_hl_db_bytes", "qpg_audio_hl_query_bytes", "qpg_hl_rows_bytes",
                                "qpg_hl_cols_bytes", "qpg_dev_kernarg", "qpg_audio_hl1_supported", "qpg_audio_hl1_db_bytes",
