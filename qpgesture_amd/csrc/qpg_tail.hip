@@ -546,11 +546,11 @@ __global__ __launch_bounds__(256) void gate_table_kernel(TailArgs A, GateGeom ge
 // q - 1, ci = T_kp[q - 1][pp] - and the 2 K states of a step share a few dozen to a few hundred distinct winners.  Block =
 // one step q: the states' winners go into an LDS hash table (key = (candidate, table)), every DISTINCT key is evaluated
 // once (8 lanes each, the code above), every state copies its key's result.  Same table, bit for bit
-// (tests/test_gpu_matching.py runs the walk on both).  For one chain the launch is 48 blocks and its three dependent
-// phases cost more than the evaluations they save (round 4 measured a deduplicated gate at 20-21 us against 17): the
-// launcher takes this kernel from four chains on.
+// (tests/test_gpu_fullsize.py runs the batched walk on both).  16 clips: 203 -> 30 us; ONE clip (48 blocks): 17.9 -> 13.3 us
+// (round 4's deduplicated gate - a marked-winner table and a second lookup per chase step - measured 20-21 us; this one
+// leaves the table's format and the chase alone).
 #define GD_SLOTS 2048
-#define GD_THREADS 512
+#define GD_THREADS 1024
 __global__ __launch_bounds__(GD_THREADS) void gate_table_dedup_kernel(TailArgs A, GateGeom geo, uint16_t* __restrict__ Gt) {
   __shared__ int key[GD_SLOTS];                 // ((candidate << 1) | table) + 1; 0: empty
   __shared__ unsigned short val[GD_SLOTS];
@@ -686,7 +686,7 @@ __global__ void status_only_kernel(int32_t* out_status, const int32_t* guard_fla
 
 // From how many chains per launch the gate table is deduplicated by the previous winner (gate_table_dedup_kernel); 0 =
 // never.  Measurement / test hook, process-wide.
-static int g_gate_dedup_chains = 4;
+static int g_gate_dedup_chains = 1;
 extern "C" int qpg_debug_gate_dedup(int from_chains) {
   QPG_REQUIRE(from_chains >= 0, "qpg_debug_gate_dedup: from_chains >= 0");
   g_gate_dedup_chains = from_chains;

@@ -31,6 +31,9 @@ if os.environ.get("QPG_FORCE_SHARDED") == "1":          # the row-shard code pat
     os.environ.setdefault("MASTER_PORT", "29541")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     knn.force_sharded = True
+if "QPG_GATE_DEDUP" in os.environ:                    # from how many chains the gate table is deduplicated (0: never)
+    from qpgesture_amd import _lib as _l
+    _l.load().qpg_debug_gate_dedup(int(os.environ["QPG_GATE_DEDUP"]))
 knn.audio_kernel = os.environ.get("QPG_AUDIO_KERNEL", "hl")
 knn.tie_eps = float(os.environ.get("QPG_TIE_EPS", knn.tie_eps))
 te_i = torch.randn((M * CL, 180, 1024), device=dev)
