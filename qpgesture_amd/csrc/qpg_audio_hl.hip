@@ -1527,7 +1527,9 @@ __global__ __launch_bounds__(512, 2) void hl_gemm32_kernel(HlArgs a, int n_items
 // ([tile][a.ldT], a.ldT >= Q: the 16 queries of a column tile are one 64-byte store; the by-code select reads a tile's
 // queries contiguously).  Needs KB % 4 == 0 (D % 128 == 0) and an even number of 32-row groups.
 #define G64_KS 4
-#define G64_PD 2
+#ifndef G64_PD
+#define G64_PD 2          // steps between a column tile's fragment read and its use (3 and 5 measured: see DESIGN 4.4)
+#endif
 // PAIR: two stages per trip of the k loop, LDS buffer indices static (an even number of stages: D % 256 == 0, configs[2]);
 // !PAIR: one stage per trip, the buffer index carried in a register (any D % 128 == 0; hipcc's over-tight wait at the loop
 // head - see DESIGN.md 4.4 - is then paid per stage instead of per two)
