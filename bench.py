@@ -1173,6 +1173,18 @@ def vqvae_bench(dev, a, world, rank):
     res.update({"vqvae_train_windows_per_s": round(Bw * world / tt, 1),
                 "vqvae_train_ms_per_step_b256": round(tt * 1e3, 3),
                 "vqvae_train_tflops_f32": round(train_flop / tt / 1e12, 2)})
+    # BESIDE the f32 figure, never instead of it: the same step with its FORWARD convolutions on the split-operand f16
+    # kernels (VQVAE.train_precision = "f16x3", train.py --train_precision f16x3; backward and optimiser unchanged, the weight
+    # images re-packed from the updated weights every step inside the timed region)
+    tm.train_precision = "f16x3"
+    try:
+        t16, _, _ = timed(train_step, 8, 3)
+        res["vqvae_train_f16x3_forward"] = {"ms_per_step_b256": round(t16 * 1e3, 3),
+                                            "windows_per_s": round(Bw * world / t16, 1),
+                                            "note": "opt-in; x_out within 3e-5 and gradients within 1e-4 (relative, in norm) "
+                                                    "of the f32 step's: tests/test_gpu_vqvae_train.py"}
+    except Exception as e_:                                   # noqa: BLE001 (recorded, the f32 figures stand)
+        res["vqvae_train_f16x3_forward"] = {"error": repr(e_)[:200]}
     return res
 
 

@@ -621,7 +621,10 @@ int qpg_vq_gather_f32(qpg_ctx*, void* stream, const float* k, const int64_t* ids
  *   qpg_conv16_pack_weights  w [dev] f32 [taps][Cin_pad_w][Cout_pad_w] (qpg_conv1d_f32's layout) -> image [dev].
  *   qpg_conv16_f32           x [dev] f32 [B][T_in][Cx] (Cx %% 8 == 0, Cx >= Cin, Cin %% 8 == 0; 16-byte aligned), geometry
  *                            as qpg_conv1d_f32; y [dev] f32 [B][T_y][Cout]; status [dev] i32 |= 1 if an activation's
- *                            magnitude exceeds the f16 range (the output is then meaningless: redo on the f32 kernels). */
+ *                            magnitude exceeds the f16 range (the output is then meaningless: redo on the f32 kernels).
+ *                            w_exp: the image's scale exponent, or QPG_CONV16_WEXP_FROM_IMAGE - the kernel reads it from the
+ *                            image itself (training: the weights change every step, no host read-back per layer). */
+#define QPG_CONV16_WEXP_FROM_IMAGE 0x7fff
 int64_t qpg_conv16_image_bytes(int taps, int Cin, int Cout);
 int qpg_conv16_pack_weights(qpg_ctx*, void* stream, const float* w, int taps, int Cin, int Cin_pad_w, int Cout, int Cout_pad_w,
                             void* image, int64_t image_bytes);

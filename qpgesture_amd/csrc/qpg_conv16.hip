@@ -43,6 +43,7 @@ struct Conv16Args {
   int B, T_in, Cx, Cin, Cin_pad, Cout, taps;
   int in_stride, in_offset, dil, T_out, out_stride, out_offset, T_y;
   int relu_in, relu_out, w_exp;
+  const int32_t* w_exp_dev;   // or: the exponent is read from the image's metadata on the device (no host read-back)
   const float* zeros;
   int32_t* status;
 };
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(Conv16Args a) {
   if (bad && a.status) atomicOr(a.status, 1);
   // ---- epilogue: lane (cg = lane & 15 -> position, rg = lane >> 4 -> channels 4 rg .. 4 rg + 3 of a 16-channel tile)
   const int cg = lane & 15, rg = lane >> 4;
-  const float sc = __builtin_ldexpf(1.0f, -a.w_exp);
+  const float sc = __builtin_ldexpf(1.0f, -(a.w_exp_dev ? a.w_exp_dev[0] : a.w_exp));
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int64_t m = m0 + 64 * wm + 16 * j + cg;
@@ -183,7 +184,15 @@ __global__ __launch_bounds__(1024) void conv16_absmax_kernel(const float* __rest
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     m = fmaxf(m, fabsf(w[i]));
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  // one atomic per BLOCK (round 5: one per wave - 4 096 device-scope atomics on one address - took 48 us per layer, 2.3 ms of
+  // a training step that re-packs its 48 images)
+  __shared__ float red[16];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, red[i]);
+    atomicMax(out, __float_as_uint(m));
+  }
 }
 
 __global__ void conv16_wexp_kernel(unsigned int* __restrict__ amax_bits, int32_t* __restrict__ meta) {
@@ -251,7 +260,7 @@ extern "C" int qpg_conv16_pack_weights(qpg_ctx* ctx, void* stream, const float* 
     qpg_set_error("%s: memset failed", name);
     return QPG_EHIP;
   }
-  hipLaunchKernelGGL(conv16_absmax_kernel, dim3(256), dim3(1024), 0, st, w, (int64_t)taps * Cin_pad_w * Cout_pad_w, amax);
+  hipLaunchKernelGGL(conv16_absmax_kernel, dim3(64), dim3(1024), 0, st, w, (int64_t)taps * Cin_pad_w * Cout_pad_w, amax);
   hipLaunchKernelGGL(conv16_wexp_kernel, dim3(1), dim3(1), 0, st, amax, meta);
   const int Cin_pad = (int)c16_round(Cin, C16_BK), n_blk = (int)(c16_round(Cout, C16_BN) / C16_BN);
   hipLaunchKernelGGL(conv16_pack_w_kernel, dim3(2048), dim3(256), 0, st, w, taps, Cin, Cin_pad_w, Cout, Cout_pad_w, Cin_pad,
@@ -262,7 +271,8 @@ extern "C" int qpg_conv16_pack_weights(qpg_ctx* ctx, void* stream, const float* 
 
 // The convolution of qpg_conv1d_f32's contract (same geometry arguments) on the split-f16 path.  x rows have pitch Cx floats
 // (Cx % 8 == 0, Cx >= Cin; channels >= Cin are never read); image from qpg_conv16_pack_weights for (taps, Cin, Cout);
-// w_exp = the image's scale exponent (the i32 at byte qpg_conv16_image_bytes - 64 of the image, read back once by the host);
+// w_exp = the image's scale exponent (the i32 at byte qpg_conv16_image_bytes - 64 of the image, read back once by the host),
+// or QPG_CONV16_WEXP_FROM_IMAGE: the kernel reads it there itself;
 // status [dev] i32: |= 1 if an activation's magnitude left the f16 range (the result is then garbage: redo in f32).
 extern "C" int qpg_conv16_f32(qpg_ctx* ctx, void* stream, const float* x, int B, int T_in, int Cx, int Cin, const void* image,
                               int w_exp, const float* bias, int taps, int Cout, int in_stride, int in_offset, int dil, int T_out,
@@ -272,7 +282,8 @@ extern "C" int qpg_conv16_f32(qpg_ctx* ctx, void* stream, const float* x, int B,
   QPG_REQUIRE(ctx && x && image && y, "%s: null pointer", name);
   QPG_REQUIRE(B > 0 && T_in > 0 && taps > 0 && Cin > 0 && Cout > 0 && Cx >= Cin && (Cx % 8) == 0 && (Cin % 8) == 0 &&
                   in_stride > 0 && dil > 0 && T_out > 0 && out_stride > 0 && out_offset >= 0 && T_y > 0 &&
-                  (int64_t)(T_out - 1) * out_stride + out_offset < T_y && w_exp >= -60 && w_exp <= 60,
+                  (int64_t)(T_out - 1) * out_stride + out_offset < T_y &&
+                  ((w_exp >= -60 && w_exp <= 60) || w_exp == QPG_CONV16_WEXP_FROM_IMAGE),
               "%s: bad geometry (Cx %% 8 == 0, Cin %% 8 == 0)", name);
   QPG_REQUIRE((reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(image) % 16) == 0 &&
                   (reinterpret_cast<uintptr_t>(y) % 16) == 0 && (!residual || (reinterpret_cast<uintptr_t>(residual) % 16) == 0) &&
@@ -283,6 +294,12 @@ extern "C" int qpg_conv16_f32(qpg_ctx* ctx, void* stream, const float* x, int B,
   a.B = B; a.T_in = T_in; a.Cx = Cx; a.Cin = Cin; a.Cin_pad = (int)c16_round(Cin, C16_BK); a.Cout = Cout; a.taps = taps;
   a.in_stride = in_stride; a.in_offset = in_offset; a.dil = dil; a.T_out = T_out; a.out_stride = out_stride;
   a.out_offset = out_offset; a.T_y = T_y; a.relu_in = relu_in; a.relu_out = relu_out; a.w_exp = w_exp; a.zeros = ctx->zeros;
+  // (training: the weights - and with them the exponent - change every step; a host read-back per layer would be ~40
+  // synchronisations per step)
+  a.w_exp_dev = w_exp == QPG_CONV16_WEXP_FROM_IMAGE
+                    ? reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(image) +
+                                                       (qpg_conv16_image_bytes(taps, Cin, Cout) - 64))
+                    : nullptr;
   a.status = status;
   const int64_t M = (int64_t)B * T_out;
   const int64_t gx = (M + C16_BM - 1) / C16_BM;

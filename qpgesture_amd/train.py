@@ -30,7 +30,7 @@ import torch
 from . import parallel
 from .checkpoint import load_config
 from .optim import Adam, MultiStepLR
-from .vqvae import VQVAE, init_state_dict, normalize_poses
+from .vqvae import ActivationRange, VQVAE, init_state_dict, normalize_poses
 
 
 def parse_args(argv=None):
@@ -46,6 +46,11 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("--resume", default=None, help="checkpoint to start from")
     p.add_argument("--max_updates", type=int, default=0, help="stop after this many optimiser steps (0 = all)")
+    p.add_argument("--train_precision", choices=["f32", "f16x3"], default="f32",
+                   help="forward convolutions of a training step: f32 matrix cores (default; the reference's arithmetic class) "
+                        "or split-operand f16 (three f16 MFMAs per product, f32 accumulation: ~1e-5 of the f32 kernels, half "
+                        "the forward time; the backward pass is f32 either way; a step whose activations leave the f16 range "
+                        "is redone in f32 and the run stays in f32)")
     return p.parse_args(argv)
 
 
@@ -103,6 +108,7 @@ def main(argv=None):
     logging.info("train windows: %d, validation windows: %d", train.shape[0], val.shape[0])
 
     model = VQVAE(cfg.VQVAE, 15 * 9, device=dev)
+    model.train_precision = args.train_precision
     start_epoch = 1
     if args.resume:
         from .checkpoint import load_checkpoint
@@ -162,8 +168,15 @@ def main(argv=None):
             idx = perm[i * batch + rank * per_rank: i * batch + (rank + 1) * per_rank]
             x = train[idx].to(dev, non_blocking=True)
             opt.zero_grad()
-            _, loss, metrics = model(x)
-            model.backward(sync_grads=True)          # decoder-half all-reduce overlaps the encoder half of backward
+            try:
+                _, loss, metrics = model(x)
+                model.backward(sync_grads=True)      # decoder-half all-reduce overlaps the encoder half of backward
+            except ActivationRange as e:             # (split-f16 forward only; the status word is MAX-reduced over the
+                logging.warning("%s", e)             # ranks before it is read: every rank redoes the step)
+                model.train_precision = "f32"
+                opt.zero_grad()
+                _, loss, metrics = model(x)
+                model.backward(sync_grads=True)
             opt.step()
             updates += 1
             if rank == 0:

@@ -44,6 +44,12 @@ def tpack(w_tap_ci_co, cin_pad, nb):
     return W.view(K // 16, 4, 4, cout_pad // nb, nb).permute(3, 0, 1, 4, 2).contiguous().view(-1)
 
 
+class ActivationRange(RuntimeError):
+    """A split-f16 convolution (qpg_conv16_f32) met an activation beyond the f16 range: its output is meaningless and the
+    caller falls back to the f32 kernels (VQVAE.encode_f16x3 does that itself; a training step raises this from backward()
+    before the optimiser has moved the weights)."""
+
+
 class _Conv:
     """One packed convolution: weights [taps][Cin_pad][Cout_pad], bias [Cout_pad]."""
 
@@ -304,16 +310,26 @@ class VQVAE:
     # split-operand f16 convolutions (round 5, csrc/qpg_conv16.hip): the same layers at ~3/16 of the f32 matrix time per
     # flop, agreeing with the f32 kernels to ~1e-5 - NOT bit-identical, so they serve under a margin check (encode below)
     # ------------------------------------------------------------------------------------------
-    def _conv16_image(self, c):
-        """(image, scale exponent) of convolution c for qpg_conv16_f32; built on first use, dropped when the weights change."""
+    WEXP_FROM_IMAGE = 0x7fff          # QPG_CONV16_WEXP_FROM_IMAGE: the kernel reads the scale exponent from the image
+
+    def _conv16_image(self, c, read_exp=True):
+        """(image, scale exponent) of convolution c for qpg_conv16_f32; built on first use, dropped when the weights change.
+        read_exp=False (the training forward: the weights change every step): no host read-back - the exponent slot holds
+        WEXP_FROM_IMAGE and the kernel takes it from the image."""
         img = getattr(c, "_img16", None)
         if img is None:
             lib = _lib.load()
             nb = int(lib.qpg_conv16_image_bytes(c.taps, _pad(c.cin, 8), c.cout))
-            buf = torch.empty((nb,), dtype=torch.uint8, device=self.device)
+            buf = getattr(c, "_img16_buf", None)              # (re-packed in place step after step)
+            if buf is None or buf.numel() != nb:
+                buf = c._img16_buf = torch.empty((nb,), dtype=torch.uint8, device=self.device)
             # (channels are padded to a multiple of 8 on the activation side: the 135-channel pose rows become 136 wide)
             _lib.call("qpg_conv16_pack_weights", self.device, c.w, c.taps, _pad(c.cin, 8), c.cin_pad, c.cout, c.cout_pad,
                       buf, nb)
+            img = c._img16 = (buf, None)
+        if read_exp and img[1] is None:
+            buf = img[0]
+            nb = buf.numel()
             img = c._img16 = (buf, int(buf[nb - 64:nb - 60].view(torch.int32).item()))
         return img
 
@@ -329,6 +345,26 @@ class VQVAE:
             st = self._c16_status = torch.zeros((1,), dtype=torch.int32, device=self.device)
         _lib.call("qpg_conv16_f32", self.device, x, B, T_in, x.shape[-1], _pad(c.cin, 8), img, w_exp, c.b, c.taps, c.cout,
                   in_stride, in_offset, dil, T_out, 1, 0, T_out, residual, int(relu_in), int(relu_out), out, st)
+        return out
+
+    def _conv16_fwd(self, c, x, B, T_in, T_out, in_stride=1, in_offset=0, dil=1, out=None, out_stride=1, out_offset=0,
+                    T_y=None, residual=None, relu_in=False, relu_out=False):
+        """A training-forward convolution on the split-f16 kernel (train_precision "f16x3"): _conv_fwd's arguments, the
+        exponent read on the device, the out-of-range status accumulated in self._c16_status (checked by backward())."""
+        img, _ = self._conv16_image(c, read_exp=False)
+        if x.shape[-1] % 8:                           # pose rows (135 floats) -> 136
+            xp = torch.empty((B, T_in, _pad(x.shape[-1], 8)), dtype=torch.float32, device=self.device)
+            _lib.call("qpg_pad_channels_f32", self.device, x, B * T_in, x.shape[-1], xp.shape[-1], xp)
+            x = xp
+        T_y = T_out if T_y is None else T_y
+        if out is None:
+            out = torch.empty((B, T_y, c.cout), dtype=torch.float32, device=self.device)
+        st = getattr(self, "_c16_status", None)
+        if st is None:
+            st = self._c16_status = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        _lib.call("qpg_conv16_f32", self.device, x, B, T_in, x.shape[-1], _pad(c.cin, 8), img, self.WEXP_FROM_IMAGE, c.b,
+                  c.taps, c.cout, in_stride, in_offset, dil, T_out, out_stride, out_offset, T_y, residual, int(relu_in),
+                  int(relu_out), out, st)
         return out
 
     def _resnet16(self, blocks, x, B, T, reverse):
@@ -562,10 +598,16 @@ class VQVAE:
             n_cu = self.__dict__["_n_cu"] = torch.cuda.get_device_properties(self.device).multi_processor_count
         return ((B * T + 63) // 64) * 4 >= n_cu * 3
 
+    def _train16(self):
+        """The training step's FORWARD convolutions on the split-f16 kernels (train_precision = "f16x3"; round 5, opt-in:
+        three f16 MFMAs per f32 product, f32 accumulation - within ~1e-5 of the f32 kernels, not bit-identical; the backward
+        pass stays on the f32 kernels, reading the activations this forward recorded)."""
+        return self.training and getattr(self, "train_precision", "f32") == "f16x3"
+
     def _res_fwd(self, blocks, x, B, T, reverse, tape, packs=None):
         for d, (c3, c1) in enumerate(blocks):
             dil = self.growth ** (self.depth - 1 - d if reverse else d)              # resnet.py:57-62
-            if packs is not None and self._fused_block_fills_chip(B, T):
+            if packs is not None and self._fused_block_fills_chip(B, T) and not self._train16():
                 # one launch: the hidden activation is written for the backward pass
                 y, h = torch.empty_like(x), torch.empty_like(x)
                 _lib.call("qpg_resblock_f32", self.device, x, B, T, dil, packs[d], c3.b, c1.b, y, h)
@@ -585,6 +627,8 @@ class VQVAE:
         """A training-forward convolution: on the transposed-formulation kernel (qpg_convt_f32, from the T-pack that
         _tpack_rebuild refreshed) when `fused`, else qpg_conv1d_f32.  x keeps its own channel count on the tape (the
         weight gradient reads it); the transposed kernel gets a copy padded to Cin_pad when the two differ."""
+        if self._train16():
+            return self._conv16_fwd(c, x, B, T_in, T_out, **kw)
         wt = getattr(c, "wt", None) if fused else None
         if wt is None:
             return self._conv(c, x, B, T_in, T_out, **kw)
@@ -642,7 +686,13 @@ class VQVAE:
         # training forward on the transposed-formulation kernels (round 3): their T-packs are refreshed on the device
         # from the weights the optimiser has just updated; activations are recorded as before
         fused = bool(getattr(self, "train_fused", True) and self._tpack_on)
-        if fused:
+        if self._train16():
+            # split-f16 forward: the weight images are re-packed (in place, no host read-back) from the weights the
+            # optimiser has just updated; the T-packs stay stale until an f32 / inference call needs them
+            if getattr(self, "_tpack_stale", False) or getattr(self, "_img16_stale", True):
+                self._drop_conv16_images()
+                self._img16_stale = False
+        elif fused:
             self._refresh_tpack()
         z = self._encoder_fwd(x, B, T, enc_tape, fused)             # (B,L,E) channels-last
         L, E = z.shape[1], z.shape[2]
@@ -659,6 +709,10 @@ class VQVAE:
         stats = torch.empty((3,), dtype=torch.float32, device=self.device)      # commit, fit, prenorm
         ws = self._red_ws()
         _lib.call("qpg_vq_latent_stats_f32", self.device, z2, zq, dmin, R, E, ws, ws.numel(), stats)
+        if self._train16():
+            # (the EMA below moves the codebook inside forward(): kept aside so that a step whose split-f16 forward turns
+            # out to have left the f16 range - backward() reports it - can be redone in f32 from the same state)
+            self._k_backup = [t.clone() for t in (self.k, self.k_sum, self.k_elem, self.kT.w, self.kk)]
         ema = self._update_k(z2, ids) if self.training else None
         x_out = self.decode_latent(zq.view(B, L, E), B, L, dec_tape, fused)
         out6 = torch.empty((6,), dtype=torch.float32, device=self.device)
@@ -670,7 +724,7 @@ class VQVAE:
             q = dict(fit=stats[1], pn=stats[2], entropy=ema[0], used_curr=ema[1], usage=ema[2], dk=ema[3])
             metrics.update({kk: torch.floor(v) for kk, v in q.items()})        # sum(..) // len(..) with one level
         self._saved = dict(x=x, z2=z2, zq=zq, ids=ids.view(B, L), x_out=x_out, enc=enc_tape, dec=dec_tape,
-                           B=B, T=T, L=L) if self.training else None
+                           B=B, T=T, L=L, f16x3=self._train16()) if self.training else None
         return x_out, out6[0], metrics
 
     # ------------------------------------------------------------------------------------------
@@ -750,6 +804,7 @@ class VQVAE:
         sync_grads: data-parallel averaging of the gradients in two buckets — the decoder half is all-reduced while
         the encoder half is still being computed (backward produces the decoder's gradients first)."""
         self._tpack_stale = True          # an optimiser step follows: the T-packed inference images go stale
+        self._img16_stale = True
         sv = self._saved
         assert sv is not None, "backward() needs a training-mode forward() first"
         B, T, L = sv["B"], sv["T"], sv["L"]
@@ -769,6 +824,18 @@ class VQVAE:
             if w > 1:
                 self.grad.div_(w)
         self._saved = None
+        if sv.get("f16x3"):
+            # the forward ran on the split-f16 kernels: an activation outside the f16 range made its output meaningless
+            # (status bit of qpg_conv16_f32).  Checked HERE - every launch of the step is queued, the read costs no bubble -
+            # and before the optimiser step: the caller redoes the step in f32 (train.py does)
+            if parallel.world_size() > 1:
+                parallel.allreduce_max_(self._c16_status)      # (data parallel: every rank takes the same decision)
+            if int(self._c16_status.item()):
+                self._c16_status.zero_()
+                for dst, src in zip((self.k, self.k_sum, self.k_elem, self.kT.w, self.kk), self._k_backup):
+                    dst.copy_(src)                       # the codebook as it was before this step's EMA
+                raise ActivationRange("an activation left the f16 range in a split-f16 training forward: redo this step "
+                                      "with train_precision = 'f32'")
         return self.grad
 
     __call__ = forward

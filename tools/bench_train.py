@@ -23,4 +23,11 @@ def full(): m(x); m.backward(); opt.step()
 tf = t(fwd); tfb = t(fb); tall = t(full)
 print("B=%d forward %.2f ms (%.1f TF)  fwd+bwd %.2f ms (bwd %.2f ms, %.1f TF)  step %.2f ms (adam %.2f ms)  %.0f windows/s" % (
     B, tf * 1e3, FWD / tf / 1e12, tfb * 1e3, (tfb - tf) * 1e3, 2 * FWD / (tfb - tf) / 1e12, tall * 1e3, (tall - tfb) * 1e3, B / tall))
+if os.environ.get("QPG_TRAIN_F16X3", "1") == "1":
+    # round 5: the forward convolutions on the split-f16 kernels (opt-in: VQVAE.train_precision = "f16x3"); backward in f32
+    m.train_precision = "f16x3"
+    tf = t(fwd); tfb = t(fb); tall = t(full)
+    print("B=%d train_precision=f16x3: forward %.2f ms (%.1f TF f32-equivalent)  fwd+bwd %.2f ms (bwd %.2f ms)  step %.2f ms  %.0f windows/s"
+          % (B, tf * 1e3, FWD / tf / 1e12, tfb * 1e3, (tfb - tf) * 1e3, tall * 1e3, B / tall))
+    m.train_precision = "f32"
 print("params", m.param.numel(), "peak mem GB", torch.cuda.max_memory_allocated() / 1e9)
