@@ -1158,6 +1158,16 @@ def vqvae_bench(dev, a, world, rank):
            "vqvae_decode_ms_per_24s_clip": round(td * 1e3, 3),
            "vqvae_decode_ms_median": round(td_med, 3),
            "vqvae_decode_tflops_f32": round(dec_flop / td / 1e12, 2)}
+    # beside the f32 encode: the split-operand f16 encoder under its margin check (ids identical to the f32 path's by
+    # construction: windows the bound cannot vouch for are re-encoded in f32 inside the timed call)
+    try:
+        t16e, _, t16e_med = timed(lambda: model.encode_f16x3(x), 20, 4)
+        ids16, st16 = model.encode_f16x3(x, return_stats=True)
+        res["vqvae_encode_f16x3"] = {"ms_per_batch256": round(t16e * 1e3, 3), "frames_per_s": round(240 * Bw * world / t16e, 1),
+                                     "windows_re_encoded_in_f32": int(st16["windows_re_encoded_in_f32"]),
+                                     "ids_equal_f32_path": bool(torch.equal(ids16, model.encode(x)[0]))}
+    except Exception as e_:                                   # noqa: BLE001
+        res["vqvae_encode_f16x3"] = {"error": repr(e_)[:200]}
     # training step (codebook/train.py:120-131) at the reference's batch size of 256 windows per rank: forward with
     # EMA codebook update, backward, flat-gradient all-reduce (N > 1), Adam
     from qpgesture_amd.optim import Adam
