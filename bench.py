@@ -615,7 +615,8 @@ def main():
         ridge = F16_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
         intensity = mfma_issued / alg_bytes
         on_hbm = intensity < ridge
-        kname = "audio_cosine_hl2_kernel<%d, %d>" % (planes, 2 if planes == 2 else 3)
+        # (third template argument: non-temporal fragment loads - the launcher's choice for a single query chunk)
+        kname = "audio_cosine_hl2_kernel<%d, %d, %s>" % (planes, 2 if planes == 2 else 3, "true" if chunks == 1 else "false")
         pkey = None
         if world == 1 and N == 2048 and M == 6:
             pkey = "%s|N_db=2048 Q=%d" % ("audio_cosine_hl2_kernel" if planes == 2 else "audio_cosine_hl1", Q)

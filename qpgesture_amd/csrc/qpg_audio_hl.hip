@@ -731,9 +731,19 @@ __device__ __forceinline__ double fast_rsqrt_f64(double x) {
 #define H2_PRO 1         // prologue in the k loop's request order
 #endif
 // ablation hooks (experiments/audio_hl): -DH2_PROBE=<bits>; the product build defines nothing.  1: database fragments read
-// from one address (no HBM stream); 2: no f64 flush; 8: no stage barrier
+// from one address (no HBM stream); 2: no f64 flush; 8: no stage barrier; 16: no query-fragment reads from LDS (the
+// prologue's fragments for every step); 32: no query staging (global -> register -> LDS) inside the k loop; 64: no MFMAs (the fragment loads stay)
 #ifndef H2_PROBE
 #define H2_PROBE 0
+#endif
+#ifndef H2_LAYOUT
+#define H2_LAYOUT 0
+#endif
+#ifndef H2_NT
+#define H2_NT 1          // one query chunk: the image is read ONCE - non-temporal fragment loads (round 5: the kernel with its
+#endif                   // matrix work compiled out takes 130 us with plain loads, 113 with these; 0: plain loads always)
+#ifndef H2_RS2
+#define H2_RS2 2          // stages of database fragments in flight, two-plane kernel (3 / 4: probes only - no registers)
 #endif
 // ONE-PLANE database image (round 5: the track stored in IEEE f16, GestureDB feature_dtype "f16").  An f16 value IS its
 // own h plane: no scaling (exponent 0), no l plane, no representation error on the database side - half the bytes (a
@@ -745,7 +755,7 @@ __device__ __forceinline__ double fast_rsqrt_f64(double x) {
 // The 32 registers the l plane's ring held go into the ring's depth: RS = 4 stages (8 k-blocks) of fragments in flight.
 #define HL1_WIN_UNITS(KB) ((int64_t)(KB) * (64 + HL_T1_UNITS))
 // PL: planes of the database image (2: h | l, f32 track; 1: the f16 track); RS: stages of database fragments in flight
-template <int PL, int RS>
+template <int PL, int RS, bool NT>
 __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x 2 x 6 x 2 x 1 KB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -768,16 +778,27 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
   const uint32_t wj = (uint32_t)(win_ok ? w : a.N - 1 - jb);
   const uint32_t win_units = (uint32_t)(PL == 2 ? HL_WIN_UNITS(KB) : HL1_WIN_UNITS(KB));
   const unsigned char* sbase = reinterpret_cast<const unsigned char*>(a.db) + (int64_t)jb * win_units * 16;
+#if H2_LAYOUT == 1   // TIMING EXPERIMENT (results are garbage): a block's eight windows interleaved per k-block - one 27 KB run
+  constexpr uint32_t rec = (uint32_t)PL * (64 + HL_T1_UNITS);
+  const uint32_t o0 = (wj * rec + (uint32_t)lane) * 16u;
+  const uint32_t o1 = (wj * rec + 64u * PL + 11u * rg + (cg < 11 ? cg : 10)) * 16u;
+  constexpr uint32_t st0 = (H2_PROBE & 1) ? 0u : H2_W * rec * 16u, st1 = st0;
+#else
   const uint32_t o0 = (wj * win_units + (uint32_t)lane) * 16u;
   const uint32_t o1 = (wj * win_units + (uint32_t)KB * (64 * PL) + 11u * rg + (cg < 11 ? cg : 10)) * 16u;
   constexpr uint32_t st0 = (H2_PROBE & 1) ? 0u : 64u * PL * 16u, st1 = (H2_PROBE & 1) ? 0u : (uint32_t)PL * HL_T1_UNITS * 16u;
+#endif
+  auto ld_frag = [](const unsigned char* p) -> h8 {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const h8*>(p));
+    return *reinterpret_cast<const h8*>(p);
+  };
   auto load_a = [&](int kb, h8 (&d)[2 * PL]) {                         // [tile 0 h (, l), tile 1 h (, l)]
     kb = kb < KB ? kb : KB - 1;
     const uint32_t a0 = o0 + (uint32_t)kb * st0, a1 = o1 + (uint32_t)kb * st1;
-    d[0] = *reinterpret_cast<const h8*>(sbase + a0);
-    if (PL == 2) d[1] = *reinterpret_cast<const h8*>(sbase + a0 + 64 * 16);
-    d[PL] = *reinterpret_cast<const h8*>(sbase + a1);
-    if (PL == 2) d[PL + 1] = *reinterpret_cast<const h8*>(sbase + a1 + HL_T1_UNITS * 16);
+    d[0] = ld_frag(sbase + a0);
+    if (PL == 2) d[1] = ld_frag(sbase + a0 + 64 * 16);
+    d[PL] = ld_frag(sbase + a1);
+    if (PL == 2) d[PL + 1] = ld_frag(sbase + a1 + HL_T1_UNITS * 16);
   };
   constexpr int stage_units = 2 * HL_CT * 2 * 64;
   constexpr int QLD = stage_units / (64 * H2_W);
@@ -834,6 +855,7 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
       for (int pl = 0; pl < 2; ++pl) d[k2][pl] = qb[((k2 * HL_CT + c) * 2 + pl) * 64];
   };
   ld_b(0, 0, B[0]);
+  if (H2_PROBE & 16) ld_b(0, 1, B[1]);
   f32x4 dp[2] = {zero4, zero4};                                        // the previous step's two chains, not yet flushed
   // a trip = an even number of stages that is a multiple of RS: ring slots, LDS buffers and fragment parities are static
   constexpr int TRIP = (RS % 2 == 0) ? RS : 2 * RS;
@@ -850,8 +872,8 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         h8 (&Bn)[2][2] = B[(st + 1) & 1];
         if (c == HL_CT - 1) {
           if (!(H2_PROBE & 8)) lds_barrier();  // every fragment of this stage has arrived; the next stage's are stored
-          ld_b((ss + 1) & 1, 0, Bn);
-          if (H2_QFIRST || RS > 2) {
+          if (!(H2_PROBE & 16)) ld_b((ss + 1) & 1, 0, Bn);
+          if (!(H2_PROBE & 32) && (H2_QFIRST || RS > 2)) {
             // vmcnt counts IN ORDER: the wait for a stage's query fragments (one stage after their request) also waits
             // for every OLDER request.  With the query loads behind the ring's (below: the order of the two-stage ring,
             // where it does not matter) a deeper ring buys nothing - the data of stage s + RS - 1 must be there at the
@@ -861,7 +883,7 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
             load_q(s + 3);
             __builtin_amdgcn_sched_barrier(0);
           }
-        } else {
+        } else if (!(H2_PROBE & 16)) {
           ld_b(ss & 1, c + 1, Bn);
         }
         // two chains (row tile 0 / 1), interleaved.  ORDER INSIDE A CHAIN: the cross-term instructions first (h l', l h' of
@@ -869,22 +891,30 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
         // instructions last - the chain then behaves like round 3's chain of two (measured: every instruction that
         // re-rounds a FULL-SIZE running sum costs ~1.2-1.5 units of 2^-24 sum|products|, so h h' first would mean
         // kappa_6 = 14.4 against 9.9 this way; selfcheck.py measures this order)
-        f32x4 d0 = mfma_h(A0[0], Bc[0][1], (H2_PROBE & 2) ? dp[0] : zero4);     // (probe 2: one endless chain, no flush)
-        f32x4 d1 = mfma_h(A0[PL], Bc[0][1], (H2_PROBE & 2) ? dp[1] : zero4);
-        if (PL == 2) {
-          d0 = mfma_h(A0[PL - 1], Bc[0][0], d0);
-          d1 = mfma_h(A0[2 * PL - 1], Bc[0][0], d1);
+        f32x4 d0, d1;
+        if (H2_PROBE & 64) {                                       // probe: the loads and everything else, no matrix work
+#pragma unroll
+          for (int i = 0; i < 2 * PL; ++i) asm volatile("" ::"v"(A0[i]), "v"(A1[i]));
+          d0 = zero4;
+          d1 = zero4;
+        } else {
+          d0 = mfma_h(A0[0], Bc[0][1], (H2_PROBE & 2) ? dp[0] : zero4);     // (probe 2: one endless chain, no flush)
+          d1 = mfma_h(A0[PL], Bc[0][1], (H2_PROBE & 2) ? dp[1] : zero4);
+          if (PL == 2) {
+            d0 = mfma_h(A0[PL - 1], Bc[0][0], d0);
+            d1 = mfma_h(A0[2 * PL - 1], Bc[0][0], d1);
+          }
+          d0 = mfma_h(A1[0], Bc[1][1], d0);
+          d1 = mfma_h(A1[PL], Bc[1][1], d1);
+          if (PL == 2) {
+            d0 = mfma_h(A1[PL - 1], Bc[1][0], d0);
+            d1 = mfma_h(A1[2 * PL - 1], Bc[1][0], d1);
+          }
+          d0 = mfma_h(A0[0], Bc[0][0], d0);
+          d1 = mfma_h(A0[PL], Bc[0][0], d1);
+          d0 = mfma_h(A1[0], Bc[1][0], d0);
+          d1 = mfma_h(A1[PL], Bc[1][0], d1);
         }
-        d0 = mfma_h(A1[0], Bc[1][1], d0);
-        d1 = mfma_h(A1[PL], Bc[1][1], d1);
-        if (PL == 2) {
-          d0 = mfma_h(A1[PL - 1], Bc[1][0], d0);
-          d1 = mfma_h(A1[2 * PL - 1], Bc[1][0], d1);
-        }
-        d0 = mfma_h(A0[0], Bc[0][0], d0);
-        d1 = mfma_h(A0[PL], Bc[0][0], d1);
-        d0 = mfma_h(A1[0], Bc[1][0], d0);
-        d1 = mfma_h(A1[PL], Bc[1][0], d1);
         // f64 running sums: the PREVIOUS step's chains (zeros in front of the first step)
         if (!(H2_PROBE & 2)) {
           const int pc = (c + HL_CT - 1) % HL_CT;
@@ -901,7 +931,7 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
           // stage after next (behind the barrier above: nobody reads this stage's buffer any more)
           load_a(2 * (s + RS), A0);
           load_a(2 * (s + RS) + 1, A1);
-          if (!H2_QFIRST && RS <= 2) {
+          if (!(H2_PROBE & 32) && !H2_QFIRST && RS <= 2) {
             store_q(ss & 1);
             load_q(s + 3);
           }
@@ -1114,8 +1144,11 @@ extern "C" int qpg_audio_cosine_hl(qpg_ctx* ctx, void* stream, const void* db_im
   a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0; a.tmask = nullptr; a.band = 0.f; a.chunks = chunks;
   const int64_t g8 = ((int64_t)N + H2_W - 1) / H2_W;
   QPG_REQUIRE(((g8 + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
-  hipLaunchKernelGGL((audio_cosine_hl2_kernel<2, 2>), dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W),
-                     2 * 2 * HL_CT * 2 * HL_PIECE, qpg_stream(stream), a);
+  const bool nt = H2_NT == 2 || (H2_NT == 1 && chunks == 1);      // several chunks re-read the image out of the XCD's L2
+  void (*kern)(HlArgs) = nt ? audio_cosine_hl2_kernel<2, H2_RS2, true> : audio_cosine_hl2_kernel<2, H2_RS2, false>;
+  hipLaunchKernelGGL(kern,
+                     dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W), 2 * 2 * HL_CT * 2 * HL_PIECE,
+                     qpg_stream(stream), a);
   QPG_LAUNCH_CHECK("audio_cosine_hl2_kernel");
   return QPG_OK;
 }
@@ -1194,8 +1227,11 @@ extern "C" int qpg_audio_cosine_hl1(qpg_ctx* ctx, void* stream, const void* db_i
   a.KB = KB; a.d_f32 = d_is_f32; a.tmin = nullptr; a.ldT = 0; a.tmask = nullptr; a.band = 0.f; a.chunks = chunks;
   const int64_t g8 = ((int64_t)N + H2_W - 1) / H2_W;
   QPG_REQUIRE(((g8 + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
-  hipLaunchKernelGGL((audio_cosine_hl2_kernel<1, H1_RS>), dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W),
-                     2 * 2 * HL_CT * 2 * HL_PIECE, qpg_stream(stream), a);
+  const bool nt = H2_NT == 2 || (H2_NT == 1 && chunks == 1);
+  void (*kern)(HlArgs) = nt ? audio_cosine_hl2_kernel<1, H1_RS, true> : audio_cosine_hl2_kernel<1, H1_RS, false>;
+  hipLaunchKernelGGL(kern,
+                     dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W), 2 * 2 * HL_CT * 2 * HL_PIECE,
+                     qpg_stream(stream), a);
   QPG_LAUNCH_CHECK("audio_cosine_hl2_kernel<1>");
   return QPG_OK;
 }

@@ -76,8 +76,11 @@ if prio:
 for _ in range(5):
     step()
 torch.cuda.synchronize()
+gap = float(os.environ.get("QPG_LOOP_GAP_MS", "0"))     # idle time between steps (what the sweep takes on a chip that rests)
 t0 = time.perf_counter()
 for _ in range(steps):
     step()
+    if gap:
+        time.sleep(gap * 1e-3)
 torch.cuda.synchronize()
 print("%s: %.4f ms/step" % ("graph" if graph else "eager", (time.perf_counter() - t0) / steps * 1e3))
