@@ -2,7 +2,8 @@
 """FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, one counter per pass) -> profiles/pmc_traffic.json, the file bench.py
 reads `roofline.traffic` from at run time.  HBM bytes per launch = FETCH_SIZE (KB) x 1024 x 2 (the gfx950 correction of
 MI355X_MICROARCH.md: the counter ticks per 64-byte request on this part, documented as 32) + WRITE_SIZE (KB) x 1024.
-    python tools/pmc_traffic.py <dir with pmc_FETCH_SIZE/ pmc_WRITE_SIZE/> <kernel-name substring> <shape tag> <out json>"""
+    python tools/pmc_traffic.py <dir with pmc_FETCH_SIZE/ pmc_WRITE_SIZE/> <kernel-name substring> <shape tag> <out json> [key name]
+(key name: what the record is filed under instead of the substring - "audio_cosine_hl2_kernel<1" -> "audio_cosine_hl1")"""
 import collections
 import csv
 import glob
@@ -25,7 +26,7 @@ def mean_counter(d, name, kernel):
     return sum(v) / len(v), len(v), sum(dur.values()) / len(dur)
 
 
-def main(root, kernel, tag, out):
+def main(root, kernel, tag, out, key=None):
     fetch, n1, us1 = mean_counter(os.path.join(root, "pmc_FETCH_SIZE"), "FETCH_SIZE", kernel)
     write, n2, us2 = mean_counter(os.path.join(root, "pmc_WRITE_SIZE"), "WRITE_SIZE", kernel)
     rec = {"kernel": kernel, "shape": tag, "fetch_size_kb": round(fetch, 1), "write_size_kb": round(write, 1),
@@ -34,10 +35,10 @@ def main(root, kernel, tag, out):
            "recipe": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python tools/bench_audio_hl.py; "
                      "bytes = FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024"}
     data = json.load(open(out)) if os.path.exists(out) else {}
-    data[kernel + "|" + tag] = rec
+    data[(key or kernel) + "|" + tag] = rec
     json.dump(data, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(rec))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
