@@ -643,7 +643,9 @@ def main():
                              "frac": round(mfma_issued / (k_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4),
                              "equivalent_tflops_of_the_f32_formulation": round(achieved, 1),
                              "f32_matrix_peak": F32_MFMA_PEAK_TFLOPS},
-                    "hbm_frac_of_6_3_tbs_achievable": round(gbs / 6300.0, 4)}
+                    # what a read-only stream over a buffer of this size reaches on these boxes with non-temporal loads
+                    # (experiments/hbm_read/read_bw.hip, profiles/r05_read_bw.txt: 6.57-6.63 TB/s; plain loads 6.1)
+                    "hbm_frac_of_6_6_tbs_read_stream_ceiling": round(gbs / 6600.0, 4)}
     else:
         roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4),
