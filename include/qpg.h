@@ -469,6 +469,7 @@ int qpg_l2_table_f32(qpg_ctx*, void* stream, const float* sig, int K, int Dm, fl
 #define QPG_MODE_AUD 1     /* audio only: top-2 audio candidates through the phase gate (:593-608)          */
 #define QPG_MODE_TXT 2     /* text only: top-2 text candidates through the phase gate (:610-625)            */
 #define QPG_MODE_SERIAL_WALK 0x100 /* OR-ed into mode: force the one-wave sequential walk (validation of the tabulated one) */
+#define QPG_MODE_PREFUSED 0x200    /* OR-ed into QPG_MODE_AUD_TXT: gate_tables [0] / [1] were filled by qpg_fuse_best_ranked */
 
 /* Walk all M windows x `steps` matching steps of a clip on the device.
  *   aud_rank/txt_rank: [dev] i16 [Q][K] stable ranks of the per-code minima (Q = M*steps);
@@ -507,6 +508,14 @@ int qpg_match_steps_batch(qpg_ctx*, void* stream, const int16_t* aud_rank, const
                           int n_chains, const int32_t* seed_codes, const float* seed_phase, int32_t* gate_tables,
                           int32_t* out_codes, float* out_phase, int32_t* out_vote, int32_t* out_status,
                           int64_t status_stride, const int32_t* guard_flags);
+/* One modality's half of the rank fusion in front of the walk (GestureKNN.py:540-545 + :574-576 for the audio order,
+ * :553-555 for the text order - two independent argsorts): T[q][p] = idx[q][argmin_c (pos_rank[p][c] + 0.05 freq_rank[c])
+ * + rank[q][c]] (f64, that order of operations; lowest code among equal scores).  rank [dev] i16 [Q][K] (a permutation per
+ * row), idx [dev] i32 [Q][K], T [dev] i32 [Q][K]: region [0] (audio) or [1] (text) of the walk's gate_tables.  Launched
+ * behind each modality's select on ITS stream, the walk (qpg_match_steps* with QPG_MODE_PREFUSED) then starts at the gate
+ * table and the join of the two streams has half a rank fusion less in front of it.  K % 16 == 0, K <= 4096. */
+int qpg_fuse_best_ranked(qpg_ctx*, void* stream, const int16_t* rank, const int32_t* idx, const int16_t* pos_rank,
+                         const int16_t* freq_rank, int Q, int K, int32_t* T);
 /* Measurement / test hook: from how many chains per launch qpg_match_steps_batch deduplicates the gate table by the previous
  * step's winner (one evaluation per DISTINCT winner instead of one per (previous code, vote) state; same table, bit for
  * bit).  Default 1 (always, for K <= 512); 0: never.  Process-wide. */

@@ -106,6 +106,7 @@ _SIGS = {
     "qpg_unpack_min_u64": [P, L, c_float, P, P],
     "qpg_match_steps": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P, P],
     "qpg_match_steps_batch": [P, P, P, P, P, P, P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P, P, P, P, P, P, P, L, P],
+    "qpg_fuse_best_ranked": [P, P, P, P, I, I, P],
 }
 
 

@@ -417,6 +417,8 @@ class CodeKNN:
         self.rank_cut = _os.environ.get("QPG_RANK_CUT", "1") != "0"
         self.rank_cut_probe = 64
         self.mixed_single_launch = False    # True: the select's tier-1 work stays inside one launch (tests compare both)
+        self.split_fuse = True              # the rank fusion per modality behind its select (False: one launch in the walk)
+        self.split_fuse_max_steps = 256     # ... for sweeps of at most this many matching steps
         # Row-sharded DB: the shards sweep in mixed precision too and the cross-shard merge re-evaluates what their
         # bounded tables leave open through a request / response exchange (sweep_tables; qpg_merge_mixed_*).
         # Two more (small) exchanges buy a sweep at ~1.6x the rate, so it is used where the shard's sweep is long enough
@@ -838,6 +840,15 @@ class CodeKNN:
         q_win, q_t, q_row = cache[M]
         T = dict(aud_d=None, aud_idx=None, aud_rank=None, txt_d=None, txt_idx=None, txt_rank=None)
         sharded = db.world > 1 or self.force_sharded
+        # Round 5: the rank fusion in front of the walk is two independent argmins (audio order, text order:
+        # GestureKNN.py:574-576, :553-555) - each side's half is launched behind its own select on its own stream
+        # (qpg_fuse_best_ranked) into the walk's gate tables, which the walk then takes as they are (QPG_MODE_PREFUSED):
+        # the join of the two streams has half a rank fusion less behind it.  split_fuse = False: one launch in the walk.
+        # (a clip or a few: the fusion is one latency-bound round of blocks and the critical path loses 3-4 us; 16 clips'
+        # worth of steps are throughput-bound and two launches buy nothing: tools/r05_ab_split.sh)
+        split = (for_walk and mode == MODE_AUD_TXT and not sharded and not self.host_ranks and self.split_fuse and
+                 db.K % 16 == 0 and db.K <= 4096 and M * steps <= self.split_fuse_max_steps)
+        gtab = torch.empty((3, max(M, 1) * steps, db.K), dtype=torch.int32, device=dev) if split else None
         lay = None
         if sharded:
             # per-shard tables go straight into the exchange buffer (ExchangeLayout); merged after ONE collective
@@ -912,6 +923,9 @@ class CodeKNN:
             T["txt_d"], T["txt_idx"] = r[0], r[1]
             if not sharded:
                 T["txt_rank"] = r[2]
+            if gtab is not None:            # (on the stream the text select ran on)
+                _lib.call("qpg_fuse_best_ranked", dev, T["txt_rank"], T["txt_idx"], db.pos_rank, db.freq_rank, M * steps,
+                          db.K, gtab[1])
         # Order of the two sides (both modalities on).  Round 1 enqueued the text side first: its kernels ran while the
         # host was still enqueueing the audio side, but its sweep (all CUs, ~56 us) then delayed the audio sweep by as
         # much; with the audio side first and no ordering between the streams the two sweeps contend for the same CUs
@@ -950,6 +964,9 @@ class CodeKNN:
             T["aud_d"], T["aud_idx"] = r[0], r[1]
             if not sharded:
                 T["aud_rank"] = r[2]
+            if gtab is not None:
+                _lib.call("qpg_fuse_best_ranked", dev, T["aud_rank"], T["aud_idx"], db.pos_rank, db.freq_rank, M * steps,
+                          db.K, gtab[0])
         if after:
             with torch.cuda.stream(side):
                 qn_early = None if packed is not None else text_pack()    # one small block, next to the audio sweep
@@ -1014,6 +1031,8 @@ class CodeKNN:
                 if T[p_ + "_d"] is not None:
                     T[p_ + "_rank"] = self.numpy_ranks(T[p_ + "_d"], T[p_ + "_idx"],
                                                        integer=(p_ == "aud" and self.use_wavvq))
+        if gtab is not None:
+            T["gate_tables"] = gtab         # [0], [1]: both modalities' candidates for every (step, previous code)
         return T
 
     def _merge_mixed(self, recv, src_stride, lay, owner_blocks, d, ix, rk, exact=False):
@@ -1126,8 +1145,13 @@ class CodeKNN:
             out_vote = ints_d[n_c:n_c + n_v].view(M, steps)
             status = ints_d[n_c + n_v:]                                  # always written by the walk kernels
         out_phase = torch.empty((CL * M, steps, 8, 16), dtype=torch.float32, device=dev)
-        gate = torch.empty((3, max(CL * M, 1) * steps, db.K), dtype=torch.int32, device=dev)
         q0 = window_offset * steps
+        gate = T.get("gate_tables")
+        prefused = (gate is not None and mode == MODE_AUD_TXT and q0 == 0 and gate.shape[1] == CL * M * steps and
+                    M > 0 and not self.serial_walk)
+        if not prefused:
+            gate = torch.empty((3, max(CL * M, 1) * steps, db.K), dtype=torch.int32, device=dev)
+        mode_w = mode | (0x200 if prefused else 0)             # QPG_MODE_PREFUSED
 
         def sl(t):
             return None if t is None else t[q0:q0 + CL * M * steps]
@@ -1136,12 +1160,12 @@ class CodeKNN:
             # one chain through the batch entry: its seed code is read from memory by the kernels
             _lib.call("qpg_match_steps_batch", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]),
                       sl(T["txt_idx"]), db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
-                      db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode, M, steps, db.K, CL, int(seed_ptrs[0]), sp,
+                      db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode_w, M, steps, db.K, CL, int(seed_ptrs[0]), sp,
                       gate, out_codes, out_phase, out_vote, status, 2, self._guard_stats[1:2])
         else:
             _lib.call("qpg_match_steps", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]), sl(T["txt_idx"]),
                       db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
-                      db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode | (0x100 if self.serial_walk else 0), M,
+                      db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode_w | (0x100 if self.serial_walk else 0), M,
                       steps, db.K, int(seed_code), sp,
                       gate, out_codes, out_phase, out_vote, status, self._guard_stats[1:2])
         if out_pin is not None:
@@ -1184,17 +1208,21 @@ class CodeKNN:
         codes_d = torch.empty((CL, M, num_frames_code), dtype=torch.int32, device=dev)
         votes_d = torch.empty((CL, M, steps), dtype=torch.int32, device=dev)
         out_phase = torch.empty((CL, M, steps, 8, 16), dtype=torch.float32, device=dev)
-        gate = torch.empty((3, CL * M * steps, db.K), dtype=torch.int32, device=dev)
-        a_cidx, a_pslot, a_G = self._audio_grid()
         Qt = CL * M * steps
+        gate = T.get("gate_tables")
+        prefused = gate is not None and mode == MODE_AUD_TXT and gate.shape[1] == Qt
+        if not prefused:
+            gate = torch.empty((3, Qt, db.K), dtype=torch.int32, device=dev)
+        a_cidx, a_pslot, a_G = self._audio_grid()
 
         def sl(t):
             return None if t is None else t[:Qt]
         _lib.call("qpg_match_steps_batch", dev, sl(T["aud_rank"]), sl(T["aud_idx"]), sl(T["txt_rank"]), sl(T["txt_idx"]),
                   db.pos_rank, db.freq_rank, db.code, db.code.shape[1], a_cidx, a_pslot, a_G,
-                  db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode, M, steps, db.K, CL, sc, sp,
-                  gate, codes_d, out_phase, votes_d, status_d, 2, self._guard_stats[1:2])
+                  db.txt_cidx, db.txt_pslot, db.Gt, db.phase, db.Tp, mode | (0x200 if prefused else 0), M, steps, db.K, CL,
+                  sc, sp, gate, codes_d, out_phase, votes_d, status_d, 2, self._guard_stats[1:2])
         self._last_ints = torch.cat((codes_d.view(CL, n_c), votes_d.view(CL, n_v), status_d), dim=1)
+        self._last_gate_tables = gate                       # (tests compare the candidate tables of the two fusion paths)
         return codes_d, out_phase, votes_d
 
     @staticmethod

@@ -228,6 +228,69 @@ __global__ __launch_bounds__(256) void fuse_best_ranked_kernel(const int16_t* __
   }
 }
 
+// One modality's half of fuse_best_ranked_kernel (round 5): T[task] = candidate of the code with the smallest fused score
+// pos_rank[p][c] + 0.05 freq_rank[c] + rank[q][c] - the audio order's and the text order's winners are independent
+// (GestureKNN.py:574-576 / :553-555: two separate argsorts), so each side's launch can follow its own select on its own
+// stream and the join moves behind them.  Same scan, same operations, same tie rule as the two-table kernel.
+__global__ __launch_bounds__(256) void fuse_best_ranked_one_kernel(const int16_t* __restrict__ rank,
+                                                                   const int32_t* __restrict__ idx,
+                                                                   const int16_t* __restrict__ pos_rank,
+                                                                   const int16_t* __restrict__ freq_rank, int Q, int K,
+                                                                   int32_t* __restrict__ T) {
+  extern __shared__ __attribute__((aligned(16))) int16_t inv[];          // [K]
+  __shared__ int bad;
+  const int tid = threadIdx.x, l16 = tid & 15;
+  const int64_t task = (int64_t)blockIdx.x * 16 + (tid >> 4);            // (q, p): one per 16-lane group
+  const int q = (int)(((int64_t)blockIdx.x * 16) / K);
+  const int p = (int)(task - (int64_t)q * K);
+  if (tid == 0) bad = 0;
+  for (int c = tid; c < K; c += blockDim.x) inv[c] = -1;
+  __syncthreads();
+  for (int c = tid; c < K; c += blockDim.x) {
+    const int r = rank[(int64_t)q * K + c];
+    if ((unsigned)r < (unsigned)K) inv[r] = (int16_t)c; else bad = 1;
+  }
+  __syncthreads();
+  for (int c = tid; c < K; c += blockDim.x)
+    if (inv[c] < 0) bad = 1;
+  __syncthreads();
+  const bool full = bad != 0;
+  const int16_t* pr = pos_rank + (int64_t)p * K;
+  const int16_t* rk = rank + (int64_t)q * K;
+  auto xchg = [](ArgMin m, auto tag) {
+    constexpr int PJ = decltype(tag)::value;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(m.v);
+    const unsigned int lo = (unsigned int)lane_xor<PJ>((int)(unsigned int)b);
+    const unsigned int hi = (unsigned int)lane_xor<PJ>((int)(unsigned int)(b >> 32));
+    return ArgMin{__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)), lane_xor<PJ>(m.i)};
+  };
+  ArgMin m{__builtin_inf(), 0x7fffffff};
+  for (int base = 0; base < K; base += 64) {
+    if (!full && (double)base > m.v) break;                   // (m is uniform over the group after the reduction)
+    int c[4];
+    double pv[4], fv[4], rr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = base + 16 * u + l16;
+      const bool ok = r < K;
+      c[u] = ok ? (full ? r : (int)inv[r]) : -1;
+      pv[u] = ok ? (double)pr[c[u]] : 0.0;
+      fv[u] = ok ? (double)freq_rank[c[u]] : 0.0;
+      rr[u] = ok ? (full ? (double)rk[c[u]] : (double)r) : 0.0;
+    }
+    ArgMin x{__builtin_inf(), 0x7fffffff};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c[u] >= 0) x = amin(x, ArgMin{(pv[u] + fv[u] * 0.05) + rr[u], c[u]});
+    x = amin(x, xchg(x, std::integral_constant<int, 8>{}));
+    x = amin(x, xchg(x, std::integral_constant<int, 4>{}));
+    x = amin(x, xchg(x, std::integral_constant<int, 2>{}));
+    x = amin(x, xchg(x, std::integral_constant<int, 1>{}));
+    m = amin(m, x);
+  }
+  if (l16 == 0) T[task] = idx[(int64_t)q * K + m.i];
+}
+
 struct TailArgs {
   const int32_t* T0;         // [Q][K] candidate index of the first gate candidate given previous code p
   const int32_t* T1;         // [Q][K] second gate candidate
@@ -686,6 +749,20 @@ __global__ void status_only_kernel(int32_t* out_status, const int32_t* guard_fla
 
 // From how many chains per launch the gate table is deduplicated by the previous winner (gate_table_dedup_kernel); 0 =
 // never.  Measurement / test hook, process-wide.
+// One modality's gate-candidate table, launched behind that modality's select on ITS stream (sweep_tables for the walk):
+// rank i16 [Q][K] (a permutation per row), idx i32 [Q][K], T i32 [Q][K] = the T0 (audio) or T1 (text) region of the walk's
+// gate_tables.  qpg_match_steps* with QPG_MODE_PREFUSED then starts at the gate table.  K % 16 == 0, K <= 4096.
+extern "C" int qpg_fuse_best_ranked(qpg_ctx* ctx, void* stream, const int16_t* rank, const int32_t* idx,
+                                    const int16_t* pos_rank, const int16_t* freq_rank, int Q, int K, int32_t* T) {
+  QPG_REQUIRE(ctx && rank && idx && pos_rank && freq_rank && T, "qpg_fuse_best_ranked: null pointer");
+  QPG_REQUIRE(Q > 0 && K > 0 && (K % 16) == 0 && K <= 4096 && ((int64_t)Q * K) / 16 < 0x7fffffffll,
+              "qpg_fuse_best_ranked: K %% 16 == 0, K <= 4096");
+  hipLaunchKernelGGL(fuse_best_ranked_one_kernel, dim3((unsigned)(((int64_t)Q * K) / 16)), dim3(256), 2 * (size_t)K,
+                     qpg_stream(stream), rank, idx, pos_rank, freq_rank, Q, K, T);
+  QPG_LAUNCH_CHECK("fuse_best_ranked_one_kernel");
+  return QPG_OK;
+}
+
 static int g_gate_dedup_chains = 1;
 extern "C" int qpg_debug_gate_dedup(int from_chains) {
   QPG_REQUIRE(from_chains >= 0, "qpg_debug_gate_dedup: from_chains >= 0");
@@ -707,7 +784,9 @@ static int match_steps_impl(qpg_ctx* ctx, void* stream, const int16_t* aud_rank,
   QPG_REQUIRE(n_chains >= 1 && (n_chains == 1 || (seed_codes && status_stride >= 2)),
               "qpg_match_steps_batch: n_chains >= 1, device seed codes and a status stride >= 2");
   const bool serial_walk = (mode & QPG_MODE_SERIAL_WALK) != 0;
-  mode &= ~QPG_MODE_SERIAL_WALK;
+  const bool prefused = (mode & QPG_MODE_PREFUSED) != 0;     // T0 | T1 of gate_tables were filled by qpg_fuse_best_ranked
+  mode &= ~(QPG_MODE_SERIAL_WALK | QPG_MODE_PREFUSED);
+  QPG_REQUIRE(!prefused || mode == 0, "qpg_match_steps: QPG_MODE_PREFUSED goes with the two-modality mode");
   QPG_REQUIRE(mode >= 0 && mode <= 2, "qpg_match_steps: bad mode %d", mode);
   QPG_REQUIRE(mode == QPG_MODE_TXT || (aud_rank && aud_idx && aud_cidx && aud_pslot && Ga > 0),
               "qpg_match_steps: audio tables missing");
@@ -727,7 +806,9 @@ static int match_steps_impl(qpg_ctx* ctx, void* stream, const int16_t* aud_rank,
   const int Q = Qc * n_chains;
   int32_t* T0 = gate_tables;
   int32_t* T1 = gate_tables + (int64_t)Q * K;
-  if (mode == 0 && (K % 16) == 0 && K <= 4096) {
+  if (prefused) {
+    // (nothing: both tables are there)
+  } else if (mode == 0 && (K % 16) == 0 && K <= 4096) {
     hipLaunchKernelGGL(fuse_best_ranked_kernel, dim3((unsigned)(((int64_t)Q * K) / 16)), dim3(256), 4 * (size_t)K,
                        qpg_stream(stream), aud_rank, aud_idx, txt_rank, txt_idx, pos_rank, freq_rank, Q, K, T0, T1);
   } else {

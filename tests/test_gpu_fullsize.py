@@ -523,6 +523,49 @@ def test_walk_batch_equals_one_walk_per_clip():
     assert len({tuple(o[0].reshape(-1)) for o in one}) > 1              # the clips really differ
 
 
+def test_rank_fusion_split_by_modality_equals_the_one_launch_fusion():
+    """Round 5: with both modalities on, sweep_tables(for_walk=True) launches each side's half of the rank fusion behind
+    that side's select on its own stream (qpg_fuse_best_ranked) and the walk takes the tables as they are
+    (QPG_MODE_PREFUSED).  The two candidate tables must equal the two-table kernel's bit for bit, and the walks - one clip
+    and a batch of clips, walk-relevance cut on - must return the same codes, votes, phase blocks and status words."""
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    A = _db(110, 320)
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(6))
+    CL, M = 4, 3
+    g = torch.Generator(device="cpu").manual_seed(19)
+    te_i = torch.randn((CL * M, 180, 1024), generator=g).cuda()
+    te_c = torch.randn((CL * M, 30, 384), generator=g).cuda()
+    seeds, phases = [], []
+    for c in range(CL):
+        sc, sp = knn.init_code_phase()
+        seeds.append(sc)
+        phases.append(sp)
+    res = {}
+    knn.split_fuse_max_steps = 1 << 20
+    for split in (False, True):
+        knn.split_fuse = split
+        # one clip of M windows: walk(); CL clips behind one sweep: walk_batch()
+        T1 = knn.sweep_tables(te_i[:M], te_c[:M], M, for_walk=True)
+        assert ("gate_tables" in T1) == split
+        oc, op, ov, st = knn.walk(T1, M, seed_code=seeds[0], seed_phase=phases[0], sync=False)
+        one = (oc.cpu().numpy(), op.cpu().numpy(), ov.cpu().numpy(), st.cpu().numpy())
+        Tb = knn.sweep_tables(te_i, te_c, CL * M, for_walk=True)
+        bc, bp, bv = knn.walk_batch(Tb, M, CL, seeds, np.stack(phases))
+        res[split] = (one, bc.cpu().numpy(), bp.cpu().numpy(), bv.cpu().numpy(), knn._last_ints.cpu().numpy(),
+                      knn._last_gate_tables[:2].cpu().numpy())      # both candidate tables, every (step, previous code)
+        if split:
+            assert knn._last_gate_tables.data_ptr() == Tb["gate_tables"].data_ptr()
+    knn.split_fuse = True
+    a, b = res[False], res[True]
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x, y)
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
+    assert (a[4][:, -2:] == 0).all()
+
+
 def test_walk_results_through_pinned_host_memory():
     """walk(sync="ints"): codes | votes | status written by the walk's last kernel straight into pinned host memory
     (zero-copy) == the device buffer of walk(sync=False); match_clip (sync=True) takes the same route."""

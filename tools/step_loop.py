@@ -35,6 +35,8 @@ if "QPG_GATE_DEDUP" in os.environ:                    # from how many chains the
     from qpgesture_amd import _lib as _l
     _l.load().qpg_debug_gate_dedup(int(os.environ["QPG_GATE_DEDUP"]))
 knn.audio_kernel = os.environ.get("QPG_AUDIO_KERNEL", "hl")
+if "QPG_SPLIT_FUSE" in os.environ:                    # 0: the rank fusion as ONE launch in the walk (rounds 3-5), 1: per modality
+    knn.split_fuse = os.environ["QPG_SPLIT_FUSE"] == "1"
 knn.tie_eps = float(os.environ.get("QPG_TIE_EPS", knn.tie_eps))
 te_i = torch.randn((M * CL, 180, 1024), device=dev)
 te_c = torch.randn((M * CL, 30, 384), device=dev)
