@@ -67,6 +67,13 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #endif
 #define HL_PIECE 1024         // bytes of one [plane][lane][8 f16] fragment image
 
+// value of lane (l ^ PJ), PJ = 16 / 32, through gfx950's permlane swaps (qpg_common.h: lane_xor) - the GEMM epilogues'
+// reductions over a tile's four row groups went through the LDS crossbar (__shfl_xor = ds_bpermute_b32: ~65 cycles each,
+// a wave's do not overlap; 96 of them per 64 x 96 item were a third of hl_gemm64h_kernel: tools/r05_probe_gemm64.sh)
+template <int PJ>
+__device__ __forceinline__ float xor_lanes_f(float v) {
+  return __int_as_float(lane_xor<PJ>(__float_as_int(v)));
+}
 __device__ __forceinline__ f32x4 mfma_h(h8 a, h8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -665,8 +672,8 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void hl_gemm16_kernel(HlArgs a
       *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (int64_t)q * a.ldD + (int64_t)j * 32 + 16 * t + 4 * rg) = o;
     if (a.tmin) {           // the tile's minimum over its 16 rows: lanes cg, cg + 16, cg + 32, cg + 48 hold 4 rows each
       float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
-      m = fminf(m, __shfl_xor(m, 16, 64));
-      m = fminf(m, __shfl_xor(m, 32, 64));
+      m = fminf(m, xor_lanes_f<16>(m));
+      m = fminf(m, xor_lanes_f<32>(m));
       if (rg == 0) a.tmin[(int64_t)q * a.ldT + (int64_t)j * 2 + t] = m;
       if (a.tmask) {
         // round 4: which of the 16 rows lie within the band of the TILE's minimum - a superset of the rows within the
@@ -676,8 +683,8 @@ __global__ __launch_bounds__(HL_THREADS, HL_MINW) void hl_gemm16_kernel(HlArgs a
         unsigned int bits = ((o[0] <= lim) ? 1u : 0u) | ((o[1] <= lim) ? 2u : 0u) | ((o[2] <= lim) ? 4u : 0u) |
                             ((o[3] <= lim) ? 8u : 0u);
         bits <<= 4 * rg;
-        bits |= (unsigned int)__shfl_xor((int)bits, 16, 64);
-        bits |= (unsigned int)__shfl_xor((int)bits, 32, 64);
+        bits |= (unsigned int)lane_xor<16>((int)bits);
+        bits |= (unsigned int)lane_xor<32>((int)bits);
         if (rg == 0) a.tmask[(int64_t)q * a.ldT + (int64_t)j * 2 + t] = (uint16_t)bits;
       }
     }
@@ -1529,16 +1536,16 @@ __global__ __launch_bounds__(512, 2) void hl_gemm32_kernel(HlArgs a, int n_items
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (int64_t)q * a.ldD + (int64_t)j_cur * 32 + 16 * t + 4 * rg) = o;
         if (a.tmin) {
           float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
-          m = fminf(m, __shfl_xor(m, 16, 64));
-          m = fminf(m, __shfl_xor(m, 32, 64));
+          m = fminf(m, xor_lanes_f<16>(m));
+          m = fminf(m, xor_lanes_f<32>(m));
           if (rg == 0) a.tmin[(int64_t)q * a.ldT + (int64_t)j_cur * 2 + t] = m;
           if (a.tmask) {
             const float lim = m + a.band;
             unsigned int bits = ((o[0] <= lim) ? 1u : 0u) | ((o[1] <= lim) ? 2u : 0u) | ((o[2] <= lim) ? 4u : 0u) |
                                 ((o[3] <= lim) ? 8u : 0u);
             bits <<= 4 * rg;
-            bits |= (unsigned int)__shfl_xor((int)bits, 16, 64);
-            bits |= (unsigned int)__shfl_xor((int)bits, 32, 64);
+            bits |= (unsigned int)lane_xor<16>((int)bits);
+            bits |= (unsigned int)lane_xor<32>((int)bits);
             if (rg == 0) a.tmask[(int64_t)q * a.ldT + (int64_t)j_cur * 2 + t] = (uint16_t)bits;
           }
         }
@@ -1563,6 +1570,12 @@ __global__ __launch_bounds__(512, 2) void hl_gemm32_kernel(HlArgs a, int n_items
 // ([tile][a.ldT], a.ldT >= Q: the 16 queries of a column tile are one 64-byte store; the by-code select reads a tile's
 // queries contiguously).  Needs KB % 4 == 0 (D % 128 == 0) and an even number of 32-row groups.
 #define G64_KS 4
+// ablation hooks (experiments/gemm32, tools/r05_probe_gemm64.sh): -DG64_PROBE=<bits>; the product build defines nothing.
+// 1: no epilogue (the accumulators are only kept alive); 2: row fragments from one address (no row stream); 4: no query
+// staging inside the k loop; 8: no MFMAs (loads, staging and epilogue stay); 16: no query-fragment reads from LDS
+#ifndef G64_PROBE
+#define G64_PROBE 0
+#endif
 #ifndef G64_PD
 #define G64_PD 2          // steps between a column tile's fragment read and its use (3 and 5 measured: see DESIGN 4.4)
 #endif
@@ -1637,8 +1650,9 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
     r.ok = 2 * r.jj < a.N;
     r.base = r.ok ? (gbytes_t)(reinterpret_cast<const unsigned char*>(a.db) + (int64_t)r.jj * 4 * KB * 2048)
                   : (gbytes_t)reinterpret_cast<const unsigned char*>(a.zeros);
-    r.t_step = r.ok ? (uint32_t)KB * 2048u : 0u;
-    r.kb_step = r.ok ? 2048u : 0u;
+    r.t_step = (r.ok && !(G64_PROBE & 2)) ? (uint32_t)KB * 2048u : 0u;
+    r.kb_step = (r.ok && !(G64_PROBE & 2)) ? 2048u : 0u;
+    if (G64_PROBE & 2) r.base = (gbytes_t)reinterpret_cast<const unsigned char*>(a.db);
     // (pinned in scalar registers HERE: left alone, hipcc sinks this arithmetic - a division and selects, i.e. branches -
     // into the stage's basic block, next to the refill loads)
     asm volatile("" : "+s"(r.base), "+s"(r.t_step), "+s"(r.kb_step));
@@ -1665,6 +1679,7 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
   static_assert((2 * NS) % (G64_PD + 1) == 0 && NS % (G64_PD + 1) == 0, "the fragment ring index must be static");
 #pragma unroll
   for (int i = 0; i < G64_PD; ++i) ld_b(0, i / CT, i % CT, Bq[i]);
+  if (G64_PROBE & 16) ld_b(0, 0, 0, Bq[G64_PD]);
   int sbuf = 0;                                                        // LDS buffer of the next stage to run
   for (int kk = 0;; ++kk) {
     const int item = vid(kk);
@@ -1682,7 +1697,7 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
         const int ss = PAIR ? sp : sbuf;                               // this stage's LDS buffer
         if (!PAIR) sbuf ^= 1;
         const bool last_s = s + 1 == n_stage;
-        load_q(last_s ? nitem : item, last_s ? 0 : s + 1);            // in flight underneath this stage's MFMAs
+        if (!(G64_PROBE & 4)) load_q(last_s ? nitem : item, last_s ? 0 : s + 1);   // in flight underneath this stage's MFMAs
         // the stage's k-blocks are refilled with the same k-blocks of the next stage - of this item, or (behind its last
         // stage) of the next item's first stage: scalars chosen HERE, so that the stage stays ONE basic block
         gbytes_t rf_base = cur.base + (uint32_t)(s + 1) * G64_KS * cur.kb_step;
@@ -1700,13 +1715,20 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
           h8& Bc = Bq[st % (G64_PD + 1)];                              // (NS % (G64_PD + 1) == 0)
           h8& Bn = Bq[(st + G64_PD) % (G64_PD + 1)];
           if (st == NS - G64_PD) {
-            store_q(ss ^ 1);
+            if (!(G64_PROBE & 4)) store_q(ss ^ 1);
             lds_barrier();
           }
-          if (st >= NS - G64_PD) ld_b(ss ^ 1, (st + G64_PD - NS) / CT, (st + G64_PD - NS) % CT, Bn);
-          else ld_b(ss, (st + G64_PD) / CT, (st + G64_PD) % CT, Bn);
+          if (!(G64_PROBE & 16)) {
+            if (st >= NS - G64_PD) ld_b(ss ^ 1, (st + G64_PD - NS) / CT, (st + G64_PD - NS) % CT, Bn);
+            else ld_b(ss, (st + G64_PD) / CT, (st + G64_PD) % CT, Bn);
+          }
+          if (G64_PROBE & 8) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) hh[t][c] = mfma_h(Ac[t], Bc, hh[t][c]);
+            for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(Ac[t]), "v"(Bc));
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hh[t][c] = mfma_h(Ac[t], Bc, hh[t][c]);
+          }
           if (c == CT - 1) load_a(rf_base, rf_t, (uint32_t)k2 * rf_k, Ac);      // this k-block is done: its slot is refilled
           // issue order (every class named, or hipcc sinks the loads to their uses and waits vmcnt(0) there): the
           // stage's query loads first; per step an MFMA, the fragment read underneath it, three MFMAs; the refill's
@@ -1724,6 +1746,13 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
     const Rows done = cur;
     cur = nxt;
     if (!done.ok) continue;
+    if (G64_PROBE & 1) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(hh[t][c]));
+      continue;
+    }
     const int chunk = item % a.chunks;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -1736,14 +1765,14 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = 1.0f - hh[t][c][r] * sc;
         float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
-        m = fminf(m, __shfl_xor(m, 16, 64));
-        m = fminf(m, __shfl_xor(m, 32, 64));
+        m = fminf(m, xor_lanes_f<16>(m));
+        m = fminf(m, xor_lanes_f<32>(m));
         const float lim = m + a.band;
         unsigned int bits = ((o[0] <= lim) ? 1u : 0u) | ((o[1] <= lim) ? 2u : 0u) | ((o[2] <= lim) ? 4u : 0u) |
                             ((o[3] <= lim) ? 8u : 0u);
         bits <<= 4 * rg;
-        bits |= (unsigned int)__shfl_xor((int)bits, 16, 64);
-        bits |= (unsigned int)__shfl_xor((int)bits, 32, 64);
+        bits |= (unsigned int)lane_xor<16>((int)bits);
+        bits |= (unsigned int)lane_xor<32>((int)bits);
         if (rg == 0) {
           const int64_t o_i = ((int64_t)done.jj * 4 + t) * a.ldT + q;
           a.tmin[o_i] = m;
