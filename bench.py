@@ -1171,6 +1171,21 @@ def vqvae_bench(dev, a, world, rank):
                                      "ids_equal_f32_path": bool(torch.equal(ids16, model.encode(x)[0]))}
     except Exception as e_:                                   # noqa: BLE001
         res["vqvae_encode_f16x3"] = {"error": repr(e_)[:200]}
+    # beside the f32 decode: the split-operand f16 decoder on the signature pass's shape (VisualizeCodebook.py:93-116: every
+    # code's 30-code window, 512 decodes batched as B = 512) - and, honestly, on the 24 s clip, where its general kernel's
+    # ~22 us per launch loses to the short-sequence f32 kernels
+    try:
+        ids512 = torch.arange(512, device=dev).view(512, 1).repeat(1, 30).contiguous()
+        t32b, _, _ = timed(lambda: model.decode([ids512]), 10, 3)
+        t16b, _, _ = timed(lambda: model.decode_f16x3([ids512]), 10, 3)
+        t16c, _, _ = timed(lambda: model.decode_f16x3([ids]), 10, 3)
+        o32, (o16, st16d) = model.decode([ids512]), model.decode_f16x3([ids512], return_stats=True)
+        res["vqvae_decode_f16x3"] = {"signature_pass_512x30_ms": round(t16b * 1e3, 3), "signature_pass_512x30_ms_f32": round(t32b * 1e3, 3),
+                                     "clip_24s_ms": round(t16c * 1e3, 3), "clip_24s_ms_f32": round(td * 1e3, 3),
+                                     "max_abs_pose_difference_vs_f32": float((o32 - o16).abs().max()),
+                                     "redone_in_f32": bool(st16d["activation_outside_f16_range"])}
+    except Exception as e_:                                   # noqa: BLE001
+        res["vqvae_decode_f16x3"] = {"error": repr(e_)[:200]}
     # training step (codebook/train.py:120-131) at the reference's batch size of 256 windows per rank: forward with
     # EMA codebook update, backward, flat-gradient all-reduce (N > 1), Adam
     from qpgesture_amd.optim import Adam

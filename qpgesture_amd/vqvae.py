@@ -524,6 +524,42 @@ class VQVAE:
                 raise IndexError("code id out of range [0,%d)" % self.bins)
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)      # (no copy launch for the usual single chunk)
 
+    def decode_f16x3(self, zs, return_stats=False):
+        """VQVAE.decode on the split-operand f16 convolutions (qpg_conv16_f32: three f16 MFMAs per f32 product, f32
+        accumulation), layer by layer, with the f32 kernels as the referee for RANGE only: poses have no discrete decision
+        to re-check, the outputs agree with decode() to ~1e-5 (tests: <= 1e-4 of the golden poses, the reference's own
+        tolerance), and a sequence whose activations leave the f16 range (the kernels' status word) is decoded again by
+        decode().  Reported BESIDE the f32 figure (bench.py `vqvae_decode_f16x3`), never instead: decode() stays the default.
+        A short sequence's layers are latency-bound chains of f32 matrix instructions (K = 1536 in steps of 4); the f16
+        instruction covers K = 32, which is what shortens them."""
+        assert self._loaded, "load_state_dict first"
+        ids = torch.as_tensor(zs[0]).to(self.device, torch.int64).contiguous()
+        B, L = ids.shape
+        st = getattr(self, "_c16_status", None)
+        if st is None:
+            st = self._c16_status = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        gst = getattr(self, "_dec_status", None)
+        if gst is None:
+            gst = self._dec_status = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        zq = torch.empty((B * L, self.emb), dtype=torch.float32, device=self.device)
+        _lib.call("qpg_vq_gather_f32", self.device, self.k, ids, B * L, self.emb, self.bins, zq, gst)
+        was_training, self.training = self.training, False
+        self._force16 = True
+        try:
+            out = self.decode_latent(zq.view(B, L, self.emb), B, L)
+        finally:
+            self._force16 = False
+            self.training = was_training
+        flags = torch.stack((gst[0], st[0])).cpu().numpy()              # ONE read-back for both words
+        if int(flags[0]):
+            gst.zero_()
+            raise IndexError("code id out of range [0,%d)" % self.bins)
+        redone = bool(int(flags[1]))
+        if redone:
+            st.zero_()
+            out = self.decode(zs)
+        return (out, {"activation_outside_f16_range": redone}) if return_stats else out
+
     # ------------------------------------------------------------------------------------------
     # VQVAE.forward (vqvae.py:183-302): training / validation step
     # ------------------------------------------------------------------------------------------
@@ -602,7 +638,7 @@ class VQVAE:
         """The training step's FORWARD convolutions on the split-f16 kernels (train_precision = "f16x3"; round 5, opt-in:
         three f16 MFMAs per f32 product, f32 accumulation - within ~1e-5 of the f32 kernels, not bit-identical; the backward
         pass stays on the f32 kernels, reading the activations this forward recorded)."""
-        return self.training and getattr(self, "train_precision", "f32") == "f16x3"
+        return (self.training and getattr(self, "train_precision", "f32") == "f16x3") or getattr(self, "_force16", False)
 
     def _res_fwd(self, blocks, x, B, T, reverse, tape, packs=None):
         for d, (c3, c1) in enumerate(blocks):
@@ -616,6 +652,9 @@ class VQVAE:
                 # transposed kernels, as qpg_vq_encode_f32 does below the same threshold (0.17 against 0.27 ms per block)
                 h = self._conv_fwd(c3, x, B, T, T, True, in_offset=-dil, dil=dil, relu_in=True, relu_out=True)
                 y = self._conv_fwd(c1, h, B, T, T, True, residual=x)
+            elif self._train16():
+                h = self._conv16_fwd(c3, x, B, T, T, in_offset=-dil, dil=dil, relu_in=True, relu_out=True)
+                y = self._conv16_fwd(c1, h, B, T, T, residual=x)
             else:
                 h = self._conv(c3, x, B, T, T, in_offset=-dil, dil=dil, relu_in=True, relu_out=True)
                 y = self._conv(c1, h, B, T, T, residual=x)
