@@ -743,9 +743,6 @@ __device__ __forceinline__ double fast_rsqrt_f64(double x) {
 #ifndef H2_PROBE
 #define H2_PROBE 0
 #endif
-#ifndef H2_LAYOUT
-#define H2_LAYOUT 0
-#endif
 #ifndef H2_NT
 #define H2_NT 1          // one query chunk: the image is read ONCE - non-temporal fragment loads (round 5: the kernel with its
 #endif                   // matrix work compiled out takes 130 us with plain loads, 113 with these; 0: plain loads always)
@@ -785,16 +782,9 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
   const uint32_t wj = (uint32_t)(win_ok ? w : a.N - 1 - jb);
   const uint32_t win_units = (uint32_t)(PL == 2 ? HL_WIN_UNITS(KB) : HL1_WIN_UNITS(KB));
   const unsigned char* sbase = reinterpret_cast<const unsigned char*>(a.db) + (int64_t)jb * win_units * 16;
-#if H2_LAYOUT == 1   // TIMING EXPERIMENT (results are garbage): a block's eight windows interleaved per k-block - one 27 KB run
-  constexpr uint32_t rec = (uint32_t)PL * (64 + HL_T1_UNITS);
-  const uint32_t o0 = (wj * rec + (uint32_t)lane) * 16u;
-  const uint32_t o1 = (wj * rec + 64u * PL + 11u * rg + (cg < 11 ? cg : 10)) * 16u;
-  constexpr uint32_t st0 = (H2_PROBE & 1) ? 0u : H2_W * rec * 16u, st1 = st0;
-#else
   const uint32_t o0 = (wj * win_units + (uint32_t)lane) * 16u;
   const uint32_t o1 = (wj * win_units + (uint32_t)KB * (64 * PL) + 11u * rg + (cg < 11 ? cg : 10)) * 16u;
   constexpr uint32_t st0 = (H2_PROBE & 1) ? 0u : 64u * PL * 16u, st1 = (H2_PROBE & 1) ? 0u : (uint32_t)PL * HL_T1_UNITS * 16u;
-#endif
   auto ld_frag = [](const unsigned char* p) -> h8 {
     if (NT) return __builtin_nontemporal_load(reinterpret_cast<const h8*>(p));
     return *reinterpret_cast<const h8*>(p);
