@@ -1584,12 +1584,27 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
   const int xcd = (int)blockIdx.x % nx, lx = (int)blockIdx.x / nx, lpx = nb / nx;
   const int n_rb = n_items / a.chunks;
   const int nit = ((n_rb - xcd + nx - 1) / nx) * a.chunks;             // items of this XCD
-  auto vid = [&](int k) {
-    const int i = k * lpx + lx;
-    return i < nit ? ((i / a.chunks) * nx + xcd) * a.chunks + i % a.chunks : -1;
+  // This block's items: i_k = k lpx + lx < nit, item = (row block (i / chunks) nx + xcd, chunk i % chunks).  The quotient
+  // and remainder are carried from item to item (one division pair per BLOCK; with `item` as a number the loop held ~12
+  // run-time integer divisions per item.  Measured equal - the 34 us of the kernel's "skeleton" in tools/r05_probe_gemm64.sh
+  // are its 64 fragment loads per wave and item going through the CU's 64 B/clk vector L1, not index arithmetic).
+  struct Item {
+    int i, q, rb, ch;                        // sequence number on this XCD, its quotient by chunks, row block (global), chunk
   };
-  const int it0 = vid(0);
-  if (it0 < 0) return;
+  const int dq = lpx / a.chunks, dr = lpx % a.chunks;
+  auto next_item = [&](Item t) {
+    t.i += lpx;
+    t.q += dq;
+    t.ch += dr;
+    if (t.ch >= a.chunks) {
+      t.ch -= a.chunks;
+      ++t.q;
+    }
+    t.rb = t.q * nx + xcd;
+    return t;
+  };
+  if (lx >= nit) return;
+  Item it_cur{lx, lx / a.chunks, (lx / a.chunks) * nx + xcd, lx % a.chunks};
   const int KB = a.KB, n_stage = KB / G64_KS;                          // (KB % 4 == 0; the LDS buffer of a stage: s & 1, dynamic)
   const int cg = lane & 15, rg = lane >> 4;
   const int e_c1 = a.meta[0];
@@ -1604,9 +1619,9 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
     const uint32_t v = (uint32_t)(u * NT + tid);
     qoff[u] = (v >> 6) * 2048u + (v & 63u) * 16u;
   }
-  auto load_q = [&](int item, int s) {                                 // the h pieces of the stage's (k-block, column tile)s
+  auto load_q = [&](int chunk, int s) {                                // the h pieces of the stage's (k-block, column tile)s
     const unsigned char* qsrc = reinterpret_cast<const unsigned char*>(a.qi) +
-                                ((int64_t)(item % a.chunks) * KB + (int64_t)s * G64_KS) * CT * 2048;
+                                ((int64_t)chunk * KB + (int64_t)s * G64_KS) * CT * 2048;
 #pragma unroll
     for (int u = 0; u < QLD; ++u) qreg[u] = *reinterpret_cast<const h8*>(qsrc + qoff[u]);
   };
@@ -1630,13 +1645,9 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
     int jj;
     bool ok;
   };
-  auto rows_of = [&](int item) {
+  auto rows_of = [&](int rb) {
     Rows r;
-#ifdef G64_DUP                                  /* experiment: waves w and w + 4 read the SAME rows (L1 hits: is the kernel L2-bound?) */
-    r.jj = (item / a.chunks) * NW + (w & 3);
-#else
-    r.jj = (item / a.chunks) * NW + w;
-#endif
+    r.jj = rb * NW + w;
     r.ok = 2 * r.jj < a.N;
     r.base = r.ok ? (gbytes_t)(reinterpret_cast<const unsigned char*>(a.db) + (int64_t)r.jj * 4 * KB * 2048)
                   : (gbytes_t)reinterpret_cast<const unsigned char*>(a.zeros);
@@ -1659,8 +1670,8 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
   auto ld_b = [&](int buf, int k2, int c, h8& d) {
     d = (reinterpret_cast<const h8*>(lds) + buf * stage_units + lane)[(k2 * CT + c) * 64];
   };
-  Rows cur = rows_of(it0);
-  load_q(it0, 0);
+  Rows cur = rows_of(it_cur.rb);
+  load_q(it_cur.ch, 0);
 #pragma unroll
   for (int i = 0; i < G64_KS; ++i) load_a(cur.base, cur.t_step, (uint32_t)i * cur.kb_step, A[i]);
   store_q(0);
@@ -1670,16 +1681,44 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
 #pragma unroll
   for (int i = 0; i < G64_PD; ++i) ld_b(0, i / CT, i % CT, Bq[i]);
   if (G64_PROBE & 16) ld_b(0, 0, 0, Bq[G64_PD]);
+  auto epilogue = [&](const Rows& done, int chunk) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const int q = chunk * (16 * CT) + c * 16 + cg;
+      if (q >= a.Q) continue;
+      const float sc = ldexpf(1.0f, -(e_c1 + a.qexp[q]));            // (a power of two: the product below is exact)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = 1.0f - hh[t][c][r] * sc;
+        float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
+        m = fminf(m, xor_lanes_f<16>(m));
+        m = fminf(m, xor_lanes_f<32>(m));
+        const float lim = m + a.band;
+        unsigned int bits = ((o[0] <= lim) ? 1u : 0u) | ((o[1] <= lim) ? 2u : 0u) | ((o[2] <= lim) ? 4u : 0u) |
+                            ((o[3] <= lim) ? 8u : 0u);
+        bits <<= 4 * rg;
+        bits |= (unsigned int)lane_xor<16>((int)bits);
+        bits |= (unsigned int)lane_xor<32>((int)bits);
+        if (rg == 0) {
+          const int64_t o_i = ((int64_t)done.jj * 4 + t) * a.ldT + q;
+          a.tmin[o_i] = m;
+          a.tmask[o_i] = (uint16_t)bits;
+        }
+      }
+    }
+  };
   int sbuf = 0;                                                        // LDS buffer of the next stage to run
-  for (int kk = 0;; ++kk) {
-    const int item = vid(kk);
-    if (item < 0) break;
+  for (;;) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int c = 0; c < CT; ++c) hh[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nitem = vid(kk + 1) >= 0 ? vid(kk + 1) : item;          // (behind the last item: harmless re-reads)
-    const Rows nxt = rows_of(nitem);
+    Item it_nxt = next_item(it_cur);
+    const bool more = it_nxt.i < nit;
+    if (!more) it_nxt = it_cur;                                         // (behind the last item: harmless re-reads)
+    const Rows nxt = rows_of(it_nxt.rb);
     for (int s2 = 0; s2 < n_stage; s2 += PAIR ? 2 : 1) {               // ring slots and the fragment ring's indices are static
 #pragma unroll
       for (int sp = 0; sp < (PAIR ? 2 : 1); ++sp) {
@@ -1687,7 +1726,7 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
         const int ss = PAIR ? sp : sbuf;                               // this stage's LDS buffer
         if (!PAIR) sbuf ^= 1;
         const bool last_s = s + 1 == n_stage;
-        if (!(G64_PROBE & 4)) load_q(last_s ? nitem : item, last_s ? 0 : s + 1);   // in flight underneath this stage's MFMAs
+        if (!(G64_PROBE & 4)) load_q(last_s ? it_nxt.ch : it_cur.ch, last_s ? 0 : s + 1);   // in flight underneath this stage's MFMAs
         // the stage's k-blocks are refilled with the same k-blocks of the next stage - of this item, or (behind its last
         // stage) of the next item's first stage: scalars chosen HERE, so that the stage stays ONE basic block
         gbytes_t rf_base = cur.base + (uint32_t)(s + 1) * G64_KS * cur.kb_step;
@@ -1734,42 +1773,20 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
     }
     // epilogue of the item: d = 1 - hh 2^-(e_c + e_q); lane (cg, rg) holds rows 4 rg .. 4 rg + 3 of column cg
     const Rows done = cur;
+    const int chunk = it_cur.ch;
     cur = nxt;
-    if (!done.ok) continue;
-    if (G64_PROBE & 1) {
+    it_cur = it_nxt;
+    if (done.ok) {
+      if (G64_PROBE & 1) {
 #pragma unroll
-      for (int c = 0; c < CT; ++c)
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(hh[t][c]));
-      continue;
-    }
-    const int chunk = item % a.chunks;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      const int q = chunk * (16 * CT) + c * 16 + cg;
-      if (q >= a.Q) continue;
-      const float sc = ldexpf(1.0f, -(e_c1 + a.qexp[q]));            // (a power of two: the product below is exact)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = 1.0f - hh[t][c][r] * sc;
-        float m = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
-        m = fminf(m, xor_lanes_f<16>(m));
-        m = fminf(m, xor_lanes_f<32>(m));
-        const float lim = m + a.band;
-        unsigned int bits = ((o[0] <= lim) ? 1u : 0u) | ((o[1] <= lim) ? 2u : 0u) | ((o[2] <= lim) ? 4u : 0u) |
-                            ((o[3] <= lim) ? 8u : 0u);
-        bits <<= 4 * rg;
-        bits |= (unsigned int)lane_xor<16>((int)bits);
-        bits |= (unsigned int)lane_xor<32>((int)bits);
-        if (rg == 0) {
-          const int64_t o_i = ((int64_t)done.jj * 4 + t) * a.ldT + q;
-          a.tmin[o_i] = m;
-          a.tmask[o_i] = (uint16_t)bits;
-        }
+          for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(hh[t][c]));
+      } else {
+        epilogue(done, chunk);
       }
     }
+    if (!more) break;                        // (that was the last item)
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // surplus prefetches must not outlive their registers
 }
