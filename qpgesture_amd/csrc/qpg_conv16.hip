@@ -33,6 +33,15 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define C16_BN 128          // output channels per block
 #define C16_BK 32           // contraction slice
 #define C16_SLICE_BYTES 16384   // one operand's slice: 8 tiles x 2 planes x 1 KB
+// ablation hooks (tools/r05_probe_conv16.sh): -DC16_PROBE=<bits>; the product build defines nothing.  1: no MFMAs; 2: no
+// split + LDS stores in the loop; 4: no global requests in the loop; 8: no fragment reads from LDS; 16: no slice barrier;
+// 32: the activation requests of a wave coalesced into one 2 KB run (timing only: wrong values)
+#ifndef C16_PROBE
+#define C16_PROBE 0
+#endif
+#ifndef C16_SGB
+#define C16_SGB 5          // VALU operations named behind every MFMA of a slice (0: hipcc's own order)
+#endif
 
 struct Conv16Args {
   const float* x;          // [B][T_in][Cx] channels-last, Cx % 8 == 0
@@ -74,15 +83,22 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(Conv16Args a) {
   }
   const _Float16* wsrc = a.wimg + (int64_t)nb * n_slice * (C16_SLICE_BYTES / 2);
   f32x4 xr[2][2];
+  bool xok[2];
   h8 wr[4];
   unsigned bad = 0;
   auto fetch = [&](int s) {
     const int tap = s / spt, c0 = (s - tap * spt) * C16_BK + 8 * w;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      // (no branch: a position outside the sequence / a channel group past Cin reads a CLAMPED in-range address and is
+      // zeroed when it is split - a pointer select became control flow and cut the slice into basic blocks)
       const int t_in = st[i] * a.in_stride + a.in_offset + tap * a.dil;
-      const bool ok = slive[i] && t_in >= 0 && t_in < a.T_in && c0 < a.Cin;
-      const f32x4* p = reinterpret_cast<const f32x4*>(ok ? a.x + ((int64_t)sb[i] * a.T_in + t_in) * a.Cx + c0 : a.zeros);
+      xok[i] = ((int)slive[i] & (int)(t_in >= 0) & (int)(t_in < a.T_in) & (int)(c0 < a.Cin)) != 0;   // (&, not &&: no branch)
+      const int t_c = t_in < 0 ? 0 : (t_in < a.T_in ? t_in : a.T_in - 1);
+      const int c_c = c0 + 8 <= a.Cx ? c0 : a.Cx - 8;
+      const f32x4* p = reinterpret_cast<const f32x4*>(a.x + ((int64_t)sb[i] * a.T_in + t_c) * a.Cx + c_c);
+      if (C16_PROBE & 32)     // TIMING ONLY (wrong values): the wave's 64 pieces of 32 bytes as ONE contiguous 2 KB run
+        p = reinterpret_cast<const f32x4*>(a.x + ((int64_t)sb[0] * a.T_in) * a.Cx + (int64_t)(s & 7) * 4096 + w * 1024 + i * 512 + lane * 8);
       xr[i][0] = p[0];
       xr[i][1] = p[1];
     }
@@ -90,6 +106,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(Conv16Args a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) wr[u] = wp[tid + 256 * u];
   };
+  typedef float f32x8_t __attribute__((ext_vector_type(8)));
+  const float relu_lo1 = a.relu_in ? 0.f : -__builtin_inff();
+  const f32x8_t relu_lo = {relu_lo1, relu_lo1, relu_lo1, relu_lo1, relu_lo1, relu_lo1, relu_lo1, relu_lo1};
   auto commit = [&](int buf) {
     h8* wl = reinterpret_cast<h8*>(lds + buf * 2 * C16_SLICE_BYTES);
 #pragma unroll
@@ -97,16 +116,20 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(Conv16Args a) {
     h8* xl = reinterpret_cast<h8*>(lds + buf * 2 * C16_SLICE_BYTES + C16_SLICE_BYTES);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      h8 hh, ll;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = xr[i][e >> 2][e & 3];
-        if (a.relu_in) v = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());
-        bad |= (__builtin_fabsf(v) > 60000.f) ? 1u : 0u;
-        const _Float16 h = (_Float16)v;
-        hh[e] = h;
-        ll[e] = (_Float16)(v - (float)h);
-      }
+      // the split on PACKED operations (round 5, last hours: tools/r05_probe_conv16.sh - this staging, one scalar
+      // conversion at a time, cost the kernel as much as its MFMAs): v_pk_max_f32 for the ReLU, v_cvt_pk_f16_f32 (gfx950,
+      // round to nearest even like the scalar conversion), v_pk_add_f32 for x - h; one range test per eight values
+      typedef float f32x8 __attribute__((ext_vector_type(8)));
+      f32x8 v = __builtin_shufflevector(xr[i][0], xr[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      v = xok[i] ? v : zero8;
+      v = __builtin_elementwise_max(v, relu_lo);                       // (relu_lo = 0 or -inf: no select per element)
+      const f32x8 av = __builtin_elementwise_abs(v);
+      const float m01 = fmaxf(fmaxf(av[0], av[1]), fmaxf(av[2], av[3])), m23 = fmaxf(fmaxf(av[4], av[5]), fmaxf(av[6], av[7]));
+      bad |= (!(fmaxf(m01, m23) <= 60000.f)) ? 1u : 0u;                 // (a NaN fails the test too)
+      const h8 hh = __builtin_convertvector(v, h8);
+      const f32x8 hb = __builtin_convertvector(hh, f32x8);
+      const h8 ll = __builtin_convertvector(v - hb, h8);
       // fragment position of (position p = lane + 64 i, k-group w): tile p / 16, lane (p % 16) + 16 w
       const int p = lane + 64 * i, tile = p >> 4, fl = (p & 15) + 16 * w;
       xl[(tile * 2 + 0) * 64 + fl] = hh;
@@ -121,32 +144,62 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(Conv16Args a) {
 
   fetch(0);
   commit(0);
-  if (n_slice > 1) fetch(1);
+  fetch(n_slice > 1 ? 1 : 0);
   for (int s = 0; s < n_slice; ++s) {
-    __syncthreads();                       // slice s is in buffer s & 1; buffer (s + 1) & 1 was last read in slice s - 1
+    // slice s is in buffer s & 1; buffer (s + 1) & 1 was last read in slice s - 1.  An LDS-only barrier: the global loads
+    // of the slice after next stay in flight across it (__syncthreads() is s_waitcnt vmcnt(0) first)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(C16_PROBE & 16)) __builtin_amdgcn_s_barrier();
     const int buf = s & 1;
     const h8* wl = reinterpret_cast<const h8*>(lds + buf * 2 * C16_SLICE_BYTES) + lane;
     const h8* xl = reinterpret_cast<const h8*>(lds + buf * 2 * C16_SLICE_BYTES + C16_SLICE_BYTES) + lane;
     h8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if ((C16_PROBE & 8) && s > 0) {
+        asm volatile("" : "=v"(ah[i]), "=v"(al[i]), "=v"(bh[i]), "=v"(bl[i]));
+        continue;
+      }
       ah[i] = wl[((4 * wn + i) * 2 + 0) * 64];
       al[i] = wl[((4 * wn + i) * 2 + 1) * 64];
       bh[i] = xl[((4 * wm + i) * 2 + 0) * 64];
       bl[i] = xl[((4 * wm + i) * 2 + 1) * 64];
     }
-    // the next slice's operands go to the other buffer underneath this slice's MFMAs, the slice after next is requested
-    if (s + 1 < n_slice) commit(buf ^ 1);
-    if (s + 2 < n_slice) fetch(s + 2);
+    // The next slice's operands go to the other buffer, the slice after next is requested - UNCONDITIONALLY (behind the
+    // last slices: a harmless re-stage of the last one), so that the slice is ONE basic block and the ~200 VALU
+    // operations of the split (ReLU, range check, two conversions and a subtraction per element) + the LDS stores + the
+    // address arithmetic of the requests can be issued UNDERNEATH the 48 MFMAs instead of in front of them (round 5, last
+    // hours: hipcc had left the four phases - fragment reads, split + stores, requests, MFMAs - one after the other;
+    // with two waves per SIMD the matrix pipe idled half the time).
+    if (!(C16_PROBE & 2)) commit(buf ^ 1);
+    if (!(C16_PROBE & 4)) fetch(s + 2 < n_slice ? s + 2 : n_slice - 1);
+    if (C16_PROBE & 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
+    } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[i][j] = mfma16h(ah[i], bl[j], acc[i][j]);
-        acc[i][j] = mfma16h(al[i], bh[j], acc[i][j]);
-        acc[i][j] = mfma16h(ah[i], bh[j], acc[i][j]);
-      }
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = mfma16h(ah[i], bl[j], acc[i][j]);
+          acc[i][j] = mfma16h(al[i], bh[j], acc[i][j]);
+          acc[i][j] = mfma16h(ah[i], bh[j], acc[i][j]);
+        }
+    }
+#if C16_SGB
+    // issue order: the 16 fragment reads up front (the first MFMAs need them), then per MFMA a few VALU operations of the
+    // split; the LDS stores and the requests spread over the MFMAs behind the conversions that feed them
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+      if (i == 0) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, C16_SGB, 0);
+      if (i >= 16 && (i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      if (i >= 32 && (i & 1) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+#endif
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the surplus request must not outlive its registers)
   if (bad && a.status) atomicOr(a.status, 1);
   // ---- epilogue: lane (cg = lane & 15 -> position, rg = lane >> 4 -> channels 4 rg .. 4 rg + 3 of a 16-channel tile)
   const int cg = lane & 15, rg = lane >> 4;
