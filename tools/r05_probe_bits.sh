@@ -1,5 +1,5 @@
 #!/bin/bash
-# bottom-up ablations of the two-plane sweep (experiments/audio_hl/libqpg_p<bits>.so, -DH2_PROBE=<bits>): 1 no HBM stream,
+# bottom-up ablations of the two-plane sweep (experiments/audio_hl/libqpg_p<bits>.so from tools/build_variant.sh qpg_audio_hl p<bits> "-DH2_PROBE=<bits>" experiments/audio_hl): 1 no HBM stream,
 # 2 no f64 flush, 8 no stage barrier, 16 no query-fragment reads from LDS, 32 no query staging; two alternating rounds
 cd "$(dirname "$0")/.."
 O=gpurun_out/r05p; mkdir -p $O
