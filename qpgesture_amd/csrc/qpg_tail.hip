@@ -747,8 +747,6 @@ __global__ void status_only_kernel(int32_t* out_status, const int32_t* guard_fla
   out_status[1] = guard_flags ? guard_flags[0] : 0;
 }
 
-// From how many chains per launch the gate table is deduplicated by the previous winner (gate_table_dedup_kernel); 0 =
-// never.  Measurement / test hook, process-wide.
 // One modality's gate-candidate table, launched behind that modality's select on ITS stream (sweep_tables for the walk):
 // rank i16 [Q][K] (a permutation per row), idx i32 [Q][K], T i32 [Q][K] = the T0 (audio) or T1 (text) region of the walk's
 // gate_tables.  qpg_match_steps* with QPG_MODE_PREFUSED then starts at the gate table.  K % 16 == 0, K <= 4096.
@@ -763,6 +761,8 @@ extern "C" int qpg_fuse_best_ranked(qpg_ctx* ctx, void* stream, const int16_t* r
   return QPG_OK;
 }
 
+// From how many chains per launch the gate table is deduplicated by the previous winner (gate_table_dedup_kernel); 0 =
+// never.  Measurement / test hook, process-wide.
 static int g_gate_dedup_chains = 1;
 extern "C" int qpg_debug_gate_dedup(int from_chains) {
   QPG_REQUIRE(from_chains >= 0, "qpg_debug_gate_dedup: from_chains >= 0");
