@@ -535,7 +535,7 @@ __device__ __forceinline__ double pair_dot_wave_f64(const GuardArgs& A, int q, i
 }
 
 // Workspace of the cut launch: per query [parking space | streamed state].
-//   parking space   best u64 K | v f64 K | besti u32 K | near u32 K | n, pad (16 B) | l_c i32 L | l_k i32 L | l_d f64 L
+//   parking space   best u64 K | v f64 K | besti u32 K | near u32 K | n, order-valid, pad (16 B) | l_c i32 L | l_k i32 L | l_d f64 L | order i16 K
 //   streamed state  inv u32 K (NOT of the minimum's order key, merged by atomicMax: all-zero = empty) | survivors of each
 //                   slice i32 [MIX_SPLIT] (-1: its list overflowed) | pot_c i32 P | pot_d f32 P | pot_k i16 P
 //                   (P = MIX_SPLIT x MIX_SPOT: slice s owns entries [s MIX_SPOT, (s + 1) MIX_SPOT) - no global counter)
@@ -544,7 +544,10 @@ __device__ __forceinline__ double pair_dot_wave_f64(const GuardArgs& A, int q, i
 #define MIX_SPLIT 8       // blocks per query streaming the row
 #define MIX_SPOT 3072     // potential band members a slice can hold in LDS
 #define MIX_GPOT (MIX_SPLIT * MIX_SPOT)
-__host__ __device__ __forceinline__ size_t mix_park_bytes(int K) {
+__host__ __device__ __forceinline__ size_t mix_park_bytes(int K) {      // (... | order i16 K: the cut's sorted order, round 5)
+  return 24 * (size_t)K + 16 + 8 * (size_t)MIX_LIST + 8 * (size_t)MIX_LIST + ((2 * (size_t)K + 15) & ~(size_t)15);
+}
+__host__ __device__ __forceinline__ size_t mix_park_order_off(int K) {
   return 24 * (size_t)K + 16 + 8 * (size_t)MIX_LIST + 8 * (size_t)MIX_LIST;
 }
 __host__ __device__ __forceinline__ size_t mix_ws_stride(int K) {          // bytes of one query's space (multiple of 16)
@@ -798,6 +801,7 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
     });
   };
   int n = 0;
+  bool order_parked = false;                                   // (the cut's sorted order went to the parking space)
   if (phase != 2) {
   constexpr int VE = 16 / (int)sizeof(DT);                    // matrix elements per 16-byte load
   typedef DT vecD __attribute__((ext_vector_type(VE)));
@@ -972,6 +976,10 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       rk[k] = r;
     });
     __syncthreads();
+    // (parked for the merge launch: the refined table differs from this one in a few near-tied entries, so its ranks are
+    // this order + a local repair instead of a second sort of the 512 values)
+    for (int r = tid; r < K; r += blockDim.x) reinterpret_cast<int16_t*>(wq + mix_park_order_off(K))[r] = (int16_t)s_code[r];
+    order_parked = true;
     SEL_STAMP(13);
     for (int r = tid; r < K; r += blockDim.x) {
       const int k = s_code[r];
@@ -1185,7 +1193,10 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
       w_lc[e] = l_c[e];
       w_lk[e] = l_k[e];
     }
-    if (tid == 0) w_n[0] = n;
+    if (tid == 0) {
+      w_n[0] = n;
+      w_n[1] = order_parked ? 1 : 0;         // the parked order is this launch's
+    }
     SEL_STAMP(6);
     return;
   }
@@ -1305,7 +1316,37 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   if (!out_rank) return;
   if (tid == 0) ctl[2] = 0;
   __syncthreads();
-  rank_pass(true);
+  // Merge launch behind a cut list launch: the order of the sweep values is parked; the refined values differ from them
+  // in the few re-evaluated codes, each by less than the band - the (value, code) order is restored by odd-even
+  // transposition passes over the parked order (a pass = 2 barriers; one or two rounds on a typical row against the 45
+  // stages of the sort), and a row that is not settled after 24 rounds (a flagged, crowded one) is sorted the ordinary way.
+  bool repaired = false;
+  if (phase == 2 && RC.pos_t && reinterpret_cast<const int*>(wq + 24 * (size_t)K)[1] == 1) {
+    const int16_t* w_order = reinterpret_cast<const int16_t*>(wq + mix_park_order_off(K));
+    for (int r = tid; r < K; r += blockDim.x) s_code[r] = w_order[r];
+    __syncthreads();
+    for (int round = 0; round < 24 && !repaired; ++round) {
+      if (tid == 0) ctl[5] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int parity = 0; parity < 2; ++parity) {
+        for (int r = 2 * tid + parity; r + 1 < K; r += 2 * blockDim.x) {
+          const int ka = s_code[r], kb = s_code[r + 1];
+          if (rank_gt(rank_sort_key(v[ka]), ka, rank_sort_key(v[kb]), kb)) {
+            s_code[r] = kb;
+            s_code[r + 1] = ka;
+            ctl[5] = 1;
+          }
+        }
+        __syncthreads();
+      }
+      repaired = ctl[5] == 0;
+      __syncthreads();
+    }
+    if (repaired)
+      for (int r = tid; r < K; r += blockDim.x) out_rank[(int64_t)q * K + s_code[r]] = (int16_t)r;
+  }
+  if (!repaired) rank_pass(true);
   SEL_STAMP(9);
   if (A.eps <= 0.0) return;
   __syncthreads();
