@@ -553,6 +553,8 @@ def main():
                      "frames_per_s": round(240 * M * n_clips * a.steps / de, 1),
                      "codes_equal_graph_steps": bool(np.array_equal(np.asarray(ce).reshape(-1), codes.numpy().reshape(-1)))}
     ms = [e0.elapsed_time(e1) for e0, e1 in knn.kernel_events] if knn.kernel_events else [float("nan")]
+    if os.environ.get("QPG_BENCH_DUMP_KERNEL_MS"):          # (measurement aid: the eager leg's per-step sweep times, in order)
+        print("kernel_ms per eager step:", " ".join("%.0f" % (1e3 * v) for v in ms), file=sys.stderr)
     knn.kernel_events = None
     if pipe is not None:
         for ln in pipe.lanes:
