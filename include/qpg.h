@@ -36,6 +36,10 @@ extern "C" {
 typedef struct qpg_ctx qpg_ctx;
 
 int qpg_version(void);
+/* First 16 hex digits of the SHA-256 over the sources the library was compiled from (every .hip and .h file of csrc/
+ * in name order, then include/qpg.h: qpgesture_amd/build.py:source_hash()); "unstamped" for a build that bypassed build.py.  The Python binding
+ * refuses to run a library whose id differs from the tree it sits in (it rebuilds it). */
+const char* qpg_build_id(void);
 /* One context per device, created by the host thread that drives that device.
  * PERFORMANCE NOTE for direct callers: the matcher is a chain of a dozen short dependent launches per clip, and the HIP
  * runtime hands their arguments to the command processor through device memory only when the environment variable
@@ -44,6 +48,14 @@ int qpg_version(void);
 int qpg_ctx_create(int device, qpg_ctx** out);
 int qpg_dev_kernarg(void);
 int qpg_ctx_destroy(qpg_ctx* ctx);
+/* Per-context knobs (the library holds no other mutable state; a knob of one context never affects another):
+ *   QPG_OPT_GATE_DEDUP_FROM_CHAINS  from how many chains per qpg_match_steps(_batch) launch the phase-gate table is
+ *                                   deduplicated by the previous winner (default 1 = always; 0 = never: round 4's plain
+ *                                   table, bit-identical results - the tests walk on both). */
+#define QPG_OPT_GATE_DEDUP_FROM_CHAINS 0
+#define QPG_OPT_COUNT 4
+int qpg_ctx_set_option(qpg_ctx* ctx, int option, int value);
+int qpg_ctx_get_option(qpg_ctx* ctx, int option, int* value);
 int qpg_last_error(char* buf, size_t n);
 
 /* ------------------------------------------------------------------------------------------
@@ -185,7 +197,7 @@ int qpg_audio_cosine_hl1(qpg_ctx*, void* stream, const void* db_image, int N, in
 /* Hardware probe behind the bound's one measured constant: out[tile] = A[tile] (16 x 32 f16) . B[tile]^T (16 x 32 f16)
  * + C[tile] (16 x 16 f32, NULL = 0) exactly as ONE v_mfma_f32_16x16x32_f16 computes it; the tests compare it with exact
  * sums (kappa: error of a 32-product block sum in units of 2^-24 sum |products|). */
-int qpg_debug_mfma_f16_tile(qpg_ctx*, void* stream, const void* a, const void* b, const float* c, int tiles, float* out);
+int qpg_probe_mfma_f16_tile(qpg_ctx*, void* stream, const void* a, const void* b, const float* c, int tiles, float* out);
 
 /* One-off DB preparation for the text sweep: sklearn-normalise the grid rows x[j][cand_r[g]] (bit-exact,
  * as qpg_l2_normalize_rows_f32) and store them tiled for lane-per-candidate access:
@@ -278,9 +290,6 @@ int qpg_hl_gemm_tilemin(qpg_ctx*, void* stream, const void* rows_image, int64_t 
 int qpg_hl_gemm_tilemin_h(qpg_ctx*, void* stream, const void* rows_image, int64_t R, int D, const void* cols_image, int Q,
                           float band, float* tile_min_t, uint16_t* tile_mask_t, int64_t ldQ);
 int qpg_perm32_rows_f32(qpg_ctx*, void* stream, const float* x, int64_t R, int D, float* y);
-/* Measurement hook: waves per block of qpg_hl_gemm_tilemin_h's kernel - 4 (two blocks per CU: one block's epilogue under the
- * other's MFMAs; the default) or 8 (one block per CU).  Process-wide. */
-int qpg_debug_gemm64_waves(int nw);
 int qpg_percode_select_bycode_f32(qpg_ctx*, void* stream, const float* tile_min_t, const uint16_t* tile_mask_t, int64_t ldQ,
                                   int Q, int64_t R, const int16_t* row_code, const int32_t* row_index,
                                   const int32_t* zero_row, const int32_t* code_tile, int K, float band,
@@ -516,10 +525,9 @@ int qpg_match_steps_batch(qpg_ctx*, void* stream, const int16_t* aud_rank, const
  * table and the join of the two streams has half a rank fusion less in front of it.  K % 16 == 0, K <= 4096. */
 int qpg_fuse_best_ranked(qpg_ctx*, void* stream, const int16_t* rank, const int32_t* idx, const int16_t* pos_rank,
                          const int16_t* freq_rank, int Q, int K, int32_t* T);
-/* Measurement / test hook: from how many chains per launch qpg_match_steps_batch deduplicates the gate table by the previous
- * step's winner (one evaluation per DISTINCT winner instead of one per (previous code, vote) state; same table, bit for
- * bit).  Default 1 (always, for K <= 512); 0: never.  Process-wide. */
-int qpg_debug_gate_dedup(int from_chains);
+/* (From how many chains per launch qpg_match_steps_batch deduplicates the gate table by the previous step's winner - one
+ * evaluation per DISTINCT winner instead of one per (previous code, vote) state; same table, bit for bit - is the context's
+ * QPG_OPT_GATE_DEDUP_FROM_CHAINS: qpg_ctx_set_option.) */
 
 /* ------------------------------------------------------------------------------------------
  * Library-owned collectives of the row-sharded matcher (round 5).  The reference has no
@@ -588,13 +596,6 @@ int qpg_convt_pair_f32(qpg_ctx*, void* stream, const float* x, int B, int T_in, 
                        const float* bias0, int in_offset0, int out_offset0, const float* wt1, const float* bias1,
                        int in_offset1, int out_offset1, int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride,
                        int dil, int T_out, int out_stride, int T_y, float* y);
-/* Measurement hook (tools/bench_convt_small.py): force the short-sequence kernel's block shape - nq in {1, 2, 4}
- * channel tiles of 16, pd in {0, 4} fragment-ring depth; nq = 0 restores the launcher's own choice.  Process-wide. */
-int qpg_debug_convt_shape(int nq, int pd);
-/* Measurement hook (tools/bench_decode.py, round 5): deep_ring = a wave's whole share of 8 / 12 k-blocks requested up front
- * (k3 / up-convolution layers), xcd_map = a channel group's blocks all on one XCD.  Both measured (slower / no
- * difference: csrc/qpg_convt.hip) and OFF by default.  Process-wide. */
-int qpg_debug_convt_opts(int deep_ring, int xcd_map);
 /* T-pack of a convolution's weights on the device: w [dev] f32 [taps x Cin_pad][Cout_pad] (qpg_conv1d_f32's layout, the one
  * the optimiser updates) -> out [dev] f32, the wt of qpg_convt_f32 (nb = 128) or one half of qpg_resblock_f32's wpack
  * (nb = 512 for the dilated convolution): taps x Cin_pad x (Cout_pad rounded up to nb) floats. */
@@ -757,6 +758,19 @@ int qpg_conv1d_bwd_weight_f32(qpg_ctx*, void* stream, const float* x, int B, int
                               int taps, int Cin_pad, int Cout, int Cout_pad, int in_stride, int in_offset, int dil,
                               int T_out, int out_stride, int out_offset, int T_y, int relu_in, float* dw, float* db,
                               int accumulate_bias, float* ws, int64_t ws_floats);
+
+/* ------------------------------------------------------------------------------------------
+ * NOT part of the product library: measurement hooks of the kernel experiments.  They are compiled (and exported) only
+ * with -DQPG_DEBUG_HOOKS (tools/build_variant.sh <source> <name> "-DQPG_DEBUG_HOOKS": a variant library the tools load
+ * through QPG_LIB_PATH); in libqpg_hip.so every one of these knobs is a compile-time constant and the symbols do not
+ * exist (tests/test_host_cpu.py asserts that).  Process-wide where they exist.
+ * ---------------------------------------------------------------------------------------- */
+#ifdef QPG_DEBUG_HOOKS
+int qpg_debug_gemm64_waves(int nw);                  /* waves per block of qpg_hl_gemm_tilemin_h's kernel: 4 (default) or 8 */
+int qpg_debug_convt_shape(int nq, int pd);           /* force the short-sequence convolution kernel's block shape */
+int qpg_debug_convt_opts(int deep_ring, int xcd_map);/* deep fragment ring / XCD map of that kernel (measured, off) */
+int qpg_debug_select_prof(long long* out);           /* -DQPG_SELECT_PROF section timers of the mixed select */
+#endif
 
 #ifdef __cplusplus
 }

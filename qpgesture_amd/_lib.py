@@ -40,7 +40,7 @@ _SIGS = {
     "qpg_audio_cosine_hl": [P, I, I, I, P, P, P, I, P, I, L, P],
     "qpg_audio_hl1_pack_db": [P, I, I, I, I, I, I, I, P, L],
     "qpg_audio_cosine_hl1": [P, I, I, I, P, P, P, I, P, I, L, P],
-    "qpg_debug_mfma_f16_tile": [P, P, P, I, P],
+    "qpg_probe_mfma_f16_tile": [P, P, P, I, P],
     "qpg_hl_pack_rows": [P, L, I, P, L],
     "qpg_hl_pack_cols": [P, I, I, P, L],
     "qpg_hl_gemm_distance": [P, L, I, P, I, P, L, P, L],
@@ -134,11 +134,22 @@ class VqModel(ctypes.Structure):
                 ("dec_res_pack", (c_void_p * QPG_VQ_MAX_DEPTH) * QPG_VQ_MAX_DOWN)]
 
 
+_HOOKS_RE = re.compile(r"#ifdef QPG_DEBUG_HOOKS\n(.*?)#endif", re.S)
+
+
 def declared_symbols():
-    """Every function name include/qpg.h declares (used by the CPU symbol-export test)."""
+    """Every function name include/qpg.h declares for the PRODUCT library (used by the CPU symbol-export test); the
+    #ifdef QPG_DEBUG_HOOKS block - experiment builds only - is debug_hook_symbols()."""
     txt = open(HEADER_PATH).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = _HOOKS_RE.sub("", txt)
     return sorted(set(re.findall(r"\b(qpg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def debug_hook_symbols():
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(n for blk in _HOOKS_RE.findall(txt) for n in re.findall(r"\b(qpg_[a-z0-9_]+)\s*\(", blk)))
 
 
 def load():
@@ -150,8 +161,19 @@ def load():
         raise RuntimeError(
             "libqpg_hip.so is missing (%s). Build it with `python -m qpgesture_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no fallback path." % LIB_PATH)
+    if not os.environ.get("QPG_LIB_PATH"):
+        # the in-tree library must be the one compiled from THIS tree's sources (a stale prebuilt would be tested and
+        # benchmarked as if it were HEAD): compare its stamped id with the tree's hash BEFORE mapping it; rebuild on a mismatch
+        from . import build as _build
+        want = _build.source_hash()
+        if _build.lib_build_id(LIB_PATH) != want:
+            _build.build_lib(verbose=False)
     lib = ctypes.CDLL(LIB_PATH)
     lib.qpg_version.restype = c_int
+    lib.qpg_build_id.restype = ctypes.c_char_p
+    lib.qpg_build_id.argtypes = []
+    lib.qpg_ctx_set_option.argtypes = [c_void_p, c_int, c_int]
+    lib.qpg_ctx_get_option.argtypes = [c_void_p, c_int, ctypes.POINTER(c_int)]
     lib.qpg_ctx_create.argtypes = [c_int, ctypes.POINTER(c_void_p)]
     lib.qpg_ctx_create.restype = c_int
     lib.qpg_ctx_destroy.argtypes = [c_void_p]
@@ -189,10 +211,10 @@ def load():
     lib.qpg_comm_unique_id.argtypes = [ctypes.c_char_p, c_int64]
     lib.qpg_comm_create.argtypes = [c_void_p, ctypes.c_char_p, c_int64, c_int, c_int, ctypes.POINTER(c_void_p)]
     lib.qpg_comm_destroy.argtypes = [c_void_p]
-    lib.qpg_debug_convt_shape.argtypes = [c_int, c_int]
-    lib.qpg_debug_convt_opts.argtypes = [c_int, c_int]
-    lib.qpg_debug_gemm64_waves.argtypes = [c_int]
-    lib.qpg_debug_gate_dedup.argtypes = [c_int]
+    for name, at in (("qpg_debug_convt_shape", [c_int, c_int]), ("qpg_debug_convt_opts", [c_int, c_int]),
+                     ("qpg_debug_gemm64_waves", [c_int])):      # -DQPG_DEBUG_HOOKS variant libraries only (QPG_LIB_PATH)
+        if hasattr(lib, name):
+            getattr(lib, name).argtypes = at
     lib.qpg_vq_reduce_ws_bytes.argtypes = []
     lib.qpg_vq_reduce_ws_bytes.restype = c_int64
     for name, sig in _SIGS.items():
@@ -201,6 +223,16 @@ def load():
         fn.restype = c_int
     _lib = lib
     return lib
+
+
+QPG_OPT_GATE_DEDUP_FROM_CHAINS = 0
+
+
+def set_option(device, option, value):
+    """qpg_ctx_set_option on `device`'s context (per-context knob, include/qpg.h)."""
+    rc = load().qpg_ctx_set_option(ctx(device), option, value)
+    if rc != 0:
+        raise RuntimeError("qpg_ctx_set_option failed (%d): %s" % (rc, last_error()))
 
 
 def last_error():

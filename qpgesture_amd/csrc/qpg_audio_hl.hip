@@ -1793,13 +1793,15 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
 
 // The h-plane prefilter (hl_gemm64h_kernel): tile minima + row masks, TILE-MAJOR: tile_min / tile_mask [R / 16][ldQ],
 // ldQ >= Q.  `band` must cover QPG_HL_GEMM_H_ERR (sorted_rows.gemm_h_err).  Needs D % 256 == 0 and R % 64 == 0.
-// Measurement hook: waves per block of hl_gemm64h_kernel (8: one block per CU; 4: two).  Process-wide.
-static int g_gemm64_nw = 4;
+// Measurement hook (-DQPG_DEBUG_HOOKS builds only): waves per block of hl_gemm64h_kernel (8: one block per CU; 4: two).
+QPG_HOOK_VAR(int, g_gemm64_nw, 4);
+#ifdef QPG_DEBUG_HOOKS
 extern "C" int qpg_debug_gemm64_waves(int nw) {
   QPG_REQUIRE(nw == 4 || nw == 8, "qpg_debug_gemm64_waves: 4 or 8");
   g_gemm64_nw = nw;
   return QPG_OK;
 }
+#endif
 
 extern "C" int qpg_hl_gemm_tilemin_h(qpg_ctx* ctx, void* stream, const void* rows_image, int64_t R, int D,
                                      const void* cols_image, int Q, float band, float* tile_min, uint16_t* tile_mask,
@@ -1931,9 +1933,9 @@ __global__ __launch_bounds__(64) void hl_probe_kernel(const _Float16* __restrict
   for (int r = 0; r < 4; ++r) out[(int64_t)tile * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = d[r];
 }
 
-extern "C" int qpg_debug_mfma_f16_tile(qpg_ctx* ctx, void* stream, const void* a, const void* b, const float* c, int tiles,
+extern "C" int qpg_probe_mfma_f16_tile(qpg_ctx* ctx, void* stream, const void* a, const void* b, const float* c, int tiles,
                                        float* out) {
-  QPG_REQUIRE(ctx && a && b && out && tiles > 0, "qpg_debug_mfma_f16_tile: bad argument");
+  QPG_REQUIRE(ctx && a && b && out && tiles > 0, "qpg_probe_mfma_f16_tile: bad argument");
   hipLaunchKernelGGL(hl_probe_kernel, dim3(tiles), dim3(64), 0, qpg_stream(stream), static_cast<const _Float16*>(a),
                      static_cast<const _Float16*>(b), c, out);
   QPG_LAUNCH_CHECK("hl_probe_kernel");

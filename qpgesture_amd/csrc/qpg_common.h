@@ -12,7 +12,17 @@ struct qpg_ctx {
   int n_cu;
   float* zeros;   // 4 KB of device zeros: out-of-range tile loads are redirected here instead of being selected to 0
   bool select_lds_raised;   // percode_select_mixed_f64_kernel's dynamic-LDS limit has been raised on this device
+  int opt[QPG_OPT_COUNT];   // qpg_ctx_set_option / qpg_ctx_get_option (include/qpg.h): per-context knobs, never process-wide
 };
+
+// Measurement knobs of the kernel experiments (tools/, experiments/): they exist only in a -DQPG_DEBUG_HOOKS build
+// (tools/build_variant.sh ... "-DQPG_DEBUG_HOOKS"); in the product library each one is a compile-time constant and the
+// qpg_debug_* setters are not exported (no global mutable state except the opaque context).
+#ifdef QPG_DEBUG_HOOKS
+#define QPG_HOOK_VAR(type, name, value) static type name = value
+#else
+#define QPG_HOOK_VAR(type, name, value) static constexpr type name = value
+#endif
 
 void qpg_set_error(const char* fmt, ...);
 

@@ -577,16 +577,22 @@ __global__ __launch_bounds__(64 * CTS_NW) void convt_small_f32_kernel(ConvTArgs 
 // layers are bound by the rate at which ~190-720 blocks pull their tiles out of L2, not by round trips - more requests
 // in flight only lengthen every queue, and 176 VGPRs halve the waves per SIMD); XCD map 0.285-0.290 (no difference: a
 // layer's 1-4 MB of weights fit every XCD's L2 anyway).  Both stay OFF.
-static int g_deep_ring = 0, g_xcd_map = 0;
+// (-DQPG_DEBUG_HOOKS builds only; constants in the product)
+QPG_HOOK_VAR(int, g_deep_ring, 0);
+QPG_HOOK_VAR(int, g_xcd_map, 0);
+#ifdef QPG_DEBUG_HOOKS
 extern "C" int qpg_debug_convt_opts(int deep_ring, int xcd_map) {
   g_deep_ring = deep_ring != 0;
   g_xcd_map = xcd_map != 0;
   return QPG_OK;
 }
+#endif
 
 // Measurement hook: force the short-sequence kernel's block shape (nq in {1, 2, 4} channel tiles, pd in {0, 4} ring
-// depth); nq = 0 restores the launcher's own choice.  Not thread-safe, not for production callers.
-static int g_force_nq = 0, g_force_pd = 0;
+// depth); nq = 0 restores the launcher's own choice.  -DQPG_DEBUG_HOOKS builds only; constants in the product.
+QPG_HOOK_VAR(int, g_force_nq, 0);
+QPG_HOOK_VAR(int, g_force_pd, 0);
+#ifdef QPG_DEBUG_HOOKS
 extern "C" int qpg_debug_convt_shape(int nq, int pd) {
   QPG_REQUIRE((nq == 0 || nq == 1 || nq == 2 || nq == 4 || nq == 8) && (pd == 0 || pd == 4),
               "qpg_debug_convt_shape: nq in {0,1,2,4} (8: the 64 x 128 kernel whatever the size), pd in {0,4}");
@@ -594,6 +600,7 @@ extern "C" int qpg_debug_convt_shape(int nq, int pd) {
   g_force_pd = pd;
   return QPG_OK;
 }
+#endif
 
 // nz = 2: the pair form (a.wt1 / bias1 / in_offset1 / out_offset1 set); the generic kernel then takes two launches
 static int convt_launch(qpg_ctx* ctx, void* stream, ConvTArgs a, int Cout_pad, int nz) {

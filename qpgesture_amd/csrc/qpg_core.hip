@@ -13,7 +13,16 @@ void qpg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int qpg_version(void) { return 106; }          // 1.06: round 5 (qpg_audio_cosine_hl1, qpg_comm_*, qpg_conv16_*, qpg_hl_gemm_tilemin_h, qpg_percode_select_bycode_f32, ...: include/qpg.h)
+extern "C" int qpg_version(void) { return 107; }          // 1.07: round 6 (qpg_build_id, qpg_ctx_set_option; the qpg_debug_* setters left the product: include/qpg.h)
+
+// The SHA-256 (first 16 hex digits) of the sources this library was compiled from - csrc/*.hip, csrc/*.h, include/qpg.h in
+// name order, as qpgesture_amd/build.py computes it and passes it to THIS file's compile (-DQPG_BUILD_ID).  _lib.load()
+// compares it with the tree it finds itself in and rebuilds on a mismatch; tests/test_host_cpu.py asserts the equality.
+#ifndef QPG_BUILD_ID
+#define QPG_BUILD_ID "unstamped"
+#endif
+static const char g_build_id[] = "QPG_BUILD_ID=" QPG_BUILD_ID;       // (build.py reads the marker out of the file, no dlopen)
+extern "C" const char* qpg_build_id(void) { return g_build_id + 13; }
 
 // Is HIP_FORCE_DEV_KERNARG=1 in this process's environment? (see qpg_ctx_create in include/qpg.h)
 extern "C" int qpg_dev_kernarg(void) {
@@ -45,6 +54,8 @@ extern "C" int qpg_ctx_create(int device, qpg_ctx** out) {
   c->n_cu = p.multiProcessorCount;
   c->zeros = nullptr;
   c->select_lds_raised = false;
+  for (int i = 0; i < QPG_OPT_COUNT; ++i) c->opt[i] = 0;
+  c->opt[QPG_OPT_GATE_DEDUP_FROM_CHAINS] = 1;
   int prev = 0;
   (void)hipGetDevice(&prev);
   const bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&c->zeros), 4096) == hipSuccess &&
@@ -56,6 +67,21 @@ extern "C" int qpg_ctx_create(int device, qpg_ctx** out) {
     return QPG_EHIP;
   }
   *out = c;
+  return QPG_OK;
+}
+
+extern "C" int qpg_ctx_set_option(qpg_ctx* ctx, int option, int value) {
+  QPG_REQUIRE(ctx != nullptr, "qpg_ctx_set_option: null context");
+  QPG_REQUIRE(option >= 0 && option < QPG_OPT_COUNT, "qpg_ctx_set_option: unknown option %d", option);
+  if (option == QPG_OPT_GATE_DEDUP_FROM_CHAINS) QPG_REQUIRE(value >= 0, "qpg_ctx_set_option: gate_dedup_from_chains >= 0");
+  ctx->opt[option] = value;
+  return QPG_OK;
+}
+
+extern "C" int qpg_ctx_get_option(qpg_ctx* ctx, int option, int* value) {
+  QPG_REQUIRE(ctx != nullptr && value != nullptr, "qpg_ctx_get_option: null pointer");
+  QPG_REQUIRE(option >= 0 && option < QPG_OPT_COUNT, "qpg_ctx_get_option: unknown option %d", option);
+  *value = ctx->opt[option];
   return QPG_OK;
 }
 

@@ -576,7 +576,8 @@ __host__ __device__ __forceinline__ MixStream mix_stream_of(unsigned char* ws, i
 
 
 // -DQPG_SELECT_PROF (experiments/select_prof): block 0 stamps the 100 MHz wall clock at the section boundaries of the
-// mixed select; qpg_debug_select_prof copies the stamps out.  Not in the product build.
+// mixed select; qpg_debug_select_prof copies the stamps out.  Not in the product build (-DQPG_SELECT_PROF implies a
+// hooks build: experiments/select_prof/build.sh).
 #ifdef QPG_SELECT_PROF
 __device__ long long qpg_select_prof_buf[6][16];      // [phase]: wall clock; [3 + phase]: shader clock (s_memtime)
 #define SEL_STAMP(i)                                                                          \

@@ -761,14 +761,8 @@ extern "C" int qpg_fuse_best_ranked(qpg_ctx* ctx, void* stream, const int16_t* r
   return QPG_OK;
 }
 
-// From how many chains per launch the gate table is deduplicated by the previous winner (gate_table_dedup_kernel); 0 =
-// never.  Measurement / test hook, process-wide.
-static int g_gate_dedup_chains = 1;
-extern "C" int qpg_debug_gate_dedup(int from_chains) {
-  QPG_REQUIRE(from_chains >= 0, "qpg_debug_gate_dedup: from_chains >= 0");
-  g_gate_dedup_chains = from_chains;
-  return QPG_OK;
-}
+// From how many chains per launch the gate table is deduplicated by the previous winner (gate_table_dedup_kernel; 0 =
+// never): the context's QPG_OPT_GATE_DEDUP_FROM_CHAINS (default 1; the tests set 0 to walk on round 4's plain table).
 
 static int match_steps_impl(qpg_ctx* ctx, void* stream, const int16_t* aud_rank, const int32_t* aud_idx,
                             const int16_t* txt_rank, const int32_t* txt_idx, const int16_t* pos_rank,
@@ -843,7 +837,7 @@ static int match_steps_impl(qpg_ctx* ctx, void* stream, const int16_t* aud_rank,
   }
   uint16_t* gtab = reinterpret_cast<uint16_t*>(gate_tables + (int64_t)2 * Q * K);     // third [Q][K] i32 region
   const int64_t lanes = (int64_t)Q * 2 * K * 8;
-  const int dedup_from = g_gate_dedup_chains;                          // (qpg_debug_gate_dedup; 0: never)
+  const int dedup_from = ctx->opt[QPG_OPT_GATE_DEDUP_FROM_CHAINS];      // (qpg_ctx_set_option; 0: never)
   if (dedup_from > 0 && n_chains >= dedup_from && K <= 512) {
     hipLaunchKernelGGL(gate_table_dedup_kernel, dim3((unsigned)Q), dim3(GD_THREADS), 0, qpg_stream(stream), A, geo, gtab);
     QPG_LAUNCH_CHECK("gate_table_dedup_kernel");

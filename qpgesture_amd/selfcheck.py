@@ -5,7 +5,7 @@ sorted_rows.HL_GEMM_ERR) assumes that a chain of two v_mfma_f32_16x16x32_f16 ins
 kappa_2 * 2^-24 * sum|64 products| of the exact sum, with kappa_2 <= 13.  Nothing in the ISA documents how the matrix core
 aligns and rounds its 32 products; the constant was probed (tools/probe_mfma_f16.py, tools/probe_mfma_chain.py: worst
 9.72).  So the product re-measures it once per process and device, on blocks built against the accumulator (dominant
-products, wide dynamic range, big-then-small chains), through the same instruction (qpg_debug_mfma_f16_tile), and a
+products, wide dynamic range, big-then-small chains), through the same instruction (qpg_probe_mfma_f16_tile), and a
 device that does not honour the assumption is NOT given the bounded paths: CodeKNN then sweeps in f64 and the text
 side runs the exact-order sweep (both still HIP kernels; nothing falls back to the CPU).  The exact sums the measured
 values are compared with are 64-term f64 sums of exactly representable f16 x f16 products, computed on the host with
@@ -34,7 +34,7 @@ def _probe(dev, a16, b16, c=None):
     bd = torch.from_numpy(b16).to(dev).contiguous()
     cd = None if c is None else torch.from_numpy(np.ascontiguousarray(c, np.float32)).to(dev)
     out = torch.empty((tiles, 16, 16), dtype=torch.float32, device=dev)
-    _lib.call("qpg_debug_mfma_f16_tile", dev, ad, bd, cd, tiles, out)
+    _lib.call("qpg_probe_mfma_f16_tile", dev, ad, bd, cd, tiles, out)
     return out.cpu().numpy()
 
 

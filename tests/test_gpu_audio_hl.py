@@ -19,7 +19,7 @@ def _probe(a, b, c=None):
     bd = torch.from_numpy(b).to(dev).contiguous()
     cd = None if c is None else torch.from_numpy(c).to(dev).contiguous()
     out = torch.empty((tiles, 16, 16), dtype=torch.float32, device=dev)
-    _lib.call("qpg_debug_mfma_f16_tile", dev, ad, bd, cd, tiles, out)
+    _lib.call("qpg_probe_mfma_f16_tile", dev, ad, bd, cd, tiles, out)
     return out.cpu().numpy()
 
 

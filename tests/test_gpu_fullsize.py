@@ -491,25 +491,29 @@ def test_walk_batch_equals_one_walk_per_clip():
         seeds.append(sc)
         phases.append(sp)
     from qpgesture_amd import _lib
-    lib = _lib.load()
+    dev = "cuda:0"
+
+    def gate_dedup(v):                                   # per-context knob (round 6; was a process-wide debug hook)
+        _lib.set_option(dev, _lib.QPG_OPT_GATE_DEDUP_FROM_CHAINS, v)
+        return 0
     one = []
     try:
-        assert lib.qpg_debug_gate_dedup(0) == 0          # the one-clip references on round 4's plain gate table
+        assert gate_dedup(0) == 0          # the one-clip references on round 4's plain gate table
         for c in range(CL):
             oc, op, ov, st = knn.walk(T, M, window_offset=c * M, seed_code=seeds[c], seed_phase=phases[c], sync=False)
             one.append((oc.cpu().numpy(), op.cpu().numpy(), ov.cpu().numpy(), st.cpu().numpy()))
-        assert lib.qpg_debug_gate_dedup(1) == 0          # ... and the deduplicated table must give the same one-clip walk
+        assert gate_dedup(1) == 0          # ... and the deduplicated table must give the same one-clip walk
         for c in range(CL):
             oc, op, ov, st = knn.walk(T, M, window_offset=c * M, seed_code=seeds[c], seed_phase=phases[c], sync=False)
             assert np.array_equal(oc.cpu().numpy(), one[c][0]) and np.array_equal(op.cpu().numpy(), one[c][1])
             assert np.array_equal(ov.cpu().numpy(), one[c][2]) and np.array_equal(st.cpu().numpy(), one[c][3])
     finally:
-        lib.qpg_debug_gate_dedup(1)
+        gate_dedup(1)
     try:
         # round 5: the gate table is deduplicated by the previous winner (gate_table_dedup_kernel); 0 = the plain kernel,
         # 4 = the plain kernel for the one-clip walks above only - all must agree
         for dedup_from in (4, 0, 1):
-            assert lib.qpg_debug_gate_dedup(dedup_from) == 0
+            assert gate_dedup(dedup_from) == 0
             bc, bp, bv = knn.walk_batch(T, M, CL, seeds, np.stack(phases))
             ints = knn._last_ints.cpu().numpy()
             for c in range(CL):
@@ -519,7 +523,7 @@ def test_walk_batch_equals_one_walk_per_clip():
                 assert np.array_equal(ints[c, -2:], one[c][3])
                 assert np.array_equal(ints[c, :M * 30], one[c][0].reshape(-1))
     finally:
-        lib.qpg_debug_gate_dedup(1)
+        gate_dedup(1)
     assert len({tuple(o[0].reshape(-1)) for o in one}) > 1              # the clips really differ
 
 

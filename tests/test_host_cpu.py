@@ -17,7 +17,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert len(names) >= 16 and "qpg_audio_cosine_f64" in names and "qpg_match_steps" in names
     for n in names:
         assert hasattr(lib, n), "include/qpg.h declares %s but libqpg_hip.so does not export it" % n
-    assert lib.qpg_version() >= 104
+    assert lib.qpg_version() >= 107
     import os
     assert lib.qpg_dev_kernarg() == (1 if os.environ.get("HIP_FORCE_DEV_KERNARG") == "1" else 0)
 
@@ -29,12 +29,33 @@ def test_bindings_cover_the_header():
                                "qpg_conv1d_wgrad_ws_floats", "qpg_vq_code_sums_ws_bytes",
                                "qpg_text_percode_ws_bytes", "qpg_percode_select_mixed_ws_bytes",
                                "qpg_percode_select_mixed_ws_stride",
-                               "qpg_merge_mixed_ws_bytes", "qpg_debug_convt_shape", "qpg_debug_convt_opts", "qpg_debug_gemm64_waves", "qpg_debug_gate_dedup",
+                               "qpg_merge_mixed_ws_bytes", "qpg_build_id", "qpg_ctx_set_option", "qpg_ctx_get_option",
                                "qpg_percode_select_exact_ws_bytes", "qpg_audio_hl_supported",
                                "qpg_audio_hl_db_bytes", "qpg_audio_hl_query_bytes", "qpg_hl_rows_bytes",
                                "qpg_hl_cols_bytes", "qpg_dev_kernarg", "qpg_audio_hl1_supported", "qpg_audio_hl1_db_bytes",
                                "qpg_conv16_image_bytes", "qpg_comm_unique_id", "qpg_comm_create", "qpg_comm_destroy"}
     assert declared == bound
+
+
+def test_product_library_exports_no_debug_hooks_and_is_built_from_this_tree():
+    """no global mutable state except the opaque context.  The measurement hooks (qpg_debug_*) exist only in
+    -DQPG_DEBUG_HOOKS variant builds; the product library must not export any of them - and it must be the library compiled
+    from THIS tree's sources: qpg_build_id() == the hash of csrc/* + include/qpg.h (build.source_hash)."""
+    import subprocess
+    from qpgesture_amd import build
+    lib = _lib.load()
+    hooks = _lib.debug_hook_symbols()
+    assert "qpg_debug_gemm64_waves" in hooks and "qpg_debug_convt_shape" in hooks
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert "qpg_build_id" in exported and "qpg_audio_cosine_hl" in exported
+    leaked = sorted(n for n in exported if n.startswith("qpg_debug"))
+    assert not leaked, "the product library exports debug hooks: %s" % leaked
+    for n in hooks:
+        assert not hasattr(lib, n)
+    assert lib.qpg_build_id().decode() == build.source_hash() == build.lib_build_id()
+    # the knobs that remain are per-context (they need a device: exercised in the GPU suite); bad arguments fail cleanly here
+    assert lib.qpg_ctx_set_option(None, 0, 1) == -1 and "null context" in _lib.last_error()
 
 
 def test_error_reporting_without_gpu():

@@ -1,4 +1,6 @@
 """cfg-3 (h-plane prefilter + by-code select): HIP-event time of every launch of one batch, 20 repetitions."""
+# needs a -DQPG_DEBUG_HOOKS variant of the library (the product exports no qpg_debug_* setters since round 6):
+#   tools/build_variant.sh qpg_audio_hl hooks "-DQPG_DEBUG_HOOKS" && QPG_LIB_PATH=experiments/variants/libqpg_hooks.so python tools/bench_cfg3_parts2.py
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,8 @@
 """Which convolution kernel for which number of rows: the short-sequence kernel (launcher's own block shape) against the
 64 x 128 kernel (qpg_debug_convt_shape(8, 0)) on 512 -> 512 layers, M = B x T rows, L2-cold weights (8 distinct layers
 cycled).  python tools/bench_convt_m.py"""
+# needs a -DQPG_DEBUG_HOOKS variant of the library (the product exports no qpg_debug_* setters since round 6):
+#   tools/build_variant.sh qpg_convt hooks "-DQPG_DEBUG_HOOKS" && QPG_LIB_PATH=experiments/variants/libqpg_hooks.so python tools/bench_convt_m.py
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,7 @@
 """experiments: time the short-sequence convolution kernel (convt_small_f32_kernel) for every block shape
 (qpg_debug_convt_shape(nq, pd)) on the layer shapes of a clip decode.  python tools/bench_convt_small.py"""
+# needs a -DQPG_DEBUG_HOOKS variant of the library (the product exports no qpg_debug_* setters since round 6):
+#   tools/build_variant.sh qpg_convt hooks "-DQPG_DEBUG_HOOKS" && QPG_LIB_PATH=experiments/variants/libqpg_hooks.so python tools/bench_convt_small.py
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

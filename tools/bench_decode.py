@@ -1,4 +1,6 @@
 """Decode of one 24 s clip (180 codes -> 1440 frames, one pass) and a single-window encode: HIP-event timings."""
+# needs a -DQPG_DEBUG_HOOKS variant of the library (the product exports no qpg_debug_* setters since round 6):
+#   tools/build_variant.sh qpg_convt hooks "-DQPG_DEBUG_HOOKS" && QPG_LIB_PATH=experiments/variants/libqpg_hooks.so python tools/bench_decode.py
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,12 +31,14 @@ def t(fn, n=50):
 from qpgesture_amd import _lib
 lib = _lib.load()
 ref = m.decode([ids]).clone()
-for deep, xcd in ((0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (1, 1)):
+hooks = hasattr(lib, "qpg_debug_convt_opts")           # (a -DQPG_DEBUG_HOOKS variant library; the product has none)
+for deep, xcd in ((0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (1, 1)) if hooks else ():
     lib.qpg_debug_convt_opts(deep, xcd)
     out = m.decode([ids])
     print("deep_ring=%d xcd_map=%d: decode 24 s clip min %.3f median %.3f ms; max |out - first| = %.3g"
           % ((deep, xcd) + t(lambda: m.decode([ids])) + (float((out - ref).abs().max()),)))
-lib.qpg_debug_convt_opts(0, 0)
+if hooks:
+    lib.qpg_debug_convt_opts(0, 0)
 print("decode 24 s clip: min %.3f median %.3f ms" % t(lambda: m.decode([ids])))
 print("encode 1 window:  min %.3f median %.3f ms" % t(lambda: m.encode(x1)))
 for L in (30, 60, 720):

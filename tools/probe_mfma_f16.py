@@ -10,7 +10,7 @@ def run(a, b, c=None):
     a16 = torch.from_numpy(a.astype(np.float16)).to(dev); b16 = torch.from_numpy(b.astype(np.float16)).to(dev)
     cd = None if c is None else torch.from_numpy(c.astype(np.float32)).to(dev)
     out = torch.empty((a.shape[0], 16, 16), dtype=torch.float32, device=dev)
-    _lib.call("qpg_debug_mfma_f16_tile", dev, a16, b16, cd, a.shape[0], out)
+    _lib.call("qpg_probe_mfma_f16_tile", dev, a16, b16, cd, a.shape[0], out)
     return out.cpu().numpy().astype(np.float64)
 
 def one(avals, bvals, c=0.0):

@@ -33,7 +33,7 @@ if os.environ.get("QPG_FORCE_SHARDED") == "1":          # the row-shard code pat
     knn.force_sharded = True
 if "QPG_GATE_DEDUP" in os.environ:                    # from how many chains the gate table is deduplicated (0: never)
     from qpgesture_amd import _lib as _l
-    _l.load().qpg_debug_gate_dedup(int(os.environ["QPG_GATE_DEDUP"]))
+    _l.set_option(dev, _l.QPG_OPT_GATE_DEDUP_FROM_CHAINS, int(os.environ["QPG_GATE_DEDUP"]))
 knn.audio_kernel = os.environ.get("QPG_AUDIO_KERNEL", "hl")
 if "QPG_SPLIT_FUSE" in os.environ:                    # 0: the rank fusion as ONE launch in the walk (rounds 3-5), 1: per modality
     knn.split_fuse = os.environ["QPG_SPLIT_FUSE"] == "1"
