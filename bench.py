@@ -213,19 +213,7 @@ def main():
     if (world > 1 or force_sharded) and one_gpu != "1" and os.environ.get("QPG_LIB_COLLECTIVES", "1") != "0" and \
             a.scaling != "replicated":
         from qpgesture_amd import parallel as _par
-        try:
-            _par.enable_lib_collectives(dev)
-            ok_ = 1
-        except Exception as e_:                                   # noqa: BLE001 (recorded in the line)
-            ok_, lib_coll_why = 0, repr(e_)[:200]
-        if world > 1:
-            f_ = torch.tensor([ok_], dtype=torch.int32, device=dev)
-            dist.all_reduce(f_, op=dist.ReduceOp.MIN)
-            ok_ = int(f_.item())
-        lib_coll = bool(ok_)
-        if not lib_coll:
-            _par.disable_lib_collectives()
-            lib_coll_why = lib_coll_why or "another rank could not create the library's communicator"
+        lib_coll, lib_coll_why = _par.negotiate_lib_collectives(dev)      # (every rank ends up on the same transport)
 
     if a.workload == "cfg3":
         out = cfg3_bench(a, dev, world, rank)
@@ -910,7 +898,7 @@ def main():
 def rocprof_kernel_ms(key):
     """The dominant kernel's average duration over ALL launches of a profiled run of this command - graph replays included,
     which HIP events cannot bracket - from the committed rocprofv3 --kernel-trace --stats summary (profiles/
-    kernel_replay.json, written by tools/kernel_replay.py from the pass of tools/r05_gpu_pass.sh); null for shapes that were not profiled."""
+    kernel_replay.json, written by tools/kernel_replay.py from the pass of experiments/round_scripts/r05_gpu_pass.sh); null for shapes that were not profiled."""
     path = os.path.join(ROOT, "profiles", "kernel_replay.json")
     if key is None or not os.path.exists(path):
         return {"kernel_ms_rocprof": None}
@@ -925,7 +913,7 @@ def rocprof_kernel_ms(key):
 def pmc_traffic(key):
     """`roofline.traffic` = HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x 2 per the
     gfx950 correction + WRITE_SIZE, separate passes), read at run time from the committed summary profiles/pmc_traffic.json
-    (written by tools/pmc_traffic.py from the passes of tools/r04_gpu_pass.sh); null for shapes that were not measured."""
+    (written by tools/pmc_traffic.py from the passes of experiments/round_scripts/r04_gpu_pass.sh); null for shapes that were not measured."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if key is None or not os.path.exists(path):
         return {"traffic": None, "traffic_source": None}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # non-temporal fragment loads in the sweeps (H2_NT: 0 never, 1 one query chunk only = product, 2 always), alternating on one
 # box: the kernels alone (30 back-to-back launches), then bench.py's step with the sweep bracketed by HIP events
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r05nt; mkdir -p $O; L=experiments/audio_hl
 {
 for r in 1 2 3; do for v in nt0 nt1; do echo "== Q=48 $v"; QPG_LIB_PATH=$L/libqpg_p$v.so timeout 300 python tools/bench_audio_hl.py 2048 48 2>&1 | grep "hl sweep\|hl1" | sed 's/|  *mx.*//'; done; done

@@ -1,7 +1,7 @@
 #!/bin/bash
 # sweep duration INSIDE the captured step (rocprofv3 kernel trace of graph replays), plain vs non-temporal fragment loads;
 # MODE=MODE_AUD: the audio side alone (no text GEMM queued beside the sweep)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp; R=$PWD; O=gpurun_out/r05nt; mkdir -p $O; L=experiments/audio_hl
 for m in ${MODES:-MODE_AUD_TXT MODE_AUD}; do for r in 1 2; do for v in ${VARIANTS:-nt0 nt1}; do
   rm -rf $O/tl_$v

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rank fusion per modality behind its own select (split_fuse, the default) against the one launch in the walk, alternating
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp; R=$PWD; O=gpurun_out/r05s; mkdir -p $O
 for v in 0 1 0 1 0 1; do QPG_SPLIT_FUSE=$v python tools/step_loop.py 300 graph 2>&1 | tail -1 | sed "s/^/split=$v clip1 /"; done
 for v in 0 1 0 1; do QPG_SPLIT_FUSE=$v QPG_LOOP_CLIPS=16 QPG_LOOP_F16=1 python tools/step_loop.py 40 graph 2>&1 | tail -1 | sed "s/^/split=$v clips16 /"; done

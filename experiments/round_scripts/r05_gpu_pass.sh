@@ -2,7 +2,7 @@
 # Round-5 evidence pass (everything under gpurun_out/r05e/): GPU suite, smoke, default bench line, rocprofv3 kernel stats of
 # the driver's command, graph step timeline, PMC traffic of both split-f16 sweeps (two-plane f32 track, one-plane f16 track),
 # BASELINE configs[4] (16 clips, f16 features, encode leg inside the captured step), configs[2], configs[3] on one GPU,
-# the row-shard path on one rank with the library's own collectives.  usage: tools/r05_gpu_pass.sh [quick]
+# the row-shard path on one rank with the library's own collectives.  usage: experiments/round_scripts/r05_gpu_pass.sh [quick]
 set -u
 O=gpurun_out/r05e; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
 QUICK=${1:-}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, first GPU pass: the one-plane f16 sweep (tests + kernel timing), the re-addressed two-plane sweep against round 4's
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r05
 export TMPDIR=/tmp
 {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, second GPU pass: captured 16-clip step (+ encode leg), tests of the touched paths, timelines
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r05; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
 timeout 2400 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_audio_hl.py tests/test_gpu_matching.py tests/test_gpu_guard_overflow.py tests/test_gpu_mixed.py tests/test_gpu_bench_sharded.py -x -q -m gpu > $O/pass2_tests.log 2>&1
 echo "tests rc=$?" >> $O/pass2_tests.log

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r05; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
 timeout 1200 python -m pytest tests/test_gpu_db_cache.py tests/test_gpu_matching.py tests/test_gpu_fullsize.py -x -q -m gpu -k "cache or cli or captured" > $O/pass3_tests.log 2>&1
 echo "tests rc=$?" >> $O/pass3_tests.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, fourth GPU pass: library-owned collectives (tests, forced-sharded lines, the RCCL graph + eager repro), the
 # pruned library on the whole GPU suite, the e2e CLI leg with the prepared-database cache, ABI sanitizer with a real context
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r05; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
 { for m in 0 1; do LD_LIBRARY_PATH=/opt/rocm/lib timeout 120 experiments/rccl_graph/repro $m 20; echo "rc=$?"; done; } > $O/pass4_rccl_repro.log 2>&1
 timeout 900 python tools/abi_sanitize.py > $O/pass4_abi_sanitize.log 2>&1; echo "rc=$?" >> $O/pass4_abi_sanitize.log

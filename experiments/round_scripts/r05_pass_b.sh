@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r05b; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
 for cfg in "1 96 f32" "1 96 f16x3" "1 0 f32" "0 0 f32"; do
   set -- $cfg

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, pass c: the re-ordered sweep (query loads in front of the ring, prologue in the loop's order, refill pinned) and
 # the cfg-3 path (h-plane prefilter + by-code select): tests, kernel timings, bench lines
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r05c; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
 timeout 1500 python -m pytest tests/test_gpu_cfg3.py tests/test_gpu_audio_hl.py tests/test_gpu_text_prefilter.py -x -q -m gpu -s > $O/tests.log 2>&1; echo "tests rc=$?" >> $O/tests.log
 { python tools/bench_audio_hl.py 2048 48; python tools/bench_audio_hl.py 2048 48; python tools/bench_audio_hl.py 2048 768; } > $O/kernels.log 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # 16 clips + encode leg: where the encode goes (behind the sweep on a branch / serial / at the start), stream priorities
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r05e2; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
 python -c "import torch; print(torch.cuda.Stream.priority_range())" > $O/prio_range.txt 2>&1
 for prec in f32 f16x3; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, last pass: the whole GPU suite on the final tree, the default line, the multi-clip lines (text side of >= 256 queries
 # on the by-code path since the evidence pass), cfg-3 with its traffic field read from the committed PMC summary
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r05final; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
 timeout 3000 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" > $O/rc.txt
 timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/rc.txt

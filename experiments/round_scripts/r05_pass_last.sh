@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, the pass behind the non-temporal fragment loads: PMC traffic of both sweeps first (bench.py reads it), the whole
 # GPU suite, smoke, the driver's line + its rocprofv3 kernel stats, timelines, the 16-clip / f16 / cfg-3 lines
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r05last; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
 : > $O/rc.txt
 for c in FETCH_SIZE WRITE_SIZE; do

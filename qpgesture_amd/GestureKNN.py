@@ -85,11 +85,12 @@ def main_codebook(args, maxFrames=0):
 
     t0 = time.time()
     vq = args.mode.startswith("wavvq")
-    db, cpath, ckey = None, None, None
+    db, cpath, ckey, csrc = None, None, None, None
     if args.db_cache != "off":
         files = [args.train_database, args.train_codebook, args.train_wavlm, args.codebook_signature] + \
             ([args.train_wavvq] if vq else [])
-        ckey = db_cache.file_key(files, {"tie_rule": args.tie_rule, "wavvq": vq, "device_kind": "hip"})
+        copts = {"tie_rule": args.tie_rule, "wavvq": vq, "device_kind": "hip"}
+        ckey, csrc = db_cache.file_key(files, copts), db_cache.sources_id(files, copts)
         cpath = db_cache.cache_path(ckey, args.db_cache_dir)
         if args.db_cache == "auto":
             db = GestureDB.load(cpath, args.device, ckey)
@@ -138,9 +139,9 @@ def main_codebook(args, maxFrames=0):
                                                                    t2 - t1, 240 * n_test_seq / (t2 - t1)))
     if cpath is not None and not from_cache:
         try:                                    # behind the result: a later invocation finds the database prepared
-            db.save(cpath, ckey)
-        except (OSError, TypeError) as e:
-            print('prepared-database cache not written: %s' % e)
+            db.save(cpath, ckey, sources=csrc)
+        except Exception as e:                  # noqa: BLE001 (the result is written: a cache failure must not fail the command)
+            print('prepared-database cache not written: %r' % (e,))
     return pred_seqs
 
 

@@ -323,9 +323,9 @@ class GestureDB:
 
     # -- prepared-database cache (round 5; db_cache.py): what the constructor built, written once, restored without a
     #    single build launch - the drop-in CLI's second and later invocations (GestureKNN.py:816-845 reloads everything)
-    def save(self, path, key=""):
+    def save(self, path, key="", sources=None):
         from . import db_cache
-        return db_cache.save(self, path, key)
+        return db_cache.save(self, path, key, sources=sources)
 
     @classmethod
     def load(cls, path, device="cuda:0", key=None):
@@ -845,7 +845,7 @@ class CodeKNN:
         # (qpg_fuse_best_ranked) into the walk's gate tables, which the walk then takes as they are (QPG_MODE_PREFUSED):
         # the join of the two streams has half a rank fusion less behind it.  split_fuse = False: one launch in the walk.
         # (a clip or a few: the fusion is one latency-bound round of blocks and the critical path loses 3-4 us; 16 clips'
-        # worth of steps are throughput-bound and two launches buy nothing: tools/r05_ab_split.sh)
+        # worth of steps are throughput-bound and two launches buy nothing: experiments/round_scripts/r05_ab_split.sh)
         split = (for_walk and mode == MODE_AUD_TXT and not sharded and not self.host_ranks and self.split_fuse and
                  db.K % 16 == 0 and db.K <= 4096 and M * steps <= self.split_fuse_max_steps)
         gtab = torch.empty((3, max(M, 1) * steps, db.K), dtype=torch.int32, device=dev) if split else None
@@ -1414,7 +1414,7 @@ class ClipGraph:
 
         import os as _os
         # where the encode leg forks ("start": beside the whole match, the default; "sweep_end": behind the audio sweep;
-        # "serial": no branch).  Measured with 16 clips + 96 windows per replay (tools/r05_pass_e.sh, round 5's kernels):
+        # "serial": no branch).  Measured with 16 clips + 96 windows per replay (experiments/round_scripts/r05_pass_e.sh, round 5's kernels):
         # start 3.80 / 3.19 ms (f32 / f16x3 encode), sweep_end 3.94 / 3.44, serial 4.27 / 3.60; stream priorities on either
         # branch only slow the step down.
         enc_at = _os.environ.get("QPG_ENCODE_AT", "start")

@@ -69,7 +69,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 // value of lane (l ^ PJ), PJ = 16 / 32, through gfx950's permlane swaps (qpg_common.h: lane_xor) - the GEMM epilogues'
 // reductions over a tile's four row groups went through the LDS crossbar (__shfl_xor = ds_bpermute_b32: ~65 cycles each,
-// a wave's do not overlap; 96 of them per 64 x 96 item were a third of hl_gemm64h_kernel: tools/r05_probe_gemm64.sh)
+// a wave's do not overlap; 96 of them per 64 x 96 item were a third of hl_gemm64h_kernel: experiments/round_scripts/r05_probe_gemm64.sh)
 template <int PJ>
 __device__ __forceinline__ float xor_lanes_f(float v) {
   return __int_as_float(lane_xor<PJ>(__float_as_int(v)));
@@ -1560,7 +1560,7 @@ __global__ __launch_bounds__(512, 2) void hl_gemm32_kernel(HlArgs a, int n_items
 // ([tile][a.ldT], a.ldT >= Q: the 16 queries of a column tile are one 64-byte store; the by-code select reads a tile's
 // queries contiguously).  Needs KB % 4 == 0 (D % 128 == 0) and an even number of 32-row groups.
 #define G64_KS 4
-// ablation hooks (experiments/gemm32, tools/r05_probe_gemm64.sh): -DG64_PROBE=<bits>; the product build defines nothing.
+// ablation hooks (experiments/gemm32, experiments/round_scripts/r05_probe_gemm64.sh): -DG64_PROBE=<bits>; the product build defines nothing.
 // 1: no epilogue (the accumulators are only kept alive); 2: row fragments from one address (no row stream); 4: no query
 // staging inside the k loop; 8: no MFMAs (loads, staging and epilogue stay); 16: no query-fragment reads from LDS
 #ifndef G64_PROBE
@@ -1586,7 +1586,7 @@ __global__ __launch_bounds__(64 * NW, 2) void hl_gemm64h_kernel(HlArgs a, int n_
   const int nit = ((n_rb - xcd + nx - 1) / nx) * a.chunks;             // items of this XCD
   // This block's items: i_k = k lpx + lx < nit, item = (row block (i / chunks) nx + xcd, chunk i % chunks).  The quotient
   // and remainder are carried from item to item (one division pair per BLOCK; with `item` as a number the loop held ~12
-  // run-time integer divisions per item.  Measured equal - the 34 us of the kernel's "skeleton" in tools/r05_probe_gemm64.sh
+  // run-time integer divisions per item.  Measured equal - the 34 us of the kernel's "skeleton" in experiments/round_scripts/r05_probe_gemm64.sh
   // are its 64 fragment loads per wave and item going through the CU's 64 B/clk vector L1, not index arithmetic).
   struct Item {
     int i, q, rb, ch;                        // sequence number on this XCD, its quotient by chunks, row block (global), chunk

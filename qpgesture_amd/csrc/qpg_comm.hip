@@ -18,7 +18,26 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 
+// The handful of RCCL / NCCL ABI names this file uses, declared HERE: the library is bound at run time (dlopen below), so
+// the BUILD must not need RCCL's development headers either.  These are NCCL's public, ABI-stable definitions
+// (nccl.h / rccl.h: a 128-byte opaque id, an opaque communicator handle, the enum values below); when the header is
+// present the static_asserts compare them with it.
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>) && defined(QPG_CHECK_RCCL_ABI)
 #include <rccl/rccl.h>
+#define QPG_HAVE_RCCL_H 1
+#endif
+#endif
+#ifdef QPG_HAVE_RCCL_H
+static_assert(sizeof(ncclUniqueId) == 128 && ncclSuccess == 0 && ncclUint8 == 1 && ncclInt32 == 2 && ncclUint64 == 5 &&
+              ncclMax == 2 && ncclMin == 3, "RCCL ABI constants differ from the ones qpg_comm.hip declares");
+#else
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1, ncclInt32 = 2, ncclUint64 = 5 } ncclDataType_t;
+typedef enum { ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+#endif
 
 struct qpg_comm {
   ncclComm_t comm;

@@ -33,7 +33,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define C16_BN 128          // output channels per block
 #define C16_BK 32           // contraction slice
 #define C16_SLICE_BYTES 16384   // one operand's slice: 8 tiles x 2 planes x 1 KB
-// ablation hooks (tools/r05_probe_conv16.sh): -DC16_PROBE=<bits>; the product build defines nothing.  1: no MFMAs; 2: no
+// ablation hooks (experiments/round_scripts/r05_probe_conv16.sh): -DC16_PROBE=<bits>; the product build defines nothing.  1: no MFMAs; 2: no
 // split + LDS stores in the loop; 4: no global requests in the loop; 8: no fragment reads from LDS; 16: no slice barrier;
 // 32: the activation requests of a wave coalesced into one 2 KB run (timing only: wrong values)
 #ifndef C16_PROBE
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(Conv16Args a) {
     h8* xl = reinterpret_cast<h8*>(lds + buf * 2 * C16_SLICE_BYTES + C16_SLICE_BYTES);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      // the split on PACKED operations (round 5, last hours: tools/r05_probe_conv16.sh - this staging, one scalar
+      // the split on PACKED operations (round 5, last hours: experiments/round_scripts/r05_probe_conv16.sh - this staging, one scalar
       // conversion at a time, cost the kernel as much as its MFMAs): v_pk_max_f32 for the ReLU, v_cvt_pk_f16_f32 (gfx950,
       // round to nearest even like the scalar conversion), v_pk_add_f32 for x - h; one range test per eight values
       typedef float f32x8 __attribute__((ext_vector_type(8)));

@@ -46,6 +46,16 @@ def file_key(paths, options):
     return h.hexdigest()[:24]
 
 
+def sources_id(paths, options):
+    """What a cache file was built FOR, without the files' sizes / mtimes: a later save() for the same sources (the files
+    were regenerated) replaces the older cache files instead of leaving them behind (prune)."""
+    h = hashlib.sha256()
+    for p in paths:
+        h.update((os.path.abspath(p) + ";").encode())
+    h.update(json.dumps(options, sort_keys=True).encode())
+    return h.hexdigest()[:24]
+
+
 def default_dir():
     return os.environ.get("QPG_DB_CACHE_DIR") or os.path.join(os.environ.get("XDG_CACHE_HOME") or
                                                               os.path.expanduser("~/.cache"), "qpgesture_amd")
@@ -99,8 +109,20 @@ def _flatten(obj, prefix, tensors, seen):
     return out
 
 
-def _restore(cls, desc, tensors, device):
+def _class_of(spec):
+    """'module:Name' of a header -> the class, for THIS package's modules only: the header is data read from a file, and
+    importlib.import_module on an arbitrary name runs that module's top level."""
     import importlib
+    mod, name = str(spec).split(":")
+    if not (mod == "qpgesture_amd" or mod.startswith("qpgesture_amd.")) or not name.isidentifier():
+        raise ValueError("cache header names a foreign class: %r" % (spec,))
+    cls = getattr(importlib.import_module(mod), name)
+    if not isinstance(cls, type):
+        raise ValueError("cache header names a non-class: %r" % (spec,))
+    return cls
+
+
+def _restore(cls, desc, tensors, device):
     obj = object.__new__(cls)
     for k, v in desc.items():
         if isinstance(v, dict) and "__tensor__" in v:
@@ -116,8 +138,7 @@ def _restore(cls, desc, tensors, device):
         elif isinstance(v, dict) and "__dict__" in v:
             val = dict(v["__dict__"])
         elif isinstance(v, dict) and "__object__" in v:
-            mod, name = v["__object__"].split(":")
-            val = _restore(getattr(importlib.import_module(mod), name), v["attrs"], tensors, device)
+            val = _restore(_class_of(v["__object__"]), v["attrs"], tensors, device)
         else:
             val = v
         obj.__dict__[k] = val
@@ -125,14 +146,17 @@ def _restore(cls, desc, tensors, device):
 
 
 # ---- file I/O --------------------------------------------------------------------------------------------------------
-def save(db, path, key=""):
-    """Write `db` (a GestureDB) to `path` atomically (tmp + rename).  Device tensors are copied out in chunks."""
+def save(db, path, key="", sources=None, keep=None):
+    """Write `db` (a GestureDB) to `path` atomically (tmp + rename; the tmp file is removed on ANY failure).  Device tensors
+    are copied out in chunks.  sources (sources_id): older cache files of the same sources are deleted afterwards, and at
+    most `keep` files (default $QPG_DB_CACHE_MAX_FILES or 8, newest first) stay in the directory."""
     tensors, seen = {}, {}
     desc = _flatten(db, "", tensors, seen)
     table, off = [], 0
     for name, t in tensors.items():
         if isinstance(t, torch.Tensor):
-            assert t.is_contiguous(), name
+            if not t.is_contiguous():
+                raise ValueError("db_cache.save: tensor %s is not contiguous" % name)
             nbytes, dt, where = t.numel() * t.element_size(), str(t.dtype).split(".")[1], ("device" if t.is_cuda else "host_t")
         else:
             t = tensors[name] = np.ascontiguousarray(t)
@@ -140,26 +164,89 @@ def save(db, path, key=""):
         table.append({"name": name, "dtype": dt, "shape": list(t.shape), "offset": off, "nbytes": nbytes, "where": where})
         off += (nbytes + ALIGN - 1) // ALIGN * ALIGN
     head = json.dumps({"key": key, "version": VERSION, "class": "qpgesture_amd.code_knn:GestureDB", "attrs": desc,
-                       "tensors": table, "data_bytes": off}).encode()
+                       "tensors": table, "data_bytes": off, "sources": sources}).encode()
     data0 = (16 + len(head) + ALIGN - 1) // ALIGN * ALIGN
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     tmp = "%s.tmp.%d" % (path, os.getpid())
-    with open(tmp, "wb") as f:
-        f.write(MAGIC)
-        f.write(len(head).to_bytes(8, "little"))
-        f.write(head)
-        for ent in table:
-            f.seek(data0 + ent["offset"])
-            t = tensors[ent["name"]]
-            if isinstance(t, np.ndarray):
-                f.write(memoryview(t).cast("B"))
-                continue
-            flat = t.reshape(-1).view(torch.uint8) if t.dtype != torch.bool else t.reshape(-1).to(torch.uint8)
-            for o in range(0, flat.numel(), 256 << 20):                  # (bounded host copies of a 1.5 GB array)
-                f.write(memoryview(flat[o:o + (256 << 20)].cpu().numpy()))
-        f.truncate(data0 + off)
-    os.replace(tmp, path)
+    try:
+        with open(tmp, "wb") as f:
+            f.write(MAGIC)
+            f.write(len(head).to_bytes(8, "little"))
+            f.write(head)
+            for ent in table:
+                f.seek(data0 + ent["offset"])
+                t = tensors[ent["name"]]
+                if isinstance(t, np.ndarray):
+                    f.write(memoryview(t).cast("B"))
+                    continue
+                flat = t.reshape(-1).view(torch.uint8) if t.dtype != torch.bool else t.reshape(-1).to(torch.uint8)
+                for o in range(0, flat.numel(), 256 << 20):                  # (bounded host copies of a 1.5 GB array)
+                    f.write(memoryview(flat[o:o + (256 << 20)].cpu().numpy()))
+            f.truncate(data0 + off)
+        os.replace(tmp, path)
+    finally:
+        try:
+            os.unlink(tmp)                       # (gone after a successful rename; left behind by anything else)
+        except OSError:
+            pass
+    prune(os.path.dirname(os.path.abspath(path)), path, sources, keep)
     return path
+
+
+def _read_head(path):
+    """The JSON header of a cache file, None for anything that is not one (missing, foreign, truncated, corrupt)."""
+    try:
+        with open(path, "rb") as f:
+            pre = f.read(16)
+            if len(pre) != 16 or pre[:8] != MAGIC:
+                return None
+            hl = int.from_bytes(pre[8:], "little")
+            if hl <= 0 or hl > (64 << 20):
+                return None
+            head = json.loads(f.read(hl).decode())
+        return head if isinstance(head, dict) else None
+    except (OSError, ValueError, UnicodeDecodeError):
+        return None
+
+
+def prune(directory, keep_path, sources=None, keep=None):
+    """Eviction (one file per distinct key was written and never removed; the bench database is ~1.5 GB):
+    delete the other db_*.qpgdb files of the same `sources`, then the oldest beyond `keep` files, and stale tmp files."""
+    if keep is None:
+        keep = int(os.environ.get("QPG_DB_CACHE_MAX_FILES", "8"))
+    keep_path = os.path.abspath(keep_path)
+    try:
+        names = os.listdir(directory)
+    except OSError:
+        return
+    live = []
+    for n in names:
+        p = os.path.join(directory, n)
+        if n.startswith("db_") and ".qpgdb.tmp." in n:
+            pid = n.rsplit(".", 1)[-1]
+            if not (pid.isdigit() and os.path.exists("/proc/%s" % pid)):
+                _unlink(p)
+            continue
+        if not (n.startswith("db_") and n.endswith(".qpgdb")) or os.path.abspath(p) == keep_path:
+            continue
+        head = _read_head(p)
+        if sources is not None and head is not None and head.get("sources") == sources:
+            _unlink(p)
+            continue
+        try:
+            live.append((os.path.getmtime(p), p))
+        except OSError:
+            pass
+    live.sort(reverse=True)
+    for _, p in live[max(0, keep - 1):]:
+        _unlink(p)
+
+
+def _unlink(p):
+    try:
+        os.unlink(p)
+    except OSError:
+        pass
 
 
 class _Stager:
@@ -179,50 +266,71 @@ class _Stager:
 
 
 def load(path, device, expect_key=None, n_readers=4):
-    """Restore the GestureDB written by save(); None if the file is missing, foreign or keyed differently."""
+    """Restore the GestureDB written by save(); None if the file is missing, foreign, keyed differently, truncated or its
+    header does not parse (the caller then rebuilds the database and overwrites the file) - only I/O and device errors while
+    the DATA is streamed raise."""
     dev = torch.device(device)
+    head = _read_head(path)
+    if head is None:
+        return None
+    try:
+        if head.get("version") != VERSION or (expect_key is not None and head.get("key") != expect_key):
+            return None
+        cls = _class_of(head["class"])
+        plan = []
+        for ent in head["tensors"]:
+            where, dt = ent["where"], ent["dtype"]
+            if where not in ("host", "host_t", "device"):
+                raise ValueError(where)
+            plan.append((str(ent["name"]), where, np.dtype(dt) if where == "host" else _DT[dt],
+                         tuple(int(x) for x in ent["shape"]), int(ent["offset"]), int(ent["nbytes"])))
+        data_bytes, attrs = int(head["data_bytes"]), head["attrs"]
+        if not isinstance(attrs, dict) or any(o < 0 or nb < 0 or o + nb > data_bytes for _, _, _, _, o, nb in plan):
+            raise ValueError("tensor table outside the data section")
+    except (ValueError, KeyError, TypeError, AttributeError, ImportError):
+        return None                              # a corrupt / foreign header: rebuild (ADVICE r5: this used to raise on every run)
     try:
         fd = os.open(path, os.O_RDONLY)
     except OSError:
         return None
     try:
-        pre = os.pread(fd, 16, 0)
-        if len(pre) != 16 or pre[:8] != MAGIC:
-            return None
-        hl = int.from_bytes(pre[8:], "little")
-        head = json.loads(os.pread(fd, hl, 16).decode())
-        if head.get("version") != VERSION or (expect_key is not None and head.get("key") != expect_key):
-            return None
+        hl = int.from_bytes(os.pread(fd, 16, 0)[8:], "little")
         data0 = (16 + hl + ALIGN - 1) // ALIGN * ALIGN
-        if os.fstat(fd).st_size < data0 + head["data_bytes"]:
+        if os.fstat(fd).st_size < data0 + data_bytes:
             return None
         tensors, jobs = {}, []
-        for ent in head["tensors"]:
-            shape, nb = tuple(ent["shape"]), ent["nbytes"]
-            if ent["where"] == "host":
-                a = np.empty(shape, np.dtype(ent["dtype"]))
+        for name, where, dt, shape, off, nb in plan:
+            if where == "host":
+                a = np.empty(shape, dt)
+                if a.nbytes != nb:
+                    return None
                 if nb:
-                    os.preadv(fd, [memoryview(a).cast("B")], data0 + ent["offset"])
-                tensors[ent["name"]] = a
-            elif ent["where"] == "host_t":
-                t = torch.empty(shape, dtype=_DT[ent["dtype"]])
+                    os.preadv(fd, [memoryview(a).cast("B")], data0 + off)
+                tensors[name] = a
+            elif where == "host_t":
+                t = torch.empty(shape, dtype=dt)
+                if t.numel() * t.element_size() != nb:
+                    return None
                 if nb:
-                    os.preadv(fd, [memoryview(t.numpy()).cast("B")], data0 + ent["offset"])
-                tensors[ent["name"]] = t
+                    os.preadv(fd, [memoryview(t.numpy()).cast("B")], data0 + off)
+                tensors[name] = t
             else:
-                t = torch.empty(shape, dtype=_DT[ent["dtype"]], device=dev)
-                tensors[ent["name"]] = t
-                flat = t.reshape(-1).view(torch.uint8) if t.dtype != torch.bool else None
-                if flat is None:
-                    raise TypeError("bool device tensors are not cached")
+                if dt == torch.bool:
+                    return None                  # (save() never writes one to the device section)
+                t = torch.empty(shape, dtype=dt, device=dev)
+                if t.numel() * t.element_size() != nb:
+                    return None
+                tensors[name] = t
+                flat = t.reshape(-1).view(torch.uint8)
                 for o in range(0, nb, CHUNK):
-                    jobs.append((flat, o, min(CHUNK, nb - o), data0 + ent["offset"] + o))
+                    jobs.append((flat, o, min(CHUNK, nb - o), data0 + off + o))
         _stream_in(fd, jobs, dev, n_readers)
     finally:
         os.close(fd)
-    import importlib
-    mod, name = head["class"].split(":")
-    return _restore(getattr(importlib.import_module(mod), name), head["attrs"], tensors, dev)
+    try:
+        return _restore(cls, attrs, tensors, dev)
+    except (ValueError, KeyError, TypeError, AttributeError, ImportError):
+        return None
 
 
 def _stream_in(fd, jobs, dev, n_readers):

@@ -73,38 +73,89 @@ class LibComm:
     id is generated on rank 0 and handed to the other ranks through the already-initialised torch.distributed process
     group (any backend: an object broadcast, once); after that torch.distributed is not involved in the data path."""
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, uid=None, deadline_s=None):
+        """uid: the 128-byte id if the caller has already exchanged it (exchange_unique_id).  deadline_s: run the RCCL
+        rendezvous (qpg_comm_create = ncclCommInitRank, which blocks until every rank has arrived) in a helper thread and
+        raise TimeoutError when it has not returned by then.  ONLY the rendezvous runs there: the id's broadcast is a
+        torch.distributed collective and stays on the caller's thread (an abandoned helper still inside
+        dist.broadcast_object_list would race the caller's next collective on the same process group)."""
+        import ctypes
+        import threading
+        from . import _lib
+        lib = _lib.load()
+        self.device = torch.device(device)
+        self.handle = None
+        self.calls = 0
+        if uid is None:
+            uid = LibComm.exchange_unique_id(group)
+        import torch.distributed as dist_
+        self.rank, self.world = dist_.get_rank(group), dist_.get_world_size(group)
+        ctx = _lib.ctx(self.device)
+        box = {"abandoned": False}
+        lock = threading.Lock()
+
+        def create():
+            try:
+                if self.device.type == "cuda":
+                    torch.cuda.set_device(self.device)       # (the current device is per thread)
+                h = ctypes.c_void_p()
+                rc = lib.qpg_comm_create(ctx, uid, 128, self.rank, self.world, ctypes.byref(h))
+                err = None if rc == 0 else RuntimeError("qpg_comm_create failed: %s" % _lib.last_error())
+            except Exception as e:                           # noqa: BLE001 (re-raised on the caller's thread)
+                h, err = None, e
+            with lock:
+                if box["abandoned"]:
+                    if err is None and h is not None:        # finished after the deadline: nobody will use or free it
+                        lib.qpg_comm_destroy(h)
+                    return
+                box["handle"], box["err"] = h, err
+
+        if deadline_s is None:
+            create()
+        else:
+            th = threading.Thread(target=create, name="qpg-libcomm-init", daemon=True)
+            th.start()
+            th.join(deadline_s)
+            with lock:
+                if "err" not in box:
+                    box["abandoned"] = True
+                    raise TimeoutError("LibComm: the RCCL rendezvous did not complete within %.0f s" % deadline_s)
+        if box["err"] is not None:
+            raise box["err"]
+        self.handle = box["handle"]
+
+    @staticmethod
+    def exchange_unique_id(group=None):
+        """The 128-byte RCCL unique id: generated on rank 0, handed to the other ranks through the already-initialised
+        torch.distributed process group (an object broadcast, once) - on the CALLER's thread."""
         import ctypes
         import torch.distributed as dist_
         from . import _lib
         if not (dist_.is_available() and dist_.is_initialized()):
             raise RuntimeError("LibComm: initialise torch.distributed first (it carries the unique id to the ranks)")
         lib = _lib.load()
-        self.device = torch.device(device)
-        self.rank, self.world = dist_.get_rank(group), dist_.get_world_size(group)
+        rank, world = dist_.get_rank(group), dist_.get_world_size(group)
         buf = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            if lib.qpg_comm_unique_id(buf, 128) != 0:
-                raise RuntimeError("qpg_comm_unique_id failed: %s" % _lib.last_error())
-        box = [bytes(buf.raw) if self.rank == 0 else None]
-        if self.world > 1:
+        if rank == 0 and lib.qpg_comm_unique_id(buf, 128) != 0:
+            raise RuntimeError("qpg_comm_unique_id failed: %s" % _lib.last_error())
+        box = [bytes(buf.raw) if rank == 0 else None]
+        if world > 1:
             dist_.broadcast_object_list(box, src=0, group=group)
-        h = ctypes.c_void_p()
-        rc = lib.qpg_comm_create(_lib.ctx(self.device), box[0], 128, self.rank, self.world, ctypes.byref(h))
-        if rc != 0:
-            raise RuntimeError("qpg_comm_create failed: %s" % _lib.last_error())
-        self.handle = h
-        self.calls = 0
+        return box[0]
 
     def close(self):
         from . import _lib
         if self.handle is not None:
-            torch.cuda.synchronize(self.device)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
             _lib.load().qpg_comm_destroy(self.handle)
             self.handle = None
 
     def exchange(self, send, out, owner_blocks):
         from . import _lib
+        # the library takes BYTE counts: numel() is one only for byte tensors
+        assert send.dtype == torch.uint8 and out.dtype == torch.uint8 and send.is_contiguous() and out.is_contiguous(), \
+            "LibComm.exchange moves contiguous uint8 buffers (code_knn.ExchangeLayout)"
         self.calls += 1
         if owner_blocks:
             _lib.call("qpg_comm_alltoall", self.device, self.handle, send, out, send.numel() // self.world)
@@ -139,31 +190,41 @@ def enable_lib_collectives(device, group=None):
     LibComm, or raises - the caller decides whether torch.distributed stays the transport (bench.py records the reason)."""
     global _libcomm
     if _libcomm is None:
-        # The bring-up (ncclCommInitRank: a rendezvous of all ranks) runs in a helper thread with a deadline: a rank whose
+        # The rendezvous (ncclCommInitRank: blocks until all ranks have arrived) runs under a deadline: a rank whose
         # rendezvous never completes reports a failure instead of hanging the job, and the caller's agreement step (bench.py:
         # a MIN all-reduce of the ranks' verdicts over torch.distributed) then puts EVERY rank on the torch.distributed
-        # transport.  W > 1 over xGMI has never been run here (no multi-GPU box behind gpurun): this is the seat belt.
+        # transport.  The id's broadcast - a torch.distributed collective - is made HERE, on the caller's thread, so an
+        # abandoned helper thread is never inside a process-group collective when the caller issues the next one; a helper
+        # that comes back late destroys its communicator itself (LibComm.__init__).  W > 1 over xGMI has never been run here
+        # (no multi-GPU box behind gpurun): this is the seat belt; tests/test_distributed_gloo.py injects the failure.
         import os
-        import threading
-        box = {}
-
-        def bring_up():
-            try:
-                torch.cuda.set_device(torch.device(device))      # (the current device is per thread: the id's broadcast
-                box["comm"] = LibComm(device, group)             # over an nccl group stages through it)
-            except Exception as e:                 # noqa: BLE001 (re-raised on the caller's thread)
-                box["err"] = e
-
         deadline = float(os.environ.get("QPG_LIB_COLLECTIVES_TIMEOUT_S", "120"))
-        th = threading.Thread(target=bring_up, name="qpg-libcomm-init", daemon=True)
-        th.start()
-        th.join(deadline)
-        if th.is_alive():
-            raise TimeoutError("LibComm: the RCCL rendezvous did not complete within %.0f s" % deadline)
-        if "err" in box:
-            raise box["err"]
-        _libcomm = box["comm"]
+        uid = LibComm.exchange_unique_id(group)
+        _libcomm = LibComm(device, group, uid=uid, deadline_s=deadline)
     return _libcomm
+
+
+def negotiate_lib_collectives(device, group=None):
+    """enable_lib_collectives + the AGREEMENT every caller of it needs: a rank that could not bring the library's
+    communicator up (no RCCL, a rendezvous that missed its deadline, a bad id) must not leave the others on it.  Each rank's
+    verdict is MIN-reduced over torch.distributed (the process group that is up by definition); unless every rank
+    succeeded, every rank closes what it has and stays on the torch.distributed transport.  Returns (enabled, why)."""
+    import torch.distributed as dist_
+    why = None
+    try:
+        enable_lib_collectives(device, group)
+        ok = 1
+    except Exception as e:                                        # noqa: BLE001 (reported to the caller)
+        ok, why = 0, repr(e)[:200]
+    if dist_.get_world_size(group) > 1:
+        gloo = dist_.get_backend(group) == "gloo"
+        f = torch.tensor([ok], dtype=torch.int32, device="cpu" if gloo else device)
+        dist_.all_reduce(f, op=dist_.ReduceOp.MIN, group=group)
+        ok = int(f.item())
+    if not ok:
+        disable_lib_collectives()
+        why = why or "another rank could not create the library's communicator"
+    return bool(ok), why
 
 
 def disable_lib_collectives():
@@ -217,6 +278,33 @@ def exchange_bytes(send, world, owner_blocks, group=None):
     return _exchange_into(None, send, world, owner_blocks, group)
 
 
+_hip_rt = None
+
+
+def _graph_node_count(g):
+    """Number of nodes of a captured torch.cuda.CUDAGraph(keep_graph=True), through the HIP runtime torch itself uses."""
+    global _hip_rt
+    import ctypes
+    if _hip_rt is None:
+        path = "libamdhip64.so"
+        try:                                   # the runtime this process has ALREADY mapped (torch ships its own copy): a
+            with open("/proc/self/maps") as f:  # second runtime would not know the graph handle
+                for ln in f:
+                    if "libamdhip64" in ln:
+                        path = ln.split()[-1]
+                        break
+        except OSError:
+            pass
+        _hip_rt = ctypes.CDLL(path)
+        _hip_rt.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        _hip_rt.hipGraphGetNodes.restype = ctypes.c_int
+    n = ctypes.c_size_t(0)
+    rc = _hip_rt.hipGraphGetNodes(ctypes.c_void_p(g.raw_cuda_graph()), None, ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError("hipGraphGetNodes failed (%d)" % rc)
+    return int(n.value)
+
+
 class SegmentRecorder:
     """A row-sharded clip as a PROGRAM: hipGraph, collective, hipGraph, collective, ..., hipGraph.
 
@@ -238,7 +326,8 @@ class SegmentRecorder:
 
     def begin(self):
         from . import _lib
-        self._g = torch.cuda.CUDAGraph()
+        # keep_graph: the hipGraph_t stays readable after capture_end, so end() can COUNT its nodes
+        self._g = torch.cuda.CUDAGraph(keep_graph=True)
         self._n0 = _lib.n_calls
         # thread_local: the process group's watchdog thread may query its events while this thread captures
         self._g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
@@ -247,15 +336,14 @@ class SegmentRecorder:
         from . import _lib
         g, self._g = self._g, None
         g.capture_end()
-        if _lib.n_calls == self._n0:
-            # No launch of this library's in the segment.  It may still hold torch-native nodes (a copy_, a zero_, an index
-            # op between two collectives), which a replay must not lose - or be empty, which torch refuses to
-            # replay.  One trial replay tells the two apart: an empty graph raises, anything else runs once more than
-            # the eager recording pass did (stream-ordered, during recording only).
-            try:
-                g.replay()
-            except Exception:                   # noqa: BLE001 (an empty capture)
-                return
+        if _lib.n_calls == self._n0 and _graph_node_count(g) == 0:
+            # No launch of this library's in the segment and no torch-native node either (a copy_, a zero_, an index op
+            # between two collectives would be one, and a replay must not lose it: ADVICE r4): an empty capture, which torch
+            # refuses to replay.  The nodes are COUNTED (hipGraphGetNodes on the kept graph), nothing is executed: round 5
+            # told the two cases apart by a trial replay, which ran a torch-only segment's in-place ops a second time during
+            # recording and hid real replay failures behind a bare except.
+            return
+        g.instantiate()
         self.program.append(g.replay)
         self.kinds.append("graph")
 

@@ -133,6 +133,8 @@ class VQVAE:
         # split-K scratch of the per-layer path (the whole-network calls carve theirs out of the workspace)
         self._split_ws = torch.empty((8 * 2048 * _pad(max(self.width, self.emb, self.bins), BN),), dtype=torch.float32,
                                      device=dev)
+        self.hl_latent_tol = None                # (measured per loaded set of weights; the conv objects - and their split-f16
+        self._img16_stale = False                #  images - are new)
         self._loaded = True
         return self
 
@@ -214,10 +216,19 @@ class VQVAE:
                     _lib.call("qpg_tpack_f32", dev, c1.w, c1.taps, c1.cin_pad, c1.cout_pad, 128, pack[n3:])
 
     def _refresh_tpack(self):
+        """Every inference entry point calls this first (the f32 ones since round 3, the split-f16 ones since round 6 -
+        ADVICE r5: encode_latent('f16x3'), encode_f16x3(_device), _hl_tolerance and decode_f16x3 ran on the weight images
+        and the latent tolerance of the PREVIOUS weights after a training step): whatever is a copy of the weights - the
+        T-packs, the split-f16 images, the measured latent tolerance - is rebuilt or dropped when the weights have moved."""
         if getattr(self, "_tpack_stale", False):
             self._tpack_rebuild()
             self._drop_conv16_images()           # (the split-f16 images are copies of the weights too)
             self.hl_latent_tol = None
+            self._img16_stale = False
+        elif getattr(self, "_img16_stale", False) and getattr(self, "_loaded", False):
+            self._drop_conv16_images()
+            self.hl_latent_tol = None
+            self._img16_stale = False
 
     def parameters(self):
         """(param, grad) flat buffers — what optim.Adam(model.parameters()) iterates in the reference (train.py:71)."""
@@ -379,6 +390,7 @@ class VQVAE:
         f32 matrix-core kernels (exact f32 FMA chains); "f16x3": the split-operand f16 kernels (qpg_conv16_f32), within
         ~1e-5 of them.  (encode()'s default is the whole-network f32 call, qpg_vq_encode_f32.)"""
         assert self._loaded, "load_state_dict first"
+        self._refresh_tpack()
         x = x.to(self.device, torch.float32).contiguous()
         B, T, C = x.shape
         if precision == "f16x3":
@@ -433,7 +445,9 @@ class VQVAE:
         bound (or an activation left the f16 range) and the HOST must encode it again on the f32 kernels
         (VQVAE.resolve_f16x3).  The latent tolerance must have been measured before (call _hl_tolerance(T) ahead of a
         capture)."""
-        assert self._loaded and getattr(self, "hl_latent_tol", None) is not None, "call _hl_tolerance(T) first"
+        assert self._loaded, "load_state_dict first"
+        self._refresh_tpack()                    # (weights moved since the tolerance was measured: it is gone, see below)
+        assert getattr(self, "hl_latent_tol", None) is not None, "call _hl_tolerance(T) first (again after a training step)"
         tol = float(self.hl_latent_tol)
         B = x.shape[0]
         st = getattr(self, "_c16_status", None)
@@ -471,6 +485,7 @@ class VQVAE:
     def _hl_tolerance(self, T):
         """Bound on |z_f16x3 - z_f32| (row-wise l2) assumed by encode_f16x3: 8 x the largest difference measured on a probe
         batch of standard-normal pose windows, once per loaded set of weights."""
+        self._refresh_tpack()
         tol = getattr(self, "hl_latent_tol", None)
         if tol is None:
             g = torch.Generator(device="cpu").manual_seed(20260929)
@@ -533,6 +548,7 @@ class VQVAE:
         A short sequence's layers are latency-bound chains of f32 matrix instructions (K = 1536 in steps of 4); the f16
         instruction covers K = 32, which is what shortens them."""
         assert self._loaded, "load_state_dict first"
+        self._refresh_tpack()
         ids = torch.as_tensor(zs[0]).to(self.device, torch.int64).contiguous()
         B, L = ids.shape
         st = getattr(self, "_c16_status", None)

@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -271,3 +272,66 @@ def test_segment_recorder_collectives_replay_on_persistent_buffers(tmp_path):
     out = str(tmp_path / "s.npz")
     mp.spawn(_worker_segments, args=(2, _free_port(), out), nprocs=2, join=True)
     assert int(np.load(out)["ok"][0]) == 1
+
+
+def _worker_libcomm_fault(rank, world, port, out, fault):
+    """The bring-up of the library's RCCL communicator with ONE rank failing (fault injection on CPU: the C entry points
+    are replaced by stubs, everything above them - the id's broadcast on the caller's thread, the deadline thread, the
+    abandoned-handle clean-up, the agreement, the fall-back transport - is the product's code)."""
+    import ctypes
+    import time
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["QPG_LIB_COLLECTIVES_TIMEOUT_S"] = "0.5"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qpgesture_amd import _lib, parallel as par
+    lib = _lib.load()
+    log = {"created": 0, "destroyed": 0, "uids": []}
+
+    def fake_unique_id(buf, n):
+        ctypes.memmove(buf, b"U" * 128, 128)
+        return 0
+
+    def fake_create(ctx, uid, n, r, w, out_h):
+        log["uids"].append(bytes(uid[:4]))
+        if r == 1 and fault == "hang":
+            time.sleep(2.0)                               # the rendezvous that never completes (deadline 0.5 s) ...
+        if r == 1 and fault == "bad_id":
+            return -2                                     # ... or RCCL refusing the id
+        log["created"] += 1
+        ctypes.cast(out_h, ctypes.POINTER(ctypes.c_void_p))[0] = 0x1234
+        return 0
+
+    def fake_destroy(h):
+        log["destroyed"] += 1
+        return 0
+
+    lib.qpg_comm_unique_id, lib.qpg_comm_create, lib.qpg_comm_destroy = fake_unique_id, fake_create, fake_destroy
+    _lib.ctx = lambda device: None
+    enabled, why = par.negotiate_lib_collectives("cpu")
+    # every rank on torch.distributed now; the exchange works and is the gloo one
+    send = torch.arange(4, dtype=torch.uint8) + 10 * rank
+    got = par.exchange_bytes(send, world, False)
+    want = torch.cat([torch.arange(4, dtype=torch.uint8) + 10 * w for w in range(world)])
+    time.sleep(2.0)                                       # (the abandoned helper thread comes back meanwhile)
+    np.save(out % rank, np.array([int(enabled), int(par._libcomm is None), int(torch.equal(got, want)), log["created"],
+                                  log["destroyed"], int(why is not None and ("Timeout" in why or "qpg_comm_create" in why
+                                                                             or "another rank" in why)),
+                                  int(all(u == b"UUUU" for u in log["uids"]))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fault", ["hang", "bad_id"])
+def test_lib_collectives_fall_back_on_every_rank_when_one_rendezvous_fails(tmp_path, fault):
+    """VERDICT r5 #12 / next #8b: a rank whose RCCL rendezvous misses its deadline (or whose id is refused) must put EVERY
+    rank on the torch.distributed transport - and its abandoned helper thread must neither touch the process group nor
+    leak the communicator it gets late."""
+    out = str(tmp_path / ("lc_%s_%%d.npy" % fault))
+    mp.spawn(_worker_libcomm_fault, args=(2, _free_port(), out, fault), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0).tolist(), np.load(out % 1).tolist()
+    # enabled, _libcomm is None, exchange ok, created, destroyed, reason given, the broadcast id arrived
+    assert r0 == [0, 1, 1, 1, 1, 1, 1], r0                 # rank 0 had a communicator and closed it
+    if fault == "hang":
+        assert r1 == [0, 1, 1, 1, 1, 1, 1], r1             # rank 1's came late and was destroyed by the helper itself
+    else:
+        assert r1 == [0, 1, 1, 0, 0, 1, 1], r1

@@ -508,6 +508,44 @@ def test_db_cache_file_format_roundtrip_on_the_host(tmp_path):
     assert k1 == db_cache.file_key([str(f1)], {"tie_rule": "numpy"}) != db_cache.file_key([str(f1)], {"tie_rule": "stable"})
     os.utime(str(f1), ns=(5, 5))
     assert db_cache.file_key([str(f1)], {"tie_rule": "numpy"}) != k1
+    # round 6: a header that names a foreign module / a non-class, or that does not parse, is a MISS - never an
+    # import of that module and never an exception on every later run
+    import json
+    open(p, "wb").write(raw)
+    hl = int.from_bytes(raw[8:16], "little")
+    head = json.loads(raw[16:16 + hl].decode())
+
+    for bad in (dict(head, **{"class": "os:system"}), dict(head, **{"class": "qpgesture_amd.db_cache:VERSION"}),
+                dict(head, **{"class": "nonsense"}), dict(head, tensors=[{"name": "x"}]), dict(head, attrs=7),
+                dict(head, data_bytes="many")):
+        hb = json.dumps(bad).encode()
+        if len(hb) > hl:
+            continue
+        blob = raw[:8] + hl.to_bytes(8, "little") + hb + b" " * (hl - len(hb)) + raw[16 + hl:]   # (JSON ignores the padding)
+        open(p, "wb").write(blob)
+        assert db_cache.load(p, "cpu", "kk") is None, bad
+    nested = json.loads(json.dumps(head))
+    nested["attrs"]["txt_sorted"]["__object__"] = "subprocess:Popen"
+    hb = json.dumps(nested).encode()
+    open(p, "wb").write(raw[:8] + hl.to_bytes(8, "little") + hb + b" " * (hl - len(hb)) + raw[16 + hl:])
+    assert db_cache.load(p, "cpu", "kk") is None
+    open(p, "wb").write(raw[:16] + b"{" * hl + raw[16 + hl:])
+    assert db_cache.load(p, "cpu", "kk") is None
+    # save(): a failure leaves no tmp file behind; eviction by sources and by count
+    db.bad = torch.arange(12).reshape(3, 4).t()                        # not contiguous
+    with pytest.raises(ValueError):
+        db_cache.save(db, p, "kk")
+    assert not [n for n in os.listdir(str(tmp_path)) if ".tmp." in n]
+    del db.__dict__["bad"]
+    d2 = tmp_path / "cache"
+    paths = [str(d2 / ("db_%02d.qpgdb" % i)) for i in range(4)]
+    db_cache.save(db, paths[0], "k0", sources="S")
+    db_cache.save(db, paths[1], "k1", sources="T")
+    db_cache.save(db, paths[2], "k2", sources="S")                     # same sources as [0]: [0] goes
+    assert sorted(os.listdir(str(d2))) == ["db_01.qpgdb", "db_02.qpgdb"]
+    db_cache.save(db, paths[3], "k3", sources="U", keep=2)             # at most two files stay: the oldest ([1]) goes
+    assert sorted(os.listdir(str(d2))) == ["db_02.qpgdb", "db_03.qpgdb"]
+    assert db_cache.load(paths[3], "cpu", "k3") is not None
 
 
 def test_c_abi_argument_checks_under_asan_ubsan():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A variant build of ONE kernel source into its own library (run with QPG_LIB_PATH=<that .so>): the product objects of every
-# other source + this one compiled with extra defines.  What tools/r05_probe_bits.sh, r05_ab_nt*.sh, r05_probe_gemm64.sh and
+# other source + this one compiled with extra defines.  What experiments/round_scripts/r05_probe_bits.sh, r05_ab_nt*.sh, r05_probe_gemm64.sh and
 # r05_probe_conv16.sh run over.
 #   tools/build_variant.sh qpg_audio_hl p122nt "-DH2_PROBE=122 -DH2_NT=1" experiments/audio_hl      -> .../libqpg_p122nt.so
 #   tools/build_variant.sh qpg_audio_hl g1 "-DG64_PROBE=1" experiments/gemm32/var                   -> .../libqpg_pg1.so (name it pg1)
