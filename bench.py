@@ -138,6 +138,9 @@ def main():
                     help="feature statistics of the synthetic DB and clips: i.i.d. N(0,1) (SURVEY.md §8d, the default line) "
                          "or speech-like (AR(1) rho 0.95 on rank-64 mixtures, 10 %% near-silent frames, repeating context "
                          "rows): prints the re-evaluation list populations the capped selects see (`band_lists`)")
+    ap.add_argument("--no-sub-records", action="store_true",
+                    help="skip the compact records of BASELINE configs[2], [3] (one GPU) and [4] that the default one-GPU run "
+                         "appends to its line (`sub_records`: each is this script run again with that configuration's flags)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vqvae", action="store_true", help="skip the VQ-VAE legs")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (H2D-inclusive) measurements")
@@ -889,10 +892,79 @@ def main():
         ok = bool(np.array_equal(np.concatenate(want), codes.numpy().astype(np.int64)))
         out["check"] = ok
         assert ok, "rank %d: sharded result differs from the single-rank result" % rank
+    if (rank == 0 and world == 1 and default_shape and a.workload == "match" and a.data == "gaussian" and not force_sharded
+            and a.clips_in_flight == 1 and not a.encode_batch and not a.no_sub_records and a.audio_precision == "mixed"):
+        out["sub_records"] = sub_records(dev)
     if rank == 0:
         print(json.dumps(out), file=JSON_OUT, flush=True)
     if world > 1 or force_sharded:
         dist.destroy_process_group()
+
+
+# The other BASELINE.json configurations in the driver's line (cfg-3, configs[3] on one GPU and
+# configs[4] existed only as builder-run lines under profiles/).  Each entry is THIS script run again as a child process with
+# that configuration's flags (so the numbers are exactly what `python bench.py <flags>` prints) and a short timed region;
+# the record keeps the fields a reader needs.  The children run after the parent's own timed regions, one at a time.
+SUB_RUNS = [
+    ("cfg3", "BASELINE configs[2]: 100 000 x 512-d rows, 512 codes, 1 000 queries - per-code min + argmin",
+     ["--workload", "cfg3", "--steps", "30", "--warmup", "5"]),
+    ("strong8192", "BASELINE configs[3] on ONE GPU: one 24 s clip vs N_db = 8192 windows (the whole speaker-1-class DB on one "
+                   "device; the 8-GPU row-sharded form needs a node)",
+     ["--scaling", "strong", "--steps", "40", "--warmup", "5"]),
+    ("clips16_f16_enc96", "BASELINE configs[4]: 16 clips per replay, fp16 features, 96 pose windows VQ-VAE-encoded in the step",
+     ["--clips", "16", "--feature-dtype", "f16", "--encode-batch", "96", "--steps", "20", "--warmup", "3"]),
+]
+SUB_COMMON = ["--gpus", "1", "--no-sub-records", "--no-cpu-baseline", "--no-vqvae", "--no-cold", "--no-e2e", "--no-f64-line"]
+
+
+def sub_records(dev):
+    import subprocess
+    out = {}
+    env = dict(os.environ)
+    for name, what, flags in SUB_RUNS:
+        if os.environ.get("QPG_BENCH_SUB", "") and name not in os.environ["QPG_BENCH_SUB"].split(","):
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__)] + flags + SUB_COMMON
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"what": what, "error": "rc %d: %s" % (r.returncode, r.stderr.decode()[-300:])}
+                continue
+            d = json.loads(line[-1])
+        except (subprocess.TimeoutExpired, ValueError) as e:
+            out[name] = {"what": what, "error": repr(e)[:300]}
+            continue
+        rf = d.get("roofline", {})
+        rec = {"what": what, "command": "python bench.py " + " ".join(flags),
+               "metric": d.get("metric"), "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"),
+               "steps": d.get("steps"), "step_mode": d.get("step_mode"), "dtype": d.get("dtype"),
+               "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes",
+                                                    "algorithmic_gflop", "kernel_ms", "issued_tflops_f16", "issued_frac")
+                            if k in rf},
+               "wall_s": round(time.perf_counter() - t0, 1)}
+        if isinstance(rf.get("hbm"), dict):
+            rec["roofline"]["hbm"] = {k: rf["hbm"].get(k) for k in ("achieved", "frac", "algorithmic_bytes")}
+        if isinstance(rf.get("mfma"), dict):
+            rec["roofline"]["mfma_issued_frac_of_f16_peak"] = rf["mfma"].get("frac")
+        if "tables_equal_exact_sweep" in d:
+            rec["tables_equal_exact_sweep"] = d["tables_equal_exact_sweep"]
+        mp_ = d.get("mixed_precision") or {}
+        for k in ("codes_equal_f64_sweep", "winners_equal_f64_sweep", "ranks_equal_f64_sweep"):
+            if k in mp_:
+                rec[k] = mp_[k]
+        gr = d.get("graph_replay") or {}
+        for k in ("other_seed_equals_eager", "encoded_ids_equal_eager_encode", "clips_per_replay"):
+            if k in gr:
+                rec[k] = gr[k]
+        if "eager" in d and d["eager"]:
+            rec["eager_ms_per_step"] = d["eager"].get("ms_per_step")
+            rec["codes_equal_eager_steps"] = d["eager"].get("codes_equal_graph_steps")
+        if "realtime_factor" in d:
+            rec["realtime_factor"] = d["realtime_factor"]
+        out[name] = rec
+    return out
 
 
 def rocprof_kernel_ms(key):

@@ -121,6 +121,7 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
     """bench.py --workload cfg3: one step = normalise the 1 000 queries + the fused sweep / per-code minimum + merge.
     N > 1: the DB is row-sharded (replicas of the query set), no exchange is timed (each rank reports its shard's
     tables; the min+index merge across shards is the same qpg_merge_select_f32 as the matcher's)."""
+    import torch
     import torch.distributed as dist
     X, code, valid, q = make_inputs()
     per = (N_DB + world - 1) // world
@@ -210,7 +211,6 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
                             "+ percode_select_sorted_kernel (+ query normalise / pack)"),
             "kernel_ms": round(k_ms, 4),
             "hbm": hbm_view,
-            "valu": valu_view,
             "note": "the tables are sklearn's separately rounded f32 arithmetic (bit-exact indices are the bar): the matrix "
                     "cores run a PREFILTER with an a-priori bound, only the rows inside each (query, code) band get the exact "
                     "order.  The whole step (GEMM + select + packs) is priced against the dense f16 matrix peak; the GEMM "
@@ -222,6 +222,15 @@ def bench(a, dev, world, rank, hbm_peak_gbs):
                                note="the distance is sklearn's separately rounded f32 arithmetic (bit-exact indices are the "
                                     "bar), so neither FMA nor the matrix cores are admissible: the kernel is VALU-bound")
         rec["roofline"]["bound"] = "hbm"          # (the contract's vocabulary; the binding unit is the VALU: see `valu`)
+    if mfma and world == 1:
+        # the timed path's tables against the exact-order sweep (every pair in sklearn's f32 arithmetic, no prefilter) on the
+        # same inputs, outside the timed region: distances, first-wins indices and nearest neighbours bit for bit
+        index._force_valu = True
+        try:
+            de, ie, ne = index.query(qd)
+        finally:
+            index._force_valu = False
+        rec["tables_equal_exact_sweep"] = bool(torch.equal(out[0], de) and torch.equal(out[1], ie) and torch.equal(out[2], ne))
     return rec
 
 

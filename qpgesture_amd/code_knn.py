@@ -1703,6 +1703,125 @@ class ClipPipeline:
         return out
 
 
+class GraphPipeline:
+    """Throughput mode on captured graphs (round 6): `depth` lanes, each ONE hipGraph of `clips_per_replay` independent clips
+    (ClipGraph(n_clips): one batched sweep over all their queries - the database image comes out of HBM once per 48-query
+    chunk's first touch and out of the XCD's L2 after that - the batched selects and ONE batched walk), replayed on the
+    lane's own stream.  What it buys over a clip at a time (the one-clip step is 2x its sweep, ~100 us of
+    near-empty dependent launches behind it; ClipPipeline's eager lanes are host-bound at ~0.25 ms per clip and their tails
+    never ran under another clip's sweep, because a one-chunk sweep holds every register of every CU for its whole
+    duration): the post-sweep chain is paid once per REPLAY, not once per clip; a host call costs one hipGraphLaunch per
+    `clips_per_replay` clips; and a multi-chunk sweep finishes its blocks in rounds, so the other lane's tail kernels get
+    CUs while it runs.  The reference's loop over test clips (GestureKNN.py:785-813) has no state between clips, so any
+    grouping returns the same codes; every clip's integers reach the host before its ticket is collected, and a clip whose
+    trouble word is raised is matched again eagerly (CodeKNN.rematch) before anything is returned.
+    Latency per clip goes UP (a clip waits for its group): this is the serving-throughput figure, bench.py reports it
+    beside the one-clip `value`, never instead."""
+
+    def __init__(self, db, n_windows, clips_per_replay=4, depth=2, mode=MODE_AUD_TXT, rng=None, **knn_flags):
+        if depth < 1 or clips_per_replay < 1:
+            raise ValueError("depth and clips_per_replay must be >= 1")
+        if db.world != 1:
+            raise NotImplementedError("GraphPipeline: one GPU holding the whole database (clip-parallel across GPUs: one "
+                                      "pipeline per rank, bench.py --scaling replicated)")
+        self.db, self.M, self.G, self.mode = db, int(n_windows), int(clips_per_replay), mode
+        self.lanes = []
+        for _ in range(depth):
+            knn = CodeKNN(db, rng=rng, **knn_flags)
+            self.lanes.append(dict(knn=knn, stream=torch.cuda.Stream(db.device), graph=None, busy=False, seeds=None))
+        self._next = 0
+        self.rematched = 0
+
+    @property
+    def depth(self):
+        return len(self.lanes)
+
+    def _graph(self, ln):
+        if ln["graph"] is None:
+            ln["graph"] = ln["knn"].capture_clip_graph(self.M, self.mode, n_clips=self.G)
+        return ln["graph"]
+
+    def buffers(self, lane):
+        """The lane's static input tensors (audio [G*M, T, F] or wavvq ids, context [G*M, 30, Dt]): a caller that produces
+        its clips on the device can write them here directly and submit(None, None, ...)."""
+        g = self._graph(self.lanes[lane])
+        return g.audio, g.context
+
+    def submit(self, audio, context, seed_codes, seed_phases):
+        """Enqueue `clips_per_replay` clips on the next lane (which must have been collected); returns the ticket.
+        audio / context: the clips' windows back to back ([G*M, ...] device tensors), copied into the lane's static
+        buffers on the lane's stream - or None: the buffers already hold them (buffers()).  seed_codes: G ints (or one for
+        all); seed_phases: [G][8][16] floats (or one block for all)."""
+        t = self._next
+        ln = self.lanes[t]
+        if ln["busy"]:
+            raise RuntimeError("lane %d still holds an uncollected group: collect() it first" % t)
+        g = self._graph(ln)
+        dev = self.db.device
+        st = ln["stream"]
+        caller = torch.cuda.current_stream(dev)                # (the stream the caller produced its inputs on)
+        with torch.cuda.stream(st):
+            if audio is not None:
+                st.wait_stream(caller)
+                if audio.data_ptr() != g.audio.data_ptr():
+                    g.audio.copy_(audio, non_blocking=True)
+                if context is not None and context.data_ptr() != g.context.data_ptr():
+                    g.context.copy_(context, non_blocking=True)
+            g.launch(seed_codes, seed_phases)
+        ln["busy"], ln["seeds"] = True, (seed_codes, seed_phases)
+        self._next = (t + 1) % len(self.lanes)
+        return t
+
+    def collect(self, ticket):
+        """Wait for the group of `ticket`; returns a list of (codes int64 [M,30], votes i32 [M,steps]) per clip (copies)."""
+        ln = self.lanes[ticket]
+        if not ln["busy"]:
+            raise RuntimeError("lane %d holds no group" % ticket)
+        g, knn = ln["graph"], ln["knn"]
+        with torch.cuda.stream(ln["stream"]):
+            ints = g.wait_ints()
+        ln["busy"] = False
+        st = g.statuses(ints)
+        n_c, n_v = g._n_c, g._n_v
+        codes = ints[:self.G * n_c].reshape(self.G, self.M, num_frames_code).astype(np.int64)
+        votes = ints[self.G * n_c:self.G * (n_c + n_v)].reshape(self.G, self.M, -1).copy()
+        out = []
+        for c in range(self.G):
+            try:
+                CodeKNN.check_status(st[c])
+                out.append((codes[c], votes[c]))
+            except GuardOverflow as e:
+                # never return codes the guard could not vouch for: this clip again, eagerly, on a path that cannot raise
+                # the word (the sticky word was cleared by wait_ints)
+                sc, sp = ln["seeds"]
+                sc_c = int(np.asarray(sc).reshape(-1)[c if np.asarray(sc).size > 1 else 0])
+                sp_a = np.asarray(sp.detach().cpu().numpy() if isinstance(sp, torch.Tensor) else sp, np.float32).reshape(-1, 128)
+                sp_c = sp_a[c if sp_a.shape[0] > 1 else 0].reshape(8, 16)
+                with torch.cuda.stream(ln["stream"]):
+                    r = knn.rematch(e.flags, g.audio[c * self.M:(c + 1) * self.M].contiguous(),
+                                    g.context[c * self.M:(c + 1) * self.M].contiguous(), self.M, self.mode, sc_c, sp_c)
+                self.rematched += 1
+                out.append((r[0], r[2]))
+        return out
+
+    def phases(self, ticket):
+        """The last collected group's phase blocks of lane `ticket` (device tensor [G*M, steps, 8, 16]; valid until the lane's
+        next submit)."""
+        return self.lanes[ticket]["graph"].out[1]
+
+    def match_groups(self, groups, seeds):
+        """groups: iterable of (audio, context) with G clips each; seeds: list of (seed_codes, seed_phases) per group.
+        Returns the per-clip results in order."""
+        out, pending = [], []
+        for i, (a_, c_) in enumerate(groups):
+            if len(pending) == len(self.lanes):
+                out.extend(self.collect(pending.pop(0)))
+            pending.append(self.submit(a_, c_, *seeds[i]))
+        while pending:
+            out.extend(self.collect(pending.pop(0)))
+        return out
+
+
 def predict_code_from_audio(db, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, rng=None):
     """predict_code_from_audio (GestureKNN.py:724-813) for the shipped flags; returns (M,30) int64."""
     knn = CodeKNN(db, rng=rng)

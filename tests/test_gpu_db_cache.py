@@ -90,6 +90,11 @@ def test_cli_second_invocation_takes_the_cache_and_writes_the_same_bytes(tmp_pat
     assert first.dtype == np.int64 and np.array_equal(first, second) and np.array_equal(first, off)
     stable, _ = run(["--tie_rule", "stable"])                                # another key (options are part of it)
     assert len(os.listdir(cdir)) == 2
+    before = set(os.listdir(cdir))
     os.utime(paths["train_codebook"], ns=(1, 1))                             # the database changed on disk
     third, o3 = run()
-    assert "prepared-database cache)" not in o3 and np.array_equal(third, first) and len(os.listdir(cdir)) == 3
+    # a new key - and the cache file of the SAME sources under the old key is evicted (round 6: db_cache.prune), the other
+    # options' file stays
+    after = set(os.listdir(cdir))
+    assert "prepared-database cache)" not in o3 and np.array_equal(third, first)
+    assert len(after) == 2 and len(after & before) == 1 and not [n for n in after if ".tmp." in n]

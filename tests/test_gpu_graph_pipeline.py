@@ -1,0 +1,91 @@
+"""GraphPipeline (round 6): several clips per captured replay, several replays in flight - the serving-throughput mode.
+The reference's loop over test clips (GestureKNN.py:785-813) carries no state from clip to clip, so every grouping must
+return, clip for clip, what CodeKNN.match_clip returns for that clip alone with the same seed; a clip whose trouble word
+is raised inside a group is never handed out unguarded."""
+import numpy as np
+import pytest
+
+from tests.helpers import fixture_arrays, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _db(N, seed):
+    from qpgesture_amd import synth
+    from qpgesture_amd.data_processing import interp_wavlm
+    tr = synth.make_db(N, seed, 1024)
+    return dict(interp=interp_wavlm(tr["wavlm"]), ctx=np.ascontiguousarray(tr["context"].squeeze(2)),
+                code=synth.make_codes(N, seed + 1), phase=tr["phase_dense"], sig=synth.make_signature(seed + 2))
+
+
+@pytest.mark.parametrize("G,depth", [(3, 2), (1, 3), (5, 1)])
+def test_groups_in_flight_equal_one_clip_at_a_time(G, depth):
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB, GraphPipeline
+    A = _db(160, 410)
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(4))
+    M, n_groups = 2, 5
+    g = torch.Generator(device="cpu").manual_seed(31 + G)
+    groups, seeds, want = [], [], []
+    for i in range(n_groups):
+        ti = torch.randn((G * M, 180, 1024), generator=g).cuda()
+        tc = torch.randn((G * M, 30, 384), generator=g).cuda()
+        sc, sp = [], []
+        for c in range(G):
+            c_, p_ = knn.init_code_phase()
+            sc.append(c_)
+            sp.append(p_)
+            want.append(knn.match_clip(ti[c * M:(c + 1) * M], tc[c * M:(c + 1) * M], M, seed_code=c_, seed_phase=p_))
+        groups.append((ti, tc))
+        seeds.append((sc, np.stack(sp)))
+    pipe = GraphPipeline(db, M, clips_per_replay=G, depth=depth, rng=np.random.RandomState(5))
+    got = pipe.match_groups(groups, seeds)
+    assert len(got) == n_groups * G and pipe.rematched == 0
+    for (codes, votes), w in zip(got, want):
+        assert codes.dtype == np.int64 and np.array_equal(codes, w[0]) and np.array_equal(votes, w[2])
+    assert len({tuple(w[0].reshape(-1)) for w in want}) > 1                       # the clips really differ
+    # one capture per lane, whatever the number of groups; a lane refuses a second group before the first is collected
+    assert all(ln["graph"] is None or ln["graph"].captures == 1 for ln in pipe.lanes)
+    t = pipe.submit(*groups[0], *seeds[0])
+    if depth == 1:
+        with pytest.raises(RuntimeError):
+            pipe.submit(*groups[1], *seeds[1])
+    # phase blocks of the group: those of the clips alone
+    first = pipe.collect(t)
+    ph = pipe.phases(t).cpu().numpy().reshape(G, M, -1, 8, 16)
+    for c in range(G):
+        assert np.array_equal(first[c][0], want[c][0]) and np.array_equal(ph[c], want[c][1])
+    # inputs written straight into the lane's buffers
+    a_, c_ = pipe.buffers(pipe._next)
+    a_.copy_(groups[2][0])
+    c_.copy_(groups[2][1])
+    again = pipe.collect(pipe.submit(None, None, *seeds[2]))
+    for c in range(G):
+        assert np.array_equal(again[c][0], want[2 * G + c][0])
+
+
+def test_a_flagged_clip_inside_a_group_is_rematched():
+    """The near-silent golden stretch (780 candidates within 1e-14 of each other: the capped lists overflow) as one clip of a
+    group of two: the group's trouble word is raised, both clips are matched again eagerly, both results are those of the
+    clips alone (whose own match re-matches the quiet one)."""
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB, GraphPipeline
+    g = load_golden("shipped_nearsilent_n48_m2_s50")
+    ntr, nte, s0, s1, s2, s3, mf = [int(v) for v in g["meta"]]
+    variant = (str(g["variant"]) or None) if "variant" in g.files else None
+    A = fixture_arrays(ntr, nte, s0, s1, s2, s3, variant=variant)
+    db = GestureDB(A["code"], A["tr_interp"], A["tr_ctx"], A["tr_phase"], A["sig"], device="cuda:0",
+                   freq_rank=g["step_freq_score"])
+    knn = CodeKNN(db, rng=np.random.RandomState(123456))
+    te_i = torch.from_numpy(A["te_interp"]).cuda()
+    te_c = torch.from_numpy(np.ascontiguousarray(A["te_ctx"])).cuda()
+    sc, sp = knn.init_code_phase()
+    want = [knn.match_clip(te_i[c:c + 1], te_c[c:c + 1], 1, seed_code=sc, seed_phase=sp) for c in range(2)]
+    assert knn.fallbacks >= 1                                                   # (the quiet window needs the uncapped path)
+    pipe = GraphPipeline(db, 1, clips_per_replay=2, depth=2, rng=np.random.RandomState(1))
+    for _ in range(2):                                                          # the sticky word must not leak into the next group
+        got = pipe.collect(pipe.submit(te_i[:2], te_c[:2], sc, sp))
+        for c in range(2):
+            assert np.array_equal(got[c][0], want[c][0]) and np.array_equal(got[c][1], want[c][2])
+    assert pipe.rematched >= 2
