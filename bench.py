@@ -779,43 +779,77 @@ def main():
                                **({"segments": list(cg.segment_kinds)} if cg.segmented else {})}
     if (mixed and not sharded_run and world == 1 and can_pipe and pipe is None and not a.no_f64_line and
             os.environ.get("QPG_BENCH_NO_PIPELINED", "") != "1"):
-        # the same per-clip launches with three clips in flight (ClipPipeline: the next clips' sweeps are enqueued before a
-        # clip's indices are collected, so the host's ~50 us between a step's last GPU event and the next step's first
-        # launch and the thinly occupied tail overlap another clip's sweep); every clip's indices still reach the host
-        # inside the timed region.  A throughput figure beside the one-clip-at-a-time `value`, not a replacement for it.
-        from qpgesture_amd.code_knn import ClipPipeline
-        p3 = ClipPipeline(db, depth=3, rng=np.random.RandomState(123456))
-        for ln in p3.lanes:
-            ln["knn"].overlap_sweeps = knn.overlap_sweeps
-            ln["knn"].audio_precision = knn.audio_precision
-            ln["knn"].audio_kernel = knn.audio_kernel
+        # Clips in flight (round 6: GraphPipeline).  Round 5's figure here came from ClipPipeline's eager lanes: host-bound
+        # (~0.25 ms of Python per clip) and without overlap - a one-chunk sweep holds every register of every CU, so another
+        # clip's tail kernels advance by one launch per sweep.  Now: `clips_per_replay` independent clips per captured graph
+        # (one batched sweep - the database image out of HBM once, out of the XCD's L2 for the other chunks - batched selects,
+        # ONE batched walk: the ~100 us post-sweep chain is paid once per replay) on `lanes` streams (a multi-chunk sweep
+        # retires its blocks in rounds, the other lane's tail gets CUs meanwhile).  Every clip's integers are on the host
+        # inside the timed region; the clips of a group are DIFFERENT clips and each is compared with the one-clip path.
+        # A throughput figure beside the one-clip-at-a-time `value`, not a replacement for it (a clip's latency goes up).
+        from qpgesture_amd.code_knn import GraphPipeline
+        out["pipelined"] = {}
+        for key_, G_, L_ in (("", int(os.environ.get("QPG_BENCH_PIPE_CLIPS", "4")), int(os.environ.get("QPG_BENCH_PIPE_LANES", "2"))),
+                             ("deeper", 8, 2)):
+            gp = GraphPipeline(db, M, clips_per_replay=G_, depth=L_, rng=np.random.RandomState(123456))
+            for ln in gp.lanes:
+                ln["knn"].overlap_sweeps = knn.overlap_sweeps
+                ln["knn"].audio_precision = knn.audio_precision
+                ln["knn"].audio_kernel = knn.audio_kernel
+            gclips = [clips[0]] + [synth.make_db(M, 2000 + r) for r in range(1, G_)]
+            gi = torch.from_numpy(np.concatenate([interp_wavlm(c["wavlm"]) for c in gclips])).to(dev)
+            gc_ = torch.from_numpy(np.concatenate([c["context"].squeeze(2) for c in gclips])).to(dev)
+            want_g = [codes.numpy().reshape(-1).astype(np.int64)] + [
+                knn.match_clip(gi[c * M:(c + 1) * M], gc_[c * M:(c + 1) * M], M, seed_code=seed_code,
+                               seed_phase=seed_phase)[0].reshape(-1) for c in range(1, G_)]
+            for l_ in range(L_):
+                ba_, bc_ = gp.buffers(l_)
+                ba_.copy_(gi)
+                bc_.copy_(gc_)
 
-        def run3(n):
-            pending, res = [], None
-            for _ in range(n):
-                if len(pending) == p3.depth:
-                    res = p3.collect(pending.pop(0))[0]
-                pending.append(p3.submit(te_interp, te_ctx, M, seed_code=seed_code, seed_phase=seed_phase_d))
-            while pending:
-                res = p3.collect(pending.pop(0))[0]
-            return torch.from_numpy(res.astype(np.int32))
-        run3(30)
-        gc.collect()
-        gc.disable()
-        d7s = []
-        for _ in range(3):              # 100 steps are 30 ms: one hiccup of the host doubles the figure - best of three
+            def run_g(n, gp=gp, L_=L_):
+                pending, res = [], None
+                for _ in range(n):
+                    if len(pending) == L_:
+                        res = gp.collect(pending.pop(0))
+                    pending.append(gp.submit(None, None, seed_code, seed_phase))
+                while pending:
+                    res = gp.collect(pending.pop(0))
+                return res
+            n_g = max(10, 120 // G_)
+            run_g(max(5, n_g // 3))
+            gc.collect()
+            gc.disable()
+            d7s = []
+            for _ in range(3):              # ~20 ms each: one hiccup of the host shows - best of three, all three reported
+                fence()
+                t7 = time.perf_counter()
+                rg = run_g(n_g)
+                fence()
+                d7s.append(time.perf_counter() - t7)
             fence()
-            t7 = time.perf_counter()
-            c3 = run3(100)
+            t8 = time.perf_counter()
+            for _ in range(10):
+                gp.collect(gp.submit(None, None, seed_code, seed_phase))     # one group at a time: a group's latency
             fence()
-            d7s.append(time.perf_counter() - t7)
-        gc.enable()
-        d7 = min(d7s)
-        out["pipelined"] = {"clips_in_flight": 3, "steps": 100, "ms_per_step": round(d7 / 100 * 1e3, 4),
-                            "ms_per_step_all_three_runs": [round(x / 100 * 1e3, 4) for x in d7s],
-                            "frames_per_s": round(frames_per_step * 100 / d7, 1),
-                            "codes_equal_default_path": bool(torch.equal(c3.reshape(-1), codes.reshape(-1).to(torch.int32))),
-                            "rematched_steps": p3.fallbacks}
+            lat = (time.perf_counter() - t8) / 10
+            gc.enable()
+            d7 = min(d7s)
+            rec_ = {"clips_in_flight": G_ * L_, "clips_per_replay": G_, "lanes": L_, "steps": n_g * G_,
+                    "ms_per_step": round(d7 / (n_g * G_) * 1e3, 4),
+                    "ms_per_step_all_three_runs": [round(x / (n_g * G_) * 1e3, 4) for x in d7s],
+                    "frames_per_s": round(frames_per_step * n_g * G_ / d7, 1),
+                    "latency_ms_per_group_one_at_a_time": round(lat * 1e3, 4),
+                    "codes_equal_default_path": bool(all(np.array_equal(rg[c][0].reshape(-1), want_g[c]) for c in range(G_))),
+                    "distinct_clips_per_group": len({tuple(w) for w in want_g}),
+                    "rematched_steps": gp.rematched,
+                    "step": "one clip of a group; a replay = one hipGraph of %d clips (ClipGraph(n_clips)), %d replays in "
+                            "flight on their own streams (code_knn.GraphPipeline)" % (G_, L_)}
+            if key_:
+                out["pipelined"][key_] = rec_
+            else:
+                out["pipelined"].update(rec_)
+            del gp
     if serial is not None:
         serial["roofline_frac"] = (round(alg_bytes / (serial["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if hl else
                                    round(flops / (serial["kernel_ms"] * 1e-3) / 1e12 / peak, 4))

@@ -536,11 +536,16 @@ __device__ __forceinline__ double pair_dot_wave_f64(const GuardArgs& A, int q, i
 
 // Workspace of the cut launch: per query [parking space | streamed state].
 //   parking space   best u64 K | v f64 K | besti u32 K | near u32 K | n, order-valid, pad (16 B) | l_c i32 L | l_k i32 L | l_d f64 L | order i16 K
-//   streamed state  inv u32 K (NOT of the minimum's order key, merged by atomicMax: all-zero = empty) | survivors of each
-//                   slice i32 [MIX_SPLIT] (-1: its list overflowed) | pot_c i32 P | pot_d f32 P | pot_k i16 P
+//   streamed state  inv u32 [MIX_SPLIT][K] (NOT of each slice's minimum's order key, 0 = the slice has no candidate of the
+//                   code; every slice stores its whole row - round 6: 196 K device-scope atomicMax per clip into one
+//                   shared row were the slowest thing the streaming pass did, experiments/epilogue_atomics) | survivors of
+//                   each slice i32 [MIX_SPLIT] (-1: its list overflowed) | pot_c i32 P | pot_d f32 P | pot_k i16 P
 //                   (P = MIX_SPLIT x MIX_SPOT: slice s owns entries [s MIX_SPOT, (s + 1) MIX_SPOT) - no global counter)
 // The streamed states are ALL-ZERO between launches (the list kernel resets what it consumes; offsets do not depend on
 // Q): the caller zero-fills the workspace once.
+#ifndef MIX_INV_ATOMIC
+#define MIX_INV_ATOMIC 0  // 1 (A/B builds only): round 5's merge of the slices' minima - atomicMax into one shared row
+#endif
 #define MIX_SPLIT 8       // blocks per query streaming the row
 #define MIX_SPOT 3072     // potential band members a slice can hold in LDS
 #define MIX_GPOT (MIX_SPLIT * MIX_SPOT)
@@ -551,7 +556,7 @@ __host__ __device__ __forceinline__ size_t mix_park_order_off(int K) {
   return 24 * (size_t)K + 16 + 8 * (size_t)MIX_LIST + 8 * (size_t)MIX_LIST;
 }
 __host__ __device__ __forceinline__ size_t mix_ws_stride(int K) {          // bytes of one query's space (multiple of 16)
-  return ((mix_park_bytes(K) + 4 * (size_t)K + 4 * MIX_SPLIT + 10 * (size_t)MIX_GPOT) + 15) & ~(size_t)15;
+  return ((mix_park_bytes(K) + 4 * (size_t)K * MIX_SPLIT + 4 * MIX_SPLIT + 10 * (size_t)MIX_GPOT) + 15) & ~(size_t)15;
 }
 struct MixStream {        // one query's streamed state
   unsigned int* inv;
@@ -567,7 +572,7 @@ __host__ __device__ __forceinline__ MixStream mix_stream_of(unsigned char* ws, i
   unsigned char* b = mix_query_base(ws, q, K) + mix_park_bytes(K);
   MixStream m;
   m.inv = reinterpret_cast<unsigned int*>(b);
-  m.cnt = reinterpret_cast<int*>(b + 4 * (size_t)K);
+  m.cnt = reinterpret_cast<int*>(b + 4 * (size_t)K * MIX_SPLIT);
   m.pot_c = m.cnt + MIX_SPLIT;
   m.pot_d = reinterpret_cast<float*>(m.pot_c + MIX_GPOT);
   m.pot_k = reinterpret_cast<int16_t*>(m.pot_d + MIX_GPOT);
@@ -719,8 +724,12 @@ __global__ __launch_bounds__(1024) void mixed_stream_kernel(const float* __restr
   __syncthreads();
   SEL_STAMP(1);
   MixStream m = mix_stream_of(ws, q, K);
-  for (int k = tid; k < K; k += blockDim.x)
-    if (best32[k] != 0xffffffffu) atomicMax(&m.inv[k], ~best32[k]);
+  if (MIX_INV_ATOMIC) {
+    for (int k = tid; k < K; k += blockDim.x)
+      if (best32[k] != 0xffffffffu) atomicMax(&m.inv[k], ~best32[k]);
+  } else {
+    for (int k = tid; k < K; k += blockDim.x) m.inv[(size_t)sl * K + k] = ~best32[k];     // (0: no candidate in this slice)
+  }
   SEL_STAMP(2);
   const int np = n_pot;
   if (np > MIX_SPOT) {                        // the list kernel then streams the row itself (its own fallback)
@@ -866,9 +875,16 @@ __global__ __launch_bounds__(1024) void percode_select_mixed_f64_kernel(
   if (K32) {
     for (int k = tid; k < K; k += blockDim.x) {
       unsigned int b;
-      if (streamed) {
+      if (streamed && MIX_INV_ATOMIC) {
         b = ~ms.inv[k];
         ms.inv[k] = 0;                        // (left all-zero for the next launch)
+      } else if (streamed) {
+        unsigned int iv[MIX_SPLIT], mx = 0u;  // the slices' rows: independent loads, one round trip
+#pragma unroll
+        for (int sl = 0; sl < MIX_SPLIT; ++sl) iv[sl] = ms.inv[(size_t)sl * K + k];
+#pragma unroll
+        for (int sl = 0; sl < MIX_SPLIT; ++sl) mx = iv[sl] > mx ? iv[sl] : mx;
+        b = ~mx;
       } else {
         b = best32[k];
       }
