@@ -263,6 +263,12 @@ int64_t qpg_hl_rows_bytes(int64_t R, int D);
 int64_t qpg_hl_cols_bytes(int Q, int D);
 int qpg_hl_pack_rows(qpg_ctx*, void* stream, const float* xs, int64_t R, int D, void* image, int64_t image_bytes);
 int qpg_hl_pack_cols(qpg_ctx*, void* stream, const float* qn, int Q, int D, void* image, int64_t image_bytes);
+/* Round 6: the query side of a prefilter batch in ONE launch - qpg_l2_normalize_rows_f32 (sklearn's normalize, bit for bit)
+ * + qpg_hl_pack_cols + qpg_perm32_rows_f32 on the RAW queries q [dev] f32 [Q][D]: qn_out (optional) [dev] f32 [Q][D] the
+ * normalised rows, cols_image qpg_hl_cols_bytes(Q, D) bytes, qperm_out (optional) [dev] f32 [Q][D] the chain-permuted
+ * normalised rows qpg_percode_select_bycode_f32 reads.  Outputs bit-identical to the three calls.  D %% 128 == 0. */
+int qpg_hl_prepare_queries(qpg_ctx*, void* stream, const float* q, int Q, int D, float* qn_out, void* cols_image,
+                           int64_t image_bytes, float* qperm_out);
 int qpg_hl_gemm_distance(qpg_ctx*, void* stream, const void* rows_image, int64_t R, int D, const void* cols_image, int Q,
                          float* Dm, int64_t ldD, float* tile_min, int64_t ldT);
 /* Round 4: the same GEMM WITHOUT its matrix - per (query, 16-row tile) the minimum and a 16-bit mask of the rows within

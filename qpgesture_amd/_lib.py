@@ -43,6 +43,7 @@ _SIGS = {
     "qpg_probe_mfma_f16_tile": [P, P, P, I, P],
     "qpg_hl_pack_rows": [P, L, I, P, L],
     "qpg_hl_pack_cols": [P, I, I, P, L],
+    "qpg_hl_prepare_queries": [P, I, I, P, P, L, P],
     "qpg_hl_gemm_distance": [P, L, I, P, I, P, L, P, L],
     "qpg_percode_select_sorted_f32": [P, L, P, P, L, I, L, P, P, P, P, I, c_float, P, P, I, c_float, P, P, P, P, P,
                                       ctypes.c_int32, I, L],

@@ -89,12 +89,17 @@ class CosineIndex:
         """q: f32 [Q][d] device tensor.  Returns (dist f32 [Q][K], idx i32 [Q][K], nn i32 [Q])."""
         dev = self.device
         Q = q.shape[0]
-        qn = torch.empty_like(q)
-        _lib.call("qpg_l2_normalize_rows_f32", dev, q, Q, self.d, qn)
+        qn = None
         if self.method == "mfma" and not getattr(self, "_force_valu", False):
             self.sorted.band = self.band
             nn = torch.empty((Q,), dtype=torch.int32, device=dev) if want_nn else None
-            dist, idx, nn = self.sorted.select(qn, ABSENT, self._stats, nn=nn, scratch=self._scratch)
+            if self.sorted.uses_by_code(Q) and getattr(self, "fused_prepare", True):
+                # (round 6) normalise + column image + permuted copy: one launch on the raw queries
+                dist, idx, nn = self.sorted.select_raw(q, ABSENT, self._stats, nn=nn, scratch=self._scratch)
+            else:
+                qn = torch.empty_like(q)
+                _lib.call("qpg_l2_normalize_rows_f32", dev, q, Q, self.d, qn)
+                dist, idx, nn = self.sorted.select(qn, ABSENT, self._stats, nn=nn, scratch=self._scratch)
             if not getattr(self, "check_flags", True):
                 return dist, idx, nn                   # (timing loops: the flag is read once, after the loop)
             if int(self._stats[1].item()) == 0:
@@ -102,6 +107,9 @@ class CosineIndex:
             # a band list overflowed (massive exact ties): the exact sweep decides this batch
             self._stats.zero_()
             self.fallbacks += 1
+        if qn is None:
+            qn = torch.empty_like(q)
+            _lib.call("qpg_l2_normalize_rows_f32", dev, q, Q, self.d, qn)
         need = int(_lib.load().qpg_text_percode_ws_bytes(self.n, Q, self.K, self.tiles_per_chunk))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)

@@ -1356,6 +1356,118 @@ extern "C" int qpg_hl_pack_cols(qpg_ctx* ctx, void* stream, const float* q, int 
   return QPG_OK;
 }
 
+// ---- round 6: the query side of a prefilter + by-code batch in ONE launch ------------------------------------------------
+// cfg-3's step spent ~40 of its 300 us in three tiny launches in front of the GEMM - sklearn's normalisation (16 blocks: four
+// lanes per row walking NumPy-einsum's chains), the split-f16 column image, the chain-permuted copy the by-code select reads
+// - and the gaps between them.  One block per query does all three: the norm by four lanes in the reference's order
+// (l2_normalize_rows_kernel's code, bit for bit), the normalised row through LDS, then qn (optional), the column image
+// (hl_pack_cols_kernel's layout and exponent) and the permuted row (perm32_kernel's layout).  Padding queries of the last
+// chunk of 96 write zero fragments, as hl_pack_cols_kernel does.
+__global__ __launch_bounds__(128) void hl_prepare_queries_kernel(const float* __restrict__ q, int Q, int D,
+                                                                 float* __restrict__ qn, _Float16* __restrict__ image,
+                                                                 int32_t* __restrict__ qexp, float* __restrict__ qperm) {
+  extern __shared__ __attribute__((aligned(16))) float rowbuf[];         // [D] the normalised row
+  __shared__ float n_s, red[2];
+  __shared__ int e_s;
+  const int qi = blockIdx.x, tid = threadIdx.x;
+  const bool live = qi < Q;
+  const float* p = q + (int64_t)(live ? qi : 0) * D;
+  if (tid < 4) {                                       // the norm, in NumPy einsum's order (lane chains l = 0..3)
+    const int l = tid;
+    float a = 0.f;
+    const int nfull = D >> 4;
+    int g = 0;
+    for (; g + 8 <= nfull; g += 8) {
+      float v[32];
+#pragma unroll
+      for (int jx = 0; jx < 32; ++jx) v[jx] = p[(g + (jx >> 2)) * 16 + (jx & 3) * 4 + l];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) {
+#pragma unroll
+        for (int u = 3; u >= 0; --u) a = f_add(f_mul(v[jx * 4 + u], v[jx * 4 + u]), a);
+      }
+    }
+    for (; g < nfull; ++g) {
+#pragma unroll
+      for (int u = 3; u >= 0; --u) {
+        const float v = p[g * 16 + u * 4 + l];
+        a = f_add(f_mul(v, v), a);
+      }
+    }
+    for (int i = nfull * 16; i < D; i += 4) {
+      const float v = (i + l < D) ? p[i + l] : 0.f;
+      a = f_add(f_mul(v, v), a);
+    }
+    const float o1 = __shfl_xor(a, 1, 64);
+    const float pair = f_add(a, o1);
+    const float o2 = __shfl_xor(pair, 2, 64);
+    float n = f_sqrt(f_add(pair, o2));
+    if (n < 10.f * 1.1920928955078125e-07f) n = 1.f;   // sklearn _handle_zeros_in_scale
+    if (l == 0) n_s = n;
+  }
+  __syncthreads();
+  const float n = n_s;
+  float m = 0.f;
+  for (int e = tid; e < D; e += 128) {
+    const float v = live ? f_div(p[e], n) : 0.f;
+    rowbuf[e] = v;
+    if (live && qn) qn[(int64_t)qi * D + e] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    m = fmaxf(red[0], red[1]);
+    e_s = hl_exponent(m);
+    if (live) qexp[qi] = e_s;
+  }
+  __syncthreads();
+  const float sc = ldexpf(1.0f, e_s);
+  const int KB = D / 32, K8 = D / 8;
+  const int chunk = qi / HL_GQC, qq = qi % HL_GQC;
+  for (int k8 = tid; k8 < K8; k8 += 128) {
+    const int k = k8 * 8;
+    h8 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 a0, b0;
+      split_hl(rowbuf[k + e] * sc, a0, b0);
+      hh[e] = a0;
+      ll[e] = b0;
+    }
+    const int kb = k / 32, ct = qq / 16, lane = (qq & 15) + 16 * ((k & 31) >> 3);
+    const int64_t piece = ((((int64_t)chunk * KB + kb) * HL_CT + ct) * 2);
+    reinterpret_cast<h8*>(image)[(piece + 0) * 64 + lane] = hh;
+    reinterpret_cast<h8*>(image)[(piece + 1) * 64 + lane] = ll;
+  }
+  if (live && qperm) {
+    // y[32 G + 8 k + j] = x[16 (2 G + (j >> 2)) + 4 (3 - (j & 3)) + k]   (perm32_kernel, csrc/qpg_sorted.hip)
+    float* y = qperm + (int64_t)qi * D;
+    for (int e = tid; e < D; e += 128) {
+      const int G = e >> 5, k = (e & 31) >> 3, j = e & 7;
+      y[e] = rowbuf[16 * (2 * G + (j >> 2)) + 4 * (3 - (j & 3)) + k];
+    }
+  }
+}
+
+extern "C" int qpg_hl_prepare_queries(qpg_ctx* ctx, void* stream, const float* q, int Q, int D, float* qn, void* image,
+                                      int64_t image_bytes, float* qperm) {
+  const char* name = "qpg_hl_prepare_queries";
+  QPG_REQUIRE(ctx && q && image && Q > 0 && D > 0 && (D % 128) == 0 && D <= 8192, "%s: bad argument (D %% 128 == 0, D <= 8192)",
+              name);
+  QPG_REQUIRE(image_bytes >= qpg_hl_cols_bytes(Q, D) && (reinterpret_cast<uintptr_t>(image) % 16) == 0,
+              "%s: image too small or misaligned (qpg_hl_cols_bytes)", name);
+  QPG_REQUIRE(q != qn && q != qperm && (qn == nullptr || qn != qperm), "%s: outputs must not alias the input", name);
+  const int chunks = (Q + HL_GQC - 1) / HL_GQC;
+  unsigned char* img = static_cast<unsigned char*>(image);
+  int32_t* qexp = reinterpret_cast<int32_t*>(img + (int64_t)chunks * (D / 32) * HL_CT * 2 * HL_PIECE);
+  hipLaunchKernelGGL(hl_prepare_queries_kernel, dim3(chunks * HL_GQC), dim3(128), (size_t)D * 4, qpg_stream(stream), q, Q, D,
+                     qn, reinterpret_cast<_Float16*>(img), qexp, qperm);
+  QPG_LAUNCH_CHECK("hl_prepare_queries_kernel");
+  return QPG_OK;
+}
+
 // ---- the prefilter GEMM on 32-ROW wave tiles (round 4): hl_gemm32_kernel --------------------------------------------------
 // hl_gemm16_kernel inherits round 3's sweep organisation (16 rows x 96 columns per wave, f64 block sums).  For the
 // prefilter of the exact-f32 cosine family the band is dominated by sklearn's own rounding (8.6e-5 at D = 512), so the

@@ -126,17 +126,22 @@ class SortedRows:
     def uses_by_code(self, Q, q_block=0):
         return bool(self.by_code and Q >= self.by_code_min_q and self.d % 128 == 0 and q_block == 0 and self.use_masks)
 
-    def _select_by_code(self, qn, absent, stats, dist, idx, nn, rank, idx_base, sc, cols_packed):
-        dev, Q = self.device, qn.shape[0]
+    def _select_by_code(self, qn, absent, stats, dist, idx, nn, rank, idx_base, sc, cols_packed, raw=None):
+        dev = self.device
+        Q = (raw if qn is None else qn).shape[0]
         nt, ldq = self.R // 16, (Q + 15) // 16 * 16
         if sc.get("tmin_t") is None or sc["tmin_t"].shape != (nt, ldq):
             sc["tmin_t"] = torch.empty((nt, ldq), dtype=torch.float32, device=dev)
             sc["tmask_t"] = torch.empty((nt, ldq), dtype=torch.int16, device=dev)
-        if sc.get("qperm") is None or sc["qperm"].shape != qn.shape:
-            sc["qperm"] = torch.empty_like(qn)
-        if not cols_packed:
-            _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, sc["cols"], sc["cols"].numel())
-        _lib.call("qpg_perm32_rows_f32", dev, qn, Q, self.d, sc["qperm"])
+        if sc.get("qperm") is None or tuple(sc["qperm"].shape) != (Q, self.d):
+            sc["qperm"] = torch.empty((Q, self.d), dtype=torch.float32, device=dev)
+        if raw is not None:
+            # round 6: sklearn's normalisation, the column image and the chain-permuted copy in ONE launch on the raw queries
+            _lib.call("qpg_hl_prepare_queries", dev, raw, Q, self.d, None, sc["cols"], sc["cols"].numel(), sc["qperm"])
+        else:
+            if not cols_packed:
+                _lib.call("qpg_hl_pack_cols", dev, qn, Q, self.d, sc["cols"], sc["cols"].numel())
+            _lib.call("qpg_perm32_rows_f32", dev, qn, Q, self.d, sc["qperm"])
         _lib.call("qpg_hl_gemm_tilemin_h", dev, self.image, self.R, self.d, sc["cols"], Q, self.band_h, sc["tmin_t"],
                   sc["tmask_t"], ldq)
         _lib.call("qpg_percode_select_bycode_f32", dev, sc["tmin_t"], sc["tmask_t"], ldq, Q, self.R, self.row_code,
@@ -178,6 +183,22 @@ class SortedRows:
         if scratch.get("cols") is None or scratch["cols"].numel() < nb:
             scratch["cols"] = torch.empty((nb,), dtype=torch.uint8, device=self.device)
         return scratch["cols"]
+
+    def select_raw(self, q, absent, stats, dist=None, idx=None, nn=None, rank=None, idx_base=0, scratch=None):
+        """select() on RAW (not yet normalised) queries q f32 [Q][d], for batches that take the by-code path
+        (uses_by_code(Q)): the whole query side - sklearn's normalisation included - is one launch (qpg_hl_prepare_queries).
+        Same tables, bit for bit, as select(normalise(q))."""
+        dev, Q = self.device, q.shape[0]
+        if not self.uses_by_code(Q):
+            raise ValueError("select_raw: this batch does not take the by-code path (normalise and call select)")
+        sc = scratch if scratch is not None else {}
+        nb = int(_lib.load().qpg_hl_cols_bytes(Q, self.d))
+        if sc.get("cols") is None or sc["cols"].numel() < nb:
+            sc["cols"] = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        if dist is None:
+            dist = torch.empty((Q, self.K), dtype=torch.float32, device=dev)
+            idx = torch.empty((Q, self.K), dtype=torch.int32, device=dev)
+        return self._select_by_code(None, absent, stats, dist, idx, nn, rank, idx_base, sc, False, raw=q.contiguous())
 
     def select(self, qn, absent, stats, dist=None, idx=None, nn=None, rank=None, idx_base=0, q_block=0, block_stride=0,
                scratch=None, cols_packed=False):

@@ -347,3 +347,52 @@ def test_cfg3_h_plane_prefilter_and_by_code_select_equal_the_exact_sweep():
     assert idx2.fallbacks == 1
     for a, b in zip(got5, want5):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("Qn,Dn", [(1000, 512), (257, 384), (96, 128), (5, 1024)])
+def test_fused_query_prepare_equals_the_three_launches(Qn, Dn):
+    """Round 6: qpg_hl_prepare_queries (sklearn's normalisation + the split-f16 column image + the chain-permuted copy in one
+    launch on the raw queries) against qpg_l2_normalize_rows_f32 + qpg_hl_pack_cols + qpg_perm32_rows_f32: every output byte
+    equal - ragged last chunk of 96, an all-zero query (sklearn leaves it at zero), a tiny-norm and a huge-norm query."""
+    import torch
+    from qpgesture_amd import _lib
+    dev = torch.device("cuda:0")
+    rng = np.random.Generator(np.random.PCG64(Qn * 7 + Dn))
+    q = rng.standard_normal((Qn, Dn), dtype=np.float32)
+    q[1] = 0.0
+    q[2] *= np.float32(1e-20)
+    q[3] *= np.float32(1e15)
+    qd = torch.from_numpy(q).to(dev)
+    nb = int(_lib.load().qpg_hl_cols_bytes(Qn, Dn))
+    qn_a, qp_a = torch.empty_like(qd), torch.empty_like(qd)
+    img_a = torch.full((nb,), 0x5a, dtype=torch.uint8, device=dev)
+    _lib.call("qpg_l2_normalize_rows_f32", dev, qd, Qn, Dn, qn_a)
+    _lib.call("qpg_hl_pack_cols", dev, qn_a, Qn, Dn, img_a, nb)
+    _lib.call("qpg_perm32_rows_f32", dev, qn_a, Qn, Dn, qp_a)
+    qn_b, qp_b = torch.empty_like(qd), torch.empty_like(qd)
+    img_b = torch.full((nb,), 0xa5, dtype=torch.uint8, device=dev)
+    _lib.call("qpg_hl_prepare_queries", dev, qd, Qn, Dn, qn_b, img_b, nb, qp_b)
+    assert torch.equal(qn_a.view(torch.int32), qn_b.view(torch.int32))
+    assert torch.equal(qp_a.view(torch.int32), qp_b.view(torch.int32))
+    chunks = (Qn + 95) // 96
+    frag = chunks * (Dn // 32) * 6 * 2 * 1024
+    assert torch.equal(img_a[:frag], img_b[:frag])                              # fragments incl. the zero padding queries
+    assert torch.equal(img_a[frag:frag + 4 * Qn], img_b[frag:frag + 4 * Qn])    # the scale exponents of the live queries
+    # optional outputs may be left out
+    img_c = torch.empty_like(img_b)
+    _lib.call("qpg_hl_prepare_queries", dev, qd, Qn, Dn, None, img_c, nb, None)
+    assert torch.equal(img_c[:frag], img_a[:frag])
+
+
+def test_cfg3_fused_prepare_and_three_launch_paths_return_the_same_tables():
+    import torch
+    from qpgesture_amd.cfg3 import CosineIndex
+    X, code, valid, q, rows = _inputs()
+    qd = torch.from_numpy(q).cuda()
+    index = CosineIndex(X, code, valid, n_codes=K)
+    assert index.sorted.uses_by_code(Q)
+    a = index.query(qd)
+    index.fused_prepare = False
+    b = index.query(qd)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
