@@ -57,6 +57,10 @@ int qpg_ctx_destroy(qpg_ctx* ctx);
 int qpg_ctx_set_option(qpg_ctx* ctx, int option, int value);
 int qpg_ctx_get_option(qpg_ctx* ctx, int option, int* value);
 int qpg_last_error(char* buf, size_t n);
+/* Stream-ordered signal to the host: *dst = value (system-scope store by a one-thread kernel) once everything enqueued on
+ * `stream` before this call has completed.  dst: [host-pinned, device-accessible or dev] i32.  The multi-lane replay
+ * pipeline (qpgesture_amd.code_knn.GraphPipeline) polls it to learn that a replay's sweep is over. */
+int qpg_signal_i32(qpg_ctx*, void* stream, int32_t* dst, int32_t value);
 
 /* ------------------------------------------------------------------------------------------
  * Database preparation (one-off per speaker DB; replaces the host-side feature windowing of

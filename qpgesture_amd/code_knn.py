@@ -8,6 +8,8 @@ Design difference from the reference (same results): the audio and text scans de
 the query position, never on the running (code, phase) state, so all Q = 8*M scans of a clip are
 issued as two batched sweeps, and the sequential part walks (Q,512) tables on the device.
 """
+import time
+
 import numpy as np
 import torch
 
@@ -1236,7 +1238,7 @@ class CodeKNN:
 
     def capture_clip_graph(self, n_windows, mode=MODE_AUD_TXT, n_sweep_windows=None, window_offset=0, audio=None,
                            context=None, owner_blocks=False, n_clips=1, encoder=None, encode_input=None,
-                           encode_precision="f32"):
+                           encode_precision="f32", sweep_signal=False):
         """Capture the whole per-clip launch sequence (pack, both sweeps, per-code argmin passes, ranks,
         rank-fusion tables, walk) into one HIP graph for a fixed clip shape.  Returns a ClipGraph whose
         run(test_audio, test_context, seed_code, seed_phase) replays it; results are device tensors.
@@ -1247,7 +1249,7 @@ class CodeKNN:
         encoder / encode_input: a VQVAE and a resident pose batch f32 [B][T][C] whose encode (make_beat_dataset.py:314-316)
         runs INSIDE the capture on a branch of its own beside the match - one replay = the fused encode + match step."""
         return ClipGraph(self, n_windows, mode, n_sweep_windows or n_windows * n_clips, window_offset, audio, context,
-                         owner_blocks, n_clips, encoder, encode_input, encode_precision)
+                         owner_blocks, n_clips, encoder, encode_input, encode_precision, sweep_signal)
 
     def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
                    seed_phase=None, return_tables=False):
@@ -1319,9 +1321,13 @@ class ClipGraph:
     sentinel, hipGraphLaunch, watch the status word.  One capture serves every clip of that shape."""
 
     def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset, audio=None, context=None, owner_blocks=False,
-                 n_clips=1, encoder=None, encode_input=None, encode_precision="f32"):
+                 n_clips=1, encoder=None, encode_input=None, encode_precision="f32", sweep_signal=False):
         db, dev = knn.db, knn.db.device
         self.owner_blocks = owner_blocks
+        # sweep_signal (GraphPipeline): a one-thread kernel behind the audio sweep stores 1 into pinned host memory
+        # (qpg_signal_i32) - the host learns that the replay's sweep is over without waiting for its tail
+        self._sweep_flag = torch.zeros((1,), dtype=torch.int32).pin_memory() if sweep_signal else None
+        self._sweep_flag_np = self._sweep_flag.numpy() if sweep_signal else None
         self.CL = int(n_clips)
         if self.CL < 1 or n_sweep_windows < window_offset + self.CL * n_windows:
             raise ValueError("n_clips x n_windows windows must lie inside the swept windows")
@@ -1453,6 +1459,8 @@ class ClipGraph:
                     encode_leg()
                 else:
                     knn.after_sweep = encode_leg
+            elif self._sweep_flag is not None:
+                knn.after_sweep = lambda: _lib.call("qpg_signal_i32", dev, self._sweep_flag.data_ptr(), 1)
             try:
                 T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode, owner_blocks=self.owner_blocks,
                                      for_walk=True)
@@ -1538,12 +1546,18 @@ class ClipGraph:
         if self.graph is None:
             self._capture()
         self._pin_np.fill(_PIN_SENTINEL)
+        if self._sweep_flag_np is not None:
+            self._sweep_flag_np[0] = 0
         self._in_flight = True
         if self.segmented:
             for f in self._program:                 # hipGraphLaunch, collective, hipGraphLaunch, ...
                 f()
         else:
             self.graph.replay()
+
+    def sweep_done(self):
+        """sweep_signal graphs: has the replay in flight passed its audio sweep?  (True when nothing is in flight.)"""
+        return (not self._in_flight) or self._sweep_flag_np is None or self._sweep_flag_np[0] != 0
 
     def wait_ints(self):
         """Host-side wait for the replay's last store (the status words, behind a system-scope fence); returns a copy of
@@ -1718,7 +1732,7 @@ class GraphPipeline:
     Latency per clip goes UP (a clip waits for its group): this is the serving-throughput figure, bench.py reports it
     beside the one-clip `value`, never instead."""
 
-    def __init__(self, db, n_windows, clips_per_replay=4, depth=2, mode=MODE_AUD_TXT, rng=None, **knn_flags):
+    def __init__(self, db, n_windows, clips_per_replay=4, depth=2, mode=MODE_AUD_TXT, rng=None, stagger=True, **knn_flags):
         if depth < 1 or clips_per_replay < 1:
             raise ValueError("depth and clips_per_replay must be >= 1")
         if db.world != 1:
@@ -1731,6 +1745,15 @@ class GraphPipeline:
             self.lanes.append(dict(knn=knn, stream=torch.cuda.Stream(db.device), graph=None, busy=False, seeds=None))
         self._next = 0
         self.rematched = 0
+        # stagger: a lane's replay is launched only when the replay launched BEFORE it (another lane's) has passed its audio
+        # sweep.  Left to themselves two lanes fall into lockstep - their sweeps share the CUs (each takes twice as long),
+        # end together, and both tails then run on an otherwise idle GPU (profiles/r06_pipeline_timeline_4x2_lockstep.md:
+        # 330 of every 1 240 us with no sweep resident).  Staggered, the sweeps follow one another back to back and a lane's
+        # tail runs underneath the other lane's sweep.  The host learns "sweep over" from a word the replay stores into
+        # pinned memory behind its sweep kernel (ClipGraph(sweep_signal=True), qpg_signal_i32).
+        self.stagger = bool(stagger) and depth > 1 and mode in (MODE_AUD_TXT, MODE_AUD)
+        self._last = None                       # lane of the most recently launched replay
+        self.stagger_timeouts = 0
 
     @property
     def depth(self):
@@ -1738,8 +1761,20 @@ class GraphPipeline:
 
     def _graph(self, ln):
         if ln["graph"] is None:
-            ln["graph"] = ln["knn"].capture_clip_graph(self.M, self.mode, n_clips=self.G)
+            ln["graph"] = ln["knn"].capture_clip_graph(self.M, self.mode, n_clips=self.G, sweep_signal=self.stagger)
         return ln["graph"]
+
+    def _wait_previous_sweep(self):
+        if not self.stagger or self._last is None:
+            return
+        g = self.lanes[self._last]["graph"]
+        if g is None or g.sweep_done():
+            return
+        t0 = time.perf_counter()
+        while not g.sweep_done():
+            if time.perf_counter() - t0 > 0.05:         # (a replay whose sweep never signals: do not hang the pipeline)
+                self.stagger_timeouts += 1
+                return
 
     def buffers(self, lane):
         """The lane's static input tensors (audio [G*M, T, F] or wavvq ids, context [G*M, 30, Dt]): a caller that produces
@@ -1767,7 +1802,11 @@ class GraphPipeline:
                     g.audio.copy_(audio, non_blocking=True)
                 if context is not None and context.data_ptr() != g.context.data_ptr():
                     g.context.copy_(context, non_blocking=True)
+            if g.graph is None:
+                g._capture()                     # (the first replay of a lane: capture before waiting for the other lane)
+            self._wait_previous_sweep()
             g.launch(seed_codes, seed_phases)
+        self._last = t
         ln["busy"], ln["seeds"] = True, (seed_codes, seed_phases)
         self._next = (t + 1) % len(self.lanes)
         return t

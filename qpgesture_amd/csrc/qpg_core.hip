@@ -92,6 +92,22 @@ extern "C" int qpg_ctx_destroy(qpg_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// A stream-ordered signal to the host (round 6, GraphPipeline): one thread stores `value` to *dst - pinned host memory
+// the device can reach - at system scope, behind everything enqueued on the stream before it.  What the host polls to learn
+// that a replay's SWEEP is over (the moment the other lane's sweep may start) without waiting for the replay's tail.
+// ---------------------------------------------------------------------------------------------
+__global__ void signal_i32_kernel(int32_t* dst, int32_t value) {
+  __hip_atomic_store(dst, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int qpg_signal_i32(qpg_ctx* ctx, void* stream, int32_t* dst, int32_t value) {
+  QPG_REQUIRE(ctx && dst && (reinterpret_cast<uintptr_t>(dst) % 4) == 0, "qpg_signal_i32: null or misaligned destination");
+  hipLaunchKernelGGL(signal_i32_kernel, dim3(1), dim3(1), 0, qpg_stream(stream), dst, value);
+  QPG_LAUNCH_CHECK("signal_i32_kernel");
+  return QPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-frame squared norm in f64: one wave per row, 16 B loads, wave64 shuffle reduce.
 // HBM-bound: reads rows*F*4 bytes once.
 // ---------------------------------------------------------------------------------------------

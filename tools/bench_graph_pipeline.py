@@ -18,15 +18,16 @@ phase = rng.standard_normal((N, 240, 4, 8)).astype(np.float32)
 db = GestureDB(synth.make_codes(N, 2), interp, ctx, phase, synth.make_signature(3), device=dev)
 knn = CodeKNN(db, rng=np.random.RandomState(123456))
 sc, sp = knn.init_code_phase()
-combos = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or \
-    [(1, 1), (1, 2), (2, 1), (2, 2), (4, 1), (4, 2), (4, 3), (8, 1), (8, 2), (16, 1)]
-Gmax = max(g for g, _ in combos)
+# G:lanes[:stagger]   stagger 1 (default): a lane's replay waits for the previous lane's SWEEP; 0: launched at once
+combos = [(tuple(int(x) for x in a.split(":")) + (1,))[:3] for a in sys.argv[1:]] or \
+    [(1, 1, 1), (2, 2, 0), (2, 2, 1), (2, 3, 1), (4, 1, 1), (4, 2, 0), (4, 2, 1), (4, 3, 1), (8, 2, 0), (8, 2, 1), (16, 1, 1)]
+Gmax = max(c[0] for c in combos)
 g_ = torch.Generator(device="cpu").manual_seed(7)
 te_i = torch.randn((Gmax * M, 180, 1024), generator=g_).to(dev)
 te_c = torch.randn((Gmax * M, 30, 384), generator=g_).to(dev)
 want = [knn.match_clip(te_i[c * M:(c + 1) * M], te_c[c * M:(c + 1) * M], M, seed_code=sc, seed_phase=sp)[0] for c in range(Gmax)]
-for G, depth in combos:
-    pipe = GraphPipeline(db, M, clips_per_replay=G, depth=depth, rng=np.random.RandomState(1))
+for G, depth, stag in combos:
+    pipe = GraphPipeline(db, M, clips_per_replay=G, depth=depth, rng=np.random.RandomState(1), stagger=bool(stag))
     for ln in range(depth):
         a_, c_ = pipe.buffers(ln)
         a_.copy_(te_i[:G * M])
@@ -51,6 +52,7 @@ for G, depth in combos:
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / (n * G))
     ok = all(np.array_equal(res[c][0], want[c]) for c in range(G))
-    print("clips/replay %2d lanes %d: %.4f ms per clip (%.2f M frames/s), %.3f ms per replay, codes equal one-clip path: %s, rematched %d"
-          % (G, depth, best * 1e3, 240 * M / best / 1e6, best * 1e3 * G, ok, pipe.rematched), flush=True)
+    print("clips/replay %2d lanes %d stagger %d: %.4f ms per clip (%.2f M frames/s), %.3f ms per replay, codes equal one-clip path: %s, "
+          "rematched %d, stagger timeouts %d" % (G, depth, int(pipe.stagger), best * 1e3, 240 * M / best / 1e6, best * 1e3 * G, ok,
+                                                 pipe.rematched, pipe.stagger_timeouts), flush=True)
     del pipe
