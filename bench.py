@@ -789,9 +789,12 @@ def main():
         # A throughput figure beside the one-clip-at-a-time `value`, not a replacement for it (a clip's latency goes up).
         from qpgesture_amd.code_knn import GraphPipeline
         out["pipelined"] = {}
-        for key_, G_, L_ in (("", int(os.environ.get("QPG_BENCH_PIPE_CLIPS", "4")), int(os.environ.get("QPG_BENCH_PIPE_LANES", "2"))),
-                             ("deeper", 8, 2)):
-            gp = GraphPipeline(db, M, clips_per_replay=G_, depth=L_, rng=np.random.RandomState(123456))
+        # (staggered lanes: a replay is launched when the other lane's SWEEP is over, so the sweeps follow one another and a
+        # lane's tail runs under the other lane's sweep - profiles/r06_pipeline_timeline_*.md; it pays at 4 clips per replay,
+        # not at 8, where a lane's sweep is long against its tail either way: tools/bench_graph_pipeline.py)
+        for key_, G_, L_, S_ in (("", int(os.environ.get("QPG_BENCH_PIPE_CLIPS", "4")),
+                                  int(os.environ.get("QPG_BENCH_PIPE_LANES", "2")), True), ("deeper", 8, 2, False)):
+            gp = GraphPipeline(db, M, clips_per_replay=G_, depth=L_, rng=np.random.RandomState(123456), stagger=S_)
             for ln in gp.lanes:
                 ln["knn"].overlap_sweeps = knn.overlap_sweeps
                 ln["knn"].audio_precision = knn.audio_precision
@@ -835,7 +838,8 @@ def main():
             lat = (time.perf_counter() - t8) / 10
             gc.enable()
             d7 = min(d7s)
-            rec_ = {"clips_in_flight": G_ * L_, "clips_per_replay": G_, "lanes": L_, "steps": n_g * G_,
+            rec_ = {"clips_in_flight": G_ * L_, "clips_per_replay": G_, "lanes": L_, "staggered_lanes": bool(gp.stagger),
+                    "steps": n_g * G_,
                     "ms_per_step": round(d7 / (n_g * G_) * 1e3, 4),
                     "ms_per_step_all_three_runs": [round(x / (n_g * G_) * 1e3, 4) for x in d7s],
                     "frames_per_s": round(frames_per_step * n_g * G_ / d7, 1),
