@@ -951,6 +951,10 @@ SUB_RUNS = [
      ["--scaling", "strong", "--steps", "40", "--warmup", "5"]),
     ("clips16_f16_enc96", "BASELINE configs[4]: 16 clips per replay, fp16 features, 96 pose windows VQ-VAE-encoded in the step",
      ["--clips", "16", "--feature-dtype", "f16", "--encode-batch", "96", "--steps", "20", "--warmup", "3"]),
+    ("clips16_f16_enc96_f16x3", "the same with the encoder on the split-f16 convolutions under their margin check (windows the "
+                                "bound cannot vouch for are re-encoded in f32 inside the step: ids identical)",
+     ["--clips", "16", "--feature-dtype", "f16", "--encode-batch", "96", "--encode-precision", "f16x3", "--steps", "20",
+      "--warmup", "3"]),
 ]
 SUB_COMMON = ["--gpus", "1", "--no-sub-records", "--no-cpu-baseline", "--no-vqvae", "--no-cold", "--no-e2e", "--no-f64-line"]
 
@@ -993,7 +997,8 @@ def sub_records(dev):
             if k in mp_:
                 rec[k] = mp_[k]
         gr = d.get("graph_replay") or {}
-        for k in ("other_seed_equals_eager", "encoded_ids_equal_eager_encode", "clips_per_replay"):
+        for k in ("other_seed_equals_eager", "encoded_ids_equal_eager_encode", "clips_per_replay", "encode_precision",
+                  "encode_windows_re_encoded_in_f32"):
             if k in gr:
                 rec[k] = gr[k]
         if "eager" in d and d["eager"]:
