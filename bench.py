@@ -89,7 +89,7 @@ def self_launch(n, argv=None, extra_env=None):
     return subprocess.call(cmd, env=env)
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -154,7 +154,11 @@ def main():
     ap.add_argument("--mixed-requests", type=int, default=None,
                     help="(testing) request slots per (owner, shard) pair of the sharded mixed-precision merge: a tiny "
                          "value forces the overflow -> agreed re-match path")
-    a = ap.parse_args()
+    return ap
+
+
+def main():
+    a = build_parser().parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as the driver types it: become the launcher - one rank per GPU under

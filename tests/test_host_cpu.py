@@ -560,3 +560,26 @@ def test_c_abi_argument_checks_under_asan_ubsan():
                        timeout=1200)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "no sanitizer report" in r.stdout and "refused with a message" in r.stdout
+
+
+def test_bench_sub_records_commands_parse():
+    """bench.py's `sub_records` (round 6: BASELINE configs[2], [3] on one GPU, [4] in the driver's own line) are this script run
+    again with other flags: every command must parse, must not recurse into further sub-records, and must name the
+    configuration it claims."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    got = {}
+    for name, what, flags in b.SUB_RUNS:
+        a = b.build_parser().parse_args(flags + b.SUB_COMMON)
+        assert a.no_sub_records and a.gpus == 1 and a.no_cpu_baseline and a.steps >= 20 and what
+        got[name] = a
+    assert got["cfg3"].workload == "cfg3"
+    assert got["strong8192"].scaling == "strong" and got["strong8192"].n_db is None        # (strong: 8192 windows)
+    c = got["clips16_f16_enc96"]
+    assert (c.clips, c.feature_dtype, c.encode_batch, c.encode_precision) == (16, "f16", 96, "f32")
+    assert got["clips16_f16_enc96_f16x3"].encode_precision == "f16x3"
+    d = b.build_parser().parse_args([])                                                     # the driver's default run
+    assert not d.no_sub_records and d.gpus == 1 and d.workload == "match"
