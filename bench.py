@@ -1017,7 +1017,7 @@ def sub_records(dev):
 def rocprof_kernel_ms(key):
     """The dominant kernel's average duration over ALL launches of a profiled run of this command - graph replays included,
     which HIP events cannot bracket - from the committed rocprofv3 --kernel-trace --stats summary (profiles/
-    kernel_replay.json, written by tools/kernel_replay.py from the pass of experiments/round_scripts/r05_gpu_pass.sh); null for shapes that were not profiled."""
+    kernel_replay.json, written by tools/kernel_replay.py from the last evidence pass: experiments/round_scripts/r06_gpu_pass.sh); null for shapes that were not profiled."""
     path = os.path.join(ROOT, "profiles", "kernel_replay.json")
     if key is None or not os.path.exists(path):
         return {"kernel_ms_rocprof": None}
