@@ -375,7 +375,11 @@ def main():
         cg = knn_g.capture_clip_graph(M, n_sweep_windows=M * n_sweep_clips, audio=te_interp, context=te_ctx,
                                       owner_blocks=sharded_run and not strong, n_clips=my_clips,
                                       encoder=enc, encode_input=enc_x if enc is not None else None,
-                                      encode_precision=a.encode_precision)
+                                      encode_precision=a.encode_precision,
+                                      # (not with the encode leg: its margin check may enqueue an eager f32 encode between
+                                      # two replays, and nothing may sit on this stream in front of a pre-launched replay)
+                                      doorbell=(not sharded_run and enc is None and
+                                                os.environ.get("QPG_BENCH_DOORBELL", "1") == "1"))
         if sharded_run:
             # the segments are recorded NOW, and every rank ends up in the same step mode: a capture that failed on any
             # rank sends all of them to the eager step (MIN over the ranks of "captured")
@@ -395,13 +399,25 @@ def main():
 
     graph_fallbacks = [0]
 
-    def step_graph():
-        arr = cg.run_ints(seed_code, seed_phase)
+    # Round 6: the replay of the NEXT step is enqueued while this one still runs (ClipGraph.prelaunch: hipGraphLaunch costs
+    # ~17 us of host time and the command processor's start-up) and waits at its first node for the host's doorbell; the
+    # host rings it in launch() AFTER this step's codes are on the host and the next seed is written.  GPU work of a step
+    # still starts only when its inputs are final - one clip at a time - only the launch overhead moved out of the gap
+    # between two steps.  `more` = another step of the same loop follows (nothing is left pre-launched behind a loop).
+    door = bool(cg is not None and getattr(cg, "_doorbell", False))
+
+    def step_graph(more=False):
+        cg.launch(seed_code, seed_phase)
+        if door and more:
+            cg.prelaunch()
+        arr = cg.wait_ints()
         if enc is not None:
             cg.encoded_ids(arr)                    # (f16x3: windows the margin check flagged are re-encoded in f32 HERE)
         st_ = cg.statuses(arr)
         if (st_[:, 1] != 0).any():                 # a trouble word came out with the codes: this step again, eagerly
             graph_fallbacks[0] += 1                # (ClipGraph.wait_ints cleared the capture's matcher's sticky word)
+            if door:
+                cg.drain()
             return step_eager()
         for c in range(my_clips):
             knn.check_status(st_[c])
@@ -443,9 +459,9 @@ def main():
         def run_steps(n):
             res = None
             rec = os.environ.get("QPG_BENCH_STEP_TIMES", "") == "1"
-            for _ in range(n):
+            for i_ in range(n):
                 t_ = time.perf_counter()
-                res = step()
+                res = step(more=i_ + 1 < n) if graph_mode else step()
                 if rec:
                     step_times.append(time.perf_counter() - t_)
             return torch.from_numpy(res) if isinstance(res, np.ndarray) else res
@@ -773,6 +789,10 @@ def main():
             enc_same = bool(np.array_equal(cg.encoded_ids(g2), enc.encode(enc_x)[0].cpu().numpy()))
         out["graph_replay"] = {"ms_per_step": out["ms_per_step"], "steps": a.steps, "captures": cg.captures,
                                "is_the_timed_region": True, "clips_per_replay": my_clips,
+                               # the next step's replay is enqueued while the current one runs and waits at its first node
+                               # for the host's doorbell, rung when this step's codes are on the host and the next seed is
+                               # written (ClipGraph.prelaunch; QPG_BENCH_DOORBELL=0: launched after the results, as round 5)
+                               "next_replay_prelaunched_behind_a_doorbell": door,
                                "fallbacks_to_eager_in_the_timed_region": graph_fallbacks[0],
                                **({"encode_leg_in_the_capture": True, "encoded_ids_equal_eager_encode": enc_same,
                                    "encode_precision": a.encode_precision,

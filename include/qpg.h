@@ -61,6 +61,13 @@ int qpg_last_error(char* buf, size_t n);
  * `stream` before this call has completed.  dst: [host-pinned, device-accessible or dev] i32.  The multi-lane replay
  * pipeline (qpgesture_amd.code_knn.GraphPipeline) polls it to learn that a replay's sweep is over. */
 int qpg_signal_i32(qpg_ctx*, void* stream, int32_t* dst, int32_t value);
+/* The doorbell of a pre-launched graph replay: a one-thread kernel that takes its sequence number seq = ++*counter
+ * (counter: [dev] i32, zero-initialised by the caller, one per captured graph) and waits until *go - seq >= 0 (go:
+ * [host-pinned, device-accessible] i32 the host stores to), at most timeout_ms (1..60000; a host that never rings cannot hang
+ * the device).  As the FIRST node of a captured matching step it lets the host enqueue the next replay - hipGraphLaunch is
+ * ~17 us of host time - while the current one still runs, and start it by a single store once the current results are read
+ * and the next seeds written (qpgesture_amd.code_knn.ClipGraph(doorbell=True)). */
+int qpg_doorbell_wait(qpg_ctx*, void* stream, int32_t* counter, const int32_t* go, int32_t timeout_ms);
 
 /* ------------------------------------------------------------------------------------------
  * Database preparation (one-off per speaker DB; replaces the host-side feature windowing of

@@ -24,6 +24,7 @@ P, I, L = c_void_p, c_int, c_int64
 # name -> argtypes (after ctx, stream)
 _SIGS = {
     "qpg_signal_i32": [P, ctypes.c_int32],
+    "qpg_doorbell_wait": [P, P, ctypes.c_int32],
     "qpg_wavlm_resample_f32": [P, L, I, I, I, P],
     "qpg_frame_norm2_f64": [P, L, I, P],
     "qpg_audio_cand_norm2": [P, I, I, P, I, I, I, P],

@@ -1238,7 +1238,7 @@ class CodeKNN:
 
     def capture_clip_graph(self, n_windows, mode=MODE_AUD_TXT, n_sweep_windows=None, window_offset=0, audio=None,
                            context=None, owner_blocks=False, n_clips=1, encoder=None, encode_input=None,
-                           encode_precision="f32", sweep_signal=False):
+                           encode_precision="f32", sweep_signal=False, doorbell=False):
         """Capture the whole per-clip launch sequence (pack, both sweeps, per-code argmin passes, ranks,
         rank-fusion tables, walk) into one HIP graph for a fixed clip shape.  Returns a ClipGraph whose
         run(test_audio, test_context, seed_code, seed_phase) replays it; results are device tensors.
@@ -1249,7 +1249,7 @@ class CodeKNN:
         encoder / encode_input: a VQVAE and a resident pose batch f32 [B][T][C] whose encode (make_beat_dataset.py:314-316)
         runs INSIDE the capture on a branch of its own beside the match - one replay = the fused encode + match step."""
         return ClipGraph(self, n_windows, mode, n_sweep_windows or n_windows * n_clips, window_offset, audio, context,
-                         owner_blocks, n_clips, encoder, encode_input, encode_precision, sweep_signal)
+                         owner_blocks, n_clips, encoder, encode_input, encode_precision, sweep_signal, doorbell)
 
     def match_clip(self, test_interp, test_context, n_windows, mode=MODE_AUD_TXT, seed_code=None,
                    seed_phase=None, return_tables=False):
@@ -1321,9 +1321,21 @@ class ClipGraph:
     sentinel, hipGraphLaunch, watch the status word.  One capture serves every clip of that shape."""
 
     def __init__(self, knn, n_windows, mode, n_sweep_windows, window_offset, audio=None, context=None, owner_blocks=False,
-                 n_clips=1, encoder=None, encode_input=None, encode_precision="f32", sweep_signal=False):
+                 n_clips=1, encoder=None, encode_input=None, encode_precision="f32", sweep_signal=False, doorbell=False):
         db, dev = knn.db, knn.db.device
         self.owner_blocks = owner_blocks
+        # doorbell (round 6): the capture's FIRST node waits for the host's go (qpg_doorbell_wait), so the NEXT replay can be
+        # enqueued while the current one still runs (prelaunch(): hipGraphLaunch is ~17 us of host time + the command
+        # processor's start-up) and started by ONE store once the current results are read and the next seed is written
+        # (launch()).  The GPU work of a step still begins only when its inputs are final; a pre-launched replay nobody wants
+        # is run and discarded (drain()).  One-GPU, unsegmented captures only.
+        self._doorbell = bool(doorbell)
+        self._prelaunched = False
+        if self._doorbell:
+            self._db_cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self._db_go = torch.zeros((1,), dtype=torch.int32).pin_memory()
+            self._db_go_np = self._db_go.numpy()
+            self._db_seq = 0
         # sweep_signal (GraphPipeline): a one-thread kernel behind the audio sweep stores 1 into pinned host memory
         # (qpg_signal_i32) - the host learns that the replay's sweep is over without waiting for its tail
         self._sweep_flag = torch.zeros((1,), dtype=torch.int32).pin_memory() if sweep_signal else None
@@ -1369,6 +1381,8 @@ class ClipGraph:
             raise NotImplementedError("graph capture needs the device-side ranks (tie_rule 'stable')")
         if knn.serial_walk:
             raise NotImplementedError("graph capture replays the tabulated walk (serial_walk is an eager-path switch)")
+        if self._doorbell and self.segmented:
+            raise NotImplementedError("doorbell: one-GPU (unsegmented) captures only")
         self.knn, self.M, self.mode = knn, n_windows, mode
         Ms = n_sweep_windows
         if audio is not None:                     # the caller's resident tensors: no copy in front of a replay
@@ -1454,6 +1468,8 @@ class ClipGraph:
 
         def body():
             main = torch.cuda.current_stream(dev)
+            if self._doorbell:                   # (first node: everything below is ordered behind it)
+                _lib.call("qpg_doorbell_wait", dev, self._db_cnt, self._db_go.data_ptr(), 2000)
             if self.enc is not None:
                 if enc_at == "start" or self.mode == MODE_TXT or knn.use_wavvq:
                     encode_leg()
@@ -1471,6 +1487,8 @@ class ClipGraph:
             return knn.walk(T, self.M, self._off, self.mode, sync=False, seed_ptrs=ptrs, out_pin=self._pin,
                             n_chains=self.CL)
         import os as _os
+        if self._doorbell:
+            self._db_go_np[0] = 0x7fffffff        # (the warm-up passes below run the doorbell kernel eagerly: open)
         s = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("QPG_GRAPH_PRIO", "0")))   # (measurements)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -1508,6 +1526,10 @@ class ClipGraph:
             self.out = body()
         self.graph = g
         self.captures += 1
+        if self._doorbell:
+            torch.cuda.synchronize(dev)
+            self._db_seq = int(self._db_cnt.item())        # (the warm-up passes took sequence numbers too)
+            self._db_go_np[0] = self._db_seq               # closed: replay number _db_seq + 1 waits for launch()
 
     def _set_seed(self, seed_code, seed_phase):
         """One (code, phase block) for every clip, or one per clip (sequence of n_clips codes, [n_clips][8][16] blocks)."""
@@ -1552,8 +1574,42 @@ class ClipGraph:
         if self.segmented:
             for f in self._program:                 # hipGraphLaunch, collective, hipGraphLaunch, ...
                 f()
+        elif self._doorbell:
+            self._db_seq += 1
+            self._db_go_np[0] = self._db_seq        # ring: the seed block and the sentinels above are final (x86 store order)
+            if self._prelaunched:
+                self._prelaunched = False           # (already enqueued: the store started it)
+            else:
+                self.graph.replay()
         else:
             self.graph.replay()
+
+    def prelaunch(self):
+        """doorbell graphs: enqueue the NEXT replay now (on the current stream, behind the one in flight); it waits at its
+        first node until the next launch() rings.  At most one pre-launched replay; a pre-launched replay must be consumed
+        by launch() or drain() before anything else is enqueued on this stream or the device is synchronised."""
+        if not self._doorbell:
+            raise RuntimeError("ClipGraph.prelaunch needs doorbell=True")
+        if self._prelaunched:
+            return
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        self._prelaunched = True
+
+    def drain(self):
+        """Run and discard a pre-launched replay nobody will use (the caller leaves the replay loop: an eager re-match, the
+        end of a run).  Needs the replay in flight, if any, to have been collected."""
+        if not getattr(self, "_prelaunched", False):
+            return
+        if self._in_flight:
+            raise RuntimeError("ClipGraph.drain: collect the replay in flight first (wait_ints)")
+        self._pin_np.fill(_PIN_SENTINEL)
+        self._in_flight = True
+        self._db_seq += 1
+        self._db_go_np[0] = self._db_seq
+        self._prelaunched = False
+        self.wait_ints()
 
     def sweep_done(self):
         """sweep_signal graphs: has the replay in flight passed its audio sweep?  (True when nothing is in flight.)"""

@@ -108,6 +108,34 @@ extern "C" int qpg_signal_i32(qpg_ctx* ctx, void* stream, int32_t* dst, int32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The doorbell of a PRE-LAUNCHED replay (round 6, ClipGraph(doorbell=True)).  A serial matching step pays ~17 us of host time
+// for hipGraphLaunch plus the command processor's start-up before its first kernel runs; the host can enqueue the NEXT replay
+// while the current one still executes if that replay's first node waits for the host's go.  One thread: takes this replay's
+// sequence number from a device counter (seq = ++*counter: immune to the host racing ahead) and waits until the host has
+// stored go >= seq into pinned memory (system-scope loads, s_sleep between polls).  The host writes the replay's seed block
+// and result sentinels BEFORE it stores go, so the GPU work of a step still starts only when its inputs are final.
+// The wait is BOUNDED (timeout_ms of the 100 MHz wall clock): a host that never rings cannot hang the device - the replay then
+// runs on whatever the seed block holds and its results are discarded by the host side (ClipGraph.drain).
+// ---------------------------------------------------------------------------------------------
+__global__ void doorbell_wait_kernel(int32_t* __restrict__ counter, const int32_t* __restrict__ go, int32_t timeout_ms) {
+  const int32_t seq = atomicAdd(counter, 1) + 1;
+  const long long t0 = wall_clock64();
+  const long long limit = (long long)timeout_ms * 100000ll;                       // 100 MHz
+  while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {   // (wrap-safe comparison)
+    if (wall_clock64() - t0 > limit) break;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);                                         // the seed block written before go
+}
+
+extern "C" int qpg_doorbell_wait(qpg_ctx* ctx, void* stream, int32_t* counter, const int32_t* go, int32_t timeout_ms) {
+  QPG_REQUIRE(ctx && counter && go && timeout_ms > 0 && timeout_ms <= 60000, "qpg_doorbell_wait: bad argument (timeout 1..60000 ms)");
+  hipLaunchKernelGGL(doorbell_wait_kernel, dim3(1), dim3(1), 0, qpg_stream(stream), counter, go, timeout_ms);
+  QPG_LAUNCH_CHECK("doorbell_wait_kernel");
+  return QPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-frame squared norm in f64: one wave per row, 16 B loads, wave64 shuffle reduce.
 // HBM-bound: reads rows*F*4 bytes once.
 // ---------------------------------------------------------------------------------------------

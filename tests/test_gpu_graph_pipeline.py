@@ -89,3 +89,53 @@ def test_a_flagged_clip_inside_a_group_is_rematched():
         for c in range(2):
             assert np.array_equal(got[c][0], want[c][0]) and np.array_equal(got[c][1], want[c][2])
     assert pipe.rematched >= 2
+
+
+def test_prelaunched_replays_behind_the_doorbell_equal_plain_replays():
+    """ClipGraph(doorbell=True): the next replay is enqueued while the current one runs and starts when launch() rings.  Codes,
+    votes and status of every step equal those of a plain capture and of the eager path - with a DIFFERENT seed per step (the
+    seed is written after the pre-launch: the replay must read it when it runs, not when it was enqueued); drain() consumes
+    a pre-launched replay nobody wants; a doorbell that is never rung times out instead of hanging the device."""
+    import time
+    import torch
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    A = _db(160, 510)
+    db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
+    knn = CodeKNN(db, rng=np.random.RandomState(4))
+    M = 2
+    g = torch.Generator(device="cpu").manual_seed(77)
+    ti = torch.randn((M, 180, 1024), generator=g).cuda()
+    tc = torch.randn((M, 30, 384), generator=g).cuda()
+    seeds = [knn.init_code_phase() for _ in range(6)]
+    want = [knn.match_clip(ti, tc, M, seed_code=c_, seed_phase=p_) for c_, p_ in seeds]
+    plain = CodeKNN(db, rng=np.random.RandomState(5)).capture_clip_graph(M, audio=ti, context=tc)
+    cg = CodeKNN(db, rng=np.random.RandomState(5)).capture_clip_graph(M, audio=ti, context=tc, doorbell=True)
+    n_c = M * 30
+    for i, (c_, p_) in enumerate(seeds):
+        ref = plain.run_ints(c_, p_)
+        cg.launch(c_, p_)
+        if i + 1 < len(seeds):
+            cg.prelaunch()                                   # enqueued now, with the NEXT seed still unknown to the device
+        got = cg.wait_ints()
+        assert np.array_equal(got, ref), i
+        assert np.array_equal(got[:n_c].reshape(M, 30), want[i][0]) and not got[-2:].any()
+    assert cg.captures == 1 and not cg._prelaunched
+    # a pre-launched replay nobody wants
+    cg.launch(*seeds[0])
+    cg.prelaunch()
+    assert np.array_equal(cg.wait_ints()[:n_c].reshape(M, 30), want[0][0])
+    cg.drain()
+    assert not cg._prelaunched and not cg._in_flight
+    torch.cuda.synchronize()                                 # nothing is left waiting on the device
+    assert np.array_equal(cg.run_ints(*seeds[1])[:n_c].reshape(M, 30), want[1][0])
+    # the wait is bounded: a replay whose doorbell is never rung starts by itself after the timeout (2 s) - the device
+    # cannot hang on a host that went away
+    cg.prelaunch()
+    t0 = time.time()
+    torch.cuda.synchronize()
+    assert 1.0 < time.time() - t0 < 10.0
+    # (that replay took a sequence number: put host and device back in step, as drain() would have)
+    cg._prelaunched = False
+    cg._db_seq += 1
+    cg._db_go_np[0] = cg._db_seq
+    assert np.array_equal(cg.run_ints(*seeds[2])[:n_c].reshape(M, 30), want[2][0])
