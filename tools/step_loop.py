@@ -52,11 +52,18 @@ from qpgesture_amd import code_knn as _ck
 mode = getattr(_ck, os.environ.get("QPG_LOOP_MODE", "MODE_AUD_TXT"))        # MODE_AUD: audio side only (measurements)
 g = knn.capture_clip_graph(M, mode=mode, audio=te_i, context=te_c, owner_blocks=knn.force_sharded, n_clips=CL,
                            encoder=enc, encode_input=enc_x,
-                           encode_precision=os.environ.get("QPG_LOOP_ENC_PREC", "f32")) if graph else None
+                           encode_precision=os.environ.get("QPG_LOOP_ENC_PREC", "f32"),
+                           doorbell=os.environ.get("QPG_LOOP_DOORBELL", "0") == "1") if graph else None
+DOOR = graph and os.environ.get("QPG_LOOP_DOORBELL", "0") == "1"     # the next replay pre-launched behind the doorbell
 spb = torch.from_numpy(np.tile(sp.reshape(1, -1), (CL, 1))).to(dev)
 
 
-def step():
+def step(more=False):
+    if DOOR:
+        g.launch(sc, sp)
+        if more:
+            g.prelaunch()
+        return g.wait_ints()
     if graph:
         return g.run_ints(sc, sp)
     if enc is not None:
@@ -80,8 +87,8 @@ for _ in range(5):
 torch.cuda.synchronize()
 gap = float(os.environ.get("QPG_LOOP_GAP_MS", "0"))     # idle time between steps (what the sweep takes on a chip that rests)
 t0 = time.perf_counter()
-for _ in range(steps):
-    step()
+for i_ in range(steps):
+    step(more=i_ + 1 < steps) if DOOR else step()
     if gap:
         time.sleep(gap * 1e-3)
 torch.cuda.synchronize()
