@@ -405,19 +405,30 @@ def main():
     # still starts only when its inputs are final - one clip at a time - only the launch overhead moved out of the gap
     # between two steps.  `more` = another step of the same loop follows (nothing is left pre-launched behind a loop).
     door = bool(cg is not None and getattr(cg, "_doorbell", False))
+    sr = None
+    if door:
+        # (two captures taking turns on one stream: a graph exec is never re-launched while its own replay executes)
+        from qpgesture_amd.code_knn import SerialReplayer
+        knn_g2 = CodeKNN(db, rng=np.random.RandomState(123456))
+        knn_g2.overlap_sweeps, knn_g2.audio_precision, knn_g2.audio_kernel = knn.overlap_sweeps, knn.audio_precision, knn.audio_kernel
+        if "audio_first" in knn_g.__dict__:
+            knn_g2.text_after_sweep, knn_g2.audio_first = knn_g.text_after_sweep, knn_g.audio_first
+        cg2 = knn_g2.capture_clip_graph(M, n_sweep_windows=M * n_sweep_clips, audio=te_interp, context=te_ctx, n_clips=my_clips,
+                                        doorbell=True)
+        sr = SerialReplayer([cg, cg2])
 
     def step_graph(more=False):
-        cg.launch(seed_code, seed_phase)
-        if door and more:
-            cg.prelaunch()
-        arr = cg.wait_ints()
+        if sr is not None:
+            arr, cgx = sr.step(seed_code, seed_phase, more)
+        else:
+            arr, cgx = cg.run_ints(seed_code, seed_phase), cg
         if enc is not None:
             cg.encoded_ids(arr)                    # (f16x3: windows the margin check flagged are re-encoded in f32 HERE)
-        st_ = cg.statuses(arr)
+        st_ = cgx.statuses(arr)
         if (st_[:, 1] != 0).any():                 # a trouble word came out with the codes: this step again, eagerly
             graph_fallbacks[0] += 1                # (ClipGraph.wait_ints cleared the capture's matcher's sticky word)
-            if door:
-                cg.drain()
+            if sr is not None:
+                sr.drain()
             return step_eager()
         for c in range(my_clips):
             knn.check_status(st_[c])
@@ -904,6 +915,11 @@ def main():
             sg = knn_g.mixed_stats()
             st = {"tier1_pairs": sg["tier1_pairs"], "tier2_pairs": sg["tier2_pairs"], "flags": sg["flags"] | st["flags"]}
             n_run += 2                                 # (the capture's two warm-up passes)
+            if sr is not None:                         # (two captures took turns: the steps are split between their matchers)
+                s2 = knn_g2.mixed_stats()
+                st = {"tier1_pairs": st["tier1_pairs"] + s2["tier1_pairs"], "tier2_pairs": st["tier2_pairs"] + s2["tier2_pairs"],
+                      "flags": st["flags"] | s2["flags"]}
+                n_run += 2 + 1                         # (+ its warm-up passes, + the other-seed check's replay on the first)
         k64 = CodeKNN(db, rng=np.random.RandomState(123456))
         k64.audio_precision = "f64"
         T64 = k64.sweep_tables(te_interp, te_ctx, M * n_sweep_clips)

@@ -1592,6 +1592,12 @@ class ClipGraph:
             raise RuntimeError("ClipGraph.prelaunch needs doorbell=True")
         if self._prelaunched:
             return
+        if self._in_flight:
+            # (re-launching a graph exec whose previous launch is still executing is legal HIP, and a one-branch graph
+            # survives it, but this capture has cross-queue edges whose signals belong to the exec: measured, intermittently
+            # a replay whose last kernel never ran.  Two captures taking turns - SerialReplayer - never do it.)
+            raise RuntimeError("ClipGraph.prelaunch: this graph's own replay is still in flight; alternate two captures "
+                               "(SerialReplayer)")
         if self.graph is None:
             self._capture()
         self.graph.replay()
@@ -1771,6 +1777,33 @@ class ClipPipeline:
         while pending:
             out.append(self.collect(pending.pop(0)))
         return out
+
+
+class SerialReplayer:
+    """One clip at a time, without the launch overhead between two steps (round 6).  Two captures of the same step
+    (ClipGraph(doorbell=True), each with its own matcher and workspaces) take turns on ONE stream: while capture A's replay
+    runs, capture B's next replay is enqueued behind it (hipGraphLaunch: ~17 us of host time + the command processor's
+    start-up) and waits at its first node; when A's codes are on the host and the next seed is written, ONE store rings B.
+    The GPU work of a step still starts only after the previous step's results have been read - strictly serial - and a
+    graph exec is never re-launched while its own previous launch executes."""
+
+    def __init__(self, graphs):
+        assert len(graphs) == 2 and all(g._doorbell for g in graphs)
+        self.graphs = list(graphs)
+        self._i = 0                                    # the capture whose replay is launched next
+
+    def step(self, seed_code, seed_phase, more):
+        """launch (ring) -> pre-launch the other capture if `more` steps follow -> wait; returns (ints, the capture)."""
+        cur, nxt = self.graphs[self._i], self.graphs[self._i ^ 1]
+        cur.launch(seed_code, seed_phase)
+        if more:
+            nxt.prelaunch()
+        self._i ^= 1
+        return cur.wait_ints(), cur
+
+    def drain(self):
+        for g in self.graphs:
+            g.drain()
 
 
 class GraphPipeline:

@@ -92,13 +92,14 @@ def test_a_flagged_clip_inside_a_group_is_rematched():
 
 
 def test_prelaunched_replays_behind_the_doorbell_equal_plain_replays():
-    """ClipGraph(doorbell=True): the next replay is enqueued while the current one runs and starts when launch() rings.  Codes,
-    votes and status of every step equal those of a plain capture and of the eager path - with a DIFFERENT seed per step (the
-    seed is written after the pre-launch: the replay must read it when it runs, not when it was enqueued); drain() consumes
-    a pre-launched replay nobody wants; a doorbell that is never rung times out instead of hanging the device."""
+    """ClipGraph(doorbell=True) + SerialReplayer: the next step's replay (the OTHER of two captures) is enqueued while the current
+    one runs and starts when launch() rings.  Codes, votes and status of every step equal those of a plain capture and of the
+    eager path - with a DIFFERENT seed per step (the seed is written after the pre-launch: the replay must read it when it
+    runs, not when it was enqueued); a capture refuses to be pre-launched behind its own replay; drain() consumes a
+    pre-launched replay nobody wants; a doorbell that is never rung times out instead of hanging the device."""
     import time
     import torch
-    from qpgesture_amd.code_knn import CodeKNN, GestureDB
+    from qpgesture_amd.code_knn import CodeKNN, GestureDB, SerialReplayer
     A = _db(160, 510)
     db = GestureDB(A["code"], A["interp"], A["ctx"], A["phase"], A["sig"], device="cuda:0")
     knn = CodeKNN(db, rng=np.random.RandomState(4))
@@ -106,24 +107,28 @@ def test_prelaunched_replays_behind_the_doorbell_equal_plain_replays():
     g = torch.Generator(device="cpu").manual_seed(77)
     ti = torch.randn((M, 180, 1024), generator=g).cuda()
     tc = torch.randn((M, 30, 384), generator=g).cuda()
-    seeds = [knn.init_code_phase() for _ in range(6)]
+    seeds = [knn.init_code_phase() for _ in range(9)]
     want = [knn.match_clip(ti, tc, M, seed_code=c_, seed_phase=p_) for c_, p_ in seeds]
     plain = CodeKNN(db, rng=np.random.RandomState(5)).capture_clip_graph(M, audio=ti, context=tc)
-    cg = CodeKNN(db, rng=np.random.RandomState(5)).capture_clip_graph(M, audio=ti, context=tc, doorbell=True)
+    cgs = [CodeKNN(db, rng=np.random.RandomState(5 + i)).capture_clip_graph(M, audio=ti, context=tc, doorbell=True)
+           for i in range(2)]
+    sr = SerialReplayer(cgs)
     n_c = M * 30
-    for i, (c_, p_) in enumerate(seeds):
-        ref = plain.run_ints(c_, p_)
-        cg.launch(c_, p_)
-        if i + 1 < len(seeds):
-            cg.prelaunch()                                   # enqueued now, with the NEXT seed still unknown to the device
-        got = cg.wait_ints()
-        assert np.array_equal(got, ref), i
-        assert np.array_equal(got[:n_c].reshape(M, 30), want[i][0]) and not got[-2:].any()
-    assert cg.captures == 1 and not cg._prelaunched
-    # a pre-launched replay nobody wants
+    for rounds in range(3):                                  # (many steps: the hand-over is exercised in both directions)
+        for i, (c_, p_) in enumerate(seeds):
+            ref = plain.run_ints(c_, p_)
+            got, used = sr.step(c_, p_, more=i + 1 < len(seeds))
+            assert np.array_equal(got, ref), (rounds, i)
+            assert np.array_equal(got[:n_c].reshape(M, 30), want[i][0]) and not got[-2:].any()
+    assert all(c.captures == 1 and not c._prelaunched and not c._in_flight for c in cgs)
+    cg = cgs[0]
+    # a capture is never pre-launched behind its own replay
     cg.launch(*seeds[0])
-    cg.prelaunch()
+    with pytest.raises(RuntimeError):
+        cg.prelaunch()
     assert np.array_equal(cg.wait_ints()[:n_c].reshape(M, 30), want[0][0])
+    # a pre-launched replay nobody wants
+    cg.prelaunch()
     cg.drain()
     assert not cg._prelaunched and not cg._in_flight
     torch.cuda.synchronize()                                 # nothing is left waiting on the device

@@ -55,15 +55,16 @@ g = knn.capture_clip_graph(M, mode=mode, audio=te_i, context=te_c, owner_blocks=
                            encode_precision=os.environ.get("QPG_LOOP_ENC_PREC", "f32"),
                            doorbell=os.environ.get("QPG_LOOP_DOORBELL", "0") == "1") if graph else None
 DOOR = graph and os.environ.get("QPG_LOOP_DOORBELL", "0") == "1"     # the next replay pre-launched behind the doorbell
+if DOOR:                                                              # (two captures taking turns: code_knn.SerialReplayer)
+    knn2 = CodeKNN(db, rng=np.random.RandomState(123456))
+    g2 = knn2.capture_clip_graph(M, mode=mode, audio=te_i, context=te_c, n_clips=CL, doorbell=True)
+    SR = _ck.SerialReplayer([g, g2])
 spb = torch.from_numpy(np.tile(sp.reshape(1, -1), (CL, 1))).to(dev)
 
 
 def step(more=False):
     if DOOR:
-        g.launch(sc, sp)
-        if more:
-            g.prelaunch()
-        return g.wait_ints()
+        return SR.step(sc, sp, more)[0]
     if graph:
         return g.run_ints(sc, sp)
     if enc is not None:
