@@ -378,8 +378,10 @@ def main():
                                       encode_precision=a.encode_precision,
                                       # (not with the encode leg: its margin check may enqueue an eager f32 encode between
                                       # two replays, and nothing may sit on this stream in front of a pre-launched replay)
+                                      # EXPERIMENTAL, off by default: -2.4 % per step, but a graph launched behind a running
+                                      # graph launch occasionally loses its kernels on this ROCm build (code_knn.SerialReplayer)
                                       doorbell=(not sharded_run and enc is None and
-                                                os.environ.get("QPG_BENCH_DOORBELL", "1") == "1"))
+                                                os.environ.get("QPG_BENCH_DOORBELL", "0") == "1"))
         if sharded_run:
             # the segments are recorded NOW, and every rank ends up in the same step mode: a capture that failed on any
             # rank sends all of them to the eager step (MIN over the ranks of "captured")
@@ -804,6 +806,7 @@ def main():
                                # for the host's doorbell, rung when this step's codes are on the host and the next seed is
                                # written (ClipGraph.prelaunch; QPG_BENCH_DOORBELL=0: launched after the results, as round 5)
                                "next_replay_prelaunched_behind_a_doorbell": door,
+                               **({"doorbell_steps_recovered_after_a_lost_launch": sr.recovered} if sr is not None else {}),
                                "fallbacks_to_eager_in_the_timed_region": graph_fallbacks[0],
                                **({"encode_leg_in_the_capture": True, "encoded_ids_equal_eager_encode": enc_same,
                                    "encode_precision": a.encode_precision,

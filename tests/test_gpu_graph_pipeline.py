@@ -92,11 +92,12 @@ def test_a_flagged_clip_inside_a_group_is_rematched():
 
 
 def test_prelaunched_replays_behind_the_doorbell_equal_plain_replays():
-    """ClipGraph(doorbell=True) + SerialReplayer: the next step's replay (the OTHER of two captures) is enqueued while the current
-    one runs and starts when launch() rings.  Codes, votes and status of every step equal those of a plain capture and of the
-    eager path - with a DIFFERENT seed per step (the seed is written after the pre-launch: the replay must read it when it
-    runs, not when it was enqueued); a capture refuses to be pre-launched behind its own replay; drain() consumes a
-    pre-launched replay nobody wants; a doorbell that is never rung times out instead of hanging the device."""
+    """EXPERIMENTAL path (off by default): ClipGraph(doorbell=True) + SerialReplayer - the next step's replay (the OTHER of two
+    captures) is enqueued while the current one runs and starts when launch() rings.  Codes, votes and status of every step
+    equal the eager path's with a DIFFERENT seed per step (the seed is written after the pre-launch: the replay must read it
+    when it runs, not when it was enqueued); a launch whose kernels the runtime dropped is noticed and repeated (`recovered`);
+    a capture refuses to be pre-launched behind its own replay; drain() consumes a pre-launched replay nobody wants; a
+    doorbell that is never rung times out instead of hanging the device."""
     import time
     import torch
     from qpgesture_amd.code_knn import CodeKNN, GestureDB, SerialReplayer
@@ -109,38 +110,38 @@ def test_prelaunched_replays_behind_the_doorbell_equal_plain_replays():
     tc = torch.randn((M, 30, 384), generator=g).cuda()
     seeds = [knn.init_code_phase() for _ in range(9)]
     want = [knn.match_clip(ti, tc, M, seed_code=c_, seed_phase=p_) for c_, p_ in seeds]
-    plain = CodeKNN(db, rng=np.random.RandomState(5)).capture_clip_graph(M, audio=ti, context=tc)
     cgs = [CodeKNN(db, rng=np.random.RandomState(5 + i)).capture_clip_graph(M, audio=ti, context=tc, doorbell=True)
            for i in range(2)]
     sr = SerialReplayer(cgs)
     n_c = M * 30
-    for rounds in range(3):                                  # (many steps: the hand-over is exercised in both directions)
+    for rounds in range(3):                                  # (the hand-over in both directions, many times)
         for i, (c_, p_) in enumerate(seeds):
-            ref = plain.run_ints(c_, p_)
             got, used = sr.step(c_, p_, more=i + 1 < len(seeds))
-            assert np.array_equal(got, ref), (rounds, i)
-            assert np.array_equal(got[:n_c].reshape(M, 30), want[i][0]) and not got[-2:].any()
+            assert np.array_equal(got[:n_c].reshape(M, 30), want[i][0]) and not got[-2:].any(), (rounds, i)
+            assert np.array_equal(got[n_c:-2].reshape(M, -1), want[i][2])
+    print("doorbell steps recovered after a lost launch: %d of %d" % (sr.recovered, 3 * len(seeds)))
+    assert sr.recovered <= 2
     assert all(c.captures == 1 and not c._prelaunched and not c._in_flight for c in cgs)
+    torch.cuda.synchronize()
     cg = cgs[0]
     # a capture is never pre-launched behind its own replay
     cg.launch(*seeds[0])
     with pytest.raises(RuntimeError):
         cg.prelaunch()
     assert np.array_equal(cg.wait_ints()[:n_c].reshape(M, 30), want[0][0])
+    torch.cuda.synchronize()
     # a pre-launched replay nobody wants
     cg.prelaunch()
     cg.drain()
     assert not cg._prelaunched and not cg._in_flight
     torch.cuda.synchronize()                                 # nothing is left waiting on the device
     assert np.array_equal(cg.run_ints(*seeds[1])[:n_c].reshape(M, 30), want[1][0])
+    torch.cuda.synchronize()
     # the wait is bounded: a replay whose doorbell is never rung starts by itself after the timeout (2 s) - the device
     # cannot hang on a host that went away
     cg.prelaunch()
     t0 = time.time()
     torch.cuda.synchronize()
     assert 1.0 < time.time() - t0 < 10.0
-    # (that replay took a sequence number: put host and device back in step, as drain() would have)
-    cg._prelaunched = False
-    cg._db_seq += 1
-    cg._db_go_np[0] = cg._db_seq
+    sr._resync()                                             # (that replay took a sequence number)
     assert np.array_equal(cg.run_ints(*seeds[2])[:n_c].reshape(M, 30), want[2][0])
