@@ -56,12 +56,6 @@ int qpg_ctx_destroy(qpg_ctx* ctx);
 #define QPG_OPT_COUNT 4
 int qpg_ctx_set_option(qpg_ctx* ctx, int option, int value);
 int qpg_ctx_get_option(qpg_ctx* ctx, int option, int* value);
-/* While set (counter [dev] i32, zero; flag [host-pinned] i32; NULL, NULL clears), every qpg_audio_cosine_hl launch made
- * through this context reports its progress: the block whose k loop is the (blocks - blocks x lead_permille / 1000)-th to finish
- * stores 1 into *flag, the last one puts *counter back to 0.  A scheduling hint for a host that wants to enqueue the next
- * replay shortly BEFORE this sweep retires (qpgesture_amd.code_knn.GraphPipeline); never a dependency.  The pointers are
- * baked into a launch when it is made (or captured), so set / clear around that call. */
-int qpg_ctx_set_sweep_progress(qpg_ctx* ctx, int32_t* counter, int32_t* flag, int lead_permille);
 int qpg_last_error(char* buf, size_t n);
 /* Stream-ordered signal to the host: *dst = value (system-scope store by a one-thread kernel) once everything enqueued on
  * `stream` before this call has completed.  dst: [host-pinned, device-accessible or dev] i32.  The multi-lane replay

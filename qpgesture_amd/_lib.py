@@ -177,7 +177,6 @@ def load():
     lib.qpg_build_id.argtypes = []
     lib.qpg_ctx_set_option.argtypes = [c_void_p, c_int, c_int]
     lib.qpg_ctx_get_option.argtypes = [c_void_p, c_int, ctypes.POINTER(c_int)]
-    lib.qpg_ctx_set_sweep_progress.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
     lib.qpg_ctx_create.argtypes = [c_int, ctypes.POINTER(c_void_p)]
     lib.qpg_ctx_create.restype = c_int
     lib.qpg_ctx_destroy.argtypes = [c_void_p]

@@ -543,16 +543,7 @@ class CodeKNN:
         if ev is not None:
             e0.record(torch.cuda.current_stream(dev))          # (the events bracket the sweep kernel alone)
         if sweep_launch is not None:
-            prog = self.__dict__.get("sweep_progress")          # (ClipGraph(sweep_signal): counter tensor, pinned flag address, lead)
-            if prog is not None and db.hl_planes == 2:
-                lib_ = _lib.load()
-                lib_.qpg_ctx_set_sweep_progress(_lib.ctx(dev), prog[0].data_ptr(), prog[1], int(prog[2]))
-                try:
-                    sweep_launch()
-                finally:
-                    lib_.qpg_ctx_set_sweep_progress(_lib.ctx(dev), None, None, 0)
-            else:
-                sweep_launch()
+            sweep_launch()
         elif mixed:
             _lib.call("qpg_audio_cosine_mx_h" if half else "qpg_audio_cosine_mx", dev, db.base, db.n_local, db.T, db.F, db.aud_t, db.Ga,
                       NUM_AUDIO_FEAT_FRAMES, db.tap_stride, db.cn2, q32, qn2, Q, D, 1, D.stride(0), self._guard_stats)
@@ -1349,11 +1340,6 @@ class ClipGraph:
         # (qpg_signal_i32) - the host learns that the replay's sweep is over without waiting for its tail
         self._sweep_flag = torch.zeros((1,), dtype=torch.int32).pin_memory() if sweep_signal else None
         self._sweep_flag_np = self._sweep_flag.numpy() if sweep_signal else None
-        # (the sweep itself raises the word a little EARLY - when all but sweep_signal_lead permille of its blocks have finished
-        # their k loops, qpg_ctx_set_sweep_progress: the host needs ~40 us from the word to the next replay's sweep; the
-        # one-thread kernel behind the sweep stays as the late, unconditional form)
-        self._sweep_cnt = torch.zeros((1,), dtype=torch.int32, device=dev) if sweep_signal else None
-        self.sweep_signal_lead = int(__import__("os").environ.get("QPG_SWEEP_SIGNAL_LEAD", "80"))
         self.CL = int(n_clips)
         if self.CL < 1 or n_sweep_windows < window_offset + self.CL * n_windows:
             raise ValueError("n_clips x n_windows windows must lie inside the swept windows")
@@ -1491,14 +1477,11 @@ class ClipGraph:
                     knn.after_sweep = encode_leg
             elif self._sweep_flag is not None:
                 knn.after_sweep = lambda: _lib.call("qpg_signal_i32", dev, self._sweep_flag.data_ptr(), 1)
-                if self.sweep_signal_lead > 0:
-                    knn.sweep_progress = (self._sweep_cnt, self._sweep_flag.data_ptr(), self.sweep_signal_lead)
             try:
                 T = knn.sweep_tables(self.audio, self.context, self._n_sweep, self.mode, owner_blocks=self.owner_blocks,
                                      for_walk=True)
             finally:
                 knn.after_sweep = None
-                knn.sweep_progress = None
             if self.enc is not None:
                 main.wait_event(self._enc_done)
             return knn.walk(T, self.M, self._off, self.mode, sync=False, seed_ptrs=ptrs, out_pin=self._pin,

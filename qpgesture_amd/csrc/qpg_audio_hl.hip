@@ -453,10 +453,6 @@ struct HlArgs {
   int64_t ldT;
   uint16_t* tmask;         // MODE 1, optional (with tmin): [Q][ldT] bit r = row 16 i + r lies within `band` of the tile's minimum
   float band;              // ... the matrix itself is then not needed (D may be NULL): the select opens tiles by their masks
-  // audio_cosine_hl2_kernel<.., SIG = true> only (round 6, qpg_ctx_set_sweep_progress; garbage for every other kernel):
-  int32_t* prog_cnt;       // [dev] blocks of this launch that have finished their k loop (the last one puts it back to 0)
-  int32_t* prog_flag;      // [host-pinned] set to 1 by the block that makes the count reach prog_target
-  int32_t prog_target, prog_total;
 };
 
 #define HL_RING (2 * HL_KS)  // k-blocks of database fragments in flight per wave (2 KB each): two stages
@@ -763,10 +759,7 @@ __device__ __forceinline__ double fast_rsqrt_f64(double x) {
 // The 32 registers the l plane's ring held go into the ring's depth: RS = 4 stages (8 k-blocks) of fragments in flight.
 #define HL1_WIN_UNITS(KB) ((int64_t)(KB) * (64 + HL_T1_UNITS))
 // PL: planes of the database image (2: h | l, f32 track; 1: the f16 track); RS: stages of database fragments in flight
-// SIG (round 6): the launch reports its progress - the block whose k loop is the prog_target-th to finish stores 1 into a
-// pinned word (GraphPipeline launches the other lane's replay then, ~40 us before this sweep retires its last block).  A
-// separate instantiation: the default kernel's code is untouched.
-template <int PL, int RS, bool NT, bool SIG = false>
+template <int PL, int RS, bool NT>
 __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x 2 x 6 x 2 x 1 KB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -959,11 +952,6 @@ __global__ __launch_bounds__(64 * H2_W, 2) void audio_cosine_hl2_kernel(HlArgs a
     acc[1][HL_CT - 1][r] += (double)dp[1][r];
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // surplus prefetches must not outlive their registers
-  if (SIG && tid == 0) {                                               // (a scheduling hint for the host, never a dependency)
-    const int n = atomicAdd(a.prog_cnt, 1) + 1;
-    if (n == a.prog_target) __hip_atomic_store(a.prog_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (n == a.prog_total) __hip_atomic_store(a.prog_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   if (!win_ok) return;
   // ---- epilogue: dot(q, cand g) = S[g][lo column] + S[g + 1][hi column]; the wave holds all 27 super-rows of its window:
   // lane (cg, rg) has rows 4 rg .. 4 rg + 3 of tile t for column cg of every column tile
@@ -1155,14 +1143,6 @@ extern "C" int qpg_audio_cosine_hl(qpg_ctx* ctx, void* stream, const void* db_im
   QPG_REQUIRE(((g8 + 7) / 8) * 8 * chunks < 0x7fffffffll, "%s: too many blocks", name);
   const bool nt = H2_NT == 2 || (H2_NT == 1 && chunks == 1);      // several chunks re-read the image out of the XCD's L2
   void (*kern)(HlArgs) = nt ? audio_cosine_hl2_kernel<2, H2_RS2, true> : audio_cosine_hl2_kernel<2, H2_RS2, false>;
-  a.prog_cnt = nullptr; a.prog_flag = nullptr; a.prog_target = 0; a.prog_total = 0;
-  if (ctx->prog_cnt && ctx->prog_flag) {                           // qpg_ctx_set_sweep_progress: this launch reports
-    const int64_t total = g8 * chunks;                             // (blocks past the last window group leave at once)
-    int64_t lead = total * ctx->prog_lead_permille / 1000;
-    a.prog_cnt = ctx->prog_cnt; a.prog_flag = ctx->prog_flag; a.prog_total = (int32_t)total;
-    a.prog_target = (int32_t)(total - lead < 1 ? 1 : total - lead);
-    kern = nt ? audio_cosine_hl2_kernel<2, H2_RS2, true, true> : audio_cosine_hl2_kernel<2, H2_RS2, false, true>;
-  }
   hipLaunchKernelGGL(kern,
                      dim3((unsigned)(((g8 + 7) / 8) * 8 * chunks)), dim3(64 * H2_W), 2 * 2 * HL_CT * 2 * HL_PIECE,
                      qpg_stream(stream), a);

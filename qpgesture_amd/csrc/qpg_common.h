@@ -13,9 +13,6 @@ struct qpg_ctx {
   float* zeros;   // 4 KB of device zeros: out-of-range tile loads are redirected here instead of being selected to 0
   bool select_lds_raised;   // percode_select_mixed_f64_kernel's dynamic-LDS limit has been raised on this device
   int opt[QPG_OPT_COUNT];   // qpg_ctx_set_option / qpg_ctx_get_option (include/qpg.h): per-context knobs, never process-wide
-  int32_t* prog_cnt;        // qpg_ctx_set_sweep_progress: the next qpg_audio_cosine_hl launches report their progress
-  int32_t* prog_flag;
-  int prog_lead_permille;
 };
 
 // Measurement knobs of the kernel experiments (tools/, experiments/): they exist only in a -DQPG_DEBUG_HOOKS build

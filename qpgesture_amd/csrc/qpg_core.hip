@@ -56,9 +56,6 @@ extern "C" int qpg_ctx_create(int device, qpg_ctx** out) {
   c->select_lds_raised = false;
   for (int i = 0; i < QPG_OPT_COUNT; ++i) c->opt[i] = 0;
   c->opt[QPG_OPT_GATE_DEDUP_FROM_CHAINS] = 1;
-  c->prog_cnt = nullptr;
-  c->prog_flag = nullptr;
-  c->prog_lead_permille = 0;
   int prev = 0;
   (void)hipGetDevice(&prev);
   const bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&c->zeros), 4096) == hipSuccess &&
@@ -85,16 +82,6 @@ extern "C" int qpg_ctx_get_option(qpg_ctx* ctx, int option, int* value) {
   QPG_REQUIRE(ctx != nullptr && value != nullptr, "qpg_ctx_get_option: null pointer");
   QPG_REQUIRE(option >= 0 && option < QPG_OPT_COUNT, "qpg_ctx_get_option: unknown option %d", option);
   *value = ctx->opt[option];
-  return QPG_OK;
-}
-
-extern "C" int qpg_ctx_set_sweep_progress(qpg_ctx* ctx, int32_t* counter, int32_t* flag, int lead_permille) {
-  QPG_REQUIRE(ctx != nullptr, "qpg_ctx_set_sweep_progress: null context");
-  QPG_REQUIRE((counter == nullptr) == (flag == nullptr), "qpg_ctx_set_sweep_progress: counter and flag go together");
-  QPG_REQUIRE(lead_permille >= 0 && lead_permille <= 500, "qpg_ctx_set_sweep_progress: lead_permille in [0, 500]");
-  ctx->prog_cnt = counter;
-  ctx->prog_flag = flag;
-  ctx->prog_lead_permille = lead_permille;
   return QPG_OK;
 }
 

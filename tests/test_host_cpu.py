@@ -30,7 +30,6 @@ def test_bindings_cover_the_header():
                                "qpg_text_percode_ws_bytes", "qpg_percode_select_mixed_ws_bytes",
                                "qpg_percode_select_mixed_ws_stride",
                                "qpg_merge_mixed_ws_bytes", "qpg_build_id", "qpg_ctx_set_option", "qpg_ctx_get_option",
-                               "qpg_ctx_set_sweep_progress",
                                "qpg_percode_select_exact_ws_bytes", "qpg_audio_hl_supported",
                                "qpg_audio_hl_db_bytes", "qpg_audio_hl_query_bytes", "qpg_hl_rows_bytes",
                                "qpg_hl_cols_bytes", "qpg_dev_kernarg", "qpg_audio_hl1_supported", "qpg_audio_hl1_db_bytes",
