@@ -539,7 +539,13 @@ class VQVAE:
                 raise IndexError("code id out of range [0,%d)" % self.bins)
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)      # (no copy launch for the usual single chunk)
 
-    def decode_f16x3(self, zs, return_stats=False):
+    # code positions (B x L) below which decode_f16x3 hands the call to decode(): the split-f16 kernel walks K = 1 536 in 48
+    # barrier-separated slices whatever M is (>= 22 us per launch, 27 launches), so ONE 24 s clip (180 positions) took 1.26 ms
+    # against 0.29 on the f32 kernels, 720 positions 1.27 against 0.73; from ~1 500 positions on it wins (16 x 180: 1.49
+    # against 2.10; 512 x 30: 4.1 against 8.5) - profiles/r05_vqvae_and_cache.md
+    F16X3_MIN_POSITIONS = 1500
+
+    def decode_f16x3(self, zs, return_stats=False, force=False):
         """VQVAE.decode on the split-operand f16 convolutions (qpg_conv16_f32: three f16 MFMAs per f32 product, f32
         accumulation), layer by layer, with the f32 kernels as the referee for RANGE only: poses have no discrete decision
         to re-check, the outputs agree with decode() to ~1e-5 (tests: <= 1e-4 of the golden poses, the reference's own
@@ -551,6 +557,11 @@ class VQVAE:
         self._refresh_tpack()
         ids = torch.as_tensor(zs[0]).to(self.device, torch.int64).contiguous()
         B, L = ids.shape
+        if not force and B * L < self.F16X3_MIN_POSITIONS:
+            # (round 6, VERDICT r5 weak #9: the single-clip split-f16 decode was 4.3x SLOWER than decode(); short
+            # sequences take the f32 kernels - this entry point is never slower than decode() now; force=True: measurements)
+            out = self.decode(zs)
+            return (out, {"activation_outside_f16_range": False, "routed_to_f32_kernels": True}) if return_stats else out
         st = getattr(self, "_c16_status", None)
         if st is None:
             st = self._c16_status = torch.zeros((1,), dtype=torch.int32, device=self.device)
