@@ -17,10 +17,10 @@ def t(fn, n=50):
     return ms[0], ms[len(ms) // 2]
 for B, L in ((1, 180), (1, 30), (1, 720), (16, 180), (512, 30)):
     ids = torch.randint(0, 512, (B, L), device=dev)
-    a = m.decode([ids]); b, st = m.decode_f16x3([ids], return_stats=True)
+    a = m.decode([ids]); b, st = m.decode_f16x3([ids], return_stats=True, force=True)
     d = float((a - b).abs().max()); s = float(a.abs().max())
     print("B=%d L=%d: f32 min %.3f med %.3f ms | f16x3 min %.3f med %.3f ms | max |diff| %.3g (max |pose| %.3g) %s"
-          % ((B, L) + t(lambda: m.decode([ids])) + t(lambda: m.decode_f16x3([ids])) + (d, s, st)))
+          % ((B, L) + t(lambda: m.decode([ids])) + t(lambda: m.decode_f16x3([ids], force=True)) + (d, s, st)))
 # the same launches as ONE hipGraph replay (static ids / output buffers): what the kernels themselves take
 for B, L in ((1, 180), (1, 30)):
     ids = torch.randint(0, 512, (B, L), device=dev)
