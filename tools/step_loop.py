@@ -35,6 +35,8 @@ if "QPG_GATE_DEDUP" in os.environ:                    # from how many chains the
     from qpgesture_amd import _lib as _l
     _l.set_option(dev, _l.QPG_OPT_GATE_DEDUP_FROM_CHAINS, int(os.environ["QPG_GATE_DEDUP"]))
 knn.audio_kernel = os.environ.get("QPG_AUDIO_KERNEL", "hl")
+if "QPG_LOOP_PROBE" in os.environ:                    # probe codes of the walk-relevance cut's bound (default 64)
+    knn.rank_cut_probe = int(os.environ["QPG_LOOP_PROBE"])
 if "QPG_SPLIT_FUSE" in os.environ:                    # 0: the rank fusion as ONE launch in the walk (rounds 3-5), 1: per modality
     knn.split_fuse = os.environ["QPG_SPLIT_FUSE"] == "1"
 knn.tie_eps = float(os.environ.get("QPG_TIE_EPS", knn.tie_eps))
