@@ -1366,36 +1366,30 @@ extern "C" int qpg_hl_pack_cols(qpg_ctx* ctx, void* stream, const float* q, int 
 __global__ __launch_bounds__(128) void hl_prepare_queries_kernel(const float* __restrict__ q, int Q, int D,
                                                                  float* __restrict__ qn, _Float16* __restrict__ image,
                                                                  int32_t* __restrict__ qexp, float* __restrict__ qperm) {
-  extern __shared__ __attribute__((aligned(16))) float rowbuf[];         // [D] the normalised row
+  extern __shared__ __attribute__((aligned(16))) float rowbuf[];         // [D] the raw row, then the normalised row
   __shared__ float n_s, red[2];
   __shared__ int e_s;
   const int qi = blockIdx.x, tid = threadIdx.x;
   const bool live = qi < Q;
   const float* p = q + (int64_t)(live ? qi : 0) * D;
+  // the raw row through LDS first (one coalesced round trip for the whole block): the four chain lanes below then walk LDS,
+  // not four batches of strided global loads - the same additions in the same order
+  for (int e = tid * 4; e < D; e += 128 * 4) *reinterpret_cast<f32x4*>(rowbuf + e) = *reinterpret_cast<const f32x4*>(p + e);
+  __syncthreads();
   if (tid < 4) {                                       // the norm, in NumPy einsum's order (lane chains l = 0..3)
     const int l = tid;
+    const float* pr = rowbuf;
     float a = 0.f;
     const int nfull = D >> 4;
-    int g = 0;
-    for (; g + 8 <= nfull; g += 8) {
-      float v[32];
-#pragma unroll
-      for (int jx = 0; jx < 32; ++jx) v[jx] = p[(g + (jx >> 2)) * 16 + (jx & 3) * 4 + l];
-#pragma unroll
-      for (int jx = 0; jx < 8; ++jx) {
-#pragma unroll
-        for (int u = 3; u >= 0; --u) a = f_add(f_mul(v[jx * 4 + u], v[jx * 4 + u]), a);
-      }
-    }
-    for (; g < nfull; ++g) {
+    for (int g = 0; g < nfull; ++g) {
 #pragma unroll
       for (int u = 3; u >= 0; --u) {
-        const float v = p[g * 16 + u * 4 + l];
+        const float v = pr[g * 16 + u * 4 + l];
         a = f_add(f_mul(v, v), a);
       }
     }
     for (int i = nfull * 16; i < D; i += 4) {
-      const float v = (i + l < D) ? p[i + l] : 0.f;
+      const float v = (i + l < D) ? pr[i + l] : 0.f;
       a = f_add(f_mul(v, v), a);
     }
     const float o1 = __shfl_xor(a, 1, 64);
@@ -1409,8 +1403,8 @@ __global__ __launch_bounds__(128) void hl_prepare_queries_kernel(const float* __
   const float n = n_s;
   float m = 0.f;
   for (int e = tid; e < D; e += 128) {
-    const float v = live ? f_div(p[e], n) : 0.f;
-    rowbuf[e] = v;
+    const float v = live ? f_div(rowbuf[e], n) : 0.f;
+    rowbuf[e] = v;                                     // (element e is read and written by this thread only)
     if (live && qn) qn[(int64_t)qi * D + e] = v;
     m = fmaxf(m, fabsf(v));
   }
@@ -1456,8 +1450,9 @@ extern "C" int qpg_hl_prepare_queries(qpg_ctx* ctx, void* stream, const float* q
   const char* name = "qpg_hl_prepare_queries";
   QPG_REQUIRE(ctx && q && image && Q > 0 && D > 0 && (D % 128) == 0 && D <= 8192, "%s: bad argument (D %% 128 == 0, D <= 8192)",
               name);
-  QPG_REQUIRE(image_bytes >= qpg_hl_cols_bytes(Q, D) && (reinterpret_cast<uintptr_t>(image) % 16) == 0,
-              "%s: image too small or misaligned (qpg_hl_cols_bytes)", name);
+  QPG_REQUIRE(image_bytes >= qpg_hl_cols_bytes(Q, D) && (reinterpret_cast<uintptr_t>(image) % 16) == 0 &&
+                  (reinterpret_cast<uintptr_t>(q) % 16) == 0,
+              "%s: image too small or misaligned (qpg_hl_cols_bytes; q and the image 16-byte aligned)", name);
   QPG_REQUIRE(q != qn && q != qperm && (qn == nullptr || qn != qperm), "%s: outputs must not alias the input", name);
   const int chunks = (Q + HL_GQC - 1) / HL_GQC;
   unsigned char* img = static_cast<unsigned char*>(image);
